@@ -1,0 +1,147 @@
+"""Pins oracle/maf_oracle.py against the fixtures the REFERENCE produced (tools/make_golden.py).
+
+CPU only.  Tolerances: weights/activations are fp32 on both sides, only the accumulation order of
+the re-parameterised kernels differs.  Box coordinates reach ~1e3 px for these synthetic weights
+(ltrb distances up to 16 bins x stride 32), where one fp32 ulp is 6e-5, so boxes are compared with
+|d| <= 1e-3 + 1e-5*|ref| (north_star: "within 1e-3 fp32") and scores with 2e-5 abs; NMS rows exactly.
+"""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maf_oracle as O
+import nms_cases
+
+SCALES = ("n", "s", "m")
+
+
+def _wsum(t):
+    a = t.detach().double().reshape(-1).numpy()
+    ramp = (np.arange(a.size) % 97 + 1).astype(np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), (a * ramp).sum()])
+
+
+def _close(pred, ref):
+    np.testing.assert_allclose(pred[..., :4], ref[..., :4], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(pred[..., 4:], ref[..., 4:], rtol=0, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    torch.set_num_threads(8)
+    out = {}
+    for s in SCALES:
+        sd = O.synth_state_dict(s, 0)
+        out[s] = (sd, O.reparam(sd, s))
+    return out
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_state_dict_layout_matches_reference(golden, scale):
+    g = golden("maf_" + scale)
+    spec = O.state_spec(scale)
+    h = hashlib.sha256(json.dumps([[k, list(s)] for k, s in spec]).encode()).hexdigest()
+    assert h == str(g["spec_hash"])
+    assert len(spec) == int(g["n_train_tensors"]) == {"n": 838, "s": 1206, "m": 1568}[scale]
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_reparam_matches_reference_deploy_switch(golden, nets, scale):
+    g = golden("maf_" + scale)
+    dw = nets[scale][1]
+    names = [str(n) for n in g["deploy_names"]]
+    assert sorted(dw.keys()) == names
+    for i, n in enumerate(names):
+        w, b = dw[n]
+        np.testing.assert_allclose(_wsum(w), g["deploy_wsum"][i], rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(_wsum(b), g["deploy_bsum"][i], rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_deploy_forward_and_decode_320(golden, nets, scale):
+    g = golden("maf_" + scale)
+    with torch.no_grad():
+        heads = O.forward_deploy(nets[scale][1], scale, O.synth_images(1, 320, 1))
+        pred = O.decode(heads).numpy()
+    ref = g["pred320_deploy"]
+    assert pred.shape == ref.shape == (1, 2100, 85)
+    _close(pred, ref)
+    # decode alone, from the reference's raw head tensors
+    t = torch.zeros(1, 1, 10, 10)
+    d = O.decode([(t, torch.from_numpy(g["head2_cls"]), torch.from_numpy(g["head2_reg"]))], strides=(32,)).numpy()
+    _close(d, ref[:, 2000:])
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_train_form_forward_320(golden, nets, scale):
+    g = golden("maf_" + scale)
+    with torch.no_grad():
+        pred = O.decode(O.forward_train_form(nets[scale][0], scale, O.synth_images(1, 320, 1))).numpy()
+    ref = g["pred320_train_rows7"]
+    _close(pred[:, ::7], ref)
+
+
+def test_headline_shape_640(golden, nets):
+    g = golden("maf_n")
+    with torch.no_grad():
+        pred = O.predict(nets["n"][1], "n", O.synth_images(2, 640, 1))
+    assert pred.shape == (2, 8400, 85)
+    _close(pred[:, ::16].numpy(), g["pred640_rows16"])
+    np.testing.assert_allclose(pred.double().sum(1).numpy(), g["pred640_colsum"], rtol=1e-5, atol=1e-2)
+
+
+def test_per_node_taps_64(golden, nets):
+    g = golden("maf_n")
+    taps = {}
+    with torch.no_grad():
+        O.forward_deploy(nets["n"][1], "n", O.synth_images(1, 64, 2), taps)
+    checked = 0
+    for i, t in taps.items():
+        if isinstance(t, tuple):
+            for j, u in enumerate(t):
+                np.testing.assert_allclose(u.numpy(), g["tap64_%d_%d" % (i, j)], rtol=1e-4, atol=2e-5); checked += 1
+        else:
+            np.testing.assert_allclose(t.numpy(), g["tap64_%d" % i], rtol=1e-4, atol=2e-5); checked += 1
+    assert checked == 31 + 9
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_nms_on_reference_predictions(golden, scale):
+    g = golden("maf_" + scale)
+    pred = g["pred320_deploy"]
+    for tag, kw in (("eval", dict(conf_thres=0.03, iou_thres=0.65, multi_label=True)),
+                    ("infer", dict(conf_thres=0.1, iou_thres=0.45, agnostic=True, max_det=1000)),
+                    ("best", dict(conf_thres=0.05, iou_thres=0.45))):
+        out = O.non_max_suppression(pred, **kw)
+        assert np.array_equal(out[0], g["nms320_%s" % tag]), (scale, tag)
+
+
+@pytest.mark.parametrize("name", sorted(nms_cases.cases().keys()))
+def test_nms_edge_cases(golden, name):
+    g = golden("nms_cases")
+    pred, kw = nms_cases.cases()[name]
+    out = O.non_max_suppression(pred, **kw)
+    assert [o.shape[0] for o in out] == list(g[name + "__n"])
+    for bi, o in enumerate(out):
+        assert o.dtype == np.float32 and o.shape[1] == 6
+        assert np.array_equal(o, g["%s__%d" % (name, bi)]), (name, bi)
+
+
+def test_nms_threshold_asserts():
+    with pytest.raises(AssertionError):
+        O.non_max_suppression(np.zeros((1, 4, 85), np.float32), conf_thres=1.5)
+    with pytest.raises(AssertionError):
+        O.non_max_suppression(np.zeros((1, 4, 85), np.float32), iou_thres=-0.1)
+
+
+def test_greedy_nms_rule():
+    # descending-score order, strict '>' on IoU, stable ties
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30], [0, 0, 10, 5]], np.float32)
+    s = np.array([0.5, 0.5, 0.9, 0.4], np.float32)
+    assert list(O.greedy_nms(b, s, 0.5)) == [2, 0, 3]       # box 1 == box 0 (IoU 1); box 3 has IoU 0.5, NOT > 0.5
+    assert list(O.greedy_nms(b, s, 0.49)) == [2, 0]
+    assert list(O.greedy_nms(b[[0, 3]], s[[0, 3]], 0.5)) == [0, 1]
+    assert list(O.greedy_nms(b[[0, 3]], s[[0, 3]], 0.4999)) == [0]
