@@ -1,0 +1,141 @@
+/*
+ * mafyolo_hip.h — C-ABI of libmafyolo_hip.so: the MI355X (gfx950) native hot path of MAF-YOLO.
+ *
+ * The reference (yang-0201/MAF-YOLO) is pure PyTorch: it has no FFI layer, its "operator API" for
+ * this path is the Python surface Model.forward() / non_max_suppression().  This header is the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to run that path natively:
+ * plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless noted; all
+ * launches go to the hipStream_t passed in (pass the framework's current stream); nothing here
+ * allocates device memory, synchronises the device or keeps references after return, except
+ * maf_engine_* which keeps a host-side copy of the op list.
+ *
+ * Every entry point returns 0 on success or a negative MAF_E_* code; maf_last_error() returns a
+ * thread-local message.  Reference lines cited are relative to /root/reference.
+ *
+ * Activation layout is NHWC ("pixels x channels"), element type f16 or f32 (MAF_F16 / MAF_F32),
+ * fp32 accumulation everywhere.  A tensor view is (ptr, stride, coff): channel c of pixel m lives
+ * at ptr[m*stride + coff + c] — producers write straight into channel slices of wider buffers, so
+ * torch.cat / Tensor.split / nn.Upsample / MaxPool2d(2) of the reference (common.py:154,670,940,944;
+ * MAF-YOLO-n.yaml:21,26) never materialise.
+ */
+#ifndef MAFYOLO_HIP_H
+#define MAFYOLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* maf_stream_t;              /* hipStream_t */
+
+enum { MAF_F16 = 0, MAF_F32 = 1, MAF_U8 = 2 };
+enum { MAF_ACT_NONE = 0, MAF_ACT_RELU = 1, MAF_ACT_SILU = 2, MAF_ACT_SIGMOID = 3 };
+enum { MAF_SRC_DIRECT = 0,               /* source has the op's H x W grid                              */
+       MAF_SRC_UP2 = 1,                  /* source is H/2 x W/2, read through nearest x2 upsample       */
+       MAF_SRC_POOL2 = 2 };              /* source is 2H x 2W, read through MaxPool2d(2,2)              */
+enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 conv on the NCHW image   */
+       MAF_OP_CONV1X1 = 1,               /* Conv 1x1 (+bias+act) over up to 4 concatenated sources      */
+       MAF_OP_CONV3X3S2 = 2,             /* RepVGGBlock / ConvWrapper 3x3 stride 2 pad 1 (+bias+act)    */
+       MAF_OP_DWCONV = 3,                /* merged DilatedReparamBlock: depth-wise k x k s1 (+bias+act) */
+       MAF_OP_SPPF_POOL = 4,             /* three chained MaxPool2d(5,1,2) into concat slices           */
+       MAF_OP_DECODE = 5 };              /* Detect_yaml eval branch: DFL decode -> [B,A,5+nc] fp32      */
+enum { MAF_E_ARG = -1, MAF_E_UNSUPPORTED = -2, MAF_E_HIP = -3 };
+
+typedef struct {
+    const void* ptr;
+    int32_t C;        /* channels consumed from this source                         */
+    int32_t stride;   /* elements per pixel of the underlying buffer                */
+    int32_t coff;     /* first channel                                              */
+    int32_t mode;     /* MAF_SRC_*                                                  */
+} maf_src_t;
+
+/*
+ * One launch of the plan.  Fields not used by a kind are ignored.
+ *
+ * MAF_OP_STEM       replaces backbone.0.rbr_reparam + ReLU (yolov6/layers/common.py:216-217).
+ *                   src[0].ptr = image [B,3,2H,2W] NCHW of type in_dtype (f16/f32, or u8 scaled by
+ *                   1/255 = evaler.py:161-163 folded in); w = fp32 [27][Cout] (k = (c*3+ky)*3+kx).
+ * MAF_OP_CONV1X1    replaces Conv.forward_fuse (common.py:49-50) and the plain nn.Conv2d preds
+ *                   (common.py:1331,1335).  w = MFMA-fragment-packed (maf_pack_* in pack.py),
+ *                   K = concat of the sources' channels in order (= torch.cat order).
+ * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
+ *                   2H x 2W input (Hin, Win below); w packed per tap.
+ * MAF_OP_DWCONV     replaces DilatedReparamBlock.lk_origin after merge (common.py:3025,3033-3051).
+ *                   w = [k*k][C] of the activation dtype.
+ * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
+ *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
+ * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
+ *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride];
+ *                   out = pred fp32 [B, A, 5+nc].
+ */
+typedef struct {
+    int32_t kind, dtype, in_dtype, act;
+    int32_t B, H, W;             /* output grid per image                                       */
+    int32_t Hin, Win;            /* input grid (STEM, CONV3X3S2)                                */
+    int32_t Cin, Cout, ksize;
+    int32_t nsrc;
+    maf_src_t src[4];
+    void* out;
+    int32_t out_stride, out_coff;
+    int32_t out_f32;             /* CONV1X1: store fp32 regardless of dtype (cls_pred/reg_pred) */
+    int32_t tile_p, tile_c;      /* MFMA tile: 16*tile_p pixels x 16*tile_c channels per wave   */
+    const void* w;
+    const float* bias;
+    /* DECODE only */
+    const void* reg[3];
+    int32_t lvl_h[3], lvl_w[3];
+    int32_t reg_stride, nc, reg_max;
+    float lvl_stride[3];
+} maf_op_t;
+
+const char* maf_last_error(void);
+int maf_version(void);
+
+/* Launch one op on `stream`. */
+int maf_op_launch(const maf_op_t* op, maf_stream_t stream);
+
+/* A plan = ordered op list (Model.forward's node loop, yolo.py:186-201, flattened to launches). */
+typedef struct maf_engine maf_engine_t;
+int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_t** out);
+int maf_engine_num_ops(const maf_engine_t* e);
+/* image / pred override the STEM input and DECODE output pointers when non-NULL. */
+int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream);
+/* Same launches replayed from a hipGraph captured on first use (bs=1 latency path). Pointers are
+ * frozen at capture time: image/pred must be the same on every call. */
+int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream);
+void maf_engine_destroy(maf_engine_t* e);
+
+/*
+ * non_max_suppression (yolov6/utils/nms.py:31-105) for a whole batch in two launches.
+ *   pred      fp32 [B,N,5+nc]
+ *   classes   optional device int32[n_classes] filter (nms.py:83-84), NULL = none
+ *   workspace device scratch of maf_nms_workspace_bytes(B,N,nc) bytes
+ *   out_rows  fp32 [B,max_det,6] (x1,y1,x2,y2,conf,cls) in descending conf order
+ *   out_idx   int64 [B,max_det]  flat candidate index: box*nc+cls (multi_label) or box
+ *   out_count int32 [B]
+ * Rules kept from the reference: strict '>' on conf_thres in fp32 (nms.py:48,76,80); candidate order
+ * = row-major (box,class) (nms.py:76); conf = cls*obj (nms.py:69); boxes offset by cls*4096 unless
+ * agnostic (nms.py:94-95); > 30000 candidates -> top 30000 by score (nms.py:90-91); keep <= max_det
+ * (nms.py:97-98); greedy rule of torchvision.ops.nms (suppress when IoU > iou_thres, ties broken by
+ * lower candidate index, the fp32 IoU compared with iou_thres in double as torchvision's CPU kernel
+ * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
+ * break (nms.py:101-103) is dropped.  max_det <= 2048.
+ */
+int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc);
+int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
+            const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,
+            int32_t max_det, void* workspace, int64_t workspace_bytes,
+            float* out_rows, int64_t* out_idx, int32_t* out_count, maf_stream_t stream);
+
+/* HIP-event timing helper used by bench.py (events recorded on `stream`, not torch's). */
+int maf_timer_create(void** timer);
+int maf_timer_start(void* timer, maf_stream_t stream);
+int maf_timer_stop(void* timer, maf_stream_t stream);
+int maf_timer_elapsed_ms(void* timer, float* ms);   /* synchronises on the stop event */
+void maf_timer_destroy(void* timer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

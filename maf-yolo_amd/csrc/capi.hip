@@ -1,0 +1,130 @@
+// C-ABI glue: error reporting, op dispatch, the plan executor (engine) and HIP-event timers.
+#include <vector>
+#include <string>
+#include "maf_common.h"
+
+static thread_local std::string g_err;
+
+void maf_set_error(const std::string& msg) { g_err = msg; }
+
+int maf_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return MAF_E_HIP;
+}
+
+extern "C" const char* maf_last_error(void) { return g_err.c_str(); }
+extern "C" int maf_version(void) { return 100; }
+
+extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
+    if (!op) { maf_set_error("maf_op_launch: null op"); return MAF_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (op->kind) {
+        case MAF_OP_STEM: return maf_launch_stem(op, s);
+        case MAF_OP_CONV1X1:
+        case MAF_OP_CONV3X3S2: return maf_launch_conv_mfma(op, s);
+        case MAF_OP_DWCONV: return maf_launch_dwconv(op, s);
+        case MAF_OP_SPPF_POOL: return maf_launch_sppf_pool(op, s);
+        case MAF_OP_DECODE: return maf_launch_decode(op, s);
+        default: maf_set_error("maf_op_launch: unknown op kind"); return MAF_E_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine: the flattened Model.forward (yolov6/models/yolo.py:186-201) as a static launch list over
+// a caller-owned activation arena.  No allocation, no host sync; optional hipGraph replay.
+// ---------------------------------------------------------------------------------------------
+struct maf_engine {
+    std::vector<maf_op_t> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const void* g_image = nullptr;
+    void* g_pred = nullptr;
+};
+
+extern "C" int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_t** out) {
+    if (!ops || n_ops <= 0 || !out) { maf_set_error("maf_engine_create: bad arguments"); return MAF_E_ARG; }
+    maf_engine* e = new maf_engine();
+    e->ops.assign(ops, ops + n_ops);
+    *out = e;
+    return 0;
+}
+
+extern "C" int maf_engine_num_ops(const maf_engine_t* e) { return e ? (int)e->ops.size() : 0; }
+
+static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipStream_t s) {
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        maf_op_t op = e->ops[i];
+        if (op.kind == MAF_OP_STEM && image) op.src[0].ptr = image;
+        if (op.kind == MAF_OP_DECODE && pred) op.out = pred;
+        const int rc = maf_op_launch(&op, s);
+        if (rc) {
+            g_err = "op " + std::to_string(i) + ": " + g_err;
+            return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream) {
+    if (!e) { maf_set_error("maf_engine_run: null engine"); return MAF_E_ARG; }
+    return engine_launch_all(e, image, pred, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream) {
+    if (!e) { maf_set_error("maf_engine_run_graph: null engine"); return MAF_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (e->exec && (e->g_image != image || e->g_pred != pred)) {
+        hipGraphExecDestroy(e->exec); hipGraphDestroy(e->graph);
+        e->exec = nullptr; e->graph = nullptr;
+    }
+    if (!e->exec) {
+        int rc = maf_check_hip(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        if (rc) return rc;
+        rc = engine_launch_all(e, image, pred, s);
+        hipError_t ce = hipStreamEndCapture(s, &e->graph);
+        if (rc) return rc;
+        rc = maf_check_hip(ce, "hipStreamEndCapture");
+        if (rc) return rc;
+        rc = maf_check_hip(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        if (rc) return rc;
+        e->g_image = image; e->g_pred = pred;
+    }
+    return maf_check_hip(hipGraphLaunch(e->exec, s), "hipGraphLaunch");
+}
+
+extern "C" void maf_engine_destroy(maf_engine_t* e) {
+    if (!e) return;
+    if (e->exec) hipGraphExecDestroy(e->exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    delete e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HIP-event timer on an explicit stream (bench.py measures the stream the kernels run on)
+// ---------------------------------------------------------------------------------------------
+struct maf_timer { hipEvent_t a, b; };
+
+extern "C" int maf_timer_create(void** t) {
+    if (!t) return MAF_E_ARG;
+    maf_timer* m = new maf_timer();
+    int rc = maf_check_hip(hipEventCreate(&m->a), "hipEventCreate");
+    if (!rc) rc = maf_check_hip(hipEventCreate(&m->b), "hipEventCreate");
+    if (rc) { delete m; return rc; }
+    *t = m;
+    return 0;
+}
+extern "C" int maf_timer_start(void* t, maf_stream_t s) { return maf_check_hip(hipEventRecord(static_cast<maf_timer*>(t)->a, static_cast<hipStream_t>(s)), "hipEventRecord"); }
+extern "C" int maf_timer_stop(void* t, maf_stream_t s) { return maf_check_hip(hipEventRecord(static_cast<maf_timer*>(t)->b, static_cast<hipStream_t>(s)), "hipEventRecord"); }
+extern "C" int maf_timer_elapsed_ms(void* t, float* ms) {
+    maf_timer* m = static_cast<maf_timer*>(t);
+    int rc = maf_check_hip(hipEventSynchronize(m->b), "hipEventSynchronize");
+    if (rc) return rc;
+    return maf_check_hip(hipEventElapsedTime(ms, m->a, m->b), "hipEventElapsedTime");
+}
+extern "C" void maf_timer_destroy(void* t) {
+    maf_timer* m = static_cast<maf_timer*>(t);
+    if (!m) return;
+    hipEventDestroy(m->a); hipEventDestroy(m->b);
+    delete m;
+}

@@ -1,0 +1,62 @@
+// Argument checking + dispatch for the MFMA conv kernels (kernels: conv_mfma.inc.h)
+#include "conv_mfma.inc.h"
+
+int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
+    MAF_REQUIRE(op->dtype == MAF_F16 || op->dtype == MAF_F32, "conv: dtype must be f16/f32");
+    const int CH = op->dtype == MAF_F16 ? 8 : 4, KS = op->dtype == MAF_F16 ? 32 : 16;
+    MAF_REQUIRE(op->nsrc >= 1 && op->nsrc <= 4, "conv: nsrc must be 1..4");
+    MAF_REQUIRE(op->B > 0 && op->H > 0 && op->W > 0 && op->Cout > 0, "conv: bad dims");
+    MAF_REQUIRE(op->Cout % 4 == 0, "conv: Cout must be a multiple of 4");
+    MAF_REQUIRE(op->out_stride % 4 == 0 && op->out_coff % 4 == 0, "conv: out stride/coff must be multiples of 4");
+    MAF_REQUIRE((long long)op->B * op->H * op->W < (1ll << 31), "conv: too many pixels");
+    ConvArgs a = {};
+    int csum = 0, ksum = 0;
+    a.cum[0] = 0;
+    bool any_special = false;
+    for (int i = 0; i < 4; ++i) {
+        if (i < op->nsrc) {
+            const maf_src_t& sr = op->src[i];
+            MAF_REQUIRE(sr.ptr != nullptr, "conv: null source");
+            MAF_REQUIRE(sr.C > 0 && sr.C % CH == 0 && sr.stride % CH == 0 && sr.coff % CH == 0, "conv: source C/stride/coff must be multiples of the 16-byte channel chunk");
+            a.srcC[i] = sr.C;
+            a.src[i] = sr.ptr; a.srcStride[i] = sr.stride; a.srcCoff[i] = sr.coff; a.srcMode[i] = sr.mode;
+            csum += sr.C;
+            if (sr.mode != MAF_SRC_DIRECT) any_special = true;
+            if (sr.mode == MAF_SRC_UP2) MAF_REQUIRE(op->H % 2 == 0 && op->W % 2 == 0, "conv: UP2 source needs even H,W");
+        }
+        ksum += (i < op->nsrc) ? maf_cdiv(op->src[i].C, KS) : 0;
+        a.cum[i + 1] = ksum;
+    }
+    MAF_REQUIRE(csum == op->Cin, "conv: sum of source channels != Cin");
+    a.nsrc = op->nsrc;
+    a.B = op->B; a.H = op->H; a.W = op->W; a.Hin = op->Hin; a.Win = op->Win;
+    a.M = op->B * op->H * op->W;
+    a.Cin = op->Cin; a.Cout = op->Cout;
+    a.ksteps = ksum;   // every source padded to whole k-steps (matches the host weight packing)
+    a.w = op->w; a.bias = op->bias; a.out = op->out;
+    a.out_stride = op->out_stride; a.out_coff = op->out_coff;
+    MAF_REQUIRE(op->w && op->bias && op->out, "conv: null w/bias/out");
+    const int pt = op->tile_p, ct = op->tile_c;
+    MAF_REQUIRE(pt > 0 && ct > 0, "conv: tile_p/tile_c not set");
+    a.nM = maf_cdiv(a.M, 64 * pt);
+    a.nN = maf_cdiv(op->Cout, 16 * ct);
+    int var;
+    if (op->kind == MAF_OP_CONV3X3S2) {
+        MAF_REQUIRE(op->nsrc == 1 && op->src[0].mode == MAF_SRC_DIRECT, "conv3x3s2: single direct source");
+        MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->Hin - 1) / 2 + 1 == op->H && (op->Win - 1) / 2 + 1 == op->W, "conv3x3s2: H,W must equal floor((Hin-1)/2)+1");
+        var = VAR_3X3S2;
+    } else if (op->nsrc == 1 && op->src[0].mode == MAF_SRC_POOL2) {
+        var = VAR_POOL2;
+    } else if (op->nsrc == 1 && !any_special) {
+        var = VAR_DIRECT;
+    } else {
+        for (int i = 0; i < op->nsrc; ++i) MAF_REQUIRE(op->src[i].mode != MAF_SRC_POOL2, "conv1x1: POOL2 only as a single source");
+        var = VAR_MULTI;
+    }
+    const bool outf32 = op->out_f32 != 0 && op->dtype == MAF_F16;
+    MAF_REQUIRE(!outf32 || var == VAR_DIRECT, "conv: out_f32 only for single direct source");
+    a.act = op->act;
+    MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv: bad act");
+    if (op->dtype == MAF_F16) return maf_conv_mfma_f16(a, var, outf32, pt, ct, s);
+    return maf_conv_mfma_f32(a, var, false, pt, ct, s);
+}

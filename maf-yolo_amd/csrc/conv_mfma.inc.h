@@ -1,0 +1,313 @@
+// Pointwise (1x1) and dense 3x3 stride-2 convolutions as MFMA implicit GEMMs, NHWC, fused
+// bias + activation epilogue, concat/split/upsample/maxpool folded into the operand addressing.
+//
+// Replaces (reference, /root/reference): Conv.forward_fuse (yolov6/layers/common.py:49-50),
+// RepVGGBlock deploy forward (common.py:216-217), ConvWrapper (common.py:76-83), the cls/reg pred
+// convs of Head_DepthUni (common.py:1331-1335), torch.cat (common.py:154,944), Tensor.split
+// (common.py:940), nn.Upsample (MAF-YOLO-n.yaml:21,26), MP (common.py:667-673).
+//
+// Formulation (MI355X-first, not a cuDNN-style tiling):
+//   out^T[c, m] = sum_k W^T[c, k] * X^T[k, m]      c = output channel, m = pixel (B*H*W), k = input channel (x tap)
+// i.e. the WEIGHTS are the MFMA A operand and the ACTIVATIONS the B operand.  With NHWC storage a
+// B fragment is one 16-byte load per lane straight from global memory (8 f16 / 4 f32 consecutive
+// channels of the lane's pixel) — no LDS, no im2col — and the accumulator of lane (g, p) holds
+// 4 consecutive output channels of pixel p per channel tile.  The host packs the weight rows so
+// that the CT channel tiles of a wave interleave: lane (g, p) ends up with 4*CT *contiguous*
+// channels of its pixel, which the epilogue stores as 16-byte vectors directly from registers.
+// Weights come pre-packed in fragment order (1 KiB contiguous per wave-load, L1/L2 resident).
+//
+// Per wave: 16*PT pixels x 16*CT channels; 4 waves per workgroup split the pixel range.
+// blockIdx -> (pixel tile, channel tile) is XCD-aware: the channel tiles of one pixel tile run
+// back-to-back on the same XCD so re-reads of the activations hit that XCD's L2.
+#pragma once
+#include "maf_common.h"
+#include <type_traits>
+
+struct ConvArgs {
+    const void* src[4];
+    int srcStride[4];
+    int srcCoff[4];
+    int srcMode[4];
+    int srcC[4];
+    int cum[5];          // cumulative k-step boundaries of the sources (each source padded to whole k-steps)
+    int nsrc;
+    int B, H, W, Hin, Win;
+    int M;               // B*H*W
+    int Cin, Cout;
+    int ksteps;          // k-steps per tap
+    const void* w;
+    const float* bias;   // padded to nN*16*CT
+    void* out;
+    int out_stride, out_coff;
+    int nM, nN;
+    int act;
+};
+
+enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3 };
+
+int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
+int maf_conv_mfma_f32(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
+
+namespace {
+
+template <typename T> struct Frag;
+template <> struct Frag<half_t> {
+    typedef half8_t type;
+    static constexpr int CH = 8;    // channels per 16-byte lane chunk
+    static constexpr int KS = 32;   // channels per k-step
+    static __device__ __forceinline__ type zero() { return (type)(half_t)0; }
+    static __device__ __forceinline__ type vmax(type a, type b) {
+        type r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+        return r;
+    }
+    static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<float> {
+    typedef f32x4_t type;
+    static constexpr int CH = 4;
+    static constexpr int KS = 16;
+    static __device__ __forceinline__ type zero() { return (type)0.f; }
+    static __device__ __forceinline__ type vmax(type a, type b) {
+        type r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+        return r;
+    }
+    static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type ldg16(const T* p) {
+    return *reinterpret_cast<const typename Frag<T>::type*>(p);
+}
+
+template <typename T, int PT, int CT, int VAR, bool OUTF32>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    typedef Frag<T> F;
+    typedef typename F::type frag_t;
+    constexpr int CH = F::CH;
+    constexpr int CPS = F::KS / F::CH;     // chunks per k-step (= 4 lane groups)
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
+
+    // XCD-aware block -> tile map (block b runs on XCD b%8; keep a pixel tile's channel tiles on one XCD)
+    const int L = blockIdx.x;
+    const int xcd = L & 7, jj = L >> 3;
+    const int n_tile = jj % a.nN;
+    const int m_tile = (jj / a.nN) * 8 + xcd;
+    if (m_tile >= a.nM) return;
+    const int m_base = m_tile * (64 * PT) + wave * (16 * PT);
+
+    // ---- per-lane pixel bookkeeping ----
+    bool pvalid[PT];
+    uint32_t off0[PT];                      // VAR_DIRECT / VAR_POOL2 / VAR_3X3S2 base element offset
+    uint32_t offs[PT][4];                   // VAR_MULTI: per source
+    int iy0[PT], ix0[PT];                   // VAR_3X3S2
+    const T* s0 = static_cast<const T*>(a.src[0]);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = m_base + pt * 16 + p;
+        pvalid[pt] = m < a.M;
+        const int mm = pvalid[pt] ? m : 0;
+        if (VAR == VAR_DIRECT) {
+            off0[pt] = (uint32_t)mm * a.srcStride[0] + a.srcCoff[0];
+        } else {
+            const int x = mm % a.W;
+            const int t = mm / a.W;
+            const int y = t % a.H;
+            const int b = t / a.H;
+            if (VAR == VAR_POOL2) {
+                off0[pt] = (uint32_t)((b * (2 * a.H) + 2 * y) * (2 * a.W) + 2 * x) * a.srcStride[0] + a.srcCoff[0];
+            } else if (VAR == VAR_3X3S2) {
+                iy0[pt] = 2 * y - 1;
+                ix0[pt] = 2 * x - 1;
+                off0[pt] = (uint32_t)(b * a.Hin) * a.Win;       // pixel index of (b, 0, 0)
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < a.nsrc) {
+                        if (a.srcMode[s] == MAF_SRC_UP2)
+                            offs[pt][s] = (uint32_t)((b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.srcStride[s] + a.srcCoff[s];
+                        else
+                            offs[pt][s] = (uint32_t)mm * a.srcStride[s] + a.srcCoff[s];
+                    } else {
+                        offs[pt][s] = 0;
+                    }
+                }
+            }
+        }
+    }
+
+    f32x4_t acc[PT][CT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4_t)0.f;
+
+    const int ntaps = (VAR == VAR_3X3S2) ? 9 : 1;
+    const int total_steps = ntaps * a.ksteps;
+    const frag_t* wbase = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
+
+    auto load_src = [&](auto sidx, int ks, frag_t (&bf)[PT]) {
+        constexpr int S = decltype(sidx)::value;
+        const int c0 = ks * F::KS + g * CH;
+        const bool kvalid = c0 < a.srcC[S];
+        const T* sp = static_cast<const T*>(a.src[S]);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bf[pt] = (pvalid[pt] && kvalid) ? ldg16<T>(sp + offs[pt][S] + c0) : F::zero();
+    };
+    auto load_b = [&](int step, frag_t (&bf)[PT]) {
+        if (VAR == VAR_3X3S2) {
+            const int tap = step / a.ksteps, ks = step - tap * a.ksteps;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int c0 = ks * F::KS + g * CH;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int iy = iy0[pt] + ky, ix = ix0[pt] + kx;
+                const bool ok = pvalid[pt] && c0 < a.Cin && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+                const uint32_t o = (off0[pt] + (uint32_t)(iy * a.Win + ix)) * a.srcStride[0] + a.srcCoff[0] + c0;
+                bf[pt] = ok ? ldg16<T>(s0 + o) : F::zero();
+            }
+        } else if (VAR == VAR_MULTI) {
+            // uniform (scalar) source selection: every source owns whole k-steps
+            if (step < a.cum[1]) load_src(std::integral_constant<int, 0>{}, step, bf);
+            else if (step < a.cum[2]) load_src(std::integral_constant<int, 1>{}, step - a.cum[1], bf);
+            else if (step < a.cum[3]) load_src(std::integral_constant<int, 2>{}, step - a.cum[2], bf);
+            else load_src(std::integral_constant<int, 3>{}, step - a.cum[3], bf);
+        } else {
+            const int c0 = step * F::KS + g * CH;
+            const bool kvalid = c0 < a.Cin;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                if (pvalid[pt] && kvalid) {
+                    const T* q = s0 + off0[pt] + c0;
+                    if (VAR == VAR_POOL2) {
+                        const uint32_t rs = (uint32_t)(2 * a.W) * a.srcStride[0];
+                        frag_t v0 = ldg16<T>(q), v1 = ldg16<T>(q + a.srcStride[0]);
+                        frag_t v2 = ldg16<T>(q + rs), v3 = ldg16<T>(q + rs + a.srcStride[0]);
+                        bf[pt] = F::vmax(F::vmax(v0, v1), F::vmax(v2, v3));
+                    } else {
+                        bf[pt] = ldg16<T>(q);
+                    }
+                } else {
+                    bf[pt] = F::zero();
+                }
+            }
+        }
+    };
+    auto load_a = [&](int step, frag_t (&af)[CT]) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * total_steps + step) * 64];
+    };
+
+    frag_t bcur[PT], acur[CT], bnxt[PT], anxt[CT];
+    load_b(0, bcur);
+    load_a(0, acur);
+    for (int step = 0; step < total_steps; ++step) {
+        const bool more = step + 1 < total_steps;
+        if (more) {
+            load_b(step + 1, bnxt);
+            load_a(step + 1, anxt);
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(acur[ct], bcur[pt], acc[pt][ct]);
+        if (more) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) bcur[pt] = bnxt[pt];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acur[ct] = anxt[ct];
+        }
+    }
+
+    // ---- epilogue: bias + activation, 4*CT contiguous channels per lane ----
+    const int cl = n_tile * (16 * CT) + g * (4 * CT);       // first channel of this lane
+    f32x4_t bias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bias[ct] = *reinterpret_cast<const f32x4_t*>(a.bias + cl + ct * 4);
+
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = m_base + pt * 16 + p;
+        if (m >= a.M) continue;
+        const size_t obase = (size_t)m * a.out_stride + a.out_coff + cl;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[pt][ct][r] = maf_act_rt(acc[pt][ct][r] + bias[ct][r], a.act);
+        }
+        if (OUTF32 || sizeof(T) == 4) {
+            float* o = static_cast<float*>(a.out) + obase;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (cl + ct * 4 + 4 <= a.Cout) *reinterpret_cast<f32x4_t*>(o + ct * 4) = acc[pt][ct];
+        } else {
+            half_t* o = static_cast<half_t*>(a.out) + obase;
+#pragma unroll
+            for (int ct = 0; ct + 1 < CT; ct += 2) {
+                half8_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = (half_t)acc[pt][ct][r];
+                    v[4 + r] = (half_t)acc[pt][ct + 1][r];
+                }
+                if (cl + ct * 4 + 8 <= a.Cout) {
+                    *reinterpret_cast<half8_t*>(o + ct * 4) = v;
+                } else if (cl + ct * 4 + 4 <= a.Cout) {
+                    half4_t h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = v[r];
+                    *reinterpret_cast<half4_t*>(o + ct * 4) = h;
+                }
+            }
+            if (CT & 1) {
+                constexpr int ct = CT - 1;
+                if (cl + ct * 4 + 4 <= a.Cout) {
+                    half4_t h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[pt][ct][r];
+                    *reinterpret_cast<half4_t*>(o + ct * 4) = h;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int PT, int CT, int VAR, bool OUTF32>
+int launch_act(const ConvArgs& a, hipStream_t s) {
+    const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
+    hipLaunchKernelGGL((conv_mfma_kernel<T, PT, CT, VAR, OUTF32>), dim3(grid), dim3(256), 0, s, a);
+    return maf_check_hip(hipGetLastError(), "conv_mfma launch");
+}
+
+template <typename T, int VAR, bool OUTF32>
+int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
+#define MAF_TILE(P, C) \
+    if (pt == P && ct == C) return launch_act<T, P, C, VAR, OUTF32>(a, s);
+    MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(1, 3) MAF_TILE(2, 3) MAF_TILE(1, 4) MAF_TILE(2, 4)
+    MAF_TILE(1, 6) MAF_TILE(2, 6) MAF_TILE(1, 8) MAF_TILE(2, 8)
+#undef MAF_TILE
+    maf_set_error("conv: unsupported tile (tile_p in {1,2}, tile_c in {2,3,4,6,8})");
+    return MAF_E_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_var(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s) {
+    if (var == VAR_DIRECT) return outf32 ? launch_tile<T, VAR_DIRECT, true>(a, pt, ct, s) : launch_tile<T, VAR_DIRECT, false>(a, pt, ct, s);
+    if (var == VAR_MULTI) return launch_tile<T, VAR_MULTI, false>(a, pt, ct, s);
+    if (var == VAR_POOL2) return launch_tile<T, VAR_POOL2, false>(a, pt, ct, s);
+    return launch_tile<T, VAR_3X3S2, false>(a, pt, ct, s);
+}
+
+}  // namespace
+

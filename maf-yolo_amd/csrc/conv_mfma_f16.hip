@@ -1,0 +1,3 @@
+// f16 instantiations of the MFMA conv kernels (see conv_mfma.inc.h)
+#include "conv_mfma.inc.h"
+int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s) { return launch_var<half_t>(a, var, outf32, pt, ct, s); }

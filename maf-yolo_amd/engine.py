@@ -1,0 +1,280 @@
+"""Static launch plan for the re-parameterised (deploy-form) graph on one GPU.
+
+Model.forward of the reference walks 35 nn.Modules and issues ~210 aten ops per call
+(yolov6/models/yolo.py:186-201).  Here the same graph is flattened ONCE, for a
+given (batch, H, W, dtype), into an ordered list of `maf_op_t` launches over a single activation
+arena (one torch uint8 tensor = device memory plumbing only) and handed to the C engine
+(`maf_engine_create`); a forward is then one C call.  Concat, split, nearest-upsample and the 2x2
+max-pool of MPRep never become ops: they turn into operand addressing of the consumer conv
+(`TV` segments below), and SPPF's three max-pools write straight into the concat buffer.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib, pack
+from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Head_DepthUni)
+
+_ESIZE = {lib.F16: 2, lib.F32: 4}
+_TORCH_DT = {lib.F16: torch.float16, lib.F32: torch.float32}
+
+
+class Buf:
+    """A real NHWC buffer in the arena."""
+
+    def __init__(self, off, H, W, stride, esize):
+        self.off, self.H, self.W, self.stride, self.esize = off, H, W, stride, esize
+
+
+class Seg:
+    def __init__(self, buf, C, coff=0, mode=lib.SRC_DIRECT):
+        self.buf, self.C, self.coff, self.mode = buf, C, coff, mode
+
+
+class TV:
+    """Virtual tensor = channel-concatenation of segments on an H x W grid."""
+
+    def __init__(self, segs, H, W):
+        self.segs, self.H, self.W = segs, H, W
+
+    @property
+    def C(self):
+        return sum(s.C for s in self.segs)
+
+
+class Plan:
+    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device):
+        assert Hin % 32 == 0 and Win % 32 == 0, "image sides must be multiples of 32 (stride of P5)"
+        self.B, self.Hin, self.Win, self.dtype, self.in_dtype, self.device = B, Hin, Win, dtype, in_dtype, device
+        self.es = _ESIZE[dtype]
+        self._arena_size = 0
+        self._wblobs = []          # (offset, cpu tensor)
+        self._wsize = 0
+        self._ops = []             # python-side op records (dicts), turned into MafOp once addresses are known
+        self.nc = model.nc
+        self.reg_max = model.detect.reg_max
+        self.strides = [float(s) for s in model.detect.stride.tolist()]
+        with torch.no_grad():
+            self._build(model)
+        self._finalize()
+
+    # ---------------------------------------------------------------- allocation helpers
+    def _alloc(self, H, W, C, esize=None):
+        esize = esize or self.es
+        off = self._arena_size
+        self._arena_size += (self.B * H * W * C * esize + 255) // 256 * 256
+        return Buf(off, H, W, C, esize)
+
+    def _wput(self, t):
+        t = t.contiguous()
+        off = self._wsize
+        self._wsize += (t.numel() * t.element_size() + 255) // 256 * 256
+        self._wblobs.append((off, t))
+        return off
+
+    # ---------------------------------------------------------------- op emitters
+    def _conv1x1(self, name, w, b, src, out, out_coff, act, out_f32=False):
+        cout = w.shape[0]
+        M = self.B * src.H * src.W
+        pt, ct = pack.tile_for(cout, M)
+        srcC = [s.C for s in src.segs]
+        assert len(src.segs) <= 4, "%s: more than 4 concat sources" % name
+        self._ops.append(dict(kind=lib.OP_CONV1X1, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=cout,
+                              segs=src.segs, out=out, out_coff=out_coff, out_f32=int(out_f32), pt=pt, ct=ct,
+                              w=self._wput(pack.pack_conv1x1(w, srcC, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
+
+    def _conv3x3s2(self, name, w, b, src, out, out_coff, act):
+        assert len(src.segs) == 1 and src.segs[0].mode == lib.SRC_DIRECT, "%s: 3x3 s2 conv needs a materialised input" % name
+        cout = w.shape[0]
+        H, W = src.H // 2, src.W // 2
+        pt, ct = pack.tile_for(cout, self.B * H * W)
+        self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=name, act=act, H=H, W=W, Hin=src.H, Win=src.W, Cin=src.C, Cout=cout,
+                              segs=src.segs, out=out, out_coff=out_coff, out_f32=0, pt=pt, ct=ct,
+                              w=self._wput(pack.pack_conv3x3(w, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
+
+    def _dw(self, name, w, b, src, out, act):
+        assert len(src.segs) == 1 and src.segs[0].mode == lib.SRC_DIRECT
+        self._ops.append(dict(kind=lib.OP_DWCONV, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=src.C, ksize=w.shape[-1],
+                              segs=src.segs, out=out, out_coff=0, w=self._wput(pack.pack_dw(w, self.dtype)),
+                              b=self._wput(b.float().cpu())))
+
+    # ---------------------------------------------------------------- graph walk
+    def _build(self, model):
+        B = self.B
+        y = []                                   # TV (or list of head tuples) per node
+        self.head_bufs = []
+        for node, m in zip(model.nodes, model.backbone):
+            p = "backbone.%d" % node.i
+            srcs = [y[j] for j in node.sources()] if node.i > 0 else None
+            x = srcs[0] if srcs else None
+            if node.kind == "repvgg":
+                w, b = m.fused()
+                if node.i == 0:                   # stem: reads the caller's NCHW image
+                    H, W = self.Hin // 2, self.Win // 2
+                    out = self._alloc(H, W, node.cout)
+                    self._ops.append(dict(kind=lib.OP_STEM, name=p, act=lib.ACT_RELU, H=H, W=W, Hin=self.Hin, Win=self.Win,
+                                          Cin=3, Cout=node.cout, segs=[], out=out, out_coff=0,
+                                          w=self._wput(pack.pack_stem(w)), b=self._wput(b.float().cpu())))
+                else:
+                    out = self._alloc(x.H // 2, x.W // 2, node.cout)
+                    self._conv3x3s2(p, w, b, x, out, 0, lib.ACT_RELU)
+                y.append(TV([Seg(out, node.cout)], out.H, out.W))
+            elif node.kind == "rephdw":
+                c_, depth = m.c_, len(m.m)
+                cat = self._alloc(x.H, x.W, c_ * (depth + 2))
+                self._conv1x1(p + ".conv1", *m.conv1.fused(), x, cat, 0, lib.ACT_SILU)
+                for d, blk in enumerate(m.m):
+                    mid = blk.conv1.conv.out_channels
+                    t1, t2 = self._alloc(x.H, x.W, mid), self._alloc(x.H, x.W, mid)
+                    q = "%s.m.%d" % (p, d)
+                    self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(cat, c_, (d + 1) * c_)], x.H, x.W), t1, 0, lib.ACT_SILU)
+                    self._dw(q + ".conv2", *blk.conv2.fused(), TV([Seg(t1, mid)], x.H, x.W), t2, lib.ACT_SILU)
+                    self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), cat, (d + 2) * c_, lib.ACT_SILU)
+                out = self._alloc(x.H, x.W, node.cout)
+                self._conv1x1(p + ".conv2", *m.conv2.fused(), TV([Seg(cat, c_ * (depth + 2))], x.H, x.W), out, 0, lib.ACT_SILU)
+                y.append(TV([Seg(out, node.cout)], x.H, x.W))
+            elif node.kind == "mprep":
+                assert len(x.segs) == 1 and x.segs[0].mode == lib.SRC_DIRECT
+                c_ = node.cout // 2
+                out = self._alloc(x.H // 2, x.W // 2, node.cout)
+                s0 = x.segs[0]
+                pooled = TV([Seg(s0.buf, s0.C, s0.coff, lib.SRC_POOL2)], x.H // 2, x.W // 2)
+                self._conv1x1(p + ".conv1", *m.conv1.fused(), pooled, out, 0, lib.ACT_SILU)
+                self._conv3x3s2(p + ".conv2", *m.conv2.fused(), x, out, c_, lib.ACT_RELU)
+                y.append(TV([Seg(out, node.cout)], out.H, out.W))
+            elif node.kind == "sppf":
+                c_ = m.cv1.conv.out_channels
+                cat = self._alloc(x.H, x.W, 4 * c_)
+                self._conv1x1(p + ".cv1", *m.cv1.fused(), x, cat, 0, lib.ACT_SILU)
+                self._ops.append(dict(kind=lib.OP_SPPF_POOL, name=p + ".m", act=0, H=x.H, W=x.W, Cin=c_, Cout=3 * c_,
+                                      segs=[Seg(cat, c_, 0)], out=cat, out_coff=c_))
+                out = self._alloc(x.H, x.W, node.cout)
+                self._conv1x1(p + ".cv2", *m.cv2.fused(), TV([Seg(cat, 4 * c_)], x.H, x.W), out, 0, lib.ACT_SILU)
+                y.append(TV([Seg(out, node.cout)], x.H, x.W))
+            elif node.kind == "cw":
+                out = self._alloc(x.H // 2, x.W // 2, node.cout)
+                self._conv3x3s2(p + ".block", *m.block.fused(), x, out, 0, lib.ACT_SILU)
+                y.append(TV([Seg(out, node.cout)], out.H, out.W))
+            elif node.kind == "concat":
+                H, W = srcs[0].H, srcs[0].W
+                segs = []
+                for s in srcs:
+                    assert (s.H, s.W) == (H, W), "concat of different grids at node %d" % node.i
+                    segs += s.segs
+                y.append(TV(segs, H, W))
+            elif node.kind == "up":
+                assert all(s.mode == lib.SRC_DIRECT for s in x.segs), "upsample of a non-materialised tensor"
+                y.append(TV([Seg(s.buf, s.C, s.coff, lib.SRC_UP2) for s in x.segs], x.H * 2, x.W * 2))
+            elif node.kind == "head":
+                c = node.cout
+                t = self._alloc(x.H, x.W, c)
+                self._conv1x1(p + ".stem", *m.stem.fused(), x, t, 0, lib.ACT_SILU)
+                tv = TV([Seg(t, c)], x.H, x.W)
+                outs = []
+                for br, pred, act, cpred in (("cls", m.cls_pred, lib.ACT_SIGMOID, self.nc), ("reg", m.reg_pred, lib.ACT_NONE, 4 * (self.reg_max + 1))):
+                    u, v = self._alloc(x.H, x.W, c), self._alloc(x.H, x.W, c)
+                    o = self._alloc(x.H, x.W, cpred, 4)                                   # fp32 [B,HW,cpred]
+                    self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
+                    self._conv1x1("%s.%s_conv_s" % (p, br), *getattr(m, br + "_conv_s").fused(), TV([Seg(u, c)], x.H, x.W), v, 0, lib.ACT_SILU)
+                    self._conv1x1("%s.%s_pred" % (p, br), pred.weight.detach(), pred.bias.detach(), TV([Seg(v, c)], x.H, x.W), o, 0, act, out_f32=True)
+                    outs.append(o)
+                self.head_bufs.append((t, outs[0], outs[1]))
+                y.append(None)
+            elif node.kind == "out":
+                y.append(None)
+            else:
+                raise NotImplementedError(node.kind)
+        assert len(self.head_bufs) == 3, "MAF-YOLO has three detection levels"
+        self.A = sum(t.H * t.W for t, _, _ in self.head_bufs)
+        self._ops.append(dict(kind=lib.OP_DECODE, name="detect", act=0, H=0, W=0, Cin=0, Cout=0, segs=[], out=None, out_coff=0))
+
+    # ---------------------------------------------------------------- materialise
+    def _finalize(self):
+        dev = self.device
+        self.arena = torch.empty(self._arena_size + 256, dtype=torch.uint8, device=dev)
+        wcpu = torch.zeros(self._wsize + 256, dtype=torch.uint8)
+        for off, t in self._wblobs:
+            wcpu[off:off + t.numel() * t.element_size()] = t.reshape(-1).view(torch.uint8)
+        self.weights = wcpu.to(dev)
+        self._wblobs = None
+        abase, wbase = self.arena.data_ptr(), self.weights.data_ptr()
+        abase += (-abase) % 256
+        self._abase = abase
+        ops = (lib.MafOp * len(self._ops))()
+        for o, r in zip(ops, self._ops):
+            o.kind, o.dtype, o.in_dtype, o.act = r["kind"], self.dtype, self.in_dtype, r["act"]
+            o.B, o.H, o.W = self.B, r["H"], r["W"]
+            o.Hin, o.Win = r.get("Hin", 0), r.get("Win", 0)
+            o.Cin, o.Cout, o.ksize = r["Cin"], r["Cout"], r.get("ksize", 0)
+            o.nsrc = len(r["segs"])
+            for i, s in enumerate(r["segs"]):
+                o.src[i].ptr = abase + s.buf.off
+                o.src[i].C, o.src[i].stride, o.src[i].coff, o.src[i].mode = s.C, s.buf.stride, s.coff, s.mode
+            if r["out"] is not None:
+                o.out = abase + r["out"].off
+                o.out_stride = r["out"].stride
+            o.out_coff = r["out_coff"]
+            o.out_f32 = r.get("out_f32", 0)
+            o.tile_p, o.tile_c = r.get("pt", 0), r.get("ct", 0)
+            if "w" in r:
+                o.w = wbase + r["w"]
+                o.bias = wbase + r["b"]
+            if r["kind"] == lib.OP_STEM:
+                o.nsrc = 1
+                o.src[0].ptr = 0            # supplied per call
+                o.src[0].C = 3
+            if r["kind"] == lib.OP_DECODE:
+                o.nsrc = 3
+                for l, (t, cls, reg) in enumerate(self.head_bufs):
+                    o.src[l].ptr = abase + cls.off
+                    o.reg[l] = abase + reg.off
+                    o.lvl_h[l], o.lvl_w[l], o.lvl_stride[l] = t.H, t.W, self.strides[l]
+                o.reg_stride, o.nc, o.reg_max = 4 * (self.reg_max + 1), self.nc, self.reg_max
+        self.ops = ops
+        self.op_names = [r["name"] for r in self._ops]
+        h = C.c_void_p()
+        lib.check(lib.load().maf_engine_create(ops, len(self._ops), C.byref(h)))
+        self._engine = h
+
+    # ---------------------------------------------------------------- execution
+    def run(self, x, graph=False):
+        """x: [B,3,Hin,Win] contiguous NCHW tensor on self.device. Returns pred fp32 [B, A, 5+nc]."""
+        pred = torch.empty(self.B, self.A, 5 + self.nc, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fn = lib.load().maf_engine_run_graph if graph else lib.load().maf_engine_run
+        lib.check(fn(self._engine, x.data_ptr(), pred.data_ptr(), stream))
+        return pred
+
+    def run_into(self, x, pred, graph=False):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fn = lib.load().maf_engine_run_graph if graph else lib.load().maf_engine_run
+        lib.check(fn(self._engine, x.data_ptr(), pred.data_ptr(), stream))
+        return pred
+
+    def launch_op(self, idx, image_ptr=None, pred_ptr=None):
+        """Launch a single op of the plan (profiling / per-kernel timing)."""
+        op = self.ops[idx]
+        if op.kind == lib.OP_STEM and image_ptr is not None:
+            op.src[0].ptr = image_ptr
+        if op.kind == lib.OP_DECODE and pred_ptr is not None:
+            op.out = pred_ptr
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        lib.check(lib.load().maf_op_launch(C.byref(op), stream))
+
+    def view(self, buf):
+        """Zero-copy torch view [B,H,W,stride] of an arena buffer (valid until the next forward)."""
+        dt = torch.float32 if buf.esize == 4 else torch.float16
+        start = buf.off + (self._abase - self.arena.data_ptr())
+        n = self.B * buf.H * buf.W * buf.stride * buf.esize
+        return self.arena[start:start + n].view(dt).view(self.B, buf.H, buf.W, buf.stride)
+
+    def featmaps(self):
+        """[(stem, cls, reg)] x 3 as NCHW views, the second element of the reference's Model.forward return."""
+        return [tuple(self.view(b).permute(0, 3, 1, 2) for b in hb) for hb in self.head_bufs]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_engine", None):
+                lib.load().maf_engine_destroy(self._engine)
+        except Exception:
+            pass

@@ -1,0 +1,254 @@
+"""Train-form blocks of MAF-YOLO with the reference's parameter names, plus their deploy switch.
+
+The module tree mirrors the attribute names of yolov6/layers/common.py (RepVGGBlock :166, Conv :29,
+ConvWrapper :76, SPPF :114, MPRep :776, DepthBottleneckUni :898, RepHDW :928, Head_DepthUni :1288,
+DilatedReparamBlock :2948, UniRepLKNetBlock :3053) so a reference state_dict (838 / 1206 / 1568
+tensors for n / s / m) loads with strict=True and trained weights round-trip.
+
+`forward` here is the TRAINING-form graph in stock PyTorch ops (autograd / DDP train it today; the
+native backward kernels are the next §8 row).  Inference never runs these forwards: in eval mode
+Model.forward executes the re-parameterised graph on the HIP engine (engine.py), built from
+`fused()` below — the deploy algebra of SURVEY.md §3.3, evaluated in fp32 on the host once.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .arch import dil_branch_kernels
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03          # yolov6/utils/torch_utils.py:43-45
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=BN_EPS, momentum=BN_MOMENTUM)
+
+
+def fold_bn(weight, bn, bias=None):
+    """(conv weight, BN) -> equivalent (weight, bias): w*g/s, b' = beta + (b - mean)*g/s  with s = sqrt(var+eps)."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    b0 = bn.running_mean.new_zeros(bn.running_mean.shape) if bias is None else bias
+    return weight * scale.reshape(-1, 1, 1, 1), bn.bias + (b0 - bn.running_mean) * scale
+
+
+class ConvBN(nn.Sequential):
+    """conv (no bias) + BN pair named `.conv` / `.bn` (the reference's conv_bn helper, common.py:157-163)."""
+
+    def __init__(self, cin, cout, k, stride, pad, groups=1):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(cin, cout, k, stride, pad, groups=groups, bias=False))
+        self.add_module("bn", _bn(cout))
+
+    def fused(self):
+        return fold_bn(self.conv.weight, self.bn)
+
+
+class Conv(nn.Module):
+    """k x k conv + BN + SiLU (common.py:29-50)."""
+
+    def __init__(self, cin, cout, k=1, stride=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+        self.bn = _bn(cout)
+        self.act = nn.SiLU(inplace=True)
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+    def fused(self):
+        return fold_bn(self.conv.weight, self.bn)
+
+
+class ConvWrapper(nn.Module):
+    def __init__(self, cin, cout, k=3, stride=2):
+        super().__init__()
+        self.block = Conv(cin, cout, k, stride)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class RepVGGBlock(nn.Module):
+    """3x3 s2 conv+BN  +  1x1 s2 conv+BN, ReLU (common.py:219-224). No identity branch exists at stride 2."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.rbr_dense = ConvBN(cin, cout, 3, 2, 1)
+        self.rbr_1x1 = ConvBN(cin, cout, 1, 2, 0)
+        self.nonlinearity = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlinearity(self.rbr_dense(x) + self.rbr_1x1(x))
+
+    def fused(self):
+        """One 3x3 kernel + bias (get_equivalent_kernel_bias, common.py:226-230)."""
+        w3, b3 = self.rbr_dense.fused()
+        w1, b1 = self.rbr_1x1.fused()
+        return w3 + F.pad(w1, [1, 1, 1, 1]), b3 + b1
+
+    def switch_to_deploy(self):      # evaler.py:101-103 calls this on every RepVGGBlock: harmless here
+        return None
+
+
+class DilatedReparamBlock(nn.Module):
+    """Depth-wise k x k conv+BN plus parallel smaller depth-wise conv+BN branches (common.py:2948-3031)."""
+
+    def __init__(self, c, k):
+        super().__init__()
+        self.kernel_size = k
+        self.kernel_sizes = list(dil_branch_kernels(k))
+        self.lk_origin = nn.Conv2d(c, c, k, 1, k // 2, groups=c, bias=False)
+        self.origin_bn = _bn(c)
+        for kk in self.kernel_sizes:
+            setattr(self, "dil_conv_k%d_1" % kk, nn.Conv2d(c, c, kk, 1, kk // 2, groups=c, bias=False))
+            setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
+
+    def forward(self, x):
+        out = self.origin_bn(self.lk_origin(x))
+        for kk in self.kernel_sizes:
+            out = out + getattr(self, "dil_bn_k%d_1" % kk)(getattr(self, "dil_conv_k%d_1" % kk)(x))
+        return out
+
+    def fused(self):
+        """merge_dilated_branches (common.py:3033-3051): centre-pad each small kernel to k x k and sum."""
+        k = self.kernel_size
+        w, b = fold_bn(self.lk_origin.weight, self.origin_bn)
+        for kk in self.kernel_sizes:
+            bw, bb = fold_bn(getattr(self, "dil_conv_k%d_1" % kk).weight, getattr(self, "dil_bn_k%d_1" % kk))
+            p = k // 2 - kk // 2
+            w = w + F.pad(bw, [p, p, p, p])
+            b = b + bb
+        return w, b
+
+
+class UniRepLKNetBlock(nn.Module):
+    """DilatedReparamBlock followed by an outer BN (common.py:3053-3083)."""
+
+    def __init__(self, c, k):
+        super().__init__()
+        self.dwconv = DilatedReparamBlock(c, k)
+        self.norm = _bn(c)
+
+    def forward(self, x):
+        return self.norm(self.dwconv(x))
+
+    def fused(self):
+        """reparameterize (common.py:3085-3100): fold the outer BN into the merged depth-wise kernel."""
+        w, b = self.dwconv.fused()
+        return fold_bn(w, self.norm, b)
+
+    def reparameterize(self):        # evaler.py:107-109 calls this on every UniRepLKNetBlock: harmless here
+        return None
+
+
+class DepthBottleneckUni(nn.Module):
+    """1x1 (c -> 3c) -> depth-wise k x k -> SiLU -> 1x1 (3c -> c)   (common.py:898-927)."""
+
+    def __init__(self, c, k, expansion=3):
+        super().__init__()
+        mid = int(c * expansion)
+        self.conv1 = Conv(c, mid, 1)
+        self.conv2 = UniRepLKNetBlock(mid, k)
+        self.act = nn.SiLU(inplace=True)
+        self.one_conv = Conv(mid, c, 1)
+
+    def forward(self, x):
+        return self.one_conv(self.act(self.conv2(self.conv1(x))))
+
+
+class RepHDW(nn.Module):
+    """conv1 1x1 -> split -> chained DepthBottleneckUni -> cat -> conv2 1x1   (common.py:928-946)."""
+
+    def __init__(self, cin, cout, depth=1, expansion=0.5, k=5, depth_expansion=3):
+        super().__init__()
+        self.c_ = int(cout * expansion)
+        self.conv1 = Conv(cin, 2 * self.c_, 1)
+        self.m = nn.ModuleList(DepthBottleneckUni(self.c_, k, depth_expansion) for _ in range(depth))
+        self.conv2 = Conv(self.c_ * (depth + 2), cout, 1)
+
+    def forward(self, x):
+        t = self.conv1(x)
+        outs = [t[:, :self.c_], t[:, self.c_:]]
+        for blk in self.m:
+            outs.append(blk(outs[-1]))
+        return self.conv2(torch.cat(outs, 1))
+
+
+class MP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.m = nn.MaxPool2d(2, 2)
+
+    def forward(self, x):
+        return self.m(x)
+
+
+class MPRep(nn.Module):
+    """cat[Conv1x1(maxpool2x2(x)), RepVGG3x3s2(x)]   (common.py:776-792)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.mp = MP()
+        self.conv1 = Conv(cin, cout // 2, 1)
+        self.conv2 = RepVGGBlock(cin, cout // 2)
+
+    def forward(self, x):
+        return torch.cat([self.conv1(self.mp(x)), self.conv2(x)], 1)
+
+
+class SPPF(nn.Module):
+    """cv1 1x1 -> three chained 5x5 max pools -> cat -> cv2 1x1   (common.py:114-129)."""
+
+    def __init__(self, cin, cout, k=5):
+        super().__init__()
+        c_ = cin // 2
+        self.cv1 = Conv(cin, c_, 1)
+        self.cv2 = Conv(c_ * 4, cout, 1)
+        self.m = nn.MaxPool2d(k, 1, k // 2)
+
+    def forward(self, x):
+        x = self.cv1(x)
+        y1 = self.m(x)
+        y2 = self.m(y1)
+        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+
+
+class Concat(nn.Module):
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, xs):
+        return torch.cat(xs, self.d)
+
+
+class Head_DepthUni(nn.Module):
+    """Decoupled depth-wise head: stem 1x1; per branch UniRepLK k x k -> 1x1 -> pred 1x1   (common.py:1288-1336)."""
+
+    def __init__(self, cin, c, reg_max=16, k=5, nc=80):
+        super().__init__()
+        self.stem = Conv(cin, c, 1)
+        self.cls_conv = UniRepLKNetBlock(c, k)
+        self.cls_conv_s = Conv(c, c, 1)
+        self.reg_conv = UniRepLKNetBlock(c, k)
+        self.reg_conv_s = Conv(c, c, 1)
+        self.cls_pred = nn.Conv2d(c, nc, 1)
+        self.reg_pred = nn.Conv2d(c, 4 * (reg_max + 1), 1)
+        # common.py:1307-1323: zero pred weights, cls bias = -log((1-p)/p) with p = 0.01, reg bias = 1
+        with torch.no_grad():
+            self.cls_pred.weight.zero_()
+            self.cls_pred.bias.fill_(-math.log((1 - 1e-2) / 1e-2))
+            self.reg_pred.weight.zero_()
+            self.reg_pred.bias.fill_(1.0)
+
+    def forward(self, x):
+        x = self.stem(x)
+        cls = torch.sigmoid(self.cls_pred(self.cls_conv_s(self.cls_conv(x))))
+        reg = self.reg_pred(self.reg_conv_s(self.reg_conv(x)))
+        return x, cls, reg
+
+
+class Out(nn.Module):
+    def forward(self, xs):
+        return list(xs)

@@ -1,0 +1,103 @@
+"""ctypes binding of libmafyolo_hip.so (C-ABI: include/mafyolo_hip.h).
+
+The product path has no CPU fallback: if the library is missing this raises, loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmafyolo_hip.so")
+
+F16, F32, U8 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
+SRC_DIRECT, SRC_UP2, SRC_POOL2 = 0, 1, 2
+OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE = range(6)
+
+
+class MafSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("stride", C.c_int32), ("coff", C.c_int32), ("mode", C.c_int32)]
+
+
+class MafOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("in_dtype", C.c_int32), ("act", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("ksize", C.c_int32), ("nsrc", C.c_int32),
+                ("src", MafSrc * 4), ("out", C.c_void_p), ("out_stride", C.c_int32), ("out_coff", C.c_int32),
+                ("out_f32", C.c_int32), ("tile_p", C.c_int32), ("tile_c", C.c_int32),
+                ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("reg", C.c_void_p * 3), ("lvl_h", C.c_int32 * 3), ("lvl_w", C.c_int32 * 3),
+                ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3)]
+
+
+EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
+           "maf_engine_run", "maf_engine_run_graph", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms",
+           "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
+
+_lib = None
+
+
+class MafError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once). Raises MafError if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MafError("libmafyolo_hip.so not found at %s — the HIP extension is not built; "
+                       "run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.maf_last_error.restype = C.c_char_p
+    lib.maf_version.restype = C.c_int
+    lib.maf_op_launch.argtypes = [C.POINTER(MafOp), C.c_void_p]
+    lib.maf_engine_create.argtypes = [C.POINTER(MafOp), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.maf_engine_num_ops.argtypes = [C.c_void_p]
+    lib.maf_engine_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.maf_engine_run_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.maf_engine_destroy.argtypes = [C.c_void_p]
+    lib.maf_engine_destroy.restype = None
+    lib.maf_nms_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.maf_nms_workspace_bytes.restype = C.c_int64
+    lib.maf_nms.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32,
+                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p]
+    lib.maf_timer_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.maf_timer_start.argtypes = [C.c_void_p, C.c_void_p]
+    lib.maf_timer_stop.argtypes = [C.c_void_p, C.c_void_p]
+    lib.maf_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.maf_timer_destroy.argtypes = [C.c_void_p]
+    lib.maf_timer_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MafError("libmafyolo_hip: %s (code %d)" % (load().maf_last_error().decode(), rc))
+
+
+class Timer:
+    """HIP events recorded on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().maf_timer_create(C.byref(self._h)))
+
+    def start(self, stream):
+        check(load().maf_timer_start(self._h, stream))
+
+    def stop(self, stream):
+        check(load().maf_timer_stop(self._h, stream))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        check(load().maf_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().maf_timer_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,196 @@
+"""`Model` — the reference's model surface (yolov6/models/yolo.py:122-217) over the HIP engine.
+
+    model = Model("n")                       # or Model(cfg) with the reference's config object / YAML dict
+    model.load_state_dict(reference_state_dict)      # same 838 / 1206 / 1568 keys
+    pred, featmaps = model.eval()(images)    # [B, A, 5+nc] fp32 (xywh px, obj = 1, class probs), as yolo.py:355-396
+
+Eval-mode forward = one C call into libmafyolo_hip (engine.py): the re-parameterised graph, NHWC,
+fp16 storage / fp32 accumulate when the input is fp16 (the `--half` path of evaler.py:112,162) or
+fp32 storage when the input is fp32.  There is no CPU path: CPU tensors raise.  Training-mode
+forward returns the reference's `(feats, cls[B,A,nc], reg[B,A,4*(reg_max+1)])` tuple from the
+train-form modules in layers.py.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import arch, lib
+from .engine import Plan
+from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Concat, Head_DepthUni, Out)
+
+
+class Detect_yaml(nn.Module):
+    """Holds the DFL projection and level strides (yolo.py:301-331). Decode itself is csrc/decode.hip."""
+
+    def __init__(self, num_classes=80, anchors=1, num_layers=3, use_dfl=True, reg_max=16, stride=(8, 16, 32)):
+        super().__init__()
+        self.nc, self.no, self.nl = num_classes, num_classes + 5, num_layers
+        self.na = anchors if not isinstance(anchors, (list, tuple)) else len(anchors[0]) // 2
+        self.use_dfl, self.reg_max = use_dfl, reg_max
+        self.register_buffer("stride", torch.tensor(list(stride), dtype=torch.float32), persistent=False)
+        self.proj_conv = nn.Conv2d(reg_max + 1, 1, 1, bias=False)
+        self.initialize_biases()
+
+    def initialize_biases(self):               # yolo.py:327-330
+        self.proj = nn.Parameter(torch.linspace(0, self.reg_max, self.reg_max + 1), requires_grad=False)
+        self.proj_conv.weight = nn.Parameter(self.proj.view(1, self.reg_max + 1, 1, 1).clone().detach(), requires_grad=False)
+
+    def forward(self, heads, val_loss=False):
+        """Training branch (yolo.py:333-354): flatten + permute + cat."""
+        cls = torch.cat([h[1].flatten(2).permute(0, 2, 1) for h in heads], 1)
+        reg = torch.cat([h[2].flatten(2).permute(0, 2, 1) for h in heads], 1)
+        return [h[0] for h in heads], cls, reg
+
+
+def _nodes_from_config(config, num_classes):
+    if isinstance(config, str) and config in ("n", "s", "m"):
+        return arch.builtin(config, num_classes), dict(strides=(8, 16, 32), reg_max=16, use_dfl=True)
+    if isinstance(config, dict) and "backbone" in config:
+        return arch.nodes_from_yaml_dict(copy.deepcopy(config), 3, num_classes), dict(strides=(8, 16, 32), reg_max=16, use_dfl=True)
+    # the reference's Config object: config.model.yaml_file + config.model.head.{strides,use_dfl,reg_max}
+    model_cfg = getattr(config, "model", None)
+    if model_cfg is not None and getattr(model_cfg, "yaml_file", None):
+        import yaml
+        with open(model_cfg.yaml_file, encoding="ascii", errors="ignore") as f:
+            d = yaml.safe_load(f)
+        head = model_cfg.head
+        return (arch.nodes_from_yaml_dict(d, d.get("ch", 3), num_classes),
+                dict(strides=tuple(head.strides), reg_max=getattr(head, "reg_max", 16), use_dfl=getattr(head, "use_dfl", True)))
+    raise ValueError("Model(config): pass 'n' | 's' | 'm', a YAML dict in the reference's schema, or the reference's config object")
+
+
+class Model(nn.Module):
+    def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None):
+        super().__init__()
+        assert channels == 3, "MAF-YOLO takes 3-channel images"
+        self.nodes, hcfg = _nodes_from_config(config, num_classes)
+        assert hcfg["use_dfl"] and hcfg["reg_max"] == 16 or hcfg["use_dfl"], "DFL head expected (configs/MAF-YOLO-n.py:15-16)"
+        layers = []
+        for nd in self.nodes:
+            a = nd.args
+            if nd.kind == "repvgg":
+                m = RepVGGBlock(nd.cin, nd.cout)
+            elif nd.kind == "rephdw":
+                m = RepHDW(nd.cin, nd.cout, a["depth"], a["expansion"], a["k"], a["depth_expansion"])
+            elif nd.kind == "mprep":
+                m = MPRep(nd.cin, nd.cout)
+            elif nd.kind == "sppf":
+                m = SPPF(nd.cin, nd.cout, a["k"])
+            elif nd.kind == "cw":
+                m = ConvWrapper(nd.cin, nd.cout, 3, 2)
+            elif nd.kind == "concat":
+                m = Concat(1)
+            elif nd.kind == "up":
+                m = nn.Upsample(None, 2, "nearest")
+            elif nd.kind == "head":
+                m = Head_DepthUni(nd.cin, nd.cout, a["reg_max"], a["k"], a["nc"])
+            elif nd.kind == "out":
+                m = Out()
+            else:
+                raise NotImplementedError(nd.kind)
+            m.i, m.f, m.type = nd.i, nd.f, type(m).__name__
+            layers.append(m)
+        self.backbone = nn.Sequential(*layers)
+        self.save = sorted({s for nd in self.nodes for s in nd.sources() if nd.i > 0 and s != nd.i - 1} |
+                           {s for nd in self.nodes if isinstance(nd.f, list) for s in nd.sources()})
+        self.detect = Detect_yaml(num_classes, anchors, 3, hcfg["use_dfl"], hcfg["reg_max"], hcfg["strides"])
+        self.nc = num_classes
+        self.names = [str(i) for i in range(num_classes)]
+        self.build_type = "yaml"
+        self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
+        self._plans = {}
+        self.use_graph = False                # hipGraph replay (bs=1 latency path); needs a fixed input tensor
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    @property
+    def stride(self):
+        return self.detect.stride
+
+    def train(self, mode=True):
+        if mode:
+            self._plans = {}                  # weights are about to change
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = {}
+        return super().load_state_dict(*a, **k)
+
+    def half(self):
+        """Reference callers do `model.half()` after the deploy switch (evaler.py:112). Masters stay fp32 here;
+        fp16 plans are packed from them (fuse in fp32, then cast — the reference's order)."""
+        self.precision = "fp16"
+        return self
+
+    def float(self):
+        self.precision = None
+        return super().float()
+
+    def __deepcopy__(self, memo):
+        plans, self._plans = self._plans, {}
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self._plans = plans
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_plans"] = {}
+        return d
+
+    # ------------------------------------------------------------------ forward
+    def _forward_train_form(self, x):
+        y = []
+        for nd, m in zip(self.nodes, self.backbone):
+            if nd.i > 0:
+                src = [y[j] for j in nd.sources()]
+                x = src if isinstance(nd.f, list) else src[0]
+            x = m(x)
+            y.append(x)
+        return x                              # list of three (stem, cls, reg)
+
+    def plan_for(self, x):
+        if not x.is_cuda:
+            raise lib.MafError("MAF-YOLO eval forward runs on the HIP engine only: got a %s tensor (no CPU fallback)" % x.device)
+        B, ch, H, W = x.shape
+        assert ch == 3
+        if x.dtype == torch.uint8:
+            in_dt = lib.U8
+        elif x.dtype == torch.float16:
+            in_dt = lib.F16
+        elif x.dtype == torch.float32:
+            in_dt = lib.F32
+        else:
+            raise TypeError("image dtype must be uint8, float16 or float32")
+        if self.precision == "fp16":
+            dt = lib.F16
+        elif self.precision == "fp32":
+            dt = lib.F32
+        else:
+            dt = lib.F32 if x.dtype == torch.float32 else lib.F16
+        key = (B, H, W, dt, in_dt, x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            plan = Plan(self, B, H, W, dt, in_dt, x.device)
+            self._plans[key] = plan
+        return plan
+
+    def forward(self, x, val_loss=False):
+        if self.training:
+            heads = self._forward_train_form(x)
+            return [self.detect(heads), list(heads)]
+        plan = self.plan_for(x)
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            pred = plan.run(x, graph=self.use_graph)
+        feats = plan.featmaps()
+        if val_loss:
+            return [self.detect(feats), feats]
+        return [pred, feats]

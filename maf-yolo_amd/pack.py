@@ -1,0 +1,93 @@
+"""Host-side weight packing for the HIP kernels (done once per plan, fp32 algebra then one cast).
+
+conv_mfma (csrc/conv_mfma.inc.h) takes the weights as the MFMA *A* operand in fragment order:
+
+    packed[tile][step][lane = g*16 + i][j]      tile = n_tile*CT + ct,  g = lane >> 4, i = lane & 15
+      f16: j < 8,  k = step*32 + g*8 + j        (v_mfma_f32_16x16x32_f16: lane holds A[i][8 consecutive k])
+      f32: j < 4,  k = step*16 + g*4 + j        (4 x v_mfma_f32_16x16x4_f32, MFMA j takes component j)
+    output channel of MFMA row i of channel tile ct:   n_tile*16*CT + (i>>2)*4*CT + ct*4 + (i&3)
+
+The row interleave makes lane (g, p) of the accumulator own 4*CT *contiguous* channels of pixel p, so
+the epilogue stores 16-byte vectors without any LDS transpose.  K is the concatenation of the
+sources' channels (torch.cat order), each source zero-padded to whole k-steps; for 3x3 convs the
+steps run tap-major (ky, kx), each tap zero-padded to whole k-steps.
+"""
+import torch
+
+from . import lib
+
+
+def tile_for(cout, m_pixels):
+    """(tile_p, tile_c): least channel padding, then fewest channel tiles; 2 pixel tiles/wave when the grid stays big."""
+    best = None
+    for ct in (8, 6, 4, 3, 2):
+        n_tiles = -(-cout // (16 * ct))
+        padded = n_tiles * 16 * ct
+        key = (padded, n_tiles)
+        if best is None or key < best[0]:
+            best = (key, ct, n_tiles)
+    ct, n_tiles = best[1], best[2]
+    pt = 2 if (-(-m_pixels // 128)) * n_tiles >= 1024 else 1
+    return pt, ct
+
+
+def _steps(c, ks):
+    return -(-c // ks)
+
+
+def pack_matrix(w2d_segments, ct, dtype):
+    """w2d_segments: list of [Cout, C_s] fp32 blocks (one per source / tap). Returns packed tensor (CPU)."""
+    ks = 32 if dtype == lib.F16 else 16
+    ch = ks // 4
+    cout = w2d_segments[0].shape[0]
+    n_tiles = -(-cout // (16 * ct))
+    npad = n_tiles * 16 * ct
+    cols = []
+    for seg in w2d_segments:
+        s = _steps(seg.shape[1], ks)
+        blk = torch.zeros(npad, s * ks, dtype=torch.float32)
+        blk[:cout, :seg.shape[1]] = seg
+        cols.append(blk)
+    wp = torch.cat(cols, 1)                                   # [Npad, S*KS]
+    S = wp.shape[1] // ks
+    # channel = n_tile*16CT + gi*4CT + ct*4 + r ; k = step*KS + g*CH + j
+    wp = wp.reshape(n_tiles, 4, ct, 4, S, 4, ch)              # [nt, gi, ct, r, S, g, j]
+    wp = wp.permute(0, 2, 4, 5, 1, 3, 6).contiguous()         # [nt, ct, S, g, gi, r, j]
+    wp = wp.reshape(n_tiles * ct, S, 64, ch)
+    return wp.to(torch.float16 if dtype == lib.F16 else torch.float32).contiguous()
+
+
+def pack_conv1x1(w, src_channels, ct, dtype):
+    """w [Cout, Cin, 1, 1] fp32, Cin = sum(src_channels)."""
+    w2 = w.reshape(w.shape[0], -1).float().cpu()
+    segs, o = [], 0
+    for c in src_channels:
+        segs.append(w2[:, o:o + c])
+        o += c
+    assert o == w2.shape[1], "source channels do not add up to Cin"
+    return pack_matrix(segs, ct, dtype)
+
+
+def pack_conv3x3(w, ct, dtype):
+    """w [Cout, Cin, 3, 3] fp32 -> tap-major segments."""
+    w = w.float().cpu()
+    return pack_matrix([w[:, :, ky, kx] for ky in range(3) for kx in range(3)], ct, dtype)
+
+
+def pack_bias(b, ct):
+    cout = b.shape[0]
+    npad = -(-cout // (16 * ct)) * 16 * ct
+    out = torch.zeros(npad, dtype=torch.float32)
+    out[:cout] = b.float().cpu()
+    return out
+
+
+def pack_dw(w, dtype):
+    """w [C, 1, k, k] -> [k*k, C] in the activation dtype."""
+    c, _, k, _ = w.shape
+    return w.float().cpu().reshape(c, k * k).t().contiguous().to(torch.float16 if dtype == lib.F16 else torch.float32)
+
+
+def pack_stem(w):
+    """w [Cout, 3, 3, 3] -> fp32 [27, Cout], row = (c*3 + ky)*3 + kx."""
+    return w.float().cpu().reshape(w.shape[0], 27).t().contiguous()

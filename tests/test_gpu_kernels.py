@@ -1,0 +1,244 @@
+"""-m gpu: per-kernel parity of the HIP ops, called through the C-ABI (maf_op_launch), against plain
+PyTorch fp32 references of the same op on the CPU.
+
+Tolerances: f32 kernels 2e-5 rel-to-max (fp32 accumulation-order noise); f16 kernels: inputs and
+weights are rounded to fp16 first so only the fp16 store rounding + accumulation order remain:
+|d| <= 2e-3*max|ref| + 2e-3.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from maf_yolo_amd import lib, pack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DT = {lib.F16: torch.float16, lib.F32: torch.float32}
+
+
+def _launch(op):
+    lib.check(lib.load().maf_op_launch(C.byref(op), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+
+
+def _nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(DT[dt]).to(DEV)
+
+
+def _check(out_nhwc, ref_nchw, dt):
+    got = out_nhwc.float().cpu().permute(0, 3, 1, 2)
+    scale = ref_nchw.abs().max().item()
+    tol = 2e-5 * scale + 1e-6 if dt == lib.F32 else 2e-3 * scale + 2e-3
+    err = (got - ref_nchw).abs().max().item()
+    assert err <= tol, (err, tol)
+
+
+def _q(t, dt):
+    return t.half().float() if dt == lib.F16 else t
+
+
+def _act(y, act):
+    return {lib.ACT_NONE: y, lib.ACT_RELU: F.relu(y), lib.ACT_SILU: F.silu(y), lib.ACT_SIGMOID: torch.sigmoid(y)}[act]
+
+
+def _conv_op(kind, dt, B, H, W, cin, cout, act, srcs, out, out_stride, out_coff, w, b, pt, ct, Hin=0, Win=0, out_f32=0):
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = kind, dt, dt, act
+    op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout = B, H, W, Hin, Win, cin, cout
+    op.nsrc = len(srcs)
+    for i, (t, c, stride, coff, mode) in enumerate(srcs):
+        op.src[i].ptr, op.src[i].C, op.src[i].stride, op.src[i].coff, op.src[i].mode = t.data_ptr(), c, stride, coff, mode
+    op.out, op.out_stride, op.out_coff, op.out_f32 = out.data_ptr(), out_stride, out_coff, out_f32
+    op.tile_p, op.tile_c = pt, ct
+    op.w, op.bias = w.data_ptr(), b.data_ptr()
+    return op
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+@pytest.mark.parametrize("cin,cout,pt,ct,act", [(48, 48, 2, 3, lib.ACT_SILU), (72, 24, 1, 2, lib.ACT_SILU), (24, 72, 2, 6, lib.ACT_NONE),
+                                                (192, 128, 1, 8, lib.ACT_SILU), (128, 80, 2, 6, lib.ACT_SIGMOID), (64, 64, 1, 4, lib.ACT_RELU),
+                                                (128, 68, 1, 6, lib.ACT_NONE), (40, 200, 2, 4, lib.ACT_SILU)])
+def test_conv1x1_direct(dt, cin, cout, pt, ct, act):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    B, H, W = 2, 9, 13                                   # 234 pixels: ragged last tile
+    x = _q(torch.randn(B, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    b = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x, w, b), act)
+    xs = _nhwc(x, dt)
+    wp = pack.pack_conv1x1(w, [cin], ct, dt).to(DEV)
+    bp = pack.pack_bias(b, ct).to(DEV)
+    # write into a channel slice of a wider buffer (concat-slice epilogue)
+    stride, coff = cout + 16, 8
+    out = torch.full((B, H, W, stride), 7.0, dtype=DT[dt], device=DEV)
+    _launch(_conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, act, [(xs, cin, cin, 0, 0)], out, stride, coff, wp, bp, pt, ct))
+    _check(out[..., coff:coff + cout], ref, dt)
+    assert (out[..., :coff] == 7).all() and (out[..., coff + cout:] == 7).all(), "wrote outside its slice"
+
+
+def test_conv1x1_out_f32():
+    g = torch.Generator().manual_seed(5)
+    B, H, W, cin, cout = 1, 8, 8, 128, 68
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).half().float()
+    b = torch.randn(cout, generator=g)
+    out = torch.zeros(B, H, W, cout, dtype=torch.float32, device=DEV)
+    _launch(_conv_op(lib.OP_CONV1X1, lib.F16, B, H, W, cin, cout, 0, [(_nhwc(x, lib.F16), cin, cin, 0, 0)], out, cout, 0,
+                     pack.pack_conv1x1(w, [cin], 6, lib.F16).to(DEV), pack.pack_bias(b, 6).to(DEV), 1, 6, out_f32=1))
+    _check(out, F.conv2d(x, w, b), lib.F32)              # fp32 store: only accumulation-order noise remains
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+def test_conv1x1_multi_source_with_upsample(dt):
+    """cat[a (direct, slice of a wider buffer), up2(b), c] -> 1x1: MAF-YOLO-n.yaml:22-23 pattern."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 8, 12
+    ca, cb, cc, cout = 24, 64, 40, 96
+    a = _q(torch.randn(B, ca, H, W, generator=g), dt)
+    bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
+    c = _q(torch.randn(B, cc, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, ca + cb + cc, 1, 1, generator=g) / 11.0, dt)
+    bias = torch.randn(cout, generator=g)
+    ref = F.silu(F.conv2d(torch.cat([a, F.interpolate(bsm, scale_factor=2, mode="nearest"), c], 1), w, bias))
+    abuf = torch.zeros(B, H, W, ca + 16, dtype=DT[dt], device=DEV)
+    abuf[..., 8:8 + ca] = _nhwc(a, dt)
+    out = torch.zeros(B, H, W, cout, dtype=DT[dt], device=DEV)
+    srcs = [(abuf, ca, ca + 16, 8, lib.SRC_DIRECT), (_nhwc(bsm, dt), cb, cb, 0, lib.SRC_UP2), (_nhwc(c, dt), cc, cc, 0, lib.SRC_DIRECT)]
+    _launch(_conv_op(lib.OP_CONV1X1, dt, B, H, W, ca + cb + cc, cout, lib.ACT_SILU, srcs, out, cout, 0,
+                     pack.pack_conv1x1(w, [ca, cb, cc], 6, dt).to(DEV), pack.pack_bias(bias, 6).to(DEV), 1, 6))
+    _check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+def test_conv1x1_maxpool_source(dt):
+    """Conv1x1(MaxPool2d(2)(x)) — MPRep.conv1(mp(x)) (common.py:787-788)."""
+    g = torch.Generator().manual_seed(12)
+    B, H, W, cin, cout = 2, 6, 10, 48, 48
+    x = _q(torch.randn(B, cin, 2 * H, 2 * W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 1, 1, generator=g) / 7.0, dt)
+    bias = torch.randn(cout, generator=g)
+    ref = F.silu(F.conv2d(F.max_pool2d(x, 2, 2), w, bias))
+    out = torch.zeros(B, H, W, cout, dtype=DT[dt], device=DEV)
+    _launch(_conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, [(_nhwc(x, dt), cin, cin, 0, lib.SRC_POOL2)], out, cout, 0,
+                     pack.pack_conv1x1(w, [cin], 3, dt).to(DEV), pack.pack_bias(bias, 3).to(DEV), 1, 3))
+    _check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+@pytest.mark.parametrize("cin,cout,pt,ct,act", [(24, 48, 2, 3, lib.ACT_RELU), (48, 64, 1, 4, lib.ACT_SILU), (128, 128, 1, 8, lib.ACT_SILU)])
+def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
+    g = torch.Generator().manual_seed(cin + cout)
+    B, Hin, Win = 2, 12, 20
+    x = _q(torch.randn(B, cin, Hin, Win, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dt)
+    bias = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x, w, bias, 2, 1), act)
+    H, W = Hin // 2, Win // 2
+    out = torch.zeros(B, H, W, 2 * cout, dtype=DT[dt], device=DEV)
+    _launch(_conv_op(lib.OP_CONV3X3S2, dt, B, H, W, cin, cout, act, [(_nhwc(x, dt), cin, cin, 0, 0)], out, 2 * cout, cout,
+                     pack.pack_conv3x3(w, ct, dt).to(DEV), pack.pack_bias(bias, ct).to(DEV), pt, ct, Hin=Hin, Win=Win))
+    _check(out[..., cout:], ref, dt)
+    assert (out[..., :cout] == 0).all()
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_dwconv(dt, k):
+    g = torch.Generator().manual_seed(k)
+    B, C_, H, W = 2, 72, 11, 10                          # W not a multiple of the 4-pixel strip
+    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
+    w = _q(torch.randn(C_, 1, k, k, generator=g) / k, dt)
+    bias = torch.randn(C_, generator=g)
+    for act in (lib.ACT_SILU, lib.ACT_NONE):
+        ref = _act(F.conv2d(x, w, bias, 1, k // 2, 1, C_), act)
+        out = torch.zeros(B, H, W, C_, dtype=DT[dt], device=DEV)
+        op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, C_, act, [(_nhwc(x, dt), C_, C_, 0, 0)], out, C_, 0,
+                      pack.pack_dw(w, dt).to(DEV), bias.to(DEV), 0, 0)
+        op.ksize = k
+        _launch(op)
+        _check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+@pytest.mark.parametrize("in_dt", [lib.F32, lib.F16, lib.U8])
+def test_stem(dt, in_dt):
+    g = torch.Generator().manual_seed(3)
+    B, Hin, Win, cout = 2, 32, 64, 24
+    if in_dt == lib.U8:
+        img = torch.randint(0, 256, (B, 3, Hin, Win), generator=g, dtype=torch.uint8)
+        x = img.float() / 255
+        dimg = img.to(DEV)
+    else:
+        x = _q(torch.rand(B, 3, Hin, Win, generator=g), in_dt)
+        dimg = x.to(DT[in_dt]).to(DEV)
+    w = torch.randn(cout, 3, 3, 3, generator=g) / 5.0
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, 2, 1))
+    out = torch.zeros(B, Hin // 2, Win // 2, cout, dtype=DT[dt], device=DEV)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_STEM, dt, in_dt, lib.ACT_RELU
+    op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout = B, Hin // 2, Win // 2, Hin, Win, 3, cout
+    op.nsrc = 1
+    op.src[0].ptr = dimg.data_ptr()
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), cout, 0
+    ws, bs = pack.pack_stem(w).to(DEV), bias.to(DEV)
+    op.w, op.bias = ws.data_ptr(), bs.data_ptr()
+    _launch(op)
+    _check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+def test_sppf_pool(dt):
+    g = torch.Generator().manual_seed(4)
+    B, c_, H, W = 2, 48, 10, 7
+    x = _q(torch.randn(B, c_, H, W, generator=g), dt)
+    y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    buf = torch.zeros(B, H, W, 4 * c_, dtype=DT[dt], device=DEV)
+    buf[..., :c_] = _nhwc(x, dt)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.B, op.H, op.W, op.nsrc = lib.OP_SPPF_POOL, dt, B, H, W, 1
+    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff = buf.data_ptr(), c_, 4 * c_, 0
+    op.out, op.out_stride, op.out_coff = buf.data_ptr(), 4 * c_, c_
+    _launch(op)
+    got = buf.float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, torch.cat([x, y1, y2, y3], 1))          # max pooling is exact in any precision
+
+
+def test_decode():
+    from oracle import maf_oracle as O
+    g = torch.Generator().manual_seed(6)
+    B, nc = 2, 80
+    dims = [(12, 20), (6, 10), (3, 5)]
+    heads, cls_d, reg_d = [], [], []
+    for h, w in dims:
+        cls = torch.rand(B, nc, h, w, generator=g)
+        reg = torch.randn(B, 68, h, w, generator=g) * 2
+        heads.append((torch.zeros(B, 1, h, w), cls, reg))
+        cls_d.append(cls.permute(0, 2, 3, 1).contiguous().to(DEV)); reg_d.append(reg.permute(0, 2, 3, 1).contiguous().to(DEV))
+    ref = O.decode(heads)
+    A = sum(h * w for h, w in dims)
+    out = torch.zeros(B, A, 5 + nc, device=DEV)
+    op = lib.MafOp()
+    op.kind, op.B, op.nsrc = lib.OP_DECODE, B, 3
+    for l, (h, w) in enumerate(dims):
+        op.src[l].ptr, op.reg[l] = cls_d[l].data_ptr(), reg_d[l].data_ptr()
+        op.lvl_h[l], op.lvl_w[l], op.lvl_stride[l] = h, w, float(O.STRIDES[l])
+    op.reg_stride, op.nc, op.reg_max = 68, nc, 16
+    op.out = out.data_ptr()
+    _launch(op)
+    got = out.cpu()
+    np.testing.assert_allclose(got[..., :4].numpy(), ref[..., :4].numpy(), rtol=1e-5, atol=1e-3)
+    assert torch.equal(got[..., 4:], ref[..., 4:])
+
+
+def test_bad_arguments_are_rejected():
+    op = lib.MafOp()
+    op.kind, op.dtype, op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = lib.OP_CONV1X1, lib.F16, 1, 4, 4, 12, 16, 1
+    x = torch.zeros(64, device=DEV)
+    op.src[0].ptr, op.src[0].C, op.src[0].stride = x.data_ptr(), 12, 12          # 12 is not a multiple of 8
+    op.out, op.w, op.bias, op.out_stride, op.tile_p, op.tile_c = x.data_ptr(), x.data_ptr(), x.data_ptr(), 16, 1, 2
+    assert lib.load().maf_op_launch(C.byref(op), None) == -1
+    assert b"multiples" in lib.load().maf_last_error()

@@ -1,0 +1,157 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, the graph /
+re-param / packing logic is right, plans build (no launches without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import maf_yolo_amd as M
+from maf_yolo_amd import lib, pack, arch
+from maf_yolo_amd.engine import Plan
+from oracle import maf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return lib.load()
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "mafyolo_hip.h")).read()
+    declared = set(re.findall(r"\b(maf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.EXPORTS)
+    for s in declared:
+        assert hasattr(built, s), s
+    assert built.maf_version() >= 100
+
+
+def test_struct_layout_matches_header(built):
+    # sizeof(maf_op_t) as laid out by the C compiler == ctypes mirror (guards against field drift)
+    src = '#include <stdio.h>\n#include "mafyolo_hip.h"\nint main(){printf("%zu %zu", sizeof(maf_src_t), sizeof(maf_op_t));return 0;}'
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        a, b = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert int(a) == ctypes.sizeof(lib.MafSrc) and int(b) == ctypes.sizeof(lib.MafOp)
+
+
+def test_error_reporting_without_gpu(built):
+    op = lib.MafOp()
+    op.kind = 99
+    rc = built.maf_op_launch(ctypes.byref(op), None)
+    assert rc == -2 and b"unknown op kind" in built.maf_last_error()
+    op.kind = lib.OP_CONV1X1
+    op.dtype = 7
+    assert built.maf_op_launch(ctypes.byref(op), None) == -1
+    with pytest.raises(lib.MafError):
+        lib.check(built.maf_nms(None, 1, 1, 1, 0.5, 0.5, None, 0, 0, 0, 300, None, 0, None, None, None, None))
+
+
+@pytest.mark.parametrize("scale", ["n", "s", "m"])
+def test_model_state_dict_and_fused_weights(scale):
+    m = M.Model(scale)
+    sd = O.synth_state_dict(scale, 0)
+    assert [k for k, _ in O.state_spec(scale)] == list(m.state_dict().keys())
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    dw = O.reparam(sd, scale)
+    with torch.no_grad():
+        n = 0
+        for name, (w, b) in dw.items():
+            obj = m
+            for part in name.split("."):
+                obj = obj[int(part)] if part.isdigit() else getattr(obj, part, None)
+                if obj is None:
+                    break
+            parent = m
+            parts = name.split(".")
+            # fused() lives on the owning block: strip the deploy-form suffix
+            for suffix, up in ((".rbr_reparam", 1), (".dwconv.lk_origin", 2), (".conv", 1)):
+                if name.endswith(suffix):
+                    parts = name[: -len(suffix)].split(".")
+                    break
+            else:
+                continue            # plain pred convs carry no BN
+            for part in parts:
+                parent = parent[int(part)] if part.isdigit() else getattr(parent, part)
+            fw, fb = parent.fused()
+            assert torch.allclose(fw, w, atol=1e-6) and torch.allclose(fb, b, atol=1e-6), name
+            n += 1
+        assert n == len(dw) - 6
+        x = O.synth_images(1, 64, 1)
+        heads = m._forward_train_form(x)
+        for h, oh in zip(heads, O.forward_train_form(sd, scale, x)):
+            for a, b in zip(h, oh):
+                assert torch.equal(a, b)
+
+
+def test_reference_yaml_schema_roundtrip():
+    for s in "nsm":
+        nodes = arch.builtin(s)
+        assert [n.cout for n in nodes][:34] == O.channels_out(s)
+    with pytest.raises(NotImplementedError):
+        arch.nodes_from_yaml_dict(dict(depth_multiple=1, width_multiple=1, backbone=[[-1, 1, "Focus", [64]]], effidehead=[]))
+
+
+def test_train_mode_output_contract():
+    m = M.Model("n").train()
+    out, feats = m(torch.rand(2, 3, 64, 64))
+    f, cls, reg = out
+    assert cls.shape == (2, 8 * 8 + 4 * 4 + 2 * 2, 80) and reg.shape == (2, 84, 68) and len(f) == 3 and len(feats) == 3
+    loss = cls.sum() + reg.sum()
+    loss.backward()
+    assert m.backbone[0].rbr_dense.conv.weight.grad is not None
+
+
+def test_cpu_input_fails_loudly():
+    m = M.Model("n").eval()
+    with pytest.raises(M.MafError):
+        m(torch.rand(1, 3, 64, 64))
+    with pytest.raises(M.MafError):
+        M.non_max_suppression(torch.rand(1, 10, 85))
+    with pytest.raises(AssertionError):
+        M.non_max_suppression(torch.rand(1, 10, 85), conf_thres=1.5)
+
+
+def test_pack_layout():
+    # packed[tile][step][lane][j] == W[chan(tile,lane)][k(step,lane,j)]
+    cout, cin, ct = 72, 48, 3
+    w = torch.arange(cout * cin, dtype=torch.float32).reshape(cout, cin, 1, 1)
+    for dt, ks, ch in ((lib.F16, 32, 8), (lib.F32, 16, 4)):
+        p = pack.pack_conv1x1(w, [24, 24], ct, dt).float()
+        steps = 2 * -(-24 // ks)
+        assert p.shape == (2 * ct, steps, 64, ch)
+        for tile, step, lane, j in ((0, 0, 0, 0), (1, 1, 17, 3), (4, steps - 1, 63, ch - 1), (5, 0, 37, 1)):
+            nt, c_t = divmod(tile, ct)
+            g, i = lane >> 4, lane & 15
+            chan = nt * 16 * ct + (i >> 2) * 4 * ct + c_t * 4 + (i & 3)
+            spp = -(-24 // ks)                       # steps per source
+            src, ls = divmod(step, spp)
+            kk = ls * ks + g * ch + j
+            exp = w[chan, src * 24 + kk, 0, 0].item() if (chan < cout and kk < 24) else 0.0
+            assert p[tile, step, lane, j].item() == (float(np.float16(exp)) if dt == lib.F16 else exp)
+    assert pack.tile_for(24, 10 ** 6)[1] == 2 and pack.tile_for(128, 10 ** 6) == (2, 8) and pack.tile_for(384, 12800)[0] == 1
+
+
+@pytest.mark.parametrize("scale,nops", [("n", 88 + 2), ("s", 118 + 2), ("m", 148 + 2)])
+def test_plan_builds_on_cpu(built, scale, nops):
+    m = M.Model(scale).eval()
+    plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
+    assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
+    lo, hi = plan._abase, plan._abase + plan._arena_size
+    for o, name in zip(plan.ops, plan.op_names):
+        if o.kind in (lib.OP_CONV1X1, lib.OP_CONV3X3S2, lib.OP_DWCONV):
+            assert sum(o.src[i].C for i in range(o.nsrc)) == o.Cin, name
+            for i in range(o.nsrc):
+                assert lo <= o.src[i].ptr < hi and o.src[i].stride % 8 == 0 and o.src[i].coff % 8 == 0, name
+            assert lo <= o.out < hi, name
+    assert plan.A == 8 * 8 + 4 * 4 + 2 * 2
