@@ -104,6 +104,9 @@ int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t 
 /* Same launches replayed from a hipGraph captured on first use (bs=1 latency path). Pointers are
  * frozen at capture time: image/pred must be the same on every call. */
 int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream);
+/* One forward with a HIP event pair around every op; ms_per_op (HOST float[n_ops]) receives each
+ * op's duration.  Synchronises the stream.  Used by bench.py for the per-kernel roofline. */
+int maf_engine_run_timed(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream, float* ms_per_op);
 void maf_engine_destroy(maf_engine_t* e);
 
 /*

@@ -75,7 +75,7 @@ extern "C" int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pr
     if (!e) { maf_set_error("maf_engine_run_graph: null engine"); return MAF_E_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (e->exec && (e->g_image != image || e->g_pred != pred)) {
-        hipGraphExecDestroy(e->exec); hipGraphDestroy(e->graph);
+        (void)hipGraphExecDestroy(e->exec); (void)hipGraphDestroy(e->graph);
         e->exec = nullptr; e->graph = nullptr;
     }
     if (!e->exec) {
@@ -93,10 +93,31 @@ extern "C" int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pr
     return maf_check_hip(hipGraphLaunch(e->exec, s), "hipGraphLaunch");
 }
 
+extern "C" int maf_engine_run_timed(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream, float* ms_per_op) {
+    if (!e || !ms_per_op) { maf_set_error("maf_engine_run_timed: bad arguments"); return MAF_E_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = e->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    int rc = 0;
+    for (size_t i = 0; i <= n && !rc; ++i) rc = maf_check_hip(hipEventCreate(&ev[i]), "hipEventCreate");
+    if (!rc) rc = maf_check_hip(hipEventRecord(ev[0], s), "hipEventRecord");
+    for (size_t i = 0; i < n && !rc; ++i) {
+        maf_op_t op = e->ops[i];
+        if (op.kind == MAF_OP_STEM && image) op.src[0].ptr = image;
+        if (op.kind == MAF_OP_DECODE && pred) op.out = pred;
+        rc = maf_op_launch(&op, s);
+        if (!rc) rc = maf_check_hip(hipEventRecord(ev[i + 1], s), "hipEventRecord");
+    }
+    if (!rc) rc = maf_check_hip(hipEventSynchronize(ev[n]), "hipEventSynchronize");
+    for (size_t i = 0; i < n && !rc; ++i) rc = maf_check_hip(hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]), "hipEventElapsedTime");
+    for (size_t i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
 extern "C" void maf_engine_destroy(maf_engine_t* e) {
     if (!e) return;
-    if (e->exec) hipGraphExecDestroy(e->exec);
-    if (e->graph) hipGraphDestroy(e->graph);
+    if (e->exec) (void)hipGraphExecDestroy(e->exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
     delete e;
 }
 
@@ -125,6 +146,6 @@ extern "C" int maf_timer_elapsed_ms(void* t, float* ms) {
 extern "C" void maf_timer_destroy(void* t) {
     maf_timer* m = static_cast<maf_timer*>(t);
     if (!m) return;
-    hipEventDestroy(m->a); hipEventDestroy(m->b);
+    (void)hipEventDestroy(m->a); (void)hipEventDestroy(m->b);
     delete m;
 }

@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     typedef Frag<T> F;
     typedef typename F::type frag_t;
     constexpr int CH = F::CH;
-    constexpr int CPS = F::KS / F::CH;     // chunks per k-step (= 4 lane groups)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;

@@ -251,6 +251,71 @@ class Plan:
         lib.check(fn(self._engine, x.data_ptr(), pred.data_ptr(), stream))
         return pred
 
+    def run_timed(self, x, pred):
+        """One forward with HIP events around every op -> list of per-op milliseconds (bench.py roofline)."""
+        ms = (C.c_float * len(self.ops))()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        lib.check(lib.load().maf_engine_run_timed(self._engine, x.data_ptr(), pred.data_ptr(), stream, ms))
+        return list(ms)
+
+    def kernel_name(self, idx):
+        """Device kernel symbol (as rocprofv3 --kernel-trace prints it) behind op idx."""
+        o = self.ops[idx]
+        T = "_Float16" if o.dtype == lib.F16 else "float"
+        if o.kind in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
+            if o.kind == lib.OP_CONV3X3S2:
+                var = 3
+            elif o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2:
+                var = 2
+            elif o.nsrc == 1 and o.src[0].mode == lib.SRC_DIRECT:
+                var = 0
+            else:
+                var = 1
+            outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
+            return "conv_mfma_kernel<%s, %d, %d, %d, %s>" % (T, o.tile_p, o.tile_c, var, outf32)
+        if o.kind == lib.OP_DWCONV:
+            return "dwconv_kernel<%s, %d, 4>" % (T, o.ksize)
+        return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
+
+    def algorithmic_bytes(self, idx):
+        """Bytes one launch of op idx must move at minimum: every input element read once, every output
+        element written once, weights once (SURVEY.md §8d layer-granular model)."""
+        o = self.ops[idx]
+        es = self.es
+        px = self.B * o.H * o.W
+        if o.kind == lib.OP_STEM:
+            ies = {lib.F16: 2, lib.F32: 4, lib.U8: 1}[o.in_dtype]
+            return self.B * 3 * o.Hin * o.Win * ies + px * o.Cout * es + 27 * o.Cout * 4
+        if o.kind == lib.OP_CONV1X1:
+            rd = 0
+            for i in range(o.nsrc):
+                f = {lib.SRC_DIRECT: 1.0, lib.SRC_UP2: 0.25, lib.SRC_POOL2: 4.0}[o.src[i].mode]
+                rd += px * f * o.src[i].C * es
+            oes = 4 if o.out_f32 else es
+            return int(rd) + px * o.Cout * oes + o.Cin * o.Cout * es
+        if o.kind == lib.OP_CONV3X3S2:
+            return self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es
+        if o.kind == lib.OP_DWCONV:
+            return 2 * px * o.Cin * es + o.ksize * o.ksize * o.Cin * es
+        if o.kind == lib.OP_SPPF_POOL:
+            return 4 * px * o.src[0].C * es
+        if o.kind == lib.OP_DECODE:
+            return self.B * self.A * ((self.nc + 4 * (self.reg_max + 1)) * 4 + (5 + self.nc) * 4)
+        return 0
+
+    def flops(self, idx):
+        o = self.ops[idx]
+        px = self.B * o.H * o.W
+        if o.kind == lib.OP_STEM:
+            return 2 * px * 27 * o.Cout
+        if o.kind == lib.OP_CONV1X1:
+            return 2 * px * o.Cin * o.Cout
+        if o.kind == lib.OP_CONV3X3S2:
+            return 2 * px * 9 * o.Cin * o.Cout
+        if o.kind == lib.OP_DWCONV:
+            return 2 * px * o.ksize * o.ksize * o.Cin
+        return 0
+
     def launch_op(self, idx, image_ptr=None, pred_ptr=None):
         """Launch a single op of the plan (profiling / per-kernel timing)."""
         op = self.ops[idx]

@@ -29,7 +29,7 @@ class MafOp(C.Structure):
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
-           "maf_engine_run", "maf_engine_run_graph", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms",
+           "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
 _lib = None
@@ -55,6 +55,7 @@ def load():
     lib.maf_engine_num_ops.argtypes = [C.c_void_p]
     lib.maf_engine_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.maf_engine_run_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.maf_engine_run_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.maf_engine_destroy.argtypes = [C.c_void_p]
     lib.maf_engine_destroy.restype = None
     lib.maf_nms_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
