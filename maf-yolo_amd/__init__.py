@@ -1,7 +1,7 @@
 """MAF-YOLO hot path, MI355X-native: Model.forward() / non_max_suppression() over hand-written HIP kernels.
 
 See DESIGN.md.  Importing this package does not need a GPU; running it does (no CPU fallback)."""
-from . import lib, arch, pack  # noqa: F401
+from . import lib, arch, pack, synth  # noqa: F401
 from .lib import MafError  # noqa: F401
 from .model import Model, Detect_yaml  # noqa: F401
 from .nms import non_max_suppression, nms_raw  # noqa: F401

@@ -155,3 +155,13 @@ def test_plan_builds_on_cpu(built, scale, nops):
                 assert lo <= o.src[i].ptr < hi and o.src[i].stride % 8 == 0 and o.src[i].coff % 8 == 0, name
             assert lo <= o.out < hi, name
     assert plan.A == 8 * 8 + 4 * 4 + 2 * 2
+
+
+def test_product_synth_generator_equals_oracle_generator():
+    from maf_yolo_amd import synth
+    for s in "nsm":
+        a = synth.synth_state_dict(M.Model(s), s, 0)
+        b = O.synth_state_dict(s, 0)
+        assert list(a.keys()) == list(b.keys())
+        assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(synth.synth_images(2, 32, 5), O.synth_images(2, 32, 5))
