@@ -208,24 +208,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * total_steps + step) * 64];
     };
 
-    frag_t bcur[PT], acur[CT], bnxt[PT], anxt[CT];
-    load_b(0, bcur);
-    load_a(0, acur);
-    for (int step = 0; step < total_steps; ++step) {
-        const bool more = step + 1 < total_steps;
-        if (more) {
-            load_b(step + 1, bnxt);
-            load_a(step + 1, anxt);
+    // Software pipeline: a ring of NS register stages, loads issued NS-1 k-steps ahead of their MFMAs.
+    // Small-M layers (PT == 1: the 20x20 / 40x40 maps) are latency-bound chains of short k-steps, so they
+    // run 4 stages deep; big layers (PT == 2) keep 2 stages and spend the registers on occupancy instead.
+    constexpr int NS = PT == 1 ? 4 : 2;
+    frag_t bst[NS][PT], ast[NS][CT];
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < total_steps) {
+            load_b(s, bst[s]);
+            load_a(s, ast[s]);
         }
+    for (int step0 = 0; step0 < total_steps; step0 += NS) {
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
+        for (int u = 0; u < NS; ++u) {
+            const int step = step0 + u;
+            if (step < total_steps) {
+                if (step + NS - 1 < total_steps) {
+                    load_b(step + NS - 1, bst[(u + NS - 1) % NS]);
+                    load_a(step + NS - 1, ast[(u + NS - 1) % NS]);
+                }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(acur[ct], bcur[pt], acc[pt][ct]);
-        if (more) {
+                for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) bcur[pt] = bnxt[pt];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acur[ct] = anxt[ct];
+                    for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(ast[u][ct], bst[u][pt], acc[pt][ct]);
+            }
         }
     }
 

@@ -23,8 +23,10 @@ struct DecArgs {
     int B, A, nc, reg_stride, reg_max;
 };
 
+template <int NO_CT>   // 5+nc known at compile time (85) => the row/col split is a multiply-shift, not an integer division
 __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
     __shared__ float box[64][4];
+    __shared__ __attribute__((aligned(16))) float regs[64 * 68 + 4];   // the block's reg logits, staged with coalesced loads
     const int b = blockIdx.y;
     int blk = blockIdx.x;
     const int l = (blk >= a.lvl_blk[1]) + (blk >= a.lvl_blk[2]);
@@ -37,16 +39,23 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
     const int W = l == 0 ? a.lvl_w[0] : l == 1 ? a.lvl_w[1] : a.lvl_w[2];
     const float stride = l == 0 ? a.lvl_stride[0] : l == 1 ? a.lvl_stride[1] : a.lvl_stride[2];
     const int tid = threadIdx.x;
+    const bool staged = a.reg_stride == 68 && a.reg_max == 16;              // the MAF-YOLO head: 64 x 68 contiguous floats
+    if (staged) {
+        const int n4 = nA * 17;                                             // float4 count (68 floats = 17 float4 per anchor)
+        const f32x4_t* src = reinterpret_cast<const f32x4_t*>(reg);
+        for (int i = tid; i < n4; i += 256) *reinterpret_cast<f32x4_t*>(&regs[4 * i]) = src[i];
+        __syncthreads();
+    }
     {
         const int ai = tid >> 2, side = tid & 3;
         if (ai < nA) {
             const int nb = a.reg_max + 1;
-            const float* r = reg + (size_t)ai * a.reg_stride + side * nb;   // channel = side*17 + bin (yolo.py:376)
+            const float* r = staged ? &regs[ai * 68 + side * 17] : reg + (size_t)ai * a.reg_stride + side * nb;   // channel = side*17 + bin (yolo.py:376)
             float mx = -INFINITY;
             for (int i = 0; i < nb; ++i) mx = fmaxf(mx, r[i]);
             float se = 0.f, sw = 0.f;
             for (int i = 0; i < nb; ++i) {
-                const float e = expf(r[i] - mx);
+                const float e = __expf(r[i] - mx);
                 se += e;
                 sw += e * (float)i;
             }
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
         }
     }
     __syncthreads();
-    const int no = 5 + a.nc;
+    const int no = NO_CT > 0 ? NO_CT : 5 + a.nc;
     float* out = a.out + ((size_t)b * a.A + a.lvl_off[l] + a0) * no;
     for (int e = tid; e < nA * no; e += 256) {
         const int ai = e / no, col = e - ai * no;
@@ -95,6 +104,7 @@ int maf_launch_decode(const maf_op_t* op, hipStream_t s) {
     a.lvl_off[3] = off; a.lvl_blk[3] = blk;
     a.out = static_cast<float*>(op->out);
     a.B = op->B; a.A = off; a.nc = op->nc; a.reg_stride = op->reg_stride; a.reg_max = op->reg_max;
-    hipLaunchKernelGGL(decode_kernel, dim3(blk, op->B), dim3(256), 0, s, a);
+    if (op->nc == 80) hipLaunchKernelGGL(decode_kernel<85>, dim3(blk, op->B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(decode_kernel<0>, dim3(blk, op->B), dim3(256), 0, s, a);
     return maf_check_hip(hipGetLastError(), "decode launch");
 }

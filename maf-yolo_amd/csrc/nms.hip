@@ -5,9 +5,10 @@
 // class-offset trick :94-95, torchvision.ops.nms :96, max_det :97-98).  The reference runs a Python
 // loop over images with ~6 implicit device->host syncs each.
 //
-// Launch 1  nms_collect:  one wavefront per box.  The 5+nc floats of a box are one contiguous,
-//   coalesced read; the raw-class maximum / best class are wavefront reductions (DPP shuffles);
-//   survivors are appended to the image's candidate list with one wave-aggregated atomic.  A
+// Launch 1  nms_collect:  multi-label mode streams the prediction tensor one lane per (box, class)
+//   element, fully coalesced; best-class mode gives each box a 16-lane group and finds the arg-max
+//   with shuffles.  Survivors are appended to the image's candidate list with one wave-aggregated
+//   atomic per wavefront.  A
 //   candidate is a 64-bit key  (~score_bits << 32) | (box*nc + cls): ascending key order ==
 //   descending fp32 score, ties broken by the lower row-major (box, class) index — the order
 //   `nonzero` (nms.py:76) + a stable descending sort produce.
@@ -51,69 +52,113 @@ __device__ __forceinline__ bool class_ok(const NmsArgs& a, int c) {
     return false;
 }
 
-__global__ __launch_bounds__(256) void nms_collect_kernel(const NmsArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+// raw-class maximum of one box (only needed when obj > 1, where sc > conf does not imply it)
+__device__ float row_rmax(const float* row, int nc) {
+    float m = -INFINITY;
+    for (int c = 0; c < nc; ++c) m = fmaxf(m, row[5 + c]);
+    return m;
+}
+
+constexpr int kCntStride = 64;       // one candidate counter per 256-byte line: atomics of different images never share a line
+constexpr int kChunk = 8192;         // elements per workgroup chunk (32 KiB of fp32: stays in L1 between the two passes)
+
+__device__ __forceinline__ bool multi_test(const NmsArgs& a, const float* pred, unsigned int e32, int no, float& sc) {
+    const int box = (int)(e32 / (unsigned int)a.nc), c = (int)(e32 - (unsigned int)box * (unsigned int)a.nc);
+    const float* row = pred + (size_t)box * no;
+    const float obj = row[4];
+    sc = row[5 + c] * obj;                                                // nms.py:69
+    bool ok = obj > a.conf && sc > a.conf && class_ok(a, c);              // nms.py:48 (obj), :76, :83-84
+    // nms.py:48 also needs max(raw cls) > conf; sc > conf implies it unless obj > 1
+    if (ok && obj > 1.0f) ok = row_rmax(row, a.nc) > a.conf;
+    return ok;
+}
+
+// multi_label: one lane per (box, class) element of the prediction tensor, fully coalesced.  A workgroup owns a
+// contiguous chunk: pass 1 counts its candidates, ONE atomicAdd per chunk reserves the output range (a per-wave
+// atomic per hit costs ~10 ns each on one contended line — 64k of them were 0.65 ms), pass 2 re-tests (L1 hits)
+// and writes the keys.  Candidate order inside the list is irrelevant: the sort key carries the flat index.
+__global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a) {
+    __shared__ int wave_cnt[4];
+    __shared__ int s_base;
     const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int no = 5 + a.nc;
+    const unsigned int total = (unsigned int)a.N * (unsigned int)a.nc;     // < 2^32 (checked by maf_nms)
+    unsigned long long* keys = a.keys + (size_t)b * a.capP;
+    const float* pred = a.pred + (size_t)b * a.N * no;
+    for (unsigned int c0 = blockIdx.x * kChunk; c0 < total; c0 += gridDim.x * kChunk) {
+        int mine = 0;
+        for (int i = 0; i < kChunk / 256; ++i) {
+            const unsigned int e = c0 + i * 256 + tid;
+            float sc;
+            const bool ok = e < total && multi_test(a, pred, e, no, sc);
+            mine += __popcll(__ballot(ok));                                // wave-uniform running count
+        }
+        if (lane == 0) wave_cnt[wave] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            s_base = n > 0 ? atomicAdd(&a.cnt[b * kCntStride], n) : 0;
+        }
+        __syncthreads();
+        int pos = s_base;
+        for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+        const bool any = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3] > 0;
+        if (any) {
+            for (int i = 0; i < kChunk / 256; ++i) {
+                const unsigned int e = c0 + i * 256 + tid;
+                float sc = 0.f;
+                const bool ok = e < total && multi_test(a, pred, e, no, sc);
+                const unsigned long long m = __ballot(ok);
+                if (ok) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(sc)) << 32) | e;
+                pos += __popcll(m);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// best-class mode: 16 lanes per box (4 boxes per wavefront), arg-max by shuffles within the 16-lane group.
+__global__ __launch_bounds__(256) void nms_collect_best_kernel(const NmsArgs a) {
+    const int b = blockIdx.y;
+    const int sub = threadIdx.x & 15;
     const int no = 5 + a.nc;
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
-    for (int box = wave; box < a.N; box += nwaves) {
+    const int groups = (gridDim.x * blockDim.x) >> 4;
+    for (int box = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; box < a.N; box += groups) {
         const float* row = a.pred + ((size_t)b * a.N + box) * no;
         const float obj = row[4];
-        if (!(obj > a.conf)) continue;                           // nms.py:48 (wave-uniform)
-        // raw class maximum over all classes (nms.py:48) and, for best-class mode, argmax of obj*cls
-        float rmax = -INFINITY;
-        float best = -INFINITY; int besti = 0x7fffffff;
-        for (int c = lane; c < a.nc; c += 64) {
+        float rmax = -INFINITY, best = -INFINITY; int besti = 0x7fffffff;
+        for (int c = sub; c < a.nc; c += 16) {
             const float r = row[5 + c];
             rmax = fmaxf(rmax, r);
-            const float sc = r * obj;                            // nms.py:69
-            if (sc > best) { best = sc; besti = c; }             // first maximum per lane (c ascending)
+            const float sc = r * obj;                                     // nms.py:69
+            if (sc > best) { best = sc; besti = c; }                      // first maximum per lane (c ascending)
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 8; o > 0; o >>= 1) {
             rmax = fmaxf(rmax, __shfl_xor(rmax, o));
             const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(besti, o);
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
-        if (!(rmax > a.conf)) continue;
-        if (a.multi_label) {
-            for (int c0 = 0; c0 < a.nc; c0 += 64) {
-                const int c = c0 + lane;
-                float sc = 0.f; bool ok = false;
-                if (c < a.nc) {
-                    sc = row[5 + c] * obj;
-                    ok = sc > a.conf && class_ok(a, c);          // nms.py:76, :83-84
-                }
-                const unsigned long long m = __ballot(ok);
-                if (m == 0) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&a.cnt[b], __popcll(m));
-                base = __shfl(base, 0);
-                if (ok) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    const unsigned int flat = (unsigned int)box * a.nc + c;
-                    keys[pos] = ((unsigned long long)(~__float_as_uint(sc)) << 32) | flat;
-                }
-            }
-        } else if (lane == 0) {                                   // nms.py:78-80
-            if (best > a.conf && class_ok(a, besti)) {
-                const int pos = atomicAdd(&a.cnt[b], 1);
-                const unsigned int flat = (unsigned int)box * a.nc + besti;
-                keys[pos] = ((unsigned long long)(~__float_as_uint(best)) << 32) | flat;
-            }
+        if (sub == 0 && obj > a.conf && rmax > a.conf && best > a.conf && class_ok(a, besti)) {   // nms.py:48, :78-80, :83-84
+            const int pos = atomicAdd(&a.cnt[b * kCntStride], 1);
+            const unsigned int flat = (unsigned int)box * a.nc + besti;
+            keys[pos] = ((unsigned long long)(~__float_as_uint(best)) << 32) | flat;
         }
     }
 }
 
-struct Cand { float x1, y1, x2, y2, area; };
+struct alignas(16) Cand { float x1, y1, x2, y2, area, score; unsigned int flat, pad; };   // 32 B: two ds_read_b128
 
 __device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, double thr) {
     // torchvision nms CPU kernel: i = kept (earlier), j = candidate
     const float xx1 = fmaxf(k.x1, c.x1), yy1 = fmaxf(k.y1, c.y1);
     const float xx2 = fminf(k.x2, c.x2), yy2 = fminf(k.y2, c.y2);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    // disjoint boxes: inter = 0 (or NaN) => ovr is 0, -0 or NaN => never > thr (thr >= 0). Skips the IEEE division
+    // for the vast majority of pairs (different classes sit 4096 px apart).
+    if (!(w > 0.f) || !(h > 0.f)) return false;
     const float inter = w * h;
     const float ovr = inter / (k.area + c.area - inter);
     return (double)ovr > thr;
@@ -141,7 +186,7 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
     const long long cap = a.multi_label ? (long long)a.N * a.nc : (long long)a.N;
-    long long n64 = a.cnt[b];
+    long long n64 = a.cnt[b * kCntStride];
     if (n64 > cap) n64 = cap;
     const int n = (int)n64;
     float* rows = a.out_rows + (size_t)b * a.max_det * 6;
@@ -176,7 +221,7 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
         if (kept0 >= a.max_det) break;
         // ---- phase A: all 256 lanes screen their candidate against the kept list ----
         const int ci = base + tid;
-        Cand c = {0.f, 0.f, 0.f, 0.f, 0.f};
+        Cand c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         unsigned long long key = 0;
         bool alive = ci < ns;
         float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f, score = 0.f; int cls = 0; unsigned int flat = 0;
@@ -192,8 +237,16 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
             const float off = a.agnostic ? 0.f : (float)cls * kMaxWh;                 // nms.py:94
             c.x1 = bx1 + off; c.y1 = by1 + off; c.x2 = bx2 + off; c.y2 = by2 + off;
             c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
-            for (int k = 0; k < kept0 && alive; ++k)
-                if (iou_gt(kept[k], c, a.iou)) alive = false;
+            c.score = score; c.flat = flat;
+            for (int k0 = 0; k0 < kept0 && alive; k0 += 8) {               // 8 kept boxes per step: LDS reads overlap
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const Cand kk = kept[min(k0 + u, kept0 - 1)];
+                    hit |= iou_gt(kk, c, a.iou);
+                }
+                if (hit) alive = false;
+            }
         }
         const unsigned long long m = __ballot(alive);
         if (lane == 0) alive_mask[wave] = m;
@@ -213,10 +266,7 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
                     ki.x1 = __shfl(c.x1, i); ki.y1 = __shfl(c.y1, i); ki.x2 = __shfl(c.x2, i); ki.y2 = __shfl(c.y2, i);
                     ki.area = __shfl(c.area, i);
                     if (lane == i) {
-                        kept[nk] = c;
-                        float* o = rows + (size_t)nk * 6;
-                        o[0] = bx1; o[1] = by1; o[2] = bx2; o[3] = by2; o[4] = score; o[5] = (float)cls;
-                        oidx[nk] = a.multi_label ? (long long)flat : (long long)(flat / (unsigned int)a.nc);
+                        kept[nk] = c;                                     // rows are written after the loop, from the list
                         alive = false;
                     }
                     ++nk;
@@ -229,7 +279,19 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
             __syncthreads();
         }
     }
-    if (tid == 0) a.out_count[b] = s_kept < a.max_det ? s_kept : a.max_det;
+    // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)
+    const int nk = s_kept < a.max_det ? s_kept : a.max_det;
+    for (int k = tid; k < nk; k += 256) {
+        const unsigned int flat = kept[k].flat;
+        const unsigned int box = flat / (unsigned int)a.nc;
+        const int cls = (int)(flat - box * (unsigned int)a.nc);
+        const float* r = pred + (size_t)box * no;
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float* o = rows + (size_t)k * 6;
+        o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2; o[4] = kept[k].score; o[5] = (float)cls;
+        oidx[k] = a.multi_label ? (long long)flat : (long long)box;
+    }
+    if (tid == 0) a.out_count[b] = nk;
 }
 
 long long pow2ceil(long long v) {
@@ -243,7 +305,7 @@ long long pow2ceil(long long v) {
 extern "C" int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc) {
     if (B <= 0 || N <= 0 || nc <= 0) return 0;
     const long long capP = pow2ceil((long long)N * nc);
-    return 256 + (long long)((B * 4 + 255) / 256) * 256 + (long long)B * capP * 8;
+    return 256 + (long long)B * kCntStride * 4 + (long long)B * capP * 8;
 }
 
 extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
@@ -267,13 +329,19 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     a.max_det = max_det;
     char* ws = static_cast<char*>(workspace);
     a.cnt = reinterpret_cast<int*>(ws);
-    a.keys = reinterpret_cast<unsigned long long*>(ws + 256 + (long long)((B * 4 + 255) / 256) * 256);
+    a.keys = reinterpret_cast<unsigned long long*>(ws + 256 + (long long)B * kCntStride * 4);
     a.capP = pow2ceil((long long)N * nc);
     a.out_rows = out_rows; a.out_idx = reinterpret_cast<long long*>(out_idx); a.out_count = out_count;
-    int rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * 4, s), "nms memset");
+    int rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * kCntStride * 4, s), "nms memset");
     if (rc) return rc;
-    const int blocks_x = (N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048;    // 4 waves per block, one box per wave-iteration
-    hipLaunchKernelGGL(nms_collect_kernel, dim3(blocks_x, B), dim3(256), 0, s, a);
+    if (a.multi_label) {
+        const long long el = (long long)N * nc;
+        const int bx = (int)((el + kChunk - 1) / kChunk < 256 ? (el + kChunk - 1) / kChunk : 256);
+        hipLaunchKernelGGL(nms_collect_multi_kernel, dim3(bx, B), dim3(256), 0, s, a);
+    } else {
+        const int bx = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;      // 16 boxes per 256-thread block per iteration
+        hipLaunchKernelGGL(nms_collect_best_kernel, dim3(bx, B), dim3(256), 0, s, a);
+    }
     rc = maf_check_hip(hipGetLastError(), "nms_collect launch");
     if (rc) return rc;
     hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(256), 0, s, a);

@@ -4,7 +4,8 @@
 //
 // Chained 5x5 max pools with -inf padding equal clipped 5x5 / 9x9 / 13x13 window maxima, so one
 // thread (one 16-byte channel group of one pixel) scans the 13x13 window once, row-wise, and
-// tracks the three nested maxima.  The map is 20x20 at 640 px input: L1/L2-resident, launch-bound.
+// tracks the three nested maxima (fallback for maps larger than 64x64).  The usual case — the 20x20
+// P5 map at 640 px input — takes the LDS kernel below.
 #include "maf_common.h"
 
 namespace {
@@ -57,6 +58,54 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
     *reinterpret_cast<V*>(out + 2 * a.C) = o13;
 }
 
+// LDS version for maps up to 64x64 (the 20x20 P5 map at 640 px): one workgroup = one image x one
+// 16-byte channel group; the plane lives in LDS and each 5x5 pool is a separable row-max / col-max
+// pass pair (5+5 reads instead of 25), chained three times.
+template <typename T, typename V, int N>
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    V* cur = reinterpret_cast<V*>(smem_raw);                 // [H*W]
+    V* tmp = cur + a.H * a.W;                                // [H*W]
+    const int b = blockIdx.y, cg = blockIdx.x, HW = a.H * a.W;
+    const T* in = static_cast<const T*>(a.in) + (size_t)b * HW * a.in_stride + a.in_coff + cg * N;
+    T* out = static_cast<T*>(a.out) + (size_t)b * HW * a.out_stride + a.out_coff + cg * N;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) cur[p] = *reinterpret_cast<const V*>(in + (size_t)p * a.in_stride);
+    __syncthreads();
+    for (int level = 0; level < 3; ++level) {
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {            // row pass
+            const int x = p % a.W, y = p / a.W;
+            V m = cur[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const int xx = x + d;
+                if (d != 0 && (unsigned)xx < (unsigned)a.W) {
+                    const V v = cur[y * a.W + xx];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                }
+            }
+            tmp[p] = m;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {            // column pass
+            const int x = p % a.W, y = p / a.W;
+            V m = tmp[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const int yy = y + d;
+                if (d != 0 && (unsigned)yy < (unsigned)a.H) {
+                    const V v = tmp[yy * a.W + x];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                }
+            }
+            *reinterpret_cast<V*>(out + (size_t)p * a.out_stride + level * a.C) = m;
+            cur[p] = m;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int maf_launch_sppf_pool(const maf_op_t* op, hipStream_t s) {
@@ -71,7 +120,15 @@ int maf_launch_sppf_pool(const maf_op_t* op, hipStream_t s) {
     a.CG = sr.C / N;
     const long long total = (long long)a.B * a.H * a.W * a.CG;
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (op->dtype == MAF_F16) hipLaunchKernelGGL((sppf_pool_kernel<half_t, half8_t, 8>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((sppf_pool_kernel<float, f32x4_t, 4>), g, b, 0, s, a);
+    const size_t lds = (size_t)a.H * a.W * 16 * 2;
+    if (lds <= 64 * 1024) {
+        const dim3 gl(a.CG, a.B);
+        if (op->dtype == MAF_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, half8_t, 8>), gl, b, lds, s, a);
+        else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, f32x4_t, 4>), gl, b, lds, s, a);
+    } else if (op->dtype == MAF_F16) {
+        hipLaunchKernelGGL((sppf_pool_kernel<half_t, half8_t, 8>), g, b, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((sppf_pool_kernel<float, f32x4_t, 4>), g, b, 0, s, a);
+    }
     return maf_check_hip(hipGetLastError(), "sppf_pool launch");
 }

@@ -4,9 +4,10 @@
 // in_dtype = MAF_U8, also folds the `imgs /= 255` pass of yolov6/core/evaler.py:161-163.
 //
 // K = 27 is too thin for MFMA and the layer is bound by its 2.4 MB/img read + 4.9 MB/img write, so
-// this is a VALU direct conv: one thread per output pixel keeps its 27 taps in registers, weights
-// (27 x Cout fp32) sit in LDS and are read as broadcast float4s; each thread emits its Cout
-// channels as 16-byte NHWC stores (adjacent lanes = adjacent pixels => fully coalesced rows).
+// this is a VALU direct conv: one thread owns 4 adjacent output pixels, reads the 9 input rows
+// (3 channels x 3 ky) as one aligned 8-wide vector + 1 scalar each and keeps them in registers;
+// weights (27 x Cout fp32) sit in LDS and are read as broadcast float4s shared by the 4 pixels;
+// each pixel's Cout channels leave as 16-byte NHWC stores.
 #include "maf_common.h"
 
 namespace {
@@ -20,56 +21,101 @@ struct StemArgs {
     float in_scale;
 };
 
-template <typename TI> __device__ __forceinline__ float ld_in(const TI* p) { return (float)*p; }
+// 8 consecutive input columns starting at an 8-element-aligned column, as floats
+__device__ __forceinline__ void ld8(const half_t* p, float (&v)[8]) {
+    const half8_t h = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void ld8(const uint8_t* p, float (&v)[8]) {
+    const u32x2_t w = *reinterpret_cast<const u32x2_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (float)((w[0] >> (8 * i)) & 0xffu); v[4 + i] = (float)((w[1] >> (8 * i)) & 0xffu); }
+}
 
+// One thread = 4 horizontally adjacent output pixels (input columns 2x-1 .. 2x+7: one aligned 8-wide
+// vector load + one scalar per (channel, ky)), all Cout channels in passes of 8.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [27][Cout] + [Cout]
     const int nW = 27 * a.Cout;
     for (int i = threadIdx.x; i < nW + a.Cout; i += blockDim.x) smem[i] = i < nW ? a.w[i] : a.bias[i - nW];
     __syncthreads();
-    const int M = a.B * a.H * a.W;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int x = m % a.W, t = m / a.W, y = t % a.H, b = t / a.H;
+    // weights / bias are wave-uniform: they come through the scalar cache into SGPRs (s_load), not LDS/VGPRs
+    const int XQ = a.W >> 2;                                      // quads per output row (W % 4 == 0)
+    const int total = a.B * a.H * XQ;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int xq = t % XQ, t2 = t / XQ, y = t2 % a.H, b = t2 / a.H;
+    const int x0 = xq * 4;
     const TI* img = static_cast<const TI*>(a.img) + (size_t)b * 3 * a.Hin * a.Win;
-    float in[27];
+    float in[9][9];                                                // [c*3+ky][column 2x0-1 .. 2x0+7]
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * y - 1 + ky;
+            const bool rok = (unsigned)iy < (unsigned)a.Hin;
+            const TI* row = img + ((size_t)c * a.Hin + (rok ? iy : 0)) * a.Win + 2 * x0;
+            float v[8];
+            ld8(row, v);
+            const float left = x0 > 0 ? (float)row[-1] : 0.f;
+            const float m = rok ? a.in_scale : 0.f;
+            in[c * 3 + ky][0] = left * m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) in[c * 3 + ky][1 + i] = v[i] * m;
+        }
+    TO* o = static_cast<TO*>(a.out) + ((size_t)(b * a.H + y) * a.W + x0) * a.out_stride + a.out_coff;
+#pragma unroll 1
+    for (int c0 = 0; c0 < a.Cout; c0 += 8) {
+        float acc[4][8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = smem[nW + c0 + j];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            // keep one (channel, ky) row of weights (6 LDS reads = 24 VGPRs) in flight: without the fence the scheduler
+            // hoists all 54 reads of the pass (216 VGPRs => 1 wave/SIMD)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
-                const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-                in[(c * 3 + ky) * 3 + kx] = ok ? ld_in<TI>(img + ((size_t)c * a.Hin + iy) * a.Win + ix) * a.in_scale : 0.f;
-            }
-    TO* o = static_cast<TO*>(a.out) + (size_t)m * a.out_stride + a.out_coff;
-    for (int c0 = 0; c0 < a.Cout; c0 += 8) {
-        float acc[8];
+                const int k = r * 3 + kx;
+                float wk[8];
+                {
+                    const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(&smem[k * a.Cout + c0]);
+                    const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(&smem[k * a.Cout + c0 + 4]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = smem[nW + c0 + j];
+                    for (int j = 0; j < 4; ++j) { wk[j] = w0[j]; wk[4 + j] = w1[j]; }
+                }
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(&smem[k * a.Cout + c0]);
-            const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(&smem[k * a.Cout + c0 + 4]);
+                for (int p = 0; p < 4; ++p) {
+                    const float v = in[r][2 * p + kx];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j] = __builtin_fmaf(in[k], w0[j], acc[j]);
-                acc[4 + j] = __builtin_fmaf(in[k], w1[j], acc[4 + j]);
+                    for (int j = 0; j < 8; ++j) acc[p][j] = __builtin_fmaf(v, wk[j], acc[p][j]);
+                }
             }
         }
-        if (sizeof(TO) == 2) {
-            half8_t v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (half_t)maf_act_rt(acc[j], a.act);
-            *reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(o) + c0) = v;
-        } else {
-            f32x4_t v0, v1;
+        for (int p = 0; p < 4; ++p) {
+            if (sizeof(TO) == 2) {
+                half8_t v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] = maf_act_rt(acc[j], a.act); v1[j] = maf_act_rt(acc[4 + j], a.act); }
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(o) + c0) = v0;
-            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(o) + c0 + 4) = v1;
+                for (int j = 0; j < 8; ++j) v[j] = (half_t)fmaxf(acc[p][j], 0.f);
+                *reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(o) + (size_t)p * a.out_stride + c0) = v;
+            } else {
+                f32x4_t v0, v1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(acc[p][j], 0.f); v1[j] = fmaxf(acc[p][4 + j], 0.f); }
+                float* of = reinterpret_cast<float*>(o) + (size_t)p * a.out_stride + c0;
+                *reinterpret_cast<f32x4_t*>(of) = v0;
+                *reinterpret_cast<f32x4_t*>(of + 4) = v1;
+            }
         }
     }
 }
@@ -80,6 +126,8 @@ int maf_launch_stem(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16 || op->dtype == MAF_F32, "stem: dtype must be f16/f32");
     MAF_REQUIRE(op->Cin == 3 && op->Cout % 8 == 0 && op->Cout <= 256, "stem: Cin must be 3, Cout a multiple of 8");
     MAF_REQUIRE(op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "stem: out stride/coff multiples of 8");
+    MAF_REQUIRE(op->Win % 8 == 0, "stem: image width must be a multiple of 8");
+    MAF_REQUIRE(op->act == MAF_ACT_RELU, "stem: the RepVGG stem ends in ReLU (common.py:198)");
     MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->Hin - 1) / 2 + 1 == op->H && (op->Win - 1) / 2 + 1 == op->W, "stem: H,W must equal floor((Hin-1)/2)+1");
     MAF_REQUIRE(op->src[0].ptr && op->w && op->bias && op->out, "stem: null pointer");
     StemArgs a;
@@ -87,7 +135,7 @@ int maf_launch_stem(const maf_op_t* op, hipStream_t s) {
     a.B = op->B; a.H = op->H; a.W = op->W; a.Hin = op->Hin; a.Win = op->Win; a.Cout = op->Cout;
     a.out_stride = op->out_stride; a.out_coff = op->out_coff; a.act = op->act;
     a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;
-    const int M = op->B * op->H * op->W;
+    const int M = op->B * op->H * (op->W / 4);
     const dim3 g(maf_cdiv(M, 256)), b(256);
     const size_t sh = (size_t)(28 * op->Cout) * sizeof(float);
 #define MAF_STEM(TI, TO) hipLaunchKernelGGL((stem_kernel<TI, TO>), g, b, sh, s, a)

@@ -274,8 +274,8 @@ class Plan:
             outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
             return "conv_mfma_kernel<%s, %d, %d, %d, %s>" % (T, o.tile_p, o.tile_c, var, outf32)
         if o.kind == lib.OP_DWCONV:
-            return "dwconv_kernel<%s, %d, 4>" % (T, o.ksize)
-        return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
+            return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
+        return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
         """Bytes one launch of op idx must move at minimum: every input element read once, every output

@@ -146,9 +146,10 @@ def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
 @pytest.mark.parametrize("k", [3, 5, 7, 9])
-def test_dwconv(dt, k):
+@pytest.mark.parametrize("C_,H,W", [(72, 11, 10), (192, 40, 40), (576, 20, 20), (24, 37, 50)])   # ragged tiles, multi-tile, multi-block
+def test_dwconv(dt, k, C_, H, W):
     g = torch.Generator().manual_seed(k)
-    B, C_, H, W = 2, 72, 11, 10                          # W not a multiple of the 4-pixel strip
+    B = 2
     x = _q(torch.randn(B, C_, H, W, generator=g), dt)
     w = _q(torch.randn(C_, 1, k, k, generator=g) / k, dt)
     bias = torch.randn(C_, generator=g)
@@ -191,9 +192,10 @@ def test_stem(dt, in_dt):
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
-def test_sppf_pool(dt):
+@pytest.mark.parametrize("H,W", [(10, 7), (20, 20), (66, 70)])       # LDS kernel / brute-force fallback (> 64x64)
+def test_sppf_pool(dt, H, W):
     g = torch.Generator().manual_seed(4)
-    B, c_, H, W = 2, 48, 10, 7
+    B, c_ = 2, 48
     x = _q(torch.randn(B, c_, H, W, generator=g), dt)
     y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
     buf = torch.zeros(B, H, W, 4 * c_, dtype=DT[dt], device=DEV)
