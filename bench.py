@@ -88,6 +88,9 @@ def main():
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev).half()
     shift = calibrate_cls_bias(model, x, 2000, M, torch)
     conf, iou = 0.03, 0.65
+    with torch.no_grad():
+        cand = (model(x)[0][..., 5:] > conf).sum((1, 2))
+    cand_mean, cand_max = float(cand.float().mean()), int(cand.max())
 
     def step():
         with torch.no_grad():
@@ -204,6 +207,7 @@ def main():
                                       "forward + NMS(conf 0.03, iou 0.65, multi_label); synthetic seeded weights, cls bias "
                                       "calibrated (%+.2f) to ~2000 candidates/img" % (args.scale, B, shift),
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": "replicas x%d (no collective)" % world,
+                          "nms_candidates_per_image": {"mean": round(cand_mean, 1), "max": cand_max},
                           "detections_per_image_mean": round(float(np.mean([d.shape[0] for d in dets])), 1)},
                "forward_only": {"ms_per_step": round(fwd_ms, 4), "images_per_s_per_gpu": round(B / (fwd_ms * 1e-3), 1)},
                "roofline": roofline, "cpu_baseline": cpu}

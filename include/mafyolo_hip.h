@@ -123,7 +123,7 @@ void maf_engine_destroy(maf_engine_t* e);
  * (nms.py:97-98); greedy rule of torchvision.ops.nms (suppress when IoU > iou_thres, ties broken by
  * lower candidate index, the fp32 IoU compared with iou_thres in double as torchvision's CPU kernel
  * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
- * break (nms.py:101-103) is dropped.  max_det <= 2048.
+ * break (nms.py:101-103) is dropped.  max_det <= 1024.
  */
 int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc);
 int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,

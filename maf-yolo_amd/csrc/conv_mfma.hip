@@ -6,8 +6,9 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     const int CH = op->dtype == MAF_F16 ? 8 : 4, KS = op->dtype == MAF_F16 ? 32 : 16;
     MAF_REQUIRE(op->nsrc >= 1 && op->nsrc <= 4, "conv: nsrc must be 1..4");
     MAF_REQUIRE(op->B > 0 && op->H > 0 && op->W > 0 && op->Cout > 0, "conv: bad dims");
-    MAF_REQUIRE(op->Cout % 4 == 0, "conv: Cout must be a multiple of 4");
+    MAF_REQUIRE(op->Cout % 2 == 0, "conv: Cout must be even");
     MAF_REQUIRE(op->out_stride % 4 == 0 && op->out_coff % 4 == 0, "conv: out stride/coff must be multiples of 4");
+    MAF_REQUIRE(op->tile_c != 8 || op->dtype != MAF_F16 || op->out_f32 || (op->out_stride % 8 == 0 && op->out_coff % 8 == 0), "conv: 16-byte stores need out stride/coff multiples of 8");
     MAF_REQUIRE((long long)op->B * op->H * op->W < (1ll << 31), "conv: too many pixels");
     ConvArgs a = {};
     int csum = 0, ksum = 0;

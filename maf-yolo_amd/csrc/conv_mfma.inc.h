@@ -7,14 +7,17 @@
 // (common.py:940), nn.Upsample (MAF-YOLO-n.yaml:21,26), MP (common.py:667-673).
 //
 // Formulation (MI355X-first, not a cuDNN-style tiling):
-//   out^T[c, m] = sum_k W^T[c, k] * X^T[k, m]      c = output channel, m = pixel (B*H*W), k = input channel (x tap)
-// i.e. the WEIGHTS are the MFMA A operand and the ACTIVATIONS the B operand.  With NHWC storage a
-// B fragment is one 16-byte load per lane straight from global memory (8 f16 / 4 f32 consecutive
-// channels of the lane's pixel) — no LDS, no im2col — and the accumulator of lane (g, p) holds
-// 4 consecutive output channels of pixel p per channel tile.  The host packs the weight rows so
-// that the CT channel tiles of a wave interleave: lane (g, p) ends up with 4*CT *contiguous*
-// channels of its pixel, which the epilogue stores as 16-byte vectors directly from registers.
-// Weights come pre-packed in fragment order (1 KiB contiguous per wave-load, L1/L2 resident).
+//   out[m, c] = sum_k X[m, k] * W[k, c]      m = pixel (B*H*W), c = output channel, k = input channel (x tap)
+// The ACTIVATIONS are the MFMA A operand: with NHWC storage an A fragment is one 16-byte load per lane
+// straight from global memory (8 f16 / 4 f32 consecutive channels of the lane's pixel) — no LDS, no
+// im2col.  The WEIGHTS are the B operand, pre-packed on the host in fragment order (1 KiB contiguous
+// per wave-load, L1/L2 resident) with the output channels of the CT column tiles interleaved:
+// accumulator column p of tile ct is channel p*CT + ct.  Lane (g, p) therefore owns CT *consecutive*
+// channels of pixels g*4 .. g*4+3, the 16 lanes of a pixel cover 16*CT consecutive channels, and each
+// store instruction of the epilogue writes whole contiguous NHWC rows (4 pixels x 16*CT channels per
+// wave-store) straight from the accumulators — full cache lines, no LDS transpose.  (A first version
+// with weights as the A operand stored 16-byte pieces 48-64 B apart; the L2 write-request rate, not
+// HBM, bounded the wide layers.)
 //
 // Per wave: 16*PT pixels x 16*CT channels; 4 waves per workgroup split the pixel range.
 // blockIdx -> (pixel tile, channel tile) is XCD-aware: the channel tiles of one pixel tile run
@@ -231,58 +234,56 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(ast[u][ct], bst[u][pt], acc[pt][ct]);
+                    for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(bst[u][pt], ast[u][ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
             }
         }
     }
 
-    // ---- epilogue: bias + activation, 4*CT contiguous channels per lane ----
-    const int cl = n_tile * (16 * CT) + g * (4 * CT);       // first channel of this lane
-    f32x4_t bias[CT];
+    // ---- epilogue: bias + activation; lane (g, p) owns channels [cl, cl + CT) of pixels g*4 .. g*4+3 of each tile
+    const int cl = n_tile * (16 * CT) + p * CT;
+    float bias[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bias[ct] = *reinterpret_cast<const f32x4_t*>(a.bias + cl + ct * 4);
+    for (int ct = 0; ct < CT; ++ct) bias[ct] = a.bias[cl + ct];          // padded to nN*16*CT on the host
+    const int nvalid = a.Cout - cl;                                        // >= CT for every tile but the last
 
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const int m = m_base + pt * 16 + p;
-        if (m >= a.M) continue;
-        const size_t obase = (size_t)m * a.out_stride + a.out_coff + cl;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + pt * 16 + g * 4 + r;
+            if (m >= a.M) continue;
+            float v[CT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[pt][ct][r] = maf_act_rt(acc[pt][ct][r] + bias[ct][r], a.act);
-        }
-        if (OUTF32 || sizeof(T) == 4) {
-            float* o = static_cast<float*>(a.out) + obase;
+            for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[pt][ct][r] + bias[ct], a.act);
+            const size_t o = (size_t)m * a.out_stride + a.out_coff + cl;
+            if (OUTF32 || sizeof(T) == 4) {
+                float* op = static_cast<float*>(a.out) + o;
+                if (nvalid >= CT) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                if (cl + ct * 4 + 4 <= a.Cout) *reinterpret_cast<f32x4_t*>(o + ct * 4) = acc[pt][ct];
-        } else {
-            half_t* o = static_cast<half_t*>(a.out) + obase;
+                    for (int q = 0; q + 4 <= CT; q += 4) *reinterpret_cast<f32x4_t*>(op + q) = (f32x4_t){v[q], v[q + 1], v[q + 2], v[q + 3]};
+                    if (CT % 4 == 2) *reinterpret_cast<float2*>(op + CT - 2) = make_float2(v[CT - 2], v[CT - 1]);
+                } else {
 #pragma unroll
-            for (int ct = 0; ct + 1 < CT; ct += 2) {
-                half8_t v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = (half_t)acc[pt][ct][r];
-                    v[4 + r] = (half_t)acc[pt][ct + 1][r];
+                    for (int ct = 0; ct < CT; ++ct)
+                        if (ct < nvalid) op[ct] = v[ct];
                 }
-                if (cl + ct * 4 + 8 <= a.Cout) {
-                    *reinterpret_cast<half8_t*>(o + ct * 4) = v;
-                } else if (cl + ct * 4 + 4 <= a.Cout) {
-                    half4_t h;
+            } else {
+                half_t* op = static_cast<half_t*>(a.out) + o;
+                if (nvalid >= CT) {
+                    uint32_t w[CT / 2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = v[r];
-                    *reinterpret_cast<half4_t*>(o + ct * 4) = h;
-                }
-            }
-            if (CT & 1) {
-                constexpr int ct = CT - 1;
-                if (cl + ct * 4 + 4 <= a.Cout) {
-                    half4_t h;
+                    for (int q = 0; q < CT / 2; ++q) {
+                        const half2_t h = {(half_t)v[2 * q], (half_t)v[2 * q + 1]};
+                        w[q] = __builtin_bit_cast(uint32_t, h);
+                    }
+                    if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
+                    else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
+                    else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
+                    else *reinterpret_cast<uint32_t*>(op) = w[0];
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[pt][ct][r];
-                    *reinterpret_cast<half4_t*>(o + ct * 4) = h;
+                    for (int ct = 0; ct < CT; ++ct)
+                        if (ct < nvalid) op[ct] = (half_t)v[ct];
                 }
             }
         }
@@ -300,10 +301,10 @@ template <typename T, int VAR, bool OUTF32>
 int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
 #define MAF_TILE(P, C) \
     if (pt == P && ct == C) return launch_act<T, P, C, VAR, OUTF32>(a, s);
-    MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(1, 3) MAF_TILE(2, 3) MAF_TILE(1, 4) MAF_TILE(2, 4)
+    MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(1, 4) MAF_TILE(2, 4)
     MAF_TILE(1, 6) MAF_TILE(2, 6) MAF_TILE(1, 8) MAF_TILE(2, 8)
 #undef MAF_TILE
-    maf_set_error("conv: unsupported tile (tile_p in {1,2}, tile_c in {2,3,4,6,8})");
+    maf_set_error("conv: unsupported tile (tile_p in {1,2}, tile_c in {2,4,6,8})");
     return MAF_E_UNSUPPORTED;
 }
 

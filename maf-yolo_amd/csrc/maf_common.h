@@ -35,15 +35,15 @@ int maf_launch_decode(const maf_op_t* op, hipStream_t s);
 template <int ACT>
 __device__ __forceinline__ float maf_act(float x) {
     if (ACT == MAF_ACT_RELU) return x > 0.f ? x : 0.f;
-    if (ACT == MAF_ACT_SILU) return x / (1.f + __expf(-x));
-    if (ACT == MAF_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+    if (ACT == MAF_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));      // v_exp + v_rcp (1 ulp), no IEEE divide
+    if (ACT == MAF_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
     return x;
 }
 __device__ __forceinline__ float maf_act_rt(float x, int act) {
     switch (act) {
         case MAF_ACT_RELU: return x > 0.f ? x : 0.f;
-        case MAF_ACT_SILU: return x / (1.f + __expf(-x));
-        case MAF_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case MAF_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+        case MAF_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-x));
         default: return x;
     }
 }

@@ -30,7 +30,8 @@ namespace {
 constexpr int kMaxNms = 30000;       // nms.py:54
 constexpr float kMaxWh = 4096.f;     // nms.py:53
 constexpr int kLdsKeys = 8192;       // 64 KiB of 64-bit keys
-constexpr int kMaxDetCap = 2048;     // kept-list capacity in LDS (5 floats each)
+constexpr int kMaxDetCap = 1024;     // kept-list capacity in LDS (32 B each = lower half of the sort buffer)
+constexpr int kMaxBands = 1022;      // class bands of the cls*4096 offset trick handled by the band index
 
 struct NmsArgs {
     const float* pred;
@@ -179,6 +180,28 @@ __device__ void bitonic_sort(unsigned long long* k, int P, int tid, int nthreads
     }
 }
 
+// Band index over the kept list.  With the class-offset trick (nms.py:94-95) a box of class c lives around
+// x in [c*4096, (c+1)*4096): two boxes can only intersect if their x-intervals share a 4096-px band.  Every kept box
+// is linked into the list(s) of the band(s) its x-interval touches (or into one global list if it spans more than
+// two), a candidate walks only the lists of its own bands + the global list.  Exact for any input (bands are
+// clamped the same way on both sides); turns the candidate-vs-kept screening from O(kept) into O(kept of my class).
+struct BandIndex {
+    short* head;       // [nb + 1]  (last = global list)
+    short* next;       // [2 * kMaxDetCap]
+    short* box;        // [2 * kMaxDetCap]
+    int nb;
+};
+
+__device__ __forceinline__ int band_of(float v, int nb) {
+    const float f = floorf(v * (1.0f / kMaxWh)) + 1.0f;          // bands -1 .. nc  ->  0 .. nb-1
+    return !(f > 0.f) ? 0 : (f >= (float)(nb - 1) ? nb - 1 : (int)f);
+}
+
+__device__ __forceinline__ void band_range(const Cand& c, int nb, int& lo, int& hi) {
+    lo = band_of(fminf(c.x1, c.x2), nb);
+    hi = band_of(fmaxf(c.x1, c.x2), nb);
+}
+
 __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[kLdsKeys];   // reused as the kept list after the sort
     __shared__ unsigned long long alive_mask[4];
@@ -210,7 +233,13 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
     __syncthreads();
 
     const int ns = n < kMaxNms ? n : kMaxNms;                  // nms.py:90-91
-    Cand* kept = reinterpret_cast<Cand*>(lds_keys);            // LDS reuse: [max_det] x 5 floats
+    Cand* kept = reinterpret_cast<Cand*>(lds_keys);            // LDS reuse: lower 32 KiB = kept list [<= 1024] x 32 B
+    BandIndex bi;                                              //            upper 32 KiB = band index
+    bi.nb = (a.agnostic || a.nc + 2 > kMaxBands) ? 1 : a.nc + 2;
+    bi.head = reinterpret_cast<short*>(lds_keys + kLdsKeys / 2);
+    bi.next = bi.head + 1024;
+    bi.box = bi.next + 2 * kMaxDetCap;
+    for (int i = tid; i <= bi.nb; i += 256) bi.head[i] = -1;
     if (tid == 0) s_kept = 0;
     __syncthreads();
     const int no = 5 + a.nc;
@@ -238,14 +267,19 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
             c.x1 = bx1 + off; c.y1 = by1 + off; c.x2 = bx2 + off; c.y2 = by2 + off;
             c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
             c.score = score; c.flat = flat;
-            for (int k0 = 0; k0 < kept0 && alive; k0 += 8) {               // 8 kept boxes per step: LDS reads overlap
-                bool hit = false;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const Cand kk = kept[min(k0 + u, kept0 - 1)];
-                    hit |= iou_gt(kk, c, a.iou);
+            int lo, hi;
+            band_range(c, bi.nb, lo, hi);
+            if (hi - lo > 1) {                                             // pathological span: scan the whole list
+                for (int k = 0; k < kept0 && alive; ++k)
+                    if (iou_gt(kept[k], c, a.iou)) alive = false;
+            } else {
+                for (int pass = 0; pass < 3 && alive; ++pass) {            // my band(s), then the global list
+                    const int bnd = pass == 0 ? lo : pass == 1 ? hi : bi.nb;
+                    if (pass == 1 && hi == lo) continue;
+                    int guard = 2 * kMaxDetCap;                            // a list can never be longer than the node pool
+                    for (int nd = bi.head[bnd]; nd >= 0 && alive && guard-- > 0; nd = bi.next[nd])
+                        if (iou_gt(kept[bi.box[nd]], c, a.iou)) alive = false;
                 }
-                if (hit) alive = false;
             }
         }
         const unsigned long long m = __ballot(alive);
@@ -267,6 +301,17 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
                     ki.area = __shfl(c.area, i);
                     if (lane == i) {
                         kept[nk] = c;                                     // rows are written after the loop, from the list
+                        int lo, hi;
+                        band_range(c, bi.nb, lo, hi);
+                        // Lanes take turns here and hand the list heads to each other through LDS inside one wave:
+                        // that is a cross-thread hand-off without a barrier, so the accesses must be volatile (the
+                        // compiler may otherwise keep a lane-private copy; a stale node counter made a self-loop).
+                        // Node ids are derived from nk (2 per kept box), not from a shared counter.
+                        volatile short* vhead = bi.head;
+                        if (hi - lo > 1) { lo = hi = bi.nb; }            // spans > 2 bands: global list
+                        const int n0 = 2 * nk;
+                        bi.box[n0] = (short)nk; bi.next[n0] = vhead[lo]; vhead[lo] = (short)n0;
+                        if (hi != lo) { bi.box[n0 + 1] = (short)nk; bi.next[n0 + 1] = vhead[hi]; vhead[hi] = (short)(n0 + 1); }
                         alive = false;
                     }
                     ++nk;
@@ -317,7 +362,7 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     MAF_REQUIRE((long long)N * nc < (1ll << 32), "nms: N*nc must fit 32 bits");
     MAF_REQUIRE(conf_thres >= 0.0 && conf_thres <= 1.0, "nms: conf_thres must be in [0,1] (nms.py:50)");
     MAF_REQUIRE(iou_thres >= 0.0 && iou_thres <= 1.0, "nms: iou_thres must be in [0,1] (nms.py:51)");
-    MAF_REQUIRE(max_det > 0 && max_det <= kMaxDetCap, "nms: max_det must be in 1..2048");
+    MAF_REQUIRE(max_det > 0 && max_det <= kMaxDetCap, "nms: max_det must be in 1..1024");
     MAF_REQUIRE(workspace_bytes >= maf_nms_workspace_bytes(B, N, nc), "nms: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     NmsArgs a;

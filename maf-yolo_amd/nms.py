@@ -7,7 +7,7 @@ prediction.device, `zeros((0,6))`-shaped for empty images), same AssertionError 
 
 Differences, all documented in DESIGN.md: decode/NMS arithmetic is fp32 even for fp16 predictions
 (the reference's fp16 `cls*4096` overflows for cls >= 16); the 10 s time limit
-(nms.py:101-103) is dropped; max_det <= 2048.
+(nms.py:101-103) is dropped; max_det <= 1024.
 """
 import torch
 

@@ -1,16 +1,17 @@
 """Host-side weight packing for the HIP kernels (done once per plan, fp32 algebra then one cast).
 
-conv_mfma (csrc/conv_mfma.inc.h) takes the weights as the MFMA *A* operand in fragment order:
+conv_mfma (csrc/conv_mfma.inc.h) takes the weights as the MFMA *B* operand in fragment order:
 
-    packed[tile][step][lane = g*16 + i][j]      tile = n_tile*CT + ct,  g = lane >> 4, i = lane & 15
-      f16: j < 8,  k = step*32 + g*8 + j        (v_mfma_f32_16x16x32_f16: lane holds A[i][8 consecutive k])
+    packed[tile][step][lane = g*16 + p][j]      tile = n_tile*CT + ct,  g = lane >> 4, p = lane & 15
+      f16: j < 8,  k = step*32 + g*8 + j        (v_mfma_f32_16x16x32_f16: lane holds B[8 consecutive k][col p])
       f32: j < 4,  k = step*16 + g*4 + j        (4 x v_mfma_f32_16x16x4_f32, MFMA j takes component j)
-    output channel of MFMA row i of channel tile ct:   n_tile*16*CT + (i>>2)*4*CT + ct*4 + (i&3)
+    output channel of MFMA column p of channel tile ct:   n_tile*16*CT + p*CT + ct
 
-The row interleave makes lane (g, p) of the accumulator own 4*CT *contiguous* channels of pixel p, so
-the epilogue stores 16-byte vectors without any LDS transpose.  K is the concatenation of the
-sources' channels (torch.cat order), each source zero-padded to whole k-steps; for 3x3 convs the
-steps run tap-major (ky, kx), each tap zero-padded to whole k-steps.
+The column interleave makes the accumulator lane (g, p) own CT *consecutive* channels of 4 pixels and
+the 16 lanes of a pixel cover 16*CT consecutive channels, so every store instruction of the epilogue
+writes whole contiguous NHWC rows without an LDS transpose.  K is the concatenation of the sources'
+channels (torch.cat order), each source zero-padded to whole k-steps; for 3x3 convs the steps run
+tap-major (ky, kx), each tap zero-padded to whole k-steps.
 """
 import torch
 
@@ -20,7 +21,7 @@ from . import lib
 def tile_for(cout, m_pixels):
     """(tile_p, tile_c): least channel padding, then fewest channel tiles; 2 pixel tiles/wave when the grid stays big."""
     best = None
-    for ct in (8, 6, 4, 3, 2):
+    for ct in (8, 6, 4, 2):
         n_tiles = -(-cout // (16 * ct))
         padded = n_tiles * 16 * ct
         key = (padded, n_tiles)
@@ -50,9 +51,9 @@ def pack_matrix(w2d_segments, ct, dtype):
         cols.append(blk)
     wp = torch.cat(cols, 1)                                   # [Npad, S*KS]
     S = wp.shape[1] // ks
-    # channel = n_tile*16CT + gi*4CT + ct*4 + r ; k = step*KS + g*CH + j
-    wp = wp.reshape(n_tiles, 4, ct, 4, S, 4, ch)              # [nt, gi, ct, r, S, g, j]
-    wp = wp.permute(0, 2, 4, 5, 1, 3, 6).contiguous()         # [nt, ct, S, g, gi, r, j]
+    # channel = n_tile*16CT + p*CT + ct ; k = step*KS + g*CH + j
+    wp = wp.reshape(n_tiles, 16, ct, S, 4, ch)                # [nt, p, ct, S, g, j]
+    wp = wp.permute(0, 2, 3, 4, 1, 5).contiguous()            # [nt, ct, S, g, p, j]
     wp = wp.reshape(n_tiles * ct, S, 64, ch)
     return wp.to(torch.float16 if dtype == lib.F16 else torch.float32).contiguous()
 

@@ -73,4 +73,18 @@ def cases():
     b = base[rs.randint(0, 40, n)] + rs.randn(n, 4).astype(np.float32) * 5.0
     out["single_class"] = (np.concatenate([b, rs.rand(n, 1).astype(np.float32), rs.rand(n, 1).astype(np.float32)], 1)[None].astype(np.float32),
                            dict(conf_thres=0.2, iou_thres=0.5, multi_label=True))
+
+    # 8. boxes that leave their 4096-px class band: huge widths, negative corners, far-away centres
+    #    (cross-class overlaps through the offset trick, nms.py:94-95) + a few degenerate (w <= 0) boxes
+    n = 300
+    b = _boxes(rs, n)
+    b[:60, 2] = 3000.0 + rs.rand(60).astype(np.float32) * 9000.0          # very wide: spans 2-4 bands
+    b[60:90, 0] = -2000.0 + rs.rand(30).astype(np.float32) * 1000.0        # far left of the image
+    b[90:120, 0] = 4000.0 + rs.rand(30).astype(np.float32) * 400.0         # straddles the next class band
+    b[120:130, 2] = -5.0                                                   # negative width
+    cls = np.zeros((n, nc), np.float32)
+    cls[np.arange(n), rs.randint(0, 6, n)] = (0.3 + 0.7 * rs.rand(n)).astype(np.float32)
+    cls[np.arange(n), rs.randint(0, 6, n)] = (0.3 + 0.7 * rs.rand(n)).astype(np.float32)
+    out["cross_band"] = (np.concatenate([b, np.ones((n, 1), np.float32), cls], 1)[None],
+                         dict(conf_thres=0.25, iou_thres=0.3, multi_label=True))
     return out

@@ -58,7 +58,7 @@ def _conv_op(kind, dt, B, H, W, cin, cout, act, srcs, out, out_stride, out_coff,
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
-@pytest.mark.parametrize("cin,cout,pt,ct,act", [(48, 48, 2, 3, lib.ACT_SILU), (72, 24, 1, 2, lib.ACT_SILU), (24, 72, 2, 6, lib.ACT_NONE),
+@pytest.mark.parametrize("cin,cout,pt,ct,act", [(48, 48, 2, 4, lib.ACT_SILU), (72, 24, 1, 2, lib.ACT_SILU), (24, 72, 2, 6, lib.ACT_NONE),
                                                 (192, 128, 1, 8, lib.ACT_SILU), (128, 80, 2, 6, lib.ACT_SIGMOID), (64, 64, 1, 4, lib.ACT_RELU),
                                                 (128, 68, 1, 6, lib.ACT_NONE), (40, 200, 2, 4, lib.ACT_SILU)])
 def test_conv1x1_direct(dt, cin, cout, pt, ct, act):
@@ -123,12 +123,12 @@ def test_conv1x1_maxpool_source(dt):
     ref = F.silu(F.conv2d(F.max_pool2d(x, 2, 2), w, bias))
     out = torch.zeros(B, H, W, cout, dtype=DT[dt], device=DEV)
     _launch(_conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, [(_nhwc(x, dt), cin, cin, 0, lib.SRC_POOL2)], out, cout, 0,
-                     pack.pack_conv1x1(w, [cin], 3, dt).to(DEV), pack.pack_bias(bias, 3).to(DEV), 1, 3))
+                     pack.pack_conv1x1(w, [cin], 4, dt).to(DEV), pack.pack_bias(bias, 4).to(DEV), 1, 4))
     _check(out, ref, dt)
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
-@pytest.mark.parametrize("cin,cout,pt,ct,act", [(24, 48, 2, 3, lib.ACT_RELU), (48, 64, 1, 4, lib.ACT_SILU), (128, 128, 1, 8, lib.ACT_SILU)])
+@pytest.mark.parametrize("cin,cout,pt,ct,act", [(24, 48, 2, 4, lib.ACT_RELU), (48, 64, 1, 4, lib.ACT_SILU), (128, 128, 1, 8, lib.ACT_SILU), (96, 96, 2, 6, lib.ACT_RELU)])
 def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
     g = torch.Generator().manual_seed(cin + cout)
     B, Hin, Win = 2, 12, 20

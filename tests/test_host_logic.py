@@ -124,16 +124,16 @@ def test_cpu_input_fails_loudly():
 
 def test_pack_layout():
     # packed[tile][step][lane][j] == W[chan(tile,lane)][k(step,lane,j)]
-    cout, cin, ct = 72, 48, 3
+    cout, cin, ct = 72, 48, 4
     w = torch.arange(cout * cin, dtype=torch.float32).reshape(cout, cin, 1, 1)
     for dt, ks, ch in ((lib.F16, 32, 8), (lib.F32, 16, 4)):
         p = pack.pack_conv1x1(w, [24, 24], ct, dt).float()
         steps = 2 * -(-24 // ks)
         assert p.shape == (2 * ct, steps, 64, ch)
-        for tile, step, lane, j in ((0, 0, 0, 0), (1, 1, 17, 3), (4, steps - 1, 63, ch - 1), (5, 0, 37, 1)):
+        for tile, step, lane, j in ((0, 0, 0, 0), (1, 1, 17, 3), (4, steps - 1, 63, ch - 1), (7, 0, 37, 1)):
             nt, c_t = divmod(tile, ct)
             g, i = lane >> 4, lane & 15
-            chan = nt * 16 * ct + (i >> 2) * 4 * ct + c_t * 4 + (i & 3)
+            chan = nt * 16 * ct + i * ct + c_t
             spp = -(-24 // ks)                       # steps per source
             src, ls = divmod(step, spp)
             kk = ls * ks + g * ch + j

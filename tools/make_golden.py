@@ -49,7 +49,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_import.load(O.greedy_nms_torch)
 
-    for scale in ("n", "s", "m"):
+    for scale in (() if "--nms-only" in sys.argv else ("n", "s", "m")):
         model = ref_import.build(ns, scale)
         ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
         spec = O.state_spec(scale)

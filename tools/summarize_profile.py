@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 `--kernel-trace --stats --output-format csv` directory into a tracked summary under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof5 r5 profiles/round1 [bench.json]
+
+Copies <prefix>_kernel_stats.csv and writes <out>_kernel_stats.md (top kernels, per-forward time)."""
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+
+_T = {"DF16_": "_Float16", "f": "float", "h": "unsigned char"}
+
+
+def demangle(n):
+    """c++filt does not know the _Float16 mangling (DF16_), so the few kernel templates of this library are decoded here."""
+    import re
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+conv_mfma_kernelI(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])EEEv", n)
+    if m:
+        return "conv_mfma_kernel<%s, %s, %s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3), m.group(4), "true" if m.group(5) == "1" else "false")
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+dwconv_tile_kernelI(DF16_|f)Li(\d+)ELi(\d+)EEEv", n)
+    if m:
+        return "dwconv_tile_kernel<%s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3))
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+stem_kernelI(DF16_|f|h)(DF16_|f)EEv", n)
+    if m:
+        return "stem_kernel<%s, %s>" % (_T[m.group(1)], _T[m.group(2)])
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+(sppf_pool\w*_kernel)I(DF16_|f)", n)
+    if m:
+        return "%s<%s>" % (m.group(1), _T[m.group(2)])
+    return n
+
+
+def main():
+    d, prefix, out = sys.argv[1:4]
+    src = os.path.join(d, prefix + "_kernel_stats.csv")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    shutil.copy(src, out + "_kernel_stats.csv")
+    rows = list(csv.DictReader(open(src)))
+    lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % os.path.basename(out), "",
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline`", ""]
+    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        try:
+            j = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])
+            lines += ["bench line of the same command: value = %s %s, forward only = %s ms/step, roofline kernel = `%s` avg %s ms" %
+                      (j["value"], j["unit"], j["forward_only"]["ms_per_step"], j["roofline"]["kernel"], j["roofline"]["avg_launch_ms"]), ""]
+        except Exception as e:
+            lines += ["(bench line not parsed: %s)" % e, ""]
+    lines += ["| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+    for r in rows[:45]:
+        name = demangle(r["Name"]).replace("(anonymous namespace)::", "").replace("void ", "")
+        if len(name) > 110:
+            name = name[:107] + "..."
+        lines.append("| `%s` | %s | %.2f | %.2f | %s |" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    open(out + "_kernel_stats.md", "w").write("\n".join(lines) + "\n")
+    print("wrote", out + "_kernel_stats.md")
+
+
+if __name__ == "__main__":
+    main()
