@@ -131,6 +131,10 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
             int32_t max_det, void* workspace, int64_t workspace_bytes,
             float* out_rows, int64_t* out_idx, int32_t* out_count, maf_stream_t stream);
 
+/* Diagnostics: shader-clock cycle stamps of image 0 of the last maf_nms call (synchronises the device):
+ * [0] sort, [1] kept-list screening, [2] wave resolution, [3] total, [4] candidates, [5] survivors. */
+int maf_nms_debug(uint64_t* host8);
+
 /* HIP-event timing helper used by bench.py (events recorded on `stream`, not torch's). */
 int maf_timer_create(void** timer);
 int maf_timer_start(void* timer, maf_stream_t stream);

@@ -12,18 +12,15 @@
 //   candidate is a 64-bit key  (~score_bits << 32) | (box*nc + cls): ascending key order ==
 //   descending fp32 score, ties broken by the lower row-major (box, class) index — the order
 //   `nonzero` (nms.py:76) + a stable descending sort produce.
-// Launch 2  nms_select:   one workgroup per image.  Bitonic sort of the keys (in LDS up to 8192
-//   keys, in global memory above that), top max_nms = 30000, then greedy NMS in score order with an
-//   early exit at max_det kept boxes: 256 candidates at a time are screened against the kept list
-//   (LDS) in parallel, then one wavefront resolves the chunk 64 candidates at a time with ballots —
-//   "who is the next survivor" is a find-first-set on the wave's alive mask, so the serial part is
-//   bounded by max_det + #chunks iterations, not by the candidate count.
+// Launch 2  nms_select:   one workgroup per image; see the kernel comment (per-class fast path, generic path).
 //
 // Arithmetic is kept bit-faithful to the reference's fp32 path: boxes are cx -/+ w/2 in fp32, the
 // class offset is cls*4096 added in fp32 BEFORE the IoU, IoU = inter / (area_i + area_j - inter) with
 // IEEE division and no FMA contraction (this file is compiled with -ffp-contract=off), and the
 // quotient is compared with the threshold in double as torchvision's CPU kernel does.
 #include "maf_common.h"
+#include <cmath>
+#include <cstring>
 
 namespace {
 
@@ -31,13 +28,13 @@ constexpr int kMaxNms = 30000;       // nms.py:54
 constexpr float kMaxWh = 4096.f;     // nms.py:53
 constexpr int kLdsKeys = 8192;       // 64 KiB of 64-bit keys
 constexpr int kMaxDetCap = 1024;     // kept-list capacity in LDS (32 B each = lower half of the sort buffer)
-constexpr int kMaxBands = 1022;      // class bands of the cls*4096 offset trick handled by the band index
 
 struct NmsArgs {
     const float* pred;
     int B, N, nc;
     float conf;
     double iou;
+    double iou_m; int iou_even;   // division-free exact form of `fl(inter/union) > iou` (see iou_gt)
     const int* classes; int n_classes;
     int agnostic, multi_label, max_det;
     int* cnt;                 // [B]
@@ -152,17 +149,26 @@ __global__ __launch_bounds__(256) void nms_collect_best_kernel(const NmsArgs a) 
 
 struct alignas(16) Cand { float x1, y1, x2, y2, area, score; unsigned int flat, pad; };   // 32 B: two ds_read_b128
 
-__device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, double thr) {
+// Exact `fl32(inter / uni) > thr` without the IEEE division (~40 dependent instructions, the dominant cost of the
+// same-class tests).  Let tf be the smallest fp32 above thr, p its predecessor, m = (tf + p) / 2.  The rounded quotient
+// is >= tf  <=>  inter/uni > m, or == m with tf the even neighbour.  m has <= 25 significant bits and uni 24, so
+// m * uni is exact in double: the comparison below involves no rounding at all.
+struct IouThr { double thr, m; int even; };
+
+__device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, const IouThr& t) {
     // torchvision nms CPU kernel: i = kept (earlier), j = candidate
     const float xx1 = fmaxf(k.x1, c.x1), yy1 = fmaxf(k.y1, c.y1);
     const float xx2 = fminf(k.x2, c.x2), yy2 = fminf(k.y2, c.y2);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-    // disjoint boxes: inter = 0 (or NaN) => ovr is 0, -0 or NaN => never > thr (thr >= 0). Skips the IEEE division
-    // for the vast majority of pairs (different classes sit 4096 px apart).
+    // disjoint boxes: inter = 0 (or NaN) => ovr is 0, -0 or NaN => never > thr (thr >= 0)
     if (!(w > 0.f) || !(h > 0.f)) return false;
     const float inter = w * h;
-    const float ovr = inter / (k.area + c.area - inter);
-    return (double)ovr > thr;
+    const float uni = k.area + c.area - inter;
+    if (uni > 0.f && uni < INFINITY && inter < INFINITY) {
+        const double pm = t.m * (double)uni, di = (double)inter;
+        return di > pm || (di == pm && t.even);
+    }
+    return (double)(inter / uni) > t.thr;                   // zero / negative / non-finite union: the literal formula
 }
 
 __device__ void bitonic_sort(unsigned long long* k, int P, int tid, int nthreads) {
@@ -180,35 +186,45 @@ __device__ void bitonic_sort(unsigned long long* k, int P, int tid, int nthreads
     }
 }
 
-// Band index over the kept list.  With the class-offset trick (nms.py:94-95) a box of class c lives around
-// x in [c*4096, (c+1)*4096): two boxes can only intersect if their x-intervals share a 4096-px band.  Every kept box
-// is linked into the list(s) of the band(s) its x-interval touches (or into one global list if it spans more than
-// two), a candidate walks only the lists of its own bands + the global list.  Exact for any input (bands are
-// clamped the same way on both sides); turns the candidate-vs-kept screening from O(kept) into O(kept of my class).
-struct BandIndex {
-    short* head;       // [nb + 1]  (last = global list)
-    short* next;       // [2 * kMaxDetCap]
-    short* box;        // [2 * kMaxDetCap]
-    int nb;
-};
-
-__device__ __forceinline__ int band_of(float v, int nb) {
-    const float f = floorf(v * (1.0f / kMaxWh)) + 1.0f;          // bands -1 .. nc  ->  0 .. nb-1
-    return !(f > 0.f) ? 0 : (f >= (float)(nb - 1) ? nb - 1 : (int)f);
+__device__ __forceinline__ void make_cand(const NmsArgs& a, const float* pred, int no, unsigned int box, int cls, Cand& c) {
+    const float* r = pred + (size_t)box * no;
+    const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+    const float bx1 = cx - w / 2, by1 = cy - h / 2, bx2 = cx + w / 2, by2 = cy + h / 2;   // nms.py:21-28
+    const float off = a.agnostic ? 0.f : (float)cls * kMaxWh;                             // nms.py:94
+    c.x1 = bx1 + off; c.y1 = by1 + off; c.x2 = bx2 + off; c.y2 = by2 + off;
+    c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
 }
 
-__device__ __forceinline__ void band_range(const Cand& c, int nb, int& lo, int& hi) {
-    lo = band_of(fminf(c.x1, c.x2), nb);
-    hi = band_of(fmaxf(c.x1, c.x2), nb);
-}
+constexpr int kSelT = 256;
+__device__ unsigned long long g_nms_dbg[8];   // phase cycle stamps of image 0 (diagnostics: maf_nms_debug)
 
-__global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[kLdsKeys];   // reused as the kept list after the sort
-    __shared__ unsigned long long alive_mask[4];
-    __shared__ int s_kept;
+// One workgroup per image.
+//   1. bitonic sort of the 64-bit keys (LDS up to 8192 keys, global memory above), top max_nms = 30000;
+//   2. greedy NMS in score order with an early exit at max_det survivors.  Survivors live in LDS (`kept`) and are linked
+//      into per-class lists (`head`/`next`, newest first).  256 candidates at a time walk the list of their class in
+//      parallel (phase A); then one wavefront at a time resolves its 64 candidates (phase B):
+//        - walk only the list entries created since phase A,
+//        - lanes of equal class find each other with a ballot-built match mask, each lane tests the IoU against the
+//          earlier alive lanes of its class and records them as a 64-bit "suppressed-by" set,
+//        - a scalar scan in lane order decides survivors: lane j survives iff none of its suppressors survived,
+//        - survivors append themselves to `kept` and to their class list in parallel.
+// Per-class lists are exact only if boxes of different classes cannot intersect.  With the class-offset trick
+// (nms.py:94-95) a box of class c sits at x + c*4096, so that holds whenever the x-extent of ALL candidates of the image
+// is <= 4095 px (also under the fp32 rounding of the offset add, which is monotone).  One reduction per image decides;
+// otherwise (or agnostic, or nc > 1024) every box goes to ONE list and every pair is tested, as torchvision does.
+__global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[kLdsKeys];   // sort buffer, then: kept list (lower half)
+    // after the sort the upper half of the buffer holds: the chunk's candidates (cross-lane reads), list heads, list links
+    Cand* wbox = reinterpret_cast<Cand*>(lds_keys + kLdsKeys / 2);                    // [256] x 32 B
+    int* head = reinterpret_cast<int*>(wbox + kSelT);                                 // [1024]
+    short* nxt = reinterpret_cast<short*>(head + 1024);                               // [kMaxDetCap]
+    int* cstart = reinterpret_cast<int*>(nxt + kMaxDetCap);                           // [1025] class-sorted view of the kept list:
+    int* cfill = cstart + 1028;                                                       // [1024]   start offsets / fill cursors
+    short* order = reinterpret_cast<short*>(cfill + 1024);                            // [kMaxDetCap] kept slots grouped by class
+    __shared__ int s_kept, s_wide;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
-    const long long cap = a.multi_label ? (long long)a.N * a.nc : (long long)a.N;
+    const long long cap = (long long)a.N * a.nc;
     long long n64 = a.cnt[b * kCntStride];
     if (n64 > cap) n64 = cap;
     const int n = (int)n64;
@@ -218,115 +234,163 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const NmsArgs a) {
         if (tid == 0) a.out_count[b] = 0;
         return;
     }
-    int P = 1;
-    while (P < n) P <<= 1;
-    if (P <= kLdsKeys) {
-        for (int i = tid; i < P; i += 256) lds_keys[i] = i < n ? keys[i] : ~0ull;
-        __syncthreads();
-        bitonic_sort(lds_keys, P, tid, 256);
-        for (int i = tid; i < n; i += 256) keys[i] = lds_keys[i];
-    } else {
-        for (int i = n + tid; i < P; i += 256) keys[i] = ~0ull;
-        __syncthreads();
-        bitonic_sort(keys, P, tid, 256);
-    }
-    __syncthreads();
-
-    const int ns = n < kMaxNms ? n : kMaxNms;                  // nms.py:90-91
-    Cand* kept = reinterpret_cast<Cand*>(lds_keys);            // LDS reuse: lower 32 KiB = kept list [<= 1024] x 32 B
-    BandIndex bi;                                              //            upper 32 KiB = band index
-    bi.nb = (a.agnostic || a.nc + 2 > kMaxBands) ? 1 : a.nc + 2;
-    bi.head = reinterpret_cast<short*>(lds_keys + kLdsKeys / 2);
-    bi.next = bi.head + 1024;
-    bi.box = bi.next + 2 * kMaxDetCap;
-    for (int i = tid; i <= bi.nb; i += 256) bi.head[i] = -1;
-    if (tid == 0) s_kept = 0;
-    __syncthreads();
     const int no = 5 + a.nc;
     const float* pred = a.pred + (size_t)b * a.N * no;
+    int P = 1;
+    while (P < n) P <<= 1;
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    unsigned long long t_a = 0, t_b = 0, t_ld = 0, t0 = __builtin_readcyclecounter();
 
-    for (int base = 0; base < ns; base += 256) {
+    // ---- can classes interact in this image?  (x-extent of all candidates)
+    if (tid == 0) s_wide = (a.agnostic || a.nc > 1024) ? 1 : 0;
+    __syncthreads();
+    if (!a.agnostic && a.nc <= 1024) {
+        float lo = INFINITY, hi = -INFINITY;
+        bool bad = false;
+        for (int i = tid; i < n; i += kSelT) {
+            const unsigned int flat = (unsigned int)(keys[i] & 0xffffffffu);
+            const float* r = pred + (size_t)(flat / (unsigned int)a.nc) * no;
+            const float x1 = r[0] - r[2] / 2, x2 = r[0] + r[2] / 2;
+            if (!(x1 == x1) || !(x2 == x2)) bad = true;
+            lo = fminf(lo, fminf(x1, x2)); hi = fmaxf(hi, fmaxf(x1, x2));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if (lane == 0 && (bad || !((double)hi - (double)lo <= 4095.0))) s_wide = 1;
+    }
+
+    if (P <= kLdsKeys) {
+        for (int i = tid; i < P; i += kSelT) lds_keys[i] = i < n ? keys[i] : ~0ull;
+        __syncthreads();
+        bitonic_sort(lds_keys, P, tid, kSelT);
+        for (int i = tid; i < n; i += kSelT) keys[i] = lds_keys[i];
+    } else {
+        for (int i = n + tid; i < P; i += kSelT) keys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort(keys, P, tid, kSelT);
+    }
+    __syncthreads();
+    const bool by_class = s_wide == 0;                         // uniform
+    const unsigned long long t_sorted = __builtin_readcyclecounter();
+
+    const int ns = n < kMaxNms ? n : kMaxNms;                  // nms.py:90-91
+    Cand* kept = reinterpret_cast<Cand*>(lds_keys);            // LDS reuse: kept list [<= 1024] x 32 B
+    if (tid == 0) s_kept = 0;
+    for (int i = tid; i < 1024; i += kSelT) head[i] = -1;
+    __syncthreads();
+
+    for (int base = 0; base < ns; base += kSelT) {
         const int kept0 = s_kept;
         if (kept0 >= a.max_det) break;
-        // ---- phase A: all 256 lanes screen their candidate against the kept list ----
-        const int ci = base + tid;
-        Cand c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-        unsigned long long key = 0;
-        bool alive = ci < ns;
-        float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f, score = 0.f; int cls = 0; unsigned int flat = 0;
-        if (alive) {
-            key = keys[ci];
-            flat = (unsigned int)(key & 0xffffffffu);
-            score = __uint_as_float(~(unsigned int)(key >> 32));
-            const unsigned int box = flat / (unsigned int)a.nc;
-            cls = (int)(flat - box * (unsigned int)a.nc);
-            const float* r = pred + (size_t)box * no;
-            const float cx = r[0], cy = r[1], w = r[2], h = r[3];
-            bx1 = cx - w / 2; by1 = cy - h / 2; bx2 = cx + w / 2; by2 = cy + h / 2;   // nms.py:21-28
-            const float off = a.agnostic ? 0.f : (float)cls * kMaxWh;                 // nms.py:94
-            c.x1 = bx1 + off; c.y1 = by1 + off; c.x2 = bx2 + off; c.y2 = by2 + off;
-            c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
-            c.score = score; c.flat = flat;
-            int lo, hi;
-            band_range(c, bi.nb, lo, hi);
-            if (hi - lo > 1) {                                             // pathological span: scan the whole list
-                for (int k = 0; k < kept0 && alive; ++k)
-                    if (iou_gt(kept[k], c, a.iou)) alive = false;
-            } else {
-                for (int pass = 0; pass < 3 && alive; ++pass) {            // my band(s), then the global list
-                    const int bnd = pass == 0 ? lo : pass == 1 ? hi : bi.nb;
-                    if (pass == 1 && hi == lo) continue;
-                    int guard = 2 * kMaxDetCap;                            // a list can never be longer than the node pool
-                    for (int nd = bi.head[bnd]; nd >= 0 && alive && guard-- > 0; nd = bi.next[nd])
-                        if (iou_gt(kept[bi.box[nd]], c, a.iou)) alive = false;
-                }
+        const unsigned long long ta0 = __builtin_readcyclecounter();
+        // ---- group the survivors so far by class (counting sort: contiguous ranges instead of pointer chasing) ----
+        const int nlists = by_class ? a.nc : 1;
+        for (int i = tid; i <= nlists; i += kSelT) { cstart[i] = 0; if (i < nlists) cfill[i] = 0; }
+        __syncthreads();
+        for (int k = tid; k < kept0; k += kSelT) atomicAdd(&cstart[kept[k].pad + 1], 1);
+        __syncthreads();
+        if (wave == 0) {                                       // inclusive scan of the (<= 1024) class counts by one wavefront
+            int carry = 0;
+            for (int i0 = 0; i0 < nlists; i0 += 64) {
+                const int i = i0 + lane;
+                int v = i < nlists ? cstart[i + 1] : 0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
+                if (i < nlists) cstart[i + 1] = v + carry;
+                carry += __shfl(v, 63);
             }
         }
-        const unsigned long long m = __ballot(alive);
-        if (lane == 0) alive_mask[wave] = m;
         __syncthreads();
-        // ---- phase B: resolve the chunk in score order, one wavefront of 64 candidates at a time.
-        // Every wave runs its own sub-chunk in turn so each lane keeps its candidate in registers.
-        for (int sub = 0; sub < 4; ++sub) {
+        for (int k = tid; k < kept0; k += kSelT) {
+            const int cl = (int)kept[k].pad;
+            order[cstart[cl] + atomicAdd(&cfill[cl], 1)] = (short)k;
+        }
+        __syncthreads();
+        // ---- phase A: every lane scans the survivors of its class ----
+        const int ci = base + tid;
+        Cand c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        bool alive = ci < ns;
+        int lst = 0;                                           // list this candidate belongs to
+        if (alive) {
+            const unsigned long long key = keys[ci];
+            const unsigned int flat = (unsigned int)(key & 0xffffffffu);
+            const unsigned int box = flat / (unsigned int)a.nc;
+            const int cls = (int)(flat - box * (unsigned int)a.nc);
+            make_cand(a, pred, no, box, cls, c);
+            c.score = __uint_as_float(~(unsigned int)(key >> 32)); c.flat = flat;
+            lst = by_class ? cls : 0;
+            c.pad = (unsigned int)lst;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_ld += __builtin_readcyclecounter() - ta0;
+            const int p1 = cstart[lst + 1];
+            for (int p = cstart[lst]; p < p1 && alive; p += 4) {           // 4 independent LDS gathers per step
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hit |= iou_gt(kept[order[min(p + u, p1 - 1)]], c, iouthr);
+                if (hit) alive = false;
+            }
+        }
+        wbox[tid] = c;
+        __syncthreads();
+        const unsigned long long tb0 = __builtin_readcyclecounter();
+        t_a += tb0 - ta0;
+        // ---- phase B: one wavefront of 64 candidates at a time, in score order
+        for (int sub = 0; sub < kSelT / 64; ++sub) {
             if (wave == sub) {
                 int nk = s_kept;
-                // survivors kept by earlier sub-chunks of this chunk
-                for (int k = kept0; k < nk && alive; ++k)
-                    if (iou_gt(kept[k], c, a.iou)) alive = false;
-                unsigned long long mask = __ballot(alive);
-                while (mask != 0 && nk < a.max_det) {
-                    const int i = __ffsll((long long)mask) - 1;           // next survivor in score order
-                    Cand ki;
-                    ki.x1 = __shfl(c.x1, i); ki.y1 = __shfl(c.y1, i); ki.x2 = __shfl(c.x2, i); ki.y2 = __shfl(c.y2, i);
-                    ki.area = __shfl(c.area, i);
-                    if (lane == i) {
-                        kept[nk] = c;                                     // rows are written after the loop, from the list
-                        int lo, hi;
-                        band_range(c, bi.nb, lo, hi);
-                        // Lanes take turns here and hand the list heads to each other through LDS inside one wave:
-                        // that is a cross-thread hand-off without a barrier, so the accesses must be volatile (the
-                        // compiler may otherwise keep a lane-private copy; a stale node counter made a self-loop).
-                        // Node ids are derived from nk (2 per kept box), not from a shared counter.
-                        volatile short* vhead = bi.head;
-                        if (hi - lo > 1) { lo = hi = bi.nb; }            // spans > 2 bands: global list
-                        const int n0 = 2 * nk;
-                        bi.box[n0] = (short)nk; bi.next[n0] = vhead[lo]; vhead[lo] = (short)n0;
-                        if (hi != lo) { bi.box[n0 + 1] = (short)nk; bi.next[n0 + 1] = vhead[hi]; vhead[hi] = (short)(n0 + 1); }
-                        alive = false;
+                if (alive)                                     // survivors added since phase A (lists are newest-first)
+                    for (int k = head[lst]; k >= kept0 && alive; k = nxt[k])
+                        if (iou_gt(kept[k], c, iouthr)) alive = false;
+                // lanes of my list (ballot-built match mask), earlier and still alive
+                unsigned long long same = ~0ull;
+                if (by_class) {
+#pragma unroll
+                    for (int bit = 0; bit < 10; ++bit) {
+                        const unsigned long long m = __ballot((lst >> bit) & 1);
+                        same &= ((lst >> bit) & 1) ? m : ~m;
                     }
-                    ++nk;
-                    if (alive && lane > i && iou_gt(ki, c, a.iou)) alive = false;
-                    mask = __ballot(alive) & ~((2ull << i) - 1ull);       // only later candidates remain
-                    // (earlier lanes are already kept or suppressed)
                 }
+                const unsigned long long amask = __ballot(alive);
+                unsigned long long cand_sup = alive ? (same & amask & ((1ull << lane) - 1ull)) : 0ull;
+                unsigned long long sup = 0;                    // earlier alive lanes of my class that overlap me
+                const Cand* wb = wbox + sub * 64;
+                while (cand_sup) {
+                    const int i = __ffsll((long long)cand_sup) - 1;
+                    cand_sup &= cand_sup - 1;
+                    if (iou_gt(wb[i], c, iouthr)) sup |= 1ull << i;
+                }
+                // scalar scan in score order: lane j survives iff it is alive and none of its suppressors survived
+                const unsigned int sup_lo = (unsigned int)sup, sup_hi = (unsigned int)(sup >> 32);
+                unsigned long long keep = 0, todo = amask;
+                int room = a.max_det - nk;
+                while (todo != 0 && room > 0) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const unsigned long long sj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)sup_hi, j) << 32) |
+                                                  (unsigned int)__builtin_amdgcn_readlane((int)sup_lo, j);
+                    if ((sj & keep) == 0) { keep |= 1ull << j; --room; }
+                }
+                // survivors append themselves (parallel): kept list + class list
+                if ((keep >> lane) & 1ull) {
+                    const int slot = nk + __popcll(keep & ((1ull << lane) - 1ull));
+                    kept[slot] = c;
+                    nxt[slot] = (short)atomicExch(&head[lst], slot);
+                }
+                nk += __popcll(keep);
                 if (lane == 0) s_kept = nk;
             }
             __syncthreads();
         }
+        t_b += __builtin_readcyclecounter() - tb0;
+    }
+    if (b == 0 && tid == 0) {
+        g_nms_dbg[0] = t_sorted - t0; g_nms_dbg[1] = t_a; g_nms_dbg[2] = t_b; g_nms_dbg[3] = __builtin_readcyclecounter() - t0;
+        g_nms_dbg[4] = (unsigned long long)n; g_nms_dbg[5] = (unsigned long long)s_kept;
+        g_nms_dbg[6] = (unsigned long long)s_wide; g_nms_dbg[7] = t_ld;
     }
     // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)
     const int nk = s_kept < a.max_det ? s_kept : a.max_det;
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += kSelT) {
         const unsigned int flat = kept[k].flat;
         const unsigned int box = flat / (unsigned int)a.nc;
         const int cls = (int)(flat - box * (unsigned int)a.nc);
@@ -346,6 +410,10 @@ long long pow2ceil(long long v) {
 }
 
 }  // namespace
+
+extern "C" int maf_nms_debug(uint64_t* host8) {
+    return maf_check_hip(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_nms_dbg), sizeof(unsigned long long) * 8), "hipMemcpyFromSymbol");
+}
 
 extern "C" int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc) {
     if (B <= 0 || N <= 0 || nc <= 0) return 0;
@@ -369,6 +437,14 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     a.pred = pred; a.B = B; a.N = N; a.nc = nc;
     a.conf = (float)conf_thres;            // torch compares the fp32 tensor against the scalar in fp32
     a.iou = iou_thres;
+    {   // smallest fp32 strictly above the (double) threshold, its predecessor, their midpoint
+        float f = (float)iou_thres;
+        const float tf = ((double)f > iou_thres) ? f : nextafterf(f, INFINITY);
+        const float pf = nextafterf(tf, -INFINITY);
+        a.iou_m = ((double)tf + (double)pf) * 0.5;
+        uint32_t bits; memcpy(&bits, &tf, 4);
+        a.iou_even = (bits & 1u) == 0;
+    }
     a.classes = n_classes > 0 ? classes : nullptr; a.n_classes = n_classes;
     a.agnostic = agnostic; a.multi_label = (multi_label && nc > 1) ? 1 : 0;    // nms.py:57
     a.max_det = max_det;
@@ -389,6 +465,6 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     }
     rc = maf_check_hip(hipGetLastError(), "nms_collect launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(kSelT), 0, s, a);
     return maf_check_hip(hipGetLastError(), "nms_select launch");
 }

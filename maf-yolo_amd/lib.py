@@ -29,7 +29,7 @@ class MafOp(C.Structure):
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
-           "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms",
+           "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_debug",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
 _lib = None
@@ -63,6 +63,7 @@ def load():
     lib.maf_nms.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32,
                             C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p]
+    lib.maf_nms_debug.argtypes = [C.POINTER(C.c_uint64)]
     lib.maf_timer_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.maf_timer_start.argtypes = [C.c_void_p, C.c_void_p]
     lib.maf_timer_stop.argtypes = [C.c_void_p, C.c_void_p]

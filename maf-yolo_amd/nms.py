@@ -14,10 +14,25 @@ import torch
 from . import lib
 
 _ws = {}
+_side = {}
 
 
-def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
-    """Device-side result without the host sync: (rows [B,max_det,6], idx int64 [B,max_det], count int32 [B])."""
+def _workspace(dev, B, N, nc, need):
+    """Ring of 3 scratch buffers per shape so that up to 3 NMS calls may be in flight on a device."""
+    key = (dev.index, B, N, nc)
+    ring = _ws.get(key)
+    if ring is None or ring[0][0].numel() < need:
+        if len(_ws) > 4:
+            _ws.clear()
+        ring = [[torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(3)], 0]
+        _ws[key] = ring
+    ring[1] = (ring[1] + 1) % 3
+    return ring[0][ring[1]]
+
+
+def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, stream=None):
+    """Device-side result without the host sync: (rows [B,max_det,6], idx int64 [B,max_det], count int32 [B]).
+    Launches on `stream` (a torch.cuda.Stream) or on the current stream."""
     assert 0 <= conf_thres <= 1, f'conf_thresh must be in 0.0 to 1.0, however {conf_thres} is provided.'
     assert 0 <= iou_thres <= 1, f'iou_thres must be in 0.0 to 1.0, however {iou_thres} is provided.'
     if not prediction.is_cuda:
@@ -30,27 +45,54 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     nc = no - 5
     dev = pred.device
     L = lib.load()
-    need = L.maf_nms_workspace_bytes(B, N, nc)
-    key = (dev.index, B, N, nc)
-    ws = _ws.get(key)
-    if ws is None or ws.numel() < need:
-        if len(_ws) > 4:
-            _ws.clear()
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        _ws[key] = ws
-    rows = torch.zeros(B, max_det, 6, dtype=torch.float32, device=dev)
-    idx = torch.zeros(B, max_det, dtype=torch.int64, device=dev)
-    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
-    cls_t, ncls = None, 0
-    if classes is not None:
-        cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
-        ncls = cls_t.numel()
     with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        lib.check(L.maf_nms(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
-                            cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
-                            int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(), stream))
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            ws = _workspace(dev, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
+            rows = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
+            idx = torch.empty(B, max_det, dtype=torch.int64, device=dev)
+            cnt = torch.empty(B, dtype=torch.int32, device=dev)
+            cls_t, ncls = None, 0
+            if classes is not None:
+                cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
+                ncls = cls_t.numel()
+            lib.check(L.maf_nms(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
+                                cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
+                                int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(), st.cuda_stream))
+        if stream is not None:
+            pred.record_stream(st)
     return rows, idx, cnt
+
+
+class NmsHandle:
+    """In-flight NMS of one batch (see non_max_suppression_async)."""
+
+    def __init__(self, rows, idx, cnt, event):
+        self.rows, self.idx, self.cnt, self.event = rows, idx, cnt, event
+
+    def result(self, return_index=False):
+        self.event.synchronize()
+        counts = self.cnt.tolist()
+        out = [self.rows[b, :n] for b, n in enumerate(counts)]
+        if return_index:
+            return out, [self.idx[b, :n] for b, n in enumerate(counts)]
+        return out
+
+
+def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """Same arguments as non_max_suppression, but the two kernels go to a side stream ordered after the current one and
+    the call returns at once; `handle.result()` gives the reference's list of tensors.  A serving loop calls this for
+    batch i, launches the forward of batch i+1, then collects batch i: the (latency-bound, 32-workgroup) NMS of one
+    batch overlaps the convolutions of the next."""
+    dev = prediction.device
+    side = _side.get(dev.index)
+    if side is None:
+        side = _side[dev.index] = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, stream=side)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    return NmsHandle(rows, idx, cnt, ev)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,

@@ -187,3 +187,31 @@ def test_nms_fp16_prediction_is_upcast():
     oo = O.non_max_suppression(h.float().numpy(), **kw)
     for a, b in zip(out, oo):
         assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_async_nms_matches_sync(models):
+    x = O.synth_images(2, 320, 5).to(DEV)
+    with torch.no_grad():
+        pred = models["n"](x)[0]
+    ref = M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
+    hs = [M.non_max_suppression_async(pred, 0.03, 0.65, multi_label=True) for _ in range(4)]     # several in flight
+    for h in hs:
+        out = h.result()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.1, 1.0 / 3.0, 0.45, 0.5, 0.65, 0.75, 0.9, 1.0])
+def test_nms_division_free_iou_is_exact(thr):
+    """Heavily overlapping same-class boxes on an integer grid: many IoUs are simple rationals that hit the threshold
+    exactly (1/3, 1/2, 3/4 ...), which is where a rounding shortcut would show."""
+    rs = np.random.RandomState(int(thr * 1000) + 1)
+    n, nc = 400, 3
+    xy = rs.randint(0, 12, (n, 2)).astype(np.float32) * 4
+    wh = rs.randint(1, 7, (n, 2)).astype(np.float32) * 8
+    b = np.concatenate([xy + wh / 2 + 100, wh], 1).astype(np.float32)
+    cls = (0.2 + 0.8 * rs.rand(n, nc)).astype(np.float32)
+    pred = np.concatenate([b, np.ones((n, 1), np.float32), cls], 1)[None]
+    out, idx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), 0.25, thr, multi_label=True, max_det=1000, return_index=True)
+    oo, oi = O.non_max_suppression(pred, 0.25, thr, multi_label=True, max_det=1000, return_index=True)
+    assert np.array_equal(idx[0].cpu().numpy(), oi[0]) and np.array_equal(out[0].cpu().numpy(), oo[0])
