@@ -50,6 +50,40 @@ def calibrate_cls_bias(model, x, target_per_img, M, torch):
     return shift
 
 
+def latency_mode(args, torch, M, dev):
+    """bs=1, 640x640 fp16: forward replayed from a captured hipGraph (fixed input/output buffers) + NMS, per-call latency."""
+    import numpy as np
+    from maf_yolo_amd import synth
+    model = M.Model(args.scale)
+    model.load_state_dict(synth.synth_state_dict(model, args.scale, 0))
+    model = model.to(dev).eval()
+    x = synth.synth_images(1, 640, seed=1).to(dev).half()
+    calibrate_cls_bias(model, x, 2000, M, torch)
+    plan = model.plan_for(x)
+    pred = torch.empty(1, plan.A, 5 + plan.nc, dtype=torch.float32, device=dev)
+    res = {}
+    for tag, graph in (("hipgraph", True), ("eager", False)):
+        for _ in range(args.warmup):
+            plan.run_into(x, pred, graph=graph)
+            M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
+        torch.cuda.synchronize(dev)
+        lat_f, lat_t = [], []
+        for _ in range(max(args.steps, 200)):
+            t0 = time.perf_counter()
+            plan.run_into(x, pred, graph=graph)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
+            t2 = time.perf_counter()
+            lat_f.append(1e3 * (t1 - t0)); lat_t.append(1e3 * (t2 - t0))
+        res[tag] = {"forward_ms_p50": round(float(np.percentile(lat_f, 50)), 4), "forward_ms_p99": round(float(np.percentile(lat_f, 99)), 4),
+                    "forward_plus_nms_ms_p50": round(float(np.percentile(lat_t, 50)), 4), "forward_plus_nms_ms_p99": round(float(np.percentile(lat_t, 99)), 4)}
+    print(json.dumps({"metric": "latency ms MAF-YOLO-%s 640x640 bs=1 infer (hipGraph forward + NMS)" % args.scale,
+                      "value": res["hipgraph"]["forward_plus_nms_ms_p50"], "unit": "ms", "n_gpus": 1, "higher_is_better": False,
+                      "dtype": "f16", "data": "synthetic", "config": {"workload": "bs=1 3x640x640 fp16, %d launches per forward" % len(plan.ops)},
+                      "latency": res}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +93,8 @@ def main():
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
+    ap.add_argument("--latency", action="store_true",
+                    help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")
     args = ap.parse_args()
 
     import numpy as np
@@ -77,6 +113,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    if args.latency:
+        return latency_mode(args, torch, M, dev)
 
     # ---- model + synthetic inputs
     from maf_yolo_amd import synth

@@ -240,15 +240,21 @@ class Plan:
     def run(self, x, graph=False):
         """x: [B,3,Hin,Win] contiguous NCHW tensor on self.device. Returns pred fp32 [B, A, 5+nc]."""
         pred = torch.empty(self.B, self.A, 5 + self.nc, dtype=torch.float32, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        fn = lib.load().maf_engine_run_graph if graph else lib.load().maf_engine_run
-        lib.check(fn(self._engine, x.data_ptr(), pred.data_ptr(), stream))
-        return pred
+        return self.run_into(x, pred, graph)
 
     def run_into(self, x, pred, graph=False):
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        fn = lib.load().maf_engine_run_graph if graph else lib.load().maf_engine_run
-        lib.check(fn(self._engine, x.data_ptr(), pred.data_ptr(), stream))
+        cur = torch.cuda.current_stream(self.device)
+        if not graph:
+            lib.check(lib.load().maf_engine_run(self._engine, x.data_ptr(), pred.data_ptr(), cur.cuda_stream))
+            return pred
+        # hipGraph capture is not permitted on the legacy default stream: replay on a private stream ordered
+        # after / before the caller's current stream.  Pointers are frozen at capture (same x / pred buffers).
+        gs = getattr(self, "_gstream", None)
+        if gs is None:
+            gs = self._gstream = torch.cuda.Stream(self.device)
+        gs.wait_stream(cur)
+        lib.check(lib.load().maf_engine_run_graph(self._engine, x.data_ptr(), pred.data_ptr(), gs.cuda_stream))
+        cur.wait_stream(gs)
         return pred
 
     def run_timed(self, x, pred):

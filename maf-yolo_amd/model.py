@@ -100,7 +100,6 @@ class Model(nn.Module):
         self.build_type = "yaml"
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
-        self.use_graph = False                # hipGraph replay (bs=1 latency path); needs a fixed input tensor
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -189,7 +188,7 @@ class Model(nn.Module):
         plan = self.plan_for(x)
         x = x.contiguous()
         with torch.cuda.device(x.device):
-            pred = plan.run(x, graph=self.use_graph)
+            pred = plan.run(x, graph=False)          # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)
         feats = plan.featmaps()
         if val_loss:
             return [self.detect(feats), feats]

@@ -215,3 +215,24 @@ def test_nms_division_free_iou_is_exact(thr):
     out, idx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), 0.25, thr, multi_label=True, max_det=1000, return_index=True)
     oo, oi = O.non_max_suppression(pred, 0.25, thr, multi_label=True, max_det=1000, return_index=True)
     assert np.array_equal(idx[0].cpu().numpy(), oi[0]) and np.array_equal(out[0].cpu().numpy(), oo[0])
+
+
+def test_hipgraph_replay_equals_eager(models):
+    """bs=1 latency path (BASELINE configs[4]): the plan replayed from a captured hipGraph gives the same bits."""
+    m = models["m"]
+    x = O.synth_images(1, 320, 3).to(DEV).half()
+    with torch.no_grad():
+        eager = m(x)[0].clone()
+        plan = m.plan_for(x)
+        pred = torch.empty_like(eager)
+        for _ in range(3):                          # capture on first call, replay afterwards
+            plan.run_into(x, pred, graph=True)
+        torch.cuda.synchronize()
+    assert torch.equal(pred, eager)
+    x2 = O.synth_images(1, 320, 4).to(DEV).half()   # new data in the SAME input buffer is picked up by the replay
+    x.copy_(x2)
+    with torch.no_grad():
+        plan.run_into(x, pred, graph=True)
+        ref = m(x2)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(pred, ref)
