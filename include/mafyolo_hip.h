@@ -131,6 +131,22 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
             int32_t max_det, void* workspace, int64_t workspace_bytes,
             float* out_rows, int64_t* out_idx, int32_t* out_count, maf_stream_t stream);
 
+/*
+ * Training-side entry points.  The train-form graph keeps conv and BatchNorm apart
+ * (yolov6/layers/common.py:46-47, 219-224, 3024-3031), so the convs run through maf_op_launch with a zero bias and
+ * act = none; their backward needs:
+ *   maf_pack_w1x1   fp32 weight [Cout][Cin] of nn.Conv2d(k=1) -> the fragment-packed operand of MAF_OP_CONV1X1 in `dtype`;
+ *                   transpose = 1 packs W^T, which turns the same kernel into the data gradient dX = dY * W.
+ *   maf_pack_dw     fp32 depth-wise weight [C][k*k] -> [k*k][C] in `dtype`; flip = 1 gives the data-gradient kernel.
+ *   maf_dw_wgrad    dW[c][ky][kx] += sum over pixels of dY * shifted X  (fp32 atomics; dw must be zeroed by the caller).
+ * The 1x1 weight gradient dW = dY^T X is a plain TN GEMM and is left to hipBLASLt (torch.mm).
+ */
+int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c);
+int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c, void* out, maf_stream_t stream);
+int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
+int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
+                 int32_t k, int32_t dtype, float* dw, maf_stream_t stream);
+
 /* Diagnostics: shader-clock cycle stamps of image 0 of the last maf_nms call (synchronises the device):
  * [0] sort, [1] kept-list screening, [2] wave resolution, [3] total, [4] candidates, [5] survivors. */
 int maf_nms_debug(uint64_t* host8);

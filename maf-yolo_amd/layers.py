@@ -5,8 +5,10 @@ ConvWrapper :76, SPPF :114, MPRep :776, DepthBottleneckUni :898, RepHDW :928, He
 DilatedReparamBlock :2948, UniRepLKNetBlock :3053) so a reference state_dict (838 / 1206 / 1568
 tensors for n / s / m) loads with strict=True and trained weights round-trip.
 
-`forward` here is the TRAINING-form graph in stock PyTorch ops (autograd / DDP train it today; the
-native backward kernels are the next §8 row).  Inference never runs these forwards: in eval mode
+`forward` here is the TRAINING-form graph: the 1x1 and depth-wise convolutions (69 % of the FLOPs, most of the
+launches) run forward and backward on the HIP kernels through train_ops.py; the 3x3 stride-2 convs, BatchNorm
+and the element-wise glue are torch ops on channels_last tensors (their native backward is the next §8 row).
+Inference never runs these forwards: in eval mode
 Model.forward executes the re-parameterised graph on the HIP engine (engine.py), built from
 `fused()` below — the deploy algebra of SURVEY.md §3.3, evaluated in fp32 on the host once.
 """
@@ -17,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .arch import dil_branch_kernels
+from . import train_ops
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03          # yolov6/utils/torch_utils.py:43-45
 
@@ -54,6 +57,8 @@ class Conv(nn.Module):
         self.act = nn.SiLU(inplace=True)
 
     def forward(self, x):
+        if self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1):
+            return self.act(self.bn(train_ops.conv1x1(x, self.conv.weight)))      # HIP fwd / dgrad, hipBLASLt wgrad
         return self.act(self.bn(self.conv(x)))
 
     def fused(self):
@@ -105,9 +110,9 @@ class DilatedReparamBlock(nn.Module):
             setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
 
     def forward(self, x):
-        out = self.origin_bn(self.lk_origin(x))
+        out = self.origin_bn(train_ops.dwconv(x, self.lk_origin.weight))           # HIP fwd / dgrad / wgrad
         for kk in self.kernel_sizes:
-            out = out + getattr(self, "dil_bn_k%d_1" % kk)(getattr(self, "dil_conv_k%d_1" % kk)(x))
+            out = out + getattr(self, "dil_bn_k%d_1" % kk)(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight))
         return out
 
     def fused(self):
@@ -244,8 +249,8 @@ class Head_DepthUni(nn.Module):
 
     def forward(self, x):
         x = self.stem(x)
-        cls = torch.sigmoid(self.cls_pred(self.cls_conv_s(self.cls_conv(x))))
-        reg = self.reg_pred(self.reg_conv_s(self.reg_conv(x)))
+        cls = torch.sigmoid(train_ops.conv1x1(self.cls_conv_s(self.cls_conv(x)), self.cls_pred.weight, self.cls_pred.bias))
+        reg = train_ops.conv1x1(self.reg_conv_s(self.reg_conv(x)), self.reg_pred.weight, self.reg_pred.bias)
         return x, cls, reg
 
 

@@ -183,6 +183,8 @@ class Model(nn.Module):
 
     def forward(self, x, val_loss=False):
         if self.training:
+            if x.is_cuda:
+                x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
             heads = self._forward_train_form(x)
             return [self.detect(heads), list(heads)]
         plan = self.plan_for(x)

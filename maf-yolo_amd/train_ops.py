@@ -1,0 +1,203 @@
+"""Autograd functions that run the training-form 1x1 and depth-wise convolutions on the HIP kernels.
+
+Train step of the reference: `Trainer.train_in_steps` (yolov6/core/engine.py:141-167) — forward under
+autocast, scaled backward, DDP all-reduce of the fp32 grads.  The train-form graph keeps conv and BN
+apart, so the convs here have no epilogue; BN / activations / pooling / cat stay torch ops on
+channels_last tensors (NHWC in memory — exactly the layout the kernels take, so nothing is copied).
+
+    conv1x1(x, w, bias=None)   forward + data gradient: csrc/conv_mfma.inc.h (dgrad = same kernel on W^T, packed on
+                               the device by maf_pack_w1x1); weight gradient dW = dY^T X: a plain TN GEMM -> torch.mm
+    dwconv(x, w)               forward + data gradient: csrc/dwconv.hip (dgrad = flipped kernel, maf_pack_dw);
+                               weight gradient: csrc/train_ops.hip:dw_wgrad_kernel
+
+Both accept fp16 or fp32 NHWC *views* (channel slices of wider buffers are fine) and fp32 master
+weights; outputs are channels_last tensors of the input dtype, weight grads are fp32.
+CUDA tensors always take the HIP kernels (unsupported shapes raise); CPU tensors run plain torch ops so the
+train-form module tree can be exercised by the CPU/gloo tests (`stats` counts which path ran)."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import lib, pack
+
+_DT = {torch.float16: lib.F16, torch.float32: lib.F32}
+_zeros = {}
+stats = {"native_conv1x1": 0, "native_dwconv": 0, "fallback": 0}
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _zero_bias(dev, n):
+    z = _zeros.get(dev.index)
+    if z is None or z.numel() < n:
+        z = _zeros[dev.index] = torch.zeros(max(n, 4096), dtype=torch.float32, device=dev)
+    return z
+
+
+def nhwc(t):
+    """(tensor, pixel stride in elements) with t's memory being an NHWC view; copies only if it is not."""
+    B, Cc, H, W = t.shape
+    s = t.stride()
+    if s[1] == 1 and s[3] >= Cc and s[2] == W * s[3] and s[0] == H * W * s[3]:
+        return t, s[3]
+    t = t.contiguous(memory_format=torch.channels_last)
+    return t, t.stride()[3]
+
+
+def _ok(x, cin_mult):
+    return x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % cin_mult == 0
+
+
+def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
+    op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, cin, cout, 1
+    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, xs, 0, lib.SRC_DIRECT
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
+    op.tile_p, op.tile_c = pack.tile_for(cout, B * H * W)[0], ct
+    op.w, op.bias = wp.data_ptr(), bias.data_ptr()
+    lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+
+
+def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev):
+    n = lib.load().maf_pack_w1x1_bytes(cout, cin, transpose, dt, ct)
+    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    lib.check(lib.load().maf_pack_w1x1(w2d.data_ptr(), cout, cin, transpose, dt, ct, buf.data_ptr(), _stream(dev)))
+    return buf
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, xs = nhwc(x)
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dt = _DT[x.dtype]
+        w2d = w.detach().reshape(cout, cin).float().contiguous()
+        ct = pack.tile_for(cout, B * H * W)[1]
+        wp = _packed_1x1(w2d, cout, cin, 0, dt, ct, x.device)
+        npad = -(-cout // (16 * ct)) * 16 * ct
+        if bias is None:
+            bp = _zero_bias(x.device, npad)
+        else:
+            bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
+            bp[:cout] = bias.detach().float()
+        out = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, cout, ct, out, dt)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        stats["native_conv1x1"] += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dy, dys = nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+            dys = dy.stride()[3]
+        dt = _DT[x.dtype]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w2d = w.detach().reshape(cout, cin).float().contiguous()
+            mult = 8 if x.dtype == torch.float16 else 4
+            dyk, dyks, kk = dy, dys, cout
+            if cout % mult:                                                      # e.g. reg_pred: 68 channels in fp16
+                kk = -(-cout // mult) * mult                                     # zero-pad the reduction dim to whole 16-byte chunks
+                dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
+                dyks = kk
+                w2d = F.pad(w2d, (0, 0, 0, kk - cout))
+            ct = pack.tile_for(cin, B * H * W)[1]
+            wp = _packed_1x1(w2d, kk, cin, 1, dt, ct, x.device)                  # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci]
+            npad = -(-cin // (16 * ct)) * 16 * ct
+            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
+        if ctx.needs_input_grad[1]:
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                          # NHWC rows (a view when x is dense)
+            d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
+            dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)      # plain TN GEMM -> hipBLASLt
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3))
+        return dx, dw, db
+
+
+def conv1x1(x, w, bias=None):
+    """nn.Conv2d(k=1, stride=1) forward with autograd. x [B,Cin,H,W] (NHWC in memory preferred), w [Cout,Cin,1,1]."""
+    if not x.is_cuda:                       # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
+        stats["fallback"] += 1
+        return F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (_ok(x, mult) and w.shape[0] % 2 == 0 and w.shape[2] == 1):
+        raise lib.MafError("conv1x1: unsupported input for the HIP path: %s %s -> %d channels" % (tuple(x.shape), x.dtype, w.shape[0]))
+    return _Conv1x1.apply(x, w, bias)
+
+
+def _launch_dw(x, xs, wp, bias, B, H, W, c, k, out, dt):
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_DWCONV, dt, dt, lib.ACT_NONE
+    op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc = B, H, W, c, c, k, 1
+    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), c, xs, 0, lib.SRC_DIRECT
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
+    op.w, op.bias = wp.data_ptr(), bias.data_ptr()
+    lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+
+
+def _packed_dw(w, c, k, flip, dt, dev):
+    buf = torch.empty(c * k * k * (2 if dt == lib.F16 else 4), dtype=torch.uint8, device=dev)
+    wf = w.detach().reshape(c, k * k).float().contiguous()
+    lib.check(lib.load().maf_pack_dw(wf.data_ptr(), c, k, flip, dt, buf.data_ptr(), _stream(dev)))
+    return buf
+
+
+class _DWConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, xs = nhwc(x)
+        B, c, H, W = x.shape
+        k = w.shape[-1]
+        dt = _DT[x.dtype]
+        out = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _launch_dw(x, xs, _packed_dw(w, c, k, 0, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, out, dt)
+        ctx.save_for_backward(x, w)
+        stats["native_dwconv"] += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, c, H, W = x.shape
+        k = w.shape[-1]
+        dy, dys = nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+            dys = dy.stride()[3]
+        dt = _DT[x.dtype]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
+            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
+        if ctx.needs_input_grad[1]:
+            xx, xs = nhwc(x)
+            dwf = torch.zeros(c, k * k, dtype=torch.float32, device=x.device)
+            lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), _stream(x.device)))
+            dw = dwf.reshape(w.shape).to(w.dtype)
+        return dx, dw
+
+
+def dwconv(x, w):
+    """Depth-wise k x k stride-1 'same' conv (groups == channels) with autograd. w [C,1,k,k], k in {3,5,7,9}."""
+    k = w.shape[-1]
+    if k == 1:                               # a 1x1 depth-wise conv is a per-channel scale
+        return x * w.reshape(1, -1, 1, 1).to(x.dtype)
+    if not x.is_cuda:                        # CPU tensors: plain torch (CI / gloo tests only)
+        stats["fallback"] += 1
+        return F.conv2d(x, w.to(x.dtype), None, 1, k // 2, 1, x.shape[1])
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (_ok(x, mult) and k in (3, 5, 7, 9)):
+        raise lib.MafError("dwconv: unsupported input for the HIP path: %s %s k=%d" % (tuple(x.shape), x.dtype, k))
+    return _DWConv.apply(x, w)

@@ -1,0 +1,129 @@
+"""-m gpu: training-form ops on the HIP kernels vs torch autograd.
+
+fp32: forward / dX / dW within 2e-4 of max|ref| (fp32 accumulation order); fp16 storage: 2e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import maf_yolo_amd as M
+from maf_yolo_amd import train_ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("cin,cout,bias", [(48, 72, False), (72, 24, False), (128, 80, True), (192, 68, True), (24, 144, False)])
+def test_conv1x1_forward_backward(dtype, tol, cin, cout, bias):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, 9, 13, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    dy = torch.randn(2, cout, 9, 13, generator=g)
+    xr = x.clone().to(dtype).float().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    F.conv2d(xr, wr.to(dtype).float(), br).backward(dy)
+    xg = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    before = train_ops.stats["native_conv1x1"]
+    out = train_ops.conv1x1(xg, wg, bg)
+    assert train_ops.stats["native_conv1x1"] == before + 1
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    out.backward(dy.to(DEV).to(dtype))
+    with torch.no_grad():
+        ref = F.conv2d(xr, wr.to(dtype).float(), br)
+    assert _rel(out.cpu(), ref) < tol
+    assert _rel(xg.grad.cpu(), xr.grad) < tol and _rel(wg.grad.cpu(), wr.grad) < tol
+    assert wg.grad.dtype == torch.float32
+    if bias:
+        assert _rel(bg.grad.cpu(), br.grad) < tol
+
+
+def test_conv1x1_on_channel_slice_view():
+    """RepHDW feeds a channel slice of conv1's output to the bottleneck (common.py:940-942): no copy needed."""
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(2, 96, 8, 8, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(144, 48, 1, 1, generator=g) / 7).to(DEV)
+    out = train_ops.conv1x1(t[:, 48:], w)
+    ref = F.conv2d(t[:, 48:].contiguous(), w)
+    assert _rel(out, ref) < 2e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("k", [1, 3, 5, 7, 9])
+def test_dwconv_forward_backward(dtype, tol, k):
+    g = torch.Generator().manual_seed(k)
+    c = 72
+    x = torch.randn(2, c, 11, 14, generator=g)
+    w = torch.randn(c, 1, k, k, generator=g) / k
+    dy = torch.randn(2, c, 11, 14, generator=g)
+    xr = x.clone().to(dtype).float().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr.to(dtype).float(), None, 1, k // 2, 1, c)
+    ref.backward(dy.to(dtype).float())
+    xg = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    out = train_ops.dwconv(xg, wg)
+    out.backward(dy.to(DEV).to(dtype))
+    assert _rel(out.cpu(), ref.detach()) < tol
+    assert _rel(xg.grad.cpu(), xr.grad) < tol
+    assert _rel(wg.grad.cpu(), wr.grad) < (tol if dtype == torch.float32 else 3e-2)
+
+
+def test_train_step_matches_cpu_autograd():
+    """Whole train-form graph, fp32: loss and parameter gradients of the HIP-backed model == the same module tree on CPU."""
+    from maf_yolo_amd import synth
+    cpu = M.Model("n")
+    cpu.load_state_dict(synth.synth_state_dict(cpu, "n", 0))          # the default init zeroes the pred weights: no gradient flow
+    cpu = cpu.train()
+    gpu = M.Model("n")
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.to(DEV).train()
+    x = torch.rand(2, 3, 64, 64)
+
+    def loss_of(m, inp):
+        (feats, cls, reg), _ = m(inp)
+        return cls.float().pow(2).mean() + reg.float().pow(2).mean()
+
+    lc = loss_of(cpu, x); lc.backward()
+    n0 = dict(train_ops.stats)
+    lg = loss_of(gpu, x.to(DEV)); lg.backward()
+    assert train_ops.stats["native_conv1x1"] - n0["native_conv1x1"] >= 60 and train_ops.stats["native_dwconv"] - n0["native_dwconv"] >= 40
+    assert abs(lc.item() - lg.item()) < 1e-4 * abs(lc.item())
+    pc = dict(cpu.named_parameters())
+    checked = 0
+    for name, p in gpu.named_parameters():
+        if p.grad is None:
+            continue
+        ref = pc[name].grad
+        scale = ref.abs().max().item()
+        if scale < 1e-12:
+            continue
+        assert (p.grad.cpu() - ref).abs().max().item() < 2e-3 * scale + 1e-7, name
+        checked += 1
+    assert checked > 200
+    # BN running statistics were updated identically
+    assert torch.allclose(gpu.backbone[2].conv1.bn.running_mean.cpu(), cpu.backbone[2].conv1.bn.running_mean, atol=1e-5)
+
+
+def test_autocast_training_step_runs_and_updates():
+    """The reference's AMP recipe (engine.py:149-164): autocast forward, scaled backward, SGD step."""
+    torch.manual_seed(0)
+    m = M.Model("n").to(DEV).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, nesterov=True)
+    scaler = torch.amp.GradScaler("cuda")
+    x = torch.rand(4, 3, 128, 128, device=DEV)
+    w0 = m.backbone[2].conv1.conv.weight.detach().clone()
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = m(x)
+            loss = cls.float().mean() + reg.float().pow(2).mean()
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update()
+    assert torch.isfinite(loss) and not torch.equal(w0, m.backbone[2].conv1.conv.weight.detach())
