@@ -84,6 +84,65 @@ def latency_mode(args, torch, M, dev):
                       "latency": res}), flush=True)
 
 
+def train_mode(args, torch, M, dev, rank, world, dist):
+    """One step = forward (autocast fp16) + backward + DDP all-reduce + SGD step on a fixed synthetic batch per rank.
+    The loss is a surrogate that touches every head output (the reference's ComputeLoss is SURVEY.md §8 f2, out of scope)."""
+    from maf_yolo_amd import synth, train_ops
+    import torch.nn.functional as F
+    if args.torch_convs:                       # A/B: same module tree, convs through F.conv2d (MIOpen)
+        train_ops.conv1x1 = lambda x, w, bias=None: F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
+        train_ops.dwconv = lambda x, w: F.conv2d(x, w.to(x.dtype), None, 1, w.shape[-1] // 2, 1, x.shape[1])
+    model = M.Model(args.scale)
+    model.load_state_dict(synth.synth_state_dict(model, args.scale, 0))
+    model = model.to(dev).train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01 / 64 * args.batch * world, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    B = args.batch
+    x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = net(x)
+            loss = (cls.float().mean() + reg.float().pow(2).mean()) * world      # engine.py:161-162
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD, AMP fp16)" % (args.scale, B),
+                          "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, surrogate loss over all head outputs" % (args.scale, B),
+                                     "global_batch": B * world, "parallelism": "ddp%d" % world,
+                                     "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for 1x1 + depth-wise (fwd, dgrad, DW wgrad); 3x3 s2 + BN torch",
+                                     "native_launches": dict(train_ops.stats), "final_loss": round(float(loss), 5)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +152,9 @@ def main():
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
+    ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")
     args = ap.parse_args()
@@ -116,6 +178,8 @@ def main():
 
     if args.latency:
         return latency_mode(args, torch, M, dev)
+    if args.train:
+        return train_mode(args, torch, M, dev, rank, world, dist)
 
     # ---- model + synthetic inputs
     from maf_yolo_amd import synth
