@@ -271,9 +271,17 @@ def main():
         tot_bytes = sum(plan.algorithmic_bytes(i) for i in range(len(plan.ops)))
         tot_flops = sum(plan.flops(i) for i in range(len(plan.ops)))
         fwd_img_s = B / (fwd_ms * 1e-3)
+        traffic, traffic_src = None, None
+        try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            if name in pmc:
+                traffic = pmc[name]["traffic_bytes"]
+                traffic_src = "profiles/round1_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 per launch, gfx950 FETCH_SIZE x2 correction"
+        except Exception:
+            pass
         roofline = dict(bound="hbm", kernel=name, launches_per_forward=gd["n"], avg_launch_ms=round(avg_ms, 5),
                         bytes_per_launch=int(bytes_per_launch), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4),
                         whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), GFLOP=round(tot_flops / 1e9, 2),
                                            sum_kernel_ms=round(float(per_op_ms.sum()), 4),

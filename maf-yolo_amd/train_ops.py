@@ -47,6 +47,16 @@ def nhwc(t):
     return t, t.stride()[3]
 
 
+def _autocast(x):
+    """Convolutions are on autocast's lower-precision list: under torch.autocast an fp32 input (e.g. what nn.Upsample
+    returns, which then promotes the following cat) is cast down exactly as F.conv2d would do."""
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if x.dtype != dt and x.is_floating_point():
+            return x.to(dt)
+    return x
+
+
 def _ok(x, cin_mult):
     return x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % cin_mult == 0
 
@@ -131,6 +141,7 @@ def conv1x1(x, w, bias=None):
     if not x.is_cuda:                       # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
         stats["fallback"] += 1
         return F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    x = _autocast(x)
     mult = 8 if x.dtype == torch.float16 else 4
     if not (_ok(x, mult) and w.shape[0] % 2 == 0 and w.shape[2] == 1):
         raise lib.MafError("conv1x1: unsupported input for the HIP path: %s %s -> %d channels" % (tuple(x.shape), x.dtype, w.shape[0]))
@@ -197,6 +208,7 @@ def dwconv(x, w):
     if not x.is_cuda:                        # CPU tensors: plain torch (CI / gloo tests only)
         stats["fallback"] += 1
         return F.conv2d(x, w.to(x.dtype), None, 1, k // 2, 1, x.shape[1])
+    x = _autocast(x)
     mult = 8 if x.dtype == torch.float16 else 4
     if not (_ok(x, mult) and k in (3, 5, 7, 9)):
         raise lib.MafError("dwconv: unsupported input for the HIP path: %s %s k=%d" % (tuple(x.shape), x.dtype, k))
