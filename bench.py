@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE configs[1]: 32)")
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
@@ -187,6 +188,7 @@ def main():
     sd = synth.synth_state_dict(model, args.scale, 0)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
+    model.autotune = not args.no_autotune      # per-layer MFMA tile selection when the plan is built (outside the timed region)
     B = args.batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev).half()
     shift = calibrate_cls_bias(model, x, 2000, M, torch)

@@ -301,10 +301,10 @@ template <typename T, int VAR, bool OUTF32>
 int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
 #define MAF_TILE(P, C) \
     if (pt == P && ct == C) return launch_act<T, P, C, VAR, OUTF32>(a, s);
-    MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(1, 4) MAF_TILE(2, 4)
+    MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(4, 2) MAF_TILE(1, 4) MAF_TILE(2, 4) MAF_TILE(4, 4)
     MAF_TILE(1, 6) MAF_TILE(2, 6) MAF_TILE(1, 8) MAF_TILE(2, 8)
 #undef MAF_TILE
-    maf_set_error("conv: unsupported tile (tile_p in {1,2}, tile_c in {2,4,6,8})");
+    maf_set_error("conv: unsupported tile (tile_p in {1,2,4}, tile_c in {2,4,6,8}; tile_p = 4 only with tile_c <= 4)");
     return MAF_E_UNSUPPORTED;
 }
 

@@ -16,6 +16,7 @@ from . import lib, pack
 from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Head_DepthUni)
 
 _ESIZE = {lib.F16: 2, lib.F32: 4}
+_TUNE_CACHE = {}          # layer signature -> (tile_p, tile_c), filled by Plan.autotune
 _TORCH_DT = {lib.F16: torch.float16, lib.F32: torch.float32}
 
 
@@ -79,7 +80,7 @@ class Plan:
         pt, ct = pack.tile_for(cout, M)
         srcC = [s.C for s in src.segs]
         assert len(src.segs) <= 4, "%s: more than 4 concat sources" % name
-        self._ops.append(dict(kind=lib.OP_CONV1X1, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=cout,
+        self._ops.append(dict(kind=lib.OP_CONV1X1, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=cout, raw=(w.detach().float().cpu(), b.detach().float().cpu(), srcC),
                               segs=src.segs, out=out, out_coff=out_coff, out_f32=int(out_f32), pt=pt, ct=ct,
                               w=self._wput(pack.pack_conv1x1(w, srcC, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
 
@@ -88,7 +89,7 @@ class Plan:
         cout = w.shape[0]
         H, W = src.H // 2, src.W // 2
         pt, ct = pack.tile_for(cout, self.B * H * W)
-        self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=name, act=act, H=H, W=W, Hin=src.H, Win=src.W, Cin=src.C, Cout=cout,
+        self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=name, act=act, H=H, W=W, Hin=src.H, Win=src.W, Cin=src.C, Cout=cout, raw=(w.detach().float().cpu(), b.detach().float().cpu(), None),
                               segs=src.segs, out=out, out_coff=out_coff, out_f32=0, pt=pt, ct=ct,
                               w=self._wput(pack.pack_conv3x3(w, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
 
@@ -235,6 +236,74 @@ class Plan:
         h = C.c_void_p()
         lib.check(lib.load().maf_engine_create(ops, len(self._ops), C.byref(h)))
         self._engine = h
+
+    # ---------------------------------------------------------------- tile autotuning
+    def autotune(self, x, reps=5, verbose=False):
+        """Time every (tile_p, tile_c) candidate of every MFMA conv on this device and keep the fastest.
+        The candidates differ only in how the (pixel x channel) space is cut into wave tiles (and in the matching weight
+        packing); results are cached per layer signature in `_TUNE_CACHE` so other plans of the same model reuse them."""
+        import time
+        assert x.is_cuda
+        L = lib.load()
+        stream = torch.cuda.current_stream(self.device)
+        pred = torch.empty(self.B, self.A, 5 + self.nc, dtype=torch.float32, device=self.device)
+        self.run_into(x, pred)                                   # every buffer holds realistic data
+        torch.cuda.synchronize(self.device)
+        timer = lib.Timer()
+        self._tuned = getattr(self, "_tuned", [])
+        changed = 0
+        for i, (o, r) in enumerate(zip(self.ops, self._ops)):
+            if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
+                continue
+            M = self.B * o.H * o.W
+            sig = (o.kind, self.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32))
+            best = _TUNE_CACHE.get(sig)
+            w, b, srcC = r["raw"]
+            if best is None:
+                cands = []
+                for ct in (2, 4, 6, 8):
+                    nt = -(-o.Cout // (16 * ct))
+                    if nt * 16 * ct > 2 * max(o.Cout, 32) or (ct == 8 and o.out_stride % 8 and not o.out_f32 and self.dtype == lib.F16):
+                        continue
+                    for pt in (1, 2, 4):
+                        if pt == 4 and ct > 4:
+                            continue
+                        if -(-M // (64 * pt)) * nt < 256 and pt > 1:
+                            continue                          # would not fill the chip
+                        cands.append((pt, ct))
+                results = []
+                for pt, ct in cands:
+                    wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
+                    bp = pack.pack_bias(b, ct).to(self.device)
+                    op = lib.MafOp.from_buffer_copy(o)
+                    op.tile_p, op.tile_c, op.w, op.bias = pt, ct, wp.data_ptr(), bp.data_ptr()
+                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))          # warm-up
+                    ts = []
+                    for _ in range(reps):
+                        timer.start(stream.cuda_stream)
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        timer.stop(stream.cuda_stream)
+                        ts.append(timer.elapsed_ms())
+                    results.append((min(ts), pt, ct))
+                results.sort()
+                best = (results[0][1], results[0][2])
+                _TUNE_CACHE[sig] = best
+                if verbose:
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d)%.1fus" % (p, c, t * 1e3) for t, p, c in results)))
+            pt, ct = best
+            if (pt, ct) != (o.tile_p, o.tile_c):
+                wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
+                bp = pack.pack_bias(b, ct).to(self.device)
+                self._tuned += [wp, bp]
+                o.tile_p, o.tile_c, o.w, o.bias = pt, ct, wp.data_ptr(), bp.data_ptr()
+                changed += 1
+        if changed:
+            L.maf_engine_destroy(self._engine)
+            h = C.c_void_p()
+            lib.check(L.maf_engine_create(self.ops, len(self.ops), C.byref(h)))
+            self._engine = h
+        torch.cuda.synchronize(self.device)
+        return changed
 
     # ---------------------------------------------------------------- execution
     def run(self, x, graph=False):

@@ -100,6 +100,7 @@ class Model(nn.Module):
         self.build_type = "yaml"
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
+        self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -178,6 +179,8 @@ class Model(nn.Module):
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
             plan = Plan(self, B, H, W, dt, in_dt, x.device)
+            if self.autotune and dt == lib.F16:
+                plan.autotune(x.contiguous())
             self._plans[key] = plan
         return plan
 

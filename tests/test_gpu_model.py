@@ -236,3 +236,16 @@ def test_hipgraph_replay_equals_eager(models):
         ref = m(x2)[0]
     torch.cuda.synchronize()
     assert torch.equal(pred, ref)
+
+
+def test_autotuned_tiles_give_identical_predictions(models):
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0))
+    m = m.to(DEV).eval()
+    x = O.synth_images(4, 320, 6).to(DEV).half()
+    with torch.no_grad():
+        base = m(x)[0].clone()
+        plan = m.plan_for(x)
+        plan.autotune(x)
+        tuned = m(x)[0]
+    assert torch.equal(base, tuned)          # a tile only re-cuts the (pixel, channel) space; every dot product keeps its order
