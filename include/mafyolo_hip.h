@@ -62,7 +62,8 @@ typedef struct {
  * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
  *                   2H x 2W input (Hin, Win below); w packed per tap.
  * MAF_OP_DWCONV     replaces DilatedReparamBlock.lk_origin after merge (common.py:3025,3033-3051).
- *                   w = [k*k][C] of the activation dtype.
+ *                   w = [k*k][C] of the activation dtype.  tile_p / tile_c / tile_k optionally fix the workgroup tile
+ *                   (rows, cols, channels per block); 0 = built-in cost model.
  * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
  *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
  * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
@@ -80,6 +81,7 @@ typedef struct {
     int32_t out_stride, out_coff;
     int32_t out_f32;             /* CONV1X1: store fp32 regardless of dtype (cls_pred/reg_pred) */
     int32_t tile_p, tile_c;      /* MFMA tile: 16*tile_p pixels x 16*tile_c channels per wave   */
+    int32_t tile_k;              /* 0/1: each wave reduces all of K; 4: the 4 waves of a workgroup split K (tile_p = 1) */
     const void* w;
     const float* bias;
     /* DECODE only */

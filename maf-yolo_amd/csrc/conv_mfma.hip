@@ -37,9 +37,14 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     a.w = op->w; a.bias = op->bias; a.out = op->out;
     a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     MAF_REQUIRE(op->w && op->bias && op->out, "conv: null w/bias/out");
-    const int pt = op->tile_p, ct = op->tile_c;
+    int pt = op->tile_p;
+    const int ct = op->tile_c;
     MAF_REQUIRE(pt > 0 && ct > 0, "conv: tile_p/tile_c not set");
-    a.nM = maf_cdiv(a.M, 64 * pt);
+    const bool ks4 = op->tile_k == 4;
+    MAF_REQUIRE(op->tile_k == 0 || op->tile_k == 1 || op->tile_k == 4, "conv: tile_k must be 1 or 4");
+    MAF_REQUIRE(!ks4 || pt == 1, "conv: split-K (tile_k = 4) needs tile_p = 1");
+    a.nM = ks4 ? maf_cdiv(a.M, 16) : maf_cdiv(a.M, 64 * pt);
+    if (ks4) pt = 0;                                                 // dispatch key of the split-K instantiations
     a.nN = maf_cdiv(op->Cout, 16 * ct);
     int var;
     if (op->kind == MAF_OP_CONV3X3S2) {

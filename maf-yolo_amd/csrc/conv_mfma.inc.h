@@ -92,8 +92,9 @@ __device__ __forceinline__ typename Frag<T>::type ldg16(const T* p) {
     return *reinterpret_cast<const typename Frag<T>::type*>(p);
 }
 
-template <typename T, int PT, int CT, int VAR, bool OUTF32>
+template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    static_assert(!KS4 || PT == 1, "split-K variant is defined for one pixel tile per wave");
     typedef Frag<T> F;
     typedef typename F::type frag_t;
     constexpr int CH = F::CH;
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int n_tile = jj % a.nN;
     const int m_tile = (jj / a.nN) * 8 + xcd;
     if (m_tile >= a.nM) return;
-    const int m_base = m_tile * (64 * PT) + wave * (16 * PT);
+    // KS4: the 4 waves of the workgroup share ONE 16-pixel tile and each takes a quarter of the k-steps (small maps with
+    // long reductions are dependent-load chains; this cuts the chain 4x and puts 4x more workgroups on the chip)
+    const int m_base = KS4 ? m_tile * 16 : m_tile * (64 * PT) + wave * (16 * PT);
 
     // ---- per-lane pixel bookkeeping ----
     bool pvalid[PT];
@@ -157,6 +160,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     const int ntaps = (VAR == VAR_3X3S2) ? 9 : 1;
     const int total_steps = ntaps * a.ksteps;
+    const int s_begin = KS4 ? (total_steps * wave) / 4 : 0;
+    const int s_end = KS4 ? (total_steps * (wave + 1)) / 4 : total_steps;
     const frag_t* wbase = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
 
     auto load_src = [&](auto sidx, int ks, frag_t (&bf)[PT]) {
@@ -218,16 +223,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     frag_t bst[NS][PT], ast[NS][CT];
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < total_steps) {
-            load_b(s, bst[s]);
-            load_a(s, ast[s]);
+        if (s_begin + s < s_end) {
+            load_b(s_begin + s, bst[s]);
+            load_a(s_begin + s, ast[s]);
         }
-    for (int step0 = 0; step0 < total_steps; step0 += NS) {
+    for (int step0 = s_begin; step0 < s_end; step0 += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int step = step0 + u;
-            if (step < total_steps) {
-                if (step + NS - 1 < total_steps) {
+            if (step < s_end) {
+                if (step + NS - 1 < s_end) {
                     load_b(step + NS - 1, bst[(u + NS - 1) % NS]);
                     load_a(step + NS - 1, ast[(u + NS - 1) % NS]);
                 }
@@ -237,6 +242,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(bst[u][pt], ast[u][ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
             }
         }
+    }
+
+    if constexpr (KS4) {      // reduce the four partial accumulators through LDS; wave 0 finishes the tile
+        __shared__ f32x4_t red[3][CT][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) red[wave - 1][ct][lane] = acc[0][ct];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[0][ct] += red[0][ct][lane] + red[1][ct][lane] + red[2][ct][lane];
     }
 
     // ---- epilogue: bias + activation; lane (g, p) owns channels [cl, cl + CT) of pixels g*4 .. g*4+3 of each tile
@@ -290,10 +307,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int PT, int CT, int VAR, bool OUTF32>
+template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false>
 int launch_act(const ConvArgs& a, hipStream_t s) {
     const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
-    hipLaunchKernelGGL((conv_mfma_kernel<T, PT, CT, VAR, OUTF32>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, PT, CT, VAR, OUTF32, KS4>), dim3(grid), dim3(256), 0, s, a);
     return maf_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
@@ -304,6 +321,12 @@ int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
     MAF_TILE(1, 2) MAF_TILE(2, 2) MAF_TILE(4, 2) MAF_TILE(1, 4) MAF_TILE(2, 4) MAF_TILE(4, 4)
     MAF_TILE(1, 6) MAF_TILE(2, 6) MAF_TILE(1, 8) MAF_TILE(2, 8)
 #undef MAF_TILE
+    if (pt == 0) {                                                   // tile_p == 0 selects the split-K variant (tile_k = 4)
+        if (ct == 2) return launch_act<T, 1, 2, VAR, OUTF32, true>(a, s);
+        if (ct == 4) return launch_act<T, 1, 4, VAR, OUTF32, true>(a, s);
+        if (ct == 6) return launch_act<T, 1, 6, VAR, OUTF32, true>(a, s);
+        if (ct == 8) return launch_act<T, 1, 8, VAR, OUTF32, true>(a, s);
+    }
     maf_set_error("conv: unsupported tile (tile_p in {1,2,4}, tile_c in {2,4,6,8}; tile_p = 4 only with tile_c <= 4)");
     return MAF_E_UNSUPPORTED;
 }

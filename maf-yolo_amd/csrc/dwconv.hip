@@ -195,7 +195,14 @@ void choose_tile(int H, int W, int C, int N, int K, int& TH, int& TW, int& CB) {
 template <typename T, int ACT>
 int launch_t(DwArgs& a, int k, hipStream_t s) {
     constexpr int N = Vec<T>::N;
-    choose_tile(a.H, a.W, a.C, N, k, a.TH, a.TW, a.CB);
+    if (a.TH > 0 && a.TW > 0 && a.CB > 0) {                       // caller-chosen tile (Plan.autotune): validate it
+        if (a.TW % R != 0 || a.CB % N != 0 || a.CB > 8 * N || lds_bytes(a.TH, a.TW, a.CB, N, k) > kMaxLds) {
+            maf_set_error("dwconv: bad tile (tile_c multiple of 4, tile_k multiple of the channel group and <= 128 B, LDS <= 96 KiB)");
+            return MAF_E_ARG;
+        }
+    } else {
+        choose_tile(a.H, a.W, a.C, N, k, a.TH, a.TW, a.CB);
+    }
     a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH); a.nCB = maf_cdiv(a.C, a.CB);
     a.nwg = a.B * a.tilesY * a.tilesX * a.nCB;
     const size_t lds = lds_bytes(a.TH, a.TW, a.CB, N, k);
@@ -238,6 +245,7 @@ int maf_launch_dwconv(const maf_op_t* op, hipStream_t s) {
     a.B = op->B; a.H = op->H; a.W = op->W; a.C = op->Cin;
     a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     a.act = op->act;
+    a.TH = op->tile_p; a.TW = op->tile_c; a.CB = op->tile_k;     // 0 = cost-model choice
     MAF_REQUIRE(op->act == MAF_ACT_NONE || op->act == MAF_ACT_SILU, "dwconv: act must be none or silu");
     if (op->dtype == MAF_F16) return op->act == MAF_ACT_SILU ? launch_t<half_t, MAF_ACT_SILU>(a, op->ksize, s) : launch_t<half_t, MAF_ACT_NONE>(a, op->ksize, s);
     return op->act == MAF_ACT_SILU ? launch_t<float, MAF_ACT_SILU>(a, op->ksize, s) : launch_t<float, MAF_ACT_NONE>(a, op->ksize, s);

@@ -216,7 +216,7 @@ class Plan:
                 o.out_stride = r["out"].stride
             o.out_coff = r["out_coff"]
             o.out_f32 = r.get("out_f32", 0)
-            o.tile_p, o.tile_c = r.get("pt", 0), r.get("ct", 0)
+            o.tile_p, o.tile_c, o.tile_k = r.get("pt", 0), r.get("ct", 0), (1 if r["kind"] in (lib.OP_CONV1X1, lib.OP_CONV3X3S2) else 0)
             if "w" in r:
                 o.w = wbase + r["w"]
                 o.bias = wbase + r["b"]
@@ -253,6 +253,38 @@ class Plan:
         self._tuned = getattr(self, "_tuned", [])
         changed = 0
         for i, (o, r) in enumerate(zip(self.ops, self._ops)):
+            if o.kind == lib.OP_DWCONV:                          # depth-wise: workgroup tile (rows, cols, channel block)
+                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin, o.ksize, o.act)
+                best = _TUNE_CACHE.get(sig)
+                if best is None:
+                    n = 8 if self.dtype == lib.F16 else 4
+                    results = []
+                    for th in (4, 8, 16, 32):
+                        for tw in (8, 16, 32):
+                            for cbm in (8, 4, 2):
+                                t_h, t_w, cb = min(th, o.H), min(tw, -(-o.W // 4) * 4), min(cbm * n, -(-o.Cin // n) * n)
+                                lds = ((t_h + o.ksize - 1) * (t_w + o.ksize - 1) * (cb // n + 2) + o.ksize * o.ksize * (cb // n)) * 16
+                                if lds > 96 * 1024 or (t_h, t_w, cb) in [(a, b2, c2) for _, a, b2, c2 in results]:
+                                    continue
+                                op = lib.MafOp.from_buffer_copy(o)
+                                op.tile_p, op.tile_c, op.tile_k = t_h, t_w, cb
+                                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                ts = []
+                                for _ in range(reps):
+                                    timer.start(stream.cuda_stream)
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    timer.stop(stream.cuda_stream)
+                                    ts.append(timer.elapsed_ms())
+                                results.append((min(ts), t_h, t_w, cb))
+                    results.sort()
+                    best = results[0][1:]
+                    _TUNE_CACHE[sig] = best
+                    if verbose:
+                        print("tune %-32s %dx%d C=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d,%d)%.1fus" % (a, b2, c2, t * 1e3) for t, a, b2, c2 in results[:6])))
+                if tuple(best) != (o.tile_p, o.tile_c, o.tile_k):
+                    o.tile_p, o.tile_c, o.tile_k = best
+                    changed += 1
+                continue
             if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
                 continue
             M = self.B * o.H * o.W
@@ -270,13 +302,16 @@ class Plan:
                             continue
                         if -(-M // (64 * pt)) * nt < 256 and pt > 1:
                             continue                          # would not fill the chip
-                        cands.append((pt, ct))
+                        cands.append((pt, ct, 1))
+                    ksteps = sum(-(-o.src[k].C // (32 if self.dtype == lib.F16 else 16)) for k in range(o.nsrc)) * (9 if o.kind == lib.OP_CONV3X3S2 else 1)
+                    if ksteps >= 8 and M <= 65536:
+                        cands.append((1, ct, 4))                 # split-K across the 4 waves: long reductions on small maps
                 results = []
-                for pt, ct in cands:
+                for pt, ct, tk in cands:
                     wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
                     bp = pack.pack_bias(b, ct).to(self.device)
                     op = lib.MafOp.from_buffer_copy(o)
-                    op.tile_p, op.tile_c, op.w, op.bias = pt, ct, wp.data_ptr(), bp.data_ptr()
+                    op.tile_p, op.tile_c, op.tile_k, op.w, op.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
                     lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))          # warm-up
                     ts = []
                     for _ in range(reps):
@@ -284,18 +319,18 @@ class Plan:
                         lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
                         timer.stop(stream.cuda_stream)
                         ts.append(timer.elapsed_ms())
-                    results.append((min(ts), pt, ct))
+                    results.append((min(ts), pt, ct, tk))
                 results.sort()
-                best = (results[0][1], results[0][2])
+                best = (results[0][1], results[0][2], results[0][3])
                 _TUNE_CACHE[sig] = best
                 if verbose:
-                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d)%.1fus" % (p, c, t * 1e3) for t, p, c in results)))
-            pt, ct = best
-            if (pt, ct) != (o.tile_p, o.tile_c):
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, ",k4" if k == 4 else "", t * 1e3) for t, p, c, k in results)))
+            pt, ct, tk = best
+            if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
                 wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
                 bp = pack.pack_bias(b, ct).to(self.device)
                 self._tuned += [wp, bp]
-                o.tile_p, o.tile_c, o.w, o.bias = pt, ct, wp.data_ptr(), bp.data_ptr()
+                o.tile_p, o.tile_c, o.tile_k, o.w, o.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
                 changed += 1
         if changed:
             L.maf_engine_destroy(self._engine)
@@ -347,7 +382,7 @@ class Plan:
             else:
                 var = 1
             outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
-            return "conv_mfma_kernel<%s, %d, %d, %d, %s>" % (T, o.tile_p, o.tile_c, var, outf32)
+            return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false")
         if o.kind == lib.OP_DWCONV:
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]

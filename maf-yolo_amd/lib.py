@@ -22,7 +22,7 @@ class MafOp(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("ksize", C.c_int32), ("nsrc", C.c_int32),
                 ("src", MafSrc * 4), ("out", C.c_void_p), ("out_stride", C.c_int32), ("out_coff", C.c_int32),
-                ("out_f32", C.c_int32), ("tile_p", C.c_int32), ("tile_c", C.c_int32),
+                ("out_f32", C.c_int32), ("tile_p", C.c_int32), ("tile_c", C.c_int32), ("tile_k", C.c_int32),
                 ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("reg", C.c_void_p * 3), ("lvl_h", C.c_int32 * 3), ("lvl_w", C.c_int32 * 3),
                 ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3)]

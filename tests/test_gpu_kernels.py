@@ -79,6 +79,36 @@ def test_conv1x1_direct(dt, cin, cout, pt, ct, act):
     assert (out[..., :coff] == 7).all() and (out[..., coff + cout:] == 7).all(), "wrote outside its slice"
 
 
+@pytest.mark.parametrize("dt", [lib.F32, lib.F16])
+@pytest.mark.parametrize("kind", ["1x1", "3x3"])
+def test_conv_split_k(dt, kind):
+    """tile_k = 4: the four waves of a workgroup split the reduction (small maps, long K)."""
+    g = torch.Generator().manual_seed(9)
+    B, cin, cout, ct = 2, 384, 192, 6
+    if kind == "1x1":
+        H = W = 7
+        x = _q(torch.randn(B, cin, H, W, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [cin], ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(x, w, b))
+        opk, Hin, Win = lib.OP_CONV1X1, 0, 0
+    else:
+        cin = 96
+        Hin, Win = 10, 14
+        H, W = 5, 7
+        x = _q(torch.randn(B, cin, Hin, Win, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dt)
+        wp = pack.pack_conv3x3(w, ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(x, w, b, 2, 1))
+        opk = lib.OP_CONV3X3S2
+    bias = torch.randn(cout, generator=g)
+    out = torch.zeros(B, H, W, cout, dtype=DT[dt], device=DEV)
+    op = _conv_op(opk, dt, B, H, W, cin, cout, lib.ACT_SILU, [(_nhwc(x, dt), cin, cin, 0, 0)], out, cout, 0, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 1, ct, Hin=Hin, Win=Win)
+    op.tile_k = 4
+    _launch(op)
+    _check(out, ref_fn(bias), dt)
+
+
 def test_conv1x1_out_f32():
     g = torch.Generator().manual_seed(5)
     B, H, W, cin, cout = 1, 8, 8, 128, 68

@@ -248,4 +248,5 @@ def test_autotuned_tiles_give_identical_predictions(models):
         plan = m.plan_for(x)
         plan.autotune(x)
         tuned = m(x)[0]
-    assert torch.equal(base, tuned)          # a tile only re-cuts the (pixel, channel) space; every dot product keeps its order
+    # a tile only re-cuts the (pixel, channel) space; only the split-K variants change a summation order (fp32 partials)
+    _close16(tuned.cpu().numpy(), base.cpu().numpy())
