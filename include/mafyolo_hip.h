@@ -39,7 +39,8 @@ enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 c
        MAF_OP_CONV3X3S2 = 2,             /* RepVGGBlock / ConvWrapper 3x3 stride 2 pad 1 (+bias+act)    */
        MAF_OP_DWCONV = 3,                /* merged DilatedReparamBlock: depth-wise k x k s1 (+bias+act) */
        MAF_OP_SPPF_POOL = 4,             /* three chained MaxPool2d(5,1,2) into concat slices           */
-       MAF_OP_DECODE = 5 };              /* Detect_yaml eval branch: DFL decode -> [B,A,5+nc] fp32      */
+       MAF_OP_DECODE = 5,                /* Detect_yaml eval branch: DFL decode -> [B,A,5+nc] fp32      */
+       MAF_OP_BOTTLENECK = 6 };          /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
 enum { MAF_E_ARG = -1, MAF_E_UNSUPPORTED = -2, MAF_E_HIP = -3 };
 
 typedef struct {
@@ -66,6 +67,9 @@ typedef struct {
  *                   (rows, cols, channels per block); 0 = built-in cost model.
  * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
  *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
+ * MAF_OP_BOTTLENECK replaces one DepthBottleneckUni in deploy form (common.py:918-927): w/bias = W1 packed (tile_c 4, mid
+ *                   padded to 64-channel blocks) / b1; aux = depth-wise and second 1x1; tile_k = number of 64-channel mid
+ *                   blocks; tile_p x tile_c = output tile (rows x cols, 64/128/256 pixels); fp16 only, c <= 64.
  * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
  *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride];
  *                   out = pred fp32 [B, A, 5+nc].
@@ -89,6 +93,7 @@ typedef struct {
     int32_t lvl_h[3], lvl_w[3];
     int32_t reg_stride, nc, reg_max;
     float lvl_stride[3];
+    const void* aux[4];          /* BOTTLENECK: {wdw [k*k][mid_pad] f16, bdw fp32, W2 packed, b2 fp32}                  */
 } maf_op_t;
 
 const char* maf_last_error(void);

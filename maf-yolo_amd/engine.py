@@ -55,6 +55,7 @@ class Plan:
         self.nc = model.nc
         self.reg_max = model.detect.reg_max
         self.strides = [float(s) for s in model.detect.stride.tolist()]
+        self.fuse = getattr(model, "fuse_bottlenecks", True)
         with torch.no_grad():
             self._build(model)
         self._finalize()
@@ -126,8 +127,18 @@ class Plan:
                 self._conv1x1(p + ".conv1", *m.conv1.fused(), x, cat, 0, lib.ACT_SILU)
                 for d, blk in enumerate(m.m):
                     mid = blk.conv1.conv.out_channels
-                    t1, t2 = self._alloc(x.H, x.W, mid), self._alloc(x.H, x.W, mid)
                     q = "%s.m.%d" % (p, d)
+                    if self.fuse and self.dtype == lib.F16 and c_ <= 64 and c_ % 8 == 0:
+                        # the whole DepthBottleneckUni in one launch; its 3c-channel intermediates stay in LDS
+                        W1, b1p, wd, bdp, W2, b2p, nmb, ct2 = pack.pack_bottleneck(*blk.conv1.fused(), *blk.conv2.fused(), *blk.one_conv.fused())
+                        k = wd.shape[0]
+                        k = int(round(k ** 0.5))
+                        th, tw = (16, 16) if k <= 5 and c_ <= 48 else (8, 16)
+                        self._ops.append(dict(kind=lib.OP_BOTTLENECK, name=q, act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=c_, ksize=k, mid=mid,
+                                              segs=[Seg(cat, c_, (d + 1) * c_)], out=cat, out_coff=(d + 2) * c_, pt=th, ct=tw, tk=nmb,
+                                              w=self._wput(W1), b=self._wput(b1p), aux=[self._wput(wd), self._wput(bdp), self._wput(W2), self._wput(b2p)]))
+                        continue
+                    t1, t2 = self._alloc(x.H, x.W, mid), self._alloc(x.H, x.W, mid)
                     self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(cat, c_, (d + 1) * c_)], x.H, x.W), t1, 0, lib.ACT_SILU)
                     self._dw(q + ".conv2", *blk.conv2.fused(), TV([Seg(t1, mid)], x.H, x.W), t2, lib.ACT_SILU)
                     self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), cat, (d + 2) * c_, lib.ACT_SILU)
@@ -217,9 +228,14 @@ class Plan:
             o.out_coff = r["out_coff"]
             o.out_f32 = r.get("out_f32", 0)
             o.tile_p, o.tile_c, o.tile_k = r.get("pt", 0), r.get("ct", 0), (1 if r["kind"] in (lib.OP_CONV1X1, lib.OP_CONV3X3S2) else 0)
+            o.ksize = r.get("ksize", 0)
             if "w" in r:
                 o.w = wbase + r["w"]
                 o.bias = wbase + r["b"]
+            if r["kind"] == lib.OP_BOTTLENECK:
+                o.tile_k = r["tk"]
+                for k_, off in enumerate(r["aux"]):
+                    o.aux[k_] = wbase + off
             if r["kind"] == lib.OP_STEM:
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call
@@ -283,6 +299,35 @@ class Plan:
                         print("tune %-32s %dx%d C=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d,%d)%.1fus" % (a, b2, c2, t * 1e3) for t, a, b2, c2 in results[:6])))
                 if tuple(best) != (o.tile_p, o.tile_c, o.tile_k):
                     o.tile_p, o.tile_c, o.tile_k = best
+                    changed += 1
+                continue
+            if o.kind == lib.OP_BOTTLENECK:
+                sig = (o.kind, self.B, o.H, o.W, o.Cin, o.ksize, o.tile_k)
+                best = _TUNE_CACHE.get(sig)
+                if best is None:
+                    results = []
+                    for th, tw in ((8, 8), (4, 16), (8, 16), (16, 8), (4, 32), (16, 16), (8, 32)):
+                        npix = (th + o.ksize - 1) * (tw + o.ksize - 1)
+                        lds = (npix * (-(-o.Cin // 32) * 32 + 8) + npix * 72 + th * tw * 72 + o.ksize * o.ksize * 64) * 2
+                        if lds > 160 * 1024:
+                            continue
+                        op = lib.MafOp.from_buffer_copy(o)
+                        op.tile_p, op.tile_c = th, tw
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        ts = []
+                        for _ in range(reps):
+                            timer.start(stream.cuda_stream)
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            timer.stop(stream.cuda_stream)
+                            ts.append(timer.elapsed_ms())
+                        results.append((min(ts), th, tw))
+                    results.sort()
+                    best = results[0][1:]
+                    _TUNE_CACHE[sig] = best
+                    if verbose:
+                        print("tune %-32s %dx%d c=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d)%.1fus" % (a, b2, t * 1e3) for t, a, b2 in results)))
+                if tuple(best) != (o.tile_p, o.tile_c):
+                    o.tile_p, o.tile_c = best
                     changed += 1
                 continue
             if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
@@ -385,6 +430,8 @@ class Plan:
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false")
         if o.kind == lib.OP_DWCONV:
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
+        if o.kind == lib.OP_BOTTLENECK:
+            return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, 2 if o.Cout <= 32 else 4, o.tile_p * o.tile_c // 64)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -407,6 +454,9 @@ class Plan:
             return self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.Cin * es + o.ksize * o.ksize * o.Cin * es
+        if o.kind == lib.OP_BOTTLENECK:
+            mid = o.tile_k * 64
+            return px * (o.Cin + o.Cout) * es + (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
         if o.kind == lib.OP_SPPF_POOL:
             return 4 * px * o.src[0].C * es
         if o.kind == lib.OP_DECODE:
@@ -424,6 +474,9 @@ class Plan:
             return 2 * px * 9 * o.Cin * o.Cout
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.ksize * o.ksize * o.Cin
+        if o.kind == lib.OP_BOTTLENECK:
+            mid = self._ops[idx]["mid"]
+            return 2 * px * (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout)
         return 0
 
     def launch_op(self, idx, image_ptr=None, pred_ptr=None):

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libmafyolo_hip.so")
 F16, F32, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_DIRECT, SRC_UP2, SRC_POOL2 = 0, 1, 2
-OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE = range(6)
+OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE, OP_BOTTLENECK = range(7)
 
 
 class MafSrc(C.Structure):
@@ -25,7 +25,8 @@ class MafOp(C.Structure):
                 ("out_f32", C.c_int32), ("tile_p", C.c_int32), ("tile_c", C.c_int32), ("tile_k", C.c_int32),
                 ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("reg", C.c_void_p * 3), ("lvl_h", C.c_int32 * 3), ("lvl_w", C.c_int32 * 3),
-                ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3)]
+                ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3),
+                ("aux", C.c_void_p * 4)]
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",

@@ -92,3 +92,24 @@ def pack_dw(w, dtype):
 def pack_stem(w):
     """w [Cout, 3, 3, 3] -> fp32 [27, Cout], row = (c*3 + ky)*3 + kx."""
     return w.float().cpu().reshape(w.shape[0], 27).t().contiguous()
+
+
+def pack_bottleneck(w1, b1, wdw, bdw, w2, b2):
+    """Operands of MAF_OP_BOTTLENECK (csrc/bottleneck.hip), fp16: the mid channels are cut into 64-channel blocks.
+
+    w1 [mid, c, 1, 1], wdw [mid, 1, k, k], w2 [c, mid, 1, 1] (+ fp32 biases).  Returns (W1 packed, b1 pad, wdw [k*k][mid_pad],
+    bdw pad, W2 packed per block, b2 pad, n_blocks, ct2)."""
+    mid, c = w1.shape[0], w1.shape[1]
+    k = wdw.shape[-1]
+    nmb = -(-mid // 64)
+    mp = nmb * 64
+    w1p = torch.zeros(mp, c); w1p[:mid] = w1.reshape(mid, c).float().cpu()
+    W1 = pack_matrix([w1p], 4, lib.F16)                                   # [nmb*4, steps1, 64, 8]
+    b1p = torch.zeros(mp); b1p[:mid] = b1.float().cpu()
+    wd = torch.zeros(k * k, mp); wd[:, :mid] = wdw.float().cpu().reshape(mid, k * k).t()
+    bdp = torch.zeros(mp); bdp[:mid] = bdw.float().cpu()
+    ct2 = 2 if c <= 32 else 4
+    w2f = torch.zeros(c, mp); w2f[:, :mid] = w2.reshape(c, mid).float().cpu()
+    W2 = torch.cat([pack_matrix([w2f[:, m * 64:(m + 1) * 64]], ct2, lib.F16) for m in range(nmb)], 0)   # [nmb*ct2, 2, 64, 8]
+    b2p = torch.zeros(16 * ct2); b2p[:c] = b2.float().cpu()
+    return W1.contiguous(), b1p, wd.to(torch.float16).contiguous(), bdp, W2.contiguous(), b2p, nmb, ct2
