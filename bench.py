@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
+    ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
+    ap.add_argument("--tune-file", default=None,
+                    help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
@@ -189,6 +192,11 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.autotune = not args.no_autotune      # per-layer MFMA tile selection when the plan is built (outside the timed region)
+    if args.fuse >= 0:
+        model.fuse_bottlenecks = bool(args.fuse)
+    from maf_yolo_amd import engine as _engine
+    if args.tune_file and os.path.exists(args.tune_file):
+        _engine.load_tune_cache(args.tune_file)
     B = args.batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev).half()
     shift = calibrate_cls_bias(model, x, 2000, M, torch)
@@ -196,6 +204,8 @@ def main():
     with torch.no_grad():
         cand = (model(x)[0][..., 5:] > conf).sum((1, 2))
     cand_mean, cand_max = float(cand.float().mean()), int(cand.max())
+    if args.tune_file and rank == 0 and not os.path.exists(args.tune_file):
+        _engine.save_tune_cache(args.tune_file)
 
     def step():
         with torch.no_grad():
@@ -291,9 +301,10 @@ def main():
                                            mfma_frac=round(tot_flops / (fwd_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 5)))
         if args.per_op:
             order = np.argsort(-per_op_ms)
-            for i in order[:40]:
+            for i in order:
                 gb = plan.algorithmic_bytes(i) / (per_op_ms[i] * 1e-3) / 1e9
-                print("%-34s %-44s %8.4f ms %8.1f GB/s" % (plan.op_names[i], plan.kernel_name(i), per_op_ms[i], gb), file=sys.stderr)
+                o = plan.ops[i]
+                print("%-34s %-44s %8.4f ms %8.1f GB/s  %dx%d %d->%d k%d" % (plan.op_names[i], plan.kernel_name(i), per_op_ms[i], gb, o.H, o.W, o.Cin, o.Cout, o.ksize), file=sys.stderr)
             for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
                 print("GROUP %-46s n=%2d total %8.4f ms  avg %8.4f ms  %8.1f GB/s" %
                       (k, g["n"], g["ms"], g["ms"] / g["n"], g["bytes"] / (g["ms"] * 1e-3) / 1e9), file=sys.stderr)

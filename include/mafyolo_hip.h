@@ -67,9 +67,11 @@ typedef struct {
  *                   (rows, cols, channels per block); 0 = built-in cost model.
  * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
  *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
- * MAF_OP_BOTTLENECK replaces one DepthBottleneckUni in deploy form (common.py:918-927): w/bias = W1 packed (tile_c 4, mid
- *                   padded to 64-channel blocks) / b1; aux = depth-wise and second 1x1; tile_k = number of 64-channel mid
- *                   blocks; tile_p x tile_c = output tile (rows x cols, 64/128/256 pixels); fp16 only, c <= 64.
+ * MAF_OP_BOTTLENECK replaces one DepthBottleneckUni in deploy form (common.py:918-927: 1x1 c->3c + SiLU, depth-wise k x k + SiLU,
+ *                   1x1 3c->c + SiLU) in one launch.  w = tile_k block records of maf_bottleneck_record_bytes() bytes, one per
+ *                   32 mid channels: W1 fragments [2][S1][64][8] f16 | b1 [32] f32 | Toeplitz table of the depth-wise filter
+ *                   [8][k][parts][16][8] f16 | W2 fragments [CT2][64][8] f16 | bdw [32] f32 (maf-yolo_amd/pack.py:
+ *                   pack_bottleneck); bias = b2 fp32 padded to 16*CT2.  fp16 only, Cin = Cout = c <= 64, act = SiLU.
  * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
  *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride];
  *                   out = pred fp32 [B, A, 5+nc].
@@ -93,11 +95,13 @@ typedef struct {
     int32_t lvl_h[3], lvl_w[3];
     int32_t reg_stride, nc, reg_max;
     float lvl_stride[3];
-    const void* aux[4];          /* BOTTLENECK: {wdw [k*k][mid_pad] f16, bdw fp32, W2 packed, b2 fp32}                  */
+    const void* aux[4];          /* reserved (0)                                                                        */
 } maf_op_t;
 
 const char* maf_last_error(void);
 int maf_version(void);
+/* Bytes of one 32-mid-channel block record of MAF_OP_BOTTLENECK for kernel size k and c = Cin = Cout channels. */
+int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

@@ -1,239 +1,313 @@
 // Fused DepthBottleneckUni (deploy form): 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU -> 1x1 (3c -> c) + SiLU in ONE
-// kernel, the two 3c-channel intermediates never leave the CU.
+// kernel; the two 3c-channel intermediates never leave the CU and all three convolutions run on the matrix cores.
 //
 // Replaces, for one bottleneck, Conv.forward_fuse x2 + the merged UniRepLKNetBlock + DepthBottleneckUni.act of
 // yolov6/layers/common.py:918-927 (conv1 :905, conv2 :908, act :909, one_conv :910) — three launches that wrote and
-// re-read the 3c-wide tensors twice (4.9 MB x 2 per image at 80x80: SURVEY.md §8 a5 "prime fusion target").
+// re-read the 3c-wide tensors twice: per bottleneck the HBM traffic drops from (2c + 12c) to 2c channels per pixel.
 //
-// One workgroup = one TH x TW output tile of one image.  LDS holds the c-channel input halo tile X, and per block of
-// 64 mid channels the 1x1 output T1 on the halo tile and the depth-wise output T2 on the tile:
-//   for each mid block:   A. T1 = SiLU(X * W1[:, block] + b1)      MFMA, A fragments = ds_read_b128 of X rows, zero outside the image
-//                         B. T2 = SiLU(DW_k(T1) + bdw)             VALU (v_fma_mix_f32), 4-pixel strips per lane as in dwconv.hip
-//                         C. acc += T2 * W2[block, :]              MFMA, accumulators stay in registers across the blocks
-//   epilogue: out = SiLU(acc + b2), contiguous NHWC rows into the concat slice.
-// The 1x1 on the halo is recomputed ((TH+k-1)(TW+k-1)/(TH*TW) times) — cheap, its K is only c — in exchange for never
-// writing T1/T2: per bottleneck the HBM traffic drops from (2c + 12c) to 2c channels per pixel.
-// fp16 storage, fp32 accumulation everywhere (same arithmetic as the three separate kernels up to the fp16 rounding of
-// T1/T2, which those kernels apply as well when they store them).
+// One workgroup (4 waves) = one 16 x 16 output tile of one image; the mid channels are processed in blocks of 32:
+//
+//   A. T1 = SiLU(X * W1[:, block] + b1) on the (16+k-1)^2 halo tile     MFMA 16x16x32; A fragments are 16-byte global loads
+//      (exact zeros outside the image = the depth-wise conv's padding); T1 goes to LDS *planar* ([channel][row][x], 8-byte
+//      stores of the 4 consecutive pixels an accumulator lane owns).
+//   B. T2 = SiLU(DW_k(T1) + bdw)                                          MFMA 16x16x32 with a block-diagonal Toeplitz operand:
+//      one instruction convolves FOUR channels along x for one tap row ky:  A[(G,r)][(g,j)] = (G==g) * w[ch_G][ky][j - r]
+//      (4 outputs x 8-wide input window per channel), B[(g,j)][n] = T1[ch_g][row n + ky][x window j] — a 16-byte LDS read per
+//      lane; k instructions (2k for k > 5: two windows) accumulate a [4 ch][4 x][16 rows] block.  ~15 % of the MACs are useful
+//      and it still is 5-9x the VALU rate (v_fma_mix: 16 MAC/clk/SIMD; this: 80-144).
+//      After the 8 channel sets of a block, lane (G, n) holds channels 8G..8G+7 of pixels (row n, x = 4q + 0..3) — which IS
+//      the A fragment of the second 1x1 (lane (g, i): 8 consecutive k of row i), so T2 never touches LDS.
+//   C. acc2 += T2 * W2[block, :]                                          MFMA, accumulators stay in registers across blocks
+//   epilogue: out = SiLU(acc2 + b2), NHWC into the concat slice.
+//
+// The 1x1 on the halo is recomputed ((16+k-1)^2/256 times: its K is only c).  The remaining VALU work is the two SiLUs.
+// fp16 storage, fp32 accumulation (same arithmetic as the three separate kernels up to the fp16 rounding of T1/T2, which
+// those kernels apply when they store them; the depth-wise weights are fp16 there too).
 #include "maf_common.h"
+#include <type_traits>
 
 namespace {
 
-constexpr int MB = 64;                 // mid channels per block
-constexpr int PADH = 8;                // LDS row pad in halfs (16 B): consecutive rows start on different bank groups
-
 struct BnArgs {
     const half_t* x; half_t* out;
-    const half8_t* w1; const half8_t* w2; const half_t* wdw;
-    const float* b1; const float* bdw; const float* b2;
+    const unsigned char* par;   // [nMB] block records: Toeplitz [8][K][PARTS][16] half8 | W1 fragments [2][S1][64] half8 | W2 fragments [CT2][64] half8 | b1 [32] f32 | bdw [32] f32
+    const float* b2;
     int B, H, W, Cin, Cout, nMB, x_stride, x_coff, out_stride, out_coff;
-    int TH, TW, tilesX, tilesY, nwg, act_mid;
+    int tilesX, tilesY, nwg;
 };
 
-__device__ __forceinline__ void vmac8(float (&acc)[8], const half8_t& v, const half8_t& w) {
-    const u32x4_t a = __builtin_bit_cast(u32x4_t, v), b = __builtin_bit_cast(u32x4_t, w);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q]) : "v"(a[q]), "v"(b[q]));
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q + 1]) : "v"(a[q]), "v"(b[q]));
+typedef half_t half4v_t __attribute__((ext_vector_type(4)));
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void maf_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        maf_static_for<N, I + 1>(f);
     }
 }
 
-template <int K, int CT2, int MT2>     // MT2 = output m-tiles (16 pixels) per wave = TH*TW/64
-__global__ __launch_bounds__(256) void bottleneck_kernel(const BnArgs a) {
-    constexpr int P = K / 2, R = 4;
+template <int K, int S1, int CT2>
+struct BnCfg {
+    static constexpr int P = K / 2, PARTS = K > 5 ? 2 : 1;
+    static constexpr int RH = 16 + K - 1;                          // halo rows
+    static constexpr int RWC = (16 + K - 1 + 3) & ~3;              // halo columns computed (whole 4-pixel runs)
+    static constexpr int NHP = RH * RWC, NPT = (NHP + 15) / 16;    // halo pixels, 16-pixel m-tiles
+    static constexpr int MT = (NPT + 3) / 4;                       // m-tiles per wave
+    static constexpr int RWP = 24;                                 // T1 row stride in halfs: 48 B — the 16 rows of a B fragment tile the 256-B bank row
+    static constexpr int PSB = ((RH * RWP * 2 - 8 + 255) / 256) * 256 + 8;     // channel plane stride in bytes, = 8 (mod 256): see the bank notes below
+    static constexpr int PS = PSB / 2;
+    static constexpr int NTOE = 8 * K * PARTS * 16;                // Toeplitz entries (16 B each) per block
+    // block record = part A (operands of the first 1x1: W1 | b1) + part B (depth-wise + second 1x1: Toeplitz | W2 | bdw)
+    static constexpr int OFF_W1 = 0, OFF_B1 = 2 * S1 * 1024, REC_A = OFF_B1 + 128;
+    static constexpr int OFF_TOE = REC_A, OFF_W2 = OFF_TOE + NTOE * 16, OFF_BD = OFF_W2 + CT2 * 1024;
+    static constexpr int REC = OFF_BD + 128;                       // bytes per block record
+    static constexpr int NVA = (REC_A / 16 + 255) / 256, NVB = ((REC - REC_A) / 16 + 255) / 256;   // 16-byte vectors per thread per part
+    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC;
+};
+
+template <int K, int S1, int CT2>
+__global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
+    typedef BnCfg<K, S1, CT2> Cf;
+    constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS, NVA = Cf::NVA, NVB = Cf::NVB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t* T1 = reinterpret_cast<half_t*>(smem_raw);                        // [32][PS]
+    unsigned char* rec = smem_raw + 32 * Cf::PSB;                            // [REC]: the current block's operands (each part is refilled as soon as its phase is over)
+
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
     int lid;
-    {
+    {   // XCD-contiguous tile order: neighbouring tiles (shared halos) run on the same XCD's L2
         const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
         const int q = a.nwg >> 3, r = a.nwg & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int tx = lid % a.tilesX;
-    int t = lid / a.tilesX;
-    const int ty = t % a.tilesY;
-    const int b = t / a.tilesY;
-    const int y0 = ty * a.TH, x0 = tx * a.TW;
-    const int RH = a.TH + K - 1, RW = a.TW + K - 1, NP = RH * RW, NPT = (NP + 15) >> 4;
-    const int steps1 = (a.Cin + 31) >> 5;
-    const int XS = steps1 * 32 + PADH, TS = MB + PADH;            // LDS row strides (halfs); X rows padded to whole k-steps
-    half_t* Xs = reinterpret_cast<half_t*>(smem_raw);             // [NP][XS]
-    half_t* T1 = Xs + (size_t)NP * XS;                            // [NP][TS]
-    half_t* T2 = T1 + (size_t)NP * TS;                            // [TH*TW][TS]
-    half_t* Wd = T2 + (size_t)a.TH * a.TW * TS;                   // [K*K][MB]
+    const int tt = lid / a.tilesX;
+    const int ty = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const half_t* xin = a.x + (size_t)b * a.H * a.W * a.x_stride + a.x_coff;
 
-    {   // ---- stage the input halo tile (zero outside the image and beyond Cin up to whole k-steps)
-        const int cgs = steps1 * 4;                                // 16-byte chunks per row incl. k-step padding
-        const half_t* xin = a.x + a.x_coff;
-        for (int idx = tid; idx < NP * cgs; idx += 256) {
-            const int cg = idx % cgs, pix = idx / cgs;
-            const int rx = pix % RW, ry = pix / RW;
-            const int iy = y0 - P + ry, ix = x0 - P + rx;
-            half8_t v = (half8_t)(half_t)0;
-            if (cg * 8 < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const half8_t*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cg * 8);
-            *reinterpret_cast<half8_t*>(Xs + (size_t)pix * XS + cg * 8) = v;
-        }
-    }
-    f32x4_t acc2[MT2][CT2];
+    // the wave's share of the halo pixels (m-tiles wave, wave + 4, ...): the same global addresses for every block.
+    // Loads are unconditional: pixels outside the image are clamped to a valid pixel (their T1 is forced to zero when it is
+    // written) and channel groups beyond Cin to group 0 (their W1 rows are zero), so no lane ever reads outside the tensor.
+    const int cg0 = g * 8 < a.Cin ? g * 8 : 0;
+    const int cg1 = 32 + g * 8 < a.Cin ? 32 + g * 8 : 0;
+    uint32_t xoff[MT];
 #pragma unroll
-    for (int i = 0; i < MT2; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wave + 4 * i) * 16 + p;
+        const int hr = m / RWC, hc = m - hr * RWC;
+        const int iy = min(max(y0 - P + hr, 0), a.H - 1), ix = min(max(x0 - P + hc, 0), a.W - 1);
+        xoff[i] = (uint32_t)(iy * a.W + ix) * a.x_stride;
+    }
+    constexpr int XD = 2;                                   // activation fragments are loaded XD m-tiles ahead of their MFMAs
+    half8_t af[XD + 1][S1];
+    auto load_x = [&](auto idx) {
+        constexpr int i = decltype(idx)::value;
+        if constexpr (i < MT) {
+            af[i % (XD + 1)][0] = *reinterpret_cast<const half8_t*>(xin + xoff[i] + cg0);
+            if constexpr (S1 > 1) af[i % (XD + 1)][1] = *reinterpret_cast<const half8_t*>(xin + xoff[i] + cg1);
+        }
+    };
+    auto load_x_head = [&]() {
+        load_x(std::integral_constant<int, 0>{});
+        load_x(std::integral_constant<int, 1>{});
+    };
+    // zero mask of the T1 values this lane writes: accumulator lane (g, p) of m-tile t owns halo pixels t*16 + 4g .. +3
+    // (one row, 4 consecutive columns); bit r set = pixel r is inside the image.  interior tiles: all ones.
+    const bool interior = y0 - P >= 0 && x0 - P >= 0 && y0 - P + Cf::RH <= a.H && x0 - P + RWC <= a.W;
+    // The next block's record travels global -> registers (in flight during a whole phase) -> LDS.
+    u32x4_t prA[NVA], prB[NVB];
+    auto load_part = [&](int mb, auto& pr, auto nv, int off, int bytes) {
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.par + (size_t)mb * Cf::REC + off);
+#pragma unroll
+        for (int v = 0; v < decltype(nv)::value; ++v)
+            if (tid + v * 256 < bytes / 16) pr[v] = src[tid + v * 256];
+    };
+    auto store_part = [&](auto& pr, auto nv, int off, int bytes) {
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(rec + off);
+#pragma unroll
+        for (int v = 0; v < decltype(nv)::value; ++v)
+            if (tid + v * 256 < bytes / 16) dst[tid + v * 256] = pr[v];
+    };
+    const std::integral_constant<int, NVA> nva{};
+    const std::integral_constant<int, NVB> nvb{};
+
+    f32x4_t acc2[4][CT2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int ct = 0; ct < CT2; ++ct) acc2[i][ct] = (f32x4_t)0.f;
+
+    const bool toe_active = (p >> 2) == g;                  // block-diagonal Toeplitz: lane (g, (G, r)) is non-zero iff G == g
+    const int q4 = wave * 4;                                // this wave's 4 output columns
+    int hi_off = 4;
+    asm volatile("" : "+v"(hi_off));                        // opaque: the two 8-byte halves of a window stay two ds_read_b64 (2 LDS cycles each; ds_read2_b64 costs 8)
+
+    load_part(0, prA, nva, 0, Cf::REC_A);
+    load_part(0, prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);
+    load_x_head();
+    store_part(prA, nva, 0, Cf::REC_A);
     __syncthreads();
 
     for (int mb = 0; mb < a.nMB; ++mb) {
-        // ---- A. T1 = act(X * W1[:, block] + b1) on the halo tile; exact zeros outside the image (the DW's padding)
-        for (int i = tid; i < K * K * (MB / 8); i += 256)
-            *reinterpret_cast<half8_t*>(Wd + i * 8) = *reinterpret_cast<const half8_t*>(a.wdw + (size_t)(i / (MB / 8)) * (a.nMB * MB) + mb * MB + (i % (MB / 8)) * 8);
-        const float bl0 = a.b1[mb * MB + p * 4 + 0], bl1 = a.b1[mb * MB + p * 4 + 1], bl2 = a.b1[mb * MB + p * 4 + 2], bl3 = a.b1[mb * MB + p * 4 + 3];
-        for (int mt = wave; mt < NPT; mt += 4) {
-            f32x4_t acc1[4];
+        store_part(prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);     // part B of this block (loaded during the previous block's phase B)
+        if (mb + 1 < a.nMB) load_part(mb + 1, prA, nva, 0, Cf::REC_A);
+        // ---- A. T1 = SiLU(X * W1[:, block] + b1) on the halo tile
+        {
+            half8_t w1f[2][S1];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc1[ct] = (f32x4_t)0.f;
-            const int prow = min(mt * 16 + p, NP - 1);
-            for (int ks = 0; ks < steps1; ++ks) {
-                const half8_t av = *reinterpret_cast<const half8_t*>(Xs + (size_t)prow * XS + ks * 32 + g * 8);
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    const half8_t bv = a.w1[((size_t)(mb * 4 + ct) * steps1 + ks) * 64 + lane];
-                    acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc1[ct], 0, 0, 0);
+                for (int ks = 0; ks < S1; ++ks) w1f[ct][ks] = reinterpret_cast<const half8_t*>(rec + Cf::OFF_W1)[(ct * S1 + ks) * 64 + lane];
+            const float b1v0 = reinterpret_cast<const float*>(rec + Cf::OFF_B1)[p], b1v1 = reinterpret_cast<const float*>(rec + Cf::OFF_B1)[16 + p];
+            maf_static_for<MT>([&](auto idx) {
+                constexpr int i = decltype(idx)::value;
+                const int t = wave + 4 * i;
+                load_x(std::integral_constant<int, i + XD>{});
+                f32x4_t acc1[2] = {(f32x4_t)0.f, (f32x4_t)0.f};
+#pragma unroll
+                for (int ks = 0; ks < S1; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % (XD + 1)][ks], w1f[ct][ks], acc1[ct], 0, 0, 0);
+                const int m0 = t * 16 + g * 4;
+                const int hr = m0 / RWC, hc0 = m0 - hr * RWC;
+                uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;          // per-half keep masks for pixels (0,1) and (2,3)
+                if (!interior) {
+                    const int iy = y0 - P + hr, ixb = x0 - P + hc0;
+                    const bool rowok = (unsigned)iy < (unsigned)a.H;
+                    const uint32_t k0 = (rowok && (unsigned)(ixb + 0) < (unsigned)a.W) ? 0x0000ffffu : 0u, k1 = (rowok && (unsigned)(ixb + 1) < (unsigned)a.W) ? 0xffff0000u : 0u;
+                    const uint32_t k2 = (rowok && (unsigned)(ixb + 2) < (unsigned)a.W) ? 0x0000ffffu : 0u, k3 = (rowok && (unsigned)(ixb + 3) < (unsigned)a.W) ? 0xffff0000u : 0u;
+                    mlo = k0 | k1; mhi = k2 | k3;
+                }
+                half_t* dst = T1 + (size_t)p * PS + hr * RWP + hc0;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float bv = ct ? b1v1 : b1v0;
+                    const half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0] + bv), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1] + bv)};
+                    const half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2] + bv), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3] + bv)};
+                    const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
+                    if (m0 < NHP) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;
+                }
+            });
+        }
+        __syncthreads();
+        if (mb + 1 < a.nMB) {
+            store_part(prA, nva, 0, Cf::REC_A);             // phase A is over: its operands can be replaced
+            load_part(mb + 1, prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);
+        }
+
+        // ---- B. depth-wise k x k on the matrix cores: 8 channel sets s (channels 8g + s), k tap rows, PARTS windows
+        f32x4_t dacc[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dacc[s] = (f32x4_t)0.f;
+        const half8_t* toe = reinterpret_cast<const half8_t*>(rec + Cf::OFF_TOE) + p;
+        // lane (g, n = p): plane 4s + g, row n (+ky), window at column 4q, read as two 8-byte halves.  Banks: the 16 rows of a
+        // lane group are 48 B apart (all 16-byte slots of the 256-B bank row once) and the planes of g and g+1 are 8 B (mod 256)
+        // apart, so the 32 lanes of a ds_read_b64 group cover the 64 banks exactly once; the 8-byte stores of phase A
+        // (16 consecutive planes per group, 8 B apart mod 128) are conflict-free for the same reason.
+        const half_t* t1l = T1 + (size_t)g * PS + p * RWP + q4;
+        const half_t* t1h = t1l + hi_off;
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    half8_t av = (half8_t)(half_t)0;
+                    if (toe_active) av = toe[((s * K + ky) * PARTS + part) * 16];      // the other 48 lanes hold the zeros of the block-diagonal
+                    const int o = s * 4 * PS + ky * RWP + part * 4;
+                    const half4v_t lo = *reinterpret_cast<const half4v_t*>(t1l + o), hi = *reinterpret_cast<const half4v_t*>(t1h + o);
+                    const half8_t bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, dacc[s], 0, 0, 0);
                 }
             }
+        }
+        // ---- C. lane (g, n) now owns channels 4s + g (s = 0..7: k index 8g + s of the packed W2) of pixels (row n, x = 4q + r): the A fragments of the second 1x1
+        {
+            const f32x4_t bd0 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2], bd1 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2 + 1];
+            const float bd[8] = {bd0[0], bd0[1], bd0[2], bd0[3], bd1[0], bd1[1], bd1[2], bd1[3]};
+            half8_t w2f[CT2];
+#pragma unroll
+            for (int ct = 0; ct < CT2; ++ct) w2f[ct] = reinterpret_cast<const half8_t*>(rec + Cf::OFF_W2)[ct * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int pix = mt * 16 + g * 4 + r;
-                if (pix < NP) {
-                    const int rx = pix % RW, ry = pix / RW;
-                    const bool in = (unsigned)(y0 - P + ry) < (unsigned)a.H && (unsigned)(x0 - P + rx) < (unsigned)a.W;
-                    half4_t h;
-                    h[0] = in ? (half_t)maf_act<MAF_ACT_SILU>(acc1[0][r] + bl0) : (half_t)0;
-                    h[1] = in ? (half_t)maf_act<MAF_ACT_SILU>(acc1[1][r] + bl1) : (half_t)0;
-                    h[2] = in ? (half_t)maf_act<MAF_ACT_SILU>(acc1[2][r] + bl2) : (half_t)0;
-                    h[3] = in ? (half_t)maf_act<MAF_ACT_SILU>(acc1[3][r] + bl3) : (half_t)0;
-                    *reinterpret_cast<half4_t*>(T1 + (size_t)pix * TS + p * 4) = h;
-                }
+                half8_t t2;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) t2[s] = (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r] + bd[s]);
+#pragma unroll
+                for (int ct = 0; ct < CT2; ++ct) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);
             }
         }
-        __syncthreads();
-        // ---- B. T2 = act(DW_k(T1) + bdw): lane = one 8-channel group x a 4-pixel strip of one tile row
-        {
-            const int NSX = a.TW / R;
-            const int items = a.TH * NSX * (MB / 8);
-            for (int it = tid; it < items; it += 256) {
-                const int cgi = it % (MB / 8), u = it / (MB / 8);
-                const int s = u % NSX, ry = u / NSX;
-                float acc[R][8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float bv = a.bdw[mb * MB + cgi * 8 + j];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r][j] = bv;
-                }
-#pragma unroll 1
-                for (int ky = 0; ky < K; ++ky) {
-                    const half_t* row = T1 + (size_t)((ry + ky) * RW + s * R) * TS + cgi * 8;
-                    half8_t wv[K];
-#pragma unroll
-                    for (int kx = 0; kx < K; ++kx) wv[kx] = *reinterpret_cast<const half8_t*>(Wd + (ky * K + kx) * MB + cgi * 8);
-#pragma unroll
-                    for (int i = 0; i < R + K - 1; ++i) {
-                        const half8_t v = *reinterpret_cast<const half8_t*>(row + (size_t)i * TS);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int kx = i - r;
-                            if (kx >= 0 && kx < K) vmac8(acc[r], v, wv[kx]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    half8_t o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (half_t)(a.act_mid ? maf_act<MAF_ACT_SILU>(acc[r][j]) : acc[r][j]);
-                    *reinterpret_cast<half8_t*>(T2 + (size_t)(ry * a.TW + s * R + r) * TS + cgi * 8) = o;
-                }
-            }
+        if (mb + 1 < a.nMB) {
+            load_x_head();                                  // the next phase A's first activations (L1/L2 hits), in flight across the barrier
+            __syncthreads();                                // phase B has finished reading T1 and part B; part A of the next block is visible
         }
-        __syncthreads();
-        // ---- C. acc2 += T2 * W2[block, :]
-#pragma unroll
-        for (int i = 0; i < MT2; ++i) {
-            const int mt2 = wave * MT2 + i;
-#pragma unroll
-            for (int ks = 0; ks < MB / 32; ++ks) {
-                const half8_t av = *reinterpret_cast<const half8_t*>(T2 + (size_t)(mt2 * 16 + p) * TS + ks * 32 + g * 8);
-#pragma unroll
-                for (int ct = 0; ct < CT2; ++ct) {
-                    const half8_t bv = a.w2[((size_t)(mb * CT2 + ct) * (MB / 32) + ks) * 64 + lane];
-                    acc2[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc2[i][ct], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
     }
 
-    // ---- epilogue: out = SiLU(acc2 + b2); lane (g, p) owns channels p*CT2 .. p*CT2+CT2-1 of 4 pixels per m-tile
+    // ---- epilogue: out = SiLU(acc2 + b2); accumulator lane (g, p), register rr: pixel (row 4g + rr, x = 4q + r), channels p*CT2 ..
     float bias2[CT2];
 #pragma unroll
     for (int ct = 0; ct < CT2; ++ct) bias2[ct] = a.b2[p * CT2 + ct];
     const int nvalid = a.Cout - p * CT2;
+    half_t* obase = a.out + (size_t)b * a.H * a.W * a.out_stride + a.out_coff + p * CT2;
 #pragma unroll
-    for (int i = 0; i < MT2; ++i) {
+    for (int r = 0; r < 4; ++r) {
+        const int ox = x0 + q4 + r;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = (wave * MT2 + i) * 16 + g * 4 + r;
-            const int oy = y0 + idx / a.TW, ox = x0 + idx % a.TW;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int oy = y0 + g * 4 + rr;
             if (oy >= a.H || ox >= a.W) continue;
-            half_t* op = a.out + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + p * CT2;
+            half_t* op = obase + ((size_t)oy * a.W + ox) * a.out_stride;
             if (nvalid >= CT2) {
                 uint32_t w[CT2 / 2];
 #pragma unroll
-                for (int q = 0; q < CT2 / 2; ++q) {
-                    const half2_t h = {(half_t)maf_act<MAF_ACT_SILU>(acc2[i][2 * q][r] + bias2[2 * q]), (half_t)maf_act<MAF_ACT_SILU>(acc2[i][2 * q + 1][r] + bias2[2 * q + 1])};
-                    w[q] = __builtin_bit_cast(uint32_t, h);
+                for (int c2 = 0; c2 < CT2 / 2; ++c2) {
+                    const half2_t h = {(half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2][rr] + bias2[2 * c2]),
+                                       (half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2 + 1][rr] + bias2[2 * c2 + 1])};
+                    w[c2] = __builtin_bit_cast(uint32_t, h);
                 }
                 if (CT2 == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT2 / 2)]};
                 else *reinterpret_cast<uint32_t*>(op) = w[0];
             } else {
 #pragma unroll
                 for (int ct = 0; ct < CT2; ++ct)
-                    if (ct < nvalid) op[ct] = (half_t)maf_act<MAF_ACT_SILU>(acc2[i][ct][r] + bias2[ct]);
+                    if (ct < nvalid) op[ct] = (half_t)maf_act<MAF_ACT_SILU>(acc2[r][ct][rr] + bias2[ct]);
             }
         }
     }
 }
 
-size_t bn_lds(int TH, int TW, int K, int Cin) {
-    const size_t NP = (size_t)(TH + K - 1) * (TW + K - 1);
-    const int steps1 = (Cin + 31) / 32;
-    return (NP * (size_t)(steps1 * 32 + PADH) + NP * (MB + PADH) + (size_t)TH * TW * (MB + PADH) + (size_t)K * K * MB) * 2;
+template <int K, int S1, int CT2>
+int launch_one(const BnArgs& a, hipStream_t s) {
+    constexpr size_t lds = BnCfg<K, S1, CT2>::LDS;
+    static_assert(lds <= 160 * 1024, "bottleneck: LDS budget");
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<K, S1, CT2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(bottleneck)");
+        if (rc) return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL((bottleneck_kernel<K, S1, CT2>), dim3(a.nwg), dim3(256), lds, s, a);
+    return maf_check_hip(hipGetLastError(), "bottleneck launch");
 }
 
 template <int K>
-int launch_k(const BnArgs& a, size_t lds, hipStream_t s) {
-    const int ct2 = a.Cout <= 32 ? 2 : 4;
-    const int mt2 = a.TH * a.TW / 64;
-#define MAF_BN(C2, M2)                                                                                                                   \
-    if (ct2 == C2 && mt2 == M2) {                                                                                                        \
-        static bool attr = false;                                                                                                        \
-        if (!attr) {                                                                                                                     \
-            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<K, C2, M2>),                     \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(bottleneck)"); \
-            if (rc) return rc;                                                                                                           \
-            attr = true;                                                                                                                 \
-        }                                                                                                                                \
-        hipLaunchKernelGGL((bottleneck_kernel<K, C2, M2>), dim3(a.nwg), dim3(256), lds, s, a);                                           \
-        return maf_check_hip(hipGetLastError(), "bottleneck launch");                                                                    \
-    }
-    MAF_BN(2, 1) MAF_BN(2, 2) MAF_BN(2, 4) MAF_BN(4, 1) MAF_BN(4, 2) MAF_BN(4, 4)
-#undef MAF_BN
-    maf_set_error("bottleneck: unsupported tile (TH*TW must be 64, 128 or 256)");
+int launch_k(const BnArgs& a, hipStream_t s) {
+    const int s1 = (a.Cin + 31) / 32, ct2 = a.Cout <= 32 ? 2 : 4;
+    if (s1 == 1 && ct2 == 2) return launch_one<K, 1, 2>(a, s);          // c <= 32
+    if (s1 == 2 && ct2 == 4) return launch_one<K, 2, 4>(a, s);          // 32 < c <= 64
+    maf_set_error("bottleneck: unsupported channel count");
     return MAF_E_UNSUPPORTED;
 }
 
 }  // namespace
+
+extern "C" int64_t maf_bottleneck_record_bytes(int32_t k, int32_t cin, int32_t cout) {
+    const int parts = k > 5 ? 2 : 1, s1 = (cin + 31) / 32, ct2 = cout <= 32 ? 2 : 4;
+    return (int64_t)8 * k * parts * 16 * 16 + (int64_t)2 * s1 * 1024 + (int64_t)ct2 * 1024 + 256;   /* = BnCfg::REC */
+}
 
 int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "bottleneck: fp16 only (the fp32 parity mode runs the three kernels separately)");
@@ -241,26 +315,20 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr && op->out, "bottleneck: one direct source");
     MAF_REQUIRE(op->Cin % 8 == 0 && op->Cin <= 64 && op->Cout % 2 == 0 && op->Cout <= 64, "bottleneck: c <= 64 channels in and out");
     MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 4 == 0 && op->out_coff % 4 == 0, "bottleneck: stride/offset alignment");
-    MAF_REQUIRE(op->tile_k > 0 && op->w && op->bias && op->aux[0] && op->aux[1] && op->aux[2] && op->aux[3], "bottleneck: null weights (w=W1, bias=b1, aux = {wdw, bdw, W2, b2}), tile_k = mid blocks");
+    MAF_REQUIRE(op->act == MAF_ACT_SILU, "bottleneck: DepthBottleneckUni applies SiLU after every stage (common.py:918-927)");
+    MAF_REQUIRE(op->tile_k > 0 && op->w && op->bias, "bottleneck: null weights (w = block records, bias = b2), tile_k = 32-channel mid blocks");
     BnArgs a;
     a.x = static_cast<const half_t*>(sr.ptr); a.out = static_cast<half_t*>(op->out);
-    a.w1 = static_cast<const half8_t*>(op->w); a.b1 = op->bias;
-    a.wdw = static_cast<const half_t*>(op->aux[0]); a.bdw = static_cast<const float*>(op->aux[1]);
-    a.w2 = static_cast<const half8_t*>(op->aux[2]); a.b2 = static_cast<const float*>(op->aux[3]);
+    a.par = static_cast<const unsigned char*>(op->w); a.b2 = op->bias;
     a.B = op->B; a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout; a.nMB = op->tile_k;
     a.x_stride = sr.stride; a.x_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
-    a.act_mid = op->act == MAF_ACT_SILU;
-    a.TH = op->tile_p > 0 ? op->tile_p : 8; a.TW = op->tile_c > 0 ? op->tile_c : 16;
-    MAF_REQUIRE(a.TW % 4 == 0 && (a.TH * a.TW) % 64 == 0, "bottleneck: TW multiple of 4, TH*TW multiple of 64");
-    a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH);
+    a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, 16);
     a.nwg = a.B * a.tilesX * a.tilesY;
-    const size_t lds = bn_lds(a.TH, a.TW, op->ksize, a.Cin);
-    MAF_REQUIRE(lds <= 160 * 1024, "bottleneck: tile does not fit LDS");
     switch (op->ksize) {
-        case 3: return launch_k<3>(a, lds, s);
-        case 5: return launch_k<5>(a, lds, s);
-        case 7: return launch_k<7>(a, lds, s);
-        case 9: return launch_k<9>(a, lds, s);
+        case 3: return launch_k<3>(a, s);
+        case 5: return launch_k<5>(a, s);
+        case 7: return launch_k<7>(a, s);
+        case 9: return launch_k<9>(a, s);
         default: maf_set_error("bottleneck: k must be 3, 5, 7 or 9"); return MAF_E_UNSUPPORTED;
     }
 }

@@ -10,6 +10,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 

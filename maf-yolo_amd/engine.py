@@ -17,6 +17,49 @@ from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Head_DepthUn
 
 _ESIZE = {lib.F16: 2, lib.F32: 4}
 _TUNE_CACHE = {}          # layer signature -> (tile_p, tile_c), filled by Plan.autotune
+
+
+def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
+    """Measure, per DepthBottleneckUni, the fused kernel against the three separate launches on this device and return the
+    set of bottleneck names to fuse.  Decisions are cached by layer signature next to the tile choices."""
+    import numpy as np
+    planF = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True)
+    names = [planF.op_names[i] for i, o in enumerate(planF.ops) if o.kind == lib.OP_BOTTLENECK]
+    sigs = {planF.op_names[i]: ("bn", dtype, B, o.H, o.W, o.Cin, o.ksize, o.tile_k) for i, o in enumerate(planF.ops) if o.kind == lib.OP_BOTTLENECK}
+    if names and not all(sigs[n] in _TUNE_CACHE for n in names):
+        planU = Plan(model, B, H, W, dtype, in_dtype, device, fuse=False)
+        planU.autotune(x)
+        planF.autotune(x)
+        pred = torch.empty(B, planU.A, 5 + planU.nc, dtype=torch.float32, device=device)
+
+        def timed(plan):
+            plan.run_timed(x, pred)
+            return np.min([plan.run_timed(x, pred) for _ in range(reps)], 0)
+        tU, tF = timed(planU), timed(planF)
+        for n in names:
+            u = sum(t for t, nm in zip(tU, planU.op_names) if nm in (n + ".conv1", n + ".conv2", n + ".one_conv"))
+            f = tF[planF.op_names.index(n)]
+            _TUNE_CACHE[sigs[n]] = (1 if f < u else 0,)
+        del planU
+    del planF
+    return frozenset(n for n in names if _TUNE_CACHE[sigs[n]][0])
+
+
+def save_tune_cache(path):
+    """Persist the tile choices found by Plan.autotune (JSON: repr(signature) -> tiles) so a later process — a profiler
+    pass, a serving replica — builds byte-identical plans without re-timing."""
+    import json
+    with open(path, "w") as f:
+        json.dump({repr(k): list(v) for k, v in _TUNE_CACHE.items()}, f, indent=0, sort_keys=True)
+
+
+def load_tune_cache(path):
+    import ast
+    import json
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            _TUNE_CACHE[ast.literal_eval(k)] = tuple(v)
+    return len(_TUNE_CACHE)
 _TORCH_DT = {lib.F16: torch.float16, lib.F32: torch.float32}
 
 
@@ -44,7 +87,7 @@ class TV:
 
 
 class Plan:
-    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device):
+    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None):
         assert Hin % 32 == 0 and Win % 32 == 0, "image sides must be multiples of 32 (stride of P5)"
         self.B, self.Hin, self.Win, self.dtype, self.in_dtype, self.device = B, Hin, Win, dtype, in_dtype, device
         self.es = _ESIZE[dtype]
@@ -55,10 +98,20 @@ class Plan:
         self.nc = model.nc
         self.reg_max = model.detect.reg_max
         self.strides = [float(s) for s in model.detect.stride.tolist()]
-        self.fuse = getattr(model, "fuse_bottlenecks", True)
+        # MAF_OP_BOTTLENECK runs a whole DepthBottleneckUni in one launch (csrc/bottleneck.hip).  `fuse`: True / False for every
+        # eligible bottleneck, a set of bottleneck names, or "auto" = the built-in rule (k <= 5: the 160^2 / 80^2 maps, where it
+        # wins by 1.3-1.8x; Model.plan_for replaces the rule by a measurement when autotuning is on).
+        self.fuse = getattr(model, "fuse_bottlenecks", "auto") if fuse is None else fuse
         with torch.no_grad():
             self._build(model)
         self._finalize()
+
+    def _fuse_ok(self, name, k):
+        if isinstance(self.fuse, (set, frozenset, list, tuple)):
+            return name in self.fuse
+        if self.fuse == "auto":
+            return k <= 5
+        return bool(self.fuse)
 
     # ---------------------------------------------------------------- allocation helpers
     def _alloc(self, H, W, C, esize=None):
@@ -128,15 +181,14 @@ class Plan:
                 for d, blk in enumerate(m.m):
                     mid = blk.conv1.conv.out_channels
                     q = "%s.m.%d" % (p, d)
-                    if self.fuse and self.dtype == lib.F16 and c_ <= 64 and c_ % 8 == 0:
+                    if self.dtype == lib.F16 and c_ <= 64 and c_ % 8 == 0 and self._fuse_ok(q, blk.conv2.dwconv.kernel_size):
                         # the whole DepthBottleneckUni in one launch; its 3c-channel intermediates stay in LDS
-                        W1, b1p, wd, bdp, W2, b2p, nmb, ct2 = pack.pack_bottleneck(*blk.conv1.fused(), *blk.conv2.fused(), *blk.one_conv.fused())
-                        k = wd.shape[0]
-                        k = int(round(k ** 0.5))
-                        th, tw = (16, 16) if k <= 5 and c_ <= 48 else (8, 16)
+                        rec, b2p, nmb, ct2 = pack.pack_bottleneck(*blk.conv1.fused(), *blk.conv2.fused(), *blk.one_conv.fused())
+                        k = blk.conv2.dwconv.kernel_size
+                        th, tw = 16, 16                                   # fixed by the MFMA shapes of csrc/bottleneck.hip
                         self._ops.append(dict(kind=lib.OP_BOTTLENECK, name=q, act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=c_, ksize=k, mid=mid,
                                               segs=[Seg(cat, c_, (d + 1) * c_)], out=cat, out_coff=(d + 2) * c_, pt=th, ct=tw, tk=nmb,
-                                              w=self._wput(W1), b=self._wput(b1p), aux=[self._wput(wd), self._wput(bdp), self._wput(W2), self._wput(b2p)]))
+                                              w=self._wput(rec), b=self._wput(b2p), aux=[]))
                         continue
                     t1, t2 = self._alloc(x.H, x.W, mid), self._alloc(x.H, x.W, mid)
                     self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(cat, c_, (d + 1) * c_)], x.H, x.W), t1, 0, lib.ACT_SILU)
@@ -301,35 +353,6 @@ class Plan:
                     o.tile_p, o.tile_c, o.tile_k = best
                     changed += 1
                 continue
-            if o.kind == lib.OP_BOTTLENECK:
-                sig = (o.kind, self.B, o.H, o.W, o.Cin, o.ksize, o.tile_k)
-                best = _TUNE_CACHE.get(sig)
-                if best is None:
-                    results = []
-                    for th, tw in ((8, 8), (4, 16), (8, 16), (16, 8), (4, 32), (16, 16), (8, 32)):
-                        npix = (th + o.ksize - 1) * (tw + o.ksize - 1)
-                        lds = (npix * (-(-o.Cin // 32) * 32 + 8) + npix * 72 + th * tw * 72 + o.ksize * o.ksize * 64) * 2
-                        if lds > 160 * 1024:
-                            continue
-                        op = lib.MafOp.from_buffer_copy(o)
-                        op.tile_p, op.tile_c = th, tw
-                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
-                        ts = []
-                        for _ in range(reps):
-                            timer.start(stream.cuda_stream)
-                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
-                            timer.stop(stream.cuda_stream)
-                            ts.append(timer.elapsed_ms())
-                        results.append((min(ts), th, tw))
-                    results.sort()
-                    best = results[0][1:]
-                    _TUNE_CACHE[sig] = best
-                    if verbose:
-                        print("tune %-32s %dx%d c=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d)%.1fus" % (a, b2, t * 1e3) for t, a, b2 in results)))
-                if tuple(best) != (o.tile_p, o.tile_c):
-                    o.tile_p, o.tile_c = best
-                    changed += 1
-                continue
             if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
                 continue
             M = self.B * o.H * o.W
@@ -431,7 +454,7 @@ class Plan:
         if o.kind == lib.OP_DWCONV:
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:
-            return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, 2 if o.Cout <= 32 else 4, o.tile_p * o.tile_c // 64)
+            return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -455,7 +478,7 @@ class Plan:
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.Cin * es + o.ksize * o.ksize * o.Cin * es
         if o.kind == lib.OP_BOTTLENECK:
-            mid = o.tile_k * 64
+            mid = o.tile_k * 32
             return px * (o.Cin + o.Cout) * es + (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
         if o.kind == lib.OP_SPPF_POOL:
             return 4 * px * o.src[0].C * es

@@ -100,6 +100,7 @@ class Model(nn.Module):
         self.build_type = "yaml"
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
+        self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -178,7 +179,11 @@ class Model(nn.Module):
         if plan is None:
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
-            plan = Plan(self, B, H, W, dt, in_dt, x.device)
+            fuse = None
+            if self.autotune and dt == lib.F16 and self.fuse_bottlenecks == "auto":
+                from .engine import choose_fusion
+                fuse = choose_fusion(self, B, H, W, dt, in_dt, x.device, x.contiguous())
+            plan = Plan(self, B, H, W, dt, in_dt, x.device, fuse=fuse)
             if self.autotune and dt == lib.F16:
                 plan.autotune(x.contiguous())
             self._plans[key] = plan

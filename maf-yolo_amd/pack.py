@@ -95,21 +95,44 @@ def pack_stem(w):
 
 
 def pack_bottleneck(w1, b1, wdw, bdw, w2, b2):
-    """Operands of MAF_OP_BOTTLENECK (csrc/bottleneck.hip), fp16: the mid channels are cut into 64-channel blocks.
+    """Operands of MAF_OP_BOTTLENECK (csrc/bottleneck.hip), fp16: the mid channels are cut into 32-channel blocks.
 
-    w1 [mid, c, 1, 1], wdw [mid, 1, k, k], w2 [c, mid, 1, 1] (+ fp32 biases).  Returns (W1 packed, b1 pad, wdw [k*k][mid_pad],
-    bdw pad, W2 packed per block, b2 pad, n_blocks, ct2)."""
+    w1 [mid, c, 1, 1], wdw [mid, 1, k, k], w2 [c, mid, 1, 1] (+ fp32 biases).  Returns (records, b2 pad, n_blocks, ct2):
+    `records` is a uint8 tensor [n_blocks, REC]; one record = everything the kernel needs for one 32-channel mid block, in the
+    order it copies it to LDS:  W1 fragments [2, S1, 64, 8] f16 | b1 [32] f32 | Toeplitz table [8, k, parts, 16, 8] f16 |
+    W2 fragments [ct2, 64, 8] f16 | bdw [32] f32.
+
+    Toeplitz entry (block mb, set s, tap row ky, window part, row i = 4G + r, element j) = wdw[mb*32 + 4s + G][ky][j - r + 4*part]
+    — the depth-wise filter row of channel 4s + G (set s convolves the four channels 4s .. 4s+3; bdw and the rows of W2 are
+    permuted to the kernel's k index 8G + s accordingly) seen from output column r of a 4-output group through an 8-wide input
+    window; window 0 carries taps kx <= 4, window 1 (k > 5 only, shifted 4 columns) the taps kx >= 5."""
     mid, c = w1.shape[0], w1.shape[1]
     k = wdw.shape[-1]
-    nmb = -(-mid // 64)
-    mp = nmb * 64
+    nmb = -(-mid // 32)
+    mp = nmb * 32
     w1p = torch.zeros(mp, c); w1p[:mid] = w1.reshape(mid, c).float().cpu()
-    W1 = pack_matrix([w1p], 4, lib.F16)                                   # [nmb*4, steps1, 64, 8]
+    W1 = torch.cat([pack_matrix([w1p[m * 32:(m + 1) * 32]], 1, lib.F16) for m in range(nmb)], 0)       # [nmb*2, S1, 64, 8]
     b1p = torch.zeros(mp); b1p[:mid] = b1.float().cpu()
-    wd = torch.zeros(k * k, mp); wd[:, :mid] = wdw.float().cpu().reshape(mid, k * k).t()
+    wd = torch.zeros(mp, k, k); wd[:mid] = wdw.float().cpu().reshape(mid, k, k)
+    parts = 2 if k > 5 else 1
+    toe = torch.zeros(nmb, 8, k, parts, 4, 4, 8)                           # [mb, s, ky, part, G, r, j]
+    wv = wd.reshape(nmb, 8, 4, k, k)                                       # [mb, s, G, ky, kx]
+    for part in range(parts):
+        for r in range(4):
+            for j in range(8):
+                kx = j - r + 4 * part
+                if kx < 0 or kx >= k or (part == 0 and kx > 4) or (part == 1 and kx < 5):
+                    continue
+                toe[:, :, :, part, :, r, j] = wv[:, :, :, :, kx].permute(0, 1, 3, 2)          # [mb, s, ky, G]
     bdp = torch.zeros(mp); bdp[:mid] = bdw.float().cpu()
+    bdp = bdp.reshape(nmb, 8, 4).permute(0, 2, 1).contiguous().reshape(mp)     # [mb][G][s]: lane group G reads its 8 biases contiguously
     ct2 = 2 if c <= 32 else 4
     w2f = torch.zeros(c, mp); w2f[:, :mid] = w2.reshape(c, mid).float().cpu()
-    W2 = torch.cat([pack_matrix([w2f[:, m * 64:(m + 1) * 64]], ct2, lib.F16) for m in range(nmb)], 0)   # [nmb*ct2, 2, 64, 8]
+    w2f = w2f.reshape(c, nmb, 8, 4).permute(0, 1, 3, 2).reshape(c, mp)         # k index 8G + s <- channel 4s + G
+    W2 = torch.cat([pack_matrix([w2f[:, m * 32:(m + 1) * 32]], ct2, lib.F16) for m in range(nmb)], 0)   # [nmb*ct2, 1, 64, 8]
     b2p = torch.zeros(16 * ct2); b2p[:c] = b2.float().cpu()
-    return W1.contiguous(), b1p, wd.to(torch.float16).contiguous(), bdp, W2.contiguous(), b2p, nmb, ct2
+    def raw(t):
+        return t.contiguous().view(torch.uint8).reshape(nmb, -1)
+    rec = torch.cat([raw(W1.reshape(nmb, -1)), raw(b1p.reshape(nmb, 32)), raw(toe.reshape(nmb, -1).to(torch.float16)),
+                     raw(W2.reshape(nmb, -1)), raw(bdp.reshape(nmb, 32))], 1).contiguous()
+    return rec, b2p, nmb, ct2

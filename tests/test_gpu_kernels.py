@@ -276,11 +276,11 @@ def test_bad_arguments_are_rejected():
     assert b"multiples" in lib.load().maf_last_error()
 
 
-@pytest.mark.parametrize("c,k,th,tw", [(64, 5, 8, 16), (64, 5, 16, 16), (24, 3, 16, 16), (48, 5, 8, 8), (64, 7, 8, 16), (32, 9, 4, 16), (64, 7, 4, 32)])
-def test_fused_bottleneck(c, k, th, tw):
+@pytest.mark.parametrize("c,k,H,W", [(64, 5, 21, 27), (24, 3, 21, 27), (48, 5, 32, 16), (64, 7, 21, 27), (32, 9, 20, 20), (16, 3, 40, 33), (40, 7, 16, 16)])
+def test_fused_bottleneck(c, k, H, W):
     """MAF_OP_BOTTLENECK == Conv1x1+SiLU -> DW k x k + SiLU -> Conv1x1+SiLU (DepthBottleneckUni deploy form, common.py:918-927)."""
     g = torch.Generator().manual_seed(c + k)
-    B, H, W = 2, 21, 27                                   # ragged tiles on both axes
+    B = 2                                                 # 21 x 27: ragged 16 x 16 tiles on both axes
     mid = 3 * c
     x = torch.randn(B, c, H, W, generator=g).half().float()
     w1 = (torch.randn(mid, c, 1, 1, generator=g) / c ** 0.5).half().float(); b1 = torch.randn(mid, generator=g) * 0.3
@@ -289,8 +289,9 @@ def test_fused_bottleneck(c, k, th, tw):
     t1 = F.silu(F.conv2d(x, w1, b1)).half().float()                     # the separate kernels also store T1/T2 in fp16
     t2 = F.silu(F.conv2d(t1, wd, bd, 1, k // 2, 1, mid)).half().float()
     ref = F.silu(F.conv2d(t2, w2, b2))
-    W1, b1p, wdp, bdp, W2, b2p, nmb, ct2 = pack.pack_bottleneck(w1, b1, wd, bd, w2, b2)
-    dev = [t.to(DEV) for t in (W1, b1p, wdp, bdp, W2, b2p)]
+    rec, b2p, nmb, ct2 = pack.pack_bottleneck(w1, b1, wd, bd, w2, b2)
+    assert rec.shape[1] == lib.load().maf_bottleneck_record_bytes(k, c, c)
+    dev = [rec.to(DEV), b2p.to(DEV)]
     stride = 2 * c + 16
     buf = torch.zeros(B, H, W, stride, dtype=torch.float16, device=DEV)
     buf[..., 8:8 + c] = _nhwc(x, lib.F16)
@@ -299,10 +300,8 @@ def test_fused_bottleneck(c, k, th, tw):
     op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc = B, H, W, c, c, k, 1
     op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff = buf.data_ptr(), c, stride, 8
     op.out, op.out_stride, op.out_coff = buf.data_ptr(), stride, 8 + c
-    op.tile_p, op.tile_c, op.tile_k = th, tw, nmb
+    op.tile_p, op.tile_c, op.tile_k = 16, 16, nmb
     op.w, op.bias = dev[0].data_ptr(), dev[1].data_ptr()
-    for i in range(4):
-        op.aux[i] = dev[2 + i].data_ptr()
     _launch(op)
     _check(buf[..., 8 + c:8 + 2 * c], ref, lib.F16)
     assert (buf[..., :8] == 0).all() and (buf[..., 8 + 2 * c:] == 0).all()

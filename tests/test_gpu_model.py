@@ -250,3 +250,34 @@ def test_autotuned_tiles_give_identical_predictions(models):
         tuned = m(x)[0]
     # a tile only re-cuts the (pixel, channel) space; only the split-K variants change a summation order (fp32 partials)
     _close16(tuned.cpu().numpy(), base.cpu().numpy())
+
+
+def test_fused_bottleneck_plan_matches_unfused(models):
+    """MAF_OP_BOTTLENECK plan (6 of the n model's bottlenecks in one launch each) vs the three-kernel plan."""
+    outs = {}
+    for fuse in (True, False):
+        m = M.Model("n")
+        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = m.to(DEV).eval()
+        m.fuse_bottlenecks = fuse
+        x = O.synth_images(2, 320, 8).to(DEV).half()
+        with torch.no_grad():
+            outs[fuse] = m(x)[0].cpu().numpy()
+        assert sum(1 for o in m.plan_for(x).ops if o.kind == 6) == (6 if fuse else 0)
+    _close16(outs[True], outs[False])
+
+
+def test_fusion_choice_is_measured_when_autotuning():
+    from maf_yolo_amd import engine
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0))
+    m = m.to(DEV).eval()
+    m.autotune = True
+    x = O.synth_images(2, 320, 8).to(DEV).half()
+    with torch.no_grad():
+        m(x)
+    plan = m.plan_for(x)
+    decided = [k for k in engine._TUNE_CACHE if k[0] == "bn" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
+    assert len(decided) >= 4                       # one decision per distinct bottleneck signature
+    nf = sum(1 for o in plan.ops if o.kind == 6)
+    assert len(plan.ops) == 90 - 2 * nf

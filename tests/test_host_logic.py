@@ -142,10 +142,10 @@ def test_pack_layout():
     assert pack.tile_for(24, 10 ** 6)[1] == 2 and pack.tile_for(128, 10 ** 6) == (2, 8) and pack.tile_for(384, 12800)[0] == 1
 
 
-@pytest.mark.parametrize("scale,nops", [("n", 88 + 2 - 2 * 6), ("s", 118 + 2 - 2 * 4), ("m", 148 + 2 - 2 * 2)])     # fused bottlenecks: 3 launches -> 1 where c <= 64
+@pytest.mark.parametrize("scale,nops", [("n", 88 + 2), ("s", 118 + 2), ("m", 148 + 2)])
 def test_plan_builds_on_cpu(built, scale, nops):
     m = M.Model(scale).eval()
-    plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
+    plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
     lo, hi = plan._abase, plan._abase + plan._arena_size
     for o, name in zip(plan.ops, plan.op_names):
@@ -155,6 +155,13 @@ def test_plan_builds_on_cpu(built, scale, nops):
                 assert lo <= o.src[i].ptr < hi and o.src[i].stride % 8 == 0 and o.src[i].coff % 8 == 0, name
             assert lo <= o.out < hi, name
     assert plan.A == 8 * 8 + 4 * 4 + 2 * 2
+    m.fuse_bottlenecks = True                      # fused DepthBottleneckUni: 3 launches -> 1 wherever c <= 64
+    fused = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
+    assert len(fused.ops) == nops - 2 * {"n": 6, "s": 4, "m": 2}[scale]
+    m.fuse_bottlenecks = "auto"                    # default rule without a measurement: k <= 5 only
+    auto = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
+    assert len(auto.ops) == nops - 2 * {"n": 4, "s": 4, "m": 2}[scale]
+    assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops        # fp32 parity mode never fuses
 
 
 def test_product_synth_generator_equals_oracle_generator():
@@ -165,3 +172,21 @@ def test_product_synth_generator_equals_oracle_generator():
         assert list(a.keys()) == list(b.keys())
         assert all(torch.equal(a[k], b[k]) for k in a)
     assert torch.equal(synth.synth_images(2, 32, 5), O.synth_images(2, 32, 5))
+
+
+def test_tune_cache_roundtrip(tmp_path):
+    from maf_yolo_amd import engine
+    saved = dict(engine._TUNE_CACHE)
+    try:
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE[(1, 0, 204800, 48, 48, 1, (0,), 0)] = (2, 4, 1)
+        engine._TUNE_CACHE[(3, 0, 32, 80, 80, 96, 5, 2)] = (8, 16, 32)
+        p = str(tmp_path / "tune.json")
+        engine.save_tune_cache(p)
+        want = dict(engine._TUNE_CACHE)
+        engine._TUNE_CACHE.clear()
+        assert engine.load_tune_cache(p) == 2
+        assert engine._TUNE_CACHE == want
+    finally:
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE.update(saved)
