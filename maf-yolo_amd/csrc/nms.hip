@@ -28,6 +28,9 @@ constexpr int kMaxNms = 30000;       // nms.py:54
 constexpr float kMaxWh = 4096.f;     // nms.py:53
 constexpr int kLdsKeys = 8192;       // 64 KiB of 64-bit keys
 constexpr int kMaxDetCap = 1024;     // kept-list capacity in LDS (32 B each = lower half of the sort buffer)
+constexpr int kMaskN = 4096;         // images with at most this many candidates take the suppression-matrix path
+constexpr int kMaskW = kMaskN / 64;  // 64-bit words per matrix row
+constexpr int kMaskWgs = 256;        // matrix workgroups per image
 
 struct NmsArgs {
     const float* pred;
@@ -41,6 +44,8 @@ struct NmsArgs {
     unsigned long long* keys; // [B][capP]
     long long capP;
     float* out_rows; long long* out_idx; int* out_count;
+    struct Cand* cands;            // [B][kMaskN]           sorted candidates of the matrix path
+    unsigned long long* mask;      // [B][kMaskN][kMaskW]   bit j of word w of row i: candidate 64w+j (> i) overlaps candidate i
 };
 
 __device__ __forceinline__ bool class_ok(const NmsArgs& a, int c) {
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
         if (tid == 0) a.out_count[b] = 0;
         return;
     }
+    if (n <= kMaskN && a.mask) return;                         // this image takes the suppression-matrix path (kernels below)
     const int no = 5 + a.nc;
     const float* pred = a.pred + (size_t)b * a.N * no;
     int P = 1;
@@ -403,6 +409,171 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
     if (tid == 0) a.out_count[b] = nk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Suppression-matrix path (images with <= kMaskN candidates — the normal case: ~2000 at conf 0.03).  The greedy scan of
+// torchvision.ops.nms is sequential only in its *decisions*; all pair tests are independent.  So:
+//   nms_sort_kernel   one workgroup per image: bitonic sort of the keys in LDS, candidates materialised in score order;
+//   nms_mask_kernel   the whole chip: bit matrix M[i][j] = IoU(i, j) > thr for j > i, 64 x 64 blocks of the upper triangle;
+//   nms_scan_kernel   one workgroup per image: walks the candidates 64 at a time — the 64 x 64 diagonal block decides the
+//                     survivors of the block with a scalar bit loop (a survivor clears the bits it suppresses), then the rows
+//                     of the survivors are OR-ed into the per-word "removed" state of all later blocks, lane = word.
+// Every pair is tested with iou_gt on the class-offset boxes exactly as torchvision does, so no class reasoning is needed.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSortT = 1024;
+
+__global__ __launch_bounds__(kSortT) void nms_sort_kernel(const NmsArgs a) {
+    __shared__ unsigned long long lk[kMaskN];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    long long n64 = a.cnt[b * kCntStride];
+    const long long cap = (long long)a.N * a.nc;
+    if (n64 > cap) n64 = cap;
+    const int n = (int)n64;
+    if (n == 0 || n > kMaskN) return;
+    const unsigned long long* keys = a.keys + (size_t)b * a.capP;
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += kSortT) lk[i] = i < n ? keys[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort(lk, P, tid, kSortT);
+    const int no = 5 + a.nc;
+    const float* pred = a.pred + (size_t)b * a.N * no;
+    Cand* out = a.cands + (size_t)b * kMaskN;
+    for (int i = tid; i < n; i += kSortT) {
+        const unsigned long long key = lk[i];
+        const unsigned int flat = (unsigned int)(key & 0xffffffffu);
+        const unsigned int box = flat / (unsigned int)a.nc;
+        const int cls = (int)(flat - box * (unsigned int)a.nc);
+        Cand c;
+        make_cand(a, pred, no, box, cls, c);
+        c.score = __uint_as_float(~(unsigned int)(key >> 32)); c.flat = flat; c.pad = (unsigned int)cls;
+        out[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
+    __shared__ Cand cb[64];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    long long n64 = a.cnt[b * kCntStride];
+    const long long cap = (long long)a.N * a.nc;
+    if (n64 > cap) n64 = cap;
+    const int n = (int)n64;
+    if (n == 0 || n > kMaskN) return;
+    const int nb = (n + 63) >> 6;
+    const int npairs = nb * (nb + 1) / 2;
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    const Cand* cands = a.cands + (size_t)b * kMaskN;
+    unsigned long long* mask = a.mask + (size_t)b * kMaskN * kMaskW;
+    for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+        // pair index -> (row block rb, column block cbk >= rb): rows of the upper triangle have nb, nb-1, ... entries
+        int rb = 0, rem = pr;
+        while (rem >= nb - rb) { rem -= nb - rb; ++rb; }
+        const int cbk = rb + rem;
+        const int i = rb * 64 + lane, j0 = cbk * 64;
+        __syncthreads();
+        if (j0 + lane < n) cb[lane] = cands[j0 + lane];
+        __syncthreads();
+        if (i < n) {
+            const Cand me = cands[i];
+            unsigned long long bits = 0;
+            const int jn = min(64, n - j0);
+            for (int j = (cbk == rb ? lane + 1 : 0); j < jn; ++j)
+                if (iou_gt(me, cb[j], iouthr)) bits |= 1ull << j;
+            mask[(size_t)i * kMaskW + cbk] = bits;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
+    __shared__ unsigned long long rows[64][kMaskW + 1];        // the current block's matrix rows (+1: lanes walk a column conflict-free)
+    __shared__ int kept_idx[kMaxDetCap];
+    __shared__ int s_nk, s_done;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long n64 = a.cnt[b * kCntStride];
+    const long long cap = (long long)a.N * a.nc;
+    if (n64 > cap) n64 = cap;
+    const int n = (int)n64;
+    if (n == 0 || n > kMaskN) return;
+    const int nb = (n + 63) >> 6;
+    const unsigned long long* mask = a.mask + (size_t)b * kMaskN * kMaskW;
+    if (tid == 0) { s_nk = 0; s_done = 0; }
+    unsigned long long removed = 0;                            // wave 0: lane w = word w of the removed set
+    // each thread stages 16 words of a block: row r = tid >> 2, words (tid & 3) * 16 .. +15 (only words >= blk are defined)
+    unsigned long long pre[16];
+    auto load_blk = [&](int blk) {
+        const int r = tid >> 2, w0 = (tid & 3) * 16;
+        const int i = blk * 64 + r;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int w = w0 + u;
+            pre[u] = (i < n && w >= blk && w < nb) ? mask[(size_t)i * kMaskW + w] : 0ull;
+        }
+    };
+    auto store_blk = [&]() {
+        const int r = tid >> 2, w0 = (tid & 3) * 16;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rows[r][w0 + u] = pre[u];
+    };
+    load_blk(0);
+    for (int blk = 0; blk < nb; ++blk) {
+        __syncthreads();                                       // previous block's rows are no longer read
+        store_blk();
+        if (blk + 1 < nb) load_blk(blk + 1);                   // in flight while this block is decided
+        __syncthreads();
+        if (wave == 0) {
+            int nk = s_nk;
+            const unsigned long long diag = rows[lane][blk];   // lane r: later candidates of this block that r suppresses
+            const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+            const unsigned int rlo = (unsigned int)removed, rhi = (unsigned int)(removed >> 32);
+            const unsigned long long rw = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rhi, blk) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)rlo, blk);
+            const int nvalid = min(64, n - blk * 64);
+            unsigned long long todo = ~rw & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
+            unsigned long long keep = 0;
+            int room = a.max_det - nk;
+            while (todo != 0 && room > 0) {                    // scalar: a survivor clears the bits of the candidates it suppresses
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                keep |= 1ull << j;
+                --room;
+                const unsigned long long dj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)dlo, j);
+                todo &= ~dj;
+            }
+            if ((keep >> lane) & 1ull) kept_idx[nk + __popcll(keep & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+            nk += __popcll(keep);
+            unsigned long long k2 = keep;                      // removed |= rows of the survivors (lane = word; words <= blk are dead)
+            while (k2) {
+                const int j = __ffsll((long long)k2) - 1;
+                k2 &= k2 - 1;
+                removed |= rows[j][lane];
+            }
+            if (lane == 0) { s_nk = nk; if (nk >= a.max_det) s_done = 1; }
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    __syncthreads();
+    // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)
+    const int nk = s_nk < a.max_det ? s_nk : a.max_det;
+    const int no = 5 + a.nc;
+    const float* pred = a.pred + (size_t)b * a.N * no;
+    const Cand* cands = a.cands + (size_t)b * kMaskN;
+    float* orow = a.out_rows + (size_t)b * a.max_det * 6;
+    long long* oidx = a.out_idx + (size_t)b * a.max_det;
+    for (int k = tid; k < nk; k += 256) {
+        const Cand& c = cands[kept_idx[k]];
+        const unsigned int flat = c.flat;
+        const unsigned int box = flat / (unsigned int)a.nc;
+        const int cls = (int)(flat - box * (unsigned int)a.nc);
+        const float* r = pred + (size_t)box * no;
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float* o = orow + (size_t)k * 6;
+        o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2; o[4] = c.score; o[5] = (float)cls;
+        oidx[k] = a.multi_label ? (long long)flat : (long long)box;
+    }
+    if (tid == 0) a.out_count[b] = nk;
+}
+
 long long pow2ceil(long long v) {
     long long p = 1;
     while (p < v) p <<= 1;
@@ -418,7 +589,7 @@ extern "C" int maf_nms_debug(uint64_t* host8) {
 extern "C" int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc) {
     if (B <= 0 || N <= 0 || nc <= 0) return 0;
     const long long capP = pow2ceil((long long)N * nc);
-    return 256 + (long long)B * kCntStride * 4 + (long long)B * capP * 8;
+    return 256 + (long long)B * kCntStride * 4 + (long long)B * capP * 8 + (long long)B * kMaskN * 32 + (long long)B * kMaskN * kMaskW * 8;
 }
 
 extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
@@ -452,6 +623,8 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     a.cnt = reinterpret_cast<int*>(ws);
     a.keys = reinterpret_cast<unsigned long long*>(ws + 256 + (long long)B * kCntStride * 4);
     a.capP = pow2ceil((long long)N * nc);
+    a.cands = reinterpret_cast<Cand*>(ws + 256 + (long long)B * kCntStride * 4 + (long long)B * a.capP * 8);
+    a.mask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.cands) + (long long)B * kMaskN * 32);
     a.out_rows = out_rows; a.out_idx = reinterpret_cast<long long*>(out_idx); a.out_count = out_count;
     int rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * kCntStride * 4, s), "nms memset");
     if (rc) return rc;
@@ -465,6 +638,9 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     }
     rc = maf_check_hip(hipGetLastError(), "nms_collect launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(kSelT), 0, s, a);
+    hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(kSelT), 0, s, a);        // images with > kMaskN candidates (others return at once)
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(kSortT), 0, s, a);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskWgs, B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
     return maf_check_hip(hipGetLastError(), "nms_select launch");
 }
