@@ -50,8 +50,14 @@ enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3 };
 
 int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f32(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
+int maf_conv_mfma_f16_lb(const ConvArgs& a, int var, int pt, int ct, hipStream_t s);   // weights shared through LDS (tile_k = 2)
 
 namespace {
+
+// 16 zero bytes in global memory: the stride-2 3x3 conv points its out-of-image taps here, so every operand load is
+// unconditional (a load under a divergent branch makes the compiler wait with vmcnt(0), i.e. serialises the whole
+// software pipeline: the prefetched fragments of the next k-steps could never stay in flight across the MFMAs)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
 
 template <typename T> struct Frag;
 template <> struct Frag<half_t> {
@@ -92,9 +98,10 @@ __device__ __forceinline__ typename Frag<T>::type ldg16(const T* p) {
     return *reinterpret_cast<const typename Frag<T>::type*>(p);
 }
 
-template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false>
+template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false, bool LB = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(!KS4 || PT == 1, "split-K variant is defined for one pixel tile per wave");
+    static_assert(!(KS4 && LB), "split-K and LDS-shared weights are separate variants");
     typedef Frag<T> F;
     typedef typename F::type frag_t;
     constexpr int CH = F::CH;
@@ -164,84 +171,149 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int s_end = KS4 ? (total_steps * (wave + 1)) / 4 : total_steps;
     const frag_t* wbase = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
 
-    auto load_src = [&](auto sidx, int ks, frag_t (&bf)[PT]) {
-        constexpr int S = decltype(sidx)::value;
-        const int c0 = ks * F::KS + g * CH;
-        const bool kvalid = c0 < a.srcC[S];
-        const T* sp = static_cast<const T*>(a.src[S]);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) bf[pt] = (pvalid[pt] && kvalid) ? ldg16<T>(sp + offs[pt][S] + c0) : F::zero();
-    };
+    // Activation fragments of k-step `step` (0 .. last; a step past `last` is reduction padding and reads zeros).
+    // EVERY load is unconditional: a load under a branch makes the compiler wait with vmcnt(0) at the next use, which
+    // serialises the software pipeline.  So: pixels past the last one read pixel 0 (their rows are never stored), channel
+    // chunks past a source's last channel read chunk 0 (their weight rows are zero), out-of-image taps and padding steps
+    // read the 16-byte zero page, and the source of a concat is chosen with scalar selects, not branches.
+    const int last_step = (KS4 ? (total_steps * (wave + 1)) / 4 : total_steps) - 1;
+    const T* zpage = reinterpret_cast<const T*>(g_zero16);
     auto load_b = [&](int step, frag_t (&bf)[PT]) {
+        const bool pad = step > last_step;                                 // uniform
+        const int sc = pad ? last_step : step;
         if (VAR == VAR_3X3S2) {
-            const int tap = step / a.ksteps, ks = step - tap * a.ksteps;
+            const int tap = sc / a.ksteps, ks = sc - tap * a.ksteps;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int c0 = ks * F::KS + g * CH;
+            int c0 = ks * F::KS + g * CH;
+            c0 = c0 < a.Cin ? c0 : 0;
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const int iy = iy0[pt] + ky, ix = ix0[pt] + kx;
-                const bool ok = pvalid[pt] && c0 < a.Cin && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+                const bool ok = !pad && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;    // else: the zero padding
                 const uint32_t o = (off0[pt] + (uint32_t)(iy * a.Win + ix)) * a.srcStride[0] + a.srcCoff[0] + c0;
-                bf[pt] = ok ? ldg16<T>(s0 + o) : F::zero();
+                bf[pt] = ldg16<T>(ok ? s0 + o : zpage);
             }
         } else if (VAR == VAR_MULTI) {
-            // uniform (scalar) source selection: every source owns whole k-steps
-            if (step < a.cum[1]) load_src(std::integral_constant<int, 0>{}, step, bf);
-            else if (step < a.cum[2]) load_src(std::integral_constant<int, 1>{}, step - a.cum[1], bf);
-            else if (step < a.cum[3]) load_src(std::integral_constant<int, 2>{}, step - a.cum[2], bf);
-            else load_src(std::integral_constant<int, 3>{}, step - a.cum[3], bf);
-        } else {
-            const int c0 = step * F::KS + g * CH;
-            const bool kvalid = c0 < a.Cin;
+            // every source owns whole k-steps: source index and its first step by scalar selects
+            const int i1 = sc >= a.cum[1], i2 = sc >= a.cum[2], i3 = sc >= a.cum[3];
+            const int first = i3 ? a.cum[3] : i2 ? a.cum[2] : i1 ? a.cum[1] : 0;
+            const int srcC = i3 ? a.srcC[3] : i2 ? a.srcC[2] : i1 ? a.srcC[1] : a.srcC[0];
+            const T* sp = static_cast<const T*>(i3 ? a.src[3] : i2 ? a.src[2] : i1 ? a.src[1] : a.src[0]);
+            int c0 = (sc - first) * F::KS + g * CH;
+            c0 = c0 < srcC ? c0 : 0;
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                if (pvalid[pt] && kvalid) {
-                    const T* q = s0 + off0[pt] + c0;
-                    if (VAR == VAR_POOL2) {
-                        const uint32_t rs = (uint32_t)(2 * a.W) * a.srcStride[0];
-                        frag_t v0 = ldg16<T>(q), v1 = ldg16<T>(q + a.srcStride[0]);
-                        frag_t v2 = ldg16<T>(q + rs), v3 = ldg16<T>(q + rs + a.srcStride[0]);
-                        bf[pt] = F::vmax(F::vmax(v0, v1), F::vmax(v2, v3));
-                    } else {
-                        bf[pt] = ldg16<T>(q);
-                    }
+                const uint32_t o = i3 ? offs[pt][3] : i2 ? offs[pt][2] : i1 ? offs[pt][1] : offs[pt][0];
+                bf[pt] = ldg16<T>(pad ? zpage : sp + o + c0);
+            }
+        } else {
+            int c0 = sc * F::KS + g * CH;
+            c0 = c0 < a.Cin ? c0 : 0;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const T* q = pad ? zpage : s0 + off0[pt] + c0;
+                if (VAR == VAR_POOL2) {
+                    const uint32_t cs = pad ? 0u : (uint32_t)a.srcStride[0], rs = pad ? 0u : (uint32_t)(2 * a.W) * a.srcStride[0];
+                    frag_t v0 = ldg16<T>(q), v1 = ldg16<T>(q + cs);
+                    frag_t v2 = ldg16<T>(q + rs), v3 = ldg16<T>(q + rs + cs);
+                    bf[pt] = F::vmax(F::vmax(v0, v1), F::vmax(v2, v3));
                 } else {
-                    bf[pt] = F::zero();
+                    bf[pt] = ldg16<T>(q);
                 }
             }
         }
     };
-    auto load_a = [&](int step, frag_t (&af)[CT]) {
+    auto load_a = [&](int step, frag_t (&af)[CT]) {                       // weights: padding steps re-read the last step (times zero activations)
+        const int sc = step > last_step ? last_step : step;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * total_steps + step) * 64];
+        for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * total_steps + sc) * 64];
+    };
+    auto mma_stage = [&](const frag_t (&bf)[PT], const frag_t (&af)[CT]) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(bf[pt], af[ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
     };
 
+    if constexpr (LB) {
+        // Long reductions (3x3 taps, wide concats): the four waves of a workgroup use the SAME weight fragments, and at
+        // CT KiB per k-step per wave the L2 -> L1 weight stream, not HBM, bounds the layer.  Here the workgroup fetches each
+        // k-step's CT fragments once (global -> registers during the previous step's MFMAs -> LDS, double-buffered, one
+        // barrier per step) and every wave reads them with ds_read_b128; activations keep a private, deep register ring.
+        extern __shared__ __attribute__((aligned(16))) unsigned char lb_raw[];
+        frag_t* lb = reinterpret_cast<frag_t*>(lb_raw);                   // [2][CT * 64]
+        constexpr int NV = (CT * 64 + 255) / 256;
+        const frag_t* wsrc = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64;
+        constexpr int WD = 3;                                             // weight fragments leave global memory WD k-steps before their MFMAs
+        frag_t wreg[WD][NV];
+        auto gload = [&](int step, frag_t (&wr)[NV]) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + v * 256;
+                if (idx < CT * 64) wr[v] = wsrc[((size_t)(idx >> 6) * total_steps + step) * 64 + (idx & 63)];
+            }
+        };
+        auto lstore = [&](int buf, const frag_t (&wr)[NV]) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + v * 256;
+                if (idx < CT * 64) lb[buf * (CT * 64) + idx] = wr[v];
+            }
+        };
+        constexpr int NS = 6;                                             // activation loads run NS - 1 k-steps ahead (few, long wave-chains must keep many bytes in flight)
+        static_assert(NS % WD == 0, "ring indices are static");
+        frag_t bst[NS][PT];
+#pragma unroll
+        for (int s = 0; s < WD; ++s) gload(min(s, last_step), wreg[s]);
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) load_b(s, bst[s]);
+        lstore(0, wreg[0]);
+        gload(min(WD, last_step), wreg[0]);
+        __syncthreads();
+        // the trip count is rounded up to whole rings: padding steps multiply zero activations (zero page) with re-read weights,
+        // so the loop body has no branch and every s_waitcnt counts exactly the loads that may stay in flight
+        for (int step0 = 0; step0 < total_steps; step0 += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int step = step0 + u;
+                load_b(step + NS - 1, bst[(u + NS - 1) % NS]);
+                const frag_t* wl = lb + (step & 1) * (CT * 64) + lane;
+                frag_t wf[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wf[ct] = wl[ct * 64];
+                mma_stage(bst[u], wf);
+                lstore((step + 1) & 1, wreg[(u + 1) % WD]);              // weights of step + 1, loaded WD - 1 steps ago
+                gload(min(step + 1 + WD, last_step), wreg[(u + 1) % WD]);
+                __syncthreads();
+            }
+        }
+    } else {
     // Software pipeline: a ring of NS register stages, loads issued NS-1 k-steps ahead of their MFMAs.
     // Small-M layers (PT == 1: the 20x20 / 40x40 maps) are latency-bound chains of short k-steps, so they
     // run 4 stages deep; big layers (PT == 2) keep 2 stages and spend the registers on occupancy instead.
+    // The trip count is rounded up to whole rings (padding steps: zero activations x re-read weights), so the loop body is
+    // branch-free and the compiler's s_waitcnt lets exactly the prefetched stages stay in flight across the MFMAs.
     constexpr int NS = PT == 1 ? 4 : 2;
     frag_t bst[NS][PT], ast[NS][CT];
+    if (s_end - s_begin == 1) {                                           // single k-step (Cin <= 32): nothing to pipeline
+        load_b(s_begin, bst[0]);
+        load_a(s_begin, ast[0]);
+        mma_stage(bst[0], ast[0]);
+    } else {
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s_begin + s < s_end) {
+        for (int s = 0; s < NS - 1; ++s) {
             load_b(s_begin + s, bst[s]);
             load_a(s_begin + s, ast[s]);
         }
-    for (int step0 = s_begin; step0 < s_end; step0 += NS) {
+        for (int step0 = s_begin; step0 < s_end; step0 += NS) {
 #pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const int step = step0 + u;
-            if (step < s_end) {
-                if (step + NS - 1 < s_end) {
-                    load_b(step + NS - 1, bst[(u + NS - 1) % NS]);
-                    load_a(step + NS - 1, ast[(u + NS - 1) % NS]);
-                }
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(bst[u][pt], ast[u][ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
+            for (int u = 0; u < NS; ++u) {
+                load_b(step0 + u + NS - 1, bst[(u + NS - 1) % NS]);
+                load_a(step0 + u + NS - 1, ast[(u + NS - 1) % NS]);
+                mma_stage(bst[u], ast[u]);
             }
         }
+    }
     }
 
     if constexpr (KS4) {      // reduce the four partial accumulators through LDS; wave 0 finishes the tile
@@ -328,6 +400,23 @@ int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
         if (ct == 8) return launch_act<T, 1, 8, VAR, OUTF32, true>(a, s);
     }
     maf_set_error("conv: unsupported tile (tile_p in {1,2,4}, tile_c in {2,4,6,8}; tile_p = 4 only with tile_c <= 4)");
+    return MAF_E_UNSUPPORTED;
+}
+
+template <int PT, int CT, int VAR>
+int launch_lb(const ConvArgs& a, hipStream_t s) {
+    const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
+    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true>), dim3(grid), dim3(256), 2 * CT * 1024, s, a);
+    return maf_check_hip(hipGetLastError(), "conv_mfma (LDS-shared weights) launch");
+}
+
+template <int VAR>
+int launch_lb_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
+#define MAF_LB(P, C) \
+    if (pt == P && ct == C) return launch_lb<P, C, VAR>(a, s);
+    MAF_LB(1, 4) MAF_LB(2, 4) MAF_LB(4, 4) MAF_LB(1, 6) MAF_LB(2, 6) MAF_LB(1, 8) MAF_LB(2, 8)
+#undef MAF_LB
+    maf_set_error("conv: tile_k = 2 (LDS-shared weights) supports tile_c in {4,6,8}, tile_p in {1,2} (4 with tile_c 4)");
     return MAF_E_UNSUPPORTED;
 }
 

@@ -374,6 +374,11 @@ class Plan:
                     ksteps = sum(-(-o.src[k].C // (32 if self.dtype == lib.F16 else 16)) for k in range(o.nsrc)) * (9 if o.kind == lib.OP_CONV3X3S2 else 1)
                     if ksteps >= 8 and M <= 65536:
                         cands.append((1, ct, 4))                 # split-K across the 4 waves: long reductions on small maps
+                    pooled = o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2
+                    if ksteps >= 4 and ct >= 4 and self.dtype == lib.F16 and not o.out_f32 and not pooled:
+                        for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
+                            if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
+                                cands.append((pt, ct, 2))
                 results = []
                 for pt, ct, tk in cands:
                     wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
@@ -392,7 +397,7 @@ class Plan:
                 best = (results[0][1], results[0][2], results[0][3])
                 _TUNE_CACHE[sig] = best
                 if verbose:
-                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, ",k4" if k == 4 else "", t * 1e3) for t, p, c, k in results)))
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
                 wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
@@ -450,7 +455,7 @@ class Plan:
             else:
                 var = 1
             outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
-            return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false")
+            return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
         if o.kind == lib.OP_DWCONV:
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:

@@ -109,6 +109,45 @@ def test_conv_split_k(dt, kind):
     _check(out, ref_fn(bias), dt)
 
 
+@pytest.mark.parametrize("kind,pt,ct", [("1x1", 2, 8), ("1x1", 1, 6), ("3x3", 2, 4), ("3x3", 1, 8), ("3x3", 4, 4), ("multi", 2, 6)])
+def test_conv_lds_shared_weights(kind, pt, ct):
+    """tile_k = 2: the workgroup stages each k-step's weight fragments in LDS once for its four waves (long reductions)."""
+    g = torch.Generator().manual_seed(17 + pt + ct)
+    dt, B = lib.F16, 2
+    cout = {8: 128, 6: 88, 4: 64}[ct]
+    Hin = Win = 0
+    if kind == "1x1":
+        cin, H, W = 200, 11, 13
+        x = _q(torch.randn(B, cin, H, W, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [cin], ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(x, w, b))
+        opk, srcs = lib.OP_CONV1X1, [(_nhwc(x, dt), cin, cin, 0, 0)]
+    elif kind == "3x3":
+        cin, Hin, Win, H, W = 72, 18, 22, 9, 11
+        x = _q(torch.randn(B, cin, Hin, Win, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dt)
+        wp = pack.pack_conv3x3(w, ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(x, w, b, 2, 1))
+        opk, srcs = lib.OP_CONV3X3S2, [(_nhwc(x, dt), cin, cin, 0, 0)]
+    else:
+        ca, cb, H, W = 40, 64, 8, 12
+        cin = ca + cb
+        a = _q(torch.randn(B, ca, H, W, generator=g), dt)
+        bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [ca, cb], ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(torch.cat([a, F.interpolate(bsm, scale_factor=2, mode="nearest")], 1), w, b))
+        opk, srcs = lib.OP_CONV1X1, [(_nhwc(a, dt), ca, ca, 0, 0), (_nhwc(bsm, dt), cb, cb, 0, 1)]
+    bias = torch.randn(cout, generator=g)
+    out = torch.zeros(B, H, W, cout + 8, dtype=DT[dt], device=DEV)
+    op = _conv_op(opk, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, out, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), pt, ct, Hin=Hin, Win=Win)
+    op.tile_k = 2
+    _launch(op)
+    _check(out[..., 8:], ref_fn(bias), dt)
+    assert (out[..., :8] == 0).all()
+
+
 def test_conv1x1_out_f32():
     g = torch.Generator().manual_seed(5)
     B, H, W, cin, cout = 1, 8, 8, 128, 68

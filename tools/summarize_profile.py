@@ -18,16 +18,16 @@ _T = {"DF16_": "_Float16", "f": "float", "h": "unsigned char"}
 def demangle(n):
     """c++filt does not know the _Float16 mangling (DF16_), so the few kernel templates of this library are decoded here."""
     import re
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+conv_mfma_kernelI(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])EEEv", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+conv_mfma_kernelI(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])EEEv", n)
     if m:
-        return "conv_mfma_kernel<%s, %s, %s, %s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3), m.group(4), "true" if m.group(5) == "1" else "false",
-                                                         "true" if m.group(6) == "1" else "false")
+        tf = lambda g: "true" if m.group(g) == "1" else "false"
+        return "conv_mfma_kernel<%s, %s, %s, %s, %s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3), m.group(4), tf(5), tf(6), tf(7))
     m = re.match(r"_ZN12_GLOBAL__N_1\d+dwconv_tile_kernelI(DF16_|f)Li(\d+)ELi(\d+)EEEv", n)
     if m:
         return "dwconv_tile_kernel<%s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3))
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+stem_kernelI(DF16_|f|h)(DF16_|f)EEv", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+stem_kernelI(DF16_|f|h)(DF16_|f)Lb([01])EEEv", n)
     if m:
-        return "stem_kernel<%s, %s>" % (_T[m.group(1)], _T[m.group(2)])
+        return "stem_kernel<%s, %s, %s>" % (_T[m.group(1)], _T[m.group(2)], "true" if m.group(3) == "1" else "false")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+(sppf_pool\w*_kernel)I(DF16_|f)", n)
     if m:
         return "%s<%s>" % (m.group(1), _T[m.group(2)])
