@@ -158,6 +158,19 @@ int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtyp
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, maf_stream_t stream);
 
+/*
+ * Post-NMS tail — replaces Evaler.scale_coords (yolov6/core/evaler.py:382-409, ratio_pad branch), box_convert
+ * (:374-381) and the tensor part of convert_to_coco_format (:411-420) for a whole batch in one launch.
+ *   rows [B,max_det,6] / count [B]   the outputs of maf_nms
+ *   img_params [B][6] fp32           original h0, w0, gain applied to x, gain applied to y, pad_w, pad_h  (the reference divides
+ *                                    x by gain[1] only with scale_exact, else both axes by gain[0])
+ *   ids [n_ids]                      class index -> dataset category id (COCO 80 -> 91 table), may be NULL with n_ids = 0
+ *   out [sum(count)][7] fp32         image index in the batch, category id, x, y, w, h (original-image pixels), score;
+ *                                    rows of image b follow those of image b-1; *out_total = number of rows
+ */
+int maf_coco_rows(const float* rows, const int32_t* count, int32_t B, int32_t max_det, const float* img_params,
+                  const int32_t* ids, int32_t n_ids, float* out, int32_t* out_total, maf_stream_t stream);
+
 /* Diagnostics: shader-clock cycle stamps of image 0 of the last maf_nms call (synchronises the device):
  * [0] sort, [1] kept-list screening, [2] wave resolution, [3] total, [4] candidates, [5] survivors. */
 int maf_nms_debug(uint64_t* host8);

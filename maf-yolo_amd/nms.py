@@ -2,7 +2,7 @@
 
 Same signature, same return type (a Python list of [n_i, 6] tensors (x1,y1,x2,y2,conf,cls) on
 prediction.device, `zeros((0,6))`-shaped for empty images), same AssertionError on bad thresholds
-(nms.py:50-51).  The whole batch is two kernel launches (csrc/nms.hip) and ONE device->host copy
+(nms.py:50-51).  The whole batch is five kernel launches (csrc/nms.hip) and ONE device->host copy
 (the per-image counts) instead of a Python loop with ~6 implicit syncs per image.
 
 Differences, all documented in DESIGN.md: decode/NMS arithmetic is fp32 even for fp16 predictions
@@ -80,7 +80,7 @@ class NmsHandle:
 
 
 def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
-    """Same arguments as non_max_suppression, but the two kernels go to a side stream ordered after the current one and
+    """Same arguments as non_max_suppression, but the kernels go to a side stream ordered after the current one and
     the call returns at once; `handle.result()` gives the reference's list of tensors.  A serving loop calls this for
     batch i, launches the forward of batch i+1, then collects batch i: the (latency-bound, 32-workgroup) NMS of one
     batch overlaps the convolutions of the next."""

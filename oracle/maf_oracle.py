@@ -576,3 +576,43 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         keep = greedy_nms(rows[:, :4] + off, rows[:, 4], iou_thres)[:max_det]   # nms.py:95-98
         out.append(rows[keep]); idx_out.append(flat[keep])
     return (out, idx_out) if return_index else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Post-NMS tail: Evaler.scale_coords / box_convert / convert_to_coco_format, yolov6/core/evaler.py:374-434
+# ---------------------------------------------------------------------------------------------------------------------
+def scale_coords(coords, shape0, ratio_pad, scale_exact=False):
+    """evaler.py:382-409 with ratio_pad given (the only branch the reference can execute: its `ratio_pad is None` branch
+    multiplies an int by a list).  coords [n,4] fp32 xyxy in network-input pixels -> original-image pixels, clamped.
+    Scalars enter the fp32 tensor arithmetic as fp32, exactly as torch does."""
+    c = np.array(coords, dtype=np.float32, copy=True)
+    gain, pad = ratio_pad
+    gx = np.float32(gain[1] if scale_exact else gain[0])
+    gy = np.float32(gain[0])
+    c[:, [0, 2]] = (c[:, [0, 2]] - np.float32(pad[0])) / gx
+    c[:, [1, 3]] = (c[:, [1, 3]] - np.float32(pad[1])) / gy
+    c[:, [0, 2]] = np.clip(c[:, [0, 2]], np.float32(0), np.float32(shape0[1]))
+    c[:, [1, 3]] = np.clip(c[:, [1, 3]], np.float32(0), np.float32(shape0[0]))
+    return c
+
+
+def coco_rows(outputs, shapes, image_ids, ids, scale_exact=False):
+    """evaler.py:411-434: list of per-image [n,6] (x1,y1,x2,y2,conf,cls) -> (image_id [R], category_id [R], bbox [R,4] =
+    x,y,w,h rounded to 3 decimals, score [R] rounded to 5), images with no detection skipped."""
+    iid, cid, bb, sc = [], [], [], []
+    for i, pred in enumerate(outputs):
+        pred = np.asarray(pred, dtype=np.float32)
+        if pred.shape[0] == 0:
+            continue
+        xy = scale_coords(pred[:, :4], shapes[i][0], shapes[i][1], scale_exact)
+        cx = (xy[:, 0] + xy[:, 2]) / np.float32(2); cy = (xy[:, 1] + xy[:, 3]) / np.float32(2)     # box_convert :374-381
+        w = xy[:, 2] - xy[:, 0]; h = xy[:, 3] - xy[:, 1]
+        x = cx - w / np.float32(2); y = cy - h / np.float32(2)                                      # :420
+        box = np.stack([x, y, w, h], 1).astype(np.float64)
+        bb.append(np.round(box * 1000.0) / 1000.0)               # == Python round(v, 3) for doubles that come from fp32 (v*1000 is exact)
+        sc.append(np.round(pred[:, 4].astype(np.float64) * 100000.0) / 100000.0)
+        cid.append(np.asarray(ids)[pred[:, 5].astype(np.int64)])
+        iid.append(np.full(pred.shape[0], image_ids[i], dtype=np.int64))
+    if not bb:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 4)), np.zeros(0)
+    return np.concatenate(iid), np.concatenate(cid).astype(np.int64), np.concatenate(bb), np.concatenate(sc)

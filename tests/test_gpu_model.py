@@ -281,3 +281,39 @@ def test_fusion_choice_is_measured_when_autotuning():
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf = sum(1 for o in plan.ops if o.kind == 6)
     assert len(plan.ops) == 90 - 2 * nf
+
+
+def test_post_nms_tail_matches_reference_fixture(golden):
+    """f4: convert_to_coco_format on the device == the reference's Evaler.convert_to_coco_format (tools/make_golden_post.py)."""
+    g = golden("post_cases")
+    ids = g["ids"].tolist()
+    for ci in range(3):
+        counts = g["c%d_counts" % ci]
+        dets = torch.from_numpy(g["c%d_dets" % ci])
+        outs, o = [], 0
+        for n in counts:
+            outs.append(dets[o:o + int(n)].to(DEV)); o += int(n)
+        shapes = [((s[0], s[1]), ((s[2], s[3]), (s[4], s[5]))) for s in g["c%d_shapes" % ci]]
+        paths = ["/x/%012d.jpg" % i for i in g["c%d_image_ids" % ci]]
+        res = M.convert_to_coco_format(outs, torch.zeros(len(outs), 3, 640, 640), paths, shapes, ids, is_coco=True,
+                                       scale_exact=bool(g["c%d_scale_exact" % ci]))
+        assert [r["image_id"] for r in res] == g["c%d_out_image_id" % ci].tolist()
+        assert [r["category_id"] for r in res] == g["c%d_out_category_id" % ci].tolist()
+        assert np.array_equal(np.asarray([r["bbox"] for r in res]).reshape(-1, 4), g["c%d_out_bbox" % ci])
+        assert np.array_equal(np.asarray([r["score"] for r in res]), g["c%d_out_score" % ci])
+
+
+def test_post_nms_tail_from_device_nms_result(models):
+    """The tail consumes the NMS result without a host round trip; equals the oracle on the same detections."""
+    x = O.synth_images(3, 320, 5).to(DEV)
+    with torch.no_grad():
+        pred = models["n"](x)[0]
+    raw = M.nms_raw(pred, 0.03, 0.65, multi_label=True)
+    shapes = [((480, 640), ((0.5, 0.5), (0.0, 40.0))), ((333, 500), ((0.64, 0.64), (0.0, 53.44))), ((1080, 1920), ((1 / 6, 1 / 6), (0.0, 70.0)))]
+    ids = list(range(1, 81))
+    res = M.convert_to_coco_format(raw, x, ["1.jpg", "2.jpg", "3.jpg"], shapes, ids)
+    counts = raw[2].tolist()
+    outs = [raw[0][b, :n].cpu().numpy() for b, n in enumerate(counts)]
+    iid, cid, bb, sc = O.coco_rows(outs, shapes, [1, 2, 3], ids)
+    assert len(res) == sum(counts) and [r["image_id"] for r in res] == iid.tolist() and [r["category_id"] for r in res] == cid.tolist()
+    assert np.array_equal(np.asarray([r["bbox"] for r in res]).reshape(-1, 4), bb) and np.array_equal(np.asarray([r["score"] for r in res]), sc)

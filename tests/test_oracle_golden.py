@@ -145,3 +145,19 @@ def test_greedy_nms_rule():
     assert list(O.greedy_nms(b, s, 0.49)) == [2, 0]
     assert list(O.greedy_nms(b[[0, 3]], s[[0, 3]], 0.5)) == [0, 1]
     assert list(O.greedy_nms(b[[0, 3]], s[[0, 3]], 0.4999)) == [0]
+
+
+def test_post_nms_tail_oracle_matches_reference_fixture(golden):
+    """oracle.coco_rows == the reference's Evaler.convert_to_coco_format on the vectors of tools/make_golden_post.py."""
+    g = golden("post_cases")
+    ids = g["ids"]
+    for ci in range(3):
+        counts = g["c%d_counts" % ci]
+        dets = g["c%d_dets" % ci]
+        outs, o = [], 0
+        for n in counts:
+            outs.append(dets[o:o + n]); o += n
+        shapes = [((s[0], s[1]), ((s[2], s[3]), (s[4], s[5]))) for s in g["c%d_shapes" % ci]]
+        iid, cid, bb, sc = O.coco_rows(outs, shapes, g["c%d_image_ids" % ci], ids, bool(g["c%d_scale_exact" % ci]))
+        assert np.array_equal(iid, g["c%d_out_image_id" % ci]) and np.array_equal(cid, g["c%d_out_category_id" % ci])
+        assert np.array_equal(bb, g["c%d_out_bbox" % ci]) and np.array_equal(sc, g["c%d_out_score" % ci])
