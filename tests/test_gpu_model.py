@@ -317,3 +317,18 @@ def test_post_nms_tail_from_device_nms_result(models):
     iid, cid, bb, sc = O.coco_rows(outs, shapes, [1, 2, 3], ids)
     assert len(res) == sum(counts) and [r["image_id"] for r in res] == iid.tolist() and [r["category_id"] for r in res] == cid.tolist()
     assert np.array_equal(np.asarray([r["bbox"] for r in res]).reshape(-1, 4), bb) and np.array_equal(np.asarray([r["score"] for r in res]), sc)
+
+
+def test_checkpoint_bridge_forward_matches_reference_output(golden):
+    """f3: weights read from a reference-pickled checkpoint drive the HIP engine to the reference model's own prediction."""
+    import os
+    from maf_yolo_amd import checkpoint
+    g = golden("ref_ckpt_tiny")
+    m = checkpoint.load_checkpoint(os.path.join(os.path.dirname(__file__), "golden", "ref_ckpt_tiny.pt")).to(DEV)
+    x = O.synth_images(1, 64, 3).to(DEV)
+    with torch.no_grad():
+        pred = m(x)[0].cpu().numpy()
+    ref = g["pred"]
+    assert pred.shape == ref.shape
+    assert np.abs(pred[..., :4] - ref[..., :4]).max() <= 1e-3 + 1e-5 * np.abs(ref[..., :4]).max()
+    assert np.abs(pred[..., 4:] - ref[..., 4:]).max() <= 2e-5

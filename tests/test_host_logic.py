@@ -190,3 +190,23 @@ def test_tune_cache_roundtrip(tmp_path):
     finally:
         engine._TUNE_CACHE.clear()
         engine._TUNE_CACHE.update(saved)
+
+
+def test_checkpoint_bridge_reads_reference_pt_without_reference_code(golden):
+    """f3: a checkpoint pickled by the reference's trainer (modules, fp16, 'model' + 'ema') loads with no yolov6 on sys.path."""
+    import hashlib
+    import sys
+    from maf_yolo_amd import checkpoint
+    assert "yolov6" not in sys.modules
+    g = golden("ref_ckpt_tiny")
+    path = os.path.join(os.path.dirname(__file__), "golden", "ref_ckpt_tiny.pt")
+    sd, yaml_dict, nc, raw = checkpoint.read_reference_checkpoint(path)
+    assert raw["epoch"] == 3 and raw["updates"] == 17 and nc == 80 and yaml_dict["width_multiple"] == 0.125
+    m = checkpoint.load_checkpoint(path)
+    msd = m.state_dict()
+    assert len(msd) == int(g["n_keys"]) and not m.training and all(v.dtype != torch.float16 for v in msd.values())
+    h = int(hashlib.sha1("\n".join("%s %s" % (k, tuple(v.shape)) for k, v in msd.items()).encode()).hexdigest()[:12], 16)
+    assert h == int(g["key_hash"][0])                                     # same names, same order, same shapes as the reference's
+    assert abs(float(sum(v.double().sum() for v in msd.values())) - float(g["checksum"][0])) < 1e-6 * abs(float(g["checksum"][0])) + 1e-6   # the EMA weights
+    back = checkpoint.reference_state_dict(m)
+    assert list(back) == list(msd)
