@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
             const Cand me = cands[i];
             unsigned long long bits = 0;
             const int jn = min(64, n - j0);
-            for (int j = (cbk == rb ? lane + 1 : 0); j < jn; ++j)
+            for (int j = (cbk == rb ? lane + 1 : 0); j < jn; ++j)    // diagonal block: only later candidates
                 if (iou_gt(me, cb[j], iouthr)) bits |= 1ull << j;
             mask[(size_t)i * kMaskW + cbk] = bits;
         }
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
     if (tid == 0) { s_nk = 0; s_done = 0; }
     unsigned long long removed = 0;                            // wave 0: lane w = word w of the removed set
     // each thread stages 16 words of a block: row r = tid >> 2, words (tid & 3) * 16 .. +15 (only words >= blk are defined)
-    unsigned long long pre[16];
-    auto load_blk = [&](int blk) {
+    unsigned long long pre0[16], pre1[16];                     // two blocks in flight: the matrix rows are read two blocks ahead
+    auto load_blk = [&](int blk, unsigned long long (&pre)[16]) {
         const int r = tid >> 2, w0 = (tid & 3) * 16;
         const int i = blk * 64 + r;
 #pragma unroll
@@ -508,47 +508,55 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
             pre[u] = (i < n && w >= blk && w < nb) ? mask[(size_t)i * kMaskW + w] : 0ull;
         }
     };
-    auto store_blk = [&]() {
+    auto store_blk = [&](const unsigned long long (&pre)[16]) {
         const int r = tid >> 2, w0 = (tid & 3) * 16;
 #pragma unroll
         for (int u = 0; u < 16; ++u) rows[r][w0 + u] = pre[u];
     };
-    load_blk(0);
-    for (int blk = 0; blk < nb; ++blk) {
-        __syncthreads();                                       // previous block's rows are no longer read
-        store_blk();
-        if (blk + 1 < nb) load_blk(blk + 1);                   // in flight while this block is decided
-        __syncthreads();
-        if (wave == 0) {
-            int nk = s_nk;
-            const unsigned long long diag = rows[lane][blk];   // lane r: later candidates of this block that r suppresses
-            const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-            const unsigned int rlo = (unsigned int)removed, rhi = (unsigned int)(removed >> 32);
-            const unsigned long long rw = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rhi, blk) << 32) |
-                                          (unsigned int)__builtin_amdgcn_readlane((int)rlo, blk);
-            const int nvalid = min(64, n - blk * 64);
-            unsigned long long todo = ~rw & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
-            unsigned long long keep = 0;
-            int room = a.max_det - nk;
-            while (todo != 0 && room > 0) {                    // scalar: a survivor clears the bits of the candidates it suppresses
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                keep |= 1ull << j;
-                --room;
-                const unsigned long long dj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
-                                              (unsigned int)__builtin_amdgcn_readlane((int)dlo, j);
-                todo &= ~dj;
-            }
-            if ((keep >> lane) & 1ull) kept_idx[nk + __popcll(keep & ((1ull << lane) - 1ull))] = blk * 64 + lane;
-            nk += __popcll(keep);
-            unsigned long long k2 = keep;                      // removed |= rows of the survivors (lane = word; words <= blk are dead)
-            while (k2) {
-                const int j = __ffsll((long long)k2) - 1;
-                k2 &= k2 - 1;
-                removed |= rows[j][lane];
-            }
-            if (lane == 0) { s_nk = nk; if (nk >= a.max_det) s_done = 1; }
+    auto decide = [&](int blk) {                               // wave 0: survivors of block blk, then their rows into `removed`
+        int nk = s_nk;
+        const unsigned long long diag = rows[lane][blk];       // lane r: later candidates of this block that r suppresses
+        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+        const unsigned int rlo = (unsigned int)removed, rhi = (unsigned int)(removed >> 32);
+        const unsigned long long rw = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rhi, blk) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readlane((int)rlo, blk);
+        const int nvalid = min(64, n - blk * 64);
+        unsigned long long todo = ~rw & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
+        unsigned long long keep = 0;
+        int room = a.max_det - nk;
+        while (todo != 0 && room > 0) {                        // scalar: a survivor clears the bits of the candidates it suppresses
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            keep |= 1ull << j;
+            --room;
+            const unsigned long long dj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)dlo, j);
+            todo &= ~dj;
         }
+        if ((keep >> lane) & 1ull) kept_idx[nk + __popcll(keep & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+        nk += __popcll(keep);
+        unsigned long long k2 = keep;                          // removed |= rows of the survivors (lane = word; words <= blk are dead)
+        while (k2) {
+            const int j = __ffsll((long long)k2) - 1;
+            k2 &= k2 - 1;
+            removed |= rows[j][lane];
+        }
+        if (lane == 0) { s_nk = nk; if (nk >= a.max_det) s_done = 1; }
+    };
+    load_blk(0, pre0);
+    load_blk(1, pre1);
+    for (int blk = 0; blk < nb; blk += 2) {
+        __syncthreads();                                       // previous block's rows are no longer read
+        store_blk(pre0);
+        load_blk(blk + 2, pre0);
+        __syncthreads();
+        if (wave == 0) decide(blk);
+        __syncthreads();
+        if (s_done || blk + 1 >= nb) break;
+        store_blk(pre1);
+        load_blk(blk + 3, pre1);
+        __syncthreads();
+        if (wave == 0) decide(blk + 1);
         __syncthreads();
         if (s_done) break;
     }
