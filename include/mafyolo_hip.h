@@ -64,7 +64,9 @@ typedef struct {
  *                   2H x 2W input (Hin, Win below); w packed per tap.
  * MAF_OP_DWCONV     replaces DilatedReparamBlock.lk_origin after merge (common.py:3025,3033-3051).
  *                   w = [k*k][C] of the activation dtype.  tile_p / tile_c / tile_k optionally fix the workgroup tile
- *                   (rows, cols, channels per block); 0 = built-in cost model.
+ *                   (rows, cols, channels per block); 0 = built-in cost model.  tile_p = -1 (fp16) selects the matrix-core
+ *                   variant (csrc/dwconv_mfma.hip), whose operand is aux[0] = the Toeplitz table [C/32][8][k][parts][16][8] f16
+ *                   (maf-yolo_amd/pack.py:pack_dw_toeplitz).
  * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
  *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
  * MAF_OP_BOTTLENECK replaces one DepthBottleneckUni in deploy form (common.py:918-927: 1x1 c->3c + SiLU, depth-wise k x k + SiLU,
@@ -95,7 +97,7 @@ typedef struct {
     int32_t lvl_h[3], lvl_w[3];
     int32_t reg_stride, nc, reg_max;
     float lvl_stride[3];
-    const void* aux[4];          /* reserved (0)                                                                        */
+    const void* aux[4];          /* DWCONV: aux[0] = Toeplitz table of the matrix-core variant (else 0)                 */
 } maf_op_t;
 
 const char* maf_last_error(void);

@@ -41,7 +41,8 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     const int ct = op->tile_c;
     MAF_REQUIRE(pt > 0 && ct > 0, "conv: tile_p/tile_c not set");
     const bool ks4 = op->tile_k == 4;
-    MAF_REQUIRE(op->tile_k == 0 || op->tile_k == 1 || op->tile_k == 2 || op->tile_k == 4, "conv: tile_k must be 1, 2 (weights through LDS) or 4 (split-K)");
+    MAF_REQUIRE(op->tile_k >= 0 && op->tile_k <= 5, "conv: tile_k must be 1, 2 (weights through LDS), 3 / 5 (persistent streaming 1x1) or 4 (split-K)");
+    const bool stream = op->tile_k == 3;
     const bool lb = op->tile_k == 2;
     MAF_REQUIRE(!lb || (op->dtype == MAF_F16 && !op->out_f32), "conv: tile_k = 2 is an fp16-output variant");
     MAF_REQUIRE(!ks4 || pt == 1, "conv: split-K (tile_k = 4) needs tile_p = 1");
@@ -65,6 +66,15 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(!outf32 || var == VAR_DIRECT, "conv: out_f32 only for single direct source");
     a.act = op->act;
     MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv: bad act");
+    if (stream) {
+        MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32 && var == VAR_DIRECT && a.nsrc == 1, "conv: tile_k = 3 is an fp16 single-direct-source 1x1 variant");
+        return maf_conv1x1_stream(a, pt, ct, s);
+    }
+    if (op->tile_k == 5) {
+        MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32 && pt == 1 && (var == VAR_DIRECT || var == VAR_MULTI), "conv: tile_k = 5 is an fp16 1x1 variant with tile_p = 1");
+        a.nM = maf_cdiv(a.M, 16);
+        return maf_conv1x1_stream_lds(a, var, ct, s);
+    }
     if (lb) return maf_conv_mfma_f16_lb(a, var, pt, ct, s);
     if (op->dtype == MAF_F16) return maf_conv_mfma_f16(a, var, outf32, pt, ct, s);
     return maf_conv_mfma_f32(a, var, false, pt, ct, s);

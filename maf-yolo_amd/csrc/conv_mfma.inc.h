@@ -51,6 +51,8 @@ enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3 };
 int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f32(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f16_lb(const ConvArgs& a, int var, int pt, int ct, hipStream_t s);   // weights shared through LDS (tile_k = 2)
+int maf_conv1x1_stream(const ConvArgs& a, int pt, int ct, hipStream_t s);              // persistent waves, cross-tile prefetch (tile_k = 3)
+int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s);        // the same with LDS-resident weights (tile_k = 5)
 
 namespace {
 

@@ -151,7 +151,8 @@ class Plan:
         assert len(src.segs) == 1 and src.segs[0].mode == lib.SRC_DIRECT
         self._ops.append(dict(kind=lib.OP_DWCONV, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=src.C, ksize=w.shape[-1],
                               segs=src.segs, out=out, out_coff=0, w=self._wput(pack.pack_dw(w, self.dtype)),
-                              b=self._wput(b.float().cpu())))
+                              b=self._wput(b.float().cpu()),
+                              aux=[self._wput(pack.pack_dw_toeplitz(w))] if self.dtype == lib.F16 else []))   # operand of the matrix-core variant
 
     # ---------------------------------------------------------------- graph walk
     def _build(self, model):
@@ -286,8 +287,8 @@ class Plan:
                 o.bias = wbase + r["b"]
             if r["kind"] == lib.OP_BOTTLENECK:
                 o.tile_k = r["tk"]
-                for k_, off in enumerate(r["aux"]):
-                    o.aux[k_] = wbase + off
+            for k_, off in enumerate(r.get("aux", [])):
+                o.aux[k_] = wbase + off
             if r["kind"] == lib.OP_STEM:
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call
@@ -344,6 +345,17 @@ class Plan:
                                     timer.stop(stream.cuda_stream)
                                     ts.append(timer.elapsed_ms())
                                 results.append((min(ts), t_h, t_w, cb))
+                    if self.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
+                        op = lib.MafOp.from_buffer_copy(o)
+                        op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        ts = []
+                        for _ in range(reps):
+                            timer.start(stream.cuda_stream)
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            timer.stop(stream.cuda_stream)
+                            ts.append(timer.elapsed_ms())
+                        results.append((min(ts), -1, 0, 0))
                     results.sort()
                     best = results[0][1:]
                     _TUNE_CACHE[sig] = best
@@ -374,6 +386,13 @@ class Plan:
                     ksteps = sum(-(-o.src[k].C // (32 if self.dtype == lib.F16 else 16)) for k in range(o.nsrc)) * (9 if o.kind == lib.OP_CONV3X3S2 else 1)
                     if ksteps >= 8 and M <= 65536:
                         cands.append((1, ct, 4))                 # split-K across the 4 waves: long reductions on small maps
+                    direct = o.kind == lib.OP_CONV1X1 and o.nsrc == 1 and o.src[0].mode == lib.SRC_DIRECT
+                    if direct and self.dtype == lib.F16 and not o.out_f32 and ksteps <= 4 and ksteps * ct <= 16:
+                        for pt in (1, 2):                                # persistent waves, next tile's activations in flight during the epilogue
+                            cands.append((pt, ct, 3))
+                    if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and 2 <= ksteps <= 12 and ksteps * ct <= 96 \
+                            and all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc)) and (direct or ct >= 4):
+                        cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
                     pooled = o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2
                     if ksteps >= 4 and ct >= 4 and self.dtype == lib.F16 and not o.out_f32 and not pooled:
                         for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
@@ -397,7 +416,7 @@ class Plan:
                 best = (results[0][1], results[0][2], results[0][3])
                 _TUNE_CACHE[sig] = best
                 if verbose:
-                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
                 wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
@@ -455,8 +474,14 @@ class Plan:
             else:
                 var = 1
             outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
+            if o.tile_k == 3:
+                return "conv1x1_stream_kernel<%d, %d, %d>" % (o.tile_p, o.tile_c, -(-o.Cin // 32))
+            if o.tile_k == 5:
+                return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
         if o.kind == lib.OP_DWCONV:
+            if o.tile_p == -1:
+                return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:
             return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)

@@ -89,6 +89,26 @@ def pack_dw(w, dtype):
     return w.float().cpu().reshape(c, k * k).t().contiguous().to(torch.float16 if dtype == lib.F16 else torch.float32)
 
 
+def pack_dw_toeplitz(w):
+    """w [C, 1, k, k] -> the Toeplitz table of the matrix-core depth-wise kernel (csrc/dwconv_mfma.hip), fp16
+    [C/32 blocks, 8 sets, k, parts, 16, 8]: entry (block cb, set s, tap row ky, window part, row i = 4G + r, element j) =
+    w[cb*32 + 8G + s][ky][j - r + 4*part]; window 0 carries taps kx <= 4, window 1 (k > 5) the taps kx >= 5."""
+    c, _, k, _ = w.shape
+    ncb = -(-c // 32)
+    wd = torch.zeros(ncb * 32, k, k); wd[:c] = w.float().cpu().reshape(c, k, k)
+    parts = 2 if k > 5 else 1
+    toe = torch.zeros(ncb, 8, k, parts, 4, 4, 8)                           # [cb, s, ky, part, G, r, j]
+    wv = wd.reshape(ncb, 4, 8, k, k)                                       # [cb, G, s, ky, kx]
+    for part in range(parts):
+        for r in range(4):
+            for j in range(8):
+                kx = j - r + 4 * part
+                if kx < 0 or kx >= k or (part == 0 and kx > 4) or (part == 1 and kx < 5):
+                    continue
+                toe[:, :, :, part, :, r, j] = wv[:, :, :, :, kx].permute(0, 2, 3, 1)          # [cb, s, ky, G]
+    return toe.reshape(ncb, 8, k, parts, 16, 8).to(torch.float16).contiguous()
+
+
 def pack_stem(w):
     """w [Cout, 3, 3, 3] -> fp32 [27, Cout], row = (c*3 + ky)*3 + kx."""
     return w.float().cpu().reshape(w.shape[0], 27).t().contiguous()

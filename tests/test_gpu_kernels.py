@@ -148,6 +148,61 @@ def test_conv_lds_shared_weights(kind, pt, ct):
     assert (out[..., :8] == 0).all()
 
 
+@pytest.mark.parametrize("cin,cout,pt,ct,act", [(48, 48, 2, 4, lib.ACT_SILU), (24, 72, 2, 6, lib.ACT_SILU), (128, 64, 1, 4, lib.ACT_RELU), (64, 128, 2, 8, lib.ACT_SILU),
+                                                (72, 24, 1, 2, lib.ACT_NONE), (96, 200, 2, 4, lib.ACT_SILU), (40, 28, 2, 2, lib.ACT_SIGMOID)])
+def test_conv1x1_persistent_stream(cin, cout, pt, ct, act):
+    """tile_k = 3: persistent waves, weights resident in registers, next tile's activations prefetched across the epilogue."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    B, H, W, dt = 3, 37, 41, lib.F16                     # 4551 pixels: many tiles per wave would need a big map; ragged tail here
+    x = _q(torch.randn(B, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    b = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x, w, b), act)
+    xs = torch.zeros(B, H, W, cin + 8, dtype=torch.float16, device=DEV)
+    xs[..., 8:] = _nhwc(x, dt)
+    stride, coff = cout + 16, 8
+    out = torch.full((B, H, W, stride), 7.0, dtype=DT[dt], device=DEV)
+    op = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, act, [(xs, cin, cin + 8, 8, 0)], out, stride, coff,
+                  pack.pack_conv1x1(w, [cin], ct, dt).to(DEV), pack.pack_bias(b, ct).to(DEV), pt, ct)
+    op.tile_k = 3
+    _launch(op)
+    _check(out[..., coff:coff + cout], ref, dt)
+    assert (out[..., :coff] == 7).all() and (out[..., coff + cout:] == 7).all(), "wrote outside its slice"
+
+
+@pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2),
+                                              ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4)])
+def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
+    """tile_k = 5: persistent waves with the channel tile's weights resident in LDS; single source or concat (with upsample)."""
+    g = torch.Generator().manual_seed(31 + cout + ct)
+    dt, B, H, W = lib.F16, 2, 18, 22
+    if kind == "direct":
+        x = _q(torch.randn(B, cin, H, W, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [cin], ct, dt)
+        xs = torch.zeros(B, H, W, cin + 8, dtype=torch.float16, device=DEV)
+        xs[..., 8:] = _nhwc(x, dt)
+        srcs, full = [(xs, cin, cin + 8, 8, 0)], x
+    else:
+        ca, cb, cc = 40, 64, 24
+        cin = ca + cb + cc
+        a = _q(torch.randn(B, ca, H, W, generator=g), dt)
+        bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
+        c = _q(torch.randn(B, cc, H, W, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [ca, cb, cc], ct, dt)
+        srcs = [(_nhwc(a, dt), ca, ca, 0, 0), (_nhwc(bsm, dt), cb, cb, 0, 1), (_nhwc(c, dt), cc, cc, 0, 0)]
+        full = torch.cat([a, F.interpolate(bsm, scale_factor=2, mode="nearest"), c], 1)
+    bias = torch.randn(cout, generator=g)
+    ref = F.silu(F.conv2d(full, w, bias))
+    out = torch.full((B, H, W, cout + 8), 5.0, dtype=DT[dt], device=DEV)
+    op = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, out, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 1, ct)
+    op.tile_k = 5
+    _launch(op)
+    _check(out[..., 8:], ref, dt)
+    assert (out[..., :8] == 5).all()
+
+
 def test_conv1x1_out_f32():
     g = torch.Generator().manual_seed(5)
     B, H, W, cin, cout = 1, 8, 8, 128, 68
@@ -230,6 +285,29 @@ def test_dwconv(dt, k, C_, H, W):
         op.ksize = k
         _launch(op)
         _check(out, ref, dt)
+
+@pytest.mark.parametrize("k,C_,H,W", [(7, 72, 21, 27), (9, 40, 20, 20), (5, 64, 33, 16), (3, 24, 16, 40), (9, 192, 9, 11)])
+def test_dwconv_matrix_core_variant(k, C_, H, W):
+    """tile_p = -1: depth-wise conv as block-diagonal Toeplitz MFMAs (csrc/dwconv_mfma.hip); slices of wider buffers."""
+    g = torch.Generator().manual_seed(100 + k)
+    B, dt = 2, lib.F16
+    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
+    w = _q(torch.randn(C_, 1, k, k, generator=g) / k, dt)
+    bias = torch.randn(C_, generator=g)
+    toe = pack.pack_dw_toeplitz(w).to(DEV)
+    xs = torch.zeros(B, H, W, C_ + 16, dtype=torch.float16, device=DEV)
+    xs[..., 8:8 + C_] = _nhwc(x, dt)
+    for act in (lib.ACT_SILU, lib.ACT_NONE):
+        ref = _act(F.conv2d(x, w, bias, 1, k // 2, 1, C_), act)
+        out = torch.full((B, H, W, C_ + 8), 3.0, dtype=torch.float16, device=DEV)
+        op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, C_, act, [(xs, C_, C_ + 16, 8, 0)], out, C_ + 8, 8,
+                      pack.pack_dw(w, dt).to(DEV), bias.to(DEV), -1, 0)
+        op.ksize = k
+        op.aux[0] = toe.data_ptr()
+        _launch(op)
+        _check(out[..., 8:], ref, dt)
+        assert (out[..., :8] == 3).all()
+
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
