@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
+    ap.add_argument("--lanes", type=int, default=-1, help="engine streams: 0 one stream, 1 heads on side streams, 2 heads + neck side convs (default: the model's setting)")
     ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
     ap.add_argument("--tune-file", default=None,
                     help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning")
@@ -194,6 +195,8 @@ def main():
     model.autotune = not args.no_autotune      # per-layer MFMA tile selection when the plan is built (outside the timed region)
     if args.fuse >= 0:
         model.fuse_bottlenecks = bool(args.fuse)
+    if args.lanes >= 0:
+        model.multi_stream = args.lanes
     from maf_yolo_amd import engine as _engine
     if args.tune_file and os.path.exists(args.tune_file):
         _engine.load_tune_cache(args.tune_file)

@@ -98,6 +98,10 @@ typedef struct {
     int32_t reg_stride, nc, reg_max;
     float lvl_stride[3];
     const void* aux[4];          /* DWCONV: aux[0] = Toeplitz table of the matrix-core variant (else 0)                 */
+    /* engine scheduling (ignored by maf_op_launch): independent branches of the graph run on separate HIP streams */
+    int32_t lane;                /* 0 = the caller's stream; 1..7 = engine-owned side streams                          */
+    int32_t n_wait;              /* ops on OTHER lanes whose results this op reads (<= 8): indices into the op list     */
+    int32_t wait[8];
 } maf_op_t;
 
 const char* maf_last_error(void);
@@ -108,7 +112,10 @@ int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);
 
-/* A plan = ordered op list (Model.forward's node loop, yolo.py:186-201, flattened to launches). */
+/* A plan = ordered op list (Model.forward's node loop, yolo.py:186-201, flattened to launches).  Ops carry a lane: the
+ * engine launches lane-0 ops on the caller's stream and the others on its own streams, with event waits for the cross-lane
+ * reads listed in `wait` (the MAFPN neck and the three heads are independent branches: small-map layers overlap big ones);
+ * all lanes fork from and join the caller's stream inside every run call, so the call keeps single-stream semantics. */
 typedef struct maf_engine maf_engine_t;
 int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_t** out);
 int maf_engine_num_ops(const maf_engine_t* e);

@@ -35,13 +35,50 @@ extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
 // Engine: the flattened Model.forward (yolov6/models/yolo.py:186-201) as a static launch list over
 // a caller-owned activation arena.  No allocation, no host sync; optional hipGraph replay.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxLanes = 8;
+
 struct maf_engine {
     std::vector<maf_op_t> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const void* g_image = nullptr;
     void* g_pred = nullptr;
+    // multi-lane execution: side streams (lane 1..), one event per op that is read from another lane, fork/join events
+    int n_lanes = 1;
+    hipStream_t side[kMaxLanes] = {};
+    std::vector<hipEvent_t> done;          // done[i] valid iff signal[i]
+    std::vector<char> signal;
+    hipEvent_t fork = nullptr, join[kMaxLanes] = {};
+    bool lanes_ready = false;
 };
+
+static int engine_prepare_lanes(maf_engine* e) {
+    if (e->lanes_ready) return 0;
+    const size_t n = e->ops.size();
+    e->signal.assign(n, 0);
+    e->done.assign(n, nullptr);
+    e->n_lanes = 1;
+    for (size_t i = 0; i < n; ++i) {
+        const maf_op_t& o = e->ops[i];
+        if (o.lane < 0 || o.lane >= kMaxLanes) { maf_set_error("engine: op lane out of range (0..7)"); return MAF_E_ARG; }
+        if (o.n_wait < 0 || o.n_wait > 8) { maf_set_error("engine: n_wait out of range (0..8)"); return MAF_E_ARG; }
+        if (o.lane + 1 > e->n_lanes) e->n_lanes = o.lane + 1;
+        for (int k = 0; k < o.n_wait; ++k) {
+            if (o.wait[k] < 0 || (size_t)o.wait[k] >= i) { maf_set_error("engine: an op may only wait for earlier ops"); return MAF_E_ARG; }
+            e->signal[o.wait[k]] = 1;
+        }
+    }
+    int rc = 0;
+    for (int l = 1; l < e->n_lanes && !rc; ++l) {
+        rc = maf_check_hip(hipStreamCreateWithFlags(&e->side[l], hipStreamNonBlocking), "hipStreamCreate");
+        if (!rc) rc = maf_check_hip(hipEventCreateWithFlags(&e->join[l], hipEventDisableTiming), "hipEventCreate");
+    }
+    if (!rc && e->n_lanes > 1) rc = maf_check_hip(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming), "hipEventCreate");
+    for (size_t i = 0; i < n && !rc; ++i)
+        if (e->signal[i]) rc = maf_check_hip(hipEventCreateWithFlags(&e->done[i], hipEventDisableTiming), "hipEventCreate");
+    if (!rc) e->lanes_ready = true;
+    return rc;
+}
 
 extern "C" int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_t** out) {
     if (!ops || n_ops <= 0 || !out) { maf_set_error("maf_engine_create: bad arguments"); return MAF_E_ARG; }
@@ -54,17 +91,34 @@ extern "C" int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_
 extern "C" int maf_engine_num_ops(const maf_engine_t* e) { return e ? (int)e->ops.size() : 0; }
 
 static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipStream_t s) {
+    int rc = engine_prepare_lanes(e);
+    if (rc) return rc;
+    const bool multi = e->n_lanes > 1;
+    if (multi) {                                             // fork: the side lanes start after everything already queued on s
+        rc = maf_check_hip(hipEventRecord(e->fork, s), "hipEventRecord(fork)");
+        for (int l = 1; l < e->n_lanes && !rc; ++l) rc = maf_check_hip(hipStreamWaitEvent(e->side[l], e->fork, 0), "hipStreamWaitEvent(fork)");
+        if (rc) return rc;
+    }
     for (size_t i = 0; i < e->ops.size(); ++i) {
         maf_op_t op = e->ops[i];
         if (op.kind == MAF_OP_STEM && image) op.src[0].ptr = image;
         if (op.kind == MAF_OP_DECODE && pred) op.out = pred;
-        const int rc = maf_op_launch(&op, s);
+        hipStream_t st = op.lane == 0 ? s : e->side[op.lane];
+        for (int k = 0; k < op.n_wait && !rc; ++k) rc = maf_check_hip(hipStreamWaitEvent(st, e->done[op.wait[k]], 0), "hipStreamWaitEvent");
+        if (!rc) rc = maf_op_launch(&op, st);
+        if (!rc && e->signal[i]) rc = maf_check_hip(hipEventRecord(e->done[i], st), "hipEventRecord");
         if (rc) {
             g_err = "op " + std::to_string(i) + ": " + g_err;
             return rc;
         }
     }
-    return 0;
+    if (multi) {                                             // join: whatever the caller queues next on s sees the whole forward
+        for (int l = 1; l < e->n_lanes && !rc; ++l) {
+            rc = maf_check_hip(hipEventRecord(e->join[l], e->side[l]), "hipEventRecord(join)");
+            if (!rc) rc = maf_check_hip(hipStreamWaitEvent(s, e->join[l], 0), "hipStreamWaitEvent(join)");
+        }
+    }
+    return rc;
 }
 
 extern "C" int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream) {
@@ -119,6 +173,12 @@ extern "C" void maf_engine_destroy(maf_engine_t* e) {
     if (!e) return;
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (int l = 1; l < kMaxLanes; ++l) {
+        if (e->join[l]) (void)hipEventDestroy(e->join[l]);
+        if (e->side[l]) (void)hipStreamDestroy(e->side[l]);
+    }
+    if (e->fork) (void)hipEventDestroy(e->fork);
+    for (hipEvent_t ev : e->done) if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 

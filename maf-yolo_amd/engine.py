@@ -102,6 +102,12 @@ class Plan:
         # eligible bottleneck, a set of bottleneck names, or "auto" = the built-in rule (k <= 5: the 160^2 / 80^2 maps, where it
         # wins by 1.3-1.8x; Model.plan_for replaces the rule by a measurement when autotuning is on).
         self.fuse = getattr(model, "fuse_bottlenecks", "auto") if fuse is None else fuse
+        # independent branches (side down-sampling convs of the MAFPN neck, the three heads and their cls / reg halves) CAN run
+        # on separate HIP streams of the engine.  Measured on MI355X (n, bs 32): heads-only lanes give -1 % on forward+NMS and
+        # +1.3 % on forward alone (cross-stream event latency eats the overlap), all lanes lose 1-2 %: opt-in.
+        self.lanes = getattr(model, "multi_stream", False)
+        if isinstance(self.lanes, bool):
+            self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
         with torch.no_grad():
             self._build(model)
         self._finalize()
@@ -159,10 +165,21 @@ class Plan:
         B = self.B
         y = []                                   # TV (or list of head tuples) per node
         self.head_bufs = []
+        n_side = n_head = 0
         for node, m in zip(model.nodes, model.backbone):
+            if node.i > 0:                            # tag the ops of the previous node (lane = HIP stream of the engine)
+                self._tag(tag_from, tag_node, tag_lane, tag_after)
+            tag_from, tag_node, tag_lane, tag_after = len(self._ops), node.i, 0, None
             p = "backbone.%d" % node.i
             srcs = [y[j] for j in node.sources()] if node.i > 0 else None
             x = srcs[0] if srcs else None
+            if self.lanes >= 2 and node.kind == "cw" and node.sources()[0] != node.i - 1:
+                tag_lane = 1 + (n_side % 2)           # a down-sampling conv of an OLDER map: independent of the chain in progress
+                n_side += 1
+            if self.lanes and node.kind == "head":
+                tag_lane = (3, 5, 0)[n_head % 3]      # P3 / P4 heads overlap the rest of the neck; their reg branches take lane + 1 (P5: 7)
+                tag_after = node.sources()[0]         # ... and are launched right after the node that feeds them
+                n_head += 1
             if node.kind == "repvgg":
                 w, b = m.fused()
                 if node.i == 0:                   # stem: reads the caller's NCHW image
@@ -249,12 +266,64 @@ class Plan:
                 y.append(None)
             else:
                 raise NotImplementedError(node.kind)
+        self._tag(tag_from, tag_node, tag_lane, tag_after)
         assert len(self.head_bufs) == 3, "MAF-YOLO has three detection levels"
         self.A = sum(t.H * t.W for t, _, _ in self.head_bufs)
         self._ops.append(dict(kind=lib.OP_DECODE, name="detect", act=0, H=0, W=0, Cin=0, Cout=0, segs=[], out=None, out_coff=0))
 
+    # ---------------------------------------------------------------- lanes and cross-lane dependencies
+    def _tag(self, first, node_i, lane, after):
+        for r in self._ops[first:]:
+            r["node"], r["after"] = node_i, after
+            r["lane"] = lane
+            if lane is not None and ".reg_" in r["name"] and self.lanes:          # head: the reg branch runs beside the cls branch
+                r["lane"] = 7 if lane == 0 else lane + 1
+
+    def _schedule(self):
+        """Launch order + event waits.  The op list stays a topological order (single-stream execution of it is always valid:
+        run_timed does that); heads move up to just behind the node that feeds them so their lanes start early.  For every op
+        the ops of OTHER lanes whose output slices it reads become `wait` entries (latest one per lane, transitively pruned)."""
+        ops = self._ops
+        if self.lanes:
+            rest = [r for r in ops if r.get("after") is None]
+            for src_node in sorted({r["after"] for r in ops if r.get("after") is not None}):
+                grp = [r for r in ops if r.get("after") == src_node]          # one head, in its emission order
+                anchor = max(i for i, q in enumerate(rest) if q.get("node") == src_node)
+                rest[anchor + 1:anchor + 1] = grp
+            ops = self._ops = rest
+        writes = {}                                                # id(buf) -> [(lo, hi, op index)]
+        seen = {}                                                  # lane -> {other lane: latest op index already waited for}
+        last_on_lane = {}
+        for i, r in enumerate(ops):
+            lane = r.get("lane", 0) if self.lanes else 0
+            r["lane"] = lane
+            deps = set()
+            if r["kind"] == lib.OP_DECODE:
+                deps = set(last_on_lane.values())
+            for s_ in r["segs"]:
+                for lo, hi, j in writes.get(id(s_.buf), []):
+                    if lo < s_.coff + s_.C and s_.coff < hi:
+                        deps.add(j)
+            latest = {}
+            for j in deps:
+                lj = ops[j]["lane"]
+                if lj != lane and j > seen.setdefault(lane, {}).get(lj, -1):
+                    latest[lj] = max(latest.get(lj, -1), j)
+            # what the awaited ops had themselves waited for is ordered before them: inherit it
+            for lj, j in latest.items():
+                seen[lane][lj] = j
+                for lk, jk in seen.get(lj, {}).items():
+                    if lk != lane:
+                        seen[lane][lk] = max(seen[lane].get(lk, -1), min(jk, j))
+            r["wait"] = sorted(latest.values())
+            assert len(r["wait"]) <= 8
+            if r["out"] is not None:
+                writes.setdefault(id(r["out"]), []).append((r["out_coff"], r["out_coff"] + r["Cout"], i))
+            last_on_lane[lane] = i
+
     # ---------------------------------------------------------------- materialise
     def _finalize(self):
+        self._schedule()
         dev = self.device
         self.arena = torch.empty(self._arena_size + 256, dtype=torch.uint8, device=dev)
         wcpu = torch.zeros(self._wsize + 256, dtype=torch.uint8)
@@ -289,6 +358,9 @@ class Plan:
                 o.tile_k = r["tk"]
             for k_, off in enumerate(r.get("aux", [])):
                 o.aux[k_] = wbase + off
+            o.lane, o.n_wait = r["lane"], len(r["wait"])
+            for k_, j in enumerate(r["wait"]):
+                o.wait[k_] = j
             if r["kind"] == lib.OP_STEM:
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call

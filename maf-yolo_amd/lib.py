@@ -26,7 +26,7 @@ class MafOp(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("reg", C.c_void_p * 3), ("lvl_h", C.c_int32 * 3), ("lvl_w", C.c_int32 * 3),
                 ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3),
-                ("aux", C.c_void_p * 4)]
+                ("aux", C.c_void_p * 4), ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait", C.c_int32 * 8)]
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",

@@ -102,6 +102,7 @@ class Model(nn.Module):
         self._plans = {}
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
+        self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property

@@ -332,3 +332,24 @@ def test_checkpoint_bridge_forward_matches_reference_output(golden):
     assert pred.shape == ref.shape
     assert np.abs(pred[..., :4] - ref[..., :4]).max() <= 1e-3 + 1e-5 * np.abs(ref[..., :4]).max()
     assert np.abs(pred[..., 4:] - ref[..., 4:]).max() <= 2e-5
+
+
+def test_multi_stream_plan_equals_single_stream(models):
+    """Lanes only change WHEN an op runs: outputs are bitwise those of the single-stream plan, eager and from the hipGraph."""
+    x = O.synth_images(4, 320, 11).to(DEV).half()
+    outs = {}
+    for ms in (2, 1, False):
+        m = M.Model("n")
+        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = m.to(DEV).eval()
+        m.multi_stream = ms
+        with torch.no_grad():
+            outs[ms] = m(x)[0].clone()
+            plan = m.plan_for(x)
+            assert (max(o.lane for o in plan.ops) > 0) == bool(ms)
+            pred = torch.empty_like(outs[ms])
+            for _ in range(3):
+                plan.run_into(x, pred, graph=True)
+            torch.cuda.synchronize()
+            assert torch.equal(pred, outs[ms])
+    assert torch.equal(outs[2], outs[False]) and torch.equal(outs[1], outs[False])
