@@ -159,11 +159,15 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
  *                   transpose = 1 packs W^T, which turns the same kernel into the data gradient dX = dY * W.
  *   maf_pack_dw     fp32 depth-wise weight [C][k*k] -> [k*k][C] in `dtype`; flip = 1 gives the data-gradient kernel.
  *   maf_dw_wgrad    dW[c][ky][kx] += sum over pixels of dY * shifted X  (fp32 atomics; dw must be zeroed by the caller).
- * The 1x1 weight gradient dW = dY^T X is a plain TN GEMM and is left to hipBLASLt (torch.mm).
+ *   maf_conv1x1_wgrad  dW[co][ci] += sum over the M = B*H*W pixels of dY[m][co] * X[m][ci]  (fp16 NHWC views, fp32 result
+ *                   accumulated with atomics: dw must be zeroed by the caller) — pixel chunks per workgroup, tiles transposed
+ *                   through LDS, MFMA; replaces the TN GEMM with a tiny output and a huge reduction.
  */
 int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c);
 int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c, void* out, maf_stream_t stream);
 int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
+int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
+                      int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, maf_stream_t stream);
 

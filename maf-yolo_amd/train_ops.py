@@ -6,7 +6,7 @@ apart, so the convs here have no epilogue; BN / activations / pooling / cat stay
 channels_last tensors (NHWC in memory — exactly the layout the kernels take, so nothing is copied).
 
     conv1x1(x, w, bias=None)   forward + data gradient: csrc/conv_mfma.inc.h (dgrad = same kernel on W^T, packed on
-                               the device by maf_pack_w1x1); weight gradient dW = dY^T X: a plain TN GEMM -> torch.mm
+                               the device by maf_pack_w1x1); weight gradient dW = dY^T X: csrc/wgrad.hip (fp16; fp32: torch.mm)
     dwconv(x, w)               forward + data gradient: csrc/dwconv.hip (dgrad = flipped kernel, maf_pack_dw);
                                weight gradient: csrc/train_ops.hip:dw_wgrad_kernel
 
@@ -128,9 +128,16 @@ class _Conv1x1(torch.autograd.Function):
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
         if ctx.needs_input_grad[1]:
-            x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                          # NHWC rows (a view when x is dense)
-            d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
-            dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)      # plain TN GEMM -> hipBLASLt
+            if x.dtype == torch.float16 and cout % 8 == 0 and cin <= 1024:
+                xx, xs = nhwc(x)                                                 # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
+                dwf = torch.zeros(cout, cin, dtype=torch.float32, device=x.device)
+                lib.check(lib.load().maf_conv1x1_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B * H * W, cin, cout, dt, dwf.data_ptr(), _stream(x.device)))
+                dw = dwf.reshape(w.shape).to(w.dtype)
+                stats["native_wgrad1x1"] = stats.get("native_wgrad1x1", 0) + 1
+            else:                                                                # fp32 parity mode / odd channel counts: the framework's TN GEMM
+                x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
+                d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
+                dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db

@@ -127,3 +127,20 @@ def test_autocast_training_step_runs_and_updates():
         scaler.scale(loss).backward()
         scaler.step(opt); scaler.update()
     assert torch.isfinite(loss) and not torch.equal(w0, m.backbone[2].conv1.conv.weight.detach())
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(192, 576, 20), (24, 72, 48), (576, 192, 10), (128, 80, 33), (48, 48, 64)])
+def test_conv1x1_weight_gradient_kernel(cin, cout, hw):
+    """csrc/wgrad.hip against the fp32 GEMM: several output-row blocks, ragged pixel chunks, sliced (strided) operands."""
+    from maf_yolo_amd import lib
+    import ctypes as C
+    g = torch.Generator().manual_seed(cin + cout)
+    B = 3
+    xs = torch.randn(B, hw, hw, cin + 8, generator=g).half().to(DEV)
+    ds = torch.randn(B, hw, hw, cout + 16, generator=g).half().to(DEV)
+    x, dy = xs[..., 8:], ds[..., 8:8 + cout]                                  # channel slices of wider NHWC buffers
+    dw = torch.zeros(cout, cin, dtype=torch.float32, device=DEV)
+    lib.check(lib.load().maf_conv1x1_wgrad(x.data_ptr(), cin + 8, dy.data_ptr(), cout + 16, B * hw * hw, cin, cout, lib.F16,
+                                           dw.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    ref = dy.reshape(-1, cout).float().t() @ x.reshape(-1, cin).float()
+    assert _rel(dw, ref) < 2e-3
