@@ -158,7 +158,8 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
  *   maf_pack_w1x1   fp32 weight [Cout][Cin] of nn.Conv2d(k=1) -> the fragment-packed operand of MAF_OP_CONV1X1 in `dtype`;
  *                   transpose = 1 packs W^T, which turns the same kernel into the data gradient dX = dY * W.
  *   maf_pack_dw     fp32 depth-wise weight [C][k*k] -> [k*k][C] in `dtype`; flip = 1 gives the data-gradient kernel.
- *   maf_dw_wgrad    dW[c][ky][kx] += sum over pixels of dY * shifted X  (fp32 atomics; dw must be zeroed by the caller).
+ *   maf_dw_wgrad    dW[c][ky][kx] += sum over pixels of dY * shifted X.  dw = `replicas` zeroed copies [replicas][C][k*k] fp32: the
+ *                   workgroups spread their atomics over the copies (atomics on one cache line serialise), the caller sums them.
  *   maf_conv1x1_wgrad  dW[co][ci] += sum over the M = B*H*W pixels of dY[m][co] * X[m][ci]  (fp16 NHWC views, fp32 result
  *                   accumulated with atomics: dw must be zeroed by the caller) — pixel chunks per workgroup, tiles transposed
  *                   through LDS, MFMA; replaces the TN GEMM with a tiny output and a huge reduction.
@@ -169,7 +170,7 @@ int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtyp
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
-                 int32_t k, int32_t dtype, float* dw, maf_stream_t stream);
+                 int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 
 /*
  * Post-NMS tail — replaces Evaler.scale_coords (yolov6/core/evaler.py:382-409, ratio_pad branch), box_convert

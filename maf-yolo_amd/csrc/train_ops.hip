@@ -48,20 +48,20 @@ __global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ 
 // partial sums to dW with fp32 atomics (dW is zeroed by the caller).
 struct DwWgArgs {
     const void* x; const void* dy; float* dw;
-    int B, H, W, C, x_stride, dy_stride, TH, TW, CB, tilesX, tilesY, nCB;
+    int B, H, W, C, x_stride, dy_stride, TH, TW, CB, tilesX, tilesY, nCB, replicas;
 };
 
+// Work item = (16-byte channel group, tap row ky, strip of S = 4 output columns): for every tile row it loads the S dY vectors
+// and the S + K - 1 X vectors of the strip once and performs S x K x 8 multiply-adds (fp16 products into fp32 accumulators,
+// v_fma_mix_f32): 2S + K - 1 LDS reads per 8*S*K FMAs instead of 2 per 8.  A workgroup owns one channel block and walks many
+// (image, tile) pairs; its K x N sums per item stay in registers and reach dW with one atomic round at the end.
 template <typename T, typename V, int N, int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwWgArgs a) {
-    constexpr int P = K / 2;
+    constexpr int P = K / 2, S = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     V* xt = reinterpret_cast<V*>(smem_raw);
-    int t = blockIdx.x;
-    const int cb = t % a.nCB; t /= a.nCB;
-    const int tx = t % a.tilesX; t /= a.tilesX;
-    const int ty = t % a.tilesY;
-    const int b = t / a.tilesY;
-    const int y0 = ty * a.TH, x0 = tx * a.TW, c0 = cb * a.CB;
+    const int cb = blockIdx.x % a.nCB, wgi = blockIdx.x / a.nCB, nwg = gridDim.x / a.nCB;
+    const int c0 = cb * a.CB;
     const int CGB = min(a.CB, a.C - c0) / N;
     const int PS = a.CB / N + 1;                               // LDS pixel stride in vectors (+16 B pad)
     const int RH = a.TH + K - 1, RW = a.TW + K - 1;
@@ -69,53 +69,109 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwWgArgs a) {
     const int tid = threadIdx.x;
     const T* xin = static_cast<const T*>(a.x) + c0;
     const T* dyin = static_cast<const T*>(a.dy) + c0;
-    for (int idx = tid; idx < RH * RW * CGB; idx += 256) {
-        const int cgi = idx % CGB, p = idx / CGB;
-        const int rx = p % RW, ry = p / RW;
-        const int iy = y0 - P + ry, ix = x0 - P + rx;
-        V v = (V)(T)0;
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            v = *reinterpret_cast<const V*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cgi * N);
-        xt[p * PS + cgi] = v;
-    }
-    for (int idx = tid; idx < a.TH * a.TW * CGB; idx += 256) {
-        const int cgi = idx % CGB, p = idx / CGB;
-        const int rx = p % a.TW, ry = p / a.TW;
-        const int oy = y0 + ry, ox = x0 + rx;
-        V v = (V)(T)0;
-        if (oy < a.H && ox < a.W)
-            v = *reinterpret_cast<const V*>(dyin + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.dy_stride + cgi * N);
-        dt[p * PS + cgi] = v;
-    }
-    __syncthreads();
-    for (int pr = tid; pr < CGB * K * K; pr += 256) {
-        const int cgi = pr % CGB, tap = pr / CGB;
-        const int ky = tap / K, kx = tap - ky * K;
-        float acc[N];
+    const int nstrip = a.TW / S;                               // the launch uses TW = 16
+    const int items = CGB * K * nstrip;                        // <= 8 * 9 * 4 = 288: at most 2 per lane
+    constexpr int MAXIT = 2;
+    float acc[MAXIT][K][N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] = 0.f;
-        for (int ry = 0; ry < a.TH; ++ry) {
-            const V* xr = xt + ((ry + ky) * RW + kx) * PS + cgi;
-            const V* dr = dt + (ry * a.TW) * PS + cgi;
-            for (int rx = 0; rx < a.TW; ++rx) {
-                const V xv = xr[rx * PS], dv = dr[rx * PS];
+    for (int u = 0; u < MAXIT; ++u)
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc[j] = __builtin_fmaf((float)xv[j], (float)dv[j], acc[j]);
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[u][kx][j] = 0.f;
+    const int ntiles = a.B * a.tilesY * a.tilesX;
+    for (int tile = wgi; tile < ntiles; tile += nwg) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX;
+        const int ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        __syncthreads();                                       // the previous tile has been consumed
+        for (int idx = tid; idx < RH * RW * CGB; idx += 256) {
+            const int cgi = idx % CGB, p = idx / CGB;
+            const int rx = p % RW, ry = p / RW;
+            const int iy = y0 - P + ry, ix = x0 - P + rx;
+            V v = (V)(T)0;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const V*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cgi * N);
+            xt[p * PS + cgi] = v;
+        }
+        for (int idx = tid; idx < a.TH * a.TW * CGB; idx += 256) {
+            const int cgi = idx % CGB, p = idx / CGB;
+            const int rx = p % a.TW, ry = p / a.TW;
+            const int oy = y0 + ry, ox = x0 + rx;
+            V v = (V)(T)0;
+            if (oy < a.H && ox < a.W)
+                v = *reinterpret_cast<const V*>(dyin + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.dy_stride + cgi * N);
+            dt[p * PS + cgi] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXIT; ++u) {
+            const int it = tid + u * 256;
+            if (it >= items) break;
+            const int st = it % nstrip, r2 = it / nstrip;      // the strips of one (group, tap row) sit in adjacent lanes
+            const int cgi = r2 % CGB, ky = r2 / CGB;
+            for (int ry = 0; ry < a.TH; ++ry) {
+                const V* xr = xt + ((ry + ky) * RW + st * S) * PS + cgi;
+                const V* dr = dt + (ry * a.TW + st * S) * PS + cgi;
+                V xv[S + K - 1], dv[S];
+#pragma unroll
+                for (int i = 0; i < S + K - 1; ++i) xv[i] = xr[i * PS];
+#pragma unroll
+                for (int i = 0; i < S; ++i) dv[i] = dr[i * PS];
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        if constexpr (N == 8) {
+                            const u32x4_t xa = __builtin_bit_cast(u32x4_t, xv[i + kx]), da = __builtin_bit_cast(u32x4_t, dv[i]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[u][kx][2 * q]) : "v"(xa[q]), "v"(da[q]));
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[u][kx][2 * q + 1]) : "v"(xa[q]), "v"(da[q]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < N; ++j) acc[u][kx][j] = __builtin_fmaf((float)xv[i + kx][j], (float)dv[i][j], acc[u][kx][j]);
+                        }
+                    }
             }
         }
-        float* o = a.dw + (size_t)(c0 + cgi * N) * (K * K) + tap;
+    }
+    // Thousands of atomics on the few cache lines of dW serialise (~10 ns each per line): the 4 strips are summed with lane
+    // shuffles first, and the workgroups spread over `replicas` copies of dW that the caller adds up afterwards.
+    float* dwr = a.dw + (size_t)(wgi % a.replicas) * a.C * (K * K);
 #pragma unroll
-        for (int j = 0; j < N; ++j) atomicAdd(o + (size_t)j * (K * K), acc[j]);
+    for (int u = 0; u < MAXIT; ++u) {
+        const int it = tid + u * 256;
+        const bool live = it < items;
+        const int st = it % nstrip, r2 = it / nstrip;
+        const int cgi = r2 % CGB, ky = r2 / CGB;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float v = live ? acc[u][kx][j] : 0.f;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                if (live && st == 0) atomicAdd(dwr + (size_t)(c0 + cgi * N + j) * (K * K) + ky * K + kx, v);
+            }
+        }
     }
 }
 
 template <typename T, typename V, int N>
 int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
-    a.TH = min(8, a.H); a.TW = min(16, a.W);
-    a.CB = min(8 * N, (a.C + N - 1) / N * N);
+    a.TH = min(8, a.H); a.TW = 16;
+    const int groups = a.C / N, nblk = maf_cdiv(groups, 8);
+    a.CB = maf_cdiv(groups, nblk) * N;                                  // balanced channel blocks of <= 8 groups (72 channels: 40 + 32)
     a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH); a.nCB = maf_cdiv(a.C, a.CB);
     const size_t lds = ((size_t)(a.TH + k - 1) * (a.TW + k - 1) + (size_t)a.TH * a.TW) * (a.CB / N + 1) * 16;
-    const dim3 g(a.B * a.tilesY * a.tilesX * a.nCB), b(256);
+    int per = a.B * a.tilesY * a.tilesX;                                // workgroups per channel block: ~8 per CU in total
+    const int cap = maf_cdiv(1024, a.nCB);
+    if (per > cap) per = cap;
+    const int budget = (int)(1500000ll / ((long long)a.C * k * k));      // every workgroup ends with C*k*k/nCB atomics: keep their total ~1.5 M
+    if (per > budget) per = budget > 8 ? budget : 8;
+    const dim3 g(per * a.nCB), b(256);
     switch (k) {
         case 3: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 3>), g, b, lds, s, a); break;
         case 5: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 5>), g, b, lds, s, a); break;
@@ -161,13 +217,14 @@ extern "C" int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, i
 }
 
 extern "C" int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
-                            int32_t k, int32_t dtype, float* dw, maf_stream_t stream) {
+                            int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream) {
+    MAF_REQUIRE(replicas >= 1 && replicas <= 64, "dw_wgrad: replicas (copies of dW the workgroups spread their atomics over) must be 1..64");
     MAF_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C > 0, "dw_wgrad: bad arguments");
     MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "dw_wgrad: dtype must be f16/f32");
     const int N = dtype == MAF_F16 ? 8 : 4;
     MAF_REQUIRE(C % N == 0 && x_stride % N == 0 && dy_stride % N == 0, "dw_wgrad: C and strides must be multiples of the 16-byte channel group");
     DwWgArgs a;
-    a.x = x; a.dy = dy; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C; a.x_stride = x_stride; a.dy_stride = dy_stride;
+    a.x = x; a.dy = dy; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C; a.x_stride = x_stride; a.dy_stride = dy_stride; a.replicas = replicas;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MAF_F16) return launch_dw_wgrad<half_t, half8_t, 8>(a, k, s);
     return launch_dw_wgrad<float, f32x4_t, 4>(a, k, s);

@@ -73,7 +73,7 @@ def load():
     lib.maf_pack_w1x1_bytes.restype = C.c_int64
     lib.maf_pack_w1x1.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.maf_pack_dw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-    lib.maf_dw_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.maf_dw_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.maf_timer_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.maf_timer_start.argtypes = [C.c_void_p, C.c_void_p]
     lib.maf_timer_stop.argtypes = [C.c_void_p, C.c_void_p]

@@ -201,9 +201,10 @@ class _DWConv(torch.autograd.Function):
             _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
         if ctx.needs_input_grad[1]:
             xx, xs = nhwc(x)
-            dwf = torch.zeros(c, k * k, dtype=torch.float32, device=x.device)
-            lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), _stream(x.device)))
-            dw = dwf.reshape(w.shape).to(w.dtype)
+            reps = 32                                                           # copies of dW: atomics on one cache line serialise
+            dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
+            lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
+            dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
         return dx, dw
 
 
