@@ -167,6 +167,17 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
 int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c);
 int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c, void* out, maf_stream_t stream);
 int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
+/* BatchNorm2d in training mode fused with the activation behind it (Conv.forward = act(bn(conv(x))), common.py:46-47), NHWC views.
+ *   maf_bn_forward   batch statistics -> save_mean / save_rstd (+ running stats with torch's momentum rule, unbiased variance; may be
+ *                    NULL) and y = act(xhat*gamma + beta).   part = [R][2][C] fp32 scratch: zero on entry, zeroed again on exit (R replicas spread
+ *                    the atomics), so one buffer per stream serves all BatchNorms.
+ *   maf_bn_backward  dz = gradient w.r.t. the activation output; recomputes u from x; dx, dgamma, dbeta; sums = [2][C] scratch. */
+int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, int32_t act, void* y, int32_t y_stride,
+                   float* save_mean, float* save_rstd, float* part, int32_t R, maf_stream_t stream);
+int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
+                    void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, float* sums, maf_stream_t stream);
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,

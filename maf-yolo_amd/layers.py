@@ -58,8 +58,8 @@ class Conv(nn.Module):
 
     def forward(self, x):
         if self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1):
-            return self.act(self.bn(train_ops.conv1x1(x, self.conv.weight)))      # HIP fwd / dgrad, hipBLASLt wgrad
-        return self.act(self.bn(self.conv(x)))
+            return train_ops.bn_act(train_ops.conv1x1(x, self.conv.weight), self.bn, "silu")   # HIP conv fwd / dgrad / wgrad + fused BN(train)+SiLU
+        return train_ops.bn_act(self.conv(x), self.bn, "silu")
 
     def fused(self):
         return fold_bn(self.conv.weight, self.bn)
@@ -110,9 +110,9 @@ class DilatedReparamBlock(nn.Module):
             setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
 
     def forward(self, x):
-        out = self.origin_bn(train_ops.dwconv(x, self.lk_origin.weight))           # HIP fwd / dgrad / wgrad
+        out = train_ops.bn_act(train_ops.dwconv(x, self.lk_origin.weight), self.origin_bn)            # HIP fwd / dgrad / wgrad + BN(train)
         for kk in self.kernel_sizes:
-            out = out + getattr(self, "dil_bn_k%d_1" % kk)(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight))
+            out = out + train_ops.bn_act(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight), getattr(self, "dil_bn_k%d_1" % kk))
         return out
 
     def fused(self):
@@ -135,8 +135,8 @@ class UniRepLKNetBlock(nn.Module):
         self.dwconv = DilatedReparamBlock(c, k)
         self.norm = _bn(c)
 
-    def forward(self, x):
-        return self.norm(self.dwconv(x))
+    def forward(self, x, act=None):
+        return train_ops.bn_act(self.dwconv(x), self.norm, act)               # `act`: the SiLU of DepthBottleneckUni fused into the norm
 
     def fused(self):
         """reparameterize (common.py:3085-3100): fold the outer BN into the merged depth-wise kernel."""
@@ -159,7 +159,7 @@ class DepthBottleneckUni(nn.Module):
         self.one_conv = Conv(mid, c, 1)
 
     def forward(self, x):
-        return self.one_conv(self.act(self.conv2(self.conv1(x))))
+        return self.one_conv(self.conv2(self.conv1(x), act="silu"))
 
 
 class RepHDW(nn.Module):

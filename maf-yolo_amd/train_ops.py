@@ -208,6 +208,82 @@ class _DWConv(torch.autograd.Function):
         return dx, dw
 
 
+_ACT = {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "silu": lib.ACT_SILU}
+_BN_REPLICAS = 16
+
+
+_bn_scratch = {}
+
+
+def _bn_part(dev, c):
+    """[R][2][c] fp32 scratch, zero on entry to every BatchNorm call: the finalize kernels clear what they read, so it is allocated and
+    memset once per (device, stream, size class) — kernels on one stream are ordered, different streams get different buffers."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, -(-c // 256))
+    t = _bn_scratch.get(key)
+    if t is None:
+        if len(_bn_scratch) > 64:
+            _bn_scratch.clear()
+        t = _bn_scratch[key] = torch.zeros(_BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev)
+    return t
+
+
+class _BNAct(torch.autograd.Function):
+    """act(BatchNorm2d(x)) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act):
+        x, xs = nhwc(x)
+        B, c, H, W = x.shape
+        dt = _DT[x.dtype]
+        dev = x.device
+        y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
+        part = _bn_part(dev, c)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
+                                            None if running_mean is None else running_mean.data_ptr(),
+                                            None if running_var is None else running_var.data_ptr(), act,
+                                            y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
+                                            _stream(dev)))
+        ctx.save_for_backward(x, g32, b32, stat)
+        ctx.act = act
+        stats["native_bn_act"] = stats.get("native_bn_act", 0) + 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, g32, b32, stat = ctx.saved_tensors
+        B, c, H, W = x.shape
+        dz, dzs = nhwc(dz)
+        if dz.dtype != x.dtype:
+            dz = dz.to(x.dtype)
+            dzs = dz.stride()[3]
+        x, xs = nhwc(x)
+        dev = x.device
+        dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        dgb = torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
+        part = _bn_part(dev, c)
+        sums = torch.empty(2, c, dtype=torch.float32, device=dev)
+        lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
+                                             stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
+                                             dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, sums.data_ptr(), _stream(dev)))
+        return dx, dgb[0], dgb[1], None, None, None, None, None
+
+
+def bn_act(x, bn, act=None):
+    """act(bn(x)) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  Training mode on CUDA tensors runs the fused HIP kernels
+    (one statistics pass + one normalise/affine/activation pass; backward likewise); eval mode and CPU tensors run torch ops."""
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (x.is_cuda and bn.training and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and bn.affine):
+        y = bn(x)
+        return y if act in (None, "none") else (F.relu(y) if act == "relu" else F.silu(y))
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act])
+
+
 def dwconv(x, w):
     """Depth-wise k x k stride-1 'same' conv (groups == channels) with autograd. w [C,1,k,k], k in {3,5,7,9}."""
     k = w.shape[-1]

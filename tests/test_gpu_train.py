@@ -144,3 +144,32 @@ def test_conv1x1_weight_gradient_kernel(cin, cout, hw):
                                            dw.data_ptr(), torch.cuda.current_stream().cuda_stream))
     ref = dy.reshape(-1, cout).float().t() @ x.reshape(-1, cin).float()
     assert _rel(dw, ref) < 2e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 1e-2)])
+@pytest.mark.parametrize("act", [None, "silu", "relu"])
+@pytest.mark.parametrize("c,hw", [(72, 21), (576, 7), (24, 40)])
+def test_bn_act_forward_backward(dtype, tol, act, c, hw):
+    """Fused BatchNorm2d(train)+activation (csrc/bn_act.hip) == torch BatchNorm2d + activation: output, grads, running stats."""
+    g = torch.Generator().manual_seed(c + hw)
+    x = (torch.randn(3, c, hw, hw, generator=g) * 1.7 + 0.4)
+    dz = torch.randn(3, c, hw, hw, generator=g)
+    bn_ref = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(c, generator=g) + 0.5); bn_ref.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    import copy
+    bn_gpu = copy.deepcopy(bn_ref).to(DEV)
+    fa = {None: lambda t: t, "silu": F.silu, "relu": F.relu}[act]
+    xr = x.clone().to(dtype).float().requires_grad_(True)
+    yr = fa(bn_ref(xr)); yr.backward(dz.to(dtype).float())
+    xg = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    n0 = train_ops.stats.get("native_bn_act", 0)
+    yg = train_ops.bn_act(xg, bn_gpu, act)
+    assert train_ops.stats["native_bn_act"] == n0 + 1 and yg.dtype == dtype
+    yg.backward(dz.to(DEV).to(dtype))
+    assert _rel(yg.float().cpu(), yr.detach()) < tol
+    assert _rel(xg.grad.float().cpu(), xr.grad) < tol * 2
+    assert _rel(bn_gpu.weight.grad.cpu(), bn_ref.weight.grad) < tol * 2 and _rel(bn_gpu.bias.grad.cpu(), bn_ref.bias.grad) < tol * 2
+    assert torch.allclose(bn_gpu.running_mean.cpu(), bn_ref.running_mean, atol=2e-3 if dtype == torch.float16 else 1e-5)
+    assert torch.allclose(bn_gpu.running_var.cpu(), bn_ref.running_var, rtol=2e-3 if dtype == torch.float16 else 1e-4, atol=1e-5)
+    assert int(bn_gpu.num_batches_tracked) == 1
