@@ -6,8 +6,8 @@ DilatedReparamBlock :2948, UniRepLKNetBlock :3053) so a reference state_dict (83
 tensors for n / s / m) loads with strict=True and trained weights round-trip.
 
 `forward` here is the TRAINING-form graph: the 1x1 and depth-wise convolutions (69 % of the FLOPs, most of the
-launches) run forward and backward on the HIP kernels through train_ops.py; the 3x3 stride-2 convs, BatchNorm
-and the element-wise glue are torch ops on channels_last tensors (their native backward is the next §8 row).
+launches) and BatchNorm(train)+activation run forward and backward on the HIP kernels through train_ops.py; the 3x3
+stride-2 convs, the RepVGG branch BatchNorms and the element-wise glue are torch ops on channels_last tensors.
 Inference never runs these forwards: in eval mode
 Model.forward executes the re-parameterised graph on the HIP engine (engine.py), built from
 `fused()` below — the deploy algebra of SURVEY.md §3.3, evaluated in fp32 on the host once.

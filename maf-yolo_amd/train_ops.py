@@ -128,7 +128,7 @@ class _Conv1x1(torch.autograd.Function):
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
         if ctx.needs_input_grad[1]:
-            if x.dtype == torch.float16 and cout % 8 == 0 and cin <= 1024:
+            if x.dtype == torch.float16 and cout % 8 == 0 and cin <= 256:       # wider inputs: every output-row block re-stages X; the library GEMM wins there
                 xx, xs = nhwc(x)                                                 # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
                 dwf = torch.zeros(cout, cin, dtype=torch.float32, device=x.device)
                 lib.check(lib.load().maf_conv1x1_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B * H * W, cin, cout, dt, dwf.data_ptr(), _stream(x.device)))

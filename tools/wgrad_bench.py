@@ -3,8 +3,8 @@ sys.path.insert(0, os.getcwd())
 from maf_yolo_amd import lib
 L = lib.load()
 st = torch.cuda.current_stream().cuda_stream
-for (H, cin, cout) in [(160, 48, 48), (160, 24, 72), (160, 72, 24), (80, 96, 96), (80, 64, 192), (80, 288, 128), (40, 96, 288), (20, 384, 384), (80, 128, 80)]:
-    M = 32 * H * H
+for (H, cin, cout) in [(160, 48, 48), (160, 24, 72), (80, 64, 192), (80, 192, 576), (80, 576, 192), (40, 384, 1152), (40, 576, 384), (20, 768, 768), (80, 256, 256), (40, 192, 576), (80, 128, 384)]:
+    M = int(os.environ.get('BS', '16')) * H * H
     x = torch.randn(M, cin, device='cuda').half(); dy = torch.randn(M, cout, device='cuda').half()
     reps = int(os.environ.get("REPS", "1"))
     dw = torch.zeros(reps, cout, cin, device='cuda')
