@@ -61,14 +61,13 @@ struct BnCfg {
     static constexpr int OFF_W1 = 0, OFF_B1 = 2 * S1 * 1024, REC_A = OFF_B1 + 128;
     static constexpr int OFF_TOE = REC_A, OFF_W2 = OFF_TOE + NTOE * 16, OFF_BD = OFF_W2 + CT2 * 1024;
     static constexpr int REC = OFF_BD + 128;                       // bytes per block record
-    static constexpr int NVA = (REC_A / 16 + 255) / 256, NVB = ((REC - REC_A) / 16 + 255) / 256;   // 16-byte vectors per thread per part
     static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC;
 };
 
 template <int K, int S1, int CT2>
 __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
     typedef BnCfg<K, S1, CT2> Cf;
-    constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS, NVA = Cf::NVA, NVB = Cf::NVB;
+    constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t* T1 = reinterpret_cast<half_t*>(smem_raw);                        // [32][PS]
     unsigned char* rec = smem_raw + 32 * Cf::PSB;                            // [REC]: the current block's operands (each part is refilled as soon as its phase is over)
@@ -116,22 +115,17 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
     // zero mask of the T1 values this lane writes: accumulator lane (g, p) of m-tile t owns halo pixels t*16 + 4g .. +3
     // (one row, 4 consecutive columns); bit r set = pixel r is inside the image.  interior tiles: all ones.
     const bool interior = y0 - P >= 0 && x0 - P >= 0 && y0 - P + Cf::RH <= a.H && x0 - P + RWC <= a.W;
-    // The next block's record travels global -> registers (in flight during a whole phase) -> LDS.
-    u32x4_t prA[NVA], prB[NVB];
-    auto load_part = [&](int mb, auto& pr, auto nv, int off, int bytes) {
-        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.par + (size_t)mb * Cf::REC + off);
-#pragma unroll
-        for (int v = 0; v < decltype(nv)::value; ++v)
-            if (tid + v * 256 < bytes / 16) pr[v] = src[tid + v * 256];
+    // The next block's record travels global -> LDS by DMA (global_load_lds: no registers, no ds_write; every wave moves 1 KiB
+    // per instruction to a wave-uniform LDS base + lane * 16).  The barrier that publishes it also waits for it (vmcnt).
+    auto dma_part = [&](int mb, int off, int bytes) {
+        const unsigned char* src = a.par + (size_t)mb * Cf::REC + off;
+        const int nvec = bytes >> 4;
+        for (int v0 = wave * 64; v0 < nvec; v0 += 256) {
+            if (v0 + lane < nvec)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(v0 + lane) * 16),
+                                                 (void __attribute__((address_space(3)))*)(rec + off + v0 * 16), 16, 0, 0);
+        }
     };
-    auto store_part = [&](auto& pr, auto nv, int off, int bytes) {
-        u32x4_t* dst = reinterpret_cast<u32x4_t*>(rec + off);
-#pragma unroll
-        for (int v = 0; v < decltype(nv)::value; ++v)
-            if (tid + v * 256 < bytes / 16) dst[tid + v * 256] = pr[v];
-    };
-    const std::integral_constant<int, NVA> nva{};
-    const std::integral_constant<int, NVB> nvb{};
 
     f32x4_t acc2[4][CT2];
 #pragma unroll
@@ -144,15 +138,12 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
     int hi_off = 4;
     asm volatile("" : "+v"(hi_off));                        // opaque: the two 8-byte halves of a window stay two ds_read_b64 (2 LDS cycles each; ds_read2_b64 costs 8)
 
-    load_part(0, prA, nva, 0, Cf::REC_A);
-    load_part(0, prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);
+    dma_part(0, 0, Cf::REC);
     load_x_head();
-    store_part(prA, nva, 0, Cf::REC_A);
     __syncthreads();
 
     for (int mb = 0; mb < a.nMB; ++mb) {
-        store_part(prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);     // part B of this block (loaded during the previous block's phase B)
-        if (mb + 1 < a.nMB) load_part(mb + 1, prA, nva, 0, Cf::REC_A);
+        if (mb > 0) dma_part(mb, Cf::REC_A, Cf::REC - Cf::REC_A);  // part B of this block: free since the barrier that ended the previous block, needed after the next one
         // ---- A. T1 = SiLU(X * W1[:, block] + b1) on the halo tile
         {
             half8_t w1f[2][S1];
@@ -193,8 +184,8 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
         }
         __syncthreads();
         if (mb + 1 < a.nMB) {
-            store_part(prA, nva, 0, Cf::REC_A);             // phase A is over: its operands can be replaced
-            load_part(mb + 1, prB, nvb, Cf::REC_A, Cf::REC - Cf::REC_A);
+            dma_part(mb + 1, 0, Cf::REC_A);                  // phase A is over: its operands can be replaced
+            load_x_head();                                  // the next phase A's first activations: in flight during phase B
         }
 
         // ---- B. depth-wise k x k on the matrix cores: 8 channel sets s (channels 8g + s), k tap rows, PARTS windows
@@ -240,7 +231,6 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
             }
         }
         if (mb + 1 < a.nMB) {
-            load_x_head();                                  // the next phase A's first activations (L1/L2 hits), in flight across the barrier
             __syncthreads();                                // phase B has finished reading T1 and part B; part A of the next block is visible
         }
     }
