@@ -353,3 +353,35 @@ def test_multi_stream_plan_equals_single_stream(models):
             torch.cuda.synchronize()
             assert torch.equal(pred, outs[ms])
     assert torch.equal(outs[2], outs[False]) and torch.equal(outs[1], outs[False])
+
+
+@pytest.mark.parametrize("hw", [(384, 640), (352, 608), (64, 96)])
+def test_rectangular_images_vs_oracle(models, hw):
+    """Rect inference (evaler.py pads to multiples of 32, not to squares): every level's grid is H/s x W/s."""
+    g = torch.Generator().manual_seed(hw[0] + hw[1])
+    x = torch.rand(2, 3, hw[0], hw[1], generator=g)
+    sd = {k: v.detach().cpu() for k, v in models["n"].state_dict().items()}
+    ref = O.predict(O.reparam(sd, "n"), "n", x).numpy()
+    with torch.no_grad():
+        got = models["n"](x.to(DEV))[0].cpu().numpy()
+    assert got.shape == ref.shape == (2, (hw[0] // 8) * (hw[1] // 8) + (hw[0] // 16) * (hw[1] // 16) + (hw[0] // 32) * (hw[1] // 32), 85)
+    _close32(got, ref)
+    with torch.no_grad():
+        got16 = models["n"](x.to(DEV).half())[0].cpu().numpy()
+    _close16(got16, ref)
+
+
+@pytest.mark.parametrize("n_cand", [4095, 4096, 4097, 6000])
+def test_nms_matrix_and_list_paths_meet_at_4096_candidates(n_cand):
+    """<= 4096 candidates: suppression-matrix kernels; more: the one-workgroup greedy kernel (LDS sort up to 8192).  Same answer."""
+    rng = np.random.RandomState(n_cand)
+    N, nc = 9000, 6
+    pred = np.zeros((1, N, 5 + nc), np.float32)
+    pred[0, :, 0:2] = rng.uniform(40, 600, (N, 2)); pred[0, :, 2:4] = rng.uniform(8, 90, (N, 2))
+    pred[0, :, 4] = 1.0
+    pred[0, :, 5:] = 0.01
+    rows = rng.choice(N, n_cand, replace=False)
+    pred[0, rows, 5 + rng.randint(0, nc, n_cand)] = rng.uniform(0.3, 0.99, n_cand).astype(np.float32)     # exactly n_cand candidates > conf
+    want, widx = O.non_max_suppression(pred, 0.25, 0.5, multi_label=True, max_det=300, return_index=True)
+    got, gidx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), 0.25, 0.5, multi_label=True, max_det=300, return_index=True)
+    assert np.array_equal(gidx[0].cpu().numpy(), widx[0]) and np.array_equal(got[0].cpu().numpy(), want[0])
