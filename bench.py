@@ -194,7 +194,7 @@ def main():
     model = model.to(dev).eval()
     model.autotune = not args.no_autotune      # per-layer MFMA tile selection when the plan is built (outside the timed region)
     if args.fuse >= 0:
-        model.fuse_bottlenecks = bool(args.fuse)
+        model.fuse_bottlenecks = {0: False, 1: True}.get(args.fuse, args.fuse)
     if args.lanes >= 0:
         model.multi_stream = args.lanes
     from maf_yolo_amd import engine as _engine

@@ -27,6 +27,7 @@ extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
         case MAF_OP_SPPF_POOL: return maf_launch_sppf_pool(op, s);
         case MAF_OP_DECODE: return maf_launch_decode(op, s);
         case MAF_OP_BOTTLENECK: return maf_launch_bottleneck(op, s);
+        case MAF_OP_CONV1DW: return maf_launch_conv1dw(op, s);
         default: maf_set_error("maf_op_launch: unknown op kind"); return MAF_E_UNSUPPORTED;
     }
 }

@@ -20,29 +20,36 @@ _TUNE_CACHE = {}          # layer signature -> (tile_p, tile_c), filled by Plan.
 
 
 def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
-    """Measure, per DepthBottleneckUni, the fused kernel against the three separate launches on this device and return the
-    set of bottleneck names to fuse.  Decisions are cached by layer signature next to the tile choices."""
+    """Measure, per DepthBottleneckUni, the three ways of running it on this device — three launches, the fully fused kernel
+    (c <= 64), conv1+depth-wise fused followed by the plain 1x1 — and return {bottleneck name: mode}.  Decisions are cached by layer
+    signature next to the tile choices."""
     import numpy as np
-    planF = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True)
-    names = [planF.op_names[i] for i, o in enumerate(planF.ops) if o.kind == lib.OP_BOTTLENECK]
-    sigs = {planF.op_names[i]: ("bn", dtype, B, o.H, o.W, o.Cin, o.ksize, o.tile_k) for i, o in enumerate(planF.ops) if o.kind == lib.OP_BOTTLENECK}
+    plan1 = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True)           # full fusion where it exists, partial elsewhere
+    names, sigs = [], {}
+    for i, o in enumerate(plan1.ops):
+        nm = plan1.op_names[i]
+        if o.kind == lib.OP_BOTTLENECK:
+            names.append(nm); sigs[nm] = ("bn3", dtype, B, o.H, o.W, o.Cin, o.ksize)
+        elif o.kind == lib.OP_CONV1DW:
+            names.append(nm[:-len(".conv1dw")]); sigs[names[-1]] = ("bn3", dtype, B, o.H, o.W, o.Cin, o.ksize)
     if names and not all(sigs[n] in _TUNE_CACHE for n in names):
-        planU = Plan(model, B, H, W, dtype, in_dtype, device, fuse=False)
-        planU.autotune(x)
-        planF.autotune(x)
-        pred = torch.empty(B, planU.A, 5 + planU.nc, dtype=torch.float32, device=device)
+        pred = torch.empty(B, plan1.A, 5 + plan1.nc, dtype=torch.float32, device=device)
 
         def timed(plan):
+            plan.autotune(x)
             plan.run_timed(x, pred)
-            return np.min([plan.run_timed(x, pred) for _ in range(reps)], 0)
-        tU, tF = timed(planU), timed(planF)
+            t = np.min([plan.run_timed(x, pred) for _ in range(reps)], 0)
+            return dict(zip(plan.op_names, t))
+        t0 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=False))
+        t1 = timed(plan1)
+        t2 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=2))
         for n in names:
-            u = sum(t for t, nm in zip(tU, planU.op_names) if nm in (n + ".conv1", n + ".conv2", n + ".one_conv"))
-            f = tF[planF.op_names.index(n)]
-            _TUNE_CACHE[sigs[n]] = (1 if f < u else 0,)
-        del planU
-    del planF
-    return frozenset(n for n in names if _TUNE_CACHE[sigs[n]][0])
+            cost = {0: t0[n + ".conv1"] + t0[n + ".conv2"] + t0[n + ".one_conv"], 2: t2[n + ".conv1dw"] + t2[n + ".one_conv"]}
+            if n in t1:
+                cost[1] = t1[n]
+            _TUNE_CACHE[sigs[n]] = (min(cost, key=cost.get),)
+    del plan1
+    return {n: _TUNE_CACHE[sigs[n]][0] for n in names}
 
 
 def save_tune_cache(path):
@@ -98,9 +105,10 @@ class Plan:
         self.nc = model.nc
         self.reg_max = model.detect.reg_max
         self.strides = [float(s) for s in model.detect.stride.tolist()]
-        # MAF_OP_BOTTLENECK runs a whole DepthBottleneckUni in one launch (csrc/bottleneck.hip).  `fuse`: True / False for every
-        # eligible bottleneck, a set of bottleneck names, or "auto" = the built-in rule (k <= 5: the 160^2 / 80^2 maps, where it
-        # wins by 1.3-1.8x; Model.plan_for replaces the rule by a measurement when autotuning is on).
+        # A DepthBottleneckUni runs as three launches (mode 0), as ONE launch (mode 1, csrc/bottleneck.hip, c <= 64) or as conv1 +
+        # depth-wise fused followed by the plain 1x1 (mode 2, csrc/conv1dw.hip, any c).  `fuse`: False (0 everywhere), True (1 where
+        # it exists, else 2), 2, a {name: mode} dict, or "auto" = the built-in rule (mode 1 for k <= 5 and c <= 64: the 160^2 / 80^2
+        # maps, where it wins by 1.3-1.8x; Model.plan_for replaces the rule by a measurement when autotuning is on).
         self.fuse = getattr(model, "fuse_bottlenecks", "auto") if fuse is None else fuse
         # independent branches (side down-sampling convs of the MAFPN neck, the three heads and their cls / reg halves) CAN run
         # on separate HIP streams of the engine.  Measured on MI355X (n, bs 32): heads-only lanes give -1 % on forward+NMS and
@@ -112,12 +120,25 @@ class Plan:
             self._build(model)
         self._finalize()
 
-    def _fuse_ok(self, name, k):
-        if isinstance(self.fuse, (set, frozenset, list, tuple)):
-            return name in self.fuse
-        if self.fuse == "auto":
-            return k <= 5
-        return bool(self.fuse)
+    def _fuse_mode(self, name, k, c):
+        if self.dtype != lib.F16 or c % 8:
+            return 0
+        f = self.fuse
+        if isinstance(f, dict):
+            m = f.get(name, 0)
+        elif isinstance(f, (set, frozenset, list, tuple)):
+            m = 1 if name in f else 0
+        elif f == "auto":
+            m = 1 if k <= 5 else 0
+        elif f is True:
+            m = 1
+        else:
+            m = int(f or 0)
+        if m == 1 and c > 64:
+            m = 2 if (f is True or isinstance(f, dict)) else 0
+        if m == 2 and c > 512:
+            m = 0
+        return m
 
     # ---------------------------------------------------------------- allocation helpers
     def _alloc(self, H, W, C, esize=None):
@@ -199,7 +220,17 @@ class Plan:
                 for d, blk in enumerate(m.m):
                     mid = blk.conv1.conv.out_channels
                     q = "%s.m.%d" % (p, d)
-                    if self.dtype == lib.F16 and c_ <= 64 and c_ % 8 == 0 and self._fuse_ok(q, blk.conv2.dwconv.kernel_size):
+                    mode = self._fuse_mode(q, blk.conv2.dwconv.kernel_size, c_)
+                    if mode == 2:
+                        # conv1 + depth-wise in one launch (the 3c-wide T1 stays in LDS), then the plain 1x1
+                        rec, nmb = pack.pack_conv1dw(*blk.conv1.fused(), *blk.conv2.fused())
+                        t2 = self._alloc(x.H, x.W, mid)
+                        self._ops.append(dict(kind=lib.OP_CONV1DW, name=q + ".conv1dw", act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=mid,
+                                              ksize=blk.conv2.dwconv.kernel_size, segs=[Seg(cat, c_, (d + 1) * c_)], out=t2, out_coff=0, w=self._wput(rec),
+                                              b=self._wput(torch.zeros(8))))
+                        self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), cat, (d + 2) * c_, lib.ACT_SILU)
+                        continue
+                    if mode == 1:
                         # the whole DepthBottleneckUni in one launch; its 3c-channel intermediates stay in LDS
                         rec, b2p, nmb, ct2 = pack.pack_bottleneck(*blk.conv1.fused(), *blk.conv2.fused(), *blk.one_conv.fused())
                         k = blk.conv2.dwconv.kernel_size
@@ -557,6 +588,8 @@ class Plan:
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:
             return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)
+        if o.kind == lib.OP_CONV1DW:
+            return "conv1dw_kernel<%d>" % o.ksize
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -579,6 +612,8 @@ class Plan:
             return self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.Cin * es + o.ksize * o.ksize * o.Cin * es
+        if o.kind == lib.OP_CONV1DW:
+            return px * (o.Cin + o.Cout) * es + (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout) * es
         if o.kind == lib.OP_BOTTLENECK:
             mid = o.tile_k * 32
             return px * (o.Cin + o.Cout) * es + (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
@@ -599,6 +634,8 @@ class Plan:
             return 2 * px * 9 * o.Cin * o.Cout
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.ksize * o.ksize * o.Cin
+        if o.kind == lib.OP_CONV1DW:
+            return 2 * px * (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout)
         if o.kind == lib.OP_BOTTLENECK:
             mid = self._ops[idx]["mid"]
             return 2 * px * (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout)

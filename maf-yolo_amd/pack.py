@@ -89,6 +89,31 @@ def pack_dw(w, dtype):
     return w.float().cpu().reshape(c, k * k).t().contiguous().to(torch.float16 if dtype == lib.F16 else torch.float32)
 
 
+def pack_conv1dw(w1, b1, wdw, bdw):
+    """Operands of MAF_OP_CONV1DW (csrc/conv1dw.hip), fp16: one record per 32 mid channels, in the order the kernel copies it to
+    LDS: W1 fragments [2, S1, 64, 8] | b1 [32] f32 | Toeplitz table [8, k, parts, 16, 8] | bdw [32] f32.
+    Inside a block the kernel's plane pl = 4s + g holds real channel 8g + s (lane group g ends with 8 consecutive channels), so the
+    W1 columns / b1 of plane pl are those of channel 8*(pl % 4) + pl // 4; Toeplitz entry (s, G) and bdw are in real channel order."""
+    mid, c = w1.shape[0], w1.shape[1]
+    k = wdw.shape[-1]
+    nmb = -(-mid // 32)
+    mp = nmb * 32
+    perm = torch.tensor([8 * (pl % 4) + pl // 4 for pl in range(32)])
+    w1p = torch.zeros(mp, c); w1p[:mid] = w1.reshape(mid, c).float().cpu()
+    b1p = torch.zeros(mp); b1p[:mid] = b1.float().cpu()
+    w1p = w1p.reshape(nmb, 32, c)[:, perm].reshape(mp, c)
+    b1q = b1p.reshape(nmb, 32)[:, perm]
+    W1 = torch.cat([pack_matrix([w1p[m * 32:(m + 1) * 32]], 1, lib.F16) for m in range(nmb)], 0)       # [nmb*2, S1, 64, 8]
+    wfull = torch.zeros(mp, 1, k, k); wfull[:mid] = wdw.float().cpu()
+    toe = pack_dw_toeplitz(wfull)                                          # [nmb, 8, k, parts, 16, 8], entry (s, G) = channel 8G + s
+    bdp = torch.zeros(mp); bdp[:mid] = bdw.float().cpu()
+
+    def raw(t):
+        return t.contiguous().view(torch.uint8).reshape(nmb, -1)
+    rec = torch.cat([raw(W1.reshape(nmb, -1)), raw(b1q.contiguous()), raw(toe.reshape(nmb, -1)), raw(bdp.reshape(nmb, 32))], 1).contiguous()
+    return rec, nmb
+
+
 def pack_dw_toeplitz(w):
     """w [C, 1, k, k] -> the Toeplitz table of the matrix-core depth-wise kernel (csrc/dwconv_mfma.hip), fp16
     [C/32 blocks, 8 sets, k, parts, 16, 8]: entry (block cb, set s, tap row ky, window part, row i = 4G + r, element j) =

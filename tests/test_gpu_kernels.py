@@ -423,3 +423,30 @@ def test_fused_bottleneck(c, k, H, W):
     _check(buf[..., 8 + c:8 + 2 * c], ref, lib.F16)
     assert (buf[..., :8] == 0).all() and (buf[..., 8 + 2 * c:] == 0).all()
     assert torch.equal(buf[..., 8:8 + c].float().cpu().permute(0, 3, 1, 2), x)         # input slice untouched
+
+
+@pytest.mark.parametrize("c,k,H,W", [(96, 7, 21, 27), (192, 9, 20, 20), (24, 3, 33, 18), (128, 5, 16, 32), (72, 5, 40, 40)])
+def test_conv1_dw_partial_fusion(c, k, H, W):
+    """MAF_OP_CONV1DW == Conv1x1+SiLU -> DW k x k + SiLU (first half of DepthBottleneckUni, common.py:905-909) for any width."""
+    g = torch.Generator().manual_seed(3 * c + k)
+    B, mid = 2, 3 * c
+    x = torch.randn(B, c, H, W, generator=g).half().float()
+    w1 = (torch.randn(mid, c, 1, 1, generator=g) / c ** 0.5).half().float(); b1 = torch.randn(mid, generator=g) * 0.3
+    wd = (torch.randn(mid, 1, k, k, generator=g) / k).half().float(); bd = torch.randn(mid, generator=g) * 0.3
+    t1 = F.silu(F.conv2d(x, w1, b1)).half().float()
+    ref = F.silu(F.conv2d(t1, wd, bd, 1, k // 2, 1, mid))
+    rec, nmb = pack.pack_conv1dw(w1, b1, wd, bd)
+    assert rec.shape[1] == lib.load().maf_conv1dw_record_bytes(k, c) and nmb == -(-mid // 32)
+    recd = rec.to(DEV)
+    xs = torch.zeros(B, H, W, c + 8, dtype=torch.float16, device=DEV)
+    xs[..., 8:] = _nhwc(x, lib.F16)
+    out = torch.full((B, H, W, mid + 8), 2.0, dtype=torch.float16, device=DEV)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1DW, lib.F16, lib.F16, lib.ACT_SILU
+    op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc = B, H, W, c, mid, k, 1
+    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff = xs.data_ptr(), c, c + 8, 8
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), mid + 8, 8
+    op.w = recd.data_ptr()
+    _launch(op)
+    _check(out[..., 8:], ref, lib.F16)
+    assert (out[..., :8] == 2).all()

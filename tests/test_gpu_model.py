@@ -253,9 +253,9 @@ def test_autotuned_tiles_give_identical_predictions(models):
 
 
 def test_fused_bottleneck_plan_matches_unfused(models):
-    """MAF_OP_BOTTLENECK plan (6 of the n model's bottlenecks in one launch each) vs the three-kernel plan."""
+    """MAF_OP_BOTTLENECK / MAF_OP_CONV1DW plans (full fusion for c <= 64, conv1+dw elsewhere; conv1+dw everywhere) vs three kernels."""
     outs = {}
-    for fuse in (True, False):
+    for fuse in (True, 2, False):
         m = M.Model("n")
         m.load_state_dict(O.synth_state_dict("n", 0))
         m = m.to(DEV).eval()
@@ -263,8 +263,10 @@ def test_fused_bottleneck_plan_matches_unfused(models):
         x = O.synth_images(2, 320, 8).to(DEV).half()
         with torch.no_grad():
             outs[fuse] = m(x)[0].cpu().numpy()
-        assert sum(1 for o in m.plan_for(x).ops if o.kind == 6) == (6 if fuse else 0)
+        assert sum(1 for o in m.plan_for(x).ops if o.kind == 6) == (6 if fuse is True else 0)
+        assert sum(1 for o in m.plan_for(x).ops if o.kind == 7) == {True: 4, 2: 10, False: 0}[fuse]
     _close16(outs[True], outs[False])
+    _close16(outs[2], outs[False])
 
 
 def test_fusion_choice_is_measured_when_autotuning():
@@ -277,10 +279,10 @@ def test_fusion_choice_is_measured_when_autotuning():
     with torch.no_grad():
         m(x)
     plan = m.plan_for(x)
-    decided = [k for k in engine._TUNE_CACHE if k[0] == "bn" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
+    decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
-    nf = sum(1 for o in plan.ops if o.kind == 6)
-    assert len(plan.ops) == 90 - 2 * nf
+    nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
+    assert len(plan.ops) == 90 - 2 * nf - npart
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):

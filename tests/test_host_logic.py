@@ -149,15 +149,17 @@ def test_plan_builds_on_cpu(built, scale, nops):
     assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
     lo, hi = plan._abase, plan._abase + plan._arena_size
     for o, name in zip(plan.ops, plan.op_names):
-        if o.kind in (lib.OP_CONV1X1, lib.OP_CONV3X3S2, lib.OP_DWCONV, lib.OP_BOTTLENECK):
+        if o.kind in (lib.OP_CONV1X1, lib.OP_CONV3X3S2, lib.OP_DWCONV, lib.OP_BOTTLENECK, lib.OP_CONV1DW):
             assert sum(o.src[i].C for i in range(o.nsrc)) == o.Cin, name
             for i in range(o.nsrc):
                 assert lo <= o.src[i].ptr < hi and o.src[i].stride % 8 == 0 and o.src[i].coff % 8 == 0, name
             assert lo <= o.out < hi, name
     assert plan.A == 8 * 8 + 4 * 4 + 2 * 2
-    m.fuse_bottlenecks = True                      # fused DepthBottleneckUni: 3 launches -> 1 wherever c <= 64
+    m.fuse_bottlenecks = True                      # fused DepthBottleneckUni: 3 launches -> 1 wherever c <= 64, -> 2 (conv1+dw | 1x1) elsewhere
     fused = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
-    assert len(fused.ops) == nops - 2 * {"n": 6, "s": 4, "m": 2}[scale]
+    full, part = {"n": (6, 4), "s": (4, 16), "m": (2, 28)}[scale]
+    assert len(fused.ops) == nops - 2 * full - part
+    assert sum(1 for o in fused.ops if o.kind == lib.OP_BOTTLENECK) == full and sum(1 for o in fused.ops if o.kind == lib.OP_CONV1DW) == part
     m.fuse_bottlenecks = "auto"                    # default rule without a measurement: k <= 5 only
     auto = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
     assert len(auto.ops) == nops - 2 * {"n": 4, "s": 4, "m": 2}[scale]
