@@ -172,6 +172,15 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
 int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c);
 int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c, void* out, maf_stream_t stream);
 int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
+/* Task-aligned label assignment — replaces TaskAlignedAssigner.forward (yolov6/assigners/tal_assigner.py:21-151,
+ * assigner_utils.py:25-89) as ComputeLoss calls it (yolov6/models/loss.py:96-103), on RAGGED targets: gts [T][5] = (label, x1, y1, x2, y2
+ * in pixels) sorted by image, offsets [B+1] = first row of every image.  pd_scores [B,A,nc] (sigmoid outputs), pd_bboxes [B,A,4] xyxy
+ * pixels, anchor_points [A,2] pixels.  out_gt [B,A] = row of the assigned box or -1 (background), out_norm [B,A] = the normalised
+ * alignment metric that scales the one-hot score target (tal_assigner.py:66-71).  A <= 8400. */
+int maf_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* anchor_points, const float* gts, const int32_t* offsets,
+                   int32_t B, int32_t A, int32_t nc, int32_t topk, float alpha, float beta, float eps,
+                   int32_t* out_gt, float* out_norm, maf_stream_t stream);
+
 /* BatchNorm2d in training mode fused with the activation behind it (Conv.forward = act(bn(conv(x))), common.py:46-47), NHWC views.
  *   maf_bn_forward   batch statistics -> save_mean / save_rstd (+ running stats with torch's momentum rule, unbiased variance; may be
  *                    NULL) and y = act(xhat*gamma + beta).   part = [R][2][C] fp32 scratch: zero on entry, zeroed again on exit (R replicas spread

@@ -616,3 +616,122 @@ def coco_rows(outputs, shapes, image_ids, ids, scale_exact=False):
     if not bb:
         return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 4)), np.zeros(0)
     return np.concatenate(iid), np.concatenate(cid).astype(np.int64), np.concatenate(bb), np.concatenate(sc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training loss: ComputeLoss with the task-aligned assigner — yolov6/models/loss.py:56-193 (formal-assigner
+# branch, epoch >= warmup_epoch), yolov6/assigners/tal_assigner.py:21-151, assigner_utils.py:25-89, figure_iou.py (GIoU),
+# yolov6/utils/general.py:29-49 (dist2bbox / bbox2dist), anchor_generator.py:26-53.  Written per image and per ground-truth box
+# (the reference builds dense [B, n_max, A] masks); padded boxes of the reference never win an argmax nor a top-k, so they vanish.
+# ---------------------------------------------------------------------------------------------------------------------
+def train_anchors(feat_hw, strides=(8, 16, 32), offset=0.5):
+    """anchor_generator.py:26-53: anchor centres in pixels and the stride of every anchor, levels concatenated."""
+    pts, st = [], []
+    for (h, w), s in zip(feat_hw, strides):
+        ys = (torch.arange(h, dtype=torch.float32) + offset) * s
+        xs = (torch.arange(w, dtype=torch.float32) + offset) * s
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        pts.append(torch.stack([xx, yy], -1).reshape(-1, 2))
+        st.append(torch.full((h * w, 1), float(s)))
+    return torch.cat(pts), torch.cat(st)
+
+
+def _pair_iou(g, p, eps=1e-9):
+    """assigner_utils.py:68-89: IoU of one gt box [4] with predicted boxes [A,4]."""
+    x1y1 = torch.maximum(g[:2], p[:, :2]); x2y2 = torch.minimum(g[2:], p[:, 2:])
+    inter = (x2y2 - x1y1).clip(0).prod(-1)
+    a1 = (g[2:] - g[:2]).clip(0).prod(-1); a2 = (p[:, 2:] - p[:, :2]).clip(0).prod(-1)
+    return inter / (a1 + a2 - inter + eps)
+
+
+def tal_assign(pd_scores, pd_bboxes, anc_points, gts, nc=80, topk=13, alpha=1.0, beta=6.0, eps=1e-9):
+    """One image.  pd_scores [A,nc] (sigmoid outputs), pd_bboxes [A,4] xyxy pixels, gts [n,5] = (label, x1,y1,x2,y2) pixels.
+    -> target_labels [A] (label of gt 0 for background anchors, as the reference leaves it), target_bboxes [A,4], target_scores [A,nc], fg [A]."""
+    A = pd_scores.shape[0]
+    n = gts.shape[0]
+    if n == 0:
+        return torch.zeros(A, dtype=torch.long), torch.zeros(A, 4), torch.zeros(A, nc), torch.zeros(A, dtype=torch.bool)
+    labels = gts[:, 0].long()
+    ov = torch.stack([_pair_iou(gts[g, 1:], pd_bboxes, eps) for g in range(n)])                    # [n,A]
+    metric = pd_scores[:, labels].t().pow(alpha) * ov.pow(beta)                                    # tal_assigner.py:96-111
+    d = torch.cat([anc_points[None] - gts[:, None, 1:3], gts[:, None, 3:5] - anc_points[None]], -1)
+    in_gts = (d.min(-1)[0] > eps).float()                                                          # assigner_utils.py:25-44
+    mask_pos = torch.zeros(n, A)
+    for g in range(n):                                                                             # tal_assigner.py:113-128
+        idx = torch.topk(metric[g] * in_gts[g], topk, largest=True)[1]
+        mask_pos[g, idx] = 1.0
+    mask_pos = mask_pos * in_gts
+    fg = mask_pos.sum(0)
+    multi = fg > 1                                                                                 # assigner_utils.py:46-66
+    if bool(multi.any()):
+        best = ov.argmax(0)
+        mask_pos[:, multi] = F.one_hot(best[multi], n).t().float()
+        fg = mask_pos.sum(0)
+    gt_idx = mask_pos.argmax(0)
+    t_labels = labels[gt_idx]
+    t_boxes = gts[gt_idx, 1:]
+    t_scores = F.one_hot(t_labels, nc).float() * (fg > 0).float()[:, None]
+    am = metric * mask_pos                                                                         # tal_assigner.py:66-71
+    pos_am = am.max(-1, keepdim=True)[0]
+    pos_ov = (ov * mask_pos).max(-1, keepdim=True)[0]
+    norm = (am * pos_ov / (pos_am + eps)).max(0)[0]
+    return t_labels, t_boxes, t_scores * norm[:, None], fg > 0
+
+
+def _giou_loss(b1, b2, eps=1e-10):
+    """figure_iou.py IOUloss(box_format='xyxy', iou_type='giou', eps=1e-10): rows of b1/b2 [M,4] -> [M,1]."""
+    x1, y1, x2, y2 = b1.split(1, -1); u1, v1, u2, v2 = b2.split(1, -1)
+    inter = (torch.min(x2, u2) - torch.max(x1, u1)).clamp(0) * (torch.min(y2, v2) - torch.max(y1, v1)).clamp(0)
+    w1, h1 = x2 - x1, y2 - y1 + eps
+    w2, h2 = u2 - u1, v2 - v1 + eps
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = torch.max(x2, u2) - torch.min(x1, u1); ch = torch.max(y2, v2) - torch.min(y1, v1)
+    c_area = cw * ch + eps
+    return 1.0 - (iou - (c_area - union) / c_area)
+
+
+def compute_loss(feat_hw, pred_scores, pred_distri, targets, nc=80, img_size=640, reg_max=16, strides=(8, 16, 32),
+                 weights=(1.0, 2.5, 0.5), return_assignment=False):
+    """loss.py:56-193 with the task-aligned assigner.  pred_scores [B,A,nc] in (0,1), pred_distri [B,A,4*(reg_max+1)] logits, targets
+    [T,6] = (image, class, cx, cy, w, h) normalised to the image.  -> (loss, [iou, dfl, cls] weighted items)."""
+    B, A, _ = pred_scores.shape
+    pts, st = train_anchors(feat_hw, strides)
+    pts_s = pts / st
+    proj = torch.linspace(0, reg_max, reg_max + 1)
+    dist = F.softmax(pred_distri.view(B, A, 4, reg_max + 1), -1).matmul(proj)                       # loss.py:190-193
+    pred_boxes = torch.cat([pts_s - dist[..., :2], pts_s + dist[..., 2:]], -1)                      # dist2bbox, xyxy in stride units
+    t_labels = torch.zeros(B, A, dtype=torch.long); t_boxes = torch.zeros(B, A, 4)
+    t_scores = torch.zeros(B, A, nc); fg = torch.zeros(B, A, dtype=torch.bool)
+    for b in range(B):
+        rows = targets[targets[:, 0] == b]
+        g = torch.zeros(rows.shape[0], 5)
+        if rows.shape[0]:
+            xywh = rows[:, 2:6] * img_size                                                          # loss.py:179-188
+            g[:, 0] = rows[:, 1]
+            g[:, 1] = xywh[:, 0] - xywh[:, 2] / 2; g[:, 2] = xywh[:, 1] - xywh[:, 3] / 2
+            g[:, 3] = xywh[:, 0] + xywh[:, 2] / 2; g[:, 4] = xywh[:, 1] + xywh[:, 3] / 2
+        t_labels[b], t_boxes[b], t_scores[b], fg[b] = tal_assign(pred_scores[b].detach(), (pred_boxes[b] * st).detach(), pts, g, nc)
+    t_boxes = t_boxes / st                                                                          # loss.py:152
+    lab = torch.where(fg, t_labels, torch.full_like(t_labels, nc))
+    one_hot = F.one_hot(lab, nc + 1)[..., :-1].float()
+    w = 0.75 * pred_scores.pow(2.0) * (1 - one_hot) + t_scores * one_hot                            # VarifocalLoss, loss.py:200-206
+    loss_cls = (F.binary_cross_entropy(pred_scores.float(), t_scores.float(), reduction="none") * w).sum()
+    tss = t_scores.sum()
+    loss_cls = loss_cls / tss
+    if bool(fg.any()):                                                                              # BboxLoss, loss.py:217-267
+        bw = t_scores.sum(-1)[fg].unsqueeze(-1)
+        loss_iou = (_giou_loss(pred_boxes[fg], t_boxes[fg]) * bw).sum() / tss
+        ltrb = torch.cat([pts_s - t_boxes[..., :2], t_boxes[..., 2:] - pts_s], -1).clip(0, reg_max - 0.01)[fg]   # bbox2dist
+        pd = pred_distri.view(B, A, 4, reg_max + 1)[fg]
+        tl = ltrb.long(); tr = tl + 1
+        wl = tr.float() - ltrb; wr = 1 - wl
+        ce = lambda t: F.cross_entropy(pd.reshape(-1, reg_max + 1), t.reshape(-1), reduction="none").view(tl.shape)
+        loss_dfl = (((ce(tl) * wl + ce(tr) * wr).mean(-1, keepdim=True)) * bw).sum() / tss
+    else:
+        loss_iou = torch.tensor(0.); loss_dfl = torch.tensor(0.)
+    loss = weights[0] * loss_cls + weights[1] * loss_iou + weights[2] * loss_dfl
+    items = torch.stack([weights[1] * loss_iou, weights[2] * loss_dfl, weights[0] * loss_cls]).detach()
+    if return_assignment:
+        return loss, items, (t_labels, t_boxes, t_scores, fg)
+    return loss, items

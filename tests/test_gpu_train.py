@@ -173,3 +173,61 @@ def test_bn_act_forward_backward(dtype, tol, act, c, hw):
     assert torch.allclose(bn_gpu.running_mean.cpu(), bn_ref.running_mean, atol=2e-3 if dtype == torch.float16 else 1e-5)
     assert torch.allclose(bn_gpu.running_var.cpu(), bn_ref.running_var, rtol=2e-3 if dtype == torch.float16 else 1e-4, atol=1e-5)
     assert int(bn_gpu.num_batches_tracked) == 1
+
+
+def _loss_case(golden_fn, ci):
+    g = golden_fn("loss_cases")
+    size = int(g["c%d_size" % ci])
+    hw = [(size // s, size // s) for s in (8, 16, 32)]
+    return g, size, hw
+
+
+@pytest.mark.parametrize("ci", [0, 1, 3])
+def test_compute_loss_matches_reference_fixture(golden, ci):
+    """f2: device ComputeLoss (HIP task-aligned assignment on ragged labels + torch loss terms) == the reference's ComputeLoss
+    (tools/make_golden_loss.py): loss, weighted items and the gradient into both head outputs."""
+    g, size, hw = _loss_case(golden, ci)
+    s = torch.from_numpy(g["c%d_scores" % ci]).to(DEV).requires_grad_(True)
+    d = torch.from_numpy(g["c%d_distri" % ci]).to(DEV).requires_grad_(True)
+    feats = [torch.zeros(s.shape[0], 8, h, w, device=DEV) for h, w in hw]
+    crit = M.ComputeLoss(ori_img_size=size)
+    loss, items = crit((feats, s, d), torch.from_numpy(g["c%d_targets" % ci]).to(DEV), 5, 1)
+    want = float(g["c%d_loss" % ci])
+    assert abs(loss.item() - want) <= 5e-5 * abs(want)
+    assert np.allclose(items.cpu().numpy(), g["c%d_items" % ci], rtol=5e-5, atol=1e-6)
+    loss.backward()
+    gs, gd = g["c%d_gscores" % ci], g["c%d_gdistri" % ci]
+    assert np.abs(s.grad.cpu().numpy() - gs).max() <= 5e-4 * np.abs(gs).max()
+    assert np.abs(d.grad.cpu().numpy() - gd).max() <= 5e-4 * np.abs(gd).max()
+
+
+def test_task_aligned_assignment_matches_oracle():
+    """The ragged HIP assigner against the per-box oracle on a 640 x 640 grid (8400 anchors), images with 0 / few / many boxes."""
+    from oracle import maf_oracle as O
+    g = torch.Generator().manual_seed(9)
+    B, nc, size = 4, 80, 640
+    hw = [(80, 80), (40, 40), (20, 20)]
+    A = 8400
+    scores = torch.sigmoid(torch.randn(B, A, nc, generator=g) * 1.5 - 2.0)
+    pts, st = O.train_anchors(hw)
+    ltrb = torch.rand(B, A, 4, generator=g) * 6 + 0.5
+    boxes = torch.cat([pts / st - ltrb[..., :2], pts / st + ltrb[..., 2:]], -1) * st
+    rows = []
+    for b, n in enumerate([0, 3, 40, 12]):
+        for _ in range(n):
+            cx, cy = torch.rand(2, generator=g).tolist()
+            w, h = (torch.rand(2, generator=g) * 0.4 + 0.03).tolist()
+            rows.append([b, int(torch.randint(0, nc, (1,), generator=g)), cx, cy, w, h])
+    rows = [rows[i] for i in torch.randperm(len(rows), generator=g).tolist()]       # labels arrive in any order
+    targets = torch.tensor(rows, dtype=torch.float32)
+    labels, tb, ts, fg = M.task_aligned_assign(scores.to(DEV), boxes.to(DEV), pts.to(DEV).contiguous(), targets.to(DEV), B, size, nc)
+    for b in range(B):
+        r = targets[targets[:, 0] == b]
+        gts = torch.zeros(r.shape[0], 5)
+        if r.shape[0]:
+            xywh = r[:, 2:6] * size
+            gts[:, 0] = r[:, 1]; gts[:, 1:3] = xywh[:, :2] - xywh[:, 2:] / 2; gts[:, 3:5] = xywh[:, :2] + xywh[:, 2:] / 2
+        ol, ob, os_, ofg = O.tal_assign(scores[b], boxes[b], pts, gts, nc)
+        assert torch.equal(fg[b].cpu(), ofg), b
+        assert torch.equal(labels[b].cpu()[ofg], ol[ofg]) and torch.allclose(tb[b].cpu()[ofg], ob[ofg], atol=1e-4)
+        assert torch.allclose(ts[b].cpu(), os_, rtol=2e-4, atol=1e-7)

@@ -161,3 +161,24 @@ def test_post_nms_tail_oracle_matches_reference_fixture(golden):
         iid, cid, bb, sc = O.coco_rows(outs, shapes, g["c%d_image_ids" % ci], ids, bool(g["c%d_scale_exact" % ci]))
         assert np.array_equal(iid, g["c%d_out_image_id" % ci]) and np.array_equal(cid, g["c%d_out_category_id" % ci])
         assert np.array_equal(bb, g["c%d_out_bbox" % ci]) and np.array_equal(sc, g["c%d_out_score" % ci])
+
+
+def test_training_loss_oracle_matches_reference_fixture(golden):
+    """oracle.compute_loss (per-image, per-box task-aligned assignment + VFL/GIoU/DFL) == the reference's ComputeLoss on the
+    vectors of tools/make_golden_loss.py: loss, the three weighted items and the gradients w.r.t. both head outputs."""
+    g = golden("loss_cases")
+    for ci in range(4):
+        size = int(g["c%d_size" % ci])
+        hw = [(size // s, size // s) for s in (8, 16, 32)]
+        s = torch.from_numpy(g["c%d_scores" % ci]).requires_grad_(True)
+        d = torch.from_numpy(g["c%d_distri" % ci]).requires_grad_(True)
+        loss, items = O.compute_loss(hw, s, d, torch.from_numpy(g["c%d_targets" % ci]), img_size=size)
+        want = float(g["c%d_loss" % ci])
+        if not np.isfinite(want):                           # no ground truth in the whole batch: the reference divides by zero too
+            assert not np.isfinite(loss.item())
+            continue
+        assert abs(loss.item() - want) <= 2e-5 * abs(want)
+        assert np.allclose(items.numpy(), g["c%d_items" % ci], rtol=2e-5, atol=1e-6)
+        loss.backward()
+        gs, gd = g["c%d_gscores" % ci], g["c%d_gdistri" % ci]
+        assert np.abs(s.grad.numpy() - gs).max() <= 2e-4 * np.abs(gs).max() and np.abs(d.grad.numpy() - gd).max() <= 2e-4 * np.abs(gd).max()
