@@ -86,7 +86,8 @@ def latency_mode(args, torch, M, dev):
 
 def train_mode(args, torch, M, dev, rank, world, dist):
     """One step = forward (autocast fp16) + backward + DDP all-reduce + SGD step on a fixed synthetic batch per rank.
-    The loss is a surrogate that touches every head output (the reference's ComputeLoss is SURVEY.md §8 f2, out of scope)."""
+    The loss is the device-side ComputeLoss (HIP task-aligned assignment + VFL / GIoU / DFL) on synthetic labels,
+    7 boxes per image (the COCO average); --surrogate-loss swaps in a mean over the head outputs (the first rounds' measurement)."""
     from maf_yolo_amd import synth, train_ops
     import torch.nn.functional as F
     if args.torch_convs:                       # A/B: same module tree, convs through F.conv2d (MIOpen)
@@ -102,11 +103,20 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     scaler = torch.amp.GradScaler("cuda")
     B = args.batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255
+    g = torch.Generator().manual_seed(100 + rank)
+    nbox = 7 * B
+    wh = torch.rand(nbox, 2, generator=g) * 0.35 + 0.04
+    ctr = wh / 2 + torch.rand(nbox, 2, generator=g) * (1 - wh)
+    targets = torch.cat([torch.arange(B).repeat_interleave(7)[:, None].float(), torch.randint(0, 80, (nbox, 1), generator=g).float(), ctr, wh], 1).to(dev)
+    crit = M.ComputeLoss(ori_img_size=640)
 
     def step():
         with torch.autocast("cuda", dtype=torch.float16):
             (feats, cls, reg), _ = net(x)
-            loss = (cls.float().mean() + reg.float().pow(2).mean()) * world      # engine.py:161-162
+        if args.surrogate_loss:
+            loss = (cls.float().mean() + reg.float().pow(2).mean()) * world
+        else:
+            loss = crit((feats, cls, reg), targets, 0, 0)[0] * world            # engine.py:161-162 (loss scaled by the world size)
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward()
         scaler.step(opt)
@@ -134,7 +144,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
                           "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-                          "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, surrogate loss over all head outputs" % (args.scale, B),
+                          "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, %s" % (args.scale, B, "surrogate loss over all head outputs" if args.surrogate_loss else "ComputeLoss (HIP task-aligned assigner + VFL/GIoU/DFL), 7 boxes/image"),
                                      "global_batch": B * world, "parallelism": "ddp%d" % world,
                                      "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for 1x1 + depth-wise (fwd, dgrad, DW wgrad); 3x3 s2 + BN torch",
                                      "native_launches": dict(train_ops.stats), "final_loss": round(float(loss), 5)}}), flush=True)
@@ -159,6 +169,7 @@ def main():
                     help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
+    ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")

@@ -174,12 +174,27 @@ int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, 
 int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
 /* Task-aligned label assignment — replaces TaskAlignedAssigner.forward (yolov6/assigners/tal_assigner.py:21-151,
  * assigner_utils.py:25-89) as ComputeLoss calls it (yolov6/models/loss.py:96-103), on RAGGED targets: gts [T][5] = (label, x1, y1, x2, y2
- * in pixels) sorted by image, offsets [B+1] = first row of every image.  pd_scores [B,A,nc] (sigmoid outputs), pd_bboxes [B,A,4] xyxy
- * pixels, anchor_points [A,2] pixels.  out_gt [B,A] = row of the assigned box or -1 (background), out_norm [B,A] = the normalised
- * alignment metric that scales the one-hot score target (tal_assigner.py:66-71).  A <= 8400. */
-int maf_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* anchor_points, const float* gts, const int32_t* offsets,
-                   int32_t B, int32_t A, int32_t nc, int32_t topk, float alpha, float beta, float eps,
-                   int32_t* out_gt, float* out_norm, maf_stream_t stream);
+ * in pixels) sorted by image, gt_image [T] = image of every row, offsets [B+1] = first row of every image.  pd_scores [B,A,nc] (sigmoid
+ * outputs, score_dtype MAF_F16 / MAF_F32), pd_bboxes [B,A,4] xyxy pixels fp32, anchor_points [A,2] pixels.  cand_scratch: T*topk int32.
+ * out_gt [B,A] = row of the assigned box or -1 (background), out_norm [B,A] = the normalised alignment metric that scales the one-hot
+ * score target (tal_assigner.py:66-71).  A <= 8400; at most 8400 boxes per image are considered. */
+int maf_tal_assign(const void* pd_scores, int32_t score_dtype, const float* pd_bboxes, const float* anchor_points, const float* gts,
+                   const int32_t* gt_image, const int32_t* offsets, int32_t T, int32_t B, int32_t A, int32_t nc, int32_t topk,
+                   float alpha, float beta, float eps, int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream);
+/* The loss terms of ComputeLoss (yolov6/models/loss.py:56-267, task-aligned branch) from the assigner's two arrays; head outputs in
+ * `dtype` (MAF_F16 under autocast, or MAF_F32); reg_max must be 16; anchor_strides [A] = stride of every anchor.
+ *   maf_loss_decode  bbox_decode (:190-193) * stride: pred_distri [B,A,4*17] logits -> out_boxes [B,A,4] xyxy pixels fp32.
+ *   maf_loss_terms   VarifocalLoss (:196-206) over all scores + GIoU (figure_iou.py) and DFL (:209-267) over the foreground anchors.
+ *                    partials (may be NULL in the gradient form): maf_loss_partial_rows(B,A,nc) rows of float4 = per-workgroup sums of
+ *                    (cls, iou, dfl, target-score sum); the caller adds the rows; loss_x = sum_x / sum_tss.
+ *                    grad_scores / grad_distri (both or neither; same shape and dtype as the inputs): d(sum_k scale[k]*sum_k)/d input,
+ *                    scale = 3 device floats (upstream gradient * loss weight / sum_tss for cls, iou, dfl). */
+int64_t maf_loss_partial_rows(int32_t B, int32_t A, int32_t nc);
+int maf_loss_decode(const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides, int32_t B, int32_t A,
+                    int32_t reg_max, float* out_boxes, maf_stream_t stream);
+int maf_loss_terms(const void* pred_scores, const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides,
+                   const float* gts, const int32_t* assigned_gt, const float* norm, int32_t B, int32_t A, int32_t nc, int32_t reg_max,
+                   const float* scale, float* partials, void* grad_scores, void* grad_distri, maf_stream_t stream);
 
 /* BatchNorm2d in training mode fused with the activation behind it (Conv.forward = act(bn(conv(x))), common.py:46-47), NHWC views.
  *   maf_bn_forward   batch statistics -> save_mean / save_rstd (+ running stats with torch's momentum rule, unbiased variance; may be

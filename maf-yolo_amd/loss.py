@@ -8,7 +8,9 @@ box loss and Distribution Focal Loss over the targets of the task-aligned assign
   host sync every step); here they are sorted by image and bucketed with `bincount` / `cumsum`;
 * the assignment is one HIP kernel on the ragged boxes (csrc/tal_assign.hip) instead of dense [B, n_max, 8400] masks, `one_hot` of the
   top-k indices and the try/except that falls back to the CPU when those masks run out of memory (loss.py:82-149);
-* the loss terms themselves are differentiable torch ops on the device (autograd supplies the gradient into both head outputs).
+* the loss terms are three more kernels (csrc/loss_terms.hip): the box decode that feeds the assigner, and VariFocal / GIoU + DFL sums
+  with their gradients straight from the assigner's two per-anchor arrays — the [B,A,nc] one-hot labels and score targets of the
+  reference are never built.  `fused=False` keeps the terms as torch ops on the device (the A/B the kernels are tested against).
 
 The reference uses ATSS for the first `warmup_epoch` epochs (loss.py:83-91); this class uses the task-aligned assigner from the first
 step (pass warmup_epoch=0 to the reference to compare) — ATSS is the remaining piece of this row.
@@ -32,34 +34,87 @@ def _anchors(feats, strides, offset, device):
     return torch.cat(pts).contiguous(), torch.cat(st)
 
 
-def task_aligned_assign(pred_scores, pred_bboxes, anchor_points, targets, batch_size, img_size, num_classes=80, topk=13, alpha=1.0, beta=6.0):
-    """targets [T,6] = (image, class, cx, cy, w, h) normalised -> (target_labels [B,A] long, target_bboxes [B,A,4] pixels,
-    target_scores [B,A,nc], fg_mask [B,A] bool), all on the device, no synchronisation."""
-    dev = pred_scores.device
-    B, A, nc = pred_scores.shape
+def _targets_on_device(targets, batch_size, img_size, dev):
+    """loss.py:179-188 without the host: rows sorted by image, boxes as pixel xyxy, per-image offsets."""
     t = targets.to(dev, torch.float32)
-    order = torch.sort(t[:, 0], stable=True)[1] if t.shape[0] else torch.zeros(0, dtype=torch.long, device=dev)
-    t = t[order]
+    T = t.shape[0]
+    if T == 0:
+        return torch.zeros(1, 5, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(batch_size + 1, dtype=torch.int32, device=dev), 0
+    t = t[torch.sort(t[:, 0], stable=True)[1]]
     xywh = t[:, 2:6] * float(img_size)
     gts = torch.cat([t[:, 1:2], xywh[:, :2] - xywh[:, 2:] / 2, xywh[:, :2] + xywh[:, 2:] / 2], 1).contiguous()       # loss.py:186-187
-    counts = torch.bincount(t[:, 0].long(), minlength=batch_size)[:batch_size]
+    img = t[:, 0].int()
     offs = torch.zeros(batch_size + 1, dtype=torch.int32, device=dev)
-    offs[1:] = torch.cumsum(counts, 0).int()
-    if gts.shape[0] == 0:
-        gts = torch.zeros(1, 5, device=dev)                                    # never read (all counts are 0); keeps the pointer valid
+    offs[1:] = torch.cumsum(torch.bincount(img, minlength=batch_size)[:batch_size], 0)
+    return gts, img.contiguous(), offs, T
+
+
+def _assign(pred_scores, pred_bboxes, anchor_points, gts, gt_img, offs, T, topk, alpha, beta):
+    """csrc/tal_assign.hip -> (row of the assigned box or -1 [B,A] int32, normalised alignment metric [B,A] fp32)."""
+    dev = pred_scores.device
+    B, A, nc = pred_scores.shape
+    ps = pred_scores.detach()
+    if ps.dtype not in (torch.float16, torch.float32):
+        ps = ps.float()
+    ps = ps.contiguous()
+    pb = pred_bboxes.detach().float().contiguous()
     out_gt = torch.empty(B, A, dtype=torch.int32, device=dev)
     out_norm = torch.empty(B, A, dtype=torch.float32, device=dev)
-    ps = pred_scores.detach().float().contiguous()
-    pb = pred_bboxes.detach().float().contiguous()
-    lib.check(lib.load().maf_tal_assign(ps.data_ptr(), pb.data_ptr(), anchor_points.data_ptr(), gts.data_ptr(), offs.data_ptr(), B, A, nc, topk,
-                                        float(alpha), float(beta), 1e-9, out_gt.data_ptr(), out_norm.data_ptr(),
-                                        torch.cuda.current_stream(dev).cuda_stream))
+    cand = torch.empty(max(T, 1) * topk, dtype=torch.int32, device=dev)
+    lib.check(lib.load().maf_tal_assign(ps.data_ptr(), lib.F16 if ps.dtype == torch.float16 else lib.F32, pb.data_ptr(), anchor_points.data_ptr(),
+                                        gts.data_ptr(), gt_img.data_ptr(), offs.data_ptr(), T, B, A, nc, topk, float(alpha), float(beta), 1e-9,
+                                        cand.data_ptr(), out_gt.data_ptr(), out_norm.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return out_gt, out_norm
+
+
+def task_aligned_assign(pred_scores, pred_bboxes, anchor_points, targets, batch_size, img_size, num_classes=80, topk=13, alpha=1.0, beta=6.0):
+    """targets [T,6] = (image, class, cx, cy, w, h) normalised -> (target_labels [B,A] long, target_bboxes [B,A,4] pixels,
+    target_scores [B,A,nc], fg_mask [B,A] bool) as TaskAlignedAssigner.forward returns them, all on the device, no synchronisation.
+    (The fused loss never builds these; this is the reference-shaped view of the assigner's output.)"""
+    dev = pred_scores.device
+    gts, gt_img, offs, T = _targets_on_device(targets, batch_size, img_size, dev)
+    out_gt, out_norm = _assign(pred_scores, pred_bboxes, anchor_points, gts, gt_img, offs, T, topk, alpha, beta)
     fg = out_gt >= 0
     idx = out_gt.clamp(min=0).long()
     labels = gts[:, 0].long()[idx]
     boxes = gts[:, 1:][idx] * fg.unsqueeze(-1)
-    scores = F.one_hot(labels, nc).float() * (out_norm * fg).unsqueeze(-1)
+    scores = F.one_hot(labels, pred_scores.shape[-1]).float() * (out_norm * fg).unsqueeze(-1)
     return labels, boxes, scores, fg
+
+
+class _FusedTerms(torch.autograd.Function):
+    """(cls, iou, dfl) = sums of csrc/loss_terms.hip / target-score sum; backward re-runs the kernels in their gradient form with the
+    upstream gradient folded into three device scalars, and writes the gradients in the dtype of the head outputs."""
+
+    @staticmethod
+    def forward(ctx, scores, distri, pts, st, gts, out_gt, out_norm, reg_max):
+        B, A, nc = scores.shape
+        L = lib.load()
+        dt = lib.F16 if scores.dtype == torch.float16 else lib.F32
+        rows = L.maf_loss_partial_rows(B, A, nc)
+        part = torch.empty(rows, 4, dtype=torch.float32, device=scores.device)
+        lib.check(L.maf_loss_terms(scores.data_ptr(), distri.data_ptr(), dt, pts.data_ptr(), st.data_ptr(), gts.data_ptr(), out_gt.data_ptr(),
+                                   out_norm.data_ptr(), B, A, nc, reg_max, None, part.data_ptr(), None, None, torch.cuda.current_stream(scores.device).cuda_stream))
+        S = part.sum(0)
+        tss = S[3]
+        out = S[:3] / tss
+        out = torch.cat([out[:1], torch.where(tss > 0, out[1:], torch.zeros_like(out[1:]))])       # no foreground: BboxLoss returns zeros (loss.py:262-266)
+        ctx.save_for_backward(scores, distri, pts, st, gts, out_gt, out_norm, tss)
+        ctx.reg_max = reg_max
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, distri, pts, st, gts, out_gt, out_norm, tss = ctx.saved_tensors
+        B, A, nc = scores.shape
+        L = lib.load()
+        dt = lib.F16 if scores.dtype == torch.float16 else lib.F32
+        scale = (g.float() / tss).contiguous()
+        gs, gd = torch.empty_like(scores), torch.empty_like(distri)
+        lib.check(L.maf_loss_terms(scores.data_ptr(), distri.data_ptr(), dt, pts.data_ptr(), st.data_ptr(), gts.data_ptr(), out_gt.data_ptr(),
+                                   out_norm.data_ptr(), B, A, nc, ctx.reg_max, scale.data_ptr(), None, gs.data_ptr(), gd.data_ptr(),
+                                   torch.cuda.current_stream(scores.device).cuda_stream))
+        return gs, gd, None, None, None, None, None, None
 
 
 def _giou_loss(b1, b2, eps=1e-10):
@@ -74,12 +129,13 @@ def _giou_loss(b1, b2, eps=1e-10):
 
 class ComputeLoss:
     def __init__(self, fpn_strides=(8, 16, 32), grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, ori_img_size=640, warmup_epoch=0,
-                 use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None):
+                 use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None, fused=True):
         assert use_dfl and iou_type == "giou", "MAF-YOLO trains with DFL + GIoU (configs/MAF-YOLO-n.py:14-16)"
         self.fpn_strides, self.grid_cell_offset = tuple(fpn_strides), grid_cell_offset
         self.num_classes, self.ori_img_size, self.reg_max = num_classes, ori_img_size, reg_max
         self.loss_weight = loss_weight or {"class": 1.0, "iou": 2.5, "dfl": 0.5}
         self.topk, self.alpha, self.beta = 13, 1.0, 6.0                       # loss.py:46
+        self.fused = fused                     # False: same assigner kernels, loss terms as torch ops (the A/B the fused kernels are tested against)
         self._cache = {}
 
     def __call__(self, outputs, targets, epoch_num=0, step_num=0):
@@ -90,8 +146,30 @@ class ComputeLoss:
         B, A, nc = pred_scores.shape
         key = (tuple(tuple(f.shape[-2:]) for f in feats), dev.index)
         if key not in self._cache:
-            self._cache = {key: _anchors(feats, self.fpn_strides, self.grid_cell_offset, dev)}
-        pts, st = self._cache[key]
+            pts, st = _anchors(feats, self.fpn_strides, self.grid_cell_offset, dev)
+            self._cache = {key: (pts, st, st.reshape(-1).contiguous())}
+        pts, st, st_flat = self._cache[key]
+        gts, gt_img, offs, T = _targets_on_device(targets, B, self.ori_img_size, dev)
+        lw = self.loss_weight
+        if self.fused:
+            if pred_scores.dtype != pred_distri.dtype or pred_scores.dtype not in (torch.float16, torch.float32):
+                pred_scores, pred_distri = pred_scores.float(), pred_distri.float()
+            ps, pd = pred_scores.contiguous(), pred_distri.contiguous()
+            boxes = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
+            lib.check(lib.load().maf_loss_decode(pd.data_ptr(), lib.F16 if pd.dtype == torch.float16 else lib.F32, pts.data_ptr(), st_flat.data_ptr(),
+                                                 B, A, self.reg_max, boxes.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            out_gt, out_norm = _assign(ps, boxes, pts, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+            terms = _FusedTerms.apply(ps, pd, pts, st_flat, gts, out_gt, out_norm, self.reg_max)
+            loss_cls, loss_iou, loss_dfl = terms[0], terms[1], terms[2]
+        else:
+            loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, gts, gt_img, offs, T)
+        loss = lw["class"] * loss_cls + lw["iou"] * loss_iou + lw["dfl"] * loss_dfl
+        items = torch.stack([lw["iou"] * loss_iou, lw["dfl"] * loss_dfl, lw["class"] * loss_cls]).detach()
+        return loss, items
+
+    def _torch_terms(self, pred_scores, pred_distri, pts, st, gts, gt_img, offs, T):
+        dev = pred_scores.device
+        B, A, nc = pred_scores.shape
         pts_s = pts / st
         R = self.reg_max
         proj = torch.linspace(0, R, R + 1, device=dev)
@@ -99,25 +177,26 @@ class ComputeLoss:
         dist = F.softmax(pd, -1).matmul(proj)                                   # loss.py:190-193
         pred_bboxes = torch.cat([pts_s - dist[..., :2], pts_s + dist[..., 2:]], -1)
         ps = pred_scores.float()
-        labels, t_boxes, t_scores, fg = task_aligned_assign(ps, pred_bboxes * st, pts, targets, B, self.ori_img_size, nc, self.topk, self.alpha, self.beta)
-        t_boxes = t_boxes / st                                                  # loss.py:152
-        # VariFocal loss (loss.py:196-206); the one-hot of the assigned label is t_scores > 0 up to anchors whose norm is exactly 0
+        out_gt, out_norm = _assign(ps, pred_bboxes * st, pts, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+        fg = out_gt >= 0
+        idx = out_gt.clamp(min=0).long()
+        labels = gts[:, 0].long()[idx]
+        t_boxes = gts[:, 1:][idx] * fg.unsqueeze(-1) / st                       # loss.py:152
+        t_scores = F.one_hot(labels, nc).float() * (out_norm * fg).unsqueeze(-1)
+        # VariFocal loss (loss.py:196-206)
         one_hot = F.one_hot(torch.where(fg, labels, torch.full_like(labels, nc)), nc + 1)[..., :-1].float()
         w = 0.75 * ps.pow(2.0) * (1 - one_hot) + t_scores * one_hot             # the reference lets the gradient flow through the weight too
-        loss_cls = (F.binary_cross_entropy(ps, t_scores, reduction="none") * w).sum()
         tss = t_scores.sum()
-        loss_cls = loss_cls / tss
+        loss_cls = (F.binary_cross_entropy(ps, t_scores, reduction="none") * w).sum() / tss
         # box losses over the foreground anchors (loss.py:217-267), masked instead of gathered: no data-dependent shapes, no sync
         bw = t_scores.sum(-1) * fg
-        loss_iou = (_giou_loss(pred_bboxes, t_boxes) * bw).sum() / tss
+        zero = torch.zeros((), device=dev)
+        loss_iou = torch.where(tss > 0, (_giou_loss(pred_bboxes, t_boxes) * bw).sum() / tss, zero)     # no foreground: zeros (loss.py:262-266)
         ltrb = torch.cat([pts_s - t_boxes[..., :2], t_boxes[..., 2:] - pts_s], -1).clip(0, R - 0.01)
         tl = ltrb.long()
         wl = (tl + 1).float() - ltrb
         logp = F.log_softmax(pd, -1)
         ce_l = -logp.gather(-1, tl.unsqueeze(-1)).squeeze(-1)
         ce_r = -logp.gather(-1, (tl + 1).unsqueeze(-1)).squeeze(-1)
-        loss_dfl = ((ce_l * wl + ce_r * (1 - wl)).mean(-1) * bw).sum() / tss
-        lw = self.loss_weight
-        loss = lw["class"] * loss_cls + lw["iou"] * loss_iou + lw["dfl"] * loss_dfl
-        items = torch.stack([lw["iou"] * loss_iou, lw["dfl"] * loss_dfl, lw["class"] * loss_cls]).detach()
-        return loss, items
+        loss_dfl = torch.where(tss > 0, ((ce_l * wl + ce_r * (1 - wl)).mean(-1) * bw).sum() / tss, zero)
+        return loss_cls, loss_iou, loss_dfl

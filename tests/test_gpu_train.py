@@ -182,15 +182,16 @@ def _loss_case(golden_fn, ci):
     return g, size, hw
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("ci", [0, 1, 3])
-def test_compute_loss_matches_reference_fixture(golden, ci):
+def test_compute_loss_matches_reference_fixture(golden, ci, fused):
     """f2: device ComputeLoss (HIP task-aligned assignment on ragged labels + torch loss terms) == the reference's ComputeLoss
     (tools/make_golden_loss.py): loss, weighted items and the gradient into both head outputs."""
     g, size, hw = _loss_case(golden, ci)
     s = torch.from_numpy(g["c%d_scores" % ci]).to(DEV).requires_grad_(True)
     d = torch.from_numpy(g["c%d_distri" % ci]).to(DEV).requires_grad_(True)
     feats = [torch.zeros(s.shape[0], 8, h, w, device=DEV) for h, w in hw]
-    crit = M.ComputeLoss(ori_img_size=size)
+    crit = M.ComputeLoss(ori_img_size=size, fused=fused)
     loss, items = crit((feats, s, d), torch.from_numpy(g["c%d_targets" % ci]).to(DEV), 5, 1)
     want = float(g["c%d_loss" % ci])
     assert abs(loss.item() - want) <= 5e-5 * abs(want)
@@ -231,3 +232,43 @@ def test_task_aligned_assignment_matches_oracle():
         assert torch.equal(fg[b].cpu(), ofg), b
         assert torch.equal(labels[b].cpu()[ofg], ol[ofg]) and torch.allclose(tb[b].cpu()[ofg], ob[ofg], atol=1e-4)
         assert torch.allclose(ts[b].cpu(), os_, rtol=2e-4, atol=1e-7)
+
+
+def test_compute_loss_empty_batch_matches_reference_fixture(golden):
+    """No labels at all: the reference divides the classification sum by a zero target-score sum (inf) and BboxLoss returns zeros."""
+    g, size, hw = _loss_case(golden, 2)
+    assert g["c2_targets"].shape[0] == 0
+    s = torch.from_numpy(g["c2_scores"]).to(DEV)
+    d = torch.from_numpy(g["c2_distri"]).to(DEV)
+    feats = [torch.zeros(s.shape[0], 8, h, w, device=DEV) for h, w in hw]
+    for fused in (True, False):
+        loss, items = M.ComputeLoss(ori_img_size=size, fused=fused)((feats, s, d), torch.zeros(0, 6, device=DEV), 5, 1)
+        assert np.array_equal(np.isinf(items.cpu().numpy()), np.isinf(g["c2_items"])) and float(loss) == float(g["c2_loss"])
+        if fused:
+            assert items[0].item() == 0 and items[1].item() == 0
+
+
+@pytest.mark.parametrize("per_image", [7, 40])
+def test_fused_loss_fp16_head_outputs(per_image):
+    """The autocast case at the full size (32 x 8400 x 80 fp16 scores): fused kernels == torch-op terms on the same fp16 inputs, loss to
+    1e-4 and gradients to fp16 rounding, with the GradScaler-sized upstream gradient folded into the kernels' scale."""
+    g = torch.Generator().manual_seed(3)
+    B, A, nc = 32, 8400, 80
+    s16 = torch.sigmoid(torch.randn(B, A, nc, generator=g) * 1.5 - 3).half()
+    d16 = torch.randn(B, A, 68, generator=g).half()
+    n = per_image * B
+    wh = torch.rand(n, 2, generator=g) * 0.35 + 0.04
+    ctr = wh / 2 + torch.rand(n, 2, generator=g) * (1 - wh)
+    targets = torch.cat([torch.arange(B).repeat_interleave(per_image)[:, None].float(), torch.randint(0, nc, (n, 1), generator=g).float(), ctr, wh], 1).to(DEV)
+    feats = [torch.zeros(B, 8, k, k, device=DEV) for k in (80, 40, 20)]
+    res = []
+    for fused in (True, False):
+        s = s16.to(DEV).requires_grad_(True); d = d16.to(DEV).requires_grad_(True)
+        loss, items = M.ComputeLoss(fused=fused)((feats, s, d), targets, 0, 0)
+        (loss * 1024.0).backward()
+        assert s.grad.dtype == torch.float16 and d.grad.dtype == torch.float16
+        res.append((loss.item(), items.cpu().numpy(), s.grad.float().cpu().numpy(), d.grad.float().cpu().numpy()))
+    (l1, i1, gs1, gd1), (l0, i0, gs0, gd0) = res
+    assert abs(l1 - l0) <= 1e-4 * abs(l0) and np.allclose(i1, i0, rtol=1e-4)
+    assert np.abs(gs1 - gs0).max() <= 2e-3 * np.abs(gs0).max() and np.abs(gd1 - gd0).max() <= 2e-3 * np.abs(gd0).max()
+    assert np.count_nonzero(gd1) > 0 and np.array_equal(gd1.reshape(B, A, -1).any(-1), gd0.reshape(B, A, -1).any(-1))
