@@ -172,29 +172,38 @@ int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thr
 int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c);
 int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c, void* out, maf_stream_t stream);
 int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream);
-/* Task-aligned label assignment — replaces TaskAlignedAssigner.forward (yolov6/assigners/tal_assigner.py:21-151,
- * assigner_utils.py:25-89) as ComputeLoss calls it (yolov6/models/loss.py:96-103), on RAGGED targets: gts [T][5] = (label, x1, y1, x2, y2
- * in pixels) sorted by image, gt_image [T] = image of every row, offsets [B+1] = first row of every image.  pd_scores [B,A,nc] (sigmoid
- * outputs, score_dtype MAF_F16 / MAF_F32), pd_bboxes [B,A,4] xyxy pixels fp32, anchor_points [A,2] pixels.  cand_scratch: T*topk int32.
- * out_gt [B,A] = row of the assigned box or -1 (background), out_norm [B,A] = the normalised alignment metric that scales the one-hot
- * score target (tal_assigner.py:66-71).  A <= 8400; at most 8400 boxes per image are considered. */
+/* Task-aligned label assignment on RAGGED targets, no host round trip.
+ *   maf_tal_targets  replaces ComputeLoss.preprocess (yolov6/models/loss.py:179-188: python lists + targets.cpu().numpy()):
+ *                    targets [T][6] = (image, class, cx, cy, w, h) normalised -> gts [T][5] = (label, x1, y1, x2, y2 in pixels) grouped by
+ *                    image in their original order, gt_image [T], offsets [B+1] = first row of every image.  Rows whose image id is
+ *                    outside [0, B) are dropped (offsets[B] rows are valid).  T <= 16384, B <= 4096.
+ *   maf_tal_assign   replaces TaskAlignedAssigner.forward (yolov6/assigners/tal_assigner.py:21-151, assigner_utils.py:25-89) as
+ *                    ComputeLoss calls it (loss.py:96-103).  pd_scores [B,A,nc] (sigmoid outputs, score_dtype MAF_F16 / MAF_F32),
+ *                    pd_bboxes [B,A,4] xyxy pixels fp32, cand_scratch: T*topk int32.  Anchors: n_levels <= 4 grids, level_hw [n_levels][2]
+ *                    (host ints, rows x columns), level_stride [n_levels] (host floats), row-major per level, levels concatenated;
+ *                    anchor_points [A,2] (device) = (cell + cell_offset) * stride as generate_anchors builds them.  out_gt [B,A] = row of
+ *                    the assigned box or -1 (background), out_norm [B,A] = the normalised alignment metric that scales the one-hot
+ *                    score target (tal_assigner.py:66-71).  A <= 8400; at most 8400 boxes per image are considered. */
+int maf_tal_targets(const float* targets, int32_t T, int32_t B, float img_size, float* gts, int32_t* gt_image, int32_t* offsets, maf_stream_t stream);
 int maf_tal_assign(const void* pd_scores, int32_t score_dtype, const float* pd_bboxes, const float* anchor_points, const float* gts,
                    const int32_t* gt_image, const int32_t* offsets, int32_t T, int32_t B, int32_t A, int32_t nc, int32_t topk,
-                   float alpha, float beta, float eps, int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream);
+                   float alpha, float beta, float eps, int32_t n_levels, const int32_t* level_hw, const float* level_stride, float cell_offset,
+                   int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream);
 /* The loss terms of ComputeLoss (yolov6/models/loss.py:56-267, task-aligned branch) from the assigner's two arrays; head outputs in
  * `dtype` (MAF_F16 under autocast, or MAF_F32); reg_max must be 16; anchor_strides [A] = stride of every anchor.
  *   maf_loss_decode  bbox_decode (:190-193) * stride: pred_distri [B,A,4*17] logits -> out_boxes [B,A,4] xyxy pixels fp32.
  *   maf_loss_terms   VarifocalLoss (:196-206) over all scores + GIoU (figure_iou.py) and DFL (:209-267) over the foreground anchors.
- *                    partials (may be NULL in the gradient form): maf_loss_partial_rows(B,A,nc) rows of float4 = per-workgroup sums of
- *                    (cls, iou, dfl, target-score sum); the caller adds the rows; loss_x = sum_x / sum_tss.
- *                    grad_scores / grad_distri (both or neither; same shape and dtype as the inputs): d(sum_k scale[k]*sum_k)/d input,
- *                    scale = 3 device floats (upstream gradient * loss weight / sum_tss for cls, iou, dfl). */
+ *     forward form   (upstream, grad_* NULL): out[5] (device) = weighted total, w_iou*iou, w_dfl*dfl, w_cls*cls (the order of the
+ *                    reference's loss items), target-score sum; partials = scratch of maf_loss_partial_rows(B,A,nc) float4 rows.
+ *     gradient form  upstream = device scalar d(objective)/d(total); out = what the forward form wrote; grad_scores / grad_distri
+ *                    (shape and dtype of the inputs) receive d(objective)/d(input). */
 int64_t maf_loss_partial_rows(int32_t B, int32_t A, int32_t nc);
 int maf_loss_decode(const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides, int32_t B, int32_t A,
                     int32_t reg_max, float* out_boxes, maf_stream_t stream);
 int maf_loss_terms(const void* pred_scores, const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides,
                    const float* gts, const int32_t* assigned_gt, const float* norm, int32_t B, int32_t A, int32_t nc, int32_t reg_max,
-                   const float* scale, float* partials, void* grad_scores, void* grad_distri, maf_stream_t stream);
+                   float w_cls, float w_iou, float w_dfl, float* partials, float* out, const float* upstream, void* grad_scores,
+                   void* grad_distri, maf_stream_t stream);
 
 /* BatchNorm2d in training mode fused with the activation behind it (Conv.forward = act(bn(conv(x))), common.py:46-47), NHWC views.
  *   maf_bn_forward   batch statistics -> save_mean / save_rstd (+ running stats with torch's momentum rule, unbiased variance; may be

@@ -7,9 +7,10 @@
 //                        target of the reference are never built;
 //   loss_box_kernel      BboxLoss (:209-267) on the foreground anchors: GIoU loss (figure_iou.py, eps 1e-10) and Distribution Focal
 //                        Loss, both weighted by the anchor's target score.
-// Both term kernels come in a sums-only form (forward) and a form that also writes the gradient with respect to the head outputs,
-// scaled by scale[0..2] = upstream gradient * loss weight / target-score sum (device scalars: nothing is read back).  Sums leave as
-// one float4 per workgroup (cls, iou, dfl, target-score sum) which the host side adds up: deterministic, no atomics.
+//   loss_finish_kernel   adds the per-workgroup sums (deterministic, no atomics) -> out[5] = weighted total, the three weighted items
+//                        (iou, dfl, cls: the order ComputeLoss returns them in) and the target-score sum.
+// Both term kernels come in a sums-only form (forward) and a form that writes the gradient with respect to the head outputs, scaled
+// by upstream * loss weight / target-score sum read from device memory: nothing is ever read back to the host.
 #include "maf_common.h"
 
 namespace {
@@ -79,34 +80,47 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
     reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
 }
 
+// log / reciprocal on the transcendental unit (v_log_f32 * ln 2, v_rcp_f32: ~1 ulp each) — the sum over 21.5 M scores is VALU-bound
+// with the IEEE-exact library forms, and the tests pin the result to the reference at 5e-5 either way.
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+
 template <typename T, int VEC, bool GRAD>
 __global__ __launch_bounds__(kTB) void loss_cls_kernel(const T* __restrict__ scores, const float* __restrict__ gts, const int* __restrict__ agt,
-                                                       const float* __restrict__ norm, int nvec, int nc, const float* __restrict__ scale,
-                                                       float4* __restrict__ partials, T* __restrict__ grad) {
+                                                       const float* __restrict__ norm, int nvec, int nc, float w_cls, const float* __restrict__ upstream,
+                                                       const float* __restrict__ fwd_out, float4* __restrict__ partials, T* __restrict__ grad) {
     __shared__ float red[kTB / 64];
     float loss = 0.f;
-    const float sc = GRAD ? scale[0] : 0.f;
+    const float sc = GRAD ? upstream[0] * w_cls / fwd_out[4] : 0.f;
     for (int v = blockIdx.x * kTB + threadIdx.x; v < nvec; v += gridDim.x * kTB) {
         const int e0 = v * VEC;
         const int an = e0 / nc;
         const int c0 = e0 - an * nc;
         const int gi = agt[an];
-        const float t1 = norm[an];
-        const int label = gi >= 0 ? (int)gts[(size_t)gi * 5] : -1;
         float p[VEC], g[VEC];
         if (VEC == 8) load8<T>(scores + e0, p); else p[0] = (float)scores[e0];
+        // every score as a negative first (target 0, weight 0.75 p^2): loss = -0.75 p^2 log(1-p)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const bool y = c0 + i == label;
-            const float t = y ? t1 : 0.f;
-            const float l1 = fmaxf(logf(1.f - p[i]), -100.f);                    // F.binary_cross_entropy clamps its logs at -100
-            float bce = -(1.f - t) * l1;
-            if (y) bce -= t * fmaxf(logf(p[i]), -100.f);
-            const float w = y ? t : 0.75f * p[i] * p[i];
-            loss += bce * w;
-            if (GRAD) {
-                const float dbce = (p[i] - t) / fmaxf(p[i] * (1.f - p[i]), 1e-12f);
-                g[i] = (dbce * w + (y ? 0.f : bce * 1.5f * p[i])) * sc;
+            const float l1 = fmaxf(fast_log(1.f - p[i]), -100.f);                // F.binary_cross_entropy clamps its logs at -100
+            const float w = 0.75f * p[i] * p[i];
+            loss -= l1 * w;
+            if (GRAD) g[i] = (w * p[i] * __builtin_amdgcn_rcpf(fmaxf(p[i] * (1.f - p[i]), 1e-12f)) - 1.5f * p[i] * l1) * sc;
+        }
+        if (gi >= 0) {                                                            // foreground anchor (about 1 %): redo the score of its class
+            const int k = (int)gts[(size_t)gi * 5] - c0;
+            if (k >= 0 && k < VEC) {
+                float pk = p[0];
+#pragma unroll
+                for (int i = 1; i < VEC; ++i) pk = i == k ? p[i] : pk;
+                const float t = norm[an];
+                const float l1 = fmaxf(logf(1.f - pk), -100.f), l0 = fmaxf(logf(pk), -100.f);
+                loss += 0.75f * pk * pk * fmaxf(fast_log(1.f - pk), -100.f);     // take the negative's term back
+                loss += -(t * l0 + (1.f - t) * l1) * t;                          // BCE(p, t) * weight t
+                if (GRAD) {
+                    const float gk = (pk - t) / fmaxf(pk * (1.f - pk), 1e-12f) * t * sc;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] = i == k ? gk : g[i];
+                }
             }
         }
         if (GRAD) { if (VEC == 8) store8<T>(grad + e0, g); else grad[e0] = (T)g[0]; }
@@ -118,17 +132,37 @@ __global__ __launch_bounds__(kTB) void loss_cls_kernel(const T* __restrict__ sco
     if (threadIdx.x == 0) partials[blockIdx.x] = make_float4(red[0] + red[1] + red[2] + red[3], 0.f, 0.f, 0.f);
 }
 
+// adds the per-workgroup rows: out = (weighted total, w_iou * iou, w_dfl * dfl, w_cls * cls, target-score sum)
+__global__ __launch_bounds__(kTB) void loss_finish_kernel(const float4* __restrict__ partials, int rows, float w_cls, float w_iou, float w_dfl,
+                                                          float* __restrict__ out) {
+    __shared__ float red[kTB / 64][4];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = threadIdx.x; r < rows; r += kTB) { const float4 v = partials[r]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    a.x = wave_sum(a.x); a.y = wave_sum(a.y); a.z = wave_sum(a.z); a.w = wave_sum(a.w);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a.x; red[threadIdx.x >> 6][1] = a.y; red[threadIdx.x >> 6][2] = a.z; red[threadIdx.x >> 6][3] = a.w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4];
+        for (int c = 0; c < 4; ++c) t[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        const float tss = t[3];
+        const float cls = w_cls * (t[0] / tss);                                  // loss.py:162-163: divided even when the sum is 0 (inf)
+        const float iou = tss > 0.f ? w_iou * (t[1] / tss) : 0.f, dfl = tss > 0.f ? w_dfl * (t[2] / tss) : 0.f;   // no foreground: BboxLoss returns zeros (:262-266)
+        out[0] = cls + iou + dfl; out[1] = iou; out[2] = dfl; out[3] = cls; out[4] = tss;
+    }
+}
+
 // ---- box terms: one thread per (anchor, side); waves without a foreground anchor do no loads beyond the assignment
 template <typename T, bool GRAD>
 __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ distri, const float* __restrict__ pts, const float* __restrict__ st,
                                                        const float* __restrict__ gts, const int* __restrict__ agt, const float* __restrict__ norm,
-                                                       int NA, int A, const float* __restrict__ scale, float4* __restrict__ partials,
-                                                       T* __restrict__ grad) {
+                                                       int NA, int A, float w_iou, float w_dfl, const float* __restrict__ upstream,
+                                                       const float* __restrict__ fwd_out, float4* __restrict__ partials, T* __restrict__ grad) {
     __shared__ float red[kTB / 64][3];
     const int tid = threadIdx.x, lane = tid & 63, side = tid & 3;
-    const long long an = (long long)blockIdx.x * 64 + (tid >> 2);
-    const int gi = an < NA ? agt[an] : -1;
     float l_iou = 0.f, l_dfl = 0.f, l_tss = 0.f;
+    for (int tile = blockIdx.x; tile * 64 < NA; tile += gridDim.x) {
+    const long long an = (long long)tile * 64 + (tid >> 2);
+    const int gi = an < NA ? agt[an] : -1;
     if (__any(gi >= 0)) {
         const bool fg = gi >= 0;
         const long long ac = fg ? an : 0;                                        // background lanes compute on anchor 0 and drop the result
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ dis
             const float cw = fmaxf(x2, u2) - fminf(x1, u1), ch = fmaxf(y2, v2) - fminf(y1, v1);
             const float carea = cw * ch + eps;
             const float iou = inter / uni;
-            if (side == 0) { l_iou = (1.f - (iou - (carea - uni) / carea)) * bw; l_tss = bw; }
+            if (side == 0) { l_iou += (1.f - (iou - (carea - uni) / carea)) * bw; l_tss += bw; }
             // DFL of this side (loss.py:253-267): target distance, its two neighbouring bins
             float tgt = side == 0 ? px - u1 : side == 1 ? py - v1 : side == 2 ? u2 - px : v2 - py;
             tgt = fminf(fmaxf(tgt, 0.f), (float)(kR1 - 1) - 0.01f);
@@ -168,7 +202,7 @@ __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ dis
 #pragma unroll
             for (int k = 0; k < kR1; ++k) { el = k == tl ? e[k] : el; er = k == tl + 1 ? e[k] : er; }
             const float ce = -(wl * logf(el * inv) + wr * logf(er * inv));
-            l_dfl = ce * 0.25f * bw;
+            l_dfl += ce * 0.25f * bw;
             if (GRAD) {
                 // derivative of the GIoU loss with respect to this side's box coordinate (sub-gradients of min / max / clamp as autograd takes them)
                 const bool xs = (side & 1) == 0, lo = side < 2;
@@ -184,7 +218,8 @@ __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ dis
                 const float dcar = xs ? dc1 * ch : cw * dc1;
                 const float dL = -diou - (duni * carea - uni * dcar) / (carea * carea);
                 const float dd = lo ? -dL : dL;                                      // x1 = px - d0 ... x2 = px + d2
-                const float gi_ = scale[1] * bw * dd, gd_ = scale[2] * bw * 0.25f;
+                const float up = upstream[0] / fwd_out[4];
+                const float gi_ = up * w_iou * bw * dd, gd_ = up * w_dfl * bw * 0.25f;
                 T* go = grad + ((size_t)an * 4 + side) * kR1;
 #pragma unroll
                 for (int k = 0; k < kR1; ++k) {
@@ -194,6 +229,7 @@ __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ dis
             }
         }
     }
+    }
     if (partials == nullptr) return;
     l_iou = wave_sum(l_iou); l_dfl = wave_sum(l_dfl); l_tss = wave_sum(l_tss);
     if (lane == 0) { red[tid >> 6][0] = l_iou; red[tid >> 6][1] = l_dfl; red[tid >> 6][2] = l_tss; }
@@ -202,29 +238,29 @@ __global__ __launch_bounds__(kTB) void loss_box_kernel(const T* __restrict__ dis
                                                      red[0][2] + red[1][2] + red[2][2] + red[3][2]);
 }
 
-int cls_grid(long long nvec) { return (int)std::min<long long>((nvec + kTB - 1) / kTB, 4096); }
+int cls_grid(long long nvec) { return (int)std::min<long long>((nvec + kTB - 1) / kTB, 1024); }
 
 template <typename T>
 int launch_terms(const void* scores, const void* distri, const float* pts, const float* st, const float* gts, const int* agt, const float* norm,
-                 int B, int A, int nc, const float* scale, float* partials, void* gs, void* gd, hipStream_t s) {
+                 int B, int A, int nc, float wc, float wi, float wd, float* partials, float* out, const float* up, void* gs, void* gd, hipStream_t s) {
     const int NA = B * A;
-    const bool grad = gs != nullptr;
     const bool v8 = nc % 8 == 0;
     const int nvec = (int)((long long)NA * nc / (v8 ? 8 : 1));
-    const int g1 = cls_grid(nvec), g2 = (NA + 63) / 64;
+    const int g1 = cls_grid(nvec), g2 = std::min((NA + 63) / 64, 1024);
     float4* p1 = reinterpret_cast<float4*>(partials);
     float4* p2 = partials ? p1 + g1 : nullptr;
     const T* sc = static_cast<const T*>(scores); const T* di = static_cast<const T*>(distri);
-    if (grad) {
+    if (gs != nullptr) {
         const int rc = maf_check_hip(hipMemsetAsync(gd, 0, (size_t)NA * 4 * kR1 * sizeof(T), s), "loss_terms memset");   // the kernel writes the foreground rows only
         if (rc) return rc;
-        if (v8) hipLaunchKernelGGL((loss_cls_kernel<T, 8, true>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, scale, p1, static_cast<T*>(gs));
-        else hipLaunchKernelGGL((loss_cls_kernel<T, 1, true>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, scale, p1, static_cast<T*>(gs));
-        hipLaunchKernelGGL((loss_box_kernel<T, true>), dim3(g2), dim3(kTB), 0, s, di, pts, st, gts, agt, norm, NA, A, scale, p2, static_cast<T*>(gd));
+        if (v8) hipLaunchKernelGGL((loss_cls_kernel<T, 8, true>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, wc, up, out, (float4*)nullptr, static_cast<T*>(gs));
+        else hipLaunchKernelGGL((loss_cls_kernel<T, 1, true>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, wc, up, out, (float4*)nullptr, static_cast<T*>(gs));
+        hipLaunchKernelGGL((loss_box_kernel<T, true>), dim3(g2), dim3(kTB), 0, s, di, pts, st, gts, agt, norm, NA, A, wi, wd, up, out, (float4*)nullptr, static_cast<T*>(gd));
     } else {
-        if (v8) hipLaunchKernelGGL((loss_cls_kernel<T, 8, false>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, scale, p1, static_cast<T*>(nullptr));
-        else hipLaunchKernelGGL((loss_cls_kernel<T, 1, false>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, scale, p1, static_cast<T*>(nullptr));
-        hipLaunchKernelGGL((loss_box_kernel<T, false>), dim3(g2), dim3(kTB), 0, s, di, pts, st, gts, agt, norm, NA, A, scale, p2, static_cast<T*>(nullptr));
+        if (v8) hipLaunchKernelGGL((loss_cls_kernel<T, 8, false>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, wc, up, out, p1, static_cast<T*>(nullptr));
+        else hipLaunchKernelGGL((loss_cls_kernel<T, 1, false>), dim3(g1), dim3(kTB), 0, s, sc, gts, agt, norm, nvec, nc, wc, up, out, p1, static_cast<T*>(nullptr));
+        hipLaunchKernelGGL((loss_box_kernel<T, false>), dim3(g2), dim3(kTB), 0, s, di, pts, st, gts, agt, norm, NA, A, wi, wd, up, out, p2, static_cast<T*>(nullptr));
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kTB), 0, s, p1, g1 + g2, wc, wi, wd, out);
     }
     return maf_check_hip(hipGetLastError(), "loss_terms launch");
 }
@@ -233,7 +269,7 @@ int launch_terms(const void* scores, const void* distri, const float* pts, const
 
 extern "C" int64_t maf_loss_partial_rows(int32_t B, int32_t A, int32_t nc) {
     const long long NA = (long long)B * A;
-    return cls_grid(NA * nc / (nc % 8 == 0 ? 8 : 1)) + (NA + 63) / 64;
+    return cls_grid(NA * nc / (nc % 8 == 0 ? 8 : 1)) + std::min<long long>((NA + 63) / 64, 1024);
 }
 
 extern "C" int maf_loss_decode(const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides, int32_t B, int32_t A,
@@ -251,15 +287,16 @@ extern "C" int maf_loss_decode(const void* pred_distri, int32_t dtype, const flo
 
 extern "C" int maf_loss_terms(const void* pred_scores, const void* pred_distri, int32_t dtype, const float* anchor_points, const float* anchor_strides,
                               const float* gts, const int32_t* assigned_gt, const float* norm, int32_t B, int32_t A, int32_t nc, int32_t reg_max,
-                              const float* scale, float* partials, void* grad_scores, void* grad_distri, maf_stream_t stream) {
-    MAF_REQUIRE(pred_scores && pred_distri && anchor_points && anchor_strides && gts && assigned_gt && norm, "loss_terms: null pointer");
+                              float w_cls, float w_iou, float w_dfl, float* partials, float* out, const float* upstream, void* grad_scores,
+                              void* grad_distri, maf_stream_t stream) {
+    MAF_REQUIRE(pred_scores && pred_distri && anchor_points && anchor_strides && gts && assigned_gt && norm && out, "loss_terms: null pointer");
     MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "loss_terms: dtype must be f16 or f32");
     MAF_REQUIRE(reg_max == kR1 - 1, "loss_terms: reg_max must be 16");
     MAF_REQUIRE(B > 0 && A > 0 && nc > 0 && (long long)B * A * nc < (1ll << 31), "loss_terms: bad shape (B*A*nc must stay below 2^31)");
-    MAF_REQUIRE((grad_scores == nullptr) == (grad_distri == nullptr), "loss_terms: pass both gradient buffers or neither");
-    MAF_REQUIRE(grad_scores == nullptr || scale != nullptr, "loss_terms: the gradient form needs scale[3]");
-    MAF_REQUIRE(grad_scores != nullptr || partials != nullptr, "loss_terms: nothing to compute");
+    MAF_REQUIRE((grad_scores == nullptr) == (grad_distri == nullptr) && (grad_scores == nullptr) == (upstream == nullptr),
+                "loss_terms: the gradient form takes upstream + both gradient buffers, the forward form none of them");
+    MAF_REQUIRE(grad_scores != nullptr || partials != nullptr, "loss_terms: the forward form needs the partials scratch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == MAF_F16) return launch_terms<_Float16>(pred_scores, pred_distri, anchor_points, anchor_strides, gts, assigned_gt, norm, B, A, nc, scale, partials, grad_scores, grad_distri, s);
-    return launch_terms<float>(pred_scores, pred_distri, anchor_points, anchor_strides, gts, assigned_gt, norm, B, A, nc, scale, partials, grad_scores, grad_distri, s);
+    if (dtype == MAF_F16) return launch_terms<_Float16>(pred_scores, pred_distri, anchor_points, anchor_strides, gts, assigned_gt, norm, B, A, nc, w_cls, w_iou, w_dfl, partials, out, upstream, grad_scores, grad_distri, s);
+    return launch_terms<float>(pred_scores, pred_distri, anchor_points, anchor_strides, gts, assigned_gt, norm, B, A, nc, w_cls, w_iou, w_dfl, partials, out, upstream, grad_scores, grad_distri, s);
 }

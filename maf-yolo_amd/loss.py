@@ -5,7 +5,7 @@
 box loss and Distribution Focal Loss over the targets of the task-aligned assigner.  What differs is how it gets there:
 
 * labels stay on the device: the reference pads them per image through Python lists and `targets.cpu().numpy()` (loss.py:179-188, a
-  host sync every step); here they are sorted by image and bucketed with `bincount` / `cumsum`;
+  host sync every step); here one small kernel groups them by image and converts the boxes;
 * the assignment is one HIP kernel on the ragged boxes (csrc/tal_assign.hip) instead of dense [B, n_max, 8400] masks, `one_hot` of the
   top-k indices and the try/except that falls back to the CPU when those masks run out of memory (loss.py:82-149);
 * the loss terms are three more kernels (csrc/loss_terms.hip): the box decode that feeds the assigner, and VariFocal / GIoU + DFL sums
@@ -15,6 +15,8 @@ box loss and Distribution Focal Loss over the targets of the task-aligned assign
 The reference uses ATSS for the first `warmup_epoch` epochs (loss.py:83-91); this class uses the task-aligned assigner from the first
 step (pass warmup_epoch=0 to the reference to compare) — ATSS is the remaining piece of this row.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -35,21 +37,26 @@ def _anchors(feats, strides, offset, device):
 
 
 def _targets_on_device(targets, batch_size, img_size, dev):
-    """loss.py:179-188 without the host: rows sorted by image, boxes as pixel xyxy, per-image offsets."""
-    t = targets.to(dev, torch.float32)
+    """loss.py:179-188 without the host (csrc/tal_assign.hip tal_targets_kernel): rows grouped by image, boxes as pixel xyxy, offsets."""
+    t = targets.to(dev, torch.float32).contiguous()
     T = t.shape[0]
-    if T == 0:
-        return torch.zeros(1, 5, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(batch_size + 1, dtype=torch.int32, device=dev), 0
-    t = t[torch.sort(t[:, 0], stable=True)[1]]
-    xywh = t[:, 2:6] * float(img_size)
-    gts = torch.cat([t[:, 1:2], xywh[:, :2] - xywh[:, 2:] / 2, xywh[:, :2] + xywh[:, 2:] / 2], 1).contiguous()       # loss.py:186-187
-    img = t[:, 0].int()
-    offs = torch.zeros(batch_size + 1, dtype=torch.int32, device=dev)
-    offs[1:] = torch.cumsum(torch.bincount(img, minlength=batch_size)[:batch_size], 0)
-    return gts, img.contiguous(), offs, T
+    gts = (torch.empty if T else torch.zeros)(max(T, 1), 5, dtype=torch.float32, device=dev)     # T = 0: one all-zero row nobody is assigned to
+    gt_img = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
+    offs = torch.empty(batch_size + 1, dtype=torch.int32, device=dev)
+    lib.check(lib.load().maf_tal_targets(t.data_ptr(), T, batch_size, float(img_size), gts.data_ptr(), gt_img.data_ptr(), offs.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream))
+    return gts, gt_img, offs, T
 
 
-def _assign(pred_scores, pred_bboxes, anchor_points, gts, gt_img, offs, T, topk, alpha, beta):
+def _levels(level_hw, strides, offset):
+    """The anchor grids as the host arrays maf_tal_assign takes: (n, int32 [n][2], float [n], cell offset)."""
+    n = len(level_hw)
+    hw = (ctypes.c_int32 * (2 * n))(*[int(v) for p in level_hw for v in p])
+    st = (ctypes.c_float * n)(*[float(v) for v in strides])
+    return n, hw, st, float(offset)
+
+
+def _assign(pred_scores, pred_bboxes, anchor_points, levels, gts, gt_img, offs, T, topk, alpha, beta):
     """csrc/tal_assign.hip -> (row of the assigned box or -1 [B,A] int32, normalised alignment metric [B,A] fp32)."""
     dev = pred_scores.device
     B, A, nc = pred_scores.shape
@@ -63,17 +70,19 @@ def _assign(pred_scores, pred_bboxes, anchor_points, gts, gt_img, offs, T, topk,
     cand = torch.empty(max(T, 1) * topk, dtype=torch.int32, device=dev)
     lib.check(lib.load().maf_tal_assign(ps.data_ptr(), lib.F16 if ps.dtype == torch.float16 else lib.F32, pb.data_ptr(), anchor_points.data_ptr(),
                                         gts.data_ptr(), gt_img.data_ptr(), offs.data_ptr(), T, B, A, nc, topk, float(alpha), float(beta), 1e-9,
-                                        cand.data_ptr(), out_gt.data_ptr(), out_norm.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+                                        levels[0], ctypes.cast(levels[1], ctypes.c_void_p), ctypes.cast(levels[2], ctypes.c_void_p), levels[3], cand.data_ptr(), out_gt.data_ptr(), out_norm.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
     return out_gt, out_norm
 
 
-def task_aligned_assign(pred_scores, pred_bboxes, anchor_points, targets, batch_size, img_size, num_classes=80, topk=13, alpha=1.0, beta=6.0):
-    """targets [T,6] = (image, class, cx, cy, w, h) normalised -> (target_labels [B,A] long, target_bboxes [B,A,4] pixels,
+def task_aligned_assign(pred_scores, pred_bboxes, anchor_points, targets, batch_size, img_size, num_classes=80, topk=13, alpha=1.0, beta=6.0,
+                        level_hw=None, strides=(8, 16, 32), cell_offset=0.5):
+    """level_hw: (rows, columns) of every anchor grid (default: img_size / stride squares); targets [T,6] = (image, class, cx, cy, w, h) normalised -> (target_labels [B,A] long, target_bboxes [B,A,4] pixels,
     target_scores [B,A,nc], fg_mask [B,A] bool) as TaskAlignedAssigner.forward returns them, all on the device, no synchronisation.
     (The fused loss never builds these; this is the reference-shaped view of the assigner's output.)"""
     dev = pred_scores.device
     gts, gt_img, offs, T = _targets_on_device(targets, batch_size, img_size, dev)
-    out_gt, out_norm = _assign(pred_scores, pred_bboxes, anchor_points, gts, gt_img, offs, T, topk, alpha, beta)
+    level_hw = level_hw or [(int(img_size) // s, int(img_size) // s) for s in strides]
+    out_gt, out_norm = _assign(pred_scores, pred_bboxes, anchor_points, _levels(level_hw, strides, cell_offset), gts, gt_img, offs, T, topk, alpha, beta)
     fg = out_gt >= 0
     idx = out_gt.clamp(min=0).long()
     labels = gts[:, 0].long()[idx]
@@ -83,38 +92,36 @@ def task_aligned_assign(pred_scores, pred_bboxes, anchor_points, targets, batch_
 
 
 class _FusedTerms(torch.autograd.Function):
-    """(cls, iou, dfl) = sums of csrc/loss_terms.hip / target-score sum; backward re-runs the kernels in their gradient form with the
-    upstream gradient folded into three device scalars, and writes the gradients in the dtype of the head outputs."""
+    """out[5] = (weighted total, w_iou*iou, w_dfl*dfl, w_cls*cls, target-score sum) from csrc/loss_terms.hip; backward re-runs the kernels
+    in their gradient form with the upstream gradient read from device memory, and writes the gradients in the dtype of the head outputs."""
 
     @staticmethod
-    def forward(ctx, scores, distri, pts, st, gts, out_gt, out_norm, reg_max):
+    def forward(ctx, scores, distri, pts, st, gts, out_gt, out_norm, reg_max, weights):
         B, A, nc = scores.shape
         L = lib.load()
         dt = lib.F16 if scores.dtype == torch.float16 else lib.F32
-        rows = L.maf_loss_partial_rows(B, A, nc)
-        part = torch.empty(rows, 4, dtype=torch.float32, device=scores.device)
+        part = torch.empty(L.maf_loss_partial_rows(B, A, nc), 4, dtype=torch.float32, device=scores.device)
+        out = torch.empty(5, dtype=torch.float32, device=scores.device)
         lib.check(L.maf_loss_terms(scores.data_ptr(), distri.data_ptr(), dt, pts.data_ptr(), st.data_ptr(), gts.data_ptr(), out_gt.data_ptr(),
-                                   out_norm.data_ptr(), B, A, nc, reg_max, None, part.data_ptr(), None, None, torch.cuda.current_stream(scores.device).cuda_stream))
-        S = part.sum(0)
-        tss = S[3]
-        out = S[:3] / tss
-        out = torch.cat([out[:1], torch.where(tss > 0, out[1:], torch.zeros_like(out[1:]))])       # no foreground: BboxLoss returns zeros (loss.py:262-266)
-        ctx.save_for_backward(scores, distri, pts, st, gts, out_gt, out_norm, tss)
-        ctx.reg_max = reg_max
+                                   out_norm.data_ptr(), B, A, nc, reg_max, weights[0], weights[1], weights[2], part.data_ptr(), out.data_ptr(),
+                                   None, None, None, torch.cuda.current_stream(scores.device).cuda_stream))
+        ctx.save_for_backward(scores, distri, pts, st, gts, out_gt, out_norm, out)
+        ctx.reg_max, ctx.weights = reg_max, weights
         return out
 
     @staticmethod
     def backward(ctx, g):
-        scores, distri, pts, st, gts, out_gt, out_norm, tss = ctx.saved_tensors
+        scores, distri, pts, st, gts, out_gt, out_norm, out = ctx.saved_tensors
         B, A, nc = scores.shape
         L = lib.load()
         dt = lib.F16 if scores.dtype == torch.float16 else lib.F32
-        scale = (g.float() / tss).contiguous()
+        up = g[:1].float().contiguous()                      # only the total carries gradient: the items are reported detached (loss.py:173-176)
         gs, gd = torch.empty_like(scores), torch.empty_like(distri)
+        w = ctx.weights
         lib.check(L.maf_loss_terms(scores.data_ptr(), distri.data_ptr(), dt, pts.data_ptr(), st.data_ptr(), gts.data_ptr(), out_gt.data_ptr(),
-                                   out_norm.data_ptr(), B, A, nc, ctx.reg_max, scale.data_ptr(), None, gs.data_ptr(), gd.data_ptr(),
-                                   torch.cuda.current_stream(scores.device).cuda_stream))
-        return gs, gd, None, None, None, None, None, None
+                                   out_norm.data_ptr(), B, A, nc, ctx.reg_max, w[0], w[1], w[2], None, out.data_ptr(), up.data_ptr(),
+                                   gs.data_ptr(), gd.data_ptr(), torch.cuda.current_stream(scores.device).cuda_stream))
+        return gs, gd, None, None, None, None, None, None, None
 
 
 def _giou_loss(b1, b2, eps=1e-10):
@@ -147,8 +154,8 @@ class ComputeLoss:
         key = (tuple(tuple(f.shape[-2:]) for f in feats), dev.index)
         if key not in self._cache:
             pts, st = _anchors(feats, self.fpn_strides, self.grid_cell_offset, dev)
-            self._cache = {key: (pts, st, st.reshape(-1).contiguous())}
-        pts, st, st_flat = self._cache[key]
+            self._cache = {key: (pts, st, st.reshape(-1).contiguous(), _levels(key[0], self.fpn_strides, self.grid_cell_offset))}
+        pts, st, st_flat, levels = self._cache[key]
         gts, gt_img, offs, T = _targets_on_device(targets, B, self.ori_img_size, dev)
         lw = self.loss_weight
         if self.fused:
@@ -158,16 +165,15 @@ class ComputeLoss:
             boxes = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
             lib.check(lib.load().maf_loss_decode(pd.data_ptr(), lib.F16 if pd.dtype == torch.float16 else lib.F32, pts.data_ptr(), st_flat.data_ptr(),
                                                  B, A, self.reg_max, boxes.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-            out_gt, out_norm = _assign(ps, boxes, pts, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
-            terms = _FusedTerms.apply(ps, pd, pts, st_flat, gts, out_gt, out_norm, self.reg_max)
-            loss_cls, loss_iou, loss_dfl = terms[0], terms[1], terms[2]
-        else:
-            loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, gts, gt_img, offs, T)
+            out_gt, out_norm = _assign(ps, boxes, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+            out = _FusedTerms.apply(ps, pd, pts, st_flat, gts, out_gt, out_norm, self.reg_max, (float(lw["class"]), float(lw["iou"]), float(lw["dfl"])))
+            return out[0], out[1:4].detach()
+        loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T)
         loss = lw["class"] * loss_cls + lw["iou"] * loss_iou + lw["dfl"] * loss_dfl
         items = torch.stack([lw["iou"] * loss_iou, lw["dfl"] * loss_dfl, lw["class"] * loss_cls]).detach()
         return loss, items
 
-    def _torch_terms(self, pred_scores, pred_distri, pts, st, gts, gt_img, offs, T):
+    def _torch_terms(self, pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T):
         dev = pred_scores.device
         B, A, nc = pred_scores.shape
         pts_s = pts / st
@@ -177,7 +183,7 @@ class ComputeLoss:
         dist = F.softmax(pd, -1).matmul(proj)                                   # loss.py:190-193
         pred_bboxes = torch.cat([pts_s - dist[..., :2], pts_s + dist[..., 2:]], -1)
         ps = pred_scores.float()
-        out_gt, out_norm = _assign(ps, pred_bboxes * st, pts, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+        out_gt, out_norm = _assign(ps, pred_bboxes * st, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
         fg = out_gt >= 0
         idx = out_gt.clamp(min=0).long()
         labels = gts[:, 0].long()[idx]

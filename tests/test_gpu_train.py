@@ -219,6 +219,7 @@ def test_task_aligned_assignment_matches_oracle():
             cx, cy = torch.rand(2, generator=g).tolist()
             w, h = (torch.rand(2, generator=g) * 0.4 + 0.03).tolist()
             rows.append([b, int(torch.randint(0, nc, (1,), generator=g)), cx, cy, w, h])
+    rows += [[1, 3, 0.3, 0.6, 0.004, 0.005], [2, 5, 0.0065, 0.0065, 0.012, 0.012], [2, 7, 0.71, 0.2, 0.02, 0.001], [3, 1, 0.5, 0.5, 1.0, 1.0]]   # fewer than 13 anchors inside / the whole image
     rows = [rows[i] for i in torch.randperm(len(rows), generator=g).tolist()]       # labels arrive in any order
     targets = torch.tensor(rows, dtype=torch.float32)
     labels, tb, ts, fg = M.task_aligned_assign(scores.to(DEV), boxes.to(DEV), pts.to(DEV).contiguous(), targets.to(DEV), B, size, nc)

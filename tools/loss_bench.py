@@ -19,7 +19,8 @@ def main():
     dev = torch.device("cuda:0")
     B, A, nc = 32, 8400, 80
     g = torch.Generator().manual_seed(0)
-    for dt in (torch.float16, torch.float32):
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
+    for dt in ((torch.float16,) if only else (torch.float16, torch.float32)):
         scores = torch.sigmoid(torch.randn(B, A, nc, generator=g) * 1.5 - 3).to(dev, dt).requires_grad_(True)
         distri = (torch.randn(B, A, 68, generator=g)).to(dev, dt).requires_grad_(True)
         feats = [torch.zeros(B, 8, s, s, device=dev) for s in (80, 40, 20)]
@@ -27,8 +28,8 @@ def main():
         wh = torch.rand(n, 2, generator=g) * 0.35 + 0.04
         ctr = wh / 2 + torch.rand(n, 2, generator=g) * (1 - wh)
         targets = torch.cat([torch.arange(B).repeat_interleave(per)[:, None].float(), torch.randint(0, nc, (n, 1), generator=g).float(), ctr, wh], 1).to(dev)
-        for fused in ([False, True] if hasattr(loss_mod, "_FusedTerms") else [False]):
-            crit = M.ComputeLoss(ori_img_size=640, **({"fused": fused} if hasattr(loss_mod, "_FusedTerms") else {}))
+        for fused in ([True] if only else [False, True]):
+            crit = M.ComputeLoss(ori_img_size=640, fused=fused)
             def fwd():
                 return crit((feats, scores, distri), targets, 0, 0)[0]
             def fwdbwd():
@@ -40,6 +41,8 @@ def main():
             sc32 = scores.detach().float()
             def assign():
                 loss_mod.task_aligned_assign(sc32, boxes, pts, targets, B, 640, nc)
+            if only:
+                print("fwd+bwd %.0f us" % timeit(fwdbwd, 50)); continue
             print("%s fused=%s boxes/img=%d: assign(+gathers) %.0f us, loss fwd %.0f us, fwd+bwd %.0f us" % (dt, fused, per, timeit(assign), timeit(fwd), timeit(fwdbwd)), flush=True)
 
 main()
