@@ -189,6 +189,14 @@ int maf_tal_assign(const void* pd_scores, int32_t score_dtype, const float* pd_b
                    const int32_t* gt_image, const int32_t* offsets, int32_t T, int32_t B, int32_t A, int32_t nc, int32_t topk,
                    float alpha, float beta, float eps, int32_t n_levels, const int32_t* level_hw, const float* level_stride, float cell_offset,
                    int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream);
+/* The warm-up assigner of ComputeLoss (epoch < warmup_epoch, loss.py:83-91) — replaces ATSSAssigner.forward (yolov6/assigners/atss_assigner.py:17-161,
+ * iou2d_calculator.py:63-246, assigner_utils.py:4-66) on the same ragged targets and with the same outputs as maf_tal_assign:
+ * out_norm = IoU of the predicted box with the assigned box (the soft label, atss_assigner.py:80-84).  topk = 9 nearest anchors per
+ * level, cell_size = 5 (side of the square anchor boxes in strides, anchor_generator.py:29), cand_scratch: T * n_levels * topk int32;
+ * every level needs at least 3 x 3 anchors (the reference raises below 9 anchors on a level); box centres are expected inside the image. */
+int maf_atss_assign(const float* pd_bboxes, const float* anchor_points, const float* gts, const int32_t* gt_image, const int32_t* offsets,
+                    int32_t T, int32_t B, int32_t A, int32_t topk, int32_t n_levels, const int32_t* level_hw, const float* level_stride,
+                    float cell_offset, float cell_size, int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream);
 /* The loss terms of ComputeLoss (yolov6/models/loss.py:56-267, task-aligned branch) from the assigner's two arrays; head outputs in
  * `dtype` (MAF_F16 under autocast, or MAF_F32); reg_max must be 16; anchor_strides [A] = stride of every anchor.
  *   maf_loss_decode  bbox_decode (:190-193) * stride: pred_distri [B,A,4*17] logits -> out_boxes [B,A,4] xyxy pixels fp32.

@@ -39,6 +39,8 @@ struct TalArgs {
     float alpha, beta, eps;
     int nl, lbase[4], lw[4], lh[4];   // anchor levels: first anchor, grid width / height
     float lstride[4], loff;           // anchor centre = (cell + loff) * stride
+    int atss;                         // resolve kernel: 1 = ATSS rules (anchor-box IoU decides shared anchors, score target = IoU with the predicted box)
+    float half_cells;                 // ATSS: anchor box = centre -/+ half_cells * stride
 };
 
 template <typename T> __device__ __forceinline__ float score_at(const void* p, size_t i) { return (float)static_cast<const T*>(p)[i]; }
@@ -64,6 +66,21 @@ __device__ __forceinline__ float iou_box(float gx1, float gy1, float gx2, float 
     const float inter = ix * iy;
     const float a1 = fmaxf(gx2 - gx1, 0.f) * fmaxf(gy2 - gy1, 0.f), a2 = fmaxf(p.z - p.x, 0.f) * fmaxf(p.w - p.y, 0.f);
     return inter / (a1 + a2 - inter + eps);
+}
+
+// the square anchor box of anchor i (anchor_generator.py:29-38) and IoU as iou2d_calculator.bbox_overlaps computes it (eps 1e-6 as a floor of the union)
+__device__ __forceinline__ float4 anchor_box(const TalArgs& a, int i) {
+    const int l = (i >= a.lbase[1] && a.nl > 1) + (i >= a.lbase[2] && a.nl > 2) + (i >= a.lbase[3] && a.nl > 3);
+    const float s = l == 0 ? a.lstride[0] : l == 1 ? a.lstride[1] : l == 2 ? a.lstride[2] : a.lstride[3];
+    const float2 p = reinterpret_cast<const float2*>(a.points)[i];
+    const float h = a.half_cells * s;
+    return make_float4(p.x - h, p.y - h, p.x + h, p.y + h);
+}
+__device__ __forceinline__ float iou_anchor(float gx1, float gy1, float gx2, float gy2, const float4 p) {
+    const float a1 = (gx2 - gx1) * (gy2 - gy1), a2 = (p.z - p.x) * (p.w - p.y);
+    const float w = fmaxf(fminf(gx2, p.z) - fmaxf(gx1, p.x), 0.f), h = fmaxf(fminf(gy2, p.w) - fmaxf(gy1, p.y), 0.f);
+    const float inter = w * h;
+    return inter / fmaxf(a1 + a2 - inter, 1e-6f);
 }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -213,11 +230,12 @@ __global__ __launch_bounds__(kTR) void tal_resolve_kernel(const TalArgs a) {
     // anchors picked by several boxes go to the box with the largest IoU over ALL boxes of the image (first maximum).  Queue them and
     // give every thread one: they are a few per cent of the anchors, scattered over all waves.
     auto best_box = [&](int i) {
-        const float4 p = bx[i];
+        float4 p = bx[i];
+        if (a.atss) p = anchor_box(a, i);
         float best = -1.f; int g = 0;
         for (int j = 0; j < n; ++j) {
             const float* gt = j < kGtL ? gl + j * 5 : a.gts + (size_t)(g0 + j) * 5;
-            const float ov = iou_box(gt[1], gt[2], gt[3], gt[4], p, a.eps);
+            const float ov = a.atss ? iou_anchor(gt[1], gt[2], gt[3], gt[4], p) : iou_box(gt[1], gt[2], gt[3], gt[4], p, a.eps);
             if (ov > best) { best = ov; g = j; }
         }
         return g;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(kTR) void tal_resolve_kernel(const TalArgs a) {
         const float lab = n > 0 ? gt[0] : 0.f;
         gq[u][0] = gt[1]; gq[u][1] = gt[2]; gq[u][2] = gt[3]; gq[u][3] = gt[4];
         bb[u] = bx[i];
-        ss[u] = score_at<T>(a.scores, ((size_t)b * a.A + i) * a.nc + (on ? (int)lab : 0));
+        ss[u] = a.atss ? 1.f : score_at<T>(a.scores, ((size_t)b * a.A + i) * a.nc + (on ? (int)lab : 0));
     }
     __syncthreads();
 #pragma unroll
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(kTR) void tal_resolve_kernel(const TalArgs a) {
         const int g = my_gt[u];
         if (g < 0) continue;
         const float ov = iou_box(gq[u][0], gq[u][1], gq[u][2], gq[u][3], bb[u], a.eps);
-        const float m = pow_pos(ss[u], a.alpha) * pow_pos(ov, a.beta);
+        const float m = a.atss ? ov : pow_pos(ss[u], a.alpha) * pow_pos(ov, a.beta);
         my_m[u] = m; my_o[u] = ov;
         atomicMax(&max_m[g], __float_as_uint(m));                               // non-negative floats order like their bit patterns
         atomicMax(&max_o[g], __float_as_uint(ov));
@@ -271,7 +289,68 @@ __global__ __launch_bounds__(kTR) void tal_resolve_kernel(const TalArgs a) {
         const int i = tid + u * kTR, g = my_gt[u];
         if (i >= a.A) continue;
         a.out_gt[(size_t)b * a.A + i] = g < 0 ? -1 : g0 + g;
-        a.out_norm[(size_t)b * a.A + i] = g < 0 ? 0.f : my_m[u] * __uint_as_float(max_o[g]) / (__uint_as_float(max_m[g]) + a.eps);
+        a.out_norm[(size_t)b * a.A + i] = g < 0 ? 0.f : a.atss ? my_o[u] : my_m[u] * __uint_as_float(max_o[g]) / (__uint_as_float(max_m[g]) + a.eps);
+    }
+}
+
+// ATSS candidates (yolov6/assigners/atss_assigner.py:55-74, 89-137): per box the 9 anchors of every level nearest to its centre, the
+// threshold mean + std of their anchor-box IoUs, positives = candidates above it whose centre lies inside the box.  One workgroup per
+// box; the 9 nearest grid points of a level lie within 4 cells of the cell that holds the box centre, so a 9 x 9 window per level
+// (one thread per cell, 243 of the 256) replaces the reference's distance matrix and top-k over all anchors.  Equal distances: lowest
+// anchor first (torch.topk leaves that order open).
+constexpr int kAW = 9, kAS = kAW * kAW;
+__global__ __launch_bounds__(kTK) void atss_cand_kernel(const TalArgs a) {
+    __shared__ float sd[3 * kAS];
+    __shared__ int si[3 * kAS];
+    __shared__ float cov[32];
+    __shared__ float s_thr;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (g >= a.offs[a.B]) return;
+    const float* gt = a.gts + (size_t)g * 5;
+    const float gx1 = gt[1], gy1 = gt[2], gx2 = gt[3], gy2 = gt[4];
+    const bool gvalid = gx1 + gy1 + gx2 + gy2 > 0.f;                            // loss.py:77 mask_gt
+    const float gcx = (gx1 + gx2) / 2.0f, gcy = (gy1 + gy2) / 2.0f;
+    const int l = tid / kAS, slot = tid - l * kAS;
+    int i = -1; float d = 0.f; float4 ab = make_float4(0.f, 0.f, 0.f, 0.f); float acx = 0.f, acy = 0.f;
+    if (l < a.nl) {
+        const float s = a.lstride[l];
+        const int cx = min(max((int)floorf(gcx / s - a.loff + 0.5f), 0), a.lw[l] - 1), cy = min(max((int)floorf(gcy / s - a.loff + 0.5f), 0), a.lh[l] - 1);
+        const int x = cx + slot % kAW - kAW / 2, y = cy + slot / kAW - kAW / 2;
+        if (x >= 0 && x < a.lw[l] && y >= 0 && y < a.lh[l]) {
+            i = a.lbase[l] + y * a.lw[l] + x;
+            ab = anchor_box(a, i);
+            acx = (ab.x + ab.z) / 2.0f; acy = (ab.y + ab.w) / 2.0f;               // assigner_utils.py:17-20
+            const float dx = gcx - acx, dy = gcy - acy;
+            d = sqrtf(dx * dx + dy * dy);
+        }
+    }
+    if (tid < 3 * kAS) { sd[tid] = d; si[tid] = i; }
+    __syncthreads();
+    int pos = -1;
+    if (i >= 0) {
+        int rank = 0;
+        for (int q = l * kAS; q < (l + 1) * kAS; ++q) {
+            const int j = si[q];
+            rank += (j >= 0 && (sd[q] < d || (sd[q] == d && j < i))) ? 1 : 0;
+        }
+        if (rank < a.topk) pos = l * a.topk + rank;
+    }
+    const float ov = pos >= 0 ? iou_anchor(gx1, gy1, gx2, gy2, ab) : 0.f;
+    if (pos >= 0) cov[pos] = ov;
+    __syncthreads();
+    if (tid == 0) {
+        const int nc_ = a.nl * a.topk;
+        float sum = 0.f;
+        for (int k = 0; k < nc_; ++k) sum += cov[k];
+        const float mean = sum / (float)nc_;
+        float var = 0.f;
+        for (int k = 0; k < nc_; ++k) var += (cov[k] - mean) * (cov[k] - mean);
+        s_thr = mean + sqrtf(var / (float)(nc_ - 1));                              // torch.std: unbiased
+    }
+    __syncthreads();
+    if (pos >= 0) {
+        const float dmin = fminf(fminf(acx - gx1, acy - gy1), fminf(gx2 - acx, gy2 - acy));
+        a.cand[(size_t)g * a.nl * a.topk + pos] = (ov > s_thr && dmin > 1e-9f && gvalid) ? i : -1;
     }
 }
 
@@ -320,6 +399,43 @@ __global__ __launch_bounds__(kTR) void tal_targets_kernel(const float* __restric
 
 }  // namespace
 
+static int set_levels(TalArgs& a, int A, int n_levels, const int32_t* level_hw, const float* level_stride, float cell_offset) {
+    MAF_REQUIRE(n_levels >= 1 && n_levels <= 4 && level_hw && level_stride, "assign: 1..4 anchor levels");
+    int base = 0;
+    for (int l = 0; l < 4; ++l) {
+        a.lbase[l] = base; a.lh[l] = l < n_levels ? level_hw[2 * l] : 0; a.lw[l] = l < n_levels ? level_hw[2 * l + 1] : 0;
+        a.lstride[l] = l < n_levels ? level_stride[l] : 1.f;
+        MAF_REQUIRE(l >= n_levels || (a.lh[l] > 0 && a.lw[l] > 0 && a.lstride[l] > 0.f), "assign: bad level");
+        base += a.lh[l] * a.lw[l];
+    }
+    MAF_REQUIRE(base == A, "assign: the levels must add up to A anchors");
+    a.nl = n_levels; a.loff = cell_offset;
+    return 0;
+}
+
+extern "C" int maf_atss_assign(const float* pd_bboxes, const float* anchor_points, const float* gts, const int32_t* gt_image, const int32_t* offsets,
+                               int32_t T, int32_t B, int32_t A, int32_t topk, int32_t n_levels, const int32_t* level_hw, const float* level_stride,
+                               float cell_offset, float cell_size, int32_t* cand_scratch, int32_t* out_gt, float* out_norm, maf_stream_t stream) {
+    MAF_REQUIRE(pd_bboxes && anchor_points && offsets && out_gt && out_norm, "atss_assign: null pointer");
+    MAF_REQUIRE(T == 0 || (gts && gt_image && cand_scratch), "atss_assign: null target pointer");
+    MAF_REQUIRE(B > 0 && T >= 0 && A > 0 && A <= kMaxA && topk > 0 && topk <= 9 && n_levels <= 3, "atss_assign: bad shape (A <= 8400, topk <= 9, at most 3 levels)");
+    TalArgs a = {};
+    a.boxes = pd_bboxes; a.points = anchor_points; a.gts = gts; a.gt_img = gt_image; a.offs = offsets;
+    a.cand = cand_scratch; a.out_gt = out_gt; a.out_norm = out_norm;
+    a.A = A; a.nc = 1; a.B = B; a.alpha = 1.f; a.beta = 1.f; a.eps = 1e-9f;
+    const int rc = set_levels(a, A, n_levels, level_hw, level_stride, cell_offset);
+    if (rc) return rc;
+    for (int l = 0; l < n_levels; ++l)                                          // the reference raises below topk anchors on a level (atss_assigner.py:104)
+        MAF_REQUIRE(a.lh[l] >= 3 && a.lw[l] >= 3, "atss_assign: every level needs at least 3 x 3 anchors");
+    a.atss = 1; a.half_cells = cell_size * 0.5f;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    a.topk = topk;
+    if (T > 0) hipLaunchKernelGGL(atss_cand_kernel, dim3(T), dim3(kTK), 0, s, a);
+    a.topk = topk * n_levels;                                                   // candidates per box for the resolve kernel
+    hipLaunchKernelGGL(tal_resolve_kernel<float>, dim3(B), dim3(kTR), 0, s, a);
+    return maf_check_hip(hipGetLastError(), "atss_assign launch");
+}
+
 extern "C" int maf_tal_assign(const void* pd_scores, int32_t score_dtype, const float* pd_bboxes, const float* anchor_points, const float* gts,
                               const int32_t* gt_image, const int32_t* offsets, int32_t T, int32_t B, int32_t A, int32_t nc, int32_t topk,
                               float alpha, float beta, float eps, int32_t n_levels, const int32_t* level_hw, const float* level_stride,
@@ -332,17 +448,10 @@ extern "C" int maf_tal_assign(const void* pd_scores, int32_t score_dtype, const 
     a.scores = pd_scores; a.boxes = pd_bboxes; a.points = anchor_points; a.gts = gts; a.gt_img = gt_image; a.offs = offsets;
     a.cand = cand_scratch; a.out_gt = out_gt; a.out_norm = out_norm;
     a.A = A; a.nc = nc; a.topk = topk; a.B = B; a.alpha = alpha; a.beta = beta; a.eps = eps;
-    MAF_REQUIRE(n_levels >= 1 && n_levels <= 4 && level_hw && level_stride, "tal_assign: 1..4 anchor levels");
     MAF_REQUIRE(topk <= 32, "tal_assign: topk <= 32");
-    int base = 0;
-    for (int l = 0; l < 4; ++l) {
-        a.lbase[l] = base; a.lh[l] = l < n_levels ? level_hw[2 * l] : 0; a.lw[l] = l < n_levels ? level_hw[2 * l + 1] : 0;
-        a.lstride[l] = l < n_levels ? level_stride[l] : 1.f;
-        MAF_REQUIRE(l >= n_levels || (a.lh[l] > 0 && a.lw[l] > 0 && a.lstride[l] > 0.f), "tal_assign: bad level");
-        base += a.lh[l] * a.lw[l];
-    }
-    MAF_REQUIRE(base == A, "tal_assign: the levels must add up to A anchors");
-    a.nl = n_levels; a.loff = cell_offset;
+    const int rc = set_levels(a, A, n_levels, level_hw, level_stride, cell_offset);
+    if (rc) return rc;
+    a.atss = 0; a.half_cells = 0.f;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (score_dtype == MAF_F16) {
         if (T > 0) hipLaunchKernelGGL(tal_topk_kernel<_Float16>, dim3(T), dim3(kTK), 0, s, a);

@@ -12,8 +12,9 @@ box loss and Distribution Focal Loss over the targets of the task-aligned assign
   with their gradients straight from the assigner's two per-anchor arrays — the [B,A,nc] one-hot labels and score targets of the
   reference are never built.  `fused=False` keeps the terms as torch ops on the device (the A/B the kernels are tested against).
 
-The reference uses ATSS for the first `warmup_epoch` epochs (loss.py:83-91); this class uses the task-aligned assigner from the first
-step (pass warmup_epoch=0 to the reference to compare) — ATSS is the remaining piece of this row.
+Both assigners of the reference are here: ATSS for `epoch_num < warmup_epoch` (loss.py:83-91; csrc/tal_assign.hip atss_cand_kernel: the
+9 nearest anchors per level from a 9 x 9 window around the box centre instead of a distance matrix over all anchors) and the
+task-aligned assigner afterwards; they share the label preprocessing, the resolve kernel and the loss kernels.
 """
 import ctypes
 
@@ -71,6 +72,21 @@ def _assign(pred_scores, pred_bboxes, anchor_points, levels, gts, gt_img, offs, 
     lib.check(lib.load().maf_tal_assign(ps.data_ptr(), lib.F16 if ps.dtype == torch.float16 else lib.F32, pb.data_ptr(), anchor_points.data_ptr(),
                                         gts.data_ptr(), gt_img.data_ptr(), offs.data_ptr(), T, B, A, nc, topk, float(alpha), float(beta), 1e-9,
                                         levels[0], ctypes.cast(levels[1], ctypes.c_void_p), ctypes.cast(levels[2], ctypes.c_void_p), levels[3], cand.data_ptr(), out_gt.data_ptr(), out_norm.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return out_gt, out_norm
+
+
+def _assign_atss(pred_bboxes, anchor_points, levels, gts, gt_img, offs, T, topk=9, cell_size=5.0):
+    """csrc/tal_assign.hip atss_cand_kernel + resolve -> (row of the assigned box or -1, IoU of the predicted box with it)."""
+    dev = pred_bboxes.device
+    B, A = pred_bboxes.shape[:2]
+    pb = pred_bboxes.detach().float().contiguous()
+    out_gt = torch.empty(B, A, dtype=torch.int32, device=dev)
+    out_norm = torch.empty(B, A, dtype=torch.float32, device=dev)
+    cand = torch.empty(max(T, 1) * topk * levels[0], dtype=torch.int32, device=dev)
+    lib.check(lib.load().maf_atss_assign(pb.data_ptr(), anchor_points.data_ptr(), gts.data_ptr(), gt_img.data_ptr(), offs.data_ptr(), T, B, A, topk,
+                                         levels[0], ctypes.cast(levels[1], ctypes.c_void_p), ctypes.cast(levels[2], ctypes.c_void_p), levels[3],
+                                         float(cell_size), cand.data_ptr(), out_gt.data_ptr(), out_norm.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream))
     return out_gt, out_norm
 
 
@@ -137,8 +153,10 @@ def _giou_loss(b1, b2, eps=1e-10):
 class ComputeLoss:
     def __init__(self, fpn_strides=(8, 16, 32), grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, ori_img_size=640, warmup_epoch=0,
                  use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None, fused=True):
+        # warmup_epoch: the reference's default is 3 (loss.py:23) and the trainer does not override it (engine.py:303-308); pass 3 for the
+        # reference's schedule (ATSS for epochs 0-2, then task-aligned)
         assert use_dfl and iou_type == "giou", "MAF-YOLO trains with DFL + GIoU (configs/MAF-YOLO-n.py:14-16)"
-        self.fpn_strides, self.grid_cell_offset = tuple(fpn_strides), grid_cell_offset
+        self.fpn_strides, self.grid_cell_offset, self.grid_cell_size, self.warmup_epoch = tuple(fpn_strides), grid_cell_offset, grid_cell_size, warmup_epoch
         self.num_classes, self.ori_img_size, self.reg_max = num_classes, ori_img_size, reg_max
         self.loss_weight = loss_weight or {"class": 1.0, "iou": 2.5, "dfl": 0.5}
         self.topk, self.alpha, self.beta = 13, 1.0, 6.0                       # loss.py:46
@@ -165,15 +183,18 @@ class ComputeLoss:
             boxes = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
             lib.check(lib.load().maf_loss_decode(pd.data_ptr(), lib.F16 if pd.dtype == torch.float16 else lib.F32, pts.data_ptr(), st_flat.data_ptr(),
                                                  B, A, self.reg_max, boxes.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-            out_gt, out_norm = _assign(ps, boxes, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+            if epoch_num < self.warmup_epoch:                                   # loss.py:83-91
+                out_gt, out_norm = _assign_atss(boxes, pts, levels, gts, gt_img, offs, T, 9, self.grid_cell_size)
+            else:
+                out_gt, out_norm = _assign(ps, boxes, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
             out = _FusedTerms.apply(ps, pd, pts, st_flat, gts, out_gt, out_norm, self.reg_max, (float(lw["class"]), float(lw["iou"]), float(lw["dfl"])))
             return out[0], out[1:4].detach()
-        loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T)
+        loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T, epoch_num < self.warmup_epoch)
         loss = lw["class"] * loss_cls + lw["iou"] * loss_iou + lw["dfl"] * loss_dfl
         items = torch.stack([lw["iou"] * loss_iou, lw["dfl"] * loss_dfl, lw["class"] * loss_cls]).detach()
         return loss, items
 
-    def _torch_terms(self, pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T):
+    def _torch_terms(self, pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T, warmup):
         dev = pred_scores.device
         B, A, nc = pred_scores.shape
         pts_s = pts / st
@@ -183,7 +204,10 @@ class ComputeLoss:
         dist = F.softmax(pd, -1).matmul(proj)                                   # loss.py:190-193
         pred_bboxes = torch.cat([pts_s - dist[..., :2], pts_s + dist[..., 2:]], -1)
         ps = pred_scores.float()
-        out_gt, out_norm = _assign(ps, pred_bboxes * st, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+        if warmup:
+            out_gt, out_norm = _assign_atss(pred_bboxes * st, pts, levels, gts, gt_img, offs, T, 9, self.grid_cell_size)
+        else:
+            out_gt, out_norm = _assign(ps, pred_bboxes * st, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
         fg = out_gt >= 0
         idx = out_gt.clamp(min=0).long()
         labels = gts[:, 0].long()[idx]

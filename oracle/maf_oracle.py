@@ -678,6 +678,65 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gts, nc=80, topk=13, alpha=1.0,
     return t_labels, t_boxes, t_scores * norm[:, None], fg > 0
 
 
+def atss_assign(anchors, n_level, pd_bboxes, gts, nc=80, topk=9):
+    """ATSSAssigner.forward for one image (yolov6/assigners/atss_assigner.py:17-161), the warm-up assigner of ComputeLoss (loss.py:83-91).
+    anchors [A,4] = the 5-stride anchor boxes of generate_anchors (anchor_generator.py:27-51), n_level = anchors per level, pd_bboxes [A,4]
+    xyxy pixels, gts [n,5] = (label, x1,y1,x2,y2) pixels.  Per box: the `topk` anchors of every level nearest to its centre are candidates;
+    positives are the candidates whose IoU (anchor box vs box) exceeds mean + std of the candidates' IoUs and whose centre lies inside
+    the box; an anchor claimed by several boxes goes to the one with the largest anchor IoU; the score target is the IoU of the
+    PREDICTED box with the assigned box.  -> target_labels, target_bboxes, target_scores, fg."""
+    A = anchors.shape[0]
+    n = gts.shape[0]
+    if n == 0:
+        return torch.zeros(A, dtype=torch.long), torch.zeros(A, 4), torch.zeros(A, nc), torch.zeros(A, dtype=torch.bool)
+    labels = gts[:, 0].long()
+    gb = gts[:, 1:]
+    valid = (gb.sum(-1, keepdim=True) > 0).float()                                                 # loss.py:77 mask_gt
+    # iou2d_calculator.bbox_overlaps (iou2d_calculator.py:63-246), mode 'iou', eps 1e-6
+    area1 = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1]); area2 = (anchors[:, 2] - anchors[:, 0]) * (anchors[:, 3] - anchors[:, 1])
+    wh = (torch.min(gb[:, None, 2:], anchors[None, :, 2:]) - torch.max(gb[:, None, :2], anchors[None, :, :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    ov = inter / torch.max(area1[:, None] + area2[None] - inter, torch.tensor(1e-6))               # [n,A]
+    gc = torch.stack([(gb[:, 0] + gb[:, 2]) / 2.0, (gb[:, 1] + gb[:, 3]) / 2.0], 1)                # assigner_utils.py:4-23
+    ac = torch.stack([(anchors[:, 0] + anchors[:, 2]) / 2.0, (anchors[:, 1] + anchors[:, 3]) / 2.0], 1)
+    dist = (gc[:, None] - ac[None]).pow(2).sum(-1).sqrt()
+    in_cand = torch.zeros(n, A)
+    cand_idx = []
+    start = 0
+    for nl in n_level:                                                                             # atss_assigner.py:89-116
+        k = min(topk, nl)
+        idx = dist[:, start:start + nl].topk(k, dim=-1, largest=False)[1] + start
+        cand_idx.append(idx)
+        in_cand.scatter_(1, idx, 1.0)
+        start += nl
+    cand_idx = torch.cat(cand_idx, 1)
+    cand_ov = ov.gather(1, cand_idx)                                                               # atss_assigner.py:118-137
+    thr = cand_ov.mean(-1, keepdim=True) + cand_ov.std(-1, keepdim=True)
+    is_pos = torch.where(torch.where(in_cand > 0, ov, torch.zeros_like(ov)) > thr, in_cand, torch.zeros_like(in_cand))
+    d = torch.cat([ac[None] - gb[:, None, :2], gb[:, None, 2:] - ac[None]], -1)
+    in_gts = (d.min(-1)[0] > 1e-9).float()
+    mask_pos = is_pos * in_gts * valid
+    fg = mask_pos.sum(0)
+    multi = fg > 1                                                                                 # assigner_utils.py:46-66
+    if bool(multi.any()):
+        best = ov.argmax(0)
+        mask_pos[:, multi] = F.one_hot(best[multi], n).t().float()
+        fg = mask_pos.sum(0)
+    gt_idx = mask_pos.argmax(0)
+    t_labels = labels[gt_idx]
+    t_boxes = gb[gt_idx]
+    t_scores = F.one_hot(t_labels, nc).float() * (fg > 0).float()[:, None]
+    iou_pd = torch.stack([_pair_iou(gb[g], pd_bboxes) for g in range(n)]) * mask_pos              # atss_assigner.py:80-84
+    return t_labels, t_boxes, t_scores * iou_pd.max(0)[0][:, None], fg > 0
+
+
+def train_anchor_boxes(feat_hw, strides=(8, 16, 32), cell_size=5.0, offset=0.5):
+    """anchor_generator.py:27-38: the square anchor boxes (side cell_size * stride) ATSS measures IoU and centre distance with."""
+    pts, st = train_anchors(feat_hw, strides, offset)
+    half = cell_size * st * 0.5
+    return torch.cat([pts - half, pts + half], -1)
+
+
 def _giou_loss(b1, b2, eps=1e-10):
     """figure_iou.py IOUloss(box_format='xyxy', iou_type='giou', eps=1e-10): rows of b1/b2 [M,4] -> [M,1]."""
     x1, y1, x2, y2 = b1.split(1, -1); u1, v1, u2, v2 = b2.split(1, -1)
@@ -692,8 +751,8 @@ def _giou_loss(b1, b2, eps=1e-10):
 
 
 def compute_loss(feat_hw, pred_scores, pred_distri, targets, nc=80, img_size=640, reg_max=16, strides=(8, 16, 32),
-                 weights=(1.0, 2.5, 0.5), return_assignment=False):
-    """loss.py:56-193 with the task-aligned assigner.  pred_scores [B,A,nc] in (0,1), pred_distri [B,A,4*(reg_max+1)] logits, targets
+                 weights=(1.0, 2.5, 0.5), return_assignment=False, assigner="tal"):
+    """loss.py:56-193 with the task-aligned assigner (epochs >= warmup_epoch) or, assigner="atss", the warm-up assigner (loss.py:83-91).  pred_scores [B,A,nc] in (0,1), pred_distri [B,A,4*(reg_max+1)] logits, targets
     [T,6] = (image, class, cx, cy, w, h) normalised to the image.  -> (loss, [iou, dfl, cls] weighted items)."""
     B, A, _ = pred_scores.shape
     pts, st = train_anchors(feat_hw, strides)
@@ -711,7 +770,11 @@ def compute_loss(feat_hw, pred_scores, pred_distri, targets, nc=80, img_size=640
             g[:, 0] = rows[:, 1]
             g[:, 1] = xywh[:, 0] - xywh[:, 2] / 2; g[:, 2] = xywh[:, 1] - xywh[:, 3] / 2
             g[:, 3] = xywh[:, 0] + xywh[:, 2] / 2; g[:, 4] = xywh[:, 1] + xywh[:, 3] / 2
-        t_labels[b], t_boxes[b], t_scores[b], fg[b] = tal_assign(pred_scores[b].detach(), (pred_boxes[b] * st).detach(), pts, g, nc)
+        if assigner == "atss":
+            t_labels[b], t_boxes[b], t_scores[b], fg[b] = atss_assign(train_anchor_boxes(feat_hw, strides), [h * w for h, w in feat_hw],
+                                                                      (pred_boxes[b] * st).detach(), g, nc)
+        else:
+            t_labels[b], t_boxes[b], t_scores[b], fg[b] = tal_assign(pred_scores[b].detach(), (pred_boxes[b] * st).detach(), pts, g, nc)
     t_boxes = t_boxes / st                                                                          # loss.py:152
     lab = torch.where(fg, t_labels, torch.full_like(t_labels, nc))
     one_hot = F.one_hot(lab, nc + 1)[..., :-1].float()

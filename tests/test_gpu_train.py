@@ -273,3 +273,63 @@ def test_fused_loss_fp16_head_outputs(per_image):
     assert abs(l1 - l0) <= 1e-4 * abs(l0) and np.allclose(i1, i0, rtol=1e-4)
     assert np.abs(gs1 - gs0).max() <= 2e-3 * np.abs(gs0).max() and np.abs(gd1 - gd0).max() <= 2e-3 * np.abs(gd0).max()
     assert np.count_nonzero(gd1) > 0 and np.array_equal(gd1.reshape(B, A, -1).any(-1), gd0.reshape(B, A, -1).any(-1))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("ci", [1, 2, 3])
+def test_compute_loss_warmup_atss_matches_reference_fixture(golden, ci, fused):
+    """epoch < warmup_epoch: the ATSS kernels + loss kernels == the reference's ComputeLoss at epoch 0 (a* keys of the fixture)."""
+    g, size, hw = _loss_case(golden, ci)
+    s = torch.from_numpy(g["c%d_scores" % ci]).to(DEV).requires_grad_(True)
+    d = torch.from_numpy(g["c%d_distri" % ci]).to(DEV).requires_grad_(True)
+    feats = [torch.zeros(s.shape[0], 8, h, w, device=DEV) for h, w in hw]
+    crit = M.ComputeLoss(ori_img_size=size, warmup_epoch=3, fused=fused)
+    loss, items = crit((feats, s, d), torch.from_numpy(g["c%d_targets" % ci]).to(DEV), 0, 1)
+    want = float(g["a%d_loss" % ci])
+    if not np.isfinite(want):
+        assert not np.isfinite(loss.item()) and items[0].item() == 0 and items[1].item() == 0
+        return
+    assert abs(loss.item() - want) <= 5e-5 * abs(want)
+    assert np.allclose(items.cpu().numpy(), g["a%d_items" % ci], rtol=5e-5, atol=1e-6)
+    loss.backward()
+    gs, gd = g["a%d_gscores" % ci].astype(np.float32), g["a%d_gdistri" % ci]
+    assert np.abs(s.grad.cpu().numpy() - gs).max() <= 1e-3 * np.abs(gs).max()
+    assert np.abs(d.grad.cpu().numpy() - gd).max() <= 5e-4 * np.abs(gd).max()
+
+
+def test_atss_assignment_matches_oracle():
+    """ATSS on a 640 x 640 grid against the per-box oracle: images with 0 / few / many boxes, boxes near the border and tiny boxes."""
+    from oracle import maf_oracle as O
+    loss_mod = __import__("importlib").import_module("maf-yolo_amd.loss")
+    g = torch.Generator().manual_seed(19)
+    B, nc, size = 4, 80, 640
+    hw = [(80, 80), (40, 40), (20, 20)]
+    A = 8400
+    pts, st = O.train_anchors(hw)
+    ltrb = torch.rand(B, A, 4, generator=g) * 6 + 0.5
+    boxes = torch.cat([pts / st - ltrb[..., :2], pts / st + ltrb[..., 2:]], -1) * st
+    rows = []
+    for b, n in enumerate([0, 3, 40, 12]):
+        for _ in range(n):
+            cx, cy = torch.rand(2, generator=g).tolist()
+            w, h = (torch.rand(2, generator=g) * 0.4 + 0.03).tolist()
+            rows.append([b, int(torch.randint(0, nc, (1,), generator=g)), cx, cy, w, h])
+    rows += [[1, 3, 0.3, 0.6, 0.004, 0.005], [2, 5, 0.0065, 0.0065, 0.012, 0.012], [2, 7, 0.99, 0.2, 0.02, 0.3], [3, 1, 0.5031, 0.4973, 0.99, 0.99], [3, 2, 0.01, 0.99, 0.02, 0.02]]   # (a centre exactly on a cell corner ties distances: order open in torch.topk)
+    rows = [rows[i] for i in torch.randperm(len(rows), generator=g).tolist()]
+    targets = torch.tensor(rows, dtype=torch.float32)
+    gts, gt_img, offs, T = loss_mod._targets_on_device(targets.to(DEV), B, size, DEV)
+    out_gt, out_norm = loss_mod._assign_atss(boxes.to(DEV), pts.to(DEV).contiguous(), loss_mod._levels(hw, (8, 16, 32), 0.5), gts, gt_img, offs, T)
+    anchors = O.train_anchor_boxes(hw)
+    gts_c, out_gt, out_norm = gts.cpu(), out_gt.cpu(), out_norm.cpu()
+    for b in range(B):
+        r = targets[targets[:, 0] == b]
+        gt5 = torch.zeros(r.shape[0], 5)
+        if r.shape[0]:
+            xywh = r[:, 2:6] * size
+            gt5[:, 0] = r[:, 1]; gt5[:, 1:3] = xywh[:, :2] - xywh[:, 2:] / 2; gt5[:, 3:5] = xywh[:, :2] + xywh[:, 2:] / 2
+        ol, ob, os_, ofg = O.atss_assign(anchors, [h * w for h, w in hw], boxes[b], gt5, nc)
+        fg = out_gt[b] >= 0
+        assert torch.equal(fg, ofg), (b, int(fg.sum()), int(ofg.sum()))
+        idx = out_gt[b][fg].long()
+        assert torch.equal(gts_c[idx, 0].long(), ol[ofg]) and torch.allclose(gts_c[idx, 1:], ob[ofg], atol=1e-4)
+        assert torch.allclose(out_norm[b], os_.sum(-1), rtol=2e-4, atol=1e-7)

@@ -182,3 +182,23 @@ def test_training_loss_oracle_matches_reference_fixture(golden):
         loss.backward()
         gs, gd = g["c%d_gscores" % ci], g["c%d_gdistri" % ci]
         assert np.abs(s.grad.numpy() - gs).max() <= 2e-4 * np.abs(gs).max() and np.abs(d.grad.numpy() - gd).max() <= 2e-4 * np.abs(gd).max()
+
+
+def test_training_loss_oracle_atss_matches_reference_fixture(golden):
+    """The warm-up branch (ATSS, epoch < warmup_epoch) of ComputeLoss: oracle.compute_loss(assigner="atss") == the reference at epoch 0."""
+    g = golden("loss_cases")
+    for ci in range(1, 4):                  # case 0 (64 x 64: 4 anchors on the last level) makes the reference's ATSS raise
+        size = int(g["c%d_size" % ci])
+        hw = [(size // s, size // s) for s in (8, 16, 32)]
+        s = torch.from_numpy(g["c%d_scores" % ci]).requires_grad_(True)
+        d = torch.from_numpy(g["c%d_distri" % ci]).requires_grad_(True)
+        loss, items = O.compute_loss(hw, s, d, torch.from_numpy(g["c%d_targets" % ci]), img_size=size, assigner="atss")
+        want = float(g["a%d_loss" % ci])
+        if not np.isfinite(want):
+            assert not np.isfinite(loss.item())
+            continue
+        assert abs(loss.item() - want) <= 2e-5 * abs(want)
+        assert np.allclose(items.numpy(), g["a%d_items" % ci], rtol=2e-5, atol=1e-6)
+        loss.backward()
+        gs, gd = g["a%d_gscores" % ci].astype(np.float32), g["a%d_gdistri" % ci]
+        assert np.abs(s.grad.numpy() - gs).max() <= 1e-3 * np.abs(gs).max() and np.abs(d.grad.numpy() - gd).max() <= 2e-4 * np.abs(gd).max()

@@ -1,5 +1,5 @@
 """Golden vectors for the training loss: the reference's own ComputeLoss (yolov6/models/loss.py) with its
-TaskAlignedAssigner, run here in the build container on seeded head outputs and labels.
+TaskAlignedAssigner (c* keys) and with its warm-up ATSSAssigner (a* keys), run here in the build container on seeded head outputs and labels.
 
     python tools/make_golden_loss.py    ->  tests/golden/loss_cases.npz
 
@@ -55,6 +55,18 @@ def main():
         blob["c%d_gscores" % ci] = s.grad.numpy() if s.grad is not None else np.zeros(0)
         blob["c%d_gdistri" % ci] = d.grad.numpy() if d.grad is not None else np.zeros(0)
         print("case", ci, "loss", loss.item(), items.tolist())
+        # the same inputs through the warm-up assigner: ComputeLoss's default warmup_epoch = 3 is what the trainer uses (engine.py:303-308), epoch 0
+        if min(h * w for h, w in hw) < 9:
+            continue                       # the reference's ATSS raises when a level has fewer than topk = 9 anchors (atss_assigner.py:104)
+        crit = ComputeLoss(num_classes=80, ori_img_size=size, use_dfl=True, reg_max=16, iou_type="giou")
+        s = scores.clone().requires_grad_(True); d = distri.clone().requires_grad_(True)
+        loss, items = crit((feats, s, d), targets.clone(), 0, 1)
+        if torch.isfinite(loss):
+            loss.backward()
+        blob["a%d_loss" % ci] = np.asarray(loss.item()); blob["a%d_items" % ci] = items.numpy()
+        blob["a%d_gscores" % ci] = s.grad.numpy().astype(np.float16) if s.grad is not None else np.zeros(0)
+        blob["a%d_gdistri" % ci] = d.grad.numpy() if d.grad is not None else np.zeros(0)
+        print("case", ci, "ATSS loss", loss.item(), items.tolist())
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "loss_cases.npz"), **blob)
 
 
