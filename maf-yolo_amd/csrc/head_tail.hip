@@ -1,0 +1,205 @@
+// MAF_OP_HEADTAIL: the tail of one detection level in ONE launch — for both branches of Head_DepthUni (yolov6/layers/common.py:1288-1336)
+//   cls:  cls_conv_s (1x1 + SiLU)  ->  cls_pred (1x1)  ->  sigmoid                    -> columns 5.. of the prediction rows
+//   reg:  reg_conv_s (1x1 + SiLU)  ->  reg_pred (1x1)  ->  DFL softmax expectation, dist2bbox('xywh'), x stride, objectness 1
+//                                                                                       -> columns 0..4
+// i.e. Conv.forward_fuse x2 + the level's share of the Detect_yaml eval branch (yolov6/models/yolo.py:355-396).  Replaces four
+// MAF_OP_CONV1X1 launches per level and the level's part of MAF_OP_DECODE; the 128-channel mid activations and the fp32 logits never
+// reach HBM (per anchor: 2*C fp16 read + 85 fp32 written, instead of 2*C + 4*C + 2*148*4 + 85*4 bytes).
+//
+// Both GEMMs run on the matrix cores without a transposition in between: the first one is computed transposed (A = weight fragments,
+// B = 16 pixels x 32 input channels = ONE 16-byte load per lane), so a lane ends up holding, for its pixel, channels 16t + 4G + r of every
+// 16-channel tile t — which IS the A-operand layout (pixel row, 8 consecutive k-slots per lane) of the second GEMM once the second
+// weight matrix is packed with its K axis in that order (maf-yolo_amd/pack.py:pack_head_tail).  Weights of a branch sit in LDS for the
+// whole workgroup; the epilogue goes through a wave-private LDS tile so the prediction rows are written as full contiguous runs.
+#include "maf_common.h"
+
+namespace {
+
+constexpr int NT2 = 5;                 // 80 output columns of the second GEMM (80 classes; 68 DFL logits + zero padding)
+constexpr int NO = 85, NC = 80, NR = 68;
+
+struct HtArgs {
+    const half_t* x[2];                // [M][xs] fp16, first channel xc: input of cls_conv_s / reg_conv_s
+    int xs[2], xc[2];
+    const char* rec[2];                // weight records (pack_head_tail)
+    float* out;                        // pred [B][A][85]
+    int M, HW, Wd, A, lvl_off, iters;  // pixels of the level (B*H*W), H*W, grid width, anchors per image, first anchor of the level
+    float stride;
+};
+
+template <int C, int PT>
+__global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const HtArgs a) {
+    constexpr int KS = C / 32, T1 = C / 16;
+    constexpr int W1B = C * C * 2, W2B = 80 * C * 2;
+    __shared__ __attribute__((aligned(16))) char s_w[W1B + W2B + C * 4 + 80 * 4];
+    __shared__ __attribute__((aligned(16))) float s_stage[4][16 * NC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, n = lane & 15;
+    const int br = blockIdx.y;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.rec[br]);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        constexpr int NV = (W1B + W2B + C * 4 + 80 * 4) / 16;
+        for (int i = tid; i < NV; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const half8_t* w1 = reinterpret_cast<const half8_t*>(s_w);
+    const half8_t* w2 = reinterpret_cast<const half8_t*>(s_w + W1B);
+    const f32x4_t* b1 = reinterpret_cast<const f32x4_t*>(s_w + W1B + W2B);
+    const float* b2 = reinterpret_cast<const float*>(s_w + W1B + W2B + C * 4);
+    float bias2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) bias2[t] = b2[16 * t + n];
+    const half_t* xb = a.x[br] + a.xc[br] + 8 * G;
+    const int xs = a.xs[br];
+    float* stage = s_stage[wave];
+
+    half8_t x[PT][KS];
+    auto load_x = [&](int unit) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = min((unit * PT + p) * 16 + n, a.M - 1);                // clamped: loads stay unconditional
+            const half_t* px = xb + (size_t)m * xs;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) x[p][ks] = *reinterpret_cast<const half8_t*>(px + 32 * ks);
+        }
+    };
+    const int unit0 = blockIdx.x * a.iters * 4 + wave;
+    load_x(unit0);
+    for (int it = 0; it < a.iters; ++it) {
+        const int unit = unit0 + it * 4;
+        // ---- GEMM 1 (transposed): acc1[p][t] lane (G, n) = channels 16t + 4G + r of pixel n
+        f32x4_t acc1[PT][T1];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int t = 0; t < T1; ++t) acc1[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8_t wa = w1[(t * KS + ks) * 64 + lane];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc1[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc1[p][t], 0, 0, 0);
+            }
+        if (it + 1 < a.iters) load_x(unit + 4);                                   // next unit's activations fly during the rest
+        // ---- bias + SiLU -> fp16: the A fragments of GEMM 2 (k-slots q < 4 from tile 2j, q >= 4 from tile 2j + 1)
+        half8_t a2[PT][KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const f32x4_t bl = b1[4 * (2 * j) + G], bh = b1[4 * (2 * j + 1) + G];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a2[p][j][r] = (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j][r] + bl[r]);
+                    a2[p][j][4 + r] = (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j + 1][r] + bh[r]);
+                }
+            }
+        }
+        // ---- GEMM 2: acc2[p][t2] lane (G, n) = pixels 4G + r, output column 16 t2 + n
+        f32x4_t acc2[PT][NT2];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) acc2[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const half8_t wb = w2[(t * KS + j) * 64 + lane];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
+            }
+        // ---- epilogue: through the wave's LDS tile to whole prediction rows
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m0 = (unit * PT + p) * 16;
+            __syncthreads();                                                      // the tile is free again (uniform trip counts)
+            if (br == 0) {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[(4 * G + r) * NC + 16 * t + n] = maf_act<MAF_ACT_SIGMOID>(acc2[p][t][r] + bias2[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t)
+                    if (16 * t + n < NR) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(4 * G + r) * NR + 16 * t + n] = acc2[p][t][r] + bias2[t];
+                    }
+            }
+            __syncthreads();
+            if (br == 0) {
+#pragma unroll
+                for (int q = 0; q < 16 * NC / 64; ++q) {
+                    const int e = lane + 64 * q;
+                    const int px = e / NC, col = e - px * NC;
+                    const int m = m0 + px;
+                    if (m < a.M) {
+                        const int b = m / a.HW, pin = m - b * a.HW;
+                        a.out[((size_t)b * a.A + a.lvl_off + pin) * NO + 5 + col] = stage[e];
+                    }
+                }
+            } else {
+                const int px = lane >> 2, side = lane & 3;
+                const float* rr = stage + px * NR + side * 17;                     // channel = side * 17 + bin (yolo.py:376)
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 17; ++i) mx = fmaxf(mx, rr[i]);
+                float se = 0.f, sw = 0.f;
+#pragma unroll
+                for (int i = 0; i < 17; ++i) {
+                    const float e = __expf(rr[i] - mx);
+                    se += e;
+                    sw += e * (float)i;
+                }
+                const float d = sw / se;                                          // expected ltrb distance in grid units
+                const int l0 = lane & ~3;
+                const float lft = __shfl(d, l0), top = __shfl(d, l0 + 1), rgt = __shfl(d, l0 + 2), bot = __shfl(d, l0 + 3);
+                const int m = m0 + px;
+                if (m < a.M) {
+                    const int b = m / a.HW, pin = m - b * a.HW;
+                    const float ax = (float)(pin % a.Wd) + 0.5f, ay = (float)(pin / a.Wd) + 0.5f;
+                    const float x1 = ax - lft, y1 = ay - top, x2 = ax + rgt, y2 = ay + bot;
+                    float v = side == 0 ? (x1 + x2) * 0.5f : side == 1 ? (y1 + y2) * 0.5f : side == 2 ? x2 - x1 : y2 - y1;
+                    float* o = a.out + ((size_t)b * a.A + a.lvl_off + pin) * NO;
+                    o[side] = v * a.stride;
+                    if (side == 0) o[4] = 1.0f;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t maf_head_tail_record_bytes(int32_t C) { return (int64_t)C * C * 2 + 80ll * C * 2 + C * 4 + 80 * 4; }
+
+int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
+    MAF_REQUIRE(op->dtype == MAF_F16, "head_tail: fp16 only");
+    MAF_REQUIRE(op->Cin == 128 || op->Cin == 192 || op->Cin == 64, "head_tail: head width must be 64, 128 or 192");
+    MAF_REQUIRE(op->nc == 80 && op->reg_max == 16, "head_tail: 80 classes and reg_max 16");
+    MAF_REQUIRE(op->nsrc == 2 && op->src[0].ptr && op->src[1].ptr && op->w && op->aux[0] && op->out, "head_tail: null pointer");
+    MAF_REQUIRE(op->B > 0 && op->H > 0 && op->W > 0 && (long long)op->B * op->H * op->W < (1ll << 31), "head_tail: bad dims");
+    HtArgs a;
+    for (int i = 0; i < 2; ++i) {
+        const maf_src_t& sr = op->src[i];
+        MAF_REQUIRE(sr.C == op->Cin && sr.stride % 8 == 0 && sr.coff % 8 == 0 && sr.mode == MAF_SRC_DIRECT, "head_tail: sources must be direct, 16-byte aligned, Cin wide");
+        a.x[i] = static_cast<const half_t*>(sr.ptr); a.xs[i] = sr.stride; a.xc[i] = sr.coff;
+    }
+    a.rec[0] = static_cast<const char*>(op->w); a.rec[1] = static_cast<const char*>(op->aux[0]);
+    a.out = static_cast<float*>(op->out);
+    a.M = op->B * op->H * op->W; a.HW = op->H * op->W; a.Wd = op->W; a.A = op->Win; a.lvl_off = op->Hin; a.stride = op->lvl_stride[0];
+    MAF_REQUIRE(a.A >= a.lvl_off + a.HW && a.lvl_off >= 0, "head_tail: Hin = first anchor of the level, Win = anchors per image");
+    const int pt = op->Cin <= 128 ? 2 : 1;
+    const int units = maf_cdiv(maf_cdiv(a.M, 16), pt);
+    int iters = op->tile_k > 0 ? op->tile_k : std::min(8, std::max(1, units / (4 * 512)));
+    a.iters = iters;
+    const dim3 grid(maf_cdiv(units, 4 * iters), 2);
+    switch (op->Cin) {
+        case 64: hipLaunchKernelGGL((head_tail_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
+        case 128: hipLaunchKernelGGL((head_tail_kernel<128, 2>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((head_tail_kernel<192, 1>), grid, dim3(256), 0, s, a); break;
+    }
+    return maf_check_hip(hipGetLastError(), "head_tail launch");
+}

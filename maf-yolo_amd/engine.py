@@ -94,7 +94,7 @@ class TV:
 
 
 class Plan:
-    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None):
+    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None, fuse_head=None):
         assert Hin % 32 == 0 and Win % 32 == 0, "image sides must be multiples of 32 (stride of P5)"
         self.B, self.Hin, self.Win, self.dtype, self.in_dtype, self.device = B, Hin, Win, dtype, in_dtype, device
         self.es = _ESIZE[dtype]
@@ -113,6 +113,10 @@ class Plan:
         # independent branches (side down-sampling convs of the MAFPN neck, the three heads and their cls / reg halves) CAN run
         # on separate HIP streams of the engine.  Measured on MI355X (n, bs 32): heads-only lanes give -1 % on forward+NMS and
         # +1.3 % on forward alone (cross-stream event latency eats the overlap), all lanes lose 1-2 %: opt-in.
+        # the tail of every detection level ({cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode) as one launch per level
+        # (csrc/head_tail.hip, fp16, 80 classes, head width 64 / 128 / 192) instead of four 1x1 convs + the decode kernel
+        fh = getattr(model, "fuse_head", "auto") if fuse_head is None else fuse_head
+        self.fuse_head = bool(fh) and dtype == lib.F16 and model.nc == 80 and model.detect.reg_max == 16
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
             self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
@@ -186,6 +190,7 @@ class Plan:
         B = self.B
         y = []                                   # TV (or list of head tuples) per node
         self.head_bufs = []
+        self.fuse_head = self.fuse_head and not self.lanes and all(n.cout in (64, 128, 192) for n in model.nodes if n.kind == "head")   # all levels or none
         n_side = n_head = 0
         for node, m in zip(model.nodes, model.backbone):
             if node.i > 0:                            # tag the ops of the previous node (lane = HIP stream of the engine)
@@ -283,6 +288,20 @@ class Plan:
                 t = self._alloc(x.H, x.W, c)
                 self._conv1x1(p + ".stem", *m.stem.fused(), x, t, 0, lib.ACT_SILU)
                 tv = TV([Seg(t, c)], x.H, x.W)
+                if self.fuse_head:
+                    us = []
+                    for br in ("cls", "reg"):
+                        u = self._alloc(x.H, x.W, c)
+                        self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
+                        us.append(u)
+                    recs = [pack.pack_head_tail(*getattr(m, br + "_conv_s").fused(), pr.weight.detach(), pr.bias.detach())
+                            for br, pr in (("cls", m.cls_pred), ("reg", m.reg_pred))]
+                    self._ops.append(dict(kind=lib.OP_HEADTAIL, name=p + ".tail", act=0, H=x.H, W=x.W, Cin=c, Cout=5 + self.nc,
+                                          segs=[Seg(us[0], c), Seg(us[1], c)], out=None, out_coff=0, w=self._wput(recs[0]), b=0,
+                                          aux=[self._wput(recs[1])], level=len(self.head_bufs)))
+                    self.head_bufs.append((t, None, None))
+                    y.append(None)
+                    continue
                 outs = []
                 for br, pred, act, cpred in (("cls", m.cls_pred, lib.ACT_SIGMOID, self.nc), ("reg", m.reg_pred, lib.ACT_NONE, 4 * (self.reg_max + 1))):
                     u, v = self._alloc(x.H, x.W, c), self._alloc(x.H, x.W, c)
@@ -300,7 +319,10 @@ class Plan:
         self._tag(tag_from, tag_node, tag_lane, tag_after)
         assert len(self.head_bufs) == 3, "MAF-YOLO has three detection levels"
         self.A = sum(t.H * t.W for t, _, _ in self.head_bufs)
-        self._ops.append(dict(kind=lib.OP_DECODE, name="detect", act=0, H=0, W=0, Cin=0, Cout=0, segs=[], out=None, out_coff=0))
+        fused = [c is None for _, c, _ in self.head_bufs]
+        assert all(fused) or not any(fused), "head fusion is all levels or none"
+        if not any(fused):
+            self._ops.append(dict(kind=lib.OP_DECODE, name="detect", act=0, H=0, W=0, Cin=0, Cout=0, segs=[], out=None, out_coff=0))
 
     # ---------------------------------------------------------------- lanes and cross-lane dependencies
     def _tag(self, first, node_i, lane, after):
@@ -396,6 +418,10 @@ class Plan:
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call
                 o.src[0].C = 3
+            if r["kind"] == lib.OP_HEADTAIL:
+                lvl = r["level"]
+                o.Hin, o.Win = sum(t.H * t.W for t, _, _ in self.head_bufs[:lvl]), self.A
+                o.lvl_stride[0], o.nc, o.reg_max = self.strides[lvl], self.nc, self.reg_max
             if r["kind"] == lib.OP_DECODE:
                 o.nsrc = 3
                 for l, (t, cls, reg) in enumerate(self.head_bufs):
@@ -590,6 +616,8 @@ class Plan:
             return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)
         if o.kind == lib.OP_CONV1DW:
             return "conv1dw_kernel<%d>" % o.ksize
+        if o.kind == lib.OP_HEADTAIL:
+            return "head_tail_kernel<%d, %d>" % (o.Cin, 2 if o.Cin <= 128 else 1)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -619,6 +647,8 @@ class Plan:
             return px * (o.Cin + o.Cout) * es + (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
         if o.kind == lib.OP_SPPF_POOL:
             return 4 * px * o.src[0].C * es
+        if o.kind == lib.OP_HEADTAIL:                          # both branch inputs once, the prediction rows once, the two weight records
+            return px * (2 * o.Cin * es + (5 + self.nc) * 4) + 2 * (o.Cin * o.Cin + 80 * o.Cin) * es
         if o.kind == lib.OP_DECODE:
             return self.B * self.A * ((self.nc + 4 * (self.reg_max + 1)) * 4 + (5 + self.nc) * 4)
         return 0
@@ -639,6 +669,8 @@ class Plan:
         if o.kind == lib.OP_BOTTLENECK:
             mid = self._ops[idx]["mid"]
             return 2 * px * (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout)
+        if o.kind == lib.OP_HEADTAIL:
+            return 2 * px * (2 * o.Cin * o.Cin + o.Cin * (self.nc + 4 * (self.reg_max + 1)))
         return 0
 
     def launch_op(self, idx, image_ptr=None, pred_ptr=None):
@@ -646,7 +678,7 @@ class Plan:
         op = self.ops[idx]
         if op.kind == lib.OP_STEM and image_ptr is not None:
             op.src[0].ptr = image_ptr
-        if op.kind == lib.OP_DECODE and pred_ptr is not None:
+        if op.kind in (lib.OP_DECODE, lib.OP_HEADTAIL) and pred_ptr is not None:
             op.out = pred_ptr
         stream = torch.cuda.current_stream(self.device).cuda_stream
         lib.check(lib.load().maf_op_launch(C.byref(op), stream))
@@ -659,8 +691,9 @@ class Plan:
         return self.arena[start:start + n].view(dt).view(self.B, buf.H, buf.W, buf.stride)
 
     def featmaps(self):
-        """[(stem, cls, reg)] x 3 as NCHW views, the second element of the reference's Model.forward return."""
-        return [tuple(self.view(b).permute(0, 3, 1, 2) for b in hb) for hb in self.head_bufs]
+        """[(stem, cls, reg)] x 3 as NCHW views, the second element of the reference's Model.forward return.  Plans with the fused
+        head tail never materialise cls / reg (None there): Model.forward(val_loss=True) builds its plan with fuse_head off."""
+        return [tuple(None if b is None else self.view(b).permute(0, 3, 1, 2) for b in hb) for hb in self.head_bufs]
 
     def __del__(self):
         try:

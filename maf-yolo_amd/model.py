@@ -101,6 +101,7 @@ class Model(nn.Module):
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
+        self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
 
@@ -156,7 +157,8 @@ class Model(nn.Module):
             y.append(x)
         return x                              # list of three (stem, cls, reg)
 
-    def plan_for(self, x):
+    def plan_for(self, x, head_feats=False):
+        """head_feats: the caller wants the per-level cls / reg tensors (featmaps): plan without the fused head tail."""
         if not x.is_cuda:
             raise lib.MafError("MAF-YOLO eval forward runs on the HIP engine only: got a %s tensor (no CPU fallback)" % x.device)
         B, ch, H, W = x.shape
@@ -175,7 +177,8 @@ class Model(nn.Module):
             dt = lib.F32
         else:
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
-        key = (B, H, W, dt, in_dt, x.device.index)
+        fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
+        key = (B, H, W, dt, in_dt, x.device.index, fuse_head)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 8:
@@ -184,7 +187,7 @@ class Model(nn.Module):
             if self.autotune and dt == lib.F16 and self.fuse_bottlenecks == "auto":
                 from .engine import choose_fusion
                 fuse = choose_fusion(self, B, H, W, dt, in_dt, x.device, x.contiguous())
-            plan = Plan(self, B, H, W, dt, in_dt, x.device, fuse=fuse)
+            plan = Plan(self, B, H, W, dt, in_dt, x.device, fuse=fuse, fuse_head=fuse_head)
             if self.autotune and dt == lib.F16:
                 plan.autotune(x.contiguous())
             self._plans[key] = plan
@@ -196,7 +199,7 @@ class Model(nn.Module):
                 x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
             heads = self._forward_train_form(x)
             return [self.detect(heads), list(heads)]
-        plan = self.plan_for(x)
+        plan = self.plan_for(x, head_feats=val_loss)
         x = x.contiguous()
         with torch.cuda.device(x.device):
             pred = plan.run(x, graph=False)          # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)

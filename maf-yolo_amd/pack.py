@@ -181,3 +181,28 @@ def pack_bottleneck(w1, b1, wdw, bdw, w2, b2):
     rec = torch.cat([raw(W1.reshape(nmb, -1)), raw(b1p.reshape(nmb, 32)), raw(toe.reshape(nmb, -1).to(torch.float16)),
                      raw(W2.reshape(nmb, -1)), raw(bdp.reshape(nmb, 32))], 1).contiguous()
     return rec, b2p, nmb, ct2
+
+
+def pack_head_tail(w1, b1, w2, b2):
+    """Weight record of one branch of MAF_OP_HEADTAIL (csrc/head_tail.hip): 1x1 conv w1 [C,C] (+ b1, SiLU) followed by 1x1 conv w2
+    [n2 <= 80, C] (+ b2).  Layout: A fragments of W1 [C/16][C/32][64 lanes][8] f16 (lane (g, i): output channel 16t + i, input
+    channels 32ks + 8g ..+7) | B fragments of W2 [5][C/32][64][8] f16 whose K axis follows the accumulator layout of the first GEMM
+    (lane (g, n): output column 16 t2 + n; k-slot q of step j = channel 32j + 4g + q for q < 4, 32j + 16 + 4g + q - 4 otherwise)
+    | b1 fp32 [C] | b2 fp32 [80] (zero padded)."""
+    w1 = w1.detach().float().cpu().reshape(w1.shape[0], -1)
+    w2 = w2.detach().float().cpu().reshape(w2.shape[0], -1)
+    C = w1.shape[0]
+    assert w1.shape == (C, C) and w2.shape[1] == C and w2.shape[0] <= 80 and C % 32 == 0
+    ks, t1 = C // 32, C // 16
+    f1 = w1.view(t1, 16, ks, 4, 8).permute(0, 2, 3, 1, 4).contiguous().half()                  # [t][ks][g][i][j]
+    w2p = torch.zeros(80, C)
+    w2p[:w2.shape[0]] = w2
+    j, g, q = torch.meshgrid(torch.arange(ks), torch.arange(4), torch.arange(8), indexing="ij")
+    ch = 32 * j + torch.where(q < 4, 4 * g + q, 16 + 4 * g + q - 4)                            # [ks][4][8]
+    f2 = w2p[:, ch.reshape(-1)].view(5, 16, ks, 4, 8).permute(0, 2, 3, 1, 4).contiguous().half()   # [t2][j][g][n][q]
+    b2p = torch.zeros(80)
+    b2p[:b2.numel()] = b2.detach().float().cpu()
+    rec = torch.cat([f1.reshape(-1).view(torch.uint8), f2.reshape(-1).view(torch.uint8),
+                     b1.detach().float().cpu().contiguous().view(torch.uint8), b2p.view(torch.uint8)])
+    assert rec.numel() == C * C * 2 + 80 * C * 2 + C * 4 + 320
+    return rec

@@ -269,6 +269,35 @@ def test_fused_bottleneck_plan_matches_unfused(models):
     _close16(outs[2], outs[False])
 
 
+@pytest.mark.parametrize("shape", [(2, 320, 320), (3, 256, 384), (32, 640, 640)])
+def test_fused_head_tail_matches_unfused(shape):
+    """MAF_OP_HEADTAIL ({cls,reg}_conv_s -> pred -> sigmoid / DFL decode, one launch per level) vs four 1x1 convs + the decode kernel:
+    same fp16 rounding points, so only the fp32 summation order differs."""
+    B, H, W = shape
+    x = O.synth_images(B, max(H, W), 21)[:, :, :H, :W].contiguous().to(DEV).half()
+    outs = {}
+    for fh in (True, False):
+        m = M.Model("n")
+        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = m.to(DEV).eval()
+        m.fuse_head = fh
+        with torch.no_grad():
+            pred, feats = m(x)
+        outs[fh] = pred.float().cpu().numpy()
+        kinds = [o.kind for o in m.plan_for(x).ops]
+        assert (kinds.count(8) == 3 and 5 not in kinds) if fh else (8 not in kinds and kinds.count(5) == 1)
+        assert (feats[0][1] is None) == fh and feats[0][0] is not None
+        if fh:                                    # asking for the head tensors (val_loss) selects a plan that materialises them
+            with torch.no_grad():
+                _, feats2 = m(x, val_loss=True)
+            assert feats2[2][1].shape == (B, 80, H // 32, W // 32) and feats2[2][2].shape == (B, 68, H // 32, W // 32)
+    a, b = outs[True], outs[False]
+    assert np.array_equal(a[..., 4], b[..., 4]) and np.all(a[..., 4] == 1.0)
+    assert np.abs(a[..., 5:] - b[..., 5:]).max() <= 3e-3
+    assert np.abs(a[..., :4] - b[..., :4]).max() <= 0.05 + 2e-3 * np.abs(b[..., :4]).max()
+    assert np.abs(a[..., :4] - b[..., :4]).mean() <= 2e-3
+
+
 def test_fusion_choice_is_measured_when_autotuning():
     from maf_yolo_amd import engine
     m = M.Model("n")
@@ -282,7 +311,7 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 90 - 2 * nf - npart
+    assert len(plan.ops) == 80 - 2 * nf - npart          # 90 launches unfused; the fused head tail takes 10 off
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):
@@ -345,6 +374,7 @@ def test_multi_stream_plan_equals_single_stream(models):
         m.load_state_dict(O.synth_state_dict("n", 0))
         m = m.to(DEV).eval()
         m.multi_stream = ms
+        m.fuse_head = False                      # the fused head tail is a single-stream variant: compare like with like
         with torch.no_grad():
             outs[ms] = m(x)[0].clone()
             plan = m.plan_for(x)

@@ -145,6 +145,7 @@ def test_pack_layout():
 @pytest.mark.parametrize("scale,nops", [("n", 88 + 2), ("s", 118 + 2), ("m", 148 + 2)])
 def test_plan_builds_on_cpu(built, scale, nops):
     m = M.Model(scale).eval()
+    m.fuse_head = False
     plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
     lo, hi = plan._abase, plan._abase + plan._arena_size
@@ -164,6 +165,19 @@ def test_plan_builds_on_cpu(built, scale, nops):
     auto = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
     assert len(auto.ops) == nops - 2 * {"n": 4, "s": 4, "m": 2}[scale]
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops        # fp32 parity mode never fuses
+    m.fuse_head = "auto"                           # head tail: per level 4 convs -> 1 launch, and no decode launch
+    ht = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
+    widths = [o.Cin for o in plan.ops if o.kind == lib.OP_CONV1X1 and o.out_f32][::2]
+    assert len(widths) == 3
+    if all(w in (64, 128, 192) for w in widths):
+        assert len(ht.ops) == nops - 10 and sum(1 for o in ht.ops if o.kind == lib.OP_HEADTAIL) == 3 and not any(o.kind == lib.OP_DECODE for o in ht.ops)
+        for o in ht.ops:
+            if o.kind == lib.OP_HEADTAIL:
+                assert o.nsrc == 2 and o.src[0].C == o.Cin and o.Win == ht.A and o.w and o.aux[0]
+        assert [o.Hin for o in ht.ops if o.kind == lib.OP_HEADTAIL] == [0, 64, 80]
+    else:
+        assert len(ht.ops) == nops
+    assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops
 
 
 def test_product_synth_generator_equals_oracle_generator():
