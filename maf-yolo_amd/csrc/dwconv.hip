@@ -30,6 +30,7 @@ struct DwArgs {
     int B, H, W, C, in_stride, in_coff, out_stride, out_coff, act;
     int TH, TW, CB;                  // tile: rows, cols (multiple of R), channels per block
     int tilesX, tilesY, nCB, nwg;
+    int in_mod;                      // output channel c reads input channel c % in_mod (= C, or C/2 for two filters per input channel)
 };
 
 template <typename T> struct Vec;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwArgs a) {
     const int tid = threadIdx.x;
 
     {   // ---- stage the halo tile and the weights
-        const T* in = static_cast<const T*>(a.in) + a.in_coff + c0;
+        const T* in = static_cast<const T*>(a.in) + a.in_coff + c0 % a.in_mod;
         const int total = RH * RW * CGB;
         for (int base = tid; base < total; base += 256 * 4) {          // 4 independent 16-byte loads in flight per lane
             vec_t v[4];
@@ -203,6 +204,7 @@ int launch_t(DwArgs& a, int k, hipStream_t s) {
     } else {
         choose_tile(a.H, a.W, a.C, N, k, a.TH, a.TW, a.CB);
     }
+    while (a.in_mod % a.CB) a.CB -= N;                                  // a channel block never straddles the wrap of the input channels
     a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH); a.nCB = maf_cdiv(a.C, a.CB);
     a.nwg = a.B * a.tilesY * a.tilesX * a.nCB;
     const size_t lds = lds_bytes(a.TH, a.TW, a.CB, N, k);
@@ -240,12 +242,13 @@ int maf_launch_dwconv(const maf_op_t* op, hipStream_t s) {
     const int N = op->dtype == MAF_F16 ? 8 : 4;
     const maf_src_t& sr = op->src[0];
     MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr, "dwconv: one direct source");
-    MAF_REQUIRE(op->Cin == op->Cout && sr.C == op->Cin && op->Cin % N == 0, "dwconv: C must be a multiple of the 16-byte channel group");
+    MAF_REQUIRE((op->Cout == op->Cin || op->Cout == 2 * op->Cin) && sr.C == op->Cin && op->Cin % N == 0,
+                "dwconv: Cout = Cin or 2 Cin (two filters per input channel), Cin a multiple of the 16-byte channel group");
     MAF_REQUIRE(sr.stride % N == 0 && sr.coff % N == 0 && op->out_stride % N == 0 && op->out_coff % N == 0, "dwconv: strides/offsets must be 16-byte aligned");
     MAF_REQUIRE(op->w && op->bias && op->out, "dwconv: null pointer");
     DwArgs a;
     a.in = sr.ptr; a.w = op->w; a.bias = op->bias; a.out = op->out;
-    a.B = op->B; a.H = op->H; a.W = op->W; a.C = op->Cin;
+    a.B = op->B; a.H = op->H; a.W = op->W; a.C = op->Cout; a.in_mod = op->Cin;
     a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     a.act = op->act;
     a.TH = op->tile_p; a.TW = op->tile_c; a.CB = op->tile_k;     // 0 = cost-model choice

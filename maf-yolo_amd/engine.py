@@ -289,15 +289,18 @@ class Plan:
                 self._conv1x1(p + ".stem", *m.stem.fused(), x, t, 0, lib.ACT_SILU)
                 tv = TV([Seg(t, c)], x.H, x.W)
                 if self.fuse_head:
-                    us = []
-                    for br in ("cls", "reg"):
-                        u = self._alloc(x.H, x.W, c)
-                        self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
-                        us.append(u)
+                    # cls_conv and reg_conv read the same tensor: ONE depth-wise launch with two filters per input channel
+                    (wc, bc), (wr, brg) = m.cls_conv.fused(), m.reg_conv.fused()
+                    assert wc.shape == wr.shape
+                    u = self._alloc(x.H, x.W, 2 * c)
+                    self._ops.append(dict(kind=lib.OP_DWCONV, name=p + ".cls_reg_conv", act=lib.ACT_NONE, H=x.H, W=x.W, Cin=c, Cout=2 * c, ksize=wc.shape[-1],
+                                          segs=tv.segs, out=u, out_coff=0, w=self._wput(pack.pack_dw(torch.cat([wc, wr], 0), self.dtype)),
+                                          b=self._wput(torch.cat([bc, brg], 0).float().cpu()), aux=[]))
+                    us = [(u, 0), (u, c)]
                     recs = [pack.pack_head_tail(*getattr(m, br + "_conv_s").fused(), pr.weight.detach(), pr.bias.detach())
                             for br, pr in (("cls", m.cls_pred), ("reg", m.reg_pred))]
                     self._ops.append(dict(kind=lib.OP_HEADTAIL, name=p + ".tail", act=0, H=x.H, W=x.W, Cin=c, Cout=5 + self.nc,
-                                          segs=[Seg(us[0], c), Seg(us[1], c)], out=None, out_coff=0, w=self._wput(recs[0]), b=0,
+                                          segs=[Seg(us[0][0], c, us[0][1]), Seg(us[1][0], c, us[1][1])], out=None, out_coff=0, w=self._wput(recs[0]), b=0,
                                           aux=[self._wput(recs[1])], level=len(self.head_bufs)))
                     self.head_bufs.append((t, None, None))
                     y.append(None)
@@ -451,8 +454,34 @@ class Plan:
         self._tuned = getattr(self, "_tuned", [])
         changed = 0
         for i, (o, r) in enumerate(zip(self.ops, self._ops)):
+            if o.kind == lib.OP_HEADTAIL:                        # head tail: pixel units per wave (weights are staged once per workgroup)
+                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin)
+                best = _TUNE_CACHE.get(sig)
+                if best is None:
+                    o.out = pred.data_ptr()
+                    results = []
+                    for iters in (1, 2, 3, 4, 6, 8, 12):
+                        op = lib.MafOp.from_buffer_copy(o)
+                        op.tile_k = iters
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        ts = []
+                        for _ in range(reps):
+                            timer.start(stream.cuda_stream)
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            timer.stop(stream.cuda_stream)
+                            ts.append(timer.elapsed_ms())
+                        results.append((min(ts), iters))
+                    results.sort()
+                    best = (0, 0, results[0][1])
+                    _TUNE_CACHE[sig] = best
+                    if verbose:
+                        print("tune %-32s %dx%d C=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, " ".join("(%d)%.1fus" % (it, t * 1e3) for t, it in results)))
+                if best[2] != o.tile_k:
+                    o.tile_k = best[2]
+                    changed += 1
+                continue
             if o.kind == lib.OP_DWCONV:                          # depth-wise: workgroup tile (rows, cols, channel block)
-                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin, o.ksize, o.act)
+                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin, o.ksize, o.act) + ((o.Cout,) if o.Cout != o.Cin else ())
                 best = _TUNE_CACHE.get(sig)
                 if best is None:
                     n = 8 if self.dtype == lib.F16 else 4
@@ -639,7 +668,7 @@ class Plan:
         if o.kind == lib.OP_CONV3X3S2:
             return self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es
         if o.kind == lib.OP_DWCONV:
-            return 2 * px * o.Cin * es + o.ksize * o.ksize * o.Cin * es
+            return px * (o.Cin + o.Cout) * es + o.ksize * o.ksize * o.Cout * es
         if o.kind == lib.OP_CONV1DW:
             return px * (o.Cin + o.Cout) * es + (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout) * es
         if o.kind == lib.OP_BOTTLENECK:
@@ -663,7 +692,7 @@ class Plan:
         if o.kind == lib.OP_CONV3X3S2:
             return 2 * px * 9 * o.Cin * o.Cout
         if o.kind == lib.OP_DWCONV:
-            return 2 * px * o.ksize * o.ksize * o.Cin
+            return 2 * px * o.ksize * o.ksize * o.Cout
         if o.kind == lib.OP_CONV1DW:
             return 2 * px * (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout)
         if o.kind == lib.OP_BOTTLENECK:

@@ -311,7 +311,7 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 80 - 2 * nf - npart          # 90 launches unfused; the fused head tail takes 10 off
+    assert len(plan.ops) == 77 - 2 * nf - npart          # 90 launches unfused; the fused head (one depth-wise + one tail per level) takes 13 off
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):

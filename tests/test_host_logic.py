@@ -165,12 +165,12 @@ def test_plan_builds_on_cpu(built, scale, nops):
     auto = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
     assert len(auto.ops) == nops - 2 * {"n": 4, "s": 4, "m": 2}[scale]
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops        # fp32 parity mode never fuses
-    m.fuse_head = "auto"                           # head tail: per level 4 convs -> 1 launch, and no decode launch
+    m.fuse_head = "auto"                           # head tail: per level 2 depth-wise + 4 convs -> 1 + 1 launches, and no decode launch
     ht = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     widths = [o.Cin for o in plan.ops if o.kind == lib.OP_CONV1X1 and o.out_f32][::2]
     assert len(widths) == 3
     if all(w in (64, 128, 192) for w in widths):
-        assert len(ht.ops) == nops - 10 and sum(1 for o in ht.ops if o.kind == lib.OP_HEADTAIL) == 3 and not any(o.kind == lib.OP_DECODE for o in ht.ops)
+        assert len(ht.ops) == nops - 13 and sum(1 for o in ht.ops if o.kind == lib.OP_HEADTAIL) == 3 and not any(o.kind == lib.OP_DECODE for o in ht.ops)
         for o in ht.ops:
             if o.kind == lib.OP_HEADTAIL:
                 assert o.nsrc == 2 and o.src[0].C == o.Cin and o.Win == ht.A and o.w and o.aux[0]
