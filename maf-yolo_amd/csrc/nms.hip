@@ -46,6 +46,7 @@ struct NmsArgs {
     float* out_rows; long long* out_idx; int* out_count;
     struct Cand* cands;            // [B][kMaskN]           sorted candidates of the matrix path
     unsigned long long* mask;      // [B][kMaskN][kMaskW]   bit j of word w of row i: candidate 64w+j (> i) overlaps candidate i
+    int cpath_ok, bbits;           // per-class path allowed (not agnostic, key fields fit); bits of a box index
 };
 
 __device__ __forceinline__ bool class_ok(const NmsArgs& a, int c) {
@@ -421,8 +422,21 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSortT = 1024;
 
+// Per-class path.  Boxes of different classes are 4096 px apart (nms.py:94), so unless a box leaves its band only pairs of the SAME
+// class can overlap: then the greedy scan splits into one short scan per class, all independent.  nms_sort_kernel decides per image:
+// if the candidates' raw coordinates span less than 4095 px (no box can reach another class's band), no class holds more than
+// kClsMax candidates and the key fields fit, it sorts by (class, score desc, box) and raises the image's flag; nms_cscan_kernel then
+// runs the per-class scans on 16 wavefronts, sorts the survivors back into score order and emits the first max_det.  Every pair it
+// does test goes through the same iou_gt on the same offset boxes, and every pair it skips has an empty intersection: the survivors
+// are those of the full scan, bit for bit.  Images that do not qualify (agnostic, a dominant class, huge boxes) keep the matrix path.
+constexpr int kClsMax = 256;          // longest per-class list the per-class path accepts
+constexpr int kClsHist = 1024;        // classes it can count
+
 __global__ __launch_bounds__(kSortT) void nms_sort_kernel(const NmsArgs a) {
     __shared__ unsigned long long lk[kMaskN];
+    __shared__ int hist[kClsHist];
+    __shared__ float red_lo[kSortT / 64], red_hi[kSortT / 64];
+    __shared__ int s_bad;
     const int b = blockIdx.x, tid = threadIdx.x;
     long long n64 = a.cnt[b * kCntStride];
     const long long cap = (long long)a.N * a.nc;
@@ -430,29 +444,163 @@ __global__ __launch_bounds__(kSortT) void nms_sort_kernel(const NmsArgs a) {
     const int n = (int)n64;
     if (n == 0 || n > kMaskN) return;
     const unsigned long long* keys = a.keys + (size_t)b * a.capP;
+    const int no = 5 + a.nc;
+    const float* pred = a.pred + (size_t)b * a.N * no;
     int P = 64;
     while (P < n) P <<= 1;
     for (int i = tid; i < P; i += kSortT) lk[i] = i < n ? keys[i] : ~0ull;
+    bool cpath = a.cpath_ok != 0;
+    if (cpath) {                                                   // uniform
+        for (int i = tid; i < a.nc; i += kSortT) hist[i] = 0;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        float lo = INFINITY, hi = -INFINITY; int bad = 0;
+        for (int i = tid; i < n; i += kSortT) {
+            const unsigned int flat = (unsigned int)(lk[i] & 0xffffffffu);
+            const unsigned int box = flat / (unsigned int)a.nc;
+            const int cls = (int)(flat - box * (unsigned int)a.nc);
+            const float* r = pred + (size_t)box * no;
+            const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+            const float x1 = cx - w / 2, y1 = cy - h / 2, x2 = cx + w / 2, y2 = cy + h / 2;
+            const float mn = fminf(fminf(x1, y1), fminf(x2, y2)), mx = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+            if (!(mn > -INFINITY) || !(mx < INFINITY)) bad = 1;    // NaN / infinite coordinates: the literal all-pairs path
+            lo = fminf(lo, mn); hi = fmaxf(hi, mx);
+            if (atomicAdd(&hist[cls], 1) >= kClsMax) bad = 1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if ((tid & 63) == 0) { red_lo[tid >> 6] = lo; red_hi[tid >> 6] = hi; }
+        if (bad) s_bad = 1;
+        __syncthreads();
+        lo = red_lo[0]; hi = red_hi[0];
+        for (int w = 1; w < kSortT / 64; ++w) { lo = fminf(lo, red_lo[w]); hi = fmaxf(hi, red_hi[w]); }
+        cpath = !s_bad && (hi - lo) < kMaxWh - 1.0f;               // a pixel of slack for the rounding of the class offsets
+        if (cpath)
+            for (int i = tid; i < n; i += kSortT) {                // key: class | ~score | box  (same tie order as the flat index inside a class)
+                const unsigned long long key = lk[i];
+                const unsigned int flat = (unsigned int)(key & 0xffffffffu);
+                const unsigned int box = flat / (unsigned int)a.nc;
+                const unsigned long long cls = flat - box * (unsigned int)a.nc;
+                lk[i] = (cls << (32 + a.bbits)) | ((key >> 32) << a.bbits) | box;
+            }
+    }
+    if (tid == 0) a.cnt[b * kCntStride + 1] = cpath ? 1 : 0;
     __syncthreads();
     bitonic_sort(lk, P, tid, kSortT);
-    const int no = 5 + a.nc;
-    const float* pred = a.pred + (size_t)b * a.N * no;
     Cand* out = a.cands + (size_t)b * kMaskN;
     for (int i = tid; i < n; i += kSortT) {
         const unsigned long long key = lk[i];
-        const unsigned int flat = (unsigned int)(key & 0xffffffffu);
+        unsigned int flat, sbits;
+        if (cpath) {
+            const unsigned int box = (unsigned int)(key & ((1ull << a.bbits) - 1ull));
+            sbits = (unsigned int)(key >> a.bbits);
+            flat = box * (unsigned int)a.nc + (unsigned int)(key >> (32 + a.bbits));
+        } else {
+            flat = (unsigned int)(key & 0xffffffffu);
+            sbits = (unsigned int)(key >> 32);
+        }
         const unsigned int box = flat / (unsigned int)a.nc;
         const int cls = (int)(flat - box * (unsigned int)a.nc);
         Cand c;
         make_cand(a, pred, no, box, cls, c);
-        c.score = __uint_as_float(~(unsigned int)(key >> 32)); c.flat = flat; c.pad = (unsigned int)cls;
+        c.score = __uint_as_float(~sbits); c.flat = flat; c.pad = (unsigned int)cls;
         out[i] = c;
     }
+}
+
+__global__ __launch_bounds__(kSortT) void nms_cscan_kernel(const NmsArgs a) {
+    __shared__ float bx1[kMaskN], by1[kMaskN], bx2[kMaskN], by2[kMaskN];     // the image's candidates, class-major (64 KiB)
+    __shared__ unsigned long long skeys[kMaskN];                              // survivors as score-major keys (32 KiB)
+    __shared__ unsigned char kept[kMaskN];
+    __shared__ int seg[kClsHist + 1];
+    __shared__ int s_ns;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!a.cnt[b * kCntStride + 1]) return;
+    long long n64 = a.cnt[b * kCntStride];
+    const long long cap = (long long)a.N * a.nc;
+    if (n64 > cap) n64 = cap;
+    const int n = (int)n64;
+    const Cand* cands = a.cands + (size_t)b * kMaskN;
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    for (int i = tid; i < n; i += kSortT) {
+        const Cand c = cands[i];
+        bx1[i] = c.x1; by1[i] = c.y1; bx2[i] = c.x2; by2[i] = c.y2;
+    }
+    // seg[c] = first candidate of class >= c (lower bound on the class-major order)
+    for (int c = tid; c <= a.nc; c += kSortT) {
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)cands[mid].pad < c) lo = mid + 1; else hi = mid; }
+        seg[c] = lo;
+    }
+    if (tid == 0) s_ns = 0;
+    __syncthreads();
+    auto box_at = [&](int i, Cand& c) {
+        c.x1 = bx1[i]; c.y1 = by1[i]; c.x2 = bx2[i]; c.y2 = by2[i];
+        c.area = (c.x2 - c.x1) * (c.y2 - c.y1);                                // = make_cand's area (same operands, same operation)
+    };
+    for (int cls = wave; cls < a.nc; cls += kSortT / 64) {
+        const int s0 = seg[cls], e0 = seg[cls + 1];
+        for (int base = s0; base < e0; base += 64) {
+            const int idx = base + lane;
+            const bool valid = idx < e0;
+            Cand me; box_at(valid ? idx : s0, me);
+            bool alive = valid;
+            for (int k = s0; k < base; ++k) {                                  // survivors of the class's earlier blocks
+                if (!kept[k]) continue;
+                Cand kc; box_at(k, kc);
+                if (alive && iou_gt(kc, me, iouthr)) alive = false;
+            }
+            unsigned long long sup_by = 0;                                     // earlier candidates of this block that overlap me
+            const int bn = min(64, e0 - base);
+            for (int i = 0; i < bn - 1; ++i) {
+                Cand ic; box_at(base + i, ic);
+                if (lane > i && valid && iou_gt(ic, me, iouthr)) sup_by |= 1ull << i;
+            }
+            unsigned long long todo = __ballot(alive), keep = 0;
+            while (todo) {                                                     // a survivor removes the later candidates it overlaps
+                const int i = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                keep |= 1ull << i;
+                todo &= ~__ballot((sup_by >> i) & 1ull);
+            }
+            const bool k = (keep >> lane) & 1ull;
+            if (valid) kept[idx] = k ? 1 : 0;
+            if (k) {
+                const Cand c = cands[idx];
+                skeys[atomicAdd(&s_ns, 1)] = ((unsigned long long)(~__float_as_uint(c.score)) << 32) | c.flat;
+            }
+        }
+    }
+    __syncthreads();
+    const int ns = s_ns;
+    int P = 64;
+    while (P < ns) P <<= 1;
+    for (int i = ns + tid; i < P; i += kSortT) skeys[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort(skeys, P, tid, kSortT);
+    const int nk = ns < a.max_det ? ns : a.max_det;
+    const int no = 5 + a.nc;
+    const float* pred = a.pred + (size_t)b * a.N * no;
+    float* orow = a.out_rows + (size_t)b * a.max_det * 6;
+    long long* oidx = a.out_idx + (size_t)b * a.max_det;
+    for (int k = tid; k < nk; k += kSortT) {
+        const unsigned long long key = skeys[k];
+        const unsigned int flat = (unsigned int)(key & 0xffffffffu);
+        const unsigned int box = flat / (unsigned int)a.nc;
+        const int cls = (int)(flat - box * (unsigned int)a.nc);
+        const float* r = pred + (size_t)box * no;
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float* o = orow + (size_t)k * 6;
+        o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2; o[4] = __uint_as_float(~(unsigned int)(key >> 32)); o[5] = (float)cls;
+        oidx[k] = a.multi_label ? (long long)flat : (long long)box;
+    }
+    if (tid == 0) a.out_count[b] = nk;
 }
 
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     __shared__ Cand cb[64];
     const int b = blockIdx.y, lane = threadIdx.x;
+    if (a.cnt[b * kCntStride + 1]) return;                     // the per-class path has this image
     long long n64 = a.cnt[b * kCntStride];
     const long long cap = (long long)a.N * a.nc;
     if (n64 > cap) n64 = cap;
@@ -488,6 +636,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
     __shared__ int kept_idx[kMaxDetCap];
     __shared__ int s_nk, s_done;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.cnt[b * kCntStride + 1]) return;                     // the per-class path has this image
     long long n64 = a.cnt[b * kCntStride];
     const long long cap = (long long)a.N * a.nc;
     if (n64 > cap) n64 = cap;
@@ -627,6 +776,13 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     a.classes = n_classes > 0 ? classes : nullptr; a.n_classes = n_classes;
     a.agnostic = agnostic; a.multi_label = (multi_label && nc > 1) ? 1 : 0;    // nms.py:57
     a.max_det = max_det;
+    {   // per-class path: class and box index must fit beside the 32 score bits of the sort key
+        int cb = 0, bb = 0;
+        while ((1ll << cb) < nc) ++cb;
+        while ((1ll << bb) < N) ++bb;
+        a.bbits = bb;
+        a.cpath_ok = (!agnostic && nc >= 8 && nc <= kClsHist && cb + bb <= 32) ? 1 : 0;
+    }
     char* ws = static_cast<char*>(workspace);
     a.cnt = reinterpret_cast<int*>(ws);
     a.keys = reinterpret_cast<unsigned long long*>(ws + 256 + (long long)B * kCntStride * 4);
@@ -648,6 +804,7 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     if (rc) return rc;
     hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(kSelT), 0, s, a);        // images with > kMaskN candidates (others return at once)
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(kSortT), 0, s, a);
+    if (a.cpath_ok) hipLaunchKernelGGL(nms_cscan_kernel, dim3(B), dim3(kSortT), 0, s, a);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskWgs, B), dim3(64), 0, s, a);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
     return maf_check_hip(hipGetLastError(), "nms_select launch");

@@ -417,3 +417,34 @@ def test_nms_matrix_and_list_paths_meet_at_4096_candidates(n_cand):
     want, widx = O.non_max_suppression(pred, 0.25, 0.5, multi_label=True, max_det=300, return_index=True)
     got, gidx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), 0.25, 0.5, multi_label=True, max_det=300, return_index=True)
     assert np.array_equal(gidx[0].cpu().numpy(), widx[0]) and np.array_equal(got[0].cpu().numpy(), want[0])
+
+
+@pytest.mark.parametrize("case", ["balanced", "dominant_class", "huge_boxes", "agnostic", "ties"])
+def test_nms_per_class_path_and_matrix_path_agree_with_oracle(case):
+    """nms_sort_kernel sends an image down the per-class path (class-major sort, one short scan per class, survivors re-sorted by score)
+    when no class holds more than 256 candidates and no box can reach another class's 4096-px band, else down the all-pairs matrix path.
+    Both must give the oracle's rows and indices bit for bit: balanced classes (per-class), one class with ~1500 candidates (matrix),
+    boxes wider than a band (matrix), class-agnostic (matrix), and many equal scores in the per-class path (tie order = flat index)."""
+    rng = np.random.RandomState(7)
+    N, nc, n_cand = 8400, 80, 2200
+    pred = np.zeros((2, N, 5 + nc), np.float32)
+    for b in range(2):
+        pred[b, :, 0:2] = rng.uniform(30, 610, (N, 2)); pred[b, :, 2:4] = rng.uniform(10, 120, (N, 2))
+        pred[b, :, 4] = 1.0
+        pred[b, :, 5:] = 0.001
+        rows = rng.choice(N, n_cand, replace=True)
+        cls = rng.randint(0, nc, n_cand)
+        if case == "dominant_class":
+            cls[: 1500] = 17
+        sc = rng.uniform(0.05, 0.99, n_cand).astype(np.float32)
+        if case == "ties":
+            sc = (np.round(sc * 20) / 20).astype(np.float32)
+        pred[b, rows, 5 + cls] = sc
+        if case == "huge_boxes":
+            pred[b, rows[:5], 2:4] = 5000.0
+    kw = dict(multi_label=True, max_det=300, agnostic=(case == "agnostic"))
+    want, widx = O.non_max_suppression(pred, 0.03, 0.65, return_index=True, **kw)
+    got, gidx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), 0.03, 0.65, return_index=True, **kw)
+    for b in range(2):
+        assert np.array_equal(gidx[b].cpu().numpy(), widx[b]), (case, b)
+        assert np.array_equal(got[b].cpu().numpy(), want[b]), (case, b)
