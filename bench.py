@@ -290,25 +290,39 @@ def main():
         for i, ms in enumerate(per_op_ms):
             g = groups.setdefault(plan.kernel_name(i), dict(ms=0.0, n=0, bytes=0, flops=0))
             g["ms"] += ms; g["n"] += 1; g["bytes"] += plan.algorithmic_bytes(i); g["flops"] += plan.flops(i)
-        name, gd = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        # The dominant kernel = the kernel TEMPLATE with the largest share of forward time (its instantiations are tile / variant
+        # choices of one piece of code, picked per layer by the autotuner); every instantiation is listed beside it.
+        fams = {}
+        for k, g in groups.items():
+            f = fams.setdefault(k.split("<")[0], dict(ms=0.0, n=0, bytes=0, flops=0, inst=[]))
+            f["ms"] += g["ms"]; f["n"] += g["n"]; f["bytes"] += g["bytes"]; f["flops"] += g["flops"]; f["inst"].append(k)
+        name, gd = max(fams.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = gd["ms"] / gd["n"]
         bytes_per_launch = gd["bytes"] / gd["n"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         tot_bytes = sum(plan.algorithmic_bytes(i) for i in range(len(plan.ops)))
         tot_flops = sum(plan.flops(i) for i in range(len(plan.ops)))
         fwd_img_s = B / (fwd_ms * 1e-3)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc = None, None, {}
         try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            if name in pmc:
-                traffic = pmc[name]["traffic_bytes"]
+            have = [k for k in gd["inst"] if k in pmc]
+            if have:                           # per launch of the template: instantiations weighted by their launches in this forward
+                traffic = int(sum(pmc[k]["traffic_bytes"] * groups[k]["n"] for k in have) / sum(groups[k]["n"] for k in have))
                 traffic_src = "profiles/round1_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 per launch, gfx950 FETCH_SIZE x2 correction"
         except Exception:
             pass
-        roofline = dict(bound="hbm", kernel=name, launches_per_forward=gd["n"], avg_launch_ms=round(avg_ms, 5),
+        insts = []
+        for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]:
+            a_gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+            insts.append(dict(kernel=k, launches=g["n"], avg_launch_ms=round(g["ms"] / g["n"], 5), share_of_forward=round(g["ms"] / per_op_ms.sum(), 4),
+                              achieved_GBs=round(a_gbs, 1), hbm_frac=round(a_gbs / HBM_PEAK_GBS, 4),
+                              mfma_frac=round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                              traffic=pmc.get(k, {}).get("traffic_bytes")))
+        roofline = dict(bound="hbm", kernel=name + "<...> (%d instantiations)" % len(gd["inst"]), launches_per_forward=gd["n"], avg_launch_ms=round(avg_ms, 5),
                         bytes_per_launch=int(bytes_per_launch), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4),
+                        share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4), top_instantiations=insts,
                         whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), GFLOP=round(tot_flops / 1e9, 2),
                                            sum_kernel_ms=round(float(per_op_ms.sum()), 4),
                                            hbm_frac=round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
