@@ -42,7 +42,8 @@ enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 c
        MAF_OP_DECODE = 5,                /* Detect_yaml eval branch: DFL decode -> [B,A,5+nc] fp32      */
        MAF_OP_BOTTLENECK = 6,
        MAF_OP_CONV1DW = 7,
-       MAF_OP_HEADTAIL = 8 };            /* one detection level: {cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode into the prediction rows */             /* first half of a DepthBottleneckUni: 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU */          /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
+       MAF_OP_HEADTAIL = 8,
+       MAF_OP_STEM2 = 9 };               /* backbone.0 + backbone.1: image -> 1/4-resolution map, the 1/2-resolution tensor stays in LDS */            /* one detection level: {cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode into the prediction rows */             /* first half of a DepthBottleneckUni: 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU */          /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
 enum { MAF_E_ARG = -1, MAF_E_UNSUPPORTED = -2, MAF_E_HIP = -3 };
 
 typedef struct {
@@ -79,6 +80,10 @@ typedef struct {
  * MAF_OP_CONV1DW    conv1 -> conv2 -> act of DepthBottleneckUni (common.py:905-909) for any width: Cin = c, Cout = 3c, ksize = k;
  *                   w = ceil(3c/32) block records of maf_conv1dw_record_bytes(k, c) bytes (W1 fragments [2][S1][64][8] f16 | b1 [32]
  *                   f32 | Toeplitz table [8][k][parts][16][8] f16 | bdw [32] f32; maf-yolo_amd/pack.py:pack_conv1dw); fp16, act = SiLU.
+ * MAF_OP_STEM2      replaces backbone.0 AND backbone.1 (two RepVGGBlocks in deploy form: 3x3 s2 conv + ReLU each, common.py:216-217) in one
+ *                   launch.  src[0].ptr = image [B,3,Hin,Win] NCHW of in_dtype (u8: /255 folded); H, W = the 1/4-resolution grid; Cin = 3,
+ *                   ksize = C0 (channels of backbone.0), Cout = C1: (24, 48) or (32, 64); w = record of maf_stem2_record_bytes(C0, C1)
+ *                   bytes (maf-yolo_amd/pack.py:pack_stem2); fp16 engine only; tile_k = workgroups (0 = 512, persistent).
  * MAF_OP_HEADTAIL   replaces, for ONE level, cls_conv_s + cls_pred + sigmoid and reg_conv_s + reg_pred (Head_DepthUni, common.py:1288-1336:
  *                   Conv.forward_fuse, nn.Conv2d) and that level's share of the Detect_yaml eval branch (yolo.py:355-396) in one launch.
  *                   src[0] / src[1] = inputs of cls_conv_s / reg_conv_s (C = Cin = head width: 64, 128 or 192); w / aux[0] = weight
@@ -121,6 +126,7 @@ int maf_version(void);
 int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
+int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1);
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

@@ -29,6 +29,7 @@ extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
         case MAF_OP_BOTTLENECK: return maf_launch_bottleneck(op, s);
         case MAF_OP_CONV1DW: return maf_launch_conv1dw(op, s);
         case MAF_OP_HEADTAIL: return maf_launch_head_tail(op, s);
+        case MAF_OP_STEM2: return maf_launch_stem2(op, s);
         default: maf_set_error("maf_op_launch: unknown op kind"); return MAF_E_UNSUPPORTED;
     }
 }
@@ -103,7 +104,7 @@ static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipSt
     }
     for (size_t i = 0; i < e->ops.size(); ++i) {
         maf_op_t op = e->ops[i];
-        if (op.kind == MAF_OP_STEM && image) op.src[0].ptr = image;
+        if ((op.kind == MAF_OP_STEM || op.kind == MAF_OP_STEM2) && image) op.src[0].ptr = image;
         if ((op.kind == MAF_OP_DECODE || op.kind == MAF_OP_HEADTAIL) && pred) op.out = pred;
         hipStream_t st = op.lane == 0 ? s : e->side[op.lane];
         for (int k = 0; k < op.n_wait && !rc; ++k) rc = maf_check_hip(hipStreamWaitEvent(st, e->done[op.wait[k]], 0), "hipStreamWaitEvent");
@@ -160,7 +161,7 @@ extern "C" int maf_engine_run_timed(maf_engine_t* e, const void* image, void* pr
     if (!rc) rc = maf_check_hip(hipEventRecord(ev[0], s), "hipEventRecord");
     for (size_t i = 0; i < n && !rc; ++i) {
         maf_op_t op = e->ops[i];
-        if (op.kind == MAF_OP_STEM && image) op.src[0].ptr = image;
+        if ((op.kind == MAF_OP_STEM || op.kind == MAF_OP_STEM2) && image) op.src[0].ptr = image;
         if ((op.kind == MAF_OP_DECODE || op.kind == MAF_OP_HEADTAIL) && pred) op.out = pred;
         rc = maf_op_launch(&op, s);
         if (!rc) rc = maf_check_hip(hipEventRecord(ev[i + 1], s), "hipEventRecord");

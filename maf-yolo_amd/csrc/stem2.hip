@@ -1,0 +1,215 @@
+// MAF_OP_STEM2: backbone.0 + backbone.1 in one launch — the two RepVGGBlocks in deploy form (3x3 stride-2 conv + bias + ReLU each,
+// yolov6/layers/common.py:216-217) that take the 3-channel NCHW image to the 1/4-resolution C1-channel NHWC map, with the `/255` of
+// yolov6/core/evaler.py:161-163 folded in for uint8 images.  The 1/2-resolution C0-channel tensor between them is the largest
+// activation of the network (32 x 320 x 320 x 24 fp16 = 157 MB written and read back); here it lives in LDS.
+//
+// One workgroup iteration = a 8 x 16 tile of the final map:
+//   A  the 35 x 67 x 3 input patch goes to LDS (planar, zero outside the image);
+//   B  the 17 x 33 stem outputs the tile needs are computed on the matrix cores: K = 27 taps (padded to 32) gathered from the patch
+//      into A fragments (8 two-byte LDS reads per lane), weights as B fragments in registers, bias + ReLU, fp16, stored pixel-major
+//      in LDS with a 56-byte pixel stride (stride-2 reads of 16 lanes then cover all 64 banks); positions outside the stem map are
+//      the second conv's zero padding;
+//   C  the second conv as an implicit GEMM: K = 9 taps x 24 channels = 27 (tap, 8-channel) pairs, four pairs per MFMA k-step,
+//      A fragments = two 8-byte LDS reads, weight fragments from LDS (staged once per workgroup), bias + ReLU;
+//   D  the 128 x C1 outputs leave through LDS as 16-byte pieces of whole NHWC pixels.
+// Workgroups are persistent (weights staged once).  fp16 engine only; (C0, C1) = (24, 48) [n] or (32, 64) [s].
+#include "maf_common.h"
+
+namespace {
+
+struct S2Args {
+    const void* img;          // [B,3,Hin,Win]
+    const char* rec;          // pack_stem2 record
+    half_t* out;              // [B,H1,W1,out_stride]
+    int B, Hin, Win, H0, W0, H1, W1, out_stride, out_coff, tilesX, tilesY, ntiles;
+    float in_scale;
+};
+
+// 4 consecutive input columns (4-element aligned) as fp16
+template <typename TI> struct Chunk;
+template <> struct Chunk<half_t> {
+    typedef u32x2_t raw;
+    static __device__ __forceinline__ half4_t cvt(raw v, float) { return *reinterpret_cast<half4_t*>(&v); }
+};
+template <> struct Chunk<float> {
+    typedef f32x4_t raw;
+    static __device__ __forceinline__ half4_t cvt(raw v, float) { return half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+};
+template <> struct Chunk<uint8_t> {
+    typedef uint32_t raw;
+    static __device__ __forceinline__ half4_t cvt(raw v, float s) {
+        return half4_t{(half_t)((float)(v & 0xffu) * s), (half_t)((float)((v >> 8) & 0xffu) * s), (half_t)((float)((v >> 16) & 0xffu) * s), (half_t)((float)(v >> 24) * s)};
+    }
+};
+
+template <typename TI, int C0, int C1>
+__global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
+    constexpr int TY = 8, TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC, IR = 2 * SR + 1, IC = 2 * SC + 1;
+    constexpr int NCH = (IC + 1 + 3) / 4 + 1, ICS = 4 * NCH;     // patch rows as 18 aligned 4-column chunks starting one column left of the patch
+    constexpr int NCHUNK = 3 * IR * NCH, PF = (NCHUNK + 255) / 256;
+    constexpr int GR = C0 / 8, NP = 9 * GR, KS1 = (NP + 3) / 4, NT1 = C1 / 16;
+    constexpr int TS = (C0 / 2 + 2) | 2;                         // pixel stride of T in dwords: 2 * odd  (24 ch: 14, 32 ch: 18)
+    static_assert((TS / 2) % 2 == 1 && TS * 2 >= C0, "T stride");
+    constexpr int TSH = TS * 2;                                  // ... in halves
+    constexpr int W0B = 2 * 64 * 16, W1B = KS1 * NT1 * 64 * 16;
+    constexpr int IN_H = 4 * NCHUNK, OUT_H = TY * TX * C1;
+    __shared__ __attribute__((aligned(16))) half_t s_in[(IN_H > OUT_H ? IN_H : OUT_H) + 8];
+    __shared__ __attribute__((aligned(16))) half_t s_T[SP * TSH + 64];
+    __shared__ __attribute__((aligned(16))) char s_w1[W1B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.rec + W0B);
+        uint4* dst = reinterpret_cast<uint4*>(s_w1);
+        for (int i = tid; i < W1B / 16; i += 256) dst[i] = src[i];
+    }
+    const half8_t w0a = reinterpret_cast<const half8_t*>(a.rec)[lane], w0b = reinterpret_cast<const half8_t*>(a.rec)[64 + lane];
+    const float* bias = reinterpret_cast<const float*>(a.rec + W0B + W1B);
+    const float b0a = bias[n], b0b = bias[16 + n];
+    float b1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) b1[t] = bias[32 + 16 * t + n];
+    int off0[8];                                                 // patch offsets of this lane's 8 taps (k = 8g + j; k >= 27 meets zero weights)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = min(8 * g + j, 26);
+        off0[j] = ((k / 9) * IR + (k % 9) / 3) * ICS + k % 3 + 1;   // + 1: the chunks start one column left of the patch
+    }
+    int off1[KS1];                                               // T offsets (halves) of this lane's (tap, group) pair in every k-step
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        const int q = min(4 * s + g, NP - 1), tap = q / GR, grp = q - tap * GR;
+        off1[s] = ((tap / 3) * SC + tap % 3) * TSH + 8 * grp;
+    }
+    const half8_t* w1 = reinterpret_cast<const half8_t*>(s_w1);
+    typedef typename Chunk<TI>::raw raw_t;
+    raw_t pf[PF];                                                // the next tile's input patch, in flight while this tile computes
+    bool pf_in[PF];
+    auto prefetch = [&](int tile) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const TI* img = static_cast<const TI*>(a.img) + (size_t)b * 3 * a.Hin * a.Win;
+        const int iy0 = 4 * ty * TY - 3, ix0 = 4 * tx * TX - 4;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = min(tid + 256 * u, NCHUNK - 1);
+            const int c = e / (IR * NCH), rem = e - c * (IR * NCH), r = rem / NCH, ch = rem - r * NCH;
+            const int iy = iy0 + r, ix = ix0 + 4 * ch;
+            pf_in[u] = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const size_t at = pf_in[u] ? ((size_t)c * a.Hin + iy) * a.Win + ix : 0;      // clamped: the load stays unconditional
+            pf[u] = *reinterpret_cast<const raw_t*>(img + at);
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const int Y0 = ty * TY, X0 = tx * TX;
+        __syncthreads();                                         // s_in (= the previous tile's output stage) and s_T are free; first pass: s_w1 is in place
+        // ---- A: input patch registers -> LDS (planar, zero outside the image)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = tid + 256 * u;
+            if (e < NCHUNK) {
+                half4_t v = Chunk<TI>::cvt(pf[u], a.in_scale);
+                if (!pf_in[u]) v = half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                *reinterpret_cast<half4_t*>(s_in + 4 * e) = v;   // chunk e = (c * IR + r) * NCH + ch sits at that index: rows are ICS = 4 NCH wide
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+        // ---- B: stem outputs of the tile on the matrix cores
+        for (int mt = wave; mt < (SP + 15) / 16; mt += 4) {
+            const int p = min(mt * 16 + n, SP - 1), r = p / SC, c = p - r * SC;
+            const half_t* base = s_in + (2 * r) * ICS + 2 * c;
+            half8_t af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = base[off0[j]];
+            const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w0a, z, 0, 0, 0);
+            const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w0b, z, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pp = mt * 16 + 4 * g + q;
+                if (pp < SP) {
+                    const int sr = pp / SC, sc = pp - sr * SC;
+                    const bool in = (unsigned)(2 * Y0 - 1 + sr) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + sc) < (unsigned)a.W0;   // else: zero padding of conv 2
+                    s_T[pp * TSH + n] = (half_t)(in ? fmaxf(ca[q] + b0a, 0.f) : 0.f);
+                    if (16 + n < C0) s_T[pp * TSH + 16 + n] = (half_t)(in ? fmaxf(cb[q] + b0b, 0.f) : 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C: second conv, implicit GEMM over (tap, 8-channel group) pairs
+        f32x4_t acc[2][NT1];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            half8_t af[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int yy = wave * 2 + m;
+                const half_t* tp = s_T + ((2 * yy) * SC + 2 * n) * TSH + off1[s];
+                const half4_t lo = *reinterpret_cast<const half4_t*>(tp), hi = *reinterpret_cast<const half4_t*>(tp + 4);
+                af[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+                const half8_t bf = w1[(s * NT1 + t) * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][t], 0, 0, 0);
+            }
+        }
+        // ---- D: bias + ReLU -> LDS (aliases the input patch: its last reader was phase B) -> whole NHWC pixels
+        half_t* s_out = s_in;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_out[((wave * 2 + m) * TX + 4 * g + q) * C1 + 16 * t + n] = (half_t)fmaxf(acc[m][t][q] + b1[t], 0.f);
+        __syncthreads();
+        constexpr int CPP = C1 / 8;                               // 16-byte pieces per pixel
+        for (int q = tid; q < TY * TX * CPP; q += 256) {
+            const int px = q / CPP, part = q - px * CPP;
+            const int oy = Y0 + px / TX, ox = X0 + px % TX;
+            if (oy < a.H1 && ox < a.W1)
+                *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H1 + oy) * a.W1 + ox) * a.out_stride + a.out_coff + 8 * part) =
+                    *reinterpret_cast<const uint4*>(s_out + px * C1 + 8 * part);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1) {
+    const int ks1 = (9 * (C0 / 8) + 3) / 4;
+    return 2 * 64 * 16 + (int64_t)ks1 * (C1 / 16) * 64 * 16 + 32 * 4 + C1 * 4;
+}
+
+int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
+    MAF_REQUIRE(op->dtype == MAF_F16, "stem2: fp16 engine only");
+    MAF_REQUIRE(op->Cin == 3 && ((op->ksize == 24 && op->Cout == 48) || (op->ksize == 32 && op->Cout == 64)), "stem2: (C0, C1) must be (24, 48) or (32, 64); ksize carries C0");
+    MAF_REQUIRE(op->act == MAF_ACT_RELU, "stem2: both RepVGG blocks end in ReLU (common.py:198)");
+    MAF_REQUIRE(op->src[0].ptr && op->w && op->out, "stem2: null pointer");
+    MAF_REQUIRE(op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "stem2: out stride/coff multiples of 8");
+    S2Args a;
+    a.img = op->src[0].ptr; a.rec = static_cast<const char*>(op->w); a.out = static_cast<half_t*>(op->out);
+    a.B = op->B; a.Hin = op->Hin; a.Win = op->Win;
+    a.H0 = (op->Hin - 1) / 2 + 1; a.W0 = (op->Win - 1) / 2 + 1;
+    a.H1 = (a.H0 - 1) / 2 + 1; a.W1 = (a.W0 - 1) / 2 + 1;
+    MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && op->Win % 4 == 0 && a.H1 == op->H && a.W1 == op->W, "stem2: H,W must be the twice-halved image size, image width a multiple of 4");
+    a.out_stride = op->out_stride; a.out_coff = op->out_coff;
+    a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, 8); a.ntiles = a.B * a.tilesX * a.tilesY;
+    a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;
+    const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : 512)), blk(256);
+#define MAF_S2(TI, C0, C1) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1>), grid, blk, 0, s, a)
+#define MAF_S2T(TI) do { if (op->Cout == 48) MAF_S2(TI, 24, 48); else MAF_S2(TI, 32, 64); } while (0)
+    if (op->in_dtype == MAF_F16) MAF_S2T(half_t);
+    else if (op->in_dtype == MAF_F32) MAF_S2T(float);
+    else if (op->in_dtype == MAF_U8) MAF_S2T(uint8_t);
+    else { maf_set_error("stem2: bad in_dtype"); return MAF_E_ARG; }
+#undef MAF_S2T
+#undef MAF_S2
+    return maf_check_hip(hipGetLastError(), "stem2 launch");
+}

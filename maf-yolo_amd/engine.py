@@ -117,6 +117,8 @@ class Plan:
         # (csrc/head_tail.hip, fp16, 80 classes, head width 64 / 128 / 192) instead of four 1x1 convs + the decode kernel
         fh = getattr(model, "fuse_head", "auto") if fuse_head is None else fuse_head
         self.fuse_head = bool(fh) and dtype == lib.F16 and model.nc == 80 and model.detect.reg_max == 16
+        self.fuse_stem = bool(getattr(model, "fuse_stem", True)) and dtype == lib.F16
+        self._stem2 = None
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
             self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
@@ -206,8 +208,22 @@ class Plan:
                 tag_lane = (3, 5, 0)[n_head % 3]      # P3 / P4 heads overlap the rest of the neck; their reg branches take lane + 1 (P5: 7)
                 tag_after = node.sources()[0]         # ... and are launched right after the node that feeds them
                 n_head += 1
-            if node.kind == "repvgg":
+            if node.kind == "repvgg" and node.i == 1 and self._stem2 is not None:
+                # backbone.0 + backbone.1 in one launch (csrc/stem2.hip): the half-resolution tensor between them stays in LDS
+                w0, b0, c0 = self._stem2
                 w, b = m.fused()
+                out = self._alloc(self.Hin // 4, self.Win // 4, node.cout)
+                self._ops.append(dict(kind=lib.OP_STEM2, name="backbone.0+1", act=lib.ACT_RELU, H=out.H, W=out.W, Hin=self.Hin, Win=self.Win,
+                                      Cin=3, Cout=node.cout, ksize=c0, segs=[], out=out, out_coff=0,
+                                      w=self._wput(pack.pack_stem2(w0, b0, w, b)), b=0))
+                y.append(TV([Seg(out, node.cout)], out.H, out.W))
+            elif node.kind == "repvgg":
+                w, b = m.fused()
+                if node.i == 0 and self.fuse_stem and len(model.nodes) > 1 and model.nodes[1].kind == "repvgg" and list(model.nodes[1].sources()) == [0] \
+                        and (node.cout, model.nodes[1].cout) in ((24, 48),) and not any(0 in n_.sources() for n_ in model.nodes[2:]):
+                    self._stem2 = (w, b, node.cout)               # emitted together with node 1
+                    y.append(None)
+                    continue
                 if node.i == 0:                   # stem: reads the caller's NCHW image
                     H, W = self.Hin // 2, self.Win // 2
                     out = self._alloc(H, W, node.cout)
@@ -417,7 +433,7 @@ class Plan:
             o.lane, o.n_wait = r["lane"], len(r["wait"])
             for k_, j in enumerate(r["wait"]):
                 o.wait[k_] = j
-            if r["kind"] == lib.OP_STEM:
+            if r["kind"] in (lib.OP_STEM, lib.OP_STEM2):
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call
                 o.src[0].C = 3
@@ -647,6 +663,8 @@ class Plan:
             return "conv1dw_kernel<%d>" % o.ksize
         if o.kind == lib.OP_HEADTAIL:
             return "head_tail_kernel<%d, %d>" % (o.Cin, 2 if o.Cin <= 128 else 1)
+        if o.kind == lib.OP_STEM2:
+            return "stem2_kernel<%d, %d>" % (o.ksize, o.Cout)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -658,6 +676,9 @@ class Plan:
         if o.kind == lib.OP_STEM:
             ies = {lib.F16: 2, lib.F32: 4, lib.U8: 1}[o.in_dtype]
             return self.B * 3 * o.Hin * o.Win * ies + px * o.Cout * es + 27 * o.Cout * 4
+        if o.kind == lib.OP_STEM2:
+            ies = {lib.F16: 2, lib.F32: 4, lib.U8: 1}[o.in_dtype]
+            return self.B * 3 * o.Hin * o.Win * ies + px * o.Cout * es + (27 * o.ksize + 9 * o.ksize * o.Cout) * es
         if o.kind == lib.OP_CONV1X1:
             rd = 0
             for i in range(o.nsrc):
@@ -687,6 +708,8 @@ class Plan:
         px = self.B * o.H * o.W
         if o.kind == lib.OP_STEM:
             return 2 * px * 27 * o.Cout
+        if o.kind == lib.OP_STEM2:
+            return 2 * (4 * px * 27 * o.ksize + px * 9 * o.ksize * o.Cout)
         if o.kind == lib.OP_CONV1X1:
             return 2 * px * o.Cin * o.Cout
         if o.kind == lib.OP_CONV3X3S2:
@@ -705,7 +728,7 @@ class Plan:
     def launch_op(self, idx, image_ptr=None, pred_ptr=None):
         """Launch a single op of the plan (profiling / per-kernel timing)."""
         op = self.ops[idx]
-        if op.kind == lib.OP_STEM and image_ptr is not None:
+        if op.kind in (lib.OP_STEM, lib.OP_STEM2) and image_ptr is not None:
             op.src[0].ptr = image_ptr
         if op.kind in (lib.OP_DECODE, lib.OP_HEADTAIL) and pred_ptr is not None:
             op.out = pred_ptr

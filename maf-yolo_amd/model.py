@@ -101,6 +101,7 @@ class Model(nn.Module):
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
+        self.fuse_stem = True                 # backbone.0 + backbone.1 in one launch (csrc/stem2.hip; fp16 plans, (24, 48) channels = scale n)
         self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine

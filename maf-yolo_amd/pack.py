@@ -206,3 +206,30 @@ def pack_head_tail(w1, b1, w2, b2):
                      b1.detach().float().cpu().contiguous().view(torch.uint8), b2p.view(torch.uint8)])
     assert rec.numel() == C * C * 2 + 80 * C * 2 + C * 4 + 320
     return rec
+
+
+def pack_stem2(w0, b0, w1, b1):
+    """Record of MAF_OP_STEM2 (csrc/stem2.hip): backbone.0 w0 [C0,3,3,3] + b0 and backbone.1 w1 [C1,C0,3,3] + b1, both in deploy form.
+    Layout: B fragments of conv 0 [2 tiles][64 lanes][8] f16 (lane (g, n): tap k = 8g + j = (c*3 + ky)*3 + kx, output channel 16t + n;
+    zero for k >= 27 and channels >= C0) | B fragments of conv 1 [ceil(9*C0/8 / 4)][C1/16][64][8] f16 (lane (g, n) of k-step s: pair
+    q = 4s + g -> tap q // (C0/8), channel group q % (C0/8); element j = input channel 8*group + j; output channel 16t + n; zero for
+    pairs past the last tap) | b0 fp32 [32] (zero padded) | b1 fp32 [C1]."""
+    w0 = w0.detach().float().cpu(); w1 = w1.detach().float().cpu()
+    C0, C1 = w0.shape[0], w1.shape[0]
+    assert w0.shape[1:] == (3, 3, 3) and w1.shape[1:] == (C0, 3, 3) and C0 % 8 == 0 and C0 <= 32 and C1 % 16 == 0
+    m0 = torch.zeros(32, 32)                                          # [k][channel]
+    m0[:27, :C0] = w0.reshape(C0, 27).t()
+    f0 = m0.view(4, 8, 2, 16).permute(2, 0, 3, 1).contiguous().half()           # [t][g][n][j]
+    gr = C0 // 8
+    npair = 9 * gr
+    ks1 = (npair + 3) // 4
+    m1 = torch.zeros(ks1 * 4, 8, C1)                                 # [pair][j][out channel]
+    for q in range(npair):
+        tap, grp = divmod(q, gr)
+        m1[q] = w1[:, 8 * grp:8 * grp + 8, tap // 3, tap % 3].t()
+    f1 = m1.view(ks1, 4, 8, C1 // 16, 16).permute(0, 3, 1, 4, 2).contiguous().half()   # [s][t][g][n][j]
+    b0p = torch.zeros(32); b0p[:C0] = b0.detach().float().cpu()
+    rec = torch.cat([f0.reshape(-1).view(torch.uint8), f1.reshape(-1).view(torch.uint8), b0p.view(torch.uint8),
+                     b1.detach().float().cpu().contiguous().view(torch.uint8)])
+    assert rec.numel() == 2048 + ks1 * (C1 // 16) * 1024 + 128 + C1 * 4
+    return rec

@@ -298,6 +298,34 @@ def test_fused_head_tail_matches_unfused(shape):
     assert np.abs(a[..., :4] - b[..., :4]).mean() <= 2e-3
 
 
+@pytest.mark.parametrize("shape,dt", [((2, 320, 320), "f16"), ((3, 256, 384), "u8"), ((2, 352, 608), "f16"), ((32, 640, 640), "u8"), ((1, 64, 96), "f32")])
+def test_fused_stem_matches_unfused(shape, dt):
+    """MAF_OP_STEM2 (backbone.0 + backbone.1 in one launch, both on the matrix cores, the half-resolution tensor in LDS) vs the VALU stem +
+    the 3x3 s2 MFMA conv: node 1's output to fp16 rounding (the fused stem rounds its weights to fp16, the VALU stem keeps them fp32),
+    predictions within the fp16 class.  Tiles that hang over the map (88 x 152, 16 x 24) and every input dtype."""
+    B, H, W = shape
+    img = O.synth_images(B, max(H, W), 23)[:, :, :H, :W].contiguous()
+    x = {"f16": img.half(), "f32": img, "u8": (img * 255).round().to(torch.uint8)}[dt].to(DEV)
+    outs, taps, nops = {}, {}, {}
+    for fs in (True, False):
+        m = M.Model("n", precision="fp16")
+        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = m.to(DEV).eval()
+        m.fuse_stem = fs
+        with torch.no_grad():
+            outs[fs] = m(x)[0].float().cpu().numpy()
+        plan = m.plan_for(x)
+        assert (plan.ops[0].kind == 9) == fs
+        nops[fs] = len(plan.ops)
+        o = plan.ops[0 if fs else 1]
+        off = o.out - plan.arena.data_ptr()
+        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * 48 * 2].view(torch.float16).view(B, H // 4, W // 4, 48).float().cpu().numpy()
+    assert nops[True] == nops[False] - 1
+    d = np.abs(taps[True] - taps[False])
+    assert d.max() <= 2e-2 * max(1.0, np.abs(taps[False]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[False]).mean())
+    _close16(outs[True], outs[False])
+
+
 def test_fusion_choice_is_measured_when_autotuning():
     from maf_yolo_amd import engine
     m = M.Model("n")
@@ -311,7 +339,7 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 77 - 2 * nf - npart          # 90 launches unfused; the fused head (one depth-wise + one tail per level) takes 13 off
+    assert len(plan.ops) == 76 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem: -1
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):

@@ -146,6 +146,7 @@ def test_pack_layout():
 def test_plan_builds_on_cpu(built, scale, nops):
     m = M.Model(scale).eval()
     m.fuse_head = False
+    m.fuse_stem = False
     plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
     lo, hi = plan._abase, plan._abase + plan._arena_size
@@ -178,6 +179,12 @@ def test_plan_builds_on_cpu(built, scale, nops):
     else:
         assert len(ht.ops) == nops
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops
+    m.fuse_stem = True                             # backbone.0 + backbone.1 in one launch (scale n: 24 -> 48 channels)
+    st = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
+    if scale == "n":
+        assert len(st.ops) == len(ht.ops) - 1 and st.ops[0].kind == lib.OP_STEM2 and (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].H, st.ops[0].Hin) == (24, 48, 16, 64)
+    else:
+        assert len(st.ops) == len(ht.ops) and st.ops[0].kind == lib.OP_STEM
 
 
 def test_product_synth_generator_equals_oracle_generator():
