@@ -6,7 +6,8 @@
 // One workgroup iteration = a 8 x 16 tile of the final map:
 //   A  the 35 x 67 x 3 input patch goes to LDS (planar, zero outside the image);
 //   B  the 17 x 33 stem outputs the tile needs are computed on the matrix cores: K = 27 taps (padded to 32) gathered from the patch
-//      into A fragments (8 two-byte LDS reads per lane), weights as B fragments in registers, bias + ReLU, fp16, stored pixel-major
+//      into fragments (8 two-byte LDS reads per lane), weight fragments in registers, product taken transposed so a lane holds 4
+//      consecutive channels of one pixel (8-byte LDS stores), bias + ReLU, fp16, stored pixel-major
 //      in LDS with a 56-byte pixel stride (stride-2 reads of 16 lanes then cover all 64 banks); positions outside the stem map are
 //      the second conv's zero padding;
 //   C  the second conv as an implicit GEMM: K = 9 taps x 24 channels = 27 (tap, 8-channel) pairs, four pairs per MFMA k-step,
@@ -64,10 +65,10 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
     }
     const half8_t w0a = reinterpret_cast<const half8_t*>(a.rec)[lane], w0b = reinterpret_cast<const half8_t*>(a.rec)[64 + lane];
     const float* bias = reinterpret_cast<const float*>(a.rec + W0B + W1B);
-    const float b0a = bias[n], b0b = bias[16 + n];
-    float b1[NT1];
+    const f32x4_t b0a = *reinterpret_cast<const f32x4_t*>(bias + 4 * g), b0b = *reinterpret_cast<const f32x4_t*>(bias + 16 + 4 * g);   // lane (g, n): channels 16t + 4g + q
+    f32x4_t b1[NT1];
 #pragma unroll
-    for (int t = 0; t < NT1; ++t) b1[t] = bias[32 + 16 * t + n];
+    for (int t = 0; t < NT1; ++t) b1[t] = *reinterpret_cast<const f32x4_t*>(bias + 32 + 16 * t + 4 * g);
     int off0[8];                                                 // patch offsets of this lane's 8 taps (k = 8g + j; k >= 27 meets zero weights)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -115,29 +116,31 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
         }
         __syncthreads();
         if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
-        // ---- B: stem outputs of the tile on the matrix cores
+        // ---- B: stem outputs of the tile on the matrix cores, computed transposed (A = weights, B = gathered taps) so that a lane ends
+        //      up with 4 consecutive channels of ONE pixel: one 8-byte LDS store per 16-channel tile
         for (int mt = wave; mt < (SP + 15) / 16; mt += 4) {
-            const int p = min(mt * 16 + n, SP - 1), r = p / SC, c = p - r * SC;
+            const int pp = mt * 16 + n, p = min(pp, SP - 1), r = p / SC, c = p - r * SC;
             const half_t* base = s_in + (2 * r) * ICS + 2 * c;
-            half8_t af;
+            half8_t bf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = base[off0[j]];
+            for (int j = 0; j < 8; ++j) bf[j] = base[off0[j]];
             const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w0a, z, 0, 0, 0);
-            const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, w0b, z, 0, 0, 0);
+            const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0a, bf, z, 0, 0, 0);
+            const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, bf, z, 0, 0, 0);
+            if (pp < SP) {
+                const bool in = (unsigned)(2 * Y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + c) < (unsigned)a.W0;   // else: zero padding of conv 2
+                half4_t va, vb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pp = mt * 16 + 4 * g + q;
-                if (pp < SP) {
-                    const int sr = pp / SC, sc = pp - sr * SC;
-                    const bool in = (unsigned)(2 * Y0 - 1 + sr) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + sc) < (unsigned)a.W0;   // else: zero padding of conv 2
-                    s_T[pp * TSH + n] = (half_t)(in ? fmaxf(ca[q] + b0a, 0.f) : 0.f);
-                    if (16 + n < C0) s_T[pp * TSH + 16 + n] = (half_t)(in ? fmaxf(cb[q] + b0b, 0.f) : 0.f);
+                for (int q = 0; q < 4; ++q) {
+                    va[q] = (half_t)(in ? fmaxf(ca[q] + b0a[q], 0.f) : 0.f);
+                    vb[q] = (half_t)(in ? fmaxf(cb[q] + b0b[q], 0.f) : 0.f);
                 }
+                *reinterpret_cast<half4_t*>(s_T + pp * TSH + 4 * g) = va;
+                if (16 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 16 + 4 * g) = vb;
             }
         }
         __syncthreads();
-        // ---- C: second conv, implicit GEMM over (tap, 8-channel group) pairs
+        // ---- C: second conv, implicit GEMM over (tap, 8-channel group) pairs, transposed as well (A = weight fragments, B = T)
         f32x4_t acc[2][NT1];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -145,19 +148,19 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
             for (int t = 0; t < NT1; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS1; ++s) {
-            half8_t af[2];
+            half8_t tf[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int yy = wave * 2 + m;
                 const half_t* tp = s_T + ((2 * yy) * SC + 2 * n) * TSH + off1[s];
                 const half4_t lo = *reinterpret_cast<const half4_t*>(tp), hi = *reinterpret_cast<const half4_t*>(tp + 4);
-                af[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                tf[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int t = 0; t < NT1; ++t) {
-                const half8_t bf = w1[(s * NT1 + t) * 64 + lane];
+                const half8_t wf = w1[(s * NT1 + t) * 64 + lane];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, tf[m], acc[m][t], 0, 0, 0);
             }
         }
         // ---- D: bias + ReLU -> LDS (aliases the input patch: its last reader was phase B) -> whole NHWC pixels
@@ -165,9 +168,12 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < NT1; ++t)
+            for (int t = 0; t < NT1; ++t) {
+                half4_t v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s_out[((wave * 2 + m) * TX + 4 * g + q) * C1 + 16 * t + n] = (half_t)fmaxf(acc[m][t][q] + b1[t], 0.f);
+                for (int q = 0; q < 4; ++q) v[q] = (half_t)fmaxf(acc[m][t][q] + b1[t][q], 0.f);
+                *reinterpret_cast<half4_t*>(s_out + ((wave * 2 + m) * TX + n) * C1 + 16 * t + 4 * g) = v;
+            }
         __syncthreads();
         constexpr int CPP = C1 / 8;                               // 16-byte pieces per pixel
         for (int q = tid; q < TY * TX * CPP; q += 256) {
