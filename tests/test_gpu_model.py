@@ -298,8 +298,9 @@ def test_fused_head_tail_matches_unfused(shape):
     assert np.abs(a[..., :4] - b[..., :4]).mean() <= 2e-3
 
 
-@pytest.mark.parametrize("shape,dt", [((2, 320, 320), "f16"), ((3, 256, 384), "u8"), ((2, 352, 608), "f16"), ((32, 640, 640), "u8"), ((1, 64, 96), "f32")])
-def test_fused_stem_matches_unfused(shape, dt):
+@pytest.mark.parametrize("shape,dt,scale", [((2, 320, 320), "f16", "n"), ((3, 256, 384), "u8", "n"), ((2, 352, 608), "f16", "n"), ((32, 640, 640), "u8", "n"),
+                                            ((1, 64, 96), "f32", "n"), ((2, 320, 352), "f16", "s"), ((2, 96, 64), "u8", "s")])
+def test_fused_stem_matches_unfused(shape, dt, scale):
     """MAF_OP_STEM2 (backbone.0 + backbone.1 in one launch, both on the matrix cores, the half-resolution tensor in LDS) vs the VALU stem +
     the 3x3 s2 MFMA conv: node 1's output to fp16 rounding (the fused stem rounds its weights to fp16, the VALU stem keeps them fp32),
     predictions within the fp16 class.  Tiles that hang over the map (88 x 152, 16 x 24) and every input dtype."""
@@ -308,8 +309,8 @@ def test_fused_stem_matches_unfused(shape, dt):
     x = {"f16": img.half(), "f32": img, "u8": (img * 255).round().to(torch.uint8)}[dt].to(DEV)
     outs, taps, nops = {}, {}, {}
     for fs in (True, False):
-        m = M.Model("n", precision="fp16")
-        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = M.Model(scale, precision="fp16")
+        m.load_state_dict(O.synth_state_dict(scale, 0))
         m = m.to(DEV).eval()
         m.fuse_stem = fs
         with torch.no_grad():
@@ -319,7 +320,8 @@ def test_fused_stem_matches_unfused(shape, dt):
         nops[fs] = len(plan.ops)
         o = plan.ops[0 if fs else 1]
         off = o.out - plan.arena.data_ptr()
-        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * 48 * 2].view(torch.float16).view(B, H // 4, W // 4, 48).float().cpu().numpy()
+        c1 = o.Cout
+        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * c1 * 2].view(torch.float16).view(B, H // 4, W // 4, c1).float().cpu().numpy()
     assert nops[True] == nops[False] - 1
     d = np.abs(taps[True] - taps[False])
     assert d.max() <= 2e-2 * max(1.0, np.abs(taps[False]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[False]).mean())

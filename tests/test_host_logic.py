@@ -181,8 +181,9 @@ def test_plan_builds_on_cpu(built, scale, nops):
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops
     m.fuse_stem = True                             # backbone.0 + backbone.1 in one launch (scale n: 24 -> 48 channels)
     st = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
-    if scale == "n":
-        assert len(st.ops) == len(ht.ops) - 1 and st.ops[0].kind == lib.OP_STEM2 and (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].H, st.ops[0].Hin) == (24, 48, 16, 64)
+    if scale in ("n", "s"):
+        assert len(st.ops) == len(ht.ops) - 1 and st.ops[0].kind == lib.OP_STEM2
+        assert (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].H, st.ops[0].Hin) == {"n": (24, 48, 16, 64), "s": (32, 64, 16, 64)}[scale]
     else:
         assert len(st.ops) == len(ht.ops) and st.ops[0].kind == lib.OP_STEM
 
