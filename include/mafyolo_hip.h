@@ -91,7 +91,8 @@ typedef struct {
  *                   out = pred fp32 [B, A, 85] (supplied per run like DECODE's); Hin = first anchor of the level, Win = A (anchors
  *                   per image), lvl_stride[0] = stride; nc = 80, reg_max = 16; fp16 only.  tile_k = units per wave (0 = auto).
  * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
- *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride];
+ *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride] (both NULL: the level's rows are
+ *                   written by a MAF_OP_HEADTAIL, lvl_h / lvl_w still give its size);
  *                   out = pred fp32 [B, A, 5+nc].
  */
 typedef struct {

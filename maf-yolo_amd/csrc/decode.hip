@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
     const int l = (blk >= a.lvl_blk[1]) + (blk >= a.lvl_blk[2]);
     blk -= a.lvl_blk[l];
     const int L = a.lvl_h[l] * a.lvl_w[l];
+    if ((l == 0 ? a.cls[0] : l == 1 ? a.cls[1] : a.cls[2]) == nullptr) return;   // this level's rows were written by MAF_OP_HEADTAIL
     const int a0 = blk * 64;                       // first anchor (within level)
     const int nA = min(64, L - a0);
     const float* reg = (l == 0 ? a.reg[0] : l == 1 ? a.reg[1] : a.reg[2]) + ((size_t)b * L + a0) * a.reg_stride;
@@ -93,7 +94,7 @@ int maf_launch_decode(const maf_op_t* op, hipStream_t s) {
     DecArgs a;
     int off = 0, blk = 0;
     for (int l = 0; l < 3; ++l) {
-        MAF_REQUIRE(op->src[l].ptr && op->reg[l] && op->lvl_h[l] > 0 && op->lvl_w[l] > 0, "decode: null level tensor");
+        MAF_REQUIRE((op->src[l].ptr != nullptr) == (op->reg[l] != nullptr) && op->lvl_h[l] > 0 && op->lvl_w[l] > 0, "decode: cls and reg of a level come together (both null: level decoded elsewhere)");
         a.cls[l] = static_cast<const float*>(op->src[l].ptr);
         a.reg[l] = static_cast<const float*>(op->reg[l]);
         a.lvl_h[l] = op->lvl_h[l]; a.lvl_w[l] = op->lvl_w[l]; a.lvl_stride[l] = op->lvl_stride[l];

@@ -192,7 +192,7 @@ class Plan:
         B = self.B
         y = []                                   # TV (or list of head tuples) per node
         self.head_bufs = []
-        self.fuse_head = self.fuse_head and not self.lanes and all(n.cout in (64, 128, 192) for n in model.nodes if n.kind == "head")   # all levels or none
+        self.fuse_head = self.fuse_head and not self.lanes                     # per level: head widths 64 / 128 / 192 take the fused tail
         n_side = n_head = 0
         for node, m in zip(model.nodes, model.backbone):
             if node.i > 0:                            # tag the ops of the previous node (lane = HIP stream of the engine)
@@ -304,7 +304,7 @@ class Plan:
                 t = self._alloc(x.H, x.W, c)
                 self._conv1x1(p + ".stem", *m.stem.fused(), x, t, 0, lib.ACT_SILU)
                 tv = TV([Seg(t, c)], x.H, x.W)
-                if self.fuse_head:
+                if self.fuse_head and c in (64, 128, 192):
                     # cls_conv and reg_conv read the same tensor: ONE depth-wise launch with two filters per input channel
                     (wc, bc), (wr, brg) = m.cls_conv.fused(), m.reg_conv.fused()
                     assert wc.shape == wr.shape
@@ -339,8 +339,7 @@ class Plan:
         assert len(self.head_bufs) == 3, "MAF-YOLO has three detection levels"
         self.A = sum(t.H * t.W for t, _, _ in self.head_bufs)
         fused = [c is None for _, c, _ in self.head_bufs]
-        assert all(fused) or not any(fused), "head fusion is all levels or none"
-        if not any(fused):
+        if not all(fused):                           # the decode kernel skips the levels a fused tail has written
             self._ops.append(dict(kind=lib.OP_DECODE, name="detect", act=0, H=0, W=0, Cin=0, Cout=0, segs=[], out=None, out_coff=0))
 
     # ---------------------------------------------------------------- lanes and cross-lane dependencies
@@ -444,8 +443,9 @@ class Plan:
             if r["kind"] == lib.OP_DECODE:
                 o.nsrc = 3
                 for l, (t, cls, reg) in enumerate(self.head_bufs):
-                    o.src[l].ptr = abase + cls.off
-                    o.reg[l] = abase + reg.off
+                    if cls is not None:
+                        o.src[l].ptr = abase + cls.off
+                        o.reg[l] = abase + reg.off
                     o.lvl_h[l], o.lvl_w[l], o.lvl_stride[l] = t.H, t.W, self.strides[l]
                 o.reg_stride, o.nc, o.reg_max = 4 * (self.reg_max + 1), self.nc, self.reg_max
         self.ops = ops
@@ -700,7 +700,8 @@ class Plan:
         if o.kind == lib.OP_HEADTAIL:                          # both branch inputs once, the prediction rows once, the two weight records
             return px * (2 * o.Cin * es + (5 + self.nc) * 4) + 2 * (o.Cin * o.Cin + 80 * o.Cin) * es
         if o.kind == lib.OP_DECODE:
-            return self.B * self.A * ((self.nc + 4 * (self.reg_max + 1)) * 4 + (5 + self.nc) * 4)
+            anchors = sum(t.H * t.W for t, c, _ in self.head_bufs if c is not None)          # levels a fused tail did not take
+            return self.B * anchors * ((self.nc + 4 * (self.reg_max + 1)) * 4 + (5 + self.nc) * 4)
         return 0
 
     def flops(self, idx):

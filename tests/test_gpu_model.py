@@ -269,23 +269,24 @@ def test_fused_bottleneck_plan_matches_unfused(models):
     _close16(outs[2], outs[False])
 
 
-@pytest.mark.parametrize("shape", [(2, 320, 320), (3, 256, 384), (32, 640, 640)])
-def test_fused_head_tail_matches_unfused(shape):
+@pytest.mark.parametrize("shape,scale", [((2, 320, 320), "n"), ((3, 256, 384), "n"), ((32, 640, 640), "n"), ((2, 320, 256), "s")])
+def test_fused_head_tail_matches_unfused(shape, scale):
     """MAF_OP_HEADTAIL ({cls,reg}_conv_s -> pred -> sigmoid / DFL decode, one launch per level) vs four 1x1 convs + the decode kernel:
     same fp16 rounding points, so only the fp32 summation order differs."""
     B, H, W = shape
     x = O.synth_images(B, max(H, W), 21)[:, :, :H, :W].contiguous().to(DEV).half()
     outs = {}
+    nlev = {"n": 3, "s": 2}[scale]                      # s: the 256-wide P5 level keeps the four convs + the decode kernel (which skips the other two)
     for fh in (True, False):
-        m = M.Model("n")
-        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = M.Model(scale)
+        m.load_state_dict(O.synth_state_dict(scale, 0))
         m = m.to(DEV).eval()
         m.fuse_head = fh
         with torch.no_grad():
             pred, feats = m(x)
         outs[fh] = pred.float().cpu().numpy()
         kinds = [o.kind for o in m.plan_for(x).ops]
-        assert (kinds.count(8) == 3 and 5 not in kinds) if fh else (8 not in kinds and kinds.count(5) == 1)
+        assert (kinds.count(8) == nlev and kinds.count(5) == (nlev < 3)) if fh else (8 not in kinds and kinds.count(5) == 1)
         assert (feats[0][1] is None) == fh and feats[0][0] is not None
         if fh:                                    # asking for the head tensors (val_loss) selects a plan that materialises them
             with torch.no_grad():
