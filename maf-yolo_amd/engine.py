@@ -502,8 +502,12 @@ class Plan:
                 if best is None:
                     n = 8 if self.dtype == lib.F16 else 4
                     results = []
-                    for th in (4, 8, 16, 32):
-                        for tw in (8, 16, 32):
+                    # tile heights / widths: powers of two plus the map's own size and its half (40 x 40 and 20 x 20 maps: tiles that
+                    # divide the map exactly have no half-empty edge tiles and the smallest halo share)
+                    ths = sorted({4, 8, 16, 32} | {v for v in (o.H, o.H // 2) if 8 <= v <= 40})
+                    tws = sorted({8, 16, 32} | {v for v in (o.W, o.W // 2) if 8 <= v <= 40 and v % 4 == 0})
+                    for th in ths:
+                        for tw in tws:
                             for cbm in (8, 4, 2):
                                 t_h, t_w, cb = min(th, o.H), min(tw, -(-o.W // 4) * 4), min(cbm * n, -(-o.Cin // n) * n)
                                 lds = ((t_h + o.ksize - 1) * (t_w + o.ksize - 1) * (cb // n + 2) + o.ksize * o.ksize * (cb // n)) * 16
