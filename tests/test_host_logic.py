@@ -236,3 +236,43 @@ def test_checkpoint_bridge_reads_reference_pt_without_reference_code(golden):
     assert abs(float(sum(v.double().sum() for v in msd.values())) - float(g["checksum"][0])) < 1e-6 * abs(float(g["checksum"][0])) + 1e-6   # the EMA weights
     back = checkpoint.reference_state_dict(m)
     assert list(back) == list(msd)
+
+
+def test_fused_kernel_records_match_the_c_abi_sizes(built):
+    """pack_head_tail / pack_stem2 produce exactly the bytes the C side declares, with the documented fragment layout."""
+    g = torch.Generator().manual_seed(5)
+    for C in (64, 128, 192):
+        w1, b1 = torch.randn(C, C, 1, 1, generator=g), torch.randn(C, generator=g)
+        w2, b2 = torch.randn(68, C, 1, 1, generator=g), torch.randn(68, generator=g)
+        rec = pack.pack_head_tail(w1, b1, w2, b2)
+        assert rec.numel() == built.maf_head_tail_record_bytes(C)
+        f1 = rec[:C * C * 2].view(torch.float16).view(C // 16, C // 32, 4, 16, 8)            # [t][ks][g][i][j]
+        t, ks, gg, i, j = 1, C // 32 - 1, 3, 5, 6
+        assert f1[t, ks, gg, i, j] == w1[16 * t + i, 32 * ks + 8 * gg + j, 0, 0].half()
+        f2 = rec[C * C * 2:C * C * 2 + 80 * C * 2].view(torch.float16).view(5, C // 32, 4, 16, 8)   # [t2][j][g][n][q]
+        t2, jj, gg, n, q = 4, 1, 2, 3, 5                                                       # column 67: the last real DFL logit
+        assert f2[t2, jj, gg, n, q] == w2[16 * t2 + n, 32 * jj + 16 + 4 * gg + q - 4, 0, 0].half()
+        assert torch.all(f2[4, :, :, 4:, :] == 0)                                             # columns 68..79: zero padding
+        tail = rec[C * C * 2 + 80 * C * 2:].view(torch.float32)
+        assert torch.equal(tail[:C], b1) and torch.equal(tail[C:C + 68], b2) and torch.all(tail[C + 68:] == 0)
+    for c0, c1 in ((24, 48), (32, 64)):
+        w0, b0 = torch.randn(c0, 3, 3, 3, generator=g), torch.randn(c0, generator=g)
+        w1, b1 = torch.randn(c1, c0, 3, 3, generator=g), torch.randn(c1, generator=g)
+        rec = pack.pack_stem2(w0, b0, w1, b1)
+        assert rec.numel() == built.maf_stem2_record_bytes(c0, c1)
+        f0 = rec[:2048].view(torch.float16).view(2, 4, 16, 8)                                  # [t][g][n][j]
+        assert f0[1, 2, 3, 4] == w0[19, 2, 0, 2].half()                                        # k = 8*2+4 = 20 = (c 2, ky 0, kx 2), channel 16+3
+        assert torch.all(f0[:, 3, :, 3:] == 0)                                                 # taps 27..31 do not exist
+        gr = c0 // 8
+        ks1 = (9 * gr + 3) // 4
+        f1 = rec[2048:2048 + ks1 * (c1 // 16) * 1024].view(torch.float16).view(ks1, c1 // 16, 4, 16, 8)   # [s][t][g][n][j]
+        s_, t, gg, n, j = 2, 1, 1, 7, 3
+        tap, grp = divmod(4 * s_ + gg, gr)
+        assert f1[s_, t, gg, n, j] == w1[16 * t + n, 8 * grp + j, tap // 3, tap % 3].half()
+
+
+def test_training_loss_has_no_cpu_path():
+    crit = M.ComputeLoss()
+    feats = [torch.zeros(1, 8, s, s) for s in (8, 4, 2)]
+    with pytest.raises(lib.MafError):
+        crit((feats, torch.rand(1, 84, 80), torch.randn(1, 84, 68)), torch.zeros(0, 6), 0, 0)
