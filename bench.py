@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
     ap.add_argument("--lanes", type=int, default=-1, help="engine streams: 0 one stream, 1 heads on side streams, 2 heads + neck side convs (default: the model's setting)")
     ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight in the timed serving loop: step i runs on HIP stream i %% S with its own activation arena "
+                         "(1 = one stream; the NMS of a batch still overlaps the next forward)")
     ap.add_argument("--tune-file", default=None,
                     help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning")
     ap.add_argument("--train", action="store_true",
@@ -236,19 +239,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    S = max(1, args.inflight)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+
     def pipelined(n):
-        """n steps of the serving loop: every step = one forward + one NMS of a batch; the NMS of batch i runs on a side stream while the
-        forward of batch i+1 is issued (same work per step as step(): nothing is skipped, all n forwards and all n NMS results are complete
-        when this returns)."""
-        pending, dets = None, None
-        for _ in range(n):
-            with torch.no_grad():
-                pred_i = model(x)[0]
-            h = M.non_max_suppression_async(pred_i, conf, iou, multi_label=True)
-            if pending is not None:
-                dets = pending.result()
-            pending = h
-        return pending.result()
+        """n steps of the serving loop: every step = one forward + one NMS of a batch.  Up to S batches are in flight: step i runs on
+        stream i % S with that slot's own activation arena (Model.forward(slot=)), its NMS goes to a side stream, and its result is
+        collected when the slot comes round again.  Same work per step as step(): nothing is skipped, all n forwards and all n NMS
+        results are complete when this returns."""
+        pending, dets = [], None
+        for i in range(n):
+            k = i % S
+            with torch.cuda.stream(streams[k]), torch.no_grad():
+                pred_i = model(x, slot=k)[0]
+                pending.append(M.non_max_suppression_async(pred_i, conf, iou, multi_label=True))
+            if len(pending) > S:                                   # collect batch i - S once batch i is queued
+                dets = pending.pop(0).result()
+        for h in pending:
+            dets = h.result()
+        return dets
 
     # ---- the timed region: K steps of forward + NMS, software-pipelined across steps (the host-side hand-over of the NMS result — a
     #      count read-back and 32 slices — otherwise idles the GPU for 0.1-0.3 ms per step, and makes the number follow host jitter)
@@ -267,6 +276,18 @@ def main():
         elapsed = t.item()
     ms_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
+
+    # ---- one batch in flight (one stream; only the NMS of batch i overlaps the forward of batch i+1), rank-local
+    one_ms = None
+    if S > 1:
+        S_keep, streams_keep = S, streams
+        S, streams = 1, [torch.cuda.current_stream(dev)]
+        sync_all()
+        t0 = time.perf_counter()
+        dets = pipelined(args.steps)
+        torch.cuda.synchronize(dev)
+        one_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        S, streams = S_keep, streams_keep
 
     # ---- the same steps strictly one after the other (forward, NMS, result on the host, next forward), rank-local
     sync_all()
@@ -334,6 +355,7 @@ def main():
                         whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), GFLOP=round(tot_flops / 1e9, 2),
                                            sum_kernel_ms=round(float(per_op_ms.sum()), 4),
                                            hbm_frac=round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           hbm_frac_timed_region=round(tot_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            mfma_frac=round(tot_flops / (fwd_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 5)))
         if args.per_op:
             order = np.argsort(-per_op_ms)
@@ -382,11 +404,14 @@ def main():
                                       "forward + NMS(conf 0.03, iou 0.65, multi_label); synthetic seeded weights, cls bias "
                                       "calibrated (%+.2f) to ~2000 candidates/img" % (args.scale, B, shift),
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": "replicas x%d (no collective)" % world,
-                          "execution": "K steps of forward + NMS, software-pipelined: the NMS of batch i runs on a side stream while the forward of "
-                                       "batch i+1 is issued; all K forwards and K NMS results complete inside the timed region",
+                          "execution": "K steps of forward + NMS of one batch each; %d batches in flight (step i on HIP stream i %% %d with its own "
+                                       "activation arena, its NMS on a side stream); all K forwards and K NMS results complete inside the timed region" % (S, S),
+                          "batches_in_flight": S,
                           "nms_candidates_per_image": {"mean": round(cand_mean, 1), "max": cand_max},
                           "detections_per_image_mean": round(float(np.mean([d.shape[0] for d in dets])), 1)},
                "forward_only": {"ms_per_step": round(fwd_ms, 4), "images_per_s_per_gpu": round(B / (fwd_ms * 1e-3), 1)},
+               "one_in_flight": None if one_ms is None else {"ms_per_step": round(one_ms, 4), "images_per_s_per_gpu": round(B / (one_ms * 1e-3), 1),
+                                                              "note": "one stream, one arena: only the NMS of batch i overlaps the forward of batch i+1 (rank-local)"},
                "sequential": {"ms_per_step": round(seq_ms, 4), "images_per_s_per_gpu": round(B / (seq_ms * 1e-3), 1),
                               "note": "the same steps with no overlap: forward, NMS, result handed to the host, next forward (rank-local); the GPU idles "
                                       "during the host hand-over, so this one follows host jitter"},

@@ -158,8 +158,11 @@ class Model(nn.Module):
             y.append(x)
         return x                              # list of three (stem, cls, reg)
 
-    def plan_for(self, x, head_feats=False):
-        """head_feats: the caller wants the per-level cls / reg tensors (featmaps): plan without the fused head tail."""
+    def plan_for(self, x, head_feats=False, slot=0):
+        """head_feats: the caller wants the per-level cls / reg tensors (featmaps): plan without the fused head tail.
+        slot: plans of different slots own different activation arenas, so forwards of different slots may be in flight at the same time
+        on different HIP streams (a serving loop alternates slots: the small-map kernels of one batch run under the big-map kernels of
+        the other)."""
         if not x.is_cuda:
             raise lib.MafError("MAF-YOLO eval forward runs on the HIP engine only: got a %s tensor (no CPU fallback)" % x.device)
         B, ch, H, W = x.shape
@@ -179,7 +182,7 @@ class Model(nn.Module):
         else:
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
         fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
-        key = (B, H, W, dt, in_dt, x.device.index, fuse_head)
+        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 8:
@@ -194,13 +197,13 @@ class Model(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def forward(self, x, val_loss=False):
+    def forward(self, x, val_loss=False, slot=0):
         if self.training:
             if x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
             heads = self._forward_train_form(x)
             return [self.detect(heads), list(heads)]
-        plan = self.plan_for(x, head_feats=val_loss)
+        plan = self.plan_for(x, head_feats=val_loss, slot=slot)
         x = x.contiguous()
         with torch.cuda.device(x.device):
             pred = plan.run(x, graph=False)          # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)

@@ -67,11 +67,13 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
 class NmsHandle:
     """In-flight NMS of one batch (see non_max_suppression_async)."""
 
-    def __init__(self, rows, idx, cnt, event):
+    def __init__(self, rows, idx, cnt, event, keep=None):
         self.rows, self.idx, self.cnt, self.event = rows, idx, cnt, event
+        self._keep = keep                                  # the prediction tensor: alive until the side stream has read it
 
     def result(self, return_index=False):
         self.event.synchronize()
+        self._keep = None
         counts = self.cnt.tolist()
         out = [self.rows[b, :n] for b, n in enumerate(counts)]
         if return_index:
@@ -89,10 +91,11 @@ def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, class
     if side is None:
         side = _side[dev.index] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
+    prediction.record_stream(side)                         # the caching allocator must not hand this block out again before the NMS has read it
     rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, stream=side)
     ev = torch.cuda.Event()
     ev.record(side)
-    return NmsHandle(rows, idx, cnt, ev)
+    return NmsHandle(rows, idx, cnt, ev, keep=prediction)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,

@@ -479,3 +479,30 @@ def test_nms_per_class_path_and_matrix_path_agree_with_oracle(case):
     for b in range(2):
         assert np.array_equal(gidx[b].cpu().numpy(), widx[b]), (case, b)
         assert np.array_equal(got[b].cpu().numpy(), want[b]), (case, b)
+
+
+def test_two_batches_in_flight_on_two_streams_give_the_single_stream_result(models):
+    """Model.forward(slot=k): plans of different slots own different arenas, so consecutive batches may run concurrently on different HIP
+    streams (bench.py's serving loop).  Interleaved on two streams, with the NMS on the side stream, every batch gives bitwise the
+    predictions and detections of a lone forward."""
+    m = models["n"]
+    xs = [O.synth_images(4, 320, 30 + i).to(DEV).half() for i in range(4)]
+    with torch.no_grad():
+        want = [m(x)[0].clone() for x in xs]
+    wdets = [M.non_max_suppression(p, 0.03, 0.65, multi_label=True) for p in want]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV) for _ in range(2)]
+    for rep in range(3):
+        preds, handles = [], []
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(streams[i % 2]), torch.no_grad():
+                p = m(x, slot=i % 2)[0]
+                preds.append(p)
+                handles.append(M.non_max_suppression_async(p, 0.03, 0.65, multi_label=True))
+        dets = [h.result() for h in handles]
+        torch.cuda.synchronize()
+        for i in range(4):
+            assert torch.equal(preds[i], want[i]), (rep, i)
+            assert all(torch.equal(a, b) for a, b in zip(dets[i], wdets[i])), (rep, i)
+    assert m.plan_for(xs[0], slot=0) is not m.plan_for(xs[0], slot=1)
+    assert m.plan_for(xs[0], slot=0).arena.data_ptr() != m.plan_for(xs[0], slot=1).arena.data_ptr()

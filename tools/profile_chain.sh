@@ -4,9 +4,9 @@ cd $R
 timeout 600 python bench.py --per-op --tune-file $O/tune.json > $O/bench0.json 2> $O/per_op0.txt
 cp $O/tune.json profiles/round1_tune.json
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SIZE -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/pmcf.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/pmcw.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SIZE -o p -- python bench.py --inflight 1 --steps 3 --warmup 2 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/pmcf.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -o p -- python bench.py --inflight 1 --steps 3 --warmup 2 --no-cpu-baseline --tune-file profiles/round1_tune.json > $O/pmcw.log 2>&1
 python tools/pmc_traffic.py $O $O/pmc_traffic.json > $O/pmc.log 2>&1
 cp $O/pmc_traffic.json profiles/round1_pmc_traffic.json
 timeout 600 python bench.py --per-op --tune-file profiles/round1_tune.json > $O/bench.json 2> $O/per_op.txt

@@ -41,7 +41,7 @@ def main():
     shutil.copy(src, out + "_kernel_stats.csv")
     rows = list(csv.DictReader(open(src)))
     lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % os.path.basename(out), "",
-             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline`", ""]
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline` (one batch in flight: with two, launches of the two streams overlap and every kernel looks longer than it is alone)", ""]
     if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
         try:
             j = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])
