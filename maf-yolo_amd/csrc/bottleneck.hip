@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
                 constexpr int i = decltype(idx)::value;
                 const int t = wave + 4 * i;
                 load_x(std::integral_constant<int, i + XD>{});
-                f32x4_t acc1[2] = {(f32x4_t)0.f, (f32x4_t)0.f};
+                f32x4_t acc1[2] = {(f32x4_t)b1v0, (f32x4_t)b1v1};                    // bias as the accumulators' initial value: no add in the epilogue
 #pragma unroll
                 for (int ks = 0; ks < S1; ++ks)
 #pragma unroll
@@ -174,9 +174,8 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
                 half_t* dst = T1 + (size_t)p * PS + hr * RWP + hc0;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const float bv = ct ? b1v1 : b1v0;
-                    const half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0] + bv), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1] + bv)};
-                    const half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2] + bv), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3] + bv)};
+                    const half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1])};
+                    const half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3])};
                     const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
                     if (m0 < NHP) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;
                 }
@@ -189,9 +188,12 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
         }
 
         // ---- B. depth-wise k x k on the matrix cores: 8 channel sets s (channels 8g + s), k tap rows, PARTS windows
-        f32x4_t dacc[8];
+        f32x4_t dacc[8];                                    // initial value = the depth-wise bias of channel 4s + g (no add in phase C)
+        {
+            const f32x4_t bd0 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2], bd1 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2 + 1];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dacc[s] = (f32x4_t)0.f;
+            for (int s = 0; s < 4; ++s) { dacc[s] = (f32x4_t)bd0[s]; dacc[4 + s] = (f32x4_t)bd1[s]; }
+        }
         const half8_t* toe = reinterpret_cast<const half8_t*>(rec + Cf::OFF_TOE) + p;
         // lane (g, n = p): plane 4s + g, row n (+ky), window at column 4q, read as two 8-byte halves.  Banks: the 16 rows of a
         // lane group are 48 B apart (all 16-byte slots of the 256-B bank row once) and the planes of g and g+1 are 8 B (mod 256)
@@ -216,8 +218,6 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
         }
         // ---- C. lane (g, n) now owns channels 4s + g (s = 0..7: k index 8g + s of the packed W2) of pixels (row n, x = 4q + r): the A fragments of the second 1x1
         {
-            const f32x4_t bd0 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2], bd1 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2 + 1];
-            const float bd[8] = {bd0[0], bd0[1], bd0[2], bd0[3], bd1[0], bd1[1], bd1[2], bd1[3]};
             half8_t w2f[CT2];
 #pragma unroll
             for (int ct = 0; ct < CT2; ++ct) w2f[ct] = reinterpret_cast<const half8_t*>(rec + Cf::OFF_W2)[ct * 64 + lane];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
             for (int r = 0; r < 4; ++r) {
                 half8_t t2;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) t2[s] = (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r] + bd[s]);
+                for (int s = 0; s < 8; ++s) t2[s] = (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r]);
 #pragma unroll
                 for (int ct = 0; ct < CT2; ++ct) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);
             }
