@@ -169,7 +169,8 @@ def main():
                     help="batches in flight in the timed serving loop: step i runs on HIP stream i %% S with its own activation arena "
                          "(1 = one stream; the NMS of a batch still overlaps the next forward)")
     ap.add_argument("--tune-file", default=None,
-                    help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning")
+                    help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning; "
+                         "default: profiles/round1_tune.json if present; 'none' = time every layer afresh")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
@@ -212,6 +213,13 @@ def main():
     if args.lanes >= 0:
         model.multi_stream = args.lanes
     from maf_yolo_amd import engine as _engine
+    # tile choices (which (pixels x channels) cut, which kernel variant per layer) measured on an MI355X and frozen in the repo are the
+    # default starting point: layer signatures that are not in the file are still timed here.  --tune-file none = time everything afresh.
+    frozen = os.path.join(ROOT, "profiles", "round1_tune.json")
+    if args.tune_file is None and os.path.exists(frozen):
+        args.tune_file = frozen
+    if args.tune_file == "none":
+        args.tune_file = None
     if args.tune_file and os.path.exists(args.tune_file):
         _engine.load_tune_cache(args.tune_file)
     B = args.batch
@@ -407,6 +415,7 @@ def main():
                           "execution": "K steps of forward + NMS of one batch each; %d batches in flight (step i on HIP stream i %% %d with its own "
                                        "activation arena, its NMS on a side stream); all K forwards and K NMS results complete inside the timed region" % (S, S),
                           "batches_in_flight": S,
+                          "tiles": ("per-layer tile / variant choices loaded from %s, the rest timed at start-up" % os.path.relpath(args.tune_file, ROOT)) if args.tune_file and os.path.exists(args.tune_file) else "every layer's tile / variant timed at start-up",
                           "nms_candidates_per_image": {"mean": round(cand_mean, 1), "max": cand_max},
                           "detections_per_image_mean": round(float(np.mean([d.shape[0] for d in dets])), 1)},
                "forward_only": {"ms_per_step": round(fwd_ms, 4), "images_per_s_per_gpu": round(B / (fwd_ms * 1e-3), 1)},
