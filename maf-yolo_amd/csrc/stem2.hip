@@ -43,9 +43,10 @@ template <> struct Chunk<uint8_t> {
     }
 };
 
-template <typename TI, int C0, int C1>
-__global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
-    constexpr int TY = 8, TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC, IR = 2 * SR + 1, IC = 2 * SC + 1;
+template <typename TI, int C0, int C1, int TY>
+__global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Args a) {
+    constexpr int MR = TY / 4;                                   // output rows (16-pixel m-tiles) per wave
+    constexpr int TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC, IR = 2 * SR + 1, IC = 2 * SC + 1;
     constexpr int NCH = (IC + 1 + 3) / 4 + 1, ICS = 4 * NCH;     // patch rows as 18 aligned 4-column chunks starting one column left of the patch
     constexpr int NCHUNK = 3 * IR * NCH, PF = (NCHUNK + 255) / 256;
     constexpr int GR = C0 / 8, NP = 9 * GR, KS1 = (NP + 3) / 4, NT1 = C1 / 16;
@@ -141,17 +142,17 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
         }
         __syncthreads();
         // ---- C: second conv, implicit GEMM over (tap, 8-channel group) pairs, transposed as well (A = weight fragments, B = T)
-        f32x4_t acc[2][NT1];
+        f32x4_t acc[MR][NT1];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS1; ++s) {
-            half8_t tf[2];
+            half8_t tf[MR];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int yy = wave * 2 + m;
+            for (int m = 0; m < MR; ++m) {
+                const int yy = wave * MR + m;
                 const half_t* tp = s_T + ((2 * yy) * SC + 2 * n) * TSH + off1[s];
                 const half4_t lo = *reinterpret_cast<const half4_t*>(tp), hi = *reinterpret_cast<const half4_t*>(tp + 4);
                 tf[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -160,19 +161,19 @@ __global__ __launch_bounds__(256, 2) void stem2_kernel(const S2Args a) {
             for (int t = 0; t < NT1; ++t) {
                 const half8_t wf = w1[(s * NT1 + t) * 64 + lane];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, tf[m], acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, tf[m], acc[m][t], 0, 0, 0);
             }
         }
         // ---- D: bias + ReLU -> LDS (aliases the input patch: its last reader was phase B) -> whole NHWC pixels
         half_t* s_out = s_in;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int t = 0; t < NT1; ++t) {
                 half4_t v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = (half_t)fmaxf(acc[m][t][q] + b1[t][q], 0.f);
-                *reinterpret_cast<half4_t*>(s_out + ((wave * 2 + m) * TX + n) * C1 + 16 * t + 4 * g) = v;
+                *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C1 + 16 * t + 4 * g) = v;
             }
         __syncthreads();
         constexpr int CPP = C1 / 8;                               // 16-byte pieces per pixel
@@ -206,10 +207,11 @@ int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     a.H1 = (a.H0 - 1) / 2 + 1; a.W1 = (a.W0 - 1) / 2 + 1;
     MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && op->Win % 4 == 0 && a.H1 == op->H && a.W1 == op->W, "stem2: H,W must be the twice-halved image size, image width a multiple of 4");
     a.out_stride = op->out_stride; a.out_coff = op->out_coff;
-    a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, 8); a.ntiles = a.B * a.tilesX * a.tilesY;
+    const int ty_rows = op->tile_p == 4 ? 4 : 8;                  // tile height of the quarter-resolution map (tile_p: 0 / 8 = 8 rows, 4 = 4 rows: less LDS and registers, more halo)
+    a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, ty_rows); a.ntiles = a.B * a.tilesX * a.tilesY;
     a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;
-    const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : 512)), blk(256);
-#define MAF_S2(TI, C0, C1) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1>), grid, blk, 0, s, a)
+    const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : (ty_rows == 4 ? 768 : 512))), blk(256);
+#define MAF_S2(TI, C0, C1) do { if (ty_rows == 4) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 4>), grid, blk, 0, s, a); else hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 8>), grid, blk, 0, s, a); } while (0)
 #define MAF_S2T(TI) do { if (op->Cout == 48) MAF_S2(TI, 24, 48); else MAF_S2(TI, 32, 64); } while (0)
     if (op->in_dtype == MAF_F16) MAF_S2T(half_t);
     else if (op->in_dtype == MAF_F32) MAF_S2T(float);

@@ -470,6 +470,33 @@ class Plan:
         self._tuned = getattr(self, "_tuned", [])
         changed = 0
         for i, (o, r) in enumerate(zip(self.ops, self._ops)):
+            if o.kind == lib.OP_STEM2:                           # stem pair: tile height (8 / 4 rows) and number of persistent workgroups
+                sig = (o.kind, self.dtype, self.in_dtype, self.B, o.H, o.W, o.ksize, o.Cout)
+                best = _TUNE_CACHE.get(sig)
+                if best is None:
+                    o.src[0].ptr = x.data_ptr()
+                    results = []
+                    for rows in (8, 4):
+                        for wgs in (256, 512, 768, 1024):
+                            op = lib.MafOp.from_buffer_copy(o)
+                            op.tile_p, op.tile_k = rows, wgs
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            ts = []
+                            for _ in range(reps):
+                                timer.start(stream.cuda_stream)
+                                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                timer.stop(stream.cuda_stream)
+                                ts.append(timer.elapsed_ms())
+                            results.append((min(ts), rows, wgs))
+                    results.sort()
+                    best = (results[0][1], 0, results[0][2])
+                    _TUNE_CACHE[sig] = best
+                    if verbose:
+                        print("tune %-32s %dx%d: %s" % (self.op_names[i], o.H, o.W, " ".join("(%d,%d)%.1fus" % (r_, w_, t * 1e3) for t, r_, w_ in results)))
+                if (best[0], best[2]) != (o.tile_p, o.tile_k):
+                    o.tile_p, o.tile_k = best[0], best[2]
+                    changed += 1
+                continue
             if o.kind == lib.OP_HEADTAIL:                        # head tail: pixel units per wave (weights are staged once per workgroup)
                 sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin)
                 best = _TUNE_CACHE.get(sig)

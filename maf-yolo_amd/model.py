@@ -182,7 +182,7 @@ class Model(nn.Module):
         else:
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
         fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
-        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot)
+        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, bool(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), self.multi_stream)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 8:

@@ -324,6 +324,22 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
         c1 = o.Cout
         taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * c1 * 2].view(torch.float16).view(B, H // 4, W // 4, c1).float().cpu().numpy()
     assert nops[True] == nops[False] - 1
+    # the 4-row tile variant (tile_p = 4: what the autotuner may pick) computes every output pixel with the same operations: bitwise equal
+    m.fuse_stem = True
+    plan8 = m.plan_for(x)
+    o8 = plan8.ops[0]
+    assert o8.kind == 9
+    nbytes = B * (H // 4) * (W // 4) * o8.Cout * 2
+    off = o8.out - plan8.arena.data_ptr()
+    res = []
+    for rows, wgs in ((8, 0), (4, 300)):
+        o8.tile_p, o8.tile_k = rows, wgs
+        plan8.arena[off:off + nbytes].zero_()
+        plan8.launch_op(0, image_ptr=x.contiguous().data_ptr())
+        torch.cuda.synchronize()
+        res.append(plan8.arena[off:off + nbytes].clone())
+    o8.tile_p, o8.tile_k = 0, 0
+    assert torch.equal(res[0], res[1]) and res[0].any()
     d = np.abs(taps[True] - taps[False])
     assert d.max() <= 2e-2 * max(1.0, np.abs(taps[False]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[False]).mean())
     _close16(outs[True], outs[False])
