@@ -82,8 +82,10 @@ typedef struct {
  *                   f32 | Toeplitz table [8][k][parts][16][8] f16 | bdw [32] f32; maf-yolo_amd/pack.py:pack_conv1dw); fp16, act = SiLU.
  * MAF_OP_STEM2      replaces backbone.0 AND backbone.1 (two RepVGGBlocks in deploy form: 3x3 s2 conv + ReLU each, common.py:216-217) in one
  *                   launch.  src[0].ptr = image [B,3,Hin,Win] NCHW of in_dtype (u8: /255 folded); H, W = the 1/4-resolution grid; Cin = 3,
- *                   ksize = C0 (channels of backbone.0), Cout = C1: (24, 48) or (32, 64); w = record of maf_stem2_record_bytes(C0, C1)
- *                   bytes (maf-yolo_amd/pack.py:pack_stem2); fp16 engine only; tile_k = workgroups (0 = 512, persistent).
+ *                   ksize = C0 (channels of backbone.0), Cout = C1: (24, 48) or (32, 64); nc = C3: 0, or C1 to also apply the 1x1 conv + SiLU
+ *                   that opens the next RepHDW block (backbone.2.conv1, common.py:898-946) before anything is written — out then receives
+ *                   C3 channels; w = record of maf_stem2_record_bytes(C0, C1, C3) bytes (maf-yolo_amd/pack.py:pack_stem2); fp16 engine only;
+ *                   tile_p = tile rows (0 / 8, or 4), tile_k = workgroups (0 = default, persistent).
  * MAF_OP_HEADTAIL   replaces, for ONE level, cls_conv_s + cls_pred + sigmoid and reg_conv_s + reg_pred (Head_DepthUni, common.py:1288-1336:
  *                   Conv.forward_fuse, nn.Conv2d) and that level's share of the Detect_yaml eval branch (yolo.py:355-396) in one launch.
  *                   src[0] / src[1] = inputs of cls_conv_s / reg_conv_s (C = Cin = head width: 64, 128 or 192); w / aux[0] = weight
@@ -127,7 +129,7 @@ int maf_version(void);
 int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
-int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1);
+int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

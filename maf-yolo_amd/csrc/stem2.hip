@@ -43,7 +43,7 @@ template <> struct Chunk<uint8_t> {
     }
 };
 
-template <typename TI, int C0, int C1, int TY>
+template <typename TI, int C0, int C1, int TY, int C3>
 __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Args a) {
     constexpr int MR = TY / 4;                                   // output rows (16-pixel m-tiles) per wave
     constexpr int TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC, IR = 2 * SR + 1, IC = 2 * SC + 1;
@@ -54,15 +54,20 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
     static_assert((TS / 2) % 2 == 1 && TS * 2 >= C0, "T stride");
     constexpr int TSH = TS * 2;                                  // ... in halves
     constexpr int W0B = 2 * 64 * 16, W1B = KS1 * NT1 * 64 * 16;
-    constexpr int IN_H = 4 * NCHUNK, OUT_H = TY * TX * C1;
+    constexpr int KS3 = (C1 + 31) / 32, NT3 = C3 / 16, W3B = KS3 * NT3 * 64 * 16, CO = C3 > 0 ? C3 : C1;   // optional third conv: 1x1, C1 -> C3, SiLU
+    constexpr int IN_H = 4 * NCHUNK, OUT_H = TY * TX * CO;
     __shared__ __attribute__((aligned(16))) half_t s_in[(IN_H > OUT_H ? IN_H : OUT_H) + 8];
     __shared__ __attribute__((aligned(16))) half_t s_T[SP * TSH + 64];
-    __shared__ __attribute__((aligned(16))) char s_w1[W1B];
+    __shared__ __attribute__((aligned(16))) char s_w1[W1B + W3B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.rec + W0B);
         uint4* dst = reinterpret_cast<uint4*>(s_w1);
         for (int i = tid; i < W1B / 16; i += 256) dst[i] = src[i];
+        if constexpr (C3 > 0) {                                  // third conv's fragments sit behind the two bias vectors
+            const uint4* src3 = reinterpret_cast<const uint4*>(a.rec + W0B + W1B + (32 + C1) * 4);
+            for (int i = tid; i < W3B / 16; i += 256) dst[W1B / 16 + i] = src3[i];
+        }
     }
     const half8_t w0a = reinterpret_cast<const half8_t*>(a.rec)[lane], w0b = reinterpret_cast<const half8_t*>(a.rec)[64 + lane];
     const float* bias = reinterpret_cast<const float*>(a.rec + W0B + W1B);
@@ -70,6 +75,12 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
     f32x4_t b1[NT1];
 #pragma unroll
     for (int t = 0; t < NT1; ++t) b1[t] = *reinterpret_cast<const f32x4_t*>(bias + 32 + 16 * t + 4 * g);
+    f32x4_t b3[NT3 > 0 ? NT3 : 1];
+    if constexpr (C3 > 0) {
+        const float* bias3 = reinterpret_cast<const float*>(a.rec + W0B + W1B + (32 + C1) * 4 + W3B);
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) b3[t] = *reinterpret_cast<const f32x4_t*>(bias3 + 16 * t + 4 * g);
+    }
     int off0[8];                                                 // patch offsets of this lane's 8 taps (k = 8g + j; k >= 27 meets zero weights)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -164,40 +175,76 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                 for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, tf[m], acc[m][t], 0, 0, 0);
             }
         }
-        // ---- D: bias + ReLU -> LDS (aliases the input patch: its last reader was phase B) -> whole NHWC pixels
+        // ---- D: bias + ReLU (-> third conv: 1x1 + SiLU, see below) -> LDS (aliases the input patch: its last reader was phase B) -> whole NHWC pixels
         half_t* s_out = s_in;
+        if constexpr (C3 == 0) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+            for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) {
-                half4_t v;
+                for (int t = 0; t < NT1; ++t) {
+                    half4_t v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (half_t)fmaxf(acc[m][t][q] + b1[t][q], 0.f);
-                *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C1 + 16 * t + 4 * g) = v;
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)fmaxf(acc[m][t][q] + b1[t][q], 0.f);
+                    *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C1 + 16 * t + 4 * g) = v;
+                }
+        } else {
+            // The RepHDW block that follows starts with a 1x1 conv on exactly this tensor (backbone.2.conv1): a lane holds channels
+            // 16t + 4g + q of pixel n for every tile t, which IS a fragment (pixel column, 8 k-slots) of the next matrix product once that
+            // conv's weights are packed with their K axis in this order — so the quarter-resolution C1-channel tensor never exists in memory.
+            const half8_t* w3 = reinterpret_cast<const half8_t*>(s_w1 + W1B);
+            f32x4_t acc3[MR][NT3];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                half8_t a2[KS3];
+#pragma unroll
+                for (int j = 0; j < KS3; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a2[j][q] = (half_t)fmaxf(acc[m][2 * j][q] + b1[2 * j][q], 0.f);
+                        a2[j][4 + q] = 2 * j + 1 < NT1 ? (half_t)fmaxf(acc[m][(2 * j + 1) % NT1][q] + b1[(2 * j + 1) % NT1][q], 0.f) : (half_t)0.f;
+                    }
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) {
+                    acc3[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < KS3; ++j) acc3[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[(t * KS3 + j) * 64 + lane], a2[j], acc3[m][t], 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) {
+                    half4_t v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<MAF_ACT_SILU>(acc3[m][t][q] + b3[t][q]);
+                    *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C3 + 16 * t + 4 * g) = v;
+                }
+        }
         __syncthreads();
-        constexpr int CPP = C1 / 8;                               // 16-byte pieces per pixel
+        constexpr int CPP = CO / 8;                               // 16-byte pieces per pixel
         for (int q = tid; q < TY * TX * CPP; q += 256) {
             const int px = q / CPP, part = q - px * CPP;
             const int oy = Y0 + px / TX, ox = X0 + px % TX;
             if (oy < a.H1 && ox < a.W1)
                 *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H1 + oy) * a.W1 + ox) * a.out_stride + a.out_coff + 8 * part) =
-                    *reinterpret_cast<const uint4*>(s_out + px * C1 + 8 * part);
+                    *reinterpret_cast<const uint4*>(s_out + px * CO + 8 * part);
         }
     }
 }
 
 }  // namespace
 
-extern "C" int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1) {
+extern "C" int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3) {
     const int ks1 = (9 * (C0 / 8) + 3) / 4;
-    return 2 * 64 * 16 + (int64_t)ks1 * (C1 / 16) * 64 * 16 + 32 * 4 + C1 * 4;
+    const int64_t base = 2 * 64 * 16 + (int64_t)ks1 * (C1 / 16) * 64 * 16 + 32 * 4 + C1 * 4;
+    return C3 > 0 ? base + (int64_t)((C1 + 31) / 32) * (C3 / 16) * 64 * 16 + C3 * 4 : base;
 }
 
 int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "stem2: fp16 engine only");
     MAF_REQUIRE(op->Cin == 3 && ((op->ksize == 24 && op->Cout == 48) || (op->ksize == 32 && op->Cout == 64)), "stem2: (C0, C1) must be (24, 48) or (32, 64); ksize carries C0");
     MAF_REQUIRE(op->act == MAF_ACT_RELU, "stem2: both RepVGG blocks end in ReLU (common.py:198)");
+    MAF_REQUIRE(op->nc == 0 || op->nc == op->Cout, "stem2: the optional third conv (nc = its output channels; 1x1 + SiLU) must keep the channel count (48 -> 48, 64 -> 64)");
     MAF_REQUIRE(op->src[0].ptr && op->w && op->out, "stem2: null pointer");
     MAF_REQUIRE(op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "stem2: out stride/coff multiples of 8");
     S2Args a;
@@ -211,8 +258,8 @@ int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, ty_rows); a.ntiles = a.B * a.tilesX * a.tilesY;
     a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;
     const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : (ty_rows == 4 ? 768 : 512))), blk(256);
-#define MAF_S2(TI, C0, C1) do { if (ty_rows == 4) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 4>), grid, blk, 0, s, a); else hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 8>), grid, blk, 0, s, a); } while (0)
-#define MAF_S2T(TI) do { if (op->Cout == 48) MAF_S2(TI, 24, 48); else MAF_S2(TI, 32, 64); } while (0)
+#define MAF_S2(TI, C0, C1, C3) do { if (ty_rows == 4) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 4, C3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 8, C3>), grid, blk, 0, s, a); } while (0)
+#define MAF_S2T(TI) do { if (op->Cout == 48) { if (op->nc) MAF_S2(TI, 24, 48, 48); else MAF_S2(TI, 24, 48, 0); } else { if (op->nc) MAF_S2(TI, 32, 64, 64); else MAF_S2(TI, 32, 64, 0); } } while (0)
     if (op->in_dtype == MAF_F16) MAF_S2T(half_t);
     else if (op->in_dtype == MAF_F32) MAF_S2T(float);
     else if (op->in_dtype == MAF_U8) MAF_S2T(uint8_t);

@@ -117,8 +117,9 @@ class Plan:
         # (csrc/head_tail.hip, fp16, 80 classes, head width 64 / 128 / 192) instead of four 1x1 convs + the decode kernel
         fh = getattr(model, "fuse_head", "auto") if fuse_head is None else fuse_head
         self.fuse_head = bool(fh) and dtype == lib.F16 and model.nc == 80 and model.detect.reg_max == 16
-        self.fuse_stem = bool(getattr(model, "fuse_stem", True)) and dtype == lib.F16
-        self._stem2 = None
+        fs = getattr(model, "fuse_stem", True)                   # False | 1: backbone.0 + backbone.1 | True / 2: + the 1x1 that opens backbone.2
+        self.fuse_stem = (2 if fs is True else int(fs or 0)) if dtype == lib.F16 else 0
+        self._stem2 = self._stem3 = None
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
             self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
@@ -212,6 +213,15 @@ class Plan:
                 # backbone.0 + backbone.1 in one launch (csrc/stem2.hip): the half-resolution tensor between them stays in LDS
                 w0, b0, c0 = self._stem2
                 w, b = m.fused()
+                nxt = model.nodes[2] if len(model.nodes) > 2 else None
+                m2 = model.backbone[2] if nxt is not None else None
+                if (nxt is not None and nxt.kind == "rephdw" and list(nxt.sources()) == [1] and not any(1 in n_.sources() for n_ in model.nodes[3:])
+                        and m2.conv1.fused()[0].shape[0] == node.cout and self.fuse_stem >= 2):
+                    # ... and the 1x1 that opens backbone.2 (RepHDW.conv1) rides along: node 1's tensor is never written either.
+                    # Emitted when node 2 allocates its concat buffer.
+                    self._stem3 = (w0, b0, c0, w, b, node.cout)
+                    y.append(TV([], self.Hin // 4, self.Win // 4))
+                    continue
                 out = self._alloc(self.Hin // 4, self.Win // 4, node.cout)
                 self._ops.append(dict(kind=lib.OP_STEM2, name="backbone.0+1", act=lib.ACT_RELU, H=out.H, W=out.W, Hin=self.Hin, Win=self.Win,
                                       Cin=3, Cout=node.cout, ksize=c0, segs=[], out=out, out_coff=0,
@@ -237,7 +247,14 @@ class Plan:
             elif node.kind == "rephdw":
                 c_, depth = m.c_, len(m.m)
                 cat = self._alloc(x.H, x.W, c_ * (depth + 2))
-                self._conv1x1(p + ".conv1", *m.conv1.fused(), x, cat, 0, lib.ACT_SILU)
+                if node.i == 2 and self._stem3 is not None:
+                    w0, b0, c0, w1_, b1_, c1 = self._stem3
+                    w3, b3 = m.conv1.fused()
+                    self._ops.append(dict(kind=lib.OP_STEM2, name="backbone.0+1+2.conv1", act=lib.ACT_RELU, H=x.H, W=x.W, Hin=self.Hin, Win=self.Win,
+                                          Cin=3, Cout=c1, ksize=c0, c3=w3.shape[0], segs=[], out=cat, out_coff=0,
+                                          w=self._wput(pack.pack_stem2(w0, b0, w1_, b1_, w3, b3)), b=0))
+                else:
+                    self._conv1x1(p + ".conv1", *m.conv1.fused(), x, cat, 0, lib.ACT_SILU)
                 for d, blk in enumerate(m.m):
                     mid = blk.conv1.conv.out_channels
                     q = "%s.m.%d" % (p, d)
@@ -436,6 +453,8 @@ class Plan:
                 o.nsrc = 1
                 o.src[0].ptr = 0            # supplied per call
                 o.src[0].C = 3
+            if r["kind"] == lib.OP_STEM2:
+                o.nc = r.get("c3", 0)
             if r["kind"] == lib.OP_HEADTAIL:
                 lvl = r["level"]
                 o.Hin, o.Win = sum(t.H * t.W for t, _, _ in self.head_bufs[:lvl]), self.A
@@ -471,7 +490,7 @@ class Plan:
         changed = 0
         for i, (o, r) in enumerate(zip(self.ops, self._ops)):
             if o.kind == lib.OP_STEM2:                           # stem pair: tile height (8 / 4 rows) and number of persistent workgroups
-                sig = (o.kind, self.dtype, self.in_dtype, self.B, o.H, o.W, o.ksize, o.Cout)
+                sig = (o.kind, self.dtype, self.in_dtype, self.B, o.H, o.W, o.ksize, o.Cout, o.nc)
                 best = _TUNE_CACHE.get(sig)
                 if best is None:
                     o.src[0].ptr = x.data_ptr()
@@ -695,7 +714,7 @@ class Plan:
         if o.kind == lib.OP_HEADTAIL:
             return "head_tail_kernel<%d, %d>" % (o.Cin, 2 if o.Cin <= 128 else 1)
         if o.kind == lib.OP_STEM2:
-            return "stem2_kernel<%d, %d>" % (o.ksize, o.Cout)
+            return "stem2_kernel<%d, %d, %d>" % (o.ksize, o.Cout, o.nc)
         return {lib.OP_STEM: "stem_kernel", lib.OP_SPPF_POOL: "sppf_pool_lds_kernel", lib.OP_DECODE: "decode_kernel"}[o.kind]
 
     def algorithmic_bytes(self, idx):
@@ -709,7 +728,7 @@ class Plan:
             return self.B * 3 * o.Hin * o.Win * ies + px * o.Cout * es + 27 * o.Cout * 4
         if o.kind == lib.OP_STEM2:
             ies = {lib.F16: 2, lib.F32: 4, lib.U8: 1}[o.in_dtype]
-            return self.B * 3 * o.Hin * o.Win * ies + px * o.Cout * es + (27 * o.ksize + 9 * o.ksize * o.Cout) * es
+            return self.B * 3 * o.Hin * o.Win * ies + px * (o.nc or o.Cout) * es + (27 * o.ksize + 9 * o.ksize * o.Cout + o.Cout * o.nc) * es
         if o.kind == lib.OP_CONV1X1:
             rd = 0
             for i in range(o.nsrc):
@@ -741,7 +760,7 @@ class Plan:
         if o.kind == lib.OP_STEM:
             return 2 * px * 27 * o.Cout
         if o.kind == lib.OP_STEM2:
-            return 2 * (4 * px * 27 * o.ksize + px * 9 * o.ksize * o.Cout)
+            return 2 * (4 * px * 27 * o.ksize + px * 9 * o.ksize * o.Cout + px * o.Cout * o.nc)
         if o.kind == lib.OP_CONV1X1:
             return 2 * px * o.Cin * o.Cout
         if o.kind == lib.OP_CONV3X3S2:

@@ -83,7 +83,7 @@ def load():
     lib.maf_conv1dw_record_bytes.restype = C.c_int64
     lib.maf_head_tail_record_bytes.argtypes = [C.c_int32]
     lib.maf_head_tail_record_bytes.restype = C.c_int64
-    lib.maf_stem2_record_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.maf_stem2_record_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.maf_stem2_record_bytes.restype = C.c_int64
     lib.maf_bottleneck_record_bytes.argtypes = [C.c_int32] * 3
     lib.maf_bottleneck_record_bytes.restype = C.c_int64

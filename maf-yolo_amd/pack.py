@@ -208,8 +208,11 @@ def pack_head_tail(w1, b1, w2, b2):
     return rec
 
 
-def pack_stem2(w0, b0, w1, b1):
-    """Record of MAF_OP_STEM2 (csrc/stem2.hip): backbone.0 w0 [C0,3,3,3] + b0 and backbone.1 w1 [C1,C0,3,3] + b1, both in deploy form.
+def pack_stem2(w0, b0, w1, b1, w3=None, b3=None):
+    """Record of MAF_OP_STEM2 (csrc/stem2.hip): backbone.0 w0 [C0,3,3,3] + b0 and backbone.1 w1 [C1,C0,3,3] + b1, both in deploy form; optionally
+    the 1x1 conv w3 [C3,C1] + b3 that follows (appended: fragments [C3/16][ceil(C1/32)][64][8] f16 — lane (g, i): output channel 16t + i,
+    k-slot q of step j = channel 32j + 4g + q for q < 4, 32j + 16 + 4g + q - 4 otherwise, the order the accumulators of conv 1 come in —
+    then b3 fp32 [C3]).
     Layout: B fragments of conv 0 [2 tiles][64 lanes][8] f16 (lane (g, n): tap k = 8g + j = (c*3 + ky)*3 + kx, output channel 16t + n;
     zero for k >= 27 and channels >= C0) | B fragments of conv 1 [ceil(9*C0/8 / 4)][C1/16][64][8] f16 (lane (g, n) of k-step s: pair
     q = 4s + g -> tap q // (C0/8), channel group q % (C0/8); element j = input channel 8*group + j; output channel 16t + n; zero for
@@ -229,7 +232,20 @@ def pack_stem2(w0, b0, w1, b1):
         m1[q] = w1[:, 8 * grp:8 * grp + 8, tap // 3, tap % 3].t()
     f1 = m1.view(ks1, 4, 8, C1 // 16, 16).permute(0, 3, 1, 4, 2).contiguous().half()   # [s][t][g][n][j]
     b0p = torch.zeros(32); b0p[:C0] = b0.detach().float().cpu()
-    rec = torch.cat([f0.reshape(-1).view(torch.uint8), f1.reshape(-1).view(torch.uint8), b0p.view(torch.uint8),
-                     b1.detach().float().cpu().contiguous().view(torch.uint8)])
-    assert rec.numel() == 2048 + ks1 * (C1 // 16) * 1024 + 128 + C1 * 4
+    parts = [f0.reshape(-1).view(torch.uint8), f1.reshape(-1).view(torch.uint8), b0p.view(torch.uint8), b1.detach().float().cpu().contiguous().view(torch.uint8)]
+    n = 2048 + ks1 * (C1 // 16) * 1024 + 128 + C1 * 4
+    if w3 is not None:
+        w3 = w3.detach().float().cpu().reshape(w3.shape[0], -1)
+        C3 = w3.shape[0]
+        assert w3.shape[1] == C1 and C3 % 16 == 0
+        ks3 = (C1 + 31) // 32
+        w3p = torch.zeros(C3, ks3 * 32)
+        w3p[:, :C1] = w3
+        j, g, q = torch.meshgrid(torch.arange(ks3), torch.arange(4), torch.arange(8), indexing="ij")
+        ch = 32 * j + torch.where(q < 4, 4 * g + q, 16 + 4 * g + q - 4)
+        f3 = w3p[:, ch.reshape(-1)].view(C3 // 16, 16, ks3, 4, 8).permute(0, 2, 3, 1, 4).contiguous().half()   # [t][j][g][i][q]
+        parts += [f3.reshape(-1).view(torch.uint8), b3.detach().float().cpu().contiguous().view(torch.uint8)]
+        n += ks3 * (C3 // 16) * 1024 + C3 * 4
+    rec = torch.cat(parts)
+    assert rec.numel() == n
     return rec

@@ -309,7 +309,7 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
     img = O.synth_images(B, max(H, W), 23)[:, :, :H, :W].contiguous()
     x = {"f16": img.half(), "f32": img, "u8": (img * 255).round().to(torch.uint8)}[dt].to(DEV)
     outs, taps, nops = {}, {}, {}
-    for fs in (True, False):
+    for fs in (2, 1, 0):                           # 2 (= True): stem pair + the 1x1 that opens backbone.2; 1: stem pair; 0: three launches
         m = M.Model(scale, precision="fp16")
         m.load_state_dict(O.synth_state_dict(scale, 0))
         m = m.to(DEV).eval()
@@ -317,19 +317,20 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
         with torch.no_grad():
             outs[fs] = m(x)[0].float().cpu().numpy()
         plan = m.plan_for(x)
-        assert (plan.ops[0].kind == 9) == fs
+        assert (plan.ops[0].kind == 9) == bool(fs) and plan.ops[0].nc == (plan.ops[0].Cout if fs == 2 else 0)
         nops[fs] = len(plan.ops)
-        o = plan.ops[0 if fs else 1]
+        # the tensor all three modes materialise: the output of backbone.2.conv1 = the first channels of node 2's concat buffer
+        o = plan.ops[[i for i, nme in enumerate(plan.op_names) if nme.endswith("2.conv1")][0]]
+        c3 = o.nc if o.kind == 9 else o.Cout
         off = o.out - plan.arena.data_ptr()
-        c1 = o.Cout
-        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * c1 * 2].view(torch.float16).view(B, H // 4, W // 4, c1).float().cpu().numpy()
-    assert nops[True] == nops[False] - 1
+        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * o.out_stride * 2].view(torch.float16).view(B, H // 4, W // 4, o.out_stride)[..., :c3].float().cpu().numpy()
+    assert nops[2] == nops[0] - 2 and nops[1] == nops[0] - 1
     # the 4-row tile variant (tile_p = 4: what the autotuner may pick) computes every output pixel with the same operations: bitwise equal
     m.fuse_stem = True
     plan8 = m.plan_for(x)
     o8 = plan8.ops[0]
     assert o8.kind == 9
-    nbytes = B * (H // 4) * (W // 4) * o8.Cout * 2
+    nbytes = B * (H // 4) * (W // 4) * o8.out_stride * 2
     off = o8.out - plan8.arena.data_ptr()
     res = []
     for rows, wgs in ((8, 0), (4, 300)):
@@ -340,9 +341,10 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
         res.append(plan8.arena[off:off + nbytes].clone())
     o8.tile_p, o8.tile_k = 0, 0
     assert torch.equal(res[0], res[1]) and res[0].any()
-    d = np.abs(taps[True] - taps[False])
-    assert d.max() <= 2e-2 * max(1.0, np.abs(taps[False]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[False]).mean())
-    _close16(outs[True], outs[False])
+    for fs in (2, 1):
+        d = np.abs(taps[fs] - taps[0])
+        assert d.max() <= 2e-2 * max(1.0, np.abs(taps[0]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[0]).mean()), fs
+        _close16(outs[fs], outs[0])
 
 
 def test_fusion_choice_is_measured_when_autotuning():
@@ -358,7 +360,7 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 76 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem: -1
+    assert len(plan.ops) == 75 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem + backbone.2.conv1: -2
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):

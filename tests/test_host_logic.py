@@ -183,9 +183,14 @@ def test_plan_builds_on_cpu(built, scale, nops):
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops
     m.fuse_stem = True                             # backbone.0 + backbone.1 in one launch (scale n: 24 -> 48 channels)
     st = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
-    if scale in ("n", "s"):
-        assert len(st.ops) == len(ht.ops) - 1 and st.ops[0].kind == lib.OP_STEM2
-        assert (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].H, st.ops[0].Hin) == {"n": (24, 48, 16, 64), "s": (32, 64, 16, 64)}[scale]
+    if scale in ("n", "s"):                        # ... and the 1x1 that opens backbone.2 rides along (its output goes straight into the concat buffer)
+        assert len(st.ops) == len(ht.ops) - 2 and st.ops[0].kind == lib.OP_STEM2
+        assert (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].nc, st.ops[0].H, st.ops[0].Hin) == {"n": (24, 48, 48, 16, 64), "s": (32, 64, 64, 16, 64)}[scale]
+        assert st.ops[0].out_stride == {"n": 72, "s": 128}[scale] and st.op_names[0] == "backbone.0+1+2.conv1"
+        m.fuse_stem = 1
+        st1 = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
+        assert len(st1.ops) == len(ht.ops) - 1 and st1.ops[0].kind == lib.OP_STEM2 and st1.ops[0].nc == 0 and st1.ops[0].out_stride == st1.ops[0].Cout
+        m.fuse_stem = True
     else:
         assert len(st.ops) == len(ht.ops) and st.ops[0].kind == lib.OP_STEM
 
@@ -259,7 +264,16 @@ def test_fused_kernel_records_match_the_c_abi_sizes(built):
         w0, b0 = torch.randn(c0, 3, 3, 3, generator=g), torch.randn(c0, generator=g)
         w1, b1 = torch.randn(c1, c0, 3, 3, generator=g), torch.randn(c1, generator=g)
         rec = pack.pack_stem2(w0, b0, w1, b1)
-        assert rec.numel() == built.maf_stem2_record_bytes(c0, c1)
+        assert rec.numel() == built.maf_stem2_record_bytes(c0, c1, 0)
+        w3, b3 = torch.randn(c1, c1, 1, 1, generator=g), torch.randn(c1, generator=g)
+        rec3 = pack.pack_stem2(w0, b0, w1, b1, w3, b3)
+        assert rec3.numel() == built.maf_stem2_record_bytes(c0, c1, c1) and torch.equal(rec3[:rec.numel()], rec)
+        ks3 = (c1 + 31) // 32
+        f3 = rec3[rec.numel():rec.numel() + ks3 * (c1 // 16) * 1024].view(torch.float16).view(c1 // 16, ks3, 4, 16, 8)      # [t][j][g][i][q]
+        assert f3[1, 0, 2, 5, 6] == w3[16 + 5, 16 + 4 * 2 + 6 - 4, 0, 0].half() and f3[2, 1, 3, 0, 1] == w3[32, 32 + 12 + 1, 0, 0].half()
+        if c1 == 48:
+            assert torch.all(f3[:, 1, :, :, 4:] == 0)                                              # channels 48..63 do not exist
+        assert torch.equal(rec3[-c1 * 4:].view(torch.float32), b3)
         f0 = rec[:2048].view(torch.float16).view(2, 4, 16, 8)                                  # [t][g][n][j]
         assert f0[1, 2, 3, 4] == w0[19, 2, 0, 2].half()                                        # k = 8*2+4 = 20 = (c 2, ky 0, kx 2), channel 16+3
         assert torch.all(f0[:, 3, :, 3:] == 0)                                                 # taps 27..31 do not exist

@@ -25,9 +25,9 @@ def demangle(n):
     m = re.match(r"_ZN12_GLOBAL__N_1\d+dwconv_tile_kernelI(DF16_|f)Li(\d+)ELi(\d+)EEEv", n)
     if m:
         return "dwconv_tile_kernel<%s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3))
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+stem2_kernelI(DF16_|f|h)Li(\d+)ELi(\d+)EEEv", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+stem2_kernelI(DF16_|f|h)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEEv", n)
     if m:
-        return "stem2_kernel<%s, %s>" % (m.group(2), m.group(3))
+        return "stem2_kernel<%s, %s, %s>" % (m.group(2), m.group(3), m.group(5))
     m = re.match(r"_ZN12_GLOBAL__N_1\d+stem_kernelI(DF16_|f|h)(DF16_|f)Lb([01])EEEv", n)
     if m:
         return "stem_kernel<%s, %s, %s>" % (_T[m.group(1)], _T[m.group(2)], "true" if m.group(3) == "1" else "false")
