@@ -77,6 +77,15 @@ __device__ __forceinline__ bool multi_test(const NmsArgs& a, const float* pred, 
     return ok;
 }
 
+// the same test on values already loaded (obj = row[4], raw = row[5 + c])
+__device__ __forceinline__ bool multi_ok(const NmsArgs& a, const float* pred, unsigned int e32, int no, float obj, float raw) {
+    const float sc = raw * obj;                                           // nms.py:69
+    const int box = (int)(e32 / (unsigned int)a.nc), c = (int)(e32 - (unsigned int)box * (unsigned int)a.nc);
+    bool ok = obj > a.conf && sc > a.conf && class_ok(a, c);              // nms.py:48 (obj), :76, :83-84
+    if (ok && obj > 1.0f) ok = row_rmax(pred + (size_t)box * no, a.nc) > a.conf;
+    return ok;
+}
+
 // multi_label: one lane per (box, class) element of the prediction tensor, fully coalesced.  A workgroup owns a
 // contiguous chunk: pass 1 counts its candidates, ONE atomicAdd per chunk reserves the output range (a per-wave
 // atomic per hit costs ~10 ns each on one contended line — 64k of them were 0.65 ms), pass 2 re-tests (L1 hits)
@@ -91,12 +100,23 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
     const float* pred = a.pred + (size_t)b * a.N * no;
     for (unsigned int c0 = blockIdx.x * kChunk; c0 < total; c0 += gridDim.x * kChunk) {
+        // both passes read 8 elements per lane at a time: the 16 loads are issued together (unconditional, clamped), the tests follow
         int mine = 0;
-        for (int i = 0; i < kChunk / 256; ++i) {
-            const unsigned int e = c0 + i * 256 + tid;
-            float sc;
-            const bool ok = e < total && multi_test(a, pred, e, no, sc);
-            mine += __popcll(__ballot(ok));                                // wave-uniform running count
+        for (int i0 = 0; i0 < kChunk / 256; i0 += 8) {
+            float obj[8], raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned int e = min(c0 + (i0 + u) * 256 + tid, total - 1);
+                const unsigned int box = e / (unsigned int)a.nc;
+                const float* row = pred + (size_t)box * no;
+                obj[u] = row[4]; raw[u] = row[5 + (e - box * (unsigned int)a.nc)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned int e = c0 + (i0 + u) * 256 + tid;
+                const bool ok = e < total && multi_ok(a, pred, e, no, obj[u], raw[u]);
+                mine += __popcll(__ballot(ok));                            // wave-uniform running count
+            }
         }
         if (lane == 0) wave_cnt[wave] = mine;
         __syncthreads();
@@ -109,13 +129,23 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
         for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
         const bool any = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3] > 0;
         if (any) {
-            for (int i = 0; i < kChunk / 256; ++i) {
-                const unsigned int e = c0 + i * 256 + tid;
-                float sc = 0.f;
-                const bool ok = e < total && multi_test(a, pred, e, no, sc);
-                const unsigned long long m = __ballot(ok);
-                if (ok) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(sc)) << 32) | e;
-                pos += __popcll(m);
+            for (int i0 = 0; i0 < kChunk / 256; i0 += 8) {
+                float obj[8], raw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned int e = min(c0 + (i0 + u) * 256 + tid, total - 1);
+                    const unsigned int box = e / (unsigned int)a.nc;
+                    const float* row = pred + (size_t)box * no;
+                    obj[u] = row[4]; raw[u] = row[5 + (e - box * (unsigned int)a.nc)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned int e = c0 + (i0 + u) * 256 + tid;
+                    const bool ok = e < total && multi_ok(a, pred, e, no, obj[u], raw[u]);
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(raw[u] * obj[u])) << 32) | e;
+                    pos += __popcll(m);
+                }
             }
         }
         __syncthreads();
