@@ -189,7 +189,7 @@ struct alignas(16) Cand { float x1, y1, x2, y2, area, score; unsigned int flat, 
 // same-class tests).  Let tf be the smallest fp32 above thr, p its predecessor, m = (tf + p) / 2.  The rounded quotient
 // is >= tf  <=>  inter/uni > m, or == m with tf the even neighbour.  m has <= 25 significant bits and uni 24, so
 // m * uni is exact in double: the comparison below involves no rounding at all.
-struct IouThr { double thr, m; int even; };
+struct IouThr { double thr, m; int even; float m32; };   // m32 = fl32(m): the single-precision screen below
 
 __device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, const IouThr& t) {
     // torchvision nms CPU kernel: i = kept (earlier), j = candidate
@@ -200,6 +200,11 @@ __device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, const IouTh
     if (!(w > 0.f) || !(h > 0.f)) return false;
     const float inter = w * h;
     const float uni = k.area + c.area - inter;
+    // single-precision screen: d = inter - fl(m) * uni (one rounding) differs from inter - m * uni by at most 6e-8 * (uni + |d|), so outside
+    // a band of 3e-7 * uni its sign is the exact answer; inside the band (and for NaN / infinite / non-positive unions, which never pass
+    // this comparison) the exact double form below decides.  Most same-class pairs are far outside the band: no double arithmetic.
+    const float d = __builtin_fmaf(-t.m32, uni, inter);
+    if (uni > 0.f && fabsf(d) > 3e-7f * uni) return d > 0.f;
     if (uni > 0.f && uni < INFINITY && inter < INFINITY) {
         const double pm = t.m * (double)uni, di = (double)inter;
         return di > pm || (di == pm && t.even);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
     const float* pred = a.pred + (size_t)b * a.N * no;
     int P = 1;
     while (P < n) P <<= 1;
-    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even, (float)a.iou_m};
     unsigned long long t_a = 0, t_b = 0, t_ld = 0, t0 = __builtin_readcyclecounter();
 
     // ---- can classes interact in this image?  (x-extent of all candidates)
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(kSortT) void nms_cscan_kernel(const NmsArgs a) {
     if (n64 > cap) n64 = cap;
     const int n = (int)n64;
     const Cand* cands = a.cands + (size_t)b * kMaskN;
-    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even, (float)a.iou_m};
     for (int i = tid; i < n; i += kSortT) {
         const Cand c = cands[i];
         bx1[i] = c.x1; by1[i] = c.y1; bx2[i] = c.x2; by2[i] = c.y2;
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     if (n == 0 || n > kMaskN) return;
     const int nb = (n + 63) >> 6;
     const int npairs = nb * (nb + 1) / 2;
-    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even};
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even, (float)a.iou_m};
     const Cand* cands = a.cands + (size_t)b * kMaskN;
     unsigned long long* mask = a.mask + (size_t)b * kMaskN * kMaskW;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
