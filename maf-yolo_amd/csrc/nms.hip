@@ -212,6 +212,15 @@ __device__ __forceinline__ bool iou_gt(const Cand& k, const Cand& c, const IouTh
     return (double)(inter / uni) > t.thr;                   // zero / negative / non-finite union: the literal formula
 }
 
+// The screen alone, branch-free, for the pair-matrix kernel: 1 / 0 = decided, -1 = inside the band (or a NaN / infinite / non-positive
+// union: every comparison below is false for those) — the caller then asks iou_gt.  Disjoint boxes give inter = 0, d = -m * uni < 0: "no".
+__device__ __forceinline__ int iou_screen(const Cand& k, const Cand& c, float m32) {
+    const float w = fmaxf(0.f, fminf(k.x2, c.x2) - fmaxf(k.x1, c.x1)), h = fmaxf(0.f, fminf(k.y2, c.y2) - fmaxf(k.y1, c.y1));
+    const float inter = w * h, uni = k.area + c.area - inter;
+    const float d = __builtin_fmaf(-m32, uni, inter);
+    return (uni > 0.f && fabsf(d) > 3e-7f * uni) ? (d > 0.f ? 1 : 0) : -1;
+}
+
 __device__ void bitonic_sort(unsigned long long* k, int P, int tid, int nthreads) {
     for (int size = 2; size <= P; size <<= 1) {
         for (int j = size >> 1; j > 0; j >>= 1) {
@@ -659,8 +668,15 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
             const Cand me = cands[i];
             unsigned long long bits = 0;
             const int jn = min(64, n - j0);
-            for (int j = (cbk == rb ? lane + 1 : 0); j < jn; ++j)    // diagonal block: only later candidates
-                if (iou_gt(me, cb[j], iouthr)) bits |= 1ull << j;
+            const int jlo = cbk == rb ? lane + 1 : 0;                // diagonal block: only later candidates
+            for (int j = 0; j < jn; ++j) {                           // uniform trip count, no divergence in the common case
+                const int r = iou_screen(me, cb[j], iouthr.m32);
+                bool hit = r > 0;
+                if (__any(r < 0)) {                                  // rare: some lane sits inside the screen's band
+                    if (r < 0) hit = iou_gt(me, cb[j], iouthr);
+                }
+                bits |= (unsigned long long)(hit && j >= jlo) << j;
+            }
             mask[(size_t)i * kMaskW + cbk] = bits;
         }
     }
