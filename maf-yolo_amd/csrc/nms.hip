@@ -86,10 +86,11 @@ __device__ __forceinline__ bool multi_ok(const NmsArgs& a, const float* pred, un
     return ok;
 }
 
-// multi_label: one lane per (box, class) element of the prediction tensor, fully coalesced.  A workgroup owns a
-// contiguous chunk: pass 1 counts its candidates, ONE atomicAdd per chunk reserves the output range (a per-wave
-// atomic per hit costs ~10 ns each on one contended line — 64k of them were 0.65 ms), pass 2 re-tests (L1 hits)
-// and writes the keys.  Candidate order inside the list is irrelevant: the sort key carries the flat index.
+// multi_label: one lane per (box, class) element of the prediction tensor, fully coalesced.  A workgroup owns a contiguous chunk of
+// 8192 elements (32 per lane): it reads them once, keeps the 32 scores and a hit mask in registers, counts the candidates with wave
+// ballots, reserves the output range with ONE atomicAdd per chunk (a per-wave atomic per hit costs ~10 ns each on one contended line —
+// 64k of them were 0.65 ms) and writes the keys from the registers.  Candidate order inside the list is irrelevant: the sort key carries
+// the flat index.
 __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a) {
     __shared__ int wave_cnt[4];
     __shared__ int s_base;
@@ -100,9 +101,14 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
     const float* pred = a.pred + (size_t)b * a.N * no;
     for (unsigned int c0 = blockIdx.x * kChunk; c0 < total; c0 += gridDim.x * kChunk) {
-        // both passes read 8 elements per lane at a time: the 16 loads are issued together (unconditional, clamped), the tests follow
+        // ONE pass over memory: 8 elements per lane are loaded together (unconditional, clamped), tested, and their scores stay in
+        // registers with a hit mask; after the chunk's single atomicAdd the keys are written from the registers.
+        constexpr int E = kChunk / 256;                                    // 32 elements per lane
+        float sc[E];
+        unsigned int hits = 0;
         int mine = 0;
-        for (int i0 = 0; i0 < kChunk / 256; i0 += 8) {
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += 8) {
             float obj[8], raw[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -115,6 +121,8 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
             for (int u = 0; u < 8; ++u) {
                 const unsigned int e = c0 + (i0 + u) * 256 + tid;
                 const bool ok = e < total && multi_ok(a, pred, e, no, obj[u], raw[u]);
+                sc[i0 + u] = raw[u] * obj[u];
+                hits |= ok ? 1u << (i0 + u) : 0u;
                 mine += __popcll(__ballot(ok));                            // wave-uniform running count
             }
         }
@@ -127,25 +135,13 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
         __syncthreads();
         int pos = s_base;
         for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
-        const bool any = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3] > 0;
-        if (any) {
-            for (int i0 = 0; i0 < kChunk / 256; i0 += 8) {
-                float obj[8], raw[8];
+        if (mine > 0) {                                                    // wave-uniform
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned int e = min(c0 + (i0 + u) * 256 + tid, total - 1);
-                    const unsigned int box = e / (unsigned int)a.nc;
-                    const float* row = pred + (size_t)box * no;
-                    obj[u] = row[4]; raw[u] = row[5 + (e - box * (unsigned int)a.nc)];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned int e = c0 + (i0 + u) * 256 + tid;
-                    const bool ok = e < total && multi_ok(a, pred, e, no, obj[u], raw[u]);
-                    const unsigned long long m = __ballot(ok);
-                    if (ok) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(raw[u] * obj[u])) << 32) | e;
-                    pos += __popcll(m);
-                }
+            for (int u = 0; u < E; ++u) {
+                const bool ok = (hits >> u) & 1u;
+                const unsigned long long m = __ballot(ok);
+                if (ok) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(sc[u])) << 32) | (c0 + u * 256 + tid);
+                pos += __popcll(m);
             }
         }
         __syncthreads();
