@@ -65,6 +65,9 @@ typedef struct {
  *                   K = concat of the sources' channels in order (= torch.cat order).
  * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
  *                   2H x 2W input (Hin, Win below); w packed per tap.
+ *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
+ *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
+ *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).
  * MAF_OP_DWCONV     replaces DilatedReparamBlock.lk_origin after merge (common.py:3025,3033-3051).
  *                   w = [k*k][C] of the activation dtype.  tile_p / tile_c / tile_k optionally fix the workgroup tile
  *                   (rows, cols, channels per block); 0 = built-in cost model.  tile_p = -1 (fp16) selects the matrix-core
@@ -130,6 +133,7 @@ int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
 int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);
+int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout);
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

@@ -1,0 +1,152 @@
+// 3x3 stride-2 pad-1 conv for narrow layers on big maps (tile_k = 6 of MAF_OP_CONV3X3S2): RepVGGBlock / ConvWrapper / MPRep.conv2 in deploy
+// form (yolov6/layers/common.py:216-217, 76-83, 776-792) where 9 * Cin * Cout weights fit the LDS — backbone.3.conv2 (48 -> 48) and
+// backbone.18 (48 -> 64) of MAF-YOLO-n on the 160 x 160 map.  The generic template reads every input pixel 2.25 times through L2 and its
+// weight fragments once per wave; here a persistent workgroup keeps ALL weight fragments in LDS and stages the (2 TY + 1) x 33 input
+// patch of a TY x 16 output tile once (aligned 16-byte loads of the NHWC pixels, prefetched a tile ahead into registers, stored
+// pixel-major with a 2 * odd dword stride so the stride-2 fragment reads of 16 lanes cover all 64 banks).  The product is taken as in
+// csrc/stem2.hip phase C: K = 9 taps x Cin / 8 (tap, 8-channel group) pairs, four pairs per MFMA k-step, transposed (A = weights,
+// B = patch) so a lane holds 4 consecutive output channels of one pixel; bias + activation, through LDS, whole NHWC pixels out.
+#include "maf_common.h"
+
+namespace {
+
+struct C3Args {
+    const half_t* in; const char* rec; half_t* out;
+    int B, Hin, Win, H, W, in_stride, in_coff, out_stride, out_coff, act, tilesX, tilesY, ntiles;
+};
+
+template <int CIN, int COUT, int TY>
+__global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CIN / 2 + 2) | 2) * 4 + TY * 16 * COUT * 2) <= 80 * 1024 ? 2 : 1) void conv3s2_lds_kernel(const C3Args a) {
+    constexpr int MR = TY / 4, TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC;
+    constexpr int GR = CIN / 8, NP = 9 * GR, KS = (NP + 3) / 4, NT = COUT / 16;
+    constexpr int TS = (CIN / 2 + 2) | 2;                        // pixel stride in dwords: 2 * odd
+    static_assert((TS / 2) % 2 == 1 && TS * 2 >= CIN, "patch stride");
+    constexpr int TSH = TS * 2, WB = KS * NT * 64 * 16;
+    constexpr int NCHK = SP * GR, PF = (NCHK + 255) / 256;
+    __shared__ __attribute__((aligned(16))) half_t s_T[SP * TSH + 64];
+    __shared__ __attribute__((aligned(16))) half_t s_out[TY * TX * COUT];
+    __shared__ __attribute__((aligned(16))) char s_w[WB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.rec);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        for (int i = tid; i < WB / 16; i += 256) dst[i] = src[i];
+    }
+    const float* bias = reinterpret_cast<const float*>(a.rec + WB);
+    f32x4_t bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4_t*>(bias + 16 * t + 4 * g);
+    int off1[KS];                                                // patch offsets (halves) of this lane's (tap, group) pair in every k-step
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int q = min(4 * s + g, NP - 1), tap = q / GR, grp = q - tap * GR;
+        off1[s] = ((tap / 3) * SC + tap % 3) * TSH + 8 * grp;
+    }
+    const half8_t* wf = reinterpret_cast<const half8_t*>(s_w);
+    uint4 pf[PF];
+    bool pf_in[PF];
+    auto prefetch = [&](int tile) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const half_t* img = a.in + (size_t)b * a.Hin * a.Win * a.in_stride + a.in_coff;
+        const int iy0 = 2 * ty * TY - 1, ix0 = 2 * tx * TX - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = min(tid + 256 * u, NCHK - 1);
+            const int px = e / GR, grp = e - px * GR, sr = px / SC, sc = px - sr * SC;
+            const int iy = iy0 + sr, ix = ix0 + sc;
+            pf_in[u] = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const size_t at = pf_in[u] ? ((size_t)iy * a.Win + ix) * a.in_stride + 8 * grp : 0;   // clamped: the load stays unconditional
+            pf[u] = *reinterpret_cast<const uint4*>(img + at);
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const int Y0 = ty * TY, X0 = tx * TX;
+        __syncthreads();                                         // s_T and s_out of the previous tile are free; first pass: s_w is in place
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = tid + 256 * u;
+            if (e < NCHK) {
+                const int px = e / GR, grp = e - px * GR;
+                uint4 v = pf[u];
+                if (!pf_in[u]) v = make_uint4(0u, 0u, 0u, 0u);   // zero padding
+                uint2* d = reinterpret_cast<uint2*>(s_T + px * TSH + 8 * grp);   // 8-byte aligned (the pixel stride is 8 * odd bytes)
+                d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+        f32x4_t acc[MR][NT];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8_t tf[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int yy = wave * MR + m;
+                const half_t* tp = s_T + ((2 * yy) * SC + 2 * n) * TSH + off1[s];
+                const half4_t lo = *reinterpret_cast<const half4_t*>(tp), hi = *reinterpret_cast<const half4_t*>(tp + 4);
+                tf[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const half8_t w8 = wf[(s * NT + t) * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8, tf[m], acc[m][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                half4_t v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act_rt(acc[m][t][q] + bv[t][q], a.act);
+                *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * COUT + 16 * t + 4 * g) = v;
+            }
+        __syncthreads();
+        constexpr int CPP = COUT / 8;
+        for (int q = tid; q < TY * TX * CPP; q += 256) {
+            const int px = q / CPP, part = q - px * CPP;
+            const int oy = Y0 + px / TX, ox = X0 + px % TX;
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + 8 * part) =
+                    *reinterpret_cast<const uint4*>(s_out + px * COUT + 8 * part);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout) {
+    const int ks = (9 * (Cin / 8) + 3) / 4;
+    return (int64_t)ks * (Cout / 16) * 64 * 16 + Cout * 4;
+}
+
+int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s) {
+    MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32, "conv3x3s2 (tile_k = 6): fp16 only");
+    const maf_src_t& sr = op->src[0];
+    MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr && sr.C == op->Cin, "conv3x3s2 (tile_k = 6): one direct source");
+    MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "conv3x3s2 (tile_k = 6): 16-byte aligned channel slices");
+    MAF_REQUIRE(op->w && op->out, "conv3x3s2 (tile_k = 6): null pointer");
+    MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->Hin - 1) / 2 + 1 == op->H && (op->Win - 1) / 2 + 1 == op->W, "conv3x3s2: H,W must equal floor((Hin-1)/2)+1");
+    MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv3x3s2: bad act");
+    C3Args a;
+    a.in = static_cast<const half_t*>(sr.ptr); a.rec = static_cast<const char*>(op->w); a.out = static_cast<half_t*>(op->out);
+    a.B = op->B; a.Hin = op->Hin; a.Win = op->Win; a.H = op->H; a.W = op->W;
+    a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff; a.act = op->act;
+    const int ty = 4;                                             // 4 x 16 output tiles
+    a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, ty); a.ntiles = a.B * a.tilesX * a.tilesY;
+    const dim3 grid(std::min(a.ntiles, op->tile_c > 0 ? op->tile_c * 64 : 256)), blk(256);
+#define MAF_C3(CI, CO) hipLaunchKernelGGL((conv3s2_lds_kernel<CI, CO, 4>), grid, blk, 0, s, a)
+    if (op->Cin == 48 && op->Cout == 48) MAF_C3(48, 48);
+    else if (op->Cin == 48 && op->Cout == 64) MAF_C3(48, 64);
+    else if (op->Cin == 64 && op->Cout == 64) MAF_C3(64, 64);
+    else { maf_set_error("conv3x3s2 (tile_k = 6): (Cin, Cout) must be (48, 48), (48, 64) or (64, 64)"); return MAF_E_UNSUPPORTED; }
+#undef MAF_C3
+    return maf_check_hip(hipGetLastError(), "conv3s2_lds launch");
+}

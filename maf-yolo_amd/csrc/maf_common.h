@@ -35,6 +35,7 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s);
 int maf_launch_conv1dw(const maf_op_t* op, hipStream_t s);
 int maf_launch_head_tail(const maf_op_t* op, hipStream_t s);
 int maf_launch_stem2(const maf_op_t* op, hipStream_t s);
+int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s);
 
 // ---- device helpers ----
 template <int ACT>

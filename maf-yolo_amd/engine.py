@@ -617,6 +617,9 @@ class Plan:
                     if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and 2 <= ksteps <= 12 and ksteps * ct <= 96 \
                             and all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc)) and (direct or ct >= 4):
                         cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
+                    if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and M >= 65536:
+                        for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)
+                            cands.append((4, wg, 6))
                     pooled = o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2
                     if ksteps >= 4 and ct >= 4 and self.dtype == lib.F16 and not o.out_f32 and not pooled:
                         for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
@@ -624,8 +627,8 @@ class Plan:
                                 cands.append((pt, ct, 2))
                 results = []
                 for pt, ct, tk in cands:
-                    wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
-                    bp = pack.pack_bias(b, ct).to(self.device)
+                    wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
+                    bp = pack.pack_bias(b, ct if tk != 6 else 4).to(self.device)
                     op = lib.MafOp.from_buffer_copy(o)
                     op.tile_p, op.tile_c, op.tile_k, op.w, op.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
                     lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))          # warm-up
@@ -640,11 +643,11 @@ class Plan:
                 best = (results[0][1], results[0][2], results[0][3])
                 _TUNE_CACHE[sig] = best
                 if verbose:
-                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
-                wp = (pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
-                bp = pack.pack_bias(b, ct).to(self.device)
+                wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
+                bp = pack.pack_bias(b, ct if tk != 6 else 4).to(self.device)
                 self._tuned += [wp, bp]
                 o.tile_p, o.tile_c, o.tile_k, o.w, o.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
                 changed += 1
@@ -700,6 +703,8 @@ class Plan:
             outf32 = "true" if (o.out_f32 and o.dtype == lib.F16) else "false"
             if o.tile_k == 3:
                 return "conv1x1_stream_kernel<%d, %d, %d>" % (o.tile_p, o.tile_c, -(-o.Cin // 32))
+            if o.tile_k == 6:
+                return "conv3s2_lds_kernel<%d, %d, 4>" % (o.Cin, o.Cout)
             if o.tile_k == 5:
                 return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")

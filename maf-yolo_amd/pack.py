@@ -249,3 +249,23 @@ def pack_stem2(w0, b0, w1, b1, w3=None, b3=None):
     rec = torch.cat(parts)
     assert rec.numel() == n
     return rec
+
+
+def pack_conv3x3_lds(w, b):
+    """Record of the LDS-resident 3x3 stride-2 conv (csrc/conv3s2_lds.hip, tile_k = 6): w [Cout, Cin, 3, 3], b [Cout] -> fragments
+    [ceil(9*Cin/8 / 4)][Cout/16][64 lanes][8] f16 (lane (g, n) of k-step s: pair q = 4s + g -> tap q // (Cin/8), channel group q % (Cin/8);
+    element j = input channel 8*group + j; output channel 16t + n; zero for pairs past the last tap) | bias fp32 [Cout]."""
+    w = w.detach().float().cpu()
+    cout, cin = w.shape[:2]
+    assert cin % 8 == 0 and cout % 16 == 0 and w.shape[2:] == (3, 3)
+    gr = cin // 8
+    npair = 9 * gr
+    ks = (npair + 3) // 4
+    m1 = torch.zeros(ks * 4, 8, cout)                               # [pair][j][out channel]
+    for q in range(npair):
+        tap, grp = divmod(q, gr)
+        m1[q] = w[:, 8 * grp:8 * grp + 8, tap // 3, tap % 3].t()
+    f = m1.view(ks, 4, 8, cout // 16, 16).permute(0, 3, 1, 4, 2).contiguous().half()   # [s][t][g][n][j]
+    rec = torch.cat([f.reshape(-1).view(torch.uint8), b.detach().float().cpu().contiguous().view(torch.uint8)])
+    assert rec.numel() == ks * (cout // 16) * 1024 + cout * 4
+    return rec

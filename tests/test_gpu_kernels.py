@@ -268,6 +268,35 @@ def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
     assert (out[..., :cout] == 0).all()
 
 
+@pytest.mark.parametrize("cin,cout,act,hw", [(48, 48, lib.ACT_RELU, (36, 50)), (48, 64, lib.ACT_SILU, (64, 64)), (64, 64, lib.ACT_RELU, (22, 34)), (48, 48, lib.ACT_SILU, (160, 160))])
+def test_conv3x3_stride2_lds_resident(cin, cout, act, hw):
+    """tile_k = 6 (csrc/conv3s2_lds.hip): all weight fragments + the input patch of a 4 x 16 tile in LDS, persistent workgroups; odd input
+    sizes, tiles hanging over the map, channel slices on both sides; equals the generic MFMA template to fp32-summation-order noise."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    B, (Hin, Win) = 3, hw
+    x = _q(torch.randn(B, cin, Hin, Win, generator=g), lib.F16)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), lib.F16)
+    bias = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x, w, bias, 2, 1), act)
+    H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+    xs = torch.zeros(B, Hin, Win, cin + 16, dtype=torch.float16, device=DEV)          # the input is a channel slice of a wider buffer
+    xs[..., 8:8 + cin] = _nhwc(x, lib.F16)
+    outs = []
+    for tk, wg in ((6, 0), (6, 1), (1, 0)):
+        out = torch.full((B, H, W, 2 * cout), 3.0, dtype=torch.float16, device=DEV)
+        wp = (pack.pack_conv3x3_lds(w, bias) if tk == 6 else pack.pack_conv3x3(w, 4, lib.F16)).to(DEV)
+        op = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, cin, cout, act, [(xs, cin, cin + 16, 8, 0)], out, 2 * cout, cout, wp, pack.pack_bias(bias, 4).to(DEV),
+                      4 if tk == 6 else 1, wg if tk == 6 else 4, Hin=Hin, Win=Win)
+        op.tile_k = tk
+        _launch(op)
+        _check(out[..., cout:], ref, lib.F16)
+        assert (out[..., :cout] == 3).all(), "wrote outside its slice"
+        outs.append(out[..., cout:].float())
+    assert torch.equal(outs[0], outs[1])                                             # the workgroup count does not change a bit
+    assert (outs[0] - outs[2]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
+    assert wp.numel() * 0 == 0 and pack.pack_conv3x3_lds(w, bias).numel() == lib.load().maf_conv3s2_lds_record_bytes(cin, cout)
+
+
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
 @pytest.mark.parametrize("k", [3, 5, 7, 9])
 @pytest.mark.parametrize("C_,H,W", [(72, 11, 10), (192, 40, 40), (576, 20, 20), (24, 37, 50)])   # ragged tiles, multi-tile, multi-block
