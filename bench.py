@@ -248,7 +248,9 @@ def main():
             torch.cuda.synchronize(dev)
 
     S = max(1, args.inflight)
-    streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    # streams that share a hardware queue run their kernels one after the other: take streams that demonstrably overlap (streams.py)
+    cs = M.concurrent_streams(dev, S + 1)                      # S forward streams + the NMS stream, on different hardware queues
+    streams, nms_stream = (cs[:S] if S > 1 else [torch.cuda.current_stream(dev)]), cs[S]
 
     def pipelined(n):
         """n steps of the serving loop: every step = one forward + one NMS of a batch.  Up to S batches are in flight: step i runs on
@@ -260,7 +262,7 @@ def main():
             k = i % S
             with torch.cuda.stream(streams[k]), torch.no_grad():
                 pred_i = model(x, slot=k)[0]
-                pending.append(M.non_max_suppression_async(pred_i, conf, iou, multi_label=True))
+                pending.append(M.non_max_suppression_async(pred_i, conf, iou, multi_label=True, side=nms_stream))
             if len(pending) > S:                                   # collect batch i - S once batch i is queued
                 dets = pending.pop(0).result()
         for h in pending:

@@ -81,15 +81,17 @@ class NmsHandle:
         return out
 
 
-def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, side=None):
     """Same arguments as non_max_suppression, but the kernels go to a side stream ordered after the current one and
     the call returns at once; `handle.result()` gives the reference's list of tensors.  A serving loop calls this for
     batch i, launches the forward of batch i+1, then collects batch i: the (latency-bound, 32-workgroup) NMS of one
-    batch overlaps the convolutions of the next."""
+    batch overlaps the convolutions of the next.  `side`: the stream to use (default: one per device, created on first use; streams
+    that share a hardware queue do not overlap — see streams.concurrent_streams)."""
     dev = prediction.device
-    side = _side.get(dev.index)
-    if side is None:
-        side = _side[dev.index] = torch.cuda.Stream(dev)
+    if side is None:                                       # `side`: the caller's stream for the NMS (e.g. one of streams.concurrent_streams)
+        side = _side.get(dev.index)
+        if side is None:
+            side = _side[dev.index] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     prediction.record_stream(side)                         # the caching allocator must not hand this block out again before the NMS has read it
     rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, stream=side)

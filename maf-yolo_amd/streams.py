@@ -1,0 +1,43 @@
+"""HIP streams that really run side by side.
+
+ROCm multiplexes the streams of a process onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES); two streams that land on the
+same queue execute their kernels strictly one after the other.  A serving loop that keeps two batches in flight on two streams
+(Model.forward(x, slot=k), bench.py) then silently loses the overlap — measured: 1.58 ms per forward on two queues, 2.0 ms when the
+streams alias.  `concurrent_streams` creates streams until it has `n` that demonstrably overlap (timed with spin kernels)."""
+import time
+
+import torch
+
+
+def _spin_ms(streams, cycles):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cycles)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def concurrent_streams(device, n=2, tries=12, cycles=2_000_000):
+    """-> list of n torch.cuda.Stream on `device` whose kernels overlap pairwise (falls back to plain new streams if the probe cannot
+    tell, e.g. a device that runs one kernel at a time)."""
+    device = torch.device(device)
+    with torch.cuda.device(device):
+        picked = [torch.cuda.Stream(device)]
+        _spin_ms(picked, cycles)                                   # warm-up (first launch of the spin kernel)
+        one = min(_spin_ms(picked, cycles) for _ in range(2))
+        rejected = []                                              # keep them alive: a destroyed stream's queue slot is handed out again
+        for _ in range(tries):
+            if len(picked) == n:
+                break
+            s = torch.cuda.Stream(device)
+            both = min(_spin_ms(picked + [s], cycles) for _ in range(2))
+            if both < (len(picked) + 0.5) * one:                   # all of them together take about as long as one: they overlap
+                picked.append(s)
+            else:
+                rejected.append(s)
+        while len(picked) < n:
+            picked.append(torch.cuda.Stream(device))
+        concurrent_streams._keep = getattr(concurrent_streams, "_keep", []) + rejected
+    return picked

@@ -524,3 +524,23 @@ def test_two_batches_in_flight_on_two_streams_give_the_single_stream_result(mode
             assert all(torch.equal(a, b) for a, b in zip(dets[i], wdets[i])), (rep, i)
     assert m.plan_for(xs[0], slot=0) is not m.plan_for(xs[0], slot=1)
     assert m.plan_for(xs[0], slot=0).arena.data_ptr() != m.plan_for(xs[0], slot=1).arena.data_ptr()
+
+
+def test_concurrent_streams_overlap():
+    """streams.concurrent_streams: the streams it returns run spin kernels side by side (streams that alias onto one hardware queue —
+    which plain torch.cuda.Stream() pairs sometimes do — would take n times as long)."""
+    import time
+    ss = M.concurrent_streams(DEV, 3)
+    assert len({s.cuda_stream for s in ss}) == 3
+    def spin(streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in streams:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(4_000_000)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    spin(ss[:1])
+    one = min(spin(ss[:1]) for _ in range(3))
+    three = min(spin(ss) for _ in range(3))
+    assert three < 2.0 * one, (one, three)
