@@ -251,6 +251,7 @@ def main():
     # streams that share a hardware queue run their kernels one after the other: take streams that demonstrably overlap (streams.py)
     cs = M.concurrent_streams(dev, S + 1)                      # S forward streams + the NMS stream, on different hardware queues
     streams, nms_stream = (cs[:S] if S > 1 else [torch.cuda.current_stream(dev)]), cs[S]
+    probe0 = M.concurrent_streams.last_ratio
 
     def pipelined(n):
         """n steps of the serving loop: every step = one forward + one NMS of a batch.  Up to S batches are in flight: step i runs on
@@ -271,6 +272,10 @@ def main():
 
     # ---- the timed region: K steps of forward + NMS, software-pipelined across steps (the host-side hand-over of the NMS result — a
     #      count read-back and 32 slices — otherwise idles the GPU for 0.1-0.3 ms per step, and makes the number follow host jitter)
+    # set-up, not part of the W warm-up steps: the first few dozen iterations of the loop grow the caching allocator's pools (prediction
+    # tensors handed to the NMS stream return to the forward stream's pool late), and every hipMalloc that causes stalls the device —
+    # measured as an occasional 2.5 ms/step first run of an otherwise 1.67 ms/step loop.  Run the loop until the pools are settled.
+    pipelined(48)
     if args.warmup:
         dets = pipelined(args.warmup)
     sync_all()
@@ -286,12 +291,15 @@ def main():
         elapsed = t.item()
     ms_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
+    from maf_yolo_amd.streams import overlap_ratio
+    probe1 = overlap_ratio(cs)
+    arenas = [model.plan_for(x, slot=k).arena.data_ptr() for k in range(S)]
 
     # ---- one batch in flight (one stream; only the NMS of batch i overlaps the forward of batch i+1), rank-local
     one_ms = None
     if S > 1:
         S_keep, streams_keep = S, streams
-        S, streams = 1, [torch.cuda.current_stream(dev)]
+        S, streams = 1, [streams_keep[0]]                   # a real stream, not the legacy default one (which synchronises with every other stream)
         sync_all()
         t0 = time.perf_counter()
         dets = pipelined(args.steps)
@@ -416,7 +424,8 @@ def main():
                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": "replicas x%d (no collective)" % world,
                           "execution": "K steps of forward + NMS of one batch each; %d batches in flight (step i on HIP stream i %% %d with its own "
                                        "activation arena, its NMS on a side stream); all K forwards and K NMS results complete inside the timed region" % (S, S),
-                          "batches_in_flight": S,
+                          "batches_in_flight": S, "arena_base": ["0x%x" % a_ for a_ in arenas], "stream_overlap_probe": {"at_start": round(probe0, 2), "after_timed_region": round(probe1, 2),
+                                                                           "meaning": "spin kernels on all serving streams at once / one alone: ~1 = distinct hardware queues"},
                           "tiles": ("per-layer tile / variant choices loaded from %s, the rest timed at start-up" % os.path.relpath(args.tune_file, ROOT)) if args.tune_file and os.path.exists(args.tune_file) else "every layer's tile / variant timed at start-up",
                           "nms_candidates_per_image": {"mean": round(cand_mean, 1), "max": cand_max},
                           "detections_per_image_mean": round(float(np.mean([d.shape[0] for d in dets])), 1)},

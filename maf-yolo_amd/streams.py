@@ -19,25 +19,31 @@ def _spin_ms(streams, cycles):
     return (time.perf_counter() - t0) * 1e3
 
 
-def concurrent_streams(device, n=2, tries=12, cycles=2_000_000):
+def overlap_ratio(streams, cycles=2_000_000, reps=4):
+    """time of one spin kernel on every stream at once / time of one spin kernel alone: ~1 if all streams overlap, ~k if k of them share a queue."""
+    _spin_ms(streams[:1], cycles)
+    one = min(_spin_ms(streams[:1], cycles) for _ in range(reps))
+    return min(_spin_ms(streams, cycles) for _ in range(reps)) / one
+
+
+def concurrent_streams(device, n=2, tries=16, cycles=2_000_000):
     """-> list of n torch.cuda.Stream on `device` whose kernels overlap pairwise (falls back to plain new streams if the probe cannot
-    tell, e.g. a device that runs one kernel at a time)."""
+    tell, e.g. a device that runs one kernel at a time).  `concurrent_streams.last_ratio` = overlap_ratio of the returned set."""
     device = torch.device(device)
     with torch.cuda.device(device):
+        torch.cuda.synchronize()
         picked = [torch.cuda.Stream(device)]
-        _spin_ms(picked, cycles)                                   # warm-up (first launch of the spin kernel)
-        one = min(_spin_ms(picked, cycles) for _ in range(2))
-        rejected = []                                              # keep them alive: a destroyed stream's queue slot is handed out again
+        rejected = []                                              # kept alive: a destroyed stream's queue slot would be handed out again
         for _ in range(tries):
             if len(picked) == n:
                 break
             s = torch.cuda.Stream(device)
-            both = min(_spin_ms(picked + [s], cycles) for _ in range(2))
-            if both < (len(picked) + 0.5) * one:                   # all of them together take about as long as one: they overlap
+            if overlap_ratio(picked + [s], cycles) < 1.4:          # all of them together take about as long as one: every pair overlaps
                 picked.append(s)
             else:
                 rejected.append(s)
         while len(picked) < n:
             picked.append(torch.cuda.Stream(device))
         concurrent_streams._keep = getattr(concurrent_streams, "_keep", []) + rejected
+        concurrent_streams.last_ratio = overlap_ratio(picked, cycles) if n > 1 else 1.0
     return picked
