@@ -28,6 +28,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The serving loop keeps three batches in flight on three streams plus one for the NMS.  ROCm multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other: give them room.  (Must be set
+# before the HIP runtime starts, i.e. before torch is imported; an explicit setting in the environment wins.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense
@@ -165,7 +169,7 @@ def main():
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
     ap.add_argument("--lanes", type=int, default=-1, help="engine streams: 0 one stream, 1 heads on side streams, 2 heads + neck side convs (default: the model's setting)")
     ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight in the timed serving loop: step i runs on HIP stream i %% S with its own activation arena "
                          "(1 = one stream; the NMS of a batch still overlaps the next forward)")
     ap.add_argument("--tune-file", default=None,
