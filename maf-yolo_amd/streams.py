@@ -30,6 +30,9 @@ def concurrent_streams(device, n=2, tries=16, cycles=2_000_000):
     """-> list of n torch.cuda.Stream on `device` whose kernels overlap pairwise (falls back to plain new streams if the probe cannot
     tell, e.g. a device that runs one kernel at a time).  `concurrent_streams.last_ratio` = overlap_ratio of the returned set."""
     device = torch.device(device)
+    if not hasattr(torch.cuda, "_sleep"):                          # no spin kernel to time with: plain streams
+        concurrent_streams.last_ratio = float("nan")
+        return [torch.cuda.Stream(device) for _ in range(n)]
     with torch.cuda.device(device):
         torch.cuda.synchronize()
         picked = [torch.cuda.Stream(device)]
