@@ -112,7 +112,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     wh = torch.rand(nbox, 2, generator=g) * 0.35 + 0.04
     ctr = wh / 2 + torch.rand(nbox, 2, generator=g) * (1 - wh)
     targets = torch.cat([torch.arange(B).repeat_interleave(7)[:, None].float(), torch.randint(0, 80, (nbox, 1), generator=g).float(), ctr, wh], 1).to(dev)
-    crit = M.ComputeLoss(ori_img_size=640)
+    crit = M.ComputeLoss(ori_img_size=640, warmup_epoch=0)   # steady state of the schedule (epoch >= 3): the task-aligned assigner
 
     def step():
         with torch.autocast("cuda", dtype=torch.float16):

@@ -40,10 +40,10 @@ enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 c
        MAF_OP_DWCONV = 3,                /* merged DilatedReparamBlock: depth-wise k x k s1 (+bias+act) */
        MAF_OP_SPPF_POOL = 4,             /* three chained MaxPool2d(5,1,2) into concat slices           */
        MAF_OP_DECODE = 5,                /* Detect_yaml eval branch: DFL decode -> [B,A,5+nc] fp32      */
-       MAF_OP_BOTTLENECK = 6,
-       MAF_OP_CONV1DW = 7,
-       MAF_OP_HEADTAIL = 8,
-       MAF_OP_STEM2 = 9 };               /* backbone.0 + backbone.1: image -> 1/4-resolution map, the 1/2-resolution tensor stays in LDS */            /* one detection level: {cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode into the prediction rows */             /* first half of a DepthBottleneckUni: 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU */          /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
+       MAF_OP_BOTTLENECK = 6,            /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
+       MAF_OP_CONV1DW = 7,               /* first half of a DepthBottleneckUni: 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU */
+       MAF_OP_HEADTAIL = 8,              /* one detection level: {cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode into the prediction rows */
+       MAF_OP_STEM2 = 9 };               /* backbone.0 + backbone.1: image -> 1/4-resolution map, the 1/2-resolution tensor stays in LDS */
 enum { MAF_E_ARG = -1, MAF_E_UNSUPPORTED = -2, MAF_E_HIP = -3 };
 
 typedef struct {
@@ -96,7 +96,8 @@ typedef struct {
  *                   out = pred fp32 [B, A, 85] (supplied per run like DECODE's); Hin = first anchor of the level, Win = A (anchors
  *                   per image), lvl_stride[0] = stride; nc = 80, reg_max = 16; fp16 only.  tile_k = units per wave (0 = auto).
  * MAF_OP_DECODE     replaces Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396).
- *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,nc], and reg[l] = fp32 [B,HW_l,reg_stride] (both NULL: the level's rows are
+ *                   src[l] (l<3): ptr = cls fp32 [B,HW_l,src[l].stride] (row stride >= nc; 0 = nc: the pred conv pads nc to a multiple
+ *                   of 4 channels so that any class count runs), and reg[l] = fp32 [B,HW_l,reg_stride] (both NULL: the level's rows are
  *                   written by a MAF_OP_HEADTAIL, lvl_h / lvl_w still give its size);
  *                   out = pred fp32 [B, A, 5+nc].
  */
@@ -128,6 +129,9 @@ typedef struct {
 
 const char* maf_last_error(void);
 int maf_version(void);
+/* sizeof(maf_op_t) as this library was compiled: a binding checks its own struct against it at load time (a stub that is short of
+ * fields would make maf_engine_create read past every element of the op array). */
+int maf_op_size(void);
 /* Bytes of one 32-mid-channel block record of MAF_OP_BOTTLENECK for kernel size k and c = Cin = Cout channels. */
 int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
 int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);

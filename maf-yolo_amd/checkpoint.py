@@ -4,7 +4,8 @@ The reference checkpoints are pickled *modules*, not state_dicts: `torch.save({'
 'updates', 'optimizer', 'epoch'})` (yolov6/core/engine.py:195-201, stripped by checkpoint.py:107-122) and
 `load_checkpoint` (checkpoint.py:83-93) does `ckpt['ema' if ckpt.get('ema') else 'model'].float()` + `fuse_model`.
 Unpickling them normally needs the reference's source tree on sys.path.  Here a restricted unpickler maps every class
-that is not torch / numpy / builtins (the `yolov6.*` layers, the config Dict, ...) to an inert stand-in, so the module tree
+that is not on a short explicit allow-list (tensor rebuild functions, storages, dtypes, plain containers) — the `yolov6.*` layers, the
+torch.nn module classes, the config Dict, any builtins / functools / torch.hub callable — to an inert stand-in, so the module tree
 arrives as plain objects whose `_parameters` / `_buffers` / `_modules` dictionaries are walked into a state_dict; the
 architecture comes from the pickled model's own `yaml` dict (yolo.py:144-146).  No reference code is imported or executed.
 
@@ -19,7 +20,30 @@ import torch
 
 from .model import Model
 
-_SAFE_PREFIXES = ("torch", "numpy", "collections", "builtins", "_codecs", "copyreg", "__builtin__", "pathlib", "argparse", "functools")
+# Explicit allow-list: ONLY these globals are resolved to the real objects; everything else a pickle names — the
+# reference's `yolov6.*` layers, torch.nn module classes, builtins.eval / exec / getattr / __import__, functools.partial,
+# torch.hub / torch.utils loaders, os / subprocess ... — becomes an inert stand-in that stores state and runs nothing.
+_ALLOWED = {
+    "collections": {"OrderedDict"},
+    "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object"},
+    "__builtin__": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "object"},
+    "_codecs": {"encode"},                                     # protocol-2 encoding of bytes objects
+    "copyreg": {"_reconstructor"},                             # object.__new__(cls) for classes resolved through THIS lookup
+    "torch._utils": {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_parameter_with_state"},
+    "torch.nn.parameter": {"Parameter"},
+    "torch": {"Size", "device", "Tensor"},                     # + storage classes and dtype objects, see _allowed()
+    "numpy": {"ndarray", "dtype"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"},
+    "numpy._core.multiarray": {"_reconstruct", "scalar"},
+}
+
+
+def _allowed(module, name):
+    if name in _ALLOWED.get(module, ()):
+        return True
+    if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+        return True                                            # torch.FloatStorage ..., torch.float16 ...
+    return False
 
 
 class _Inert:
@@ -61,7 +85,7 @@ def _standin(module, name):
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] in _SAFE_PREFIXES:
+        if _allowed(module, name):
             return super().find_class(module, name)
         return _standin(module, name)
 

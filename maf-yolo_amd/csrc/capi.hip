@@ -14,7 +14,8 @@ int maf_check_hip(hipError_t e, const char* what) {
 }
 
 extern "C" const char* maf_last_error(void) { return g_err.c_str(); }
-extern "C" int maf_version(void) { return 100; }
+extern "C" int maf_version(void) { return 200; }
+extern "C" int maf_op_size(void) { return (int)sizeof(maf_op_t); }
 
 extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
     if (!op) { maf_set_error("maf_op_launch: null op"); return MAF_E_ARG; }

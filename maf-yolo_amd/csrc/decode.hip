@@ -20,7 +20,7 @@ struct DecArgs {
     int lvl_h[3], lvl_w[3], lvl_off[4], lvl_blk[4];
     float lvl_stride[3];
     float* out;
-    int B, A, nc, reg_stride, reg_max;
+    int B, A, nc, reg_stride, reg_max, cls_stride[3];
 };
 
 template <int NO_CT>   // 5+nc known at compile time (85) => the row/col split is a multiply-shift, not an integer division
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
     const int a0 = blk * 64;                       // first anchor (within level)
     const int nA = min(64, L - a0);
     const float* reg = (l == 0 ? a.reg[0] : l == 1 ? a.reg[1] : a.reg[2]) + ((size_t)b * L + a0) * a.reg_stride;
-    const float* cls = (l == 0 ? a.cls[0] : l == 1 ? a.cls[1] : a.cls[2]) + ((size_t)b * L + a0) * a.nc;
+    const int cstr = l == 0 ? a.cls_stride[0] : l == 1 ? a.cls_stride[1] : a.cls_stride[2];      // >= nc: the pred conv pads its rows to 4 channels
+    const float* cls = (l == 0 ? a.cls[0] : l == 1 ? a.cls[1] : a.cls[2]) + ((size_t)b * L + a0) * cstr;
     const int W = l == 0 ? a.lvl_w[0] : l == 1 ? a.lvl_w[1] : a.lvl_w[2];
     const float stride = l == 0 ? a.lvl_stride[0] : l == 1 ? a.lvl_stride[1] : a.lvl_stride[2];
     const int tid = threadIdx.x;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecArgs a) {
         } else if (col == 4) {
             v = 1.0f;
         } else {
-            v = cls[(size_t)ai * a.nc + (col - 5)];
+            v = cls[(size_t)ai * cstr + (col - 5)];
         }
         out[e] = v;
     }
@@ -98,6 +99,8 @@ int maf_launch_decode(const maf_op_t* op, hipStream_t s) {
         a.cls[l] = static_cast<const float*>(op->src[l].ptr);
         a.reg[l] = static_cast<const float*>(op->reg[l]);
         a.lvl_h[l] = op->lvl_h[l]; a.lvl_w[l] = op->lvl_w[l]; a.lvl_stride[l] = op->lvl_stride[l];
+        a.cls_stride[l] = op->src[l].stride > 0 ? op->src[l].stride : op->nc;
+        MAF_REQUIRE(a.cls_stride[l] >= op->nc, "decode: src[l].stride (row stride of the class scores; 0 = nc) is smaller than nc");
         a.lvl_off[l] = off; a.lvl_blk[l] = blk;
         off += op->lvl_h[l] * op->lvl_w[l];
         blk += maf_cdiv(op->lvl_h[l] * op->lvl_w[l], 64);

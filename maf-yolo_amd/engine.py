@@ -73,8 +73,9 @@ _TORCH_DT = {lib.F16: torch.float16, lib.F32: torch.float32}
 class Buf:
     """A real NHWC buffer in the arena."""
 
-    def __init__(self, off, H, W, stride, esize):
+    def __init__(self, off, H, W, stride, esize, C=None):
         self.off, self.H, self.W, self.stride, self.esize = off, H, W, stride, esize
+        self.C = stride if C is None else C       # logical channels (< stride when the conv's Cout was padded, see cls_pred)
 
 
 class Seg:
@@ -341,10 +342,18 @@ class Plan:
                 outs = []
                 for br, pred, act, cpred in (("cls", m.cls_pred, lib.ACT_SIGMOID, self.nc), ("reg", m.reg_pred, lib.ACT_NONE, 4 * (self.reg_max + 1))):
                     u, v = self._alloc(x.H, x.W, c), self._alloc(x.H, x.W, c)
-                    o = self._alloc(x.H, x.W, cpred, 4)                                   # fp32 [B,HW,cpred]
+                    # any class count (the reference takes any nc): the conv kernels store 4 channels at a time, so the pred conv is
+                    # padded with zero filters to a multiple of 4 and the decode kernel reads the rows with that stride
+                    cpad = -(-cpred // 4) * 4
+                    o = self._alloc(x.H, x.W, cpad, 4)                                    # fp32 [B,HW,cpad]
+                    o.C = cpred
+                    pw, pb = pred.weight.detach(), pred.bias.detach()
+                    if cpad != cpred:
+                        pw = torch.cat([pw, pw.new_zeros(cpad - cpred, *pw.shape[1:])], 0)
+                        pb = torch.cat([pb, pb.new_zeros(cpad - cpred)], 0)
                     self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
                     self._conv1x1("%s.%s_conv_s" % (p, br), *getattr(m, br + "_conv_s").fused(), TV([Seg(u, c)], x.H, x.W), v, 0, lib.ACT_SILU)
-                    self._conv1x1("%s.%s_pred" % (p, br), pred.weight.detach(), pred.bias.detach(), TV([Seg(v, c)], x.H, x.W), o, 0, act, out_f32=True)
+                    self._conv1x1("%s.%s_pred" % (p, br), pw, pb, TV([Seg(v, c)], x.H, x.W), o, 0, act, out_f32=True)
                     outs.append(o)
                 self.head_bufs.append((t, outs[0], outs[1]))
                 y.append(None)
@@ -464,9 +473,10 @@ class Plan:
                 for l, (t, cls, reg) in enumerate(self.head_bufs):
                     if cls is not None:
                         o.src[l].ptr = abase + cls.off
+                        o.src[l].stride = cls.stride                      # row stride of the class scores (nc rounded up to 4)
                         o.reg[l] = abase + reg.off
                     o.lvl_h[l], o.lvl_w[l], o.lvl_stride[l] = t.H, t.W, self.strides[l]
-                o.reg_stride, o.nc, o.reg_max = 4 * (self.reg_max + 1), self.nc, self.reg_max
+                o.reg_stride, o.nc, o.reg_max = -(-4 * (self.reg_max + 1) // 4) * 4, self.nc, self.reg_max
         self.ops = ops
         self.op_names = [r["name"] for r in self._ops]
         h = C.c_void_p()
@@ -801,7 +811,7 @@ class Plan:
     def featmaps(self):
         """[(stem, cls, reg)] x 3 as NCHW views, the second element of the reference's Model.forward return.  Plans with the fused
         head tail never materialise cls / reg (None there): Model.forward(val_loss=True) builds its plan with fuse_head off."""
-        return [tuple(None if b is None else self.view(b).permute(0, 3, 1, 2) for b in hb) for hb in self.head_bufs]
+        return [tuple(None if b is None else self.view(b)[..., :b.C].permute(0, 3, 1, 2) for b in hb) for hb in self.head_bufs]
 
     def __del__(self):
         try:

@@ -29,7 +29,7 @@ class MafOp(C.Structure):
                 ("aux", C.c_void_p * 4), ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait", C.c_int32 * 8)]
 
 
-EXPORTS = ["maf_last_error", "maf_version", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
+EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
            "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_dw_wgrad", "maf_bottleneck_record_bytes", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
@@ -51,6 +51,9 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.maf_last_error.restype = C.c_char_p
     lib.maf_version.restype = C.c_int
+    if not hasattr(lib, "maf_op_size") or lib.maf_op_size() != C.sizeof(MafOp):
+        raise MafError("libmafyolo_hip.so was built for a maf_op_t of %s bytes, this binding declares %d: rebuild (__graft_entry__.build())"
+                       % (lib.maf_op_size() if hasattr(lib, "maf_op_size") else "?", C.sizeof(MafOp)))
     lib.maf_op_launch.argtypes = [C.POINTER(MafOp), C.c_void_p]
     lib.maf_engine_create.argtypes = [C.POINTER(MafOp), C.c_int32, C.POINTER(C.c_void_p)]
     lib.maf_engine_num_ops.argtypes = [C.c_void_p]

@@ -151,10 +151,10 @@ def _giou_loss(b1, b2, eps=1e-10):
 
 
 class ComputeLoss:
-    def __init__(self, fpn_strides=(8, 16, 32), grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, ori_img_size=640, warmup_epoch=0,
+    def __init__(self, fpn_strides=(8, 16, 32), grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, ori_img_size=640, warmup_epoch=3,
                  use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None, fused=True):
-        # warmup_epoch: the reference's default is 3 (loss.py:23) and the trainer does not override it (engine.py:303-308); pass 3 for the
-        # reference's schedule (ATSS for epochs 0-2, then task-aligned)
+        # warmup_epoch = 3 is the reference's default (loss.py:23) and its trainer does not override it (engine.py:303-308): ATSS assigns the
+        # labels in epochs 0-2, the task-aligned assigner afterwards.  Pass 0 for the task-aligned assigner from the first step.
         assert use_dfl and iou_type == "giou", "MAF-YOLO trains with DFL + GIoU (configs/MAF-YOLO-n.py:14-16)"
         self.fpn_strides, self.grid_cell_offset, self.grid_cell_size, self.warmup_epoch = tuple(fpn_strides), grid_cell_offset, grid_cell_size, warmup_epoch
         self.num_classes, self.ori_img_size, self.reg_max = num_classes, ori_img_size, reg_max

@@ -11,6 +11,8 @@ forward returns the reference's `(feats, cls[B,A,nc], reg[B,A,4*(reg_max+1)])` t
 train-form modules in layers.py.
 """
 import copy
+import itertools
+from operator import attrgetter
 
 import torch
 import torch.nn as nn
@@ -60,6 +62,9 @@ def _nodes_from_config(config, num_classes):
     raise ValueError("Model(config): pass 'n' | 's' | 'm', a YAML dict in the reference's schema, or the reference's config object")
 
 
+_VERSION = attrgetter("_version")
+
+
 class Model(nn.Module):
     def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None):
         super().__init__()
@@ -100,6 +105,8 @@ class Model(nn.Module):
         self.build_type = "yaml"
         self.precision = precision            # None: follow the input dtype; "fp16" | "fp32" force it
         self._plans = {}
+        self._plans_version = None            # weight fingerprint the cached plans were packed from (see weights_version)
+        self._fp_tensors = None
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.fuse_stem = True                 # True / 2: backbone.0 + backbone.1 + the 1x1 that opens backbone.2 in one launch (csrc/stem2.hip; fp16 plans of n and s); 1: without the 1x1; False
         self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
@@ -117,8 +124,30 @@ class Model(nn.Module):
         return super().train(mode)
 
     def load_state_dict(self, *a, **k):
-        self._plans = {}
+        self.invalidate()
         return super().load_state_dict(*a, **k)
+
+    def invalidate(self):
+        """Drop every cached plan (they hold packed copies of the weights).  Called automatically when the weight fingerprint
+        changes; call it by hand after replacing a parameter's storage (`p.data = ...`), which leaves no trace in `_version`."""
+        self._plans = {}
+        self._plans_version = None
+        self._fp_tensors = None
+
+    def _apply(self, fn, *a, **k):
+        # .to() / .cuda() / .float() / .half()-style conversions replace buffers and parameter storage (yolo.py:211-215 moves
+        # detect.stride the same way): plans packed from the old tensors are stale
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def weights_version(self):
+        """Fingerprint of the parameters and buffers: the sum of their autograd version counters, which every in-place update bumps —
+        an optimizer step, `ema.update` (the reference evaluates `self.ema.ema`, mutated in place every step and never put in train
+        mode: engine.py:246), `load_state_dict`, manual `p.mul_()` edits.  ~60 us for the 839 tensors of n."""
+        ts = self._fp_tensors
+        if ts is None:
+            ts = self._fp_tensors = list(itertools.chain(self.parameters(), self.buffers()))
+        return sum(map(_VERSION, ts)) + len(ts)
 
     def half(self):
         """Reference callers do `model.half()` after the deploy switch (evaler.py:112). Masters stay fp32 here;
@@ -132,6 +161,7 @@ class Model(nn.Module):
 
     def __deepcopy__(self, memo):
         plans, self._plans = self._plans, {}
+        fpt, self._fp_tensors = self._fp_tensors, None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -139,12 +169,13 @@ class Model(nn.Module):
             for k, v in self.__dict__.items():
                 new.__dict__[k] = copy.deepcopy(v, memo)
         finally:
-            self._plans = plans
+            self._plans, self._fp_tensors = plans, fpt
         return new
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_plans"] = {}
+        d["_fp_tensors"] = d["_plans_version"] = None
         return d
 
     # ------------------------------------------------------------------ forward
@@ -183,6 +214,10 @@ class Model(nn.Module):
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
         fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
         key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, repr(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), self.multi_stream)
+        ver = self.weights_version()
+        if ver != self._plans_version:         # the weights changed in place since the cached plans were packed (EMA update, optimizer step ...)
+            self._plans = {}
+            self._plans_version = ver
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 8:

@@ -17,17 +17,17 @@ _ws = {}
 _side = {}
 
 
-def _workspace(dev, B, N, nc, need):
-    """Ring of 3 scratch buffers per shape so that up to 3 NMS calls may be in flight on a device."""
-    key = (dev.index, B, N, nc)
-    ring = _ws.get(key)
-    if ring is None or ring[0][0].numel() < need:
-        if len(_ws) > 4:
-            _ws.clear()
-        ring = [[torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(3)], 0]
-        _ws[key] = ring
-    ring[1] = (ring[1] + 1) % 3
-    return ring[0][ring[1]]
+def _workspace(dev, st, B, N, nc, need):
+    """Scratch buffer for one NMS call on stream `st`.  One buffer per (stream, shape): calls on the same stream are ordered, so they may
+    share it; calls on different streams never do.  The buffer comes from the caching allocator while `st` is current, so when an entry is
+    dropped the allocator hands the block out again only in `st`'s own order — nothing in flight can lose its workspace."""
+    key = (dev.index, st.cuda_stream, B, N, nc)
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < need:
+        if len(_ws) >= 16:
+            _ws.pop(next(iter(_ws)))                  # oldest entry; stream-ordered reuse keeps that safe (see above)
+        ws = _ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws
 
 
 def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, stream=None):
@@ -37,18 +37,20 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     assert 0 <= iou_thres <= 1, f'iou_thres must be in 0.0 to 1.0, however {iou_thres} is provided.'
     if not prediction.is_cuda:
         raise lib.MafError("non_max_suppression runs on the HIP path only: got a %s tensor (no CPU fallback)" % prediction.device)
-    pred = prediction
-    if pred.dtype != torch.float32:
-        pred = pred.float()
-    pred = pred.contiguous()
-    B, N, no = pred.shape
+    B, N, no = prediction.shape
     nc = no - 5
-    dev = pred.device
+    dev = prediction.device
     L = lib.load()
     with torch.cuda.device(dev):
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         with torch.cuda.stream(st):
-            ws = _workspace(dev, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
+            # the fp16 -> fp32 cast (the reference's --half predictions) and the compaction of a strided view run on `st`, the stream
+            # the kernels read them on (the caller has ordered `st` after the producer of `prediction`)
+            pred = prediction
+            if pred.dtype != torch.float32:
+                pred = pred.float()
+            pred = pred.contiguous()
+            ws = _workspace(dev, st, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
             rows = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
             idx = torch.empty(B, max_det, dtype=torch.int64, device=dev)
             cnt = torch.empty(B, dtype=torch.int32, device=dev)
@@ -59,8 +61,8 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             lib.check(L.maf_nms(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
                                 cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
                                 int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(), st.cuda_stream))
-        if stream is not None:
-            pred.record_stream(st)
+        if stream is not None and pred is prediction:
+            pred.record_stream(st)                    # a caller-owned tensor read on a stream it was not allocated on
     return rows, idx, cnt
 
 

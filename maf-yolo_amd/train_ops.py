@@ -87,20 +87,23 @@ class _Conv1x1(torch.autograd.Function):
         cout = w.shape[0]
         dt = _DT[x.dtype]
         w2d = w.detach().reshape(cout, cin).float().contiguous()
-        ct = pack.tile_for(cout, B * H * W)[1]
-        wp = _packed_1x1(w2d, cout, cin, 0, dt, ct, x.device)
-        npad = -(-cout // (16 * ct)) * 16 * ct
+        co = -(-cout // 4) * 4                                                   # the kernel stores 4 channels at a time: any class count
+        if co != cout:                                                           # (cls_pred with nc % 4 != 0) runs with zero filters appended
+            w2d = F.pad(w2d, (0, 0, 0, co - cout))
+        ct = pack.tile_for(co, B * H * W)[1]
+        wp = _packed_1x1(w2d, co, cin, 0, dt, ct, x.device)
+        npad = -(-co // (16 * ct)) * 16 * ct
         if bias is None:
             bp = _zero_bias(x.device, npad)
         else:
             bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
             bp[:cout] = bias.detach().float()
-        out = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, cout, ct, out, dt)
+        out = torch.empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         stats["native_conv1x1"] += 1
-        return out
+        return out if co == cout else out[:, :cout]
 
     @staticmethod
     def backward(ctx, dy):
@@ -150,7 +153,7 @@ def conv1x1(x, w, bias=None):
         return F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
     x = _autocast(x)
     mult = 8 if x.dtype == torch.float16 else 4
-    if not (_ok(x, mult) and w.shape[0] % 2 == 0 and w.shape[2] == 1):
+    if not (_ok(x, mult) and w.shape[2] == 1):
         raise lib.MafError("conv1x1: unsupported input for the HIP path: %s %s -> %d channels" % (tuple(x.shape), x.dtype, w.shape[0]))
     return _Conv1x1.apply(x, w, bias)
 

@@ -1,0 +1,182 @@
+"""-m gpu: the fused kernels of the benchmarked fp16 path, each called through the C-ABI (maf_op_launch) and held against a plain
+PyTorch fp32 restatement of the layers it replaces, with the SAME fp16 rounding points (inputs, weights and every tensor the
+unfused path would store in fp16 are rounded first), so only the fp32 summation order and the final store rounding remain:
+
+* `head_tail_kernel`  == {cls,reg}_conv_s (1x1 + SiLU) -> {cls,reg}_pred (1x1) -> sigmoid / DFL expectation + dist2bbox + stride
+  (Head_DepthUni.forward common.py:1325-1336 after the depth-wise convs, Detect_yaml eval branch yolo.py:355-396)
+* `stem2_kernel`      == RepVGG 3x3 s2 + ReLU -> RepVGG 3x3 s2 + ReLU [-> 1x1 + SiLU] (common.py:216-217, RepHDW.conv1 :938)
+* the whole fp16 engine -> NMS at the BASELINE configs[1] image size against the REFERENCE's own detections
+  (tests/golden/maf_n.npz `nms640_eval_*`, produced by tools/make_golden.py from the imported reference in fp32).
+
+Tolerance of the per-kernel tests: |d| <= 2e-3 * max|ref| + 2e-3 (the bar of tests/test_gpu_kernels.py for fp16 kernels).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import maf_yolo_amd as M
+from maf_yolo_amd import lib, pack
+from oracle import maf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _launch(op):
+    lib.check(lib.load().maf_op_launch(C.byref(op), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+
+
+def _h(t):
+    return t.half().float()
+
+
+@pytest.mark.parametrize("c,B,H,W,lvl", [(64, 2, 21, 27, 0), (128, 2, 21, 27, 0), (192, 2, 13, 9, 2), (128, 1, 80, 80, 0), (128, 3, 40, 24, 1),
+                                         (192, 5, 20, 20, 2), (64, 1, 7, 5, 1), (128, 32, 8, 8, 1)])
+@pytest.mark.parametrize("iters", [0, 1, 3])
+def test_head_tail_vs_fp32_torch(c, B, H, W, lvl, iters):
+    g = torch.Generator().manual_seed(c + H * W + lvl)
+    stride = float(O.STRIDES[lvl])
+    # the two depth-wise outputs the tail reads (fp16 in the arena), in slices of one wider buffer like the plan's `u`
+    u = _h(torch.randn(B, 2 * c, H, W, generator=g))
+    w1 = [_h(torch.randn(c, c, 1, 1, generator=g) / c ** 0.5) for _ in range(2)]
+    b1 = [torch.randn(c, generator=g) * 0.3 for _ in range(2)]
+    w2 = [_h(torch.randn(n, c, 1, 1, generator=g) * (2.0 / c ** 0.5)) for n in (80, 68)]
+    b2 = [torch.randn(80, generator=g) * 0.5 - 2.0, torch.randn(68, generator=g) * 0.5]
+    t = [_h(F.silu(F.conv2d(u[:, i * c:(i + 1) * c], w1[i], b1[i]))) for i in range(2)]          # the unfused path stores this tensor in fp16
+    cls = torch.sigmoid(F.conv2d(t[0], w2[0], b2[0]))
+    reg = F.conv2d(t[1], w2[1], b2[1])
+    ref = O.decode([(torch.zeros(B, 1, H, W), cls, reg)], strides=(stride,))                   # [B, HW, 85]
+    # anchors of other levels around this one must stay untouched
+    before, after = 37, 11
+    A = before + H * W + after
+    out = torch.full((B, A, 85), -7.0, device=DEV)
+    ud = torch.zeros(B, H, W, 2 * c + 16, dtype=torch.float16, device=DEV)
+    ud[..., 8:8 + 2 * c] = u.permute(0, 2, 3, 1).half().to(DEV)
+    recs = [pack.pack_head_tail(w1[i], b1[i], w2[i], b2[i]).to(DEV) for i in range(2)]
+    assert recs[0].numel() == lib.load().maf_head_tail_record_bytes(c)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype = lib.OP_HEADTAIL, lib.F16, lib.F16
+    op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, c, 85, 2
+    for i in range(2):
+        op.src[i].ptr, op.src[i].C, op.src[i].stride, op.src[i].coff, op.src[i].mode = ud.data_ptr(), c, 2 * c + 16, 8 + i * c, lib.SRC_DIRECT
+    op.w, op.aux[0] = recs[0].data_ptr(), recs[1].data_ptr()
+    op.out = out.data_ptr()
+    op.Hin, op.Win = before, A
+    op.lvl_stride[0], op.nc, op.reg_max = stride, 80, 16
+    op.tile_k = iters
+    _launch(op)
+    got = out.cpu()
+    assert (got[:, :before] == -7.0).all() and (got[:, before + H * W:] == -7.0).all()
+    got = got[:, before:before + H * W]
+    assert torch.equal(got[..., 4], torch.ones(B, H * W))
+    # class probabilities: the bar of the fp16 kernels on a [0, 1] quantity
+    assert (got[..., 5:] - ref[..., 5:]).abs().max().item() <= 2e-3 * 1.0 + 2e-3
+    # boxes: in pixels; the DFL expectation is at most 16 cells * stride, so scale the bar by the largest coordinate
+    scale = ref[..., :4].abs().max().item()
+    err = (got[..., :4] - ref[..., :4]).abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+
+
+@pytest.mark.parametrize("cfg", [(24, 48), (32, 64)])
+@pytest.mark.parametrize("third", [True, False])
+@pytest.mark.parametrize("B,H,W,dt,rows", [(2, 64, 96, "f16", 8), (1, 100, 72, "u8", 8), (2, 352, 608, "f16", 4), (3, 36, 20, "f32", 4), (1, 640, 640, "u8", 8)])
+def test_stem2_vs_fp32_torch(cfg, third, B, H, W, dt, rows):
+    C0, C1 = cfg
+    g = torch.Generator().manual_seed(C0 + H + W)
+    img = torch.rand(B, 3, H, W, generator=g)
+    if dt == "u8":
+        x_dev = (img * 255).round().to(torch.uint8)
+        x = _h(x_dev.float() * (1.0 / 255.0))              # the kernel multiplies by 1/255 in fp32 and rounds to fp16 (evaler.py:161-163 folded)
+    elif dt == "f16":
+        x_dev = img.half()
+        x = x_dev.float()
+    else:
+        x_dev = img
+        x = _h(img)
+    w0 = _h(torch.randn(C0, 3, 3, 3, generator=g) / 27 ** 0.5 * 2); b0 = torch.randn(C0, generator=g) * 0.2
+    w1 = _h(torch.randn(C1, C0, 3, 3, generator=g) / (9 * C0) ** 0.5 * 2); b1 = torch.randn(C1, generator=g) * 0.2
+    w3 = _h(torch.randn(C1, C1, 1, 1, generator=g) / C1 ** 0.5 * 2); b3 = torch.randn(C1, generator=g) * 0.2
+    t0 = _h(F.relu(F.conv2d(x, w0, b0, 2, 1)))              # the half-resolution tensor lives in LDS in fp16
+    ref = F.relu(F.conv2d(t0, w1, b1, 2, 1))
+    if third:
+        ref = F.silu(F.conv2d(_h(ref), w3, b3))             # the accumulators are rounded to fp16 to become the next product's operand
+    H1, W1 = ref.shape[2:]
+    rec = (pack.pack_stem2(w0, b0, w1, b1, w3, b3) if third else pack.pack_stem2(w0, b0, w1, b1)).to(DEV)
+    assert rec.numel() == lib.load().maf_stem2_record_bytes(C0, C1, C1 if third else 0)
+    xd = x_dev.contiguous().to(DEV)
+    stride = C1 + 24
+    out = torch.full((B, H1, W1, stride), 3.0, dtype=torch.float16, device=DEV)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_STEM2, lib.F16, {"f16": lib.F16, "f32": lib.F32, "u8": lib.U8}[dt], lib.ACT_RELU
+    op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.ksize, op.nsrc = B, H1, W1, H, W, 3, C1, C0, 1
+    op.nc = C1 if third else 0
+    op.src[0].ptr, op.src[0].C = xd.data_ptr(), 3
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), stride, 16
+    op.tile_p, op.tile_k = rows, 0
+    op.w = rec.data_ptr()
+    _launch(op)
+    got = out[..., 16:16 + C1].float().cpu().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+    assert (out[..., :16] == 3.0).all() and (out[..., 16 + C1:] == 3.0).all()
+
+
+def _iou(a, b):
+    """a [n,4], b [m,4] xyxy -> [n,m]"""
+    lt = np.maximum(a[:, None, :2], b[None, :, :2]); rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None] - inter + 1e-12)
+
+
+def match_detections(got, ref, iou_min=0.95, dscore=1e-2):
+    """Greedy one-to-one matching of detection rows (x1,y1,x2,y2,conf,cls) by class, IoU >= iou_min and |d score| <= dscore.
+    Returns (matched pairs, unmatched reference rows, unmatched rows of `got`)."""
+    iou = _iou(ref[:, :4], got[:, :4])
+    ok = (iou >= iou_min) & (ref[:, None, 5] == got[None, :, 5]) & (np.abs(ref[:, None, 4] - got[None, :, 4]) <= dscore)
+    used = np.zeros(got.shape[0], bool)
+    pairs, miss = [], []
+    for i in range(ref.shape[0]):
+        cand = np.where(ok[i] & ~used)[0]
+        if cand.size == 0:
+            miss.append(i)
+            continue
+        j = cand[np.argmax(iou[i, cand])]
+        used[j] = True
+        pairs.append((i, j))
+    return pairs, miss, np.where(~used)[0].tolist()
+
+
+def test_fp16_engine_plus_nms_vs_reference_detections_640(golden):
+    """BASELINE configs[1] product (fp16 engine -> fp32 decode + NMS at 0.03 / 0.65 / multi_label) against the detections the REFERENCE
+    computed in fp32 on the same images: every reference detection well above the score floor of the kept set has a same-class
+    partner with IoU >= 0.95 and |d score| <= 1e-2.  The lists are both cut at max_det = 300, so rows near the cut may fall on either side:
+    they are reported and bounded, not hidden."""
+    g = golden("maf_n")
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0))
+    m = m.to(DEV).eval()
+    x = O.synth_images(2, 640, 1).to(DEV).half()
+    with torch.no_grad():
+        pred = m(x)[0]
+    dets = M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
+    plan = m.plan_for(x)
+    kinds = [o.kind for o in plan.ops]
+    assert kinds.count(lib.OP_HEADTAIL) == 3 and kinds.count(lib.OP_STEM2) == 1 and kinds.count(lib.OP_BOTTLENECK) >= 1, "the benchmarked (fused) plan"
+    for b in range(2):
+        ref, got = g["nms640_eval_%d" % b], dets[b].cpu().numpy()
+        assert got.shape == ref.shape == (300, 6)
+        pairs, miss, extra = match_detections(got, ref)
+        floor = ref[:, 4].min()
+        # a reference row can only be legitimately absent if it sat within the score tolerance of the max_det cut
+        hard = [i for i in miss if ref[i, 4] > floor + 1e-2]
+        ds = max(abs(ref[i, 4] - got[j, 4]) for i, j in pairs)
+        print("image %d: %d/%d matched, %d near-cut misses, %d hard misses, max |dscore| %.2e" % (b, len(pairs), ref.shape[0], len(miss) - len(hard), len(hard), ds))
+        assert len(pairs) >= 0.97 * ref.shape[0], (len(pairs), miss)
+        assert len(hard) <= 3, hard

@@ -544,3 +544,74 @@ def test_concurrent_streams_overlap():
     one = min(spin(ss[:1]) for _ in range(3))
     three = min(spin(ss) for _ in range(3))
     assert three < 2.0 * one, (one, three)
+
+
+def test_async_nms_of_fp16_and_strided_predictions_is_ordered_after_their_producer(models):
+    """the fp16 -> fp32 cast / compaction of the prediction must run on the side stream (after its wait on the producer), not
+    on the current stream after the wait was issued.  The producer is delayed with a spin kernel so that a mis-ordered read would see
+    the buffer before the values are there."""
+    x = O.synth_images(2, 320, 5).to(DEV)
+    with torch.no_grad():
+        pred = models["n"](x)[0]
+    want = M.non_max_suppression(pred.half().float(), 0.03, 0.65, multi_label=True)
+    wide = torch.zeros(2, pred.shape[1], 96, device=DEV)
+    for rep in range(3):
+        buf16 = torch.zeros_like(pred, dtype=torch.float16)
+        torch.cuda._sleep(20_000_000)                        # ~10 ms: everything below is queued behind it on the current stream
+        buf16.copy_(pred)
+        wide.zero_(); wide[..., 3:88].copy_(pred.half().float())
+        h1 = M.non_max_suppression_async(buf16, 0.03, 0.65, multi_label=True)
+        h2 = M.non_max_suppression_async(wide[..., 3:88], 0.03, 0.65, multi_label=True)
+        for h in (h1, h2):
+            out = h.result()
+            assert all(torch.equal(a, b) for a, b in zip(out, want)), rep
+
+
+def test_eval_plans_follow_in_place_weight_updates(models):
+    """an eval-mode model whose weights are updated in place (the reference's EMA model, engine.py:246) must not keep running
+    the weights packed at its first forward."""
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0))
+    m = m.to(DEV).eval()
+    x = O.synth_images(1, 64, 2).to(DEV)
+    with torch.no_grad():
+        a = m(x)[0].clone()
+        assert torch.equal(m(x)[0], a) and len(m._plans) == 1
+        sd2 = O.synth_state_dict("n", 1)
+        for (k, p) in m.state_dict().items():                # EMA-style in-place update, no train() / load_state_dict() call
+            p.mul_(0.5).add_(0.5 * sd2[k].to(p.device, p.dtype)) if p.dtype.is_floating_point else None
+        b = m(x)[0].clone()
+    assert not torch.equal(a, b)
+    ref = M.Model("n")
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        assert torch.equal(ref.to(DEV).eval()(x)[0], b)
+
+
+@pytest.mark.parametrize("nc", [1, 3, 7, 81])
+def test_any_class_count_runs_and_matches_the_sliced_80_class_model(models, nc):
+    """the reference takes any `nc`; the conv kernels store 4 channels at a time, so cls_pred is padded internally.  A model
+    with nc classes whose cls_pred filters are the first nc (or, for 81, the 80 + one extra) of the 80-class model must reproduce the
+    corresponding prediction columns; fp32 plan vs the oracle's 80-class prediction, fp16 plan within the fp16 class."""
+    sd = O.synth_state_dict("n", 0)
+    sd_nc = dict(sd)
+    for k in list(sd):
+        if k.endswith("cls_pred.weight") or k.endswith("cls_pred.bias"):
+            v = sd[k]
+            sd_nc[k] = v[:nc].clone() if nc <= 80 else torch.cat([v, v[:nc - 80]], 0)
+    m = M.Model("n", num_classes=nc)
+    m.load_state_dict(sd_nc)
+    m = m.to(DEV).eval()
+    x = O.synth_images(2, 96, 21)
+    ref = O.predict(O.reparam(sd, "n"), "n", x).numpy()
+    cols = list(range(5 + min(nc, 80))) + ([5 + i for i in range(nc - 80)] if nc > 80 else [])
+    with torch.no_grad():
+        p32, feats = m(x.to(DEV), val_loss=False)
+        p16 = m(x.to(DEV).half())[0]
+        (f_, cls_t, reg_t), _ = m(x.to(DEV), val_loss=True)
+    assert p32.shape == (2, 144 + 36 + 9, 5 + nc) and cls_t.shape == (2, 189, nc) and feats[0][1].shape == (2, nc, 12, 12)
+    _close32(p32.cpu().numpy(), ref[..., cols])
+    _close16(p16.cpu().numpy(), ref[..., cols])
+    dets = M.non_max_suppression(p32, 0.03, 0.65, multi_label=True)
+    odets = O.non_max_suppression(p32.cpu().numpy(), 0.03, 0.65, multi_label=True)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(dets, odets))

@@ -287,6 +287,85 @@ def test_fused_kernel_records_match_the_c_abi_sizes(built):
 
 def test_training_loss_has_no_cpu_path():
     crit = M.ComputeLoss()
+    assert crit.warmup_epoch == 3                       # the reference's default (yolov6/models/loss.py:23), which its trainer relies on
     feats = [torch.zeros(1, 8, s, s) for s in (8, 4, 2)]
     with pytest.raises(lib.MafError):
         crit((feats, torch.rand(1, 84, 80), torch.randn(1, 84, 68)), torch.zeros(0, 6), 0, 0)
+
+
+def test_checkpoint_unpickler_runs_nothing_from_a_crafted_file(tmp_path):
+    """only an explicit allow-list of globals is resolved; builtins.eval / exec / getattr, os.system, functools.partial,
+    torch.hub loaders ... named by a pickle become inert stand-ins (constructed, never executed)."""
+    import pickle
+    from maf_yolo_amd import checkpoint
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __init__(self, fn, args):
+            self.fn, self.args = fn, args
+
+        def __reduce__(self):
+            return self.fn, self.args
+
+    import functools
+    import os as _os
+    payloads = [Evil(eval, ("open(%r, 'w').write('x')" % str(marker),)), Evil(_os.system, ("touch %s" % marker,)),
+                Evil(functools.partial, (_os.system, "touch %s" % marker)), Evil(getattr, (dict, "fromkeys")),
+                Evil(exec, ("import os; os.system('touch %s')" % marker,)), Evil(__import__, ("subprocess",))]
+    for p in payloads:
+        blob = pickle.dumps({"model": p, "epoch": 1}, protocol=2)
+        out = checkpoint._PickleModule.loads(blob)
+        assert not marker.exists()
+        assert isinstance(out["model"], checkpoint._Inert) and out["epoch"] == 1
+    for mod, name in (("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("builtins", "__import__"), ("functools", "partial"),
+                      ("torch.hub", "load"), ("torch.utils.cpp_extension", "load"), ("os", "system"), ("torch", "load"), ("numpy", "load")):
+        assert not checkpoint._allowed(mod, name), (mod, name)
+    for mod, name in (("torch._utils", "_rebuild_tensor_v2"), ("torch", "HalfStorage"), ("torch", "float16"), ("collections", "OrderedDict")):
+        assert checkpoint._allowed(mod, name), (mod, name)
+
+
+def test_plan_cache_fingerprint_tracks_in_place_weight_updates():
+    """cached eval plans hold packed weight copies; the reference evaluates its EMA model, which `ema.update` mutates in
+    place every step without ever calling train() (engine.py:246).  The fingerprint must move on every in-place update."""
+    m = M.Model("n").eval()
+    v0 = m.weights_version()
+    assert m.weights_version() == v0
+    with torch.no_grad():
+        for p in m.parameters():                       # what ModelEMA.update does: v *= d; v += (1 - d) * msd[k]
+            p.mul_(0.999)
+            break
+    v1 = m.weights_version()
+    assert v1 != v0
+    m.backbone[0].rbr_dense.bn.running_mean.add_(1.0)   # buffers count too
+    assert m.weights_version() != v1
+    m._plans["sentinel"] = object(); m._plans_version = m.weights_version()
+    m.float()                                           # _apply-style conversions drop the plans
+    assert m._plans == {} and m._plans_version is None
+    m._plans["sentinel"] = object()
+    m.load_state_dict(m.state_dict())
+    assert m._plans == {}
+    import copy
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        next(m2.parameters()).add_(1.0)
+    assert m2.weights_version() != m.weights_version()  # the copy tracks its own tensors
+
+
+def test_integration_md_ctypes_stub_is_the_c_struct(built):
+    """VERDICT r1 / ADVICE r1: the MafOp stub printed in INTEGRATION.md must be maf_op_t field for field (a short stub makes
+    maf_engine_create read past every op).  The stub is parsed out of the document and compared with lib.MafOp and the library's own
+    sizeof(maf_op_t)."""
+    import ctypes as C
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    m = re.search(r"class MafSrc\(C\.Structure\):.*?class MafOp\(C\.Structure\):.*?\n\n", text, re.S)
+    assert m, "stub not found in INTEGRATION.md"
+    src = re.sub(r"^assert L\..*$", "", m.group(0), flags=re.M)
+    ns = {"C": C}
+    exec(src, ns)                                           # the document's own text (ours, not the reference's)
+    doc_op, doc_src = ns["MafOp"], ns["MafSrc"]
+    assert [(n, C.sizeof(t)) for n, t in doc_op._fields_] == [(n, C.sizeof(t)) for n, t in lib.MafOp._fields_]
+    assert [(n, C.sizeof(t)) for n, t in doc_src._fields_] == [(n, C.sizeof(t)) for n, t in lib.MafSrc._fields_]
+    assert C.sizeof(doc_op) == C.sizeof(lib.MafOp) == built.maf_op_size()
+    for n, _ in lib.MafOp._fields_:
+        assert getattr(doc_op, n).offset == getattr(lib.MafOp, n).offset, n

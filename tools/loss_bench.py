@@ -29,7 +29,7 @@ def main():
         ctr = wh / 2 + torch.rand(n, 2, generator=g) * (1 - wh)
         targets = torch.cat([torch.arange(B).repeat_interleave(per)[:, None].float(), torch.randint(0, nc, (n, 1), generator=g).float(), ctr, wh], 1).to(dev)
         for fused in ([True] if only else [False, True]):
-            crit = M.ComputeLoss(ori_img_size=640, fused=fused)
+            crit = M.ComputeLoss(ori_img_size=640, warmup_epoch=0, fused=fused)
             def fwd():
                 return crit((feats, scores, distri), targets, 0, 0)[0]
             def fwdbwd():
