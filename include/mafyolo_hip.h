@@ -65,6 +65,9 @@ typedef struct {
  *                   K = concat of the sources' channels in order (= torch.cat order).
  * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
  *                   2H x 2W input (Hin, Win below); w packed per tap.
+ *                   Twin launch (CONV1X1 with one direct / pooled source, CONV3X3S2; tile_k 0 / 1 / 2 / 4): aux[0] != NULL runs a SECOND conv of
+ *                   identical shape, strides and tiles as blockIdx.y = 1 of the same grid — aux = {src, w, bias, out} of the second conv
+ *                   (the two side ConvWrappers of a MAFPN level, configs/yaml/MAF-YOLO-n.yaml nodes 23 / 24 and 27 / 28).
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
  *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
  *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).

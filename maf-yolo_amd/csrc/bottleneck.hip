@@ -34,7 +34,21 @@ struct BnArgs {
     const float* b2;
     int B, H, W, Cin, Cout, nMB, x_stride, x_coff, out_stride, out_coff;
     int tilesX, tilesY, nwg;
+    int ko;
+    unsigned long long* prof;   // MAF_BN_PROFILE builds only (op->aux[3]): cycles per phase summed over all waves, see tools/bn_profile.py
 };
+
+#ifdef MAF_BN_PROFILE
+#define BN_KO(bit) ((a.ko >> (bit)) & 1)     // knock-out switches of the profiling build (op->aux[2]): results are wrong, times tell what a piece costs
+#else
+#define BN_KO(bit) 0
+#endif
+#ifdef MAF_BN_STAMPS
+// s_memtime is a scalar-memory op (counts on lgkmcnt): every stamp drains the counter, so stamps sit only at phase boundaries
+#define BN_STAMP(i) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); prof_acc[i] += (uint32_t)(now_ - prof_t); prof_t = now_; } while (0)
+#else
+#define BN_STAMP(i) do { } while (0)
+#endif
 
 typedef half_t half4v_t __attribute__((ext_vector_type(4)));
 
@@ -45,6 +59,11 @@ __device__ __forceinline__ void maf_static_for(F&& f) {
         maf_static_for<N, I + 1>(f);
     }
 }
+
+// LDS reads as inline assembly (the caller counts them and waits with bn_wait_lgkm): see phase B.
+template <int OFF> __device__ __forceinline__ void bn_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void bn_ds_read_b64(u32x2_t& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void bn_wait_lgkm(u32x4_t& a, u32x2_t& b, u32x2_t& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
 
 template <int K, int S1, int CT2>
 struct BnCfg {
@@ -61,16 +80,18 @@ struct BnCfg {
     static constexpr int OFF_W1 = 0, OFF_B1 = 2 * S1 * 1024, REC_A = OFF_B1 + 128;
     static constexpr int OFF_TOE = REC_A, OFF_W2 = OFF_TOE + NTOE * 16, OFF_BD = OFF_W2 + CT2 * 1024;
     static constexpr int REC = OFF_BD + 128;                       // bytes per block record
-    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC;
+    static constexpr int REC_B = REC - REC_A;
+    // LDS: T1 planes | part A of the current block | part B twice (the next block's part B arrives while this block's is being read)
+    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC + (size_t)REC_B;
 };
 
 template <int K, int S1, int CT2>
-__global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
+__global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
     typedef BnCfg<K, S1, CT2> Cf;
     constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t* T1 = reinterpret_cast<half_t*>(smem_raw);                        // [32][PS]
-    unsigned char* rec = smem_raw + 32 * Cf::PSB;                            // [REC]: the current block's operands (each part is refilled as soon as its phase is over)
+    unsigned char* rec = smem_raw + 32 * Cf::PSB;                            // [REC_A][REC_B][REC_B]: part A of the current block (refilled as soon as phase A is over), part B of this and of the next block
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
     int lid;
@@ -99,11 +120,13 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
         const int iy = min(max(y0 - P + hr, 0), a.H - 1), ix = min(max(x0 - P + hc, 0), a.W - 1);
         xoff[i] = (uint32_t)(iy * a.W + ix) * a.x_stride;
     }
+    int ko_block = 0;
     constexpr int XD = 2;                                   // activation fragments are loaded XD m-tiles ahead of their MFMAs
     half8_t af[XD + 1][S1];
     auto load_x = [&](auto idx) {
         constexpr int i = decltype(idx)::value;
         if constexpr (i < MT) {
+            if (BN_KO(0) && ko_block > 0) return;            // KO 0: activations are read for the first mid block only
             af[i % (XD + 1)][0] = *reinterpret_cast<const half8_t*>(xin + xoff[i] + cg0);
             if constexpr (S1 > 1) af[i % (XD + 1)][1] = *reinterpret_cast<const half8_t*>(xin + xoff[i] + cg1);
         }
@@ -117,13 +140,13 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
     const bool interior = y0 - P >= 0 && x0 - P >= 0 && y0 - P + Cf::RH <= a.H && x0 - P + RWC <= a.W;
     // The next block's record travels global -> LDS by DMA (global_load_lds: no registers, no ds_write; every wave moves 1 KiB
     // per instruction to a wave-uniform LDS base + lane * 16).  The barrier that publishes it also waits for it (vmcnt).
-    auto dma_part = [&](int mb, int off, int bytes) {
+    auto dma_part = [&](int mb, int off, int bytes, int dst) {
         const unsigned char* src = a.par + (size_t)mb * Cf::REC + off;
         const int nvec = bytes >> 4;
         for (int v0 = wave * 64; v0 < nvec; v0 += 256) {
             if (v0 + lane < nvec)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(v0 + lane) * 16),
-                                                 (void __attribute__((address_space(3)))*)(rec + off + v0 * 16), 16, 0, 0);
+                                                 (void __attribute__((address_space(3)))*)(rec + dst + v0 * 16), 16, 0, 0);
         }
     };
 
@@ -133,19 +156,26 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
 #pragma unroll
         for (int ct = 0; ct < CT2; ++ct) acc2[i][ct] = (f32x4_t)0.f;
 
-    const bool toe_active = (p >> 2) == g;                  // block-diagonal Toeplitz: lane (g, (G, r)) is non-zero iff G == g
+    const uint32_t toe_mask = (p >> 2) == g ? 0xffffffffu : 0u;      // block-diagonal Toeplitz: lane (g, (G, r)) is non-zero iff G == g
     const int q4 = wave * 4;                                // this wave's 4 output columns
     int hi_off = 4;
     asm volatile("" : "+v"(hi_off));                        // opaque: the two 8-byte halves of a window stay two ds_read_b64 (2 LDS cycles each; ds_read2_b64 costs 8)
 
-    dma_part(0, 0, Cf::REC);
+#ifdef MAF_BN_STAMPS
+    uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof_t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t) :: "memory");
+#endif
+    dma_part(0, 0, Cf::REC, 0);
     load_x_head();
     __syncthreads();
+    BN_STAMP(0);                                            // prologue
 
     for (int mb = 0; mb < a.nMB; ++mb) {
-        if (mb > 0) dma_part(mb, Cf::REC_A, Cf::REC - Cf::REC_A);  // part B of this block: free since the barrier that ended the previous block, needed after the next one
+        ko_block = mb;
+        const unsigned char* recB = rec + (mb & 1) * Cf::REC_B;    // this block's part B (offsets OFF_TOE / OFF_W2 / OFF_BD count from the record start)
         // ---- A. T1 = SiLU(X * W1[:, block] + b1) on the halo tile
-        {
+        if (!BN_KO(8)) {                                    // KO 8: no phase A
             half8_t w1f[2][S1];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -174,98 +204,147 @@ __global__ __launch_bounds__(256, CT2 == 2 ? 3 : 2) void bottleneck_kernel(const
                 half_t* dst = T1 + (size_t)p * PS + hr * RWP + hc0;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1])};
-                    const half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3])};
+                    half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1])};
+                    half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3])};
+                    if (BN_KO(1)) { h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]}; }   // KO 1: no SiLU in phase A
                     const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
-                    if (m0 < NHP) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;
+                    if (m0 < NHP && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
                 }
             });
         }
-        __syncthreads();
+        BN_STAMP(1);                                        // phase A
+        if (!BN_KO(7)) __syncthreads();                     // KO 7: no barriers inside the block loop
+        BN_STAMP(2);                                        // barrier after A
         if (mb + 1 < a.nMB) {
-            dma_part(mb + 1, 0, Cf::REC_A);                  // phase A is over: its operands can be replaced
+            // phase A is over: its operands can be replaced; the other part-B buffer was last read before the barrier that ended the
+            // previous block.  Both DMAs are issued BEFORE the activation loads: vmcnt counts in order, so the wait in front of the next
+            // phase A's first MFMA (which the compiler has to write as vmcnt(0)) then waits for loads that are a whole phase B + C old,
+            // not for a DMA issued a few instructions earlier (the single-buffer version stalled there once per block).
+            if (!BN_KO(5)) {                                 // KO 5: the first block's operands for every block
+            dma_part(mb + 1, 0, Cf::REC_A, 0);
+            dma_part(mb + 1, Cf::REC_A, Cf::REC_B, Cf::REC_A + ((mb + 1) & 1) * Cf::REC_B);
+            }
             load_x_head();                                  // the next phase A's first activations: in flight during phase B
         }
 
         // ---- B. depth-wise k x k on the matrix cores: 8 channel sets s (channels 8g + s), k tap rows, PARTS windows
         f32x4_t dacc[8];                                    // initial value = the depth-wise bias of channel 4s + g (no add in phase C)
         {
-            const f32x4_t bd0 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2], bd1 = reinterpret_cast<const f32x4_t*>(rec + Cf::OFF_BD)[g * 2 + 1];
+            const f32x4_t bd0 = reinterpret_cast<const f32x4_t*>(recB + Cf::OFF_BD)[g * 2], bd1 = reinterpret_cast<const f32x4_t*>(recB + Cf::OFF_BD)[g * 2 + 1];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { dacc[s] = (f32x4_t)bd0[s]; dacc[4 + s] = (f32x4_t)bd1[s]; }
         }
-        const half8_t* toe = reinterpret_cast<const half8_t*>(rec + Cf::OFF_TOE) + p;
+        const half8_t* toe = reinterpret_cast<const half8_t*>(recB + Cf::OFF_TOE) + p;
         // lane (g, n = p): plane 4s + g, row n (+ky), window at column 4q, read as two 8-byte halves.  Banks: the 16 rows of a
         // lane group are 48 B apart (all 16-byte slots of the 256-B bank row once) and the planes of g and g+1 are 8 B (mod 256)
         // apart, so the 32 lanes of a ds_read_b64 group cover the 64 banks exactly once; the 8-byte stores of phase A
         // (16 consecutive planes per group, 8 B apart mod 128) are conflict-free for the same reason.
         const half_t* t1l = T1 + (size_t)g * PS + p * RWP + q4;
         const half_t* t1h = t1l + hi_off;
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-            for (int part = 0; part < PARTS; ++part) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    half8_t av = (half8_t)(half_t)0;
-                    if (toe_active) av = toe[((s * K + ky) * PARTS + part) * 16];      // the other 48 lanes hold the zeros of the block-diagonal
-                    const int o = s * 4 * PS + ky * RWP + part * 4;
-                    const half4v_t lo = *reinterpret_cast<const half4v_t*>(t1l + o), hi = *reinterpret_cast<const half4v_t*>(t1h + o);
-                    const half8_t bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, dacc[s], 0, 0, 0);
-                }
+        // The K * PARTS * 8 steps (tap row, window, channel set) are ONE straight line of code, software-pipelined by hand: the three LDS
+        // reads of step t + BD are issued before the MFMA of step t, so an MFMA never waits for a read it has just issued (the
+        // loop form did: `s_waitcnt lgkmcnt(0)` in front of every MFMA, ~150 cycles per step for a 17-cycle instruction, because the
+        // Toeplitz read sat under a lane predicate and every step became its own basic block).  All 64 lanes read a Toeplitz entry
+        // (lane p's: in range for every lane) and the 48 lanes outside the block diagonal AND it to zero.
+        // The reads are inline assembly with hand-counted `s_waitcnt lgkmcnt(n)` (LDS returns in order: when step t is consumed the
+        // 3 * min(BD, steps left) reads issued after its own may still be in flight); written as plain loads the compiler waits with
+        // lgkmcnt(0) — a full LDS round trip — on every (BD+1)-th step.
+        constexpr int NSTEP = K * PARTS * 8, BD = CT2 == 2 ? 2 : 3;    // read-ahead depth (the c <= 32 variants run 3 workgroups per CU on 168 registers)
+        u32x4_t avr[BD + 1];
+        u32x2_t blo[BD + 1], bhi[BD + 1];
+        const uint32_t a_toe = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)toe;
+        const uint32_t a_t1l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1l;
+        const uint32_t a_t1h = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1h;
+        auto ld_step = [&](auto idx) {
+            constexpr int t = decltype(idx)::value;
+            if constexpr (t < NSTEP) {
+                constexpr int s = t % 8, part = (t / 8) % PARTS, ky = t / (8 * PARTS);
+                constexpr int ot = ((s * K + ky) * PARTS + part) * 256, o = (s * 4 * PS + ky * RWP + part * 4) * 2;
+                static_assert(ot < 65536 && o < 65536, "ds offset field");
+                bn_ds_read_b128<ot>(avr[t % (BD + 1)], a_toe);
+                bn_ds_read_b64<o>(blo[t % (BD + 1)], a_t1l);
+                bn_ds_read_b64<o>(bhi[t % (BD + 1)], a_t1h);
             }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the compiler's own reads (biases) are complete: the counter now counts only the reads below
+        if (!BN_KO(2)) {                                      // KO 2: no phase B
+        maf_static_for<BD>([&](auto idx) { ld_step(idx); });
+        maf_static_for<NSTEP>([&](auto idx) {
+            constexpr int t = decltype(idx)::value, s = t % 8, sl = t % (BD + 1);
+            ld_step(std::integral_constant<int, t + BD>{});
+            constexpr int ahead = (NSTEP - 1 - t) < BD ? (NSTEP - 1 - t) : BD;      // steps whose reads were issued after step t's
+            bn_wait_lgkm<3 * ahead>(avr[sl], blo[sl], bhi[sl]);
+            const u32x4_t am = avr[sl] & toe_mask;
+            const u32x4_t bw = {blo[sl][0], blo[sl][1], bhi[sl][0], bhi[sl][1]};
+            dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, am), __builtin_bit_cast(half8_t, bw), dacc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);              // keep the issue order as written
+        });
         }
+        BN_STAMP(3);                                        // phase B
         // ---- C. lane (g, n) now owns channels 4s + g (s = 0..7: k index 8g + s of the packed W2) of pixels (row n, x = 4q + r): the A fragments of the second 1x1
         {
             half8_t w2f[CT2];
 #pragma unroll
-            for (int ct = 0; ct < CT2; ++ct) w2f[ct] = reinterpret_cast<const half8_t*>(rec + Cf::OFF_W2)[ct * 64 + lane];
+            for (int ct = 0; ct < CT2; ++ct) w2f[ct] = reinterpret_cast<const half8_t*>(recB + Cf::OFF_W2)[ct * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 half8_t t2;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) t2[s] = (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r]);
+                for (int s = 0; s < 8; ++s) t2[s] = BN_KO(3) ? (half_t)dacc[s][r] : (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r]);   // KO 3: no SiLU in phase C
 #pragma unroll
-                for (int ct = 0; ct < CT2; ++ct) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);
+                for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);   // KO 9: no second 1x1
             }
         }
-        if (mb + 1 < a.nMB) {
+        BN_STAMP(4);                                        // phase C
+        if (mb + 1 < a.nMB && !BN_KO(7)) {
             __syncthreads();                                // phase B has finished reading T1 and part B; part A of the next block is visible
         }
+        BN_STAMP(5);                                        // barrier after C
     }
 
     // ---- epilogue: out = SiLU(acc2 + b2); accumulator lane (g, p), register rr: pixel (row 4g + rr, x = 4q + r), channels p*CT2 ..
+    // Stored straight from the accumulators a lane would issue 16 stores of CT2 halfs (8 bytes): store-issue bound (10 us of the kernel).
+    // Instead every wave stages its 16 x 4 pixels in its own slice of the (now free) T1 area, pixel-major, and writes 16-byte pieces:
+    // 8 lanes cover the whole channel run of a pixel, 4x fewer store instructions.
     float bias2[CT2];
 #pragma unroll
     for (int ct = 0; ct < CT2; ++ct) bias2[ct] = a.b2[p * CT2 + ct];
-    const int nvalid = a.Cout - p * CT2;
-    half_t* obase = a.out + (size_t)b * a.H * a.W * a.out_stride + a.out_coff + p * CT2;
+    constexpr int CO = 16 * CT2;                                   // staged channels per pixel (>= Cout)
+    static_assert(4 * 64 * CO * 2 <= 32 * Cf::PSB, "epilogue staging fits the T1 area");
+    __syncthreads();                                               // every wave has finished reading T1 (phase B of the last block)
+    half_t* stg = T1 + wave * (64 * CO);                           // [64 pixels = (row 0..15) x (col 0..3)][CO]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ox = x0 + q4 + r;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int oy = y0 + g * 4 + rr;
-            if (oy >= a.H || ox >= a.W) continue;
-            half_t* op = obase + ((size_t)oy * a.W + ox) * a.out_stride;
-            if (nvalid >= CT2) {
-                uint32_t w[CT2 / 2];
+            uint32_t w[CT2 / 2];
 #pragma unroll
-                for (int c2 = 0; c2 < CT2 / 2; ++c2) {
-                    const half2_t h = {(half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2][rr] + bias2[2 * c2]),
-                                       (half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2 + 1][rr] + bias2[2 * c2 + 1])};
-                    w[c2] = __builtin_bit_cast(uint32_t, h);
-                }
-                if (CT2 == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT2 / 2)]};
-                else *reinterpret_cast<uint32_t*>(op) = w[0];
-            } else {
-#pragma unroll
-                for (int ct = 0; ct < CT2; ++ct)
-                    if (ct < nvalid) op[ct] = (half_t)maf_act<MAF_ACT_SILU>(acc2[r][ct][rr] + bias2[ct]);
+            for (int c2 = 0; c2 < CT2 / 2; ++c2) {
+                const half2_t h = {(half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2][rr] + bias2[2 * c2]),
+                                   (half_t)maf_act<MAF_ACT_SILU>(acc2[r][2 * c2 + 1][rr] + bias2[2 * c2 + 1])};
+                w[c2] = __builtin_bit_cast(uint32_t, h);
             }
+            half_t* sp = stg + ((g * 4 + rr) * 4 + r) * CO + p * CT2;
+            if (CT2 == 4) *reinterpret_cast<u32x2_t*>(sp) = (u32x2_t){w[0], w[1 % (CT2 / 2)]};
+            else *reinterpret_cast<uint32_t*>(sp) = w[0];
         }
     }
+    // a wave reads back only what it wrote itself: LDS operations of one wave complete in order, no barrier
+    const int cpp = a.Cout >> 3;                                   // 16-byte pieces per pixel (Cout is a multiple of 8)
+    half_t* obase = a.out + (size_t)b * a.H * a.W * a.out_stride + a.out_coff;
+    if (!BN_KO(6)) {                                               // KO 6: no output stores
+    for (int q = lane; q < 64 * cpp; q += 64) {
+        const int px = q / cpp, part = q - px * cpp;
+        const int oy = y0 + (px >> 2), ox = x0 + q4 + (px & 3);
+        if (oy < a.H && ox < a.W)
+            *reinterpret_cast<u32x4_t*>(obase + ((size_t)oy * a.W + ox) * a.out_stride + 8 * part) = *reinterpret_cast<const u32x4_t*>(stg + px * CO + 8 * part);
+    }
+    }
+#ifdef MAF_BN_STAMPS
+    BN_STAMP(6);                                            // epilogue
+    if (a.prof && lane == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(a.prof + i, (unsigned long long)prof_acc[i]);
+#endif
 }
 
 template <int K, int S1, int CT2>
@@ -303,8 +382,8 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "bottleneck: fp16 only (the fp32 parity mode runs the three kernels separately)");
     const maf_src_t& sr = op->src[0];
     MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr && op->out, "bottleneck: one direct source");
-    MAF_REQUIRE(op->Cin % 8 == 0 && op->Cin <= 64 && op->Cout % 2 == 0 && op->Cout <= 64, "bottleneck: c <= 64 channels in and out");
-    MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 4 == 0 && op->out_coff % 4 == 0, "bottleneck: stride/offset alignment");
+    MAF_REQUIRE(op->Cin % 8 == 0 && op->Cin <= 64 && op->Cout % 8 == 0 && op->Cout <= 64, "bottleneck: c <= 64 channels in and out, multiples of 8");
+    MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "bottleneck: stride/offset alignment (16-byte pieces)");
     MAF_REQUIRE(op->act == MAF_ACT_SILU, "bottleneck: DepthBottleneckUni applies SiLU after every stage (common.py:918-927)");
     MAF_REQUIRE(op->tile_k > 0 && op->w && op->bias, "bottleneck: null weights (w = block records, bias = b2), tile_k = 32-channel mid blocks");
     BnArgs a;
@@ -314,6 +393,11 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     a.x_stride = sr.stride; a.x_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, 16);
     a.nwg = a.B * a.tilesX * a.tilesY;
+    a.prof = nullptr; a.ko = 0;
+#ifdef MAF_BN_PROFILE
+    a.prof = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(op->aux[3]));
+    a.ko = (int)(intptr_t)op->aux[2];
+#endif
     switch (op->ksize) {
         case 3: return launch_k<3>(a, s);
         case 5: return launch_k<5>(a, s);

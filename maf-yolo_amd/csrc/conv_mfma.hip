@@ -38,6 +38,13 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     a.w = op->w; a.bias = op->bias; a.out = op->out;
     a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     MAF_REQUIRE(op->w && op->bias && op->out, "conv: null w/bias/out");
+    a.twin = op->aux[0] != nullptr;
+    if (a.twin) {
+        MAF_REQUIRE(op->aux[1] && op->aux[2] && op->aux[3], "conv twin: aux = {src, w, bias, out} of the second conv, all four");
+        MAF_REQUIRE(op->nsrc == 1 && op->src[0].mode != MAF_SRC_UP2, "conv twin: single-source variants only");
+        MAF_REQUIRE(op->tile_k <= 2 || op->tile_k == 4, "conv twin: generic, LDS-shared-weight and split-K variants only");
+        a.src_t = op->aux[0]; a.w_t = op->aux[1]; a.bias_t = static_cast<const float*>(op->aux[2]); a.out_t = const_cast<void*>(op->aux[3]);
+    }
     int pt = op->tile_p;
     const int ct = op->tile_c;
     MAF_REQUIRE(pt > 0 && ct > 0, "conv: tile_p/tile_c not set");

@@ -44,6 +44,14 @@ struct ConvArgs {
     int out_stride, out_coff;
     int nM, nN;
     int act;
+    // twin launch (op->aux[0..3]): a SECOND conv of identical shape — same everything except these four pointers — runs as
+    // blockIdx.y = 1 of the same grid (the two side convs of a MAFPN level, backbone.23 / .24 and .27 / .28: independent, equal, each too
+    // small to fill the chip and each paying a kernel's fixed cost on its own)
+    const void* src_t;
+    const void* w_t;
+    const float* bias_t;
+    void* out_t;
+    int twin;
 };
 
 enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3 };
@@ -126,7 +134,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     uint32_t off0[PT];                      // VAR_DIRECT / VAR_POOL2 / VAR_3X3S2 base element offset
     uint32_t offs[PT][4];                   // VAR_MULTI: per source
     int iy0[PT], ix0[PT];                   // VAR_3X3S2
-    const T* s0 = static_cast<const T*>(a.src[0]);
+    const bool second = blockIdx.y != 0;                                  // twin launch: the second conv of the pair
+    const T* s0 = static_cast<const T*>(second ? a.src_t : a.src[0]);
+    const void* const w_all = second ? a.w_t : a.w;
+    const float* const bias_all = second ? a.bias_t : a.bias;
+    void* const out_all = second ? a.out_t : a.out;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = m_base + pt * 16 + p;
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int total_steps = ntaps * a.ksteps;
     const int s_begin = KS4 ? (total_steps * wave) / 4 : 0;
     const int s_end = KS4 ? (total_steps * (wave + 1)) / 4 : total_steps;
-    const frag_t* wbase = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
+    const frag_t* wbase = reinterpret_cast<const frag_t*>(w_all) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
 
     // Activation fragments of k-step `step` (0 .. last; a step past `last` is reduction padding and reads zeros).
     // EVERY load is unconditional: a load under a branch makes the compiler wait with vmcnt(0) at the next use, which
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         extern __shared__ __attribute__((aligned(16))) unsigned char lb_raw[];
         frag_t* lb = reinterpret_cast<frag_t*>(lb_raw);                   // [2][CT * 64]
         constexpr int NV = (CT * 64 + 255) / 256;
-        const frag_t* wsrc = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * total_steps) * 64;
+        const frag_t* wsrc = reinterpret_cast<const frag_t*>(w_all) + ((size_t)(n_tile * CT) * total_steps) * 64;
         constexpr int WD = 3;                                             // weight fragments leave global memory WD k-steps before their MFMAs
         frag_t wreg[WD][NV];
         auto gload = [&](int step, frag_t (&wr)[NV]) {
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int cl = n_tile * (16 * CT) + p * CT;
     float bias[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bias[ct] = a.bias[cl + ct];          // padded to nN*16*CT on the host
+    for (int ct = 0; ct < CT; ++ct) bias[ct] = bias_all[cl + ct];          // padded to nN*16*CT on the host
     const int nvalid = a.Cout - cl;                                        // >= CT for every tile but the last
 
 #pragma unroll
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[pt][ct][r] + bias[ct], a.act);
             const size_t o = (size_t)m * a.out_stride + a.out_coff + cl;
             if (OUTF32 || sizeof(T) == 4) {
-                float* op = static_cast<float*>(a.out) + o;
+                float* op = static_cast<float*>(out_all) + o;
                 if (nvalid >= CT) {
 #pragma unroll
                     for (int q = 0; q + 4 <= CT; q += 4) *reinterpret_cast<f32x4_t*>(op + q) = (f32x4_t){v[q], v[q + 1], v[q + 2], v[q + 3]};
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                         if (ct < nvalid) op[ct] = v[ct];
                 }
             } else {
-                half_t* op = static_cast<half_t*>(a.out) + o;
+                half_t* op = static_cast<half_t*>(out_all) + o;
                 if (nvalid >= CT) {
                     uint32_t w[CT / 2];
 #pragma unroll
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false>
 int launch_act(const ConvArgs& a, hipStream_t s) {
     const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
-    hipLaunchKernelGGL((conv_mfma_kernel<T, PT, CT, VAR, OUTF32, KS4>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, PT, CT, VAR, OUTF32, KS4>), dim3(grid, a.twin ? 2 : 1), dim3(256), 0, s, a);
     return maf_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
@@ -408,7 +420,7 @@ int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
 template <int PT, int CT, int VAR>
 int launch_lb(const ConvArgs& a, hipStream_t s) {
     const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
-    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true>), dim3(grid), dim3(256), 2 * CT * 1024, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true>), dim3(grid, a.twin ? 2 : 1), dim3(256), 2 * CT * 1024, s, a);
     return maf_check_hip(hipGetLastError(), "conv_mfma (LDS-shared weights) launch");
 }
 

@@ -173,14 +173,23 @@ class Plan:
                               segs=src.segs, out=out, out_coff=out_coff, out_f32=int(out_f32), pt=pt, ct=ct,
                               w=self._wput(pack.pack_conv1x1(w, srcC, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
 
-    def _conv3x3s2(self, name, w, b, src, out, out_coff, act):
+    def _conv3x3s2(self, name, w, b, src, out, out_coff, act, twin=None):
+        """twin = (name2, w2, b2, src2, out2): a second, independent conv of the same shape launched as blockIdx.y = 1 of the same grid."""
         assert len(src.segs) == 1 and src.segs[0].mode == lib.SRC_DIRECT, "%s: 3x3 s2 conv needs a materialised input" % name
         cout = w.shape[0]
         H, W = src.H // 2, src.W // 2
         pt, ct = pack.tile_for(cout, self.B * H * W)
-        self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=name, act=act, H=H, W=W, Hin=src.H, Win=src.W, Cin=src.C, Cout=cout, raw=(w.detach().float().cpu(), b.detach().float().cpu(), None),
-                              segs=src.segs, out=out, out_coff=out_coff, out_f32=0, pt=pt, ct=ct,
-                              w=self._wput(pack.pack_conv3x3(w, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct))))
+        rec = dict(kind=lib.OP_CONV3X3S2, name=name, act=act, H=H, W=W, Hin=src.H, Win=src.W, Cin=src.C, Cout=cout, raw=(w.detach().float().cpu(), b.detach().float().cpu(), None),
+                   segs=src.segs, out=out, out_coff=out_coff, out_f32=0, pt=pt, ct=ct,
+                   w=self._wput(pack.pack_conv3x3(w, ct, self.dtype)), b=self._wput(pack.pack_bias(b, ct)))
+        if twin is not None:
+            name2, w2, b2, src2, out2 = twin
+            s1, s2 = src.segs[0], src2.segs[0]
+            assert len(src2.segs) == 1 and s2.mode == lib.SRC_DIRECT and (s2.buf.stride, s2.coff, s2.C) == (s1.buf.stride, s1.coff, s1.C) and w2.shape == w.shape \
+                and (out2.stride, out2.H, out2.W) == (out.stride, out.H, out.W) and out_coff == 0
+            rec.update(name=name + "+" + name2, twin=dict(seg=s2, out=out2, raw=(w2.detach().float().cpu(), b2.detach().float().cpu()),
+                                                          w=self._wput(pack.pack_conv3x3(w2, ct, self.dtype)), b=self._wput(pack.pack_bias(b2, ct))))
+        self._ops.append(rec)
 
     def _dw(self, name, w, b, src, out, act):
         assert len(src.segs) == 1 and src.segs[0].mode == lib.SRC_DIRECT
@@ -196,6 +205,7 @@ class Plan:
         self.head_bufs = []
         self.fuse_head = self.fuse_head and not self.lanes                     # per level: head widths 64 / 128 / 192 take the fused tail
         n_side = n_head = 0
+        twins_done = {}
         for node, m in zip(model.nodes, model.backbone):
             if node.i > 0:                            # tag the ops of the previous node (lane = HIP stream of the engine)
                 self._tag(tag_from, tag_node, tag_lane, tag_after)
@@ -304,8 +314,22 @@ class Plan:
                 self._conv1x1(p + ".cv2", *m.cv2.fused(), TV([Seg(cat, 4 * c_)], x.H, x.W), out, 0, lib.ACT_SILU)
                 y.append(TV([Seg(out, node.cout)], x.H, x.W))
             elif node.kind == "cw":
+                if node.i in twins_done:                  # emitted together with the previous node
+                    y.append(twins_done.pop(node.i))
+                    continue
                 out = self._alloc(x.H // 2, x.W // 2, node.cout)
-                self._conv3x3s2(p + ".block", *m.block.fused(), x, out, 0, lib.ACT_SILU)
+                # the two side convs of a MAFPN level (backbone.23 / .24, .27 / .28) are independent and equal in shape: ONE launch
+                twin = None
+                nxt = model.nodes[node.i + 1] if node.i + 1 < len(model.nodes) else None
+                if getattr(model, "twin_convs", True) and not self.lanes and nxt is not None and nxt.kind == "cw" and (nxt.cin, nxt.cout) == (node.cin, node.cout) \
+                        and node.i not in nxt.sources() and all(j < node.i for j in nxt.sources()):
+                    x2 = y[nxt.sources()[0]]
+                    if (x2.H, x2.W) == (x.H, x.W) and len(x2.segs) == 1 and len(x.segs) == 1 and x2.segs[0].mode == x.segs[0].mode == lib.SRC_DIRECT \
+                            and (x2.segs[0].buf.stride, x2.segs[0].coff) == (x.segs[0].buf.stride, x.segs[0].coff):
+                        out2 = self._alloc(x.H // 2, x.W // 2, nxt.cout)
+                        twin = ("backbone.%d.block" % nxt.i, *model.backbone[nxt.i].block.fused(), x2, out2)
+                        twins_done[nxt.i] = TV([Seg(out2, nxt.cout)], out2.H, out2.W)
+                self._conv3x3s2(p + ".block", *m.block.fused(), x, out, 0, lib.ACT_SILU, twin=twin)
                 y.append(TV([Seg(out, node.cout)], out.H, out.W))
             elif node.kind == "concat":
                 H, W = srcs[0].H, srcs[0].W
@@ -416,6 +440,8 @@ class Plan:
             assert len(r["wait"]) <= 8
             if r["out"] is not None:
                 writes.setdefault(id(r["out"]), []).append((r["out_coff"], r["out_coff"] + r["Cout"], i))
+            if "twin" in r:
+                writes.setdefault(id(r["twin"]["out"]), []).append((0, r["Cout"], i))
             last_on_lane[lane] = i
 
     # ---------------------------------------------------------------- materialise
@@ -455,6 +481,9 @@ class Plan:
                 o.tile_k = r["tk"]
             for k_, off in enumerate(r.get("aux", [])):
                 o.aux[k_] = wbase + off
+            if "twin" in r:                                   # second conv of a twin launch: {src, w, bias, out}
+                tw = r["twin"]
+                o.aux[0], o.aux[1], o.aux[2], o.aux[3] = abase + tw["seg"].buf.off, wbase + tw["w"], wbase + tw["b"], abase + tw["out"].off
             o.lane, o.n_wait = r["lane"], len(r["wait"])
             for k_, j in enumerate(r["wait"]):
                 o.wait[k_] = j
@@ -602,9 +631,14 @@ class Plan:
             if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
                 continue
             M = self.B * o.H * o.W
-            sig = (o.kind, self.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32))
+            twin = r.get("twin")
+            sig = (o.kind, self.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32)) + (("twin",) if twin else ())
             best = _TUNE_CACHE.get(sig)
             w, b, srcC = r["raw"]
+
+            def packed(wt, bt, ct_, tk_):
+                wp_ = (pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
+                return wp_, pack.pack_bias(bt, ct_ if tk_ != 6 else 4).to(self.device)
             if best is None:
                 cands = []
                 for ct in (2, 4, 6, 8):
@@ -636,11 +670,15 @@ class Plan:
                             if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
                                 cands.append((pt, ct, 2))
                 results = []
+                if twin:
+                    cands = [c_ for c_ in cands if c_[2] in (1, 2, 4)]       # the variants that take a twin launch
                 for pt, ct, tk in cands:
-                    wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
-                    bp = pack.pack_bias(b, ct if tk != 6 else 4).to(self.device)
+                    wp, bp = packed(w, b, ct, tk)
                     op = lib.MafOp.from_buffer_copy(o)
                     op.tile_p, op.tile_c, op.tile_k, op.w, op.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
+                    if twin:
+                        wp2, bp2 = packed(*twin["raw"], ct, tk)
+                        op.aux[1], op.aux[2] = wp2.data_ptr(), bp2.data_ptr()
                     lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))          # warm-up
                     ts = []
                     for _ in range(reps):
@@ -656,10 +694,13 @@ class Plan:
                     print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
-                wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, self.dtype)).to(self.device)
-                bp = pack.pack_bias(b, ct if tk != 6 else 4).to(self.device)
+                wp, bp = packed(w, b, ct, tk)
                 self._tuned += [wp, bp]
                 o.tile_p, o.tile_c, o.tile_k, o.w, o.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
+                if twin:
+                    wp2, bp2 = packed(*twin["raw"], ct, tk)
+                    self._tuned += [wp2, bp2]
+                    o.aux[1], o.aux[2] = wp2.data_ptr(), bp2.data_ptr()
                 changed += 1
         if changed:
             L.maf_engine_destroy(self._engine)
@@ -752,7 +793,7 @@ class Plan:
             oes = 4 if o.out_f32 else es
             return int(rd) + px * o.Cout * oes + o.Cin * o.Cout * es
         if o.kind == lib.OP_CONV3X3S2:
-            return self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es
+            return (2 if "twin" in self._ops[idx] else 1) * (self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es)
         if o.kind == lib.OP_DWCONV:
             return px * (o.Cin + o.Cout) * es + o.ksize * o.ksize * o.Cout * es
         if o.kind == lib.OP_CONV1DW:
@@ -779,7 +820,7 @@ class Plan:
         if o.kind == lib.OP_CONV1X1:
             return 2 * px * o.Cin * o.Cout
         if o.kind == lib.OP_CONV3X3S2:
-            return 2 * px * 9 * o.Cin * o.Cout
+            return (2 if "twin" in self._ops[idx] else 1) * 2 * px * 9 * o.Cin * o.Cout
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.ksize * o.ksize * o.Cout
         if o.kind == lib.OP_CONV1DW:

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmafyolo_hip.so")
+LIB_PATH = os.environ.get("MAF_HIP_LIB") or os.path.join(_HERE, "libmafyolo_hip.so")     # MAF_HIP_LIB: an instrumented build (make prof)
 
 F16, F32, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3

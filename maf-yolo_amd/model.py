@@ -110,6 +110,7 @@ class Model(nn.Module):
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.fuse_stem = True                 # True / 2: backbone.0 + backbone.1 + the 1x1 that opens backbone.2 in one launch (csrc/stem2.hip; fp16 plans of n and s); 1: without the 1x1; False
         self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
+        self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
 
@@ -213,7 +214,7 @@ class Model(nn.Module):
         else:
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
         fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
-        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, repr(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), self.multi_stream)
+        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, repr(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), self.multi_stream, bool(getattr(self, "twin_convs", True)))
         ver = self.weights_version()
         if ver != self._plans_version:         # the weights changed in place since the cached plans were packed (EMA update, optimizer step ...)
             self._plans = {}

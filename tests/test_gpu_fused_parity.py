@@ -178,5 +178,7 @@ def test_fp16_engine_plus_nms_vs_reference_detections_640(golden):
         hard = [i for i in miss if ref[i, 4] > floor + 1e-2]
         ds = max(abs(ref[i, 4] - got[j, 4]) for i, j in pairs)
         print("image %d: %d/%d matched, %d near-cut misses, %d hard misses, max |dscore| %.2e" % (b, len(pairs), ref.shape[0], len(miss) - len(hard), len(hard), ds))
-        assert len(pairs) >= 0.97 * ref.shape[0], (len(pairs), miss)
-        assert len(hard) <= 3, hard
+        # measured (round 2): 298 / 297 of 300 matched, one hard miss per image (an IoU that sat at the 0.65 threshold), max |d score| 9.3e-4
+        assert len(pairs) >= 294, (len(pairs), miss)
+        assert len(hard) <= 2, hard
+        assert ds <= 2e-3, ds

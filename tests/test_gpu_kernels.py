@@ -479,3 +479,30 @@ def test_conv1_dw_partial_fusion(c, k, H, W):
     _launch(op)
     _check(out[..., 8:], ref, lib.F16)
     assert (out[..., :8] == 2).all()
+
+
+@pytest.mark.parametrize("dt", [lib.F16, lib.F32])
+@pytest.mark.parametrize("tk,pt,ct", [(1, 2, 4), (2, 1, 4), (4, 1, 4), (1, 1, 8)])
+def test_conv3x3s2_twin_launch(dt, tk, pt, ct):
+    """MAF_OP_CONV3X3S2 with aux = {src, w, bias, out} of a second conv: both results equal their own fp32 references."""
+    if dt == lib.F32 and tk == 2:
+        pytest.skip("tile_k = 2 is an fp16 variant")
+    g = torch.Generator().manual_seed(tk * 10 + pt)
+    B, Hin, Win, cin, cout = 2, 22, 18, 64, 64
+    H, W = Hin // 2, Win // 2
+    xs = [_q(torch.randn(B, cin, Hin, Win, generator=g), dt) for _ in range(2)]
+    ws = [_q(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, dt) for _ in range(2)]
+    bs = [torch.randn(cout, generator=g) * 0.2 for _ in range(2)]
+    refs = [F.silu(F.conv2d(xs[i], ws[i], bs[i], 2, 1)) for i in range(2)]
+    xd = [_nhwc(x, dt) for x in xs]
+    wd = [pack.pack_conv3x3(w, ct, dt).to(DEV) for w in ws]
+    bd = [pack.pack_bias(b, ct).to(DEV) for b in bs]
+    outs = [torch.zeros(B, H, W, cout, dtype=DT[dt], device=DEV) for _ in range(2)]
+    op = _conv_op(lib.OP_CONV3X3S2, dt, B, H, W, cin, cout, lib.ACT_SILU, [(xd[0], cin, cin, 0, lib.SRC_DIRECT)], outs[0], cout, 0, wd[0], bd[0], pt, ct, Hin=Hin, Win=Win)
+    op.tile_k = tk
+    op.aux[0], op.aux[1], op.aux[2], op.aux[3] = xd[1].data_ptr(), wd[1].data_ptr(), bd[1].data_ptr(), outs[1].data_ptr()
+    _launch(op)
+    for i in range(2):
+        _check(outs[i], refs[i], dt)
+    op.aux[1] = None                                          # a half-specified twin is rejected
+    assert lib.load().maf_op_launch(C.byref(op), None) == -1

@@ -5,8 +5,11 @@
   (north_star: "within 1e-3 fp32"; the relative term covers box coordinates ~1e3 px where one
   fp32 ulp is 6e-5).
 * fp16 engine (the metric's configuration: fp16 storage, fp32 accumulate) vs the same fp32 golden:
-  scores within 2e-2, boxes within 4 px + 1.5 % — the gap is the reference's own fp32-vs-half gap
-  class, not kernel error: the same kernels in fp32 mode meet 1e-3.
+  twice the gap measured on the device (tools/fp16_gap.py, round 2): n / s: boxes 0.3 px + 0.5 %, scores
+  2e-3 / 5e-3; m (deepest graph, 151 convs of fp16 rounding): boxes 2.2 px + 0.5 %, scores 9e-3.  The gap is
+  fp16 storage of the activations, not kernel error: the same kernels in fp32 mode meet 1e-3, and every
+  fused fp16 kernel is held to 2e-3 against an fp32 reference with the same rounding points
+  (tests/test_gpu_fused_parity.py, tests/test_gpu_kernels.py).
 * NMS: rows AND flat survivor indices identical to the oracle / golden (bit-exact).
 """
 import numpy as np
@@ -26,9 +29,13 @@ def _close32(pred, ref):
     np.testing.assert_allclose(pred[..., 4:], ref[..., 4:], rtol=0, atol=2e-5)
 
 
-def _close16(pred, ref):
-    np.testing.assert_allclose(pred[..., :4], ref[..., :4], rtol=1.5e-2, atol=4.0)
-    np.testing.assert_allclose(pred[..., 4:], ref[..., 4:], rtol=0, atol=2e-2)
+_TOL16 = {"n": (0.3, 2e-3), "s": (0.3, 5e-3), "m": (2.2, 9e-3)}     # (box atol in px at rtol 5e-3, score atol): 2x the measured fp16-vs-fp32 gap
+
+
+def _close16(pred, ref, scale="n"):
+    box_atol, score_atol = _TOL16[scale]
+    np.testing.assert_allclose(pred[..., :4], ref[..., :4], rtol=5e-3, atol=box_atol)
+    np.testing.assert_allclose(pred[..., 4:], ref[..., 4:], rtol=0, atol=score_atol)
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +57,7 @@ def test_forward_320_vs_reference_golden(golden, models, scale):
         p16 = models[scale](x.half())[0]
     assert p32.shape == (1, 2100, 85) and p32.dtype == torch.float32 and len(feats) == 3
     _close32(p32.cpu().numpy(), g["pred320_deploy"])
-    _close16(p16.cpu().numpy(), g["pred320_deploy"])
+    _close16(p16.cpu().numpy(), g["pred320_deploy"], scale)
     # featmaps: (stem, cls, reg) NCHW like the reference's second return value
     t, cls, reg = feats[2]
     assert cls.shape == (1, 80, 10, 10) and reg.shape == (1, 68, 10, 10)
@@ -67,20 +74,23 @@ def test_per_node_taps_vs_reference(golden, models):
         m(x)
     torch.cuda.synchronize()
     plan = m.plan_for(x)
-    last = {}                                   # node -> last op of that node (its output buffer)
+    last = {}                                   # node -> (last op of that node, address of its output buffer)
     for o, name in zip(plan.ops, plan.op_names):
         if name.startswith("backbone."):
-            last[int(name.split(".")[1])] = o
+            last[int(name.split(".")[1])] = (o, o.out)
+            if "+backbone." in name:            # twin launch: the second conv's output is aux[3]
+                last[int(name.split("+backbone.")[1].split(".")[0])] = (o, o.aux[3])
     base = plan.arena.data_ptr()
     checked = 0
-    for node, o in last.items():
+    assert any("+backbone." in n for n in plan.op_names), "the side convs of the neck run as twin launches"
+    for node, (o, out_ptr) in last.items():
         key = "tap64_%d" % node
         if key not in g.files:
             continue                            # heads are checked through featmaps above
         ref = g[key]
         Bn, Cn, Hn, Wn = ref.shape
         n_bytes = Bn * Hn * Wn * o.out_stride * 4
-        off = o.out - base
+        off = out_ptr - base
         got = plan.arena[off:off + n_bytes].view(torch.float32).view(Bn, Hn, Wn, o.out_stride)[..., :Cn]
         np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), ref, rtol=1e-4, atol=5e-5, err_msg=key)
         checked += 1
@@ -118,7 +128,7 @@ def test_batch32_consistency_and_uint8_input(models):
         m.precision = "fp16"
         b = m((u8.float() / 255).to(DEV))[0]
         m.precision = None
-    np.testing.assert_allclose(a.cpu().numpy()[..., 4:], b.cpu().numpy()[..., 4:], atol=2e-2)
+    np.testing.assert_allclose(a.cpu().numpy()[..., 4:], b.cpu().numpy()[..., 4:], atol=2e-3)
 
 
 def test_fresh_inputs_vs_oracle_all_scales(models):
@@ -344,7 +354,7 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
     for fs in (2, 1):
         d = np.abs(taps[fs] - taps[0])
         assert d.max() <= 2e-2 * max(1.0, np.abs(taps[0]).max()) and d.mean() <= 1e-3 * max(1.0, np.abs(taps[0]).mean()), fs
-        _close16(outs[fs], outs[0])
+        _close16(outs[fs], outs[0], scale)
 
 
 def test_fusion_choice_is_measured_when_autotuning():
@@ -360,7 +370,7 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 75 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem + backbone.2.conv1: -2
+    assert len(plan.ops) == 73 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem + backbone.2.conv1: -2; twin side convs: -2
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):
@@ -615,3 +625,30 @@ def test_any_class_count_runs_and_matches_the_sliced_80_class_model(models, nc):
     dets = M.non_max_suppression(p32, 0.03, 0.65, multi_label=True)
     odets = O.non_max_suppression(p32.cpu().numpy(), 0.03, 0.65, multi_label=True)
     assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(dets, odets))
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_twin_conv_launch_equals_two_launches(models, half):
+    """backbone.23 / .24 and .27 / .28 (equal, independent ConvWrappers) as ONE launch each (blockIdx.y picks the conv): the same
+    instructions on the same data as two launches -> bitwise equal predictions, two ops fewer; also after autotuning."""
+    x = O.synth_images(3, 320, 12).to(DEV)
+    x = x.half() if half else x
+    outs = {}
+    for tw in (True, False):
+        m = M.Model("n")
+        m.load_state_dict(O.synth_state_dict("n", 0))
+        m = m.to(DEV).eval()
+        m.twin_convs = tw
+        with torch.no_grad():
+            outs[tw] = m(x)[0].clone()
+        names = m.plan_for(x).op_names
+        assert sum("+backbone." in n for n in names) == (2 if tw else 0)
+        outs[tw, "n"] = len(names)
+        if tw and half:
+            plan = m.plan_for(x)
+            plan.autotune(x)
+            with torch.no_grad():
+                tuned = m(x)[0]
+            _close16(tuned.cpu().numpy(), outs[tw].cpu().numpy())
+    assert outs[True, "n"] == outs[False, "n"] - 2
+    assert torch.equal(outs[True], outs[False])

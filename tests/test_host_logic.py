@@ -147,6 +147,14 @@ def test_plan_builds_on_cpu(built, scale, nops):
     m = M.Model(scale).eval()
     m.fuse_head = False
     m.fuse_stem = False
+    tw = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)       # default: the equal side convs 23 / 24 and 27 / 28 as twin launches
+    pairs = ["backbone.23.block+backbone.24.block", "backbone.27.block+backbone.28.block"][0 if scale != "m" else 1:]    # m: nodes 22 and 20 differ in width
+    assert len(tw.ops) == nops - len(pairs) and [n for n in tw.op_names if "+" in n] == pairs
+    for o, name in zip(tw.ops, tw.op_names):
+        assert bool(o.aux[0]) == ("+" in name) or o.kind == lib.OP_DWCONV, name
+        if "+" in name:
+            assert all(tw._abase <= o.aux[k] < tw._abase + tw._arena_size for k in (0, 3)) and o.aux[3] != o.out and o.aux[0] != o.src[0].ptr
+    m.twin_convs = False
     plan = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     assert len(plan.ops) == nops and built.maf_engine_num_ops(plan._engine) == nops
     lo, hi = plan._abase, plan._abase + plan._arena_size
