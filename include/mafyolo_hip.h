@@ -33,7 +33,8 @@ enum { MAF_F16 = 0, MAF_F32 = 1, MAF_U8 = 2 };
 enum { MAF_ACT_NONE = 0, MAF_ACT_RELU = 1, MAF_ACT_SILU = 2, MAF_ACT_SIGMOID = 3 };
 enum { MAF_SRC_DIRECT = 0,               /* source has the op's H x W grid                              */
        MAF_SRC_UP2 = 1,                  /* source is H/2 x W/2, read through nearest x2 upsample       */
-       MAF_SRC_POOL2 = 2 };              /* source is 2H x 2W, read through MaxPool2d(2,2)              */
+       MAF_SRC_POOL2 = 2,                /* source is 2H x 2W, read through MaxPool2d(2,2)              */
+       MAF_SRC_SUB2 = 3 };               /* source is 2H x 2W, pixel (2y, 2x) is read: a 1x1 conv with stride 2 (RepVGGBlock.rbr_1x1)   */
 enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 conv on the NCHW image   */
        MAF_OP_CONV1X1 = 1,               /* Conv 1x1 (+bias+act) over up to 4 concatenated sources      */
        MAF_OP_CONV3X3S2 = 2,             /* RepVGGBlock / ConvWrapper 3x3 stride 2 pad 1 (+bias+act)    */
@@ -43,7 +44,8 @@ enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 c
        MAF_OP_BOTTLENECK = 6,            /* fused DepthBottleneckUni: 1x1 -> depth-wise k x k -> 1x1    */
        MAF_OP_CONV1DW = 7,               /* first half of a DepthBottleneckUni: 1x1 (c -> 3c) + SiLU -> depth-wise k x k + SiLU */
        MAF_OP_HEADTAIL = 8,              /* one detection level: {cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode into the prediction rows */
-       MAF_OP_STEM2 = 9 };               /* backbone.0 + backbone.1: image -> 1/4-resolution map, the 1/2-resolution tensor stays in LDS */
+       MAF_OP_STEM2 = 9,                 /* backbone.0 + backbone.1: image -> 1/4-resolution map, the 1/2-resolution tensor stays in LDS */
+       MAF_OP_CONV3X3S2_DGRAD = 10 };    /* training: data gradient of a 3x3 stride-2 pad-1 conv (gather form, no atomics)              */
 enum { MAF_E_ARG = -1, MAF_E_UNSUPPORTED = -2, MAF_E_HIP = -3 };
 
 typedef struct {
@@ -71,6 +73,10 @@ typedef struct {
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
  *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
  *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).
+ * MAF_OP_CONV3X3S2_DGRAD  backward of the above w.r.t. its input (autograd of common.py:219-224 / :44-47 in Trainer.train_in_steps,
+ *                   yolov6/core/engine.py:164): src[0] = dY [B,Hin,Win,Cin] (Cin = the forward conv's OUTPUT channels, Hin x Win its output
+ *                   grid), out = dX [B,H,W,Cout] (Cout = the forward conv's input channels, H x W its input grid); w = the forward weight
+ *                   with the channel axes swapped, packed per tap like CONV3X3S2's; bias = zeros; act = NONE; tile_p in {1,2}, tile_c in {2,4,8}.
  * MAF_OP_DWCONV     replaces DilatedReparamBlock.lk_origin after merge (common.py:3025,3033-3051).
  *                   w = [k*k][C] of the activation dtype.  tile_p / tile_c / tile_k optionally fix the workgroup tile
  *                   (rows, cols, channels per block); 0 = built-in cost model.  tile_p = -1 (fp16) selects the matrix-core
@@ -254,6 +260,11 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
                     void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, float* sums, maf_stream_t stream);
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
+/* General form: dW [Cout][Cin][k][k] (fp32, accumulated into) of a conv with k = 1 (stride 1 / 2, pad 0) or k = 3 (stride 2, pad 1) —
+ * RepVGGBlock.rbr_dense / rbr_1x1 (common.py:202-203), ConvWrapper (:76-83): x [B,Hs,Ws,Cin], dy [B,Ho,Wo,Cout], fp16 NHWC views.  The taps are
+ * gathered inside the kernel (no im2col tensor); inputs wider than 256 channels run as channel chunks. */
+int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t Ho, int32_t Wo, int32_t Hs, int32_t Ws,
+                   int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 

@@ -23,7 +23,8 @@ extern "C" int maf_op_launch(const maf_op_t* op, maf_stream_t stream) {
     switch (op->kind) {
         case MAF_OP_STEM: return maf_launch_stem(op, s);
         case MAF_OP_CONV1X1:
-        case MAF_OP_CONV3X3S2: return maf_launch_conv_mfma(op, s);
+        case MAF_OP_CONV3X3S2:
+        case MAF_OP_CONV3X3S2_DGRAD: return maf_launch_conv_mfma(op, s);
         case MAF_OP_DWCONV: return maf_launch_dwconv(op, s);
         case MAF_OP_SPPF_POOL: return maf_launch_sppf_pool(op, s);
         case MAF_OP_DECODE: return maf_launch_decode(op, s);

@@ -58,16 +58,23 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     if (ks4) pt = 0;                                                 // dispatch key of the split-K instantiations
     a.nN = maf_cdiv(op->Cout, 16 * ct);
     int var;
+    if (op->kind == MAF_OP_CONV3X3S2_DGRAD) {
+        MAF_REQUIRE(op->nsrc == 1 && op->src[0].mode == MAF_SRC_DIRECT && !a.twin, "conv3x3s2 dgrad: single direct source (dY)");
+        MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->H - 1) / 2 + 1 == op->Hin && (op->W - 1) / 2 + 1 == op->Win, "conv3x3s2 dgrad: Hin,Win (the dY grid) must equal floor((H-1)/2)+1");
+        MAF_REQUIRE(op->tile_k <= 1 && !op->out_f32 && op->act == MAF_ACT_NONE, "conv3x3s2 dgrad: generic variant, no epilogue");
+        a.act = MAF_ACT_NONE;
+        return maf_conv_mfma_dgrad3(a, op->dtype, pt, ct, s);
+    }
     if (op->kind == MAF_OP_CONV3X3S2) {
         MAF_REQUIRE(op->nsrc == 1 && op->src[0].mode == MAF_SRC_DIRECT, "conv3x3s2: single direct source");
         MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->Hin - 1) / 2 + 1 == op->H && (op->Win - 1) / 2 + 1 == op->W, "conv3x3s2: H,W must equal floor((Hin-1)/2)+1");
         var = VAR_3X3S2;
-    } else if (op->nsrc == 1 && op->src[0].mode == MAF_SRC_POOL2) {
+    } else if (op->nsrc == 1 && (op->src[0].mode == MAF_SRC_POOL2 || op->src[0].mode == MAF_SRC_SUB2)) {
         var = VAR_POOL2;
     } else if (op->nsrc == 1 && !any_special) {
         var = VAR_DIRECT;
     } else {
-        for (int i = 0; i < op->nsrc; ++i) MAF_REQUIRE(op->src[i].mode != MAF_SRC_POOL2, "conv1x1: POOL2 only as a single source");
+        for (int i = 0; i < op->nsrc; ++i) MAF_REQUIRE(op->src[i].mode != MAF_SRC_POOL2 && op->src[i].mode != MAF_SRC_SUB2, "conv1x1: POOL2 / SUB2 only as a single source");
         var = VAR_MULTI;
     }
     const bool outf32 = op->out_f32 != 0 && op->dtype == MAF_F16;

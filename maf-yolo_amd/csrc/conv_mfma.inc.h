@@ -54,11 +54,16 @@ struct ConvArgs {
     int twin;
 };
 
-enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3 };
+// VAR_DGRAD3: the DATA GRADIENT of the 3x3 stride-2 pad-1 conv (training, MAF_OP_CONV3X3S2_DGRAD): output pixel = input pixel (iy, ix)
+// of the forward conv, source = dY on the half-resolution grid; tap (ky, kx) contributes dY[(iy + 1 - ky) / 2, (ix + 1 - kx) / 2] when both
+// are even and in range, else the zero page (2.25 of the 9 taps on average: the waste is MFMA time on a memory-bound layer, and the
+// gather form needs no atomics and no scatter pass).
+enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3, VAR_DGRAD3 = 4 };
 
 int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f32(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f16_lb(const ConvArgs& a, int var, int pt, int ct, hipStream_t s);   // weights shared through LDS (tile_k = 2)
+int maf_conv_mfma_dgrad3(const ConvArgs& a, int dtype, int pt, int ct, hipStream_t s);  // VAR_DGRAD3 (conv_mfma_dgrad.hip)
 int maf_conv1x1_stream(const ConvArgs& a, int pt, int ct, hipStream_t s);              // persistent waves, cross-tile prefetch (tile_k = 3)
 int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s);        // the same with LDS-resident weights (tile_k = 5)
 
@@ -157,6 +162,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 iy0[pt] = 2 * y - 1;
                 ix0[pt] = 2 * x - 1;
                 off0[pt] = (uint32_t)(b * a.Hin) * a.Win;       // pixel index of (b, 0, 0)
+            } else if (VAR == VAR_DGRAD3) {
+                iy0[pt] = y + 1;
+                ix0[pt] = x + 1;
+                off0[pt] = (uint32_t)(b * a.Hin) * a.Win;       // pixel index of (b, 0, 0) on the dY grid
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4_t)0.f;
 
-    const int ntaps = (VAR == VAR_3X3S2) ? 9 : 1;
+    const int ntaps = (VAR == VAR_3X3S2 || VAR == VAR_DGRAD3) ? 9 : 1;
     const int total_steps = ntaps * a.ksteps;
     const int s_begin = KS4 ? (total_steps * wave) / 4 : 0;
     const int s_end = KS4 ? (total_steps * (wave + 1)) / 4 : total_steps;
@@ -207,6 +216,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 const uint32_t o = (off0[pt] + (uint32_t)(iy * a.Win + ix)) * a.srcStride[0] + a.srcCoff[0] + c0;
                 bf[pt] = ldg16<T>(ok ? s0 + o : zpage);
             }
+        } else if (VAR == VAR_DGRAD3) {
+            const int tap = sc / a.ksteps, ks = sc - tap * a.ksteps;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int c0 = ks * F::KS + g * CH;
+            c0 = c0 < a.Cin ? c0 : 0;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int sy = iy0[pt] - ky, sx = ix0[pt] - kx;                      // twice the dY row / column this tap reads
+                const bool ok = !pad && ((sy | sx) & 1) == 0 && (unsigned)(sy >> 1) < (unsigned)a.Hin && (unsigned)(sx >> 1) < (unsigned)a.Win;
+                const uint32_t o = (off0[pt] + (uint32_t)((sy >> 1) * a.Win + (sx >> 1))) * a.srcStride[0] + a.srcCoff[0] + c0;
+                bf[pt] = ldg16<T>(ok ? s0 + o : zpage);
+            }
         } else if (VAR == VAR_MULTI) {
             // every source owns whole k-steps: source index and its first step by scalar selects
             const int i1 = sc >= a.cum[1], i2 = sc >= a.cum[2], i3 = sc >= a.cum[3];
@@ -227,7 +248,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int pt = 0; pt < PT; ++pt) {
                 const T* q = pad ? zpage : s0 + off0[pt] + c0;
                 if (VAR == VAR_POOL2) {
-                    const uint32_t cs = pad ? 0u : (uint32_t)a.srcStride[0], rs = pad ? 0u : (uint32_t)(2 * a.W) * a.srcStride[0];
+                    // MAF_SRC_SUB2 (a 1x1 stride-2 conv: RepVGGBlock.rbr_1x1, common.py:203): the same addressing with the window collapsed onto its top-left pixel
+                    const bool one = pad || a.srcMode[0] == MAF_SRC_SUB2;
+                    const uint32_t cs = one ? 0u : (uint32_t)a.srcStride[0], rs = one ? 0u : (uint32_t)(2 * a.W) * a.srcStride[0];
                     frag_t v0 = ldg16<T>(q), v1 = ldg16<T>(q + cs);
                     frag_t v2 = ldg16<T>(q + rs), v3 = ldg16<T>(q + rs + cs);
                     bf[pt] = F::vmax(F::vmax(v0, v1), F::vmax(v2, v3));

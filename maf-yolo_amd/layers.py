@@ -5,9 +5,9 @@ ConvWrapper :76, SPPF :114, MPRep :776, DepthBottleneckUni :898, RepHDW :928, He
 DilatedReparamBlock :2948, UniRepLKNetBlock :3053) so a reference state_dict (838 / 1206 / 1568
 tensors for n / s / m) loads with strict=True and trained weights round-trip.
 
-`forward` here is the TRAINING-form graph: the 1x1 and depth-wise convolutions (69 % of the FLOPs, most of the
-launches) and BatchNorm(train)+activation run forward and backward on the HIP kernels through train_ops.py; the 3x3
-stride-2 convs, the RepVGG branch BatchNorms and the element-wise glue are torch ops on channels_last tensors.
+`forward` here is the TRAINING-form graph: every convolution (1x1, depth-wise, 3x3 stride-2 and the stride-2 1x1 of the
+RepVGG blocks) and every BatchNorm(train)+activation runs forward and backward on the HIP kernels through train_ops.py;
+what is left to torch is element-wise glue on channels_last tensors (branch sums, max-pool, cat, upsample).
 Inference never runs these forwards: in eval mode
 Model.forward executes the re-parameterised graph on the HIP engine (engine.py), built from
 `fused()` below — the deploy algebra of SURVEY.md §3.3, evaluated in fp32 on the host once.
@@ -59,6 +59,8 @@ class Conv(nn.Module):
     def forward(self, x):
         if self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1):
             return train_ops.bn_act(train_ops.conv1x1(x, self.conv.weight), self.bn, "silu")   # HIP conv fwd / dgrad / wgrad + fused BN(train)+SiLU
+        if self.conv.kernel_size == (3, 3) and self.conv.stride == (2, 2):
+            return train_ops.bn_act(train_ops.conv3x3s2(x, self.conv.weight), self.bn, "silu")  # ConvWrapper: the same on the 3x3 stride-2 kernels
         return train_ops.bn_act(self.conv(x), self.bn, "silu")
 
     def fused(self):
@@ -84,7 +86,10 @@ class RepVGGBlock(nn.Module):
         self.nonlinearity = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.nonlinearity(self.rbr_dense(x) + self.rbr_1x1(x))
+        # both branches (conv + BatchNorm each) on the HIP kernels; their sum and the ReLU are the element-wise glue left to torch
+        y3 = train_ops.bn_act(train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), self.rbr_dense.bn)
+        y1 = train_ops.bn_act(train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight), self.rbr_1x1.bn)
+        return self.nonlinearity(y3 + y1)
 
     def fused(self):
         """One 3x3 kernel + bias (get_equivalent_kernel_bias, common.py:226-230)."""

@@ -131,19 +131,194 @@ class _Conv1x1(torch.autograd.Function):
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
         if ctx.needs_input_grad[1]:
-            if x.dtype == torch.float16 and cout % 8 == 0 and cin <= 256:       # wider inputs: every output-row block re-stages X; the library GEMM wins there
-                xx, xs = nhwc(x)                                                 # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
-                dwf = torch.zeros(cout, cin, dtype=torch.float32, device=x.device)
-                lib.check(lib.load().maf_conv1x1_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B * H * W, cin, cout, dt, dwf.data_ptr(), _stream(x.device)))
-                dw = dwf.reshape(w.shape).to(w.dtype)
-                stats["native_wgrad1x1"] = stats.get("native_wgrad1x1", 0) + 1
-            else:                                                                # fp32 parity mode / odd channel counts: the framework's TN GEMM
+            if x.dtype == torch.float16:                                        # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
+                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels)
+            else:                                                                # fp32 parity mode: the framework's TN GEMM
                 x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
                 d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
                 dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
+                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db
+
+
+def _wgrad(x, dy, dys, w, ksize, stride):
+    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32."""
+    B, cin, Hs, Ws = x.shape
+    cout, Ho, Wo = dy.shape[1:]
+    xx, xs = nhwc(x)
+    co = -(-cout // 8) * 8
+    if co != cout:                                                              # e.g. reg_pred: 68 channels, an odd class count
+        dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
+        dys = co
+    dwf = torch.zeros(co, cin, ksize, ksize, dtype=torch.float32, device=x.device)
+    lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
+    stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
+    return dwf[:cout].reshape(w.shape).to(w.dtype)
+
+
+def _tile_dgrad(n, m_pixels):
+    """(tile_p, tile_c) for the data-gradient launches: tile_c in {2, 4, 8} (the instantiations of csrc/conv_mfma_dgrad.hip)."""
+    ct = 8 if n >= 128 else 4 if n > 32 else 2
+    return (2 if -(-m_pixels // 128) * -(-n // (16 * ct)) >= 1024 else 1), ct
+
+
+def _packed_3x3(w, transpose, dt, ct, dev):
+    """Fragment-packed 3x3 weights on the device: tap-major K, every tap padded to whole k-steps == one [N, 9*Kp] matrix for maf_pack_w1x1.
+    transpose: the data gradient's operand (N = the forward conv's input channels, K = its output channels)."""
+    ks = 32 if dt == lib.F16 else 16
+    m = w.detach().float().permute(1, 2, 3, 0) if transpose else w.detach().float().permute(0, 2, 3, 1)      # [N, 3, 3, K]
+    n, k = m.shape[0], m.shape[3]
+    kp = -(-k // ks) * ks
+    big = F.pad(m, (0, kp - k)).reshape(n, 9 * kp).contiguous()
+    return _packed_1x1(big, n, 9 * kp, 0, dt, ct, dev)
+
+
+class _Conv3x3s2(torch.autograd.Function):
+    """nn.Conv2d(k=3, stride=2, padding=1, bias=False): forward csrc/conv_mfma.inc.h VAR_3X3S2, data gradient VAR_DGRAD3 (gather form),
+    weight gradient csrc/wgrad.hip with the taps gathered in the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, xs = nhwc(x)
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dt = _DT[x.dtype]
+        pt, ct = pack.tile_for(cout, B * Ho * Wo)
+        wp = _packed_3x3(w, False, dt, ct, x.device)
+        out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        op = lib.MafOp()
+        op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2, dt, dt, lib.ACT_NONE
+        op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, Ho, Wo, H, W, cin, cout, 1
+        op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, xs, 0, lib.SRC_DIRECT
+        op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
+        op.tile_p, op.tile_c = pt, ct
+        op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        ctx.save_for_backward(x, w)
+        stats["native_conv3x3s2"] = stats.get("native_conv3x3s2", 0) + 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dy, dys = nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+            dys = dy.stride()[3]
+        Ho, Wo = dy.shape[2:]
+        dt = _DT[x.dtype]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            pt, ct = _tile_dgrad(cin, B * H * W)
+            wp = _packed_3x3(w, True, dt, ct, x.device)
+            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            op = lib.MafOp()
+            op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2_DGRAD, dt, dt, lib.ACT_NONE
+            op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, H, W, Ho, Wo, cout, cin, 1
+            op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = dy.data_ptr(), cout, dys, 0, lib.SRC_DIRECT
+            op.out, op.out_stride, op.out_coff = dx.data_ptr(), dx.stride()[3], 0
+            op.tile_p, op.tile_c = pt, ct
+            op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct).data_ptr()
+            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        if ctx.needs_input_grad[1]:
+            if x.dtype == torch.float16:
+                dw = _wgrad(x, dy, dys, w, 3, 2)
+            else:                                                                # fp32 parity mode: the framework's kernel
+                dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=2, padding=1).to(w.dtype)
+                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
+        return dx, dw
+
+
+class _Conv1x1s2(torch.autograd.Function):
+    """nn.Conv2d(k=1, stride=2, bias=False) (RepVGGBlock.rbr_1x1, common.py:203): the 1x1 kernel reading pixel (2y, 2x) of its source
+    (MAF_SRC_SUB2); data gradient = the 1x1 data gradient scattered onto the even pixels; weight gradient csrc/wgrad.hip, one gathered tap."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, xs = nhwc(x)
+        B, cin, H, W = x.shape
+        assert H % 2 == 0 and W % 2 == 0, "stride-2 1x1 conv: even input sides (images are multiples of 32)"
+        cout = w.shape[0]
+        Ho, Wo = H // 2, W // 2
+        dt = _DT[x.dtype]
+        pt, ct = pack.tile_for(cout, B * Ho * Wo)
+        wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 0, dt, ct, x.device)
+        out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        op = lib.MafOp()
+        op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
+        op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, Ho, Wo, cin, cout, 1
+        op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, xs, 0, lib.SRC_SUB2
+        op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
+        op.tile_p, op.tile_c = pt, ct
+        op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        ctx.save_for_backward(x, w)
+        stats["native_conv1x1"] += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dy, dys = nhwc(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+            dys = dy.stride()[3]
+        dt = _DT[x.dtype]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
+            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device)
+            dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
+            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+            dx[:, :, ::2, ::2] = dxs
+        if ctx.needs_input_grad[1]:
+            if x.dtype == torch.float16:
+                dw = _wgrad(x, dy, dys, w, 1, 2)
+            else:
+                xsub = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(-1, cin)
+                dw = torch.mm(dy.permute(0, 2, 3, 1).reshape(-1, cout).t(), xsub).float().reshape(w.shape).to(w.dtype)
+                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
+        return dx, dw
+
+
+def _pad8(x, w):
+    """A 3-channel image for kernels that read 16-byte channel chunks: zero channels appended to x and to the filters (their gradient slices are dropped by autograd)."""
+    cin = x.shape[1]
+    if cin % 8 == 0:
+        return x, w
+    extra = 8 - cin % 8
+    xp = F.pad(x, (0, 0, 0, 0, 0, extra)).contiguous(memory_format=torch.channels_last)
+    return xp, F.pad(w, (0, 0, 0, 0, 0, extra))
+
+
+def conv3x3s2(x, w):
+    """nn.Conv2d(k=3, stride=2, padding=1, bias=False) with autograd; x [B,Cin,H,W] (NHWC in memory preferred), w [Cout,Cin,3,3]."""
+    if not x.is_cuda:                       # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
+        stats["fallback"] += 1
+        return F.conv2d(x, w.to(x.dtype), None, 2, 1)
+    x = _autocast(x)
+    if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
+        raise lib.MafError("conv3x3s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
+    return _Conv3x3s2.apply(*_pad8(x, w))
+
+
+def conv1x1s2(x, w):
+    """nn.Conv2d(k=1, stride=2, bias=False) with autograd."""
+    if not x.is_cuda:
+        stats["fallback"] += 1
+        return F.conv2d(x, w.to(x.dtype), None, 2, 0)
+    x = _autocast(x)
+    if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (1, 1)):
+        raise lib.MafError("conv1x1s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
+    return _Conv1x1s2.apply(*_pad8(x, w))
 
 
 def conv1x1(x, w, bias=None):
@@ -277,9 +452,14 @@ def bn_act(x, bn, act=None):
     """act(bn(x)) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  Training mode on CUDA tensors runs the fused HIP kernels
     (one statistics pass + one normalise/affine/activation pass; backward likewise); eval mode and CPU tensors run torch ops."""
     mult = 8 if x.dtype == torch.float16 else 4
-    if not (x.is_cuda and bn.training and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and bn.affine):
+    if not (x.is_cuda and bn.training):
+        # CPU tensors (CI / gloo tests) and eval-mode BatchNorm inside a train-form forward (Model.forward(val_loss=True) never comes here:
+        # it runs the deploy engine): torch ops, counted so that an A/B on `stats` cannot mistake them for the HIP path
+        stats["torch_bn"] = stats.get("torch_bn", 0) + 1
         y = bn(x)
         return y if act in (None, "none") else (F.relu(y) if act == "relu" else F.silu(y))
+    if not (x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and bn.affine):
+        raise lib.MafError("bn_act: unsupported input for the HIP path: %s %s (channels must be a multiple of %d, affine BatchNorm)" % (tuple(x.shape), x.dtype, mult))
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.0 if bn.momentum is None else bn.momentum
