@@ -88,6 +88,41 @@ def latency_mode(args, torch, M, dev):
                       "latency": res}), flush=True)
 
 
+def train_cpu_baseline(args, torch, M):
+    """The same train step (train-form module tree in plain torch + the oracle's ComputeLoss restatement, fp32, autograd, SGD) on the host cores: a
+    bounded sample (one warm-up + timed steps of 4 images until ~15 s have passed)."""
+    from maf_yolo_amd import synth
+    from oracle import maf_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    m = M.Model(args.scale)
+    m.load_state_dict(synth.synth_state_dict(m, args.scale, 0))
+    m = m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    bs = 4
+    x = synth.synth_images(bs, 640, seed=1)
+    g = torch.Generator().manual_seed(100)
+    wh = torch.rand(7 * bs, 2, generator=g) * 0.35 + 0.04
+    ctr = wh / 2 + torch.rand(7 * bs, 2, generator=g) * (1 - wh)
+    t = torch.cat([torch.arange(bs).repeat_interleave(7)[:, None].float(), torch.randint(0, 80, (7 * bs, 1), generator=g).float(), ctr, wh], 1)
+
+    def step():
+        (feats, cls, reg), _ = m(x)
+        loss = O.compute_loss([tuple(f.shape[-2:]) for f in feats], cls, reg, t, img_size=640)[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or time.perf_counter() - t0 < 15.0:
+        step(); n += 1
+        if n >= 20:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(bs * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps of %d images (3x640x640 fp32): train-form module tree in plain torch + oracle.compute_loss, autograd, SGD; %.1f s wall, %d torch threads" % (n, bs, el, threads)}
+
+
 def train_mode(args, torch, M, dev, rank, world, dist):
     """One step = forward (autocast fp16) + backward + DDP all-reduce + SGD step on a fixed synthetic batch per rank.
     The loss is the device-side ComputeLoss (HIP task-aligned assignment + VFL / GIoU / DFL) on synthetic labels,
@@ -127,22 +162,63 @@ def train_mode(args, torch, M, dev, rank, world, dist):
         scaler.update()
         return loss
 
+    def timed(fn, n):
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        t0_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0_
+        if dist is not None:
+            dist.barrier()
+            t_ = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el = t_.item()
+        return el
+
     for _ in range(args.warmup):
         loss = step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    last = {}
+
+    def one():
+        last["loss"] = step()
+    elapsed = timed(one, args.steps)
+    loss = last["loss"]
+    # ---- exposed (non-overlapped) all-reduce time (BASELINE configs[3], yolov6/core/engine.py:477-489): the same steps with the gradient
+    # exchange switched off (DDP.no_sync: no bucket all-reduce is launched) — the difference is what the collective adds to a step after its
+    # overlap with the remaining backward
+    comm = None
+    if world > 1:
+        def nosync():
+            with net.no_sync():
+                step()
+        k2 = max(5, args.steps // 2)
+        el_ns = timed(nosync, k2)
+        grad_bytes = sum(p_.numel() * 4 for p_ in model.parameters() if p_.requires_grad)
+        comm = {"ms_per_step_without_all_reduce": round(1e3 * el_ns / k2, 3), "exposed_all_reduce_ms": round(1e3 * (elapsed / args.steps - el_ns / k2), 3),
+                "gradient_bytes_per_step": grad_bytes, "steps": k2,
+                "note": "same steps under DistributedDataParallel.no_sync(); RCCL all-reduce of the fp32 gradient buckets is overlapped with the backward by the autograd hooks"}
+    # ---- roofline of the dominant training kernel: one more step with HIP events around every native launch (train_ops.profile)
+    roof = None
+    if rank == 0 and not args.torch_convs:
+        train_ops.profile = {}
+        step()
         torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        prof = train_ops.profile_collect()
+        train_ops.profile = None
+        tot = sum(v[0] for v in prof.values())
+        kinds = sorted(prof.items(), key=lambda kv: -kv[1][0])
+        k0, (ms0, by0, n0) = kinds[0]
+        roof = {"bound": "hbm", "kernel": k0, "launches_per_step": n0, "avg_launch_ms": round(ms0 / n0, 5), "bytes_per_launch": int(by0 / n0),
+                "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3),
+                "by_kind": {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = train_cpu_baseline(args, torch, M)
     if rank == 0:
         print(json.dumps({"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD, AMP fp16)" % (args.scale, B),
                           "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -150,8 +226,9 @@ def train_mode(args, torch, M, dev, rank, world, dist):
                           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                           "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, %s" % (args.scale, B, "surrogate loss over all head outputs" if args.surrogate_loss else "ComputeLoss (HIP task-aligned assigner + VFL/GIoU/DFL), 7 boxes/image"),
                                      "global_batch": B * world, "parallelism": "ddp%d" % world,
-                                     "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for 1x1 + depth-wise (fwd, dgrad, DW wgrad); 3x3 s2 + BN torch",
-                                     "native_launches": dict(train_ops.stats), "final_loss": round(float(loss), 5)}}), flush=True)
+                                     "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
+                                     "native_launches": dict(train_ops.stats), "final_loss": round(float(loss), 5)},
+                          "roofline": roof, "cpu_baseline": cpu, "all_reduce": comm}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -174,7 +251,7 @@ def main():
                          "(1 = one stream; the NMS of a batch still overlaps the next forward)")
     ap.add_argument("--tune-file", default=None,
                     help="JSON of autotuned tiles: loaded if it exists (no re-timing: profiler passes run the same kernels as the bench), written after tuning; "
-                         "default: profiles/round1_tune.json if present; 'none' = time every layer afresh")
+                         "default: profiles/round2_tune.json if present; 'none' = time every layer afresh")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
@@ -219,7 +296,7 @@ def main():
     from maf_yolo_amd import engine as _engine
     # tile choices (which (pixels x channels) cut, which kernel variant per layer) measured on an MI355X and frozen in the repo are the
     # default starting point: layer signatures that are not in the file are still timed here.  --tune-file none = time everything afresh.
-    frozen = os.path.join(ROOT, "profiles", "round1_tune.json")
+    frozen = os.path.join(ROOT, "profiles", "round2_tune.json")
     if args.tune_file is None and os.path.exists(frozen):
         args.tune_file = frozen
     if args.tune_file == "none":
@@ -252,6 +329,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     S = max(1, args.inflight)
+    xs = [x] + [synth.synth_images(B, 640, seed=101 + 7 * k + rank).to(dev).half() for k in range(1, S)]
     # streams that share a hardware queue run their kernels one after the other: take streams that demonstrably overlap (streams.py)
     cs = M.concurrent_streams(dev, S + 1)                      # S forward streams + the NMS stream, on different hardware queues
     streams, nms_stream = (cs[:S] if S > 1 else [torch.cuda.current_stream(dev)]), cs[S]
@@ -266,7 +344,7 @@ def main():
         for i in range(n):
             k = i % S
             with torch.cuda.stream(streams[k]), torch.no_grad():
-                pred_i = model(x, slot=k)[0]
+                pred_i = model(xs[k], slot=k)[0]                  # every slot has its own resident input batch (not one MALL-warm tensor)
                 pending.append(M.non_max_suppression_async(pred_i, conf, iou, multi_label=True, side=nms_stream))
             if len(pending) > S:                                   # collect batch i - S once batch i is queued
                 dets = pending.pop(0).result()
@@ -356,11 +434,12 @@ def main():
         fwd_img_s = B / (fwd_ms * 1e-3)
         traffic, traffic_src, pmc = None, None, {}
         try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            pmc_file = [f_ for f_ in ("round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             have = [k for k in gd["inst"] if k in pmc]
             if have:                           # per launch of the template: instantiations weighted by their launches in this forward
                 traffic = int(sum(pmc[k]["traffic_bytes"] * groups[k]["n"] for k in have) / sum(groups[k]["n"] for k in have))
-                traffic_src = "profiles/round1_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 per launch, gfx950 FETCH_SIZE x2 correction"
+                traffic_src = "profiles/%s: (FETCH_SIZE*2 + WRITE_SIZE)*1024 per launch, gfx950 FETCH_SIZE x2 correction" % pmc_file
         except Exception:
             pass
         insts = []
@@ -370,11 +449,21 @@ def main():
                               achieved_GBs=round(a_gbs, 1), hbm_frac=round(a_gbs / HBM_PEAK_GBS, 4),
                               mfma_frac=round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                               traffic=pmc.get(k, {}).get("traffic_bytes")))
+        k_big, g_big = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        big_gbs = g_big["bytes"] / (g_big["ms"] * 1e-3) / 1e9
+        largest = dict(kernel=k_big, launches=g_big["n"], avg_launch_ms=round(g_big["ms"] / g_big["n"], 5), share_of_forward=round(g_big["ms"] / per_op_ms.sum(), 4),
+                       bytes_per_launch=int(g_big["bytes"] / g_big["n"]), achieved=round(big_gbs, 1), frac=round(big_gbs / HBM_PEAK_GBS, 4), traffic=pmc.get(k_big, {}).get("traffic_bytes"))
+        # SURVEY.md 8(d) layer-granular byte model (every conv block of the UNFUSED deploy graph reads its input and writes its output once):
+        # activations per image + weights once per batch; the plan's own model (`algorithmic_GB`) counts the fused graph, where the tensors
+        # between fused layers never exist
+        act_w = {"n": (174.5, 7.5), "s": (339.3, 17.1), "m": (679.3, 47.4)}[args.scale]
+        layer_gb = (B * act_w[0] + act_w[1]) / 1e3
         roofline = dict(bound="hbm", kernel=name + "<...> (%d instantiations)" % len(gd["inst"]), launches_per_forward=gd["n"], avg_launch_ms=round(avg_ms, 5),
                         bytes_per_launch=int(bytes_per_launch), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4), top_instantiations=insts,
-                        whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), GFLOP=round(tot_flops / 1e9, 2),
+                        share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4), largest_symbol=largest, top_instantiations=insts,
+                        whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), layer_granular_GB=round(layer_gb, 4),
+                                           hbm_frac_layer_granular=round(layer_gb / (fwd_ms * 1e-3) / HBM_PEAK_GBS, 4), GFLOP=round(tot_flops / 1e9, 2),
                                            sum_kernel_ms=round(float(per_op_ms.sum()), 4),
                                            hbm_frac=round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            hbm_frac_timed_region=round(tot_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -406,17 +495,24 @@ def main():
                 if hasattr(m_, "cls_pred"):
                     key = "backbone.%d.cls_pred" % m_.i
                     dw[key] = (dw[key][0], m_.cls_pred.bias.detach().float().cpu())
-            xb = x[:4].float().cpu()
+            # batches of 8 and of 32, 3 warm-up + 5 timed runs each; `value` = the bs-32 rate (the metric's batch)
+            runs = {}
             with torch.no_grad():
-                O.non_max_suppression(O.predict(dw, args.scale, xb[:1]).numpy(), conf, iou, multi_label=True)   # warm-up
-                n_img, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < 12.0 and n_img < 256:
-                    p = O.predict(dw, args.scale, xb)
-                    O.non_max_suppression(p.numpy(), conf, iou, multi_label=True)
-                    n_img += xb.shape[0]
-                dt = time.perf_counter() - t0
-            cpu = dict(value=round(n_img / dt, 2), unit="images/s", cores=cores, kind="port",
-                       sample="%d images (batches of 4, 3x640x640 fp32) through oracle.predict + oracle.non_max_suppression, %.1f s wall, %d torch threads" % (n_img, dt, cores))
+                for bs_ in (8, 32):
+                    xb = torch.cat([t_.float().cpu() for t_ in xs])[:bs_] if bs_ > B else x[:bs_].float().cpu()
+                    ts = []
+                    for it in range(3 + 5):
+                        t0 = time.perf_counter()
+                        p = O.predict(dw, args.scale, xb)
+                        O.non_max_suppression(p.numpy(), conf, iou, multi_label=True)
+                        if it >= 3:
+                            ts.append(time.perf_counter() - t0)
+                    runs[bs_] = dict(images_per_s=round(xb.shape[0] / float(np.median(ts)), 2), best=round(xb.shape[0] / min(ts), 2), batch=int(xb.shape[0]), timed_runs=len(ts), warmup_runs=3,
+                                     seconds=round(float(sum(ts)), 1))
+            cpu = dict(value=runs[32]["images_per_s"], unit="images/s", cores=cores, kind="port",
+                       sample="oracle.predict + oracle.non_max_suppression (fp32, %d torch threads) on 3x640x640 batches of 8 and 32: 3 warm-up + 5 timed runs each, median; "
+                              "value = batch %d (%.1f s timed), batch 8: %.2f images/s" % (cores, runs[32]["batch"], runs[32]["seconds"], runs[8]["images_per_s"]),
+                       runs={str(k): v for k, v in runs.items()})
 
         out = {"metric": "images/sec MAF-YOLO-%s 640x640 bs=%d infer (Model.forward + non_max_suppression)" % (args.scale, B),
                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

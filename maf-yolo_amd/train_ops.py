@@ -25,6 +25,36 @@ _DT = {torch.float16: lib.F16, torch.float32: lib.F32}
 _zeros = {}
 stats = {"native_conv1x1": 0, "native_dwconv": 0, "fallback": 0}
 
+# Per-kernel timing of one training step (bench.py --train: the `roofline` object): while `profile` is a dict every native launch is
+# bracketed by HIP events on its stream; profile_collect() turns them into {kind: [milliseconds, algorithmic bytes, launches]}.
+profile = None
+_pending = []
+
+
+class _prof:
+    def __init__(self, kind, nbytes, dev):
+        self.kind, self.nbytes, self.dev = kind, int(nbytes), dev
+
+    def __enter__(self):
+        if profile is not None:
+            self.t = lib.Timer()
+            self.t.start(_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if profile is not None:
+            self.t.stop(_stream(self.dev))
+            _pending.append((self.kind, self.nbytes, self.t))
+        return False
+
+
+def profile_collect():
+    """Wait for the recorded launches and fold them into `profile` (kind -> [ms, algorithmic bytes, launches])."""
+    for kind, nbytes, t in _pending:
+        rec = profile.setdefault(kind, [0.0, 0, 0])
+        rec[0] += t.elapsed_ms(); rec[1] += nbytes; rec[2] += 1
+    del _pending[:]
+    return profile
+
 
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
@@ -69,7 +99,9 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
     op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
     op.tile_p, op.tile_c = pack.tile_for(cout, B * H * W)[0], ct
     op.w, op.bias = wp.data_ptr(), bias.data_ptr()
-    lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+    es = x.element_size()
+    with _prof("conv1x1", B * H * W * (cin + cout) * es + cin * cout * es, x.device):
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
 
 
 def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev):
@@ -153,7 +185,8 @@ def _wgrad(x, dy, dys, w, ksize, stride):
         dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
         dys = co
     dwf = torch.zeros(co, cin, ksize, ksize, dtype=torch.float32, device=x.device)
-    lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
+    with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device):
+        lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
     stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
     return dwf[:cout].reshape(w.shape).to(w.dtype)
 
@@ -196,7 +229,9 @@ class _Conv3x3s2(torch.autograd.Function):
         op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
         op.tile_p, op.tile_c = pt, ct
         op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
-        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        es = x.element_size()
+        with _prof("conv3x3s2", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device):
+            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
         ctx.save_for_backward(x, w)
         stats["native_conv3x3s2"] = stats.get("native_conv3x3s2", 0) + 1
         return out
@@ -224,7 +259,9 @@ class _Conv3x3s2(torch.autograd.Function):
             op.out, op.out_stride, op.out_coff = dx.data_ptr(), dx.stride()[3], 0
             op.tile_p, op.tile_c = pt, ct
             op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct).data_ptr()
-            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+            es = x.element_size()
+            with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device):
+                lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
         if ctx.needs_input_grad[1]:
             if x.dtype == torch.float16:
                 dw = _wgrad(x, dy, dys, w, 3, 2)
@@ -256,7 +293,8 @@ class _Conv1x1s2(torch.autograd.Function):
         op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
         op.tile_p, op.tile_c = pt, ct
         op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
-        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        with _prof("conv1x1", B * Ho * Wo * (cin + cout) * x.element_size(), x.device):
+            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
         ctx.save_for_backward(x, w)
         stats["native_conv1x1"] += 1
         return out
@@ -340,7 +378,8 @@ def _launch_dw(x, xs, wp, bias, B, H, W, c, k, out, dt):
     op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), c, xs, 0, lib.SRC_DIRECT
     op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
     op.w, op.bias = wp.data_ptr(), bias.data_ptr()
-    lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+    with _prof("dwconv_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
 
 
 def _packed_dw(w, c, k, flip, dt, dev):
@@ -381,7 +420,8 @@ class _DWConv(torch.autograd.Function):
             xx, xs = nhwc(x)
             reps = 32                                                           # copies of dW: atomics on one cache line serialise
             dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
-            lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
+            with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
+                lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
             dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
         return dx, dw
 
@@ -418,11 +458,12 @@ class _BNAct(torch.autograd.Function):
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
         part = _bn_part(dev, c)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
-                                            None if running_mean is None else running_mean.data_ptr(),
-                                            None if running_var is None else running_var.data_ptr(), act,
-                                            y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
-                                            _stream(dev)))
+        with _prof("bn_act_forward", 3 * B * H * W * c * x.element_size(), dev):       # statistics pass (read) + apply pass (read, write)
+            lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
+                                                None if running_mean is None else running_mean.data_ptr(),
+                                                None if running_var is None else running_var.data_ptr(), act,
+                                                y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
+                                                _stream(dev)))
         ctx.save_for_backward(x, g32, b32, stat)
         ctx.act = act
         stats["native_bn_act"] = stats.get("native_bn_act", 0) + 1
@@ -442,9 +483,10 @@ class _BNAct(torch.autograd.Function):
         dgb = torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
         part = _bn_part(dev, c)
         sums = torch.empty(2, c, dtype=torch.float32, device=dev)
-        lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
-                                             stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
-                                             dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, sums.data_ptr(), _stream(dev)))
+        with _prof("bn_act_backward", 5 * B * H * W * c * x.element_size(), dev):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
+            lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
+                                                 stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
+                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, sums.data_ptr(), _stream(dev)))
         return dx, dgb[0], dgb[1], None, None, None, None, None
 
 
