@@ -88,18 +88,31 @@ def latency_mode(args, torch, M, dev):
                       "latency": res}), flush=True)
 
 
+def host_cores():
+    """Host cores this process may use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box shows 256 CPUs, the container gets 16)
+    and by 64 (oneDNN convs stop scaling beyond)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(cores, 64)
+
+
 def train_cpu_baseline(args, torch, M):
     """The same train step (train-form module tree in plain torch + the oracle's ComputeLoss restatement, fp32, autograd, SGD) on the host cores: a
     bounded sample (one warm-up + timed steps of 4 images until ~15 s have passed)."""
     from maf_yolo_amd import synth
     from oracle import maf_oracle as O
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     m = M.Model(args.scale)
     m.load_state_dict(synth.synth_state_dict(m, args.scale, 0))
     m = m.train()
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
-    bs = 4
+    bs = 2
     x = synth.synth_images(bs, 640, seed=1)
     g = torch.Generator().manual_seed(100)
     wh = torch.rand(7 * bs, 2, generator=g) * 0.35 + 0.04
@@ -112,12 +125,12 @@ def train_cpu_baseline(args, torch, M):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-    step()
+    t_w = time.perf_counter()
+    step()                                                      # warm-up (also tells how long a step takes)
+    t_w = time.perf_counter() - t_w
     n, t0 = 0, time.perf_counter()
-    while n < 2 or time.perf_counter() - t0 < 15.0:
+    while n < 1 or (time.perf_counter() - t0 + t_w < 20.0 and n < 20):     # bounded: at least one timed step, about 20 s of CPU work
         step(); n += 1
-        if n >= 20:
-            break
     el = time.perf_counter() - t0
     return {"value": round(bs * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "%d train steps of %d images (3x640x640 fp32): train-form module tree in plain torch + oracle.compute_loss, autograd, SGD; %.1f s wall, %d torch threads" % (n, bs, el, threads)}
@@ -187,6 +200,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
         last["loss"] = step()
     elapsed = timed(one, args.steps)
     loss = last["loss"]
+    launches = dict(train_ops.stats)                            # before the CPU baseline below runs the same module tree on the host
     # ---- exposed (non-overlapped) all-reduce time (BASELINE configs[3], yolov6/core/engine.py:477-489): the same steps with the gradient
     # exchange switched off (DDP.no_sync: no bucket all-reduce is launched) — the difference is what the collective adds to a step after its
     # overlap with the remaining backward
@@ -227,7 +241,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
                           "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, %s" % (args.scale, B, "surrogate loss over all head outputs" if args.surrogate_loss else "ComputeLoss (HIP task-aligned assigner + VFL/GIoU/DFL), 7 boxes/image"),
                                      "global_batch": B * world, "parallelism": "ddp%d" % world,
                                      "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
-                                     "native_launches": dict(train_ops.stats), "final_loss": round(float(loss), 5)},
+                                     "native_launches": launches, "final_loss": round(float(loss.detach()), 5)},
                           "roofline": roof, "cpu_baseline": cpu, "all_reduce": comm}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -481,14 +495,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import maf_oracle as O          # the CPU restatement: checker / baseline only
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            try:                                        # cgroup CPU quota, if any
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q != "max":
-                    cores = max(1, min(cores, int(int(q) / int(per))))
-            except Exception:
-                pass
-            cores = min(cores, 64)                      # oneDNN convs stop scaling (and start thrashing) beyond this
+            cores = host_cores()
             torch.set_num_threads(cores)
             dw = O.reparam(sd, args.scale)
             for m_ in model.backbone:          # same calibrated head as the GPU run

@@ -12,6 +12,7 @@
 // blockIdx.z walks the taps, and the X tile of tap (ky, kx) is gathered from pixel (2 oy - 1 + ky, 2 ox - 1 + kx) of the full-resolution
 // input (zeros outside the image) while it is transposed into LDS — no im2col tensor, no per-tap copies.  Inputs wider than 256
 // channels are cut into channel chunks by the host wrapper (the LDS tile holds one chunk).
+#include <cstdlib>
 #include "maf_common.h"
 
 namespace {
@@ -25,6 +26,7 @@ struct WgArgs {
     int gather, Ho, Wo, Hs, Ws, tap0;
     int dw_stride;        // row length of dW in (ci) elements
     int dw_es;            // element stride between consecutive ci of one tap (k*k), the tap index is added
+    int tpw_taps;         // taps handled inside one workgroup (1, 3 or 9): dY is staged once per pixel step and reused for all of them
 };
 
 constexpr int kPix = 64;              // pixels per staging step
@@ -40,15 +42,16 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
     const int cob = min(a.co_blk, ((a.Cout - co0) + 15) & ~15);          // padded rows of this block
     half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [cinp][kRow]
     half_t* Ds = Xs + (size_t)cinp * kRow;                               // [cob][kRow]
-    const int tci = cinp >> 4, tco = cob >> 4, ntile = tci * tco;
+    const int tci = cinp >> 4, tco = cob >> 4, ntile1 = tci * tco, ntile = ntile1 * a.tpw_taps;     // virtual tiles: (tap in workgroup, co tile, ci tile)
 
     f32x4_t acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = (f32x4_t)0.f;
 
-    const int tap = a.tap0 + blockIdx.z, tky = tap / 3, tkx = tap - tky * 3;
     const int m_begin = blockIdx.x * a.chunk, m_end = min(a.M, m_begin + a.chunk);
     for (int m0 = m_begin; m0 < m_end; m0 += kPix) {
+      for (int tt = 0; tt < a.tpw_taps; ++tt) {
+        const int tap = a.tap0 + blockIdx.z * a.tpw_taps + tt, tky = tap / 3, tkx = tap - tky * 3;
         __syncthreads();                                                 // previous step's MFMAs have read the tiles
         // ---- stage: lane (g, p) of an item = pixel p of a 16-pixel group, channel chunk g of a 4-chunk group
         {
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
                     for (int j = 0; j < 8; ++j) Xs[(size_t)(ch + j) * kRow + px] = v[j];
                 }
             }
-            const int dg = cob >> 3;
+            const int dg = tt == 0 ? cob >> 3 : 0;                        // dY: once per pixel step, shared by the taps of this workgroup
             for (int it = tid; it < (kPix / 16) * ((dg + 3) >> 2) * 64; it += 256) {
                 const int l = it & 63, grp = it >> 6;
                 const int pg = grp % (kPix / 16), cq = grp / (kPix / 16);
@@ -90,8 +93,9 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
         // ---- MFMA: D[co][ci] += sum_k dY^T[co][k] X^T... A = rows of Ds (co), B = rows of Xs (ci), k = pixel
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int tile = wave + 4 * t;
-            if (tile < ntile) {
+            const int vt = wave + 4 * t;
+            if (vt < ntile && vt / ntile1 == tt) {
+                const int tile = vt - tt * ntile1;
                 const int ti = tile / tci, tj = tile - ti * tci;
 #pragma unroll
                 for (int ks = 0; ks < kPix / 32; ++ks) {
@@ -101,12 +105,15 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
                 }
             }
         }
+      }
     }
     // ---- accumulator lane (g, p): rows co = 4g + r, column ci = p of its tile
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tile = wave + 4 * t;
-        if (tile >= ntile) continue;
+        const int vt = wave + 4 * t;
+        if (vt >= ntile) continue;
+        const int tt = vt / ntile1, tile = vt - tt * ntile1;
+        const int tap = a.tap0 + blockIdx.z * a.tpw_taps + tt;
         const int ti = tile / tci, tj = tile - ti * tci;
         const int ci = tj * 16 + p;
 #pragma unroll
@@ -146,14 +153,20 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     MAF_REQUIRE((size_t)(cinp + tco * 16) * kRow * 2 <= 160 * 1024, "conv wgrad: Cin chunk too large for the LDS tile");
     a.co_blk = tco * 16;
     const int gy = maf_cdiv(tco_all, tco);
-    int gx = 1024 / (gy * ntaps) > 0 ? 1024 / (gy * ntaps) : 1;         // ~4 workgroups per CU
+    // taps per workgroup: as many as the accumulator budget (16 tiles per wave) allows — dY is then read once for all of them
+    // (measured on MI355X, n bs 32: looping the 9 taps inside a workgroup — dY staged once — is 20 % SLOWER than one tap per workgroup
+    //  (5.1 vs 4.3 ms per step): the strided X gather dominates and nine times fewer workgroups hide its latency worse; kept selectable)
+    a.tpw_taps = 1;
+    if (ntaps == 9 && getenv("MAF_WGRAD_TAPS_IN_WG")) a.tpw_taps = tci * tco * 9 <= 64 ? 9 : tci * tco * 3 <= 64 ? 3 : 1;
+    const int gz = ntaps / a.tpw_taps;
+    int gx = 1024 / (gy * gz) > 0 ? 1024 / (gy * gz) : 1;              // ~4 workgroups per CU
     const int steps = maf_cdiv(M, kPix);
     if (gx > steps) gx = steps;
     a.chunk = maf_cdiv(steps, gx) * kPix;
     gx = maf_cdiv(M, a.chunk);
     const size_t lds = (size_t)(cinp + a.co_blk) * kRow * 2;
-    const int tpw = maf_cdiv(tci * tco, 4);
-    const dim3 grid(gx, gy, ntaps);
+    const int tpw = maf_cdiv(tci * tco * a.tpw_taps, 4);
+    const dim3 grid(gx, gy, gz);
     int rc;
     if (tpw <= 2) rc = launch_wg<2>(a, grid, lds, s);
     else if (tpw <= 4) rc = launch_wg<4>(a, grid, lds, s);
