@@ -1,0 +1,271 @@
+// PyTorch-ROCm custom-op layer over the C-ABI of libmafyolo_hip.so (BASELINE.json north_star: "exposed behind the
+// reference's Model.forward() / non_max_suppression() surface as PyTorch-ROCm custom ops").
+//
+//   torch.ops.load_library("maf-yolo_amd/libmafyolo_torch.so")
+//   y    = torch.ops.mafyolo.conv1x1_bias_act(x, w, b, act)            # Conv.forward_fuse (yolov6/layers/common.py:49-50), nn.Conv2d preds (:1331,1335)
+//   y    = torch.ops.mafyolo.conv3x3s2_bias_act(x, w, b, act)          # RepVGGBlock deploy forward (:216-217), ConvWrapper (:76-83)
+//   y    = torch.ops.mafyolo.dwconv_bias_act(x, w, b, act)             # UniRepLKNetBlock after reparameterize (:3085-3100)
+//   pred = torch.ops.mafyolo.head_decode(cls, reg, strides)            # Detect_yaml.forward eval branch (yolov6/models/yolo.py:355-396)
+//   rows, counts = torch.ops.mafyolo.decode_nms(pred, conf, iou, agnostic, multi_label, max_det, classes)   # non_max_suppression (yolov6/utils/nms.py:31-105)
+//
+// Every op takes / returns at::Tensor (NCHW shape, channels_last = NHWC memory, fp16 or fp32, on the HIP device), runs on the CURRENT HIP
+// stream, allocates its outputs through the caching allocator, keeps no reference after it returns and reports errors as RuntimeError
+// (TORCH_CHECK).  The backward pieces (data / weight gradients) are ops of their own; maf_yolo_amd/torch_ops.py wires them up with
+// torch.library.register_autograd, registers the autocast rule (cast to the autocast dtype, like a convolution) and the fake (meta)
+// kernels.  No kernel lives here: this file only marshals tensors into the C-ABI (include/mafyolo_hip.h).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "../../include/mafyolo_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+void check(int rc, const char* what) { TORCH_CHECK(rc == 0, "mafyolo::", what, ": ", maf_last_error(), " (code ", rc, ")"); }
+
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+int dtype_of(const Tensor& t) {
+    TORCH_CHECK(t.scalar_type() == at::kHalf || t.scalar_type() == at::kFloat, "mafyolo ops take fp16 or fp32 tensors, got ", t.scalar_type());
+    return t.scalar_type() == at::kHalf ? MAF_F16 : MAF_F32;
+}
+
+Tensor nhwc(const Tensor& x) {
+    TORCH_CHECK(x.is_cuda() && x.dim() == 4, "mafyolo ops take 4-d tensors on the HIP device (there is no CPU path)");
+    return x.contiguous(at::MemoryFormat::ChannelsLast);
+}
+
+// (tile_p, tile_c) as maf-yolo_amd/pack.py:tile_for: least channel padding, then fewest tiles
+std::pair<int, int> tile_for(int64_t cout, int64_t m, bool dgrad = false) {
+    int best_ct = 2;
+    int64_t best_pad = -1, best_tiles = -1;
+    for (int ct : {8, 6, 4, 2}) {
+        if (dgrad && ct == 6) continue;
+        const int64_t tiles = (cout + 16 * ct - 1) / (16 * ct), pad = tiles * 16 * ct;
+        if (best_pad < 0 || pad < best_pad || (pad == best_pad && tiles < best_tiles)) { best_pad = pad; best_tiles = tiles; best_ct = ct; }
+    }
+    const int pt = ((m + 127) / 128) * best_tiles >= 1024 ? 2 : 1;
+    return {pt, best_ct};
+}
+
+Tensor padded_bias(const c10::optional<Tensor>& bias, int64_t cout, int ct, const Tensor& like) {
+    const int64_t npad = (cout + 16 * ct - 1) / (16 * ct) * 16 * ct;
+    Tensor b = at::zeros({npad}, like.options().dtype(at::kFloat).memory_format(c10::nullopt));
+    if (bias.has_value() && bias->defined()) b.narrow(0, 0, cout).copy_(bias->to(at::kFloat));
+    return b;
+}
+
+// fragment-packed [N, K] matrix (K = whole k-steps) on the device
+Tensor pack_matrix(const Tensor& w2d, int64_t n, int64_t k, int transpose, int dt, int ct, const Tensor& like) {
+    const int64_t bytes = maf_pack_w1x1_bytes((int)n, (int)k, transpose, dt, ct);
+    Tensor buf = at::empty({bytes}, like.options().dtype(at::kByte).memory_format(c10::nullopt));
+    Tensor wf = w2d.to(at::kFloat).contiguous();
+    check(maf_pack_w1x1(wf.data_ptr<float>(), (int)n, (int)k, transpose, dt, ct, buf.data_ptr(), stream_of(like)), "pack_w1x1");
+    return buf;
+}
+
+Tensor pack_3x3(const Tensor& w, bool transpose, int dt, int ct, const Tensor& like) {     // tap-major K, every tap padded to whole k-steps
+    const int64_t ks = dt == MAF_F16 ? 32 : 16;
+    Tensor m = transpose ? w.to(at::kFloat).permute({1, 2, 3, 0}) : w.to(at::kFloat).permute({0, 2, 3, 1});      // [N, 3, 3, K]
+    const int64_t n = m.size(0), k = m.size(3), kp = (k + ks - 1) / ks * ks;
+    Tensor big = at::constant_pad_nd(m, {0, kp - k}).reshape({n, 9 * kp}).contiguous();
+    return pack_matrix(big, n, 9 * kp, 0, dt, ct, like);
+}
+
+void fill_src(maf_op_t& op, const Tensor& x, int mode = MAF_SRC_DIRECT) {
+    op.nsrc = 1;
+    op.src[0].ptr = x.data_ptr(); op.src[0].C = (int)x.size(1); op.src[0].stride = (int)x.stride(3); op.src[0].coff = 0; op.src[0].mode = mode;
+}
+
+Tensor conv_generic(const Tensor& x_in, const Tensor& wp, const Tensor& bias, int kind, int64_t cout, int64_t Ho, int64_t Wo, int64_t Hin, int64_t Win, int act,
+                    int pt, int ct) {
+    Tensor x = x_in;
+    const int dt = dtype_of(x);
+    Tensor out = at::empty({x.size(0), cout, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    maf_op_t op = {};
+    op.kind = kind; op.dtype = dt; op.in_dtype = dt; op.act = act;
+    op.B = (int)x.size(0); op.H = (int)Ho; op.W = (int)Wo; op.Hin = (int)Hin; op.Win = (int)Win; op.Cin = (int)x.size(1); op.Cout = (int)cout;
+    fill_src(op, x);
+    op.out = out.data_ptr(); op.out_stride = (int)out.stride(3); op.out_coff = 0;
+    op.tile_p = pt; op.tile_c = ct;
+    op.w = wp.data_ptr(); op.bias = bias.data_ptr<float>();
+    check(maf_op_launch(&op, stream_of(x)), "conv launch");
+    return out;
+}
+
+Tensor pad_channels8(const Tensor& x) {            // a 3-channel image for kernels that read 16-byte channel chunks
+    const int64_t c = x.size(1), extra = (8 - c % 8) % 8;
+    if (!extra) return x;
+    return at::constant_pad_nd(x, {0, 0, 0, 0, 0, extra}).contiguous(at::MemoryFormat::ChannelsLast);
+}
+
+Tensor conv1x1_bias_act(const Tensor& x_in, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act) {
+    Tensor x = pad_channels8(nhwc(x_in));
+    TORCH_CHECK(w.dim() == 4 && w.size(2) == 1 && w.size(3) == 1 && w.size(1) == x_in.size(1), "conv1x1_bias_act: w must be [Cout, Cin, 1, 1]");
+    const int dt = dtype_of(x);
+    const int64_t cout = w.size(0), cin = x.size(1), co = (cout + 3) / 4 * 4;
+    Tensor w2 = w.reshape({cout, w.size(1)}).to(at::kFloat);
+    if (cin != w.size(1) || co != cout) w2 = at::constant_pad_nd(w2, {0, cin - w.size(1), 0, co - cout});
+    auto [pt, ct] = tile_for(co, x.size(0) * x.size(2) * x.size(3));
+    Tensor wp = pack_matrix(w2, co, cin, 0, dt, ct, x);
+    Tensor out = conv_generic(x, wp, padded_bias(bias, cout, ct, x), MAF_OP_CONV1X1, co, x.size(2), x.size(3), 0, 0, (int)act, pt, ct);
+    return co == cout ? out : out.narrow(1, 0, cout);
+}
+
+Tensor conv1x1_dgrad(const Tensor& dy_in, const Tensor& w) {       // dX = dY . W
+    Tensor dy = nhwc(dy_in);
+    const int dt = dtype_of(dy);
+    const int64_t cout = w.size(0), cin = w.size(1), mult = dt == MAF_F16 ? 8 : 4, kk = (cout + mult - 1) / mult * mult;
+    Tensor w2 = w.reshape({cout, cin}).to(at::kFloat);
+    if (kk != cout) {                                               // zero-pad the reduction dim to whole 16-byte chunks
+        dy = at::constant_pad_nd(dy, {0, 0, 0, 0, 0, kk - cout}).contiguous(at::MemoryFormat::ChannelsLast);
+        w2 = at::constant_pad_nd(w2, {0, 0, 0, kk - cout});
+    }
+    const int64_t ci = (cin + 3) / 4 * 4;
+    auto [pt, ct] = tile_for(ci, dy.size(0) * dy.size(2) * dy.size(3));
+    if (ci != cin) w2 = at::constant_pad_nd(w2, {0, ci - cin});
+    Tensor wp = pack_matrix(w2, kk, ci, 1, dt, ct, dy);
+    Tensor out = conv_generic(dy, wp, padded_bias(c10::nullopt, ci, ct, dy), MAF_OP_CONV1X1, ci, dy.size(2), dy.size(3), 0, 0, MAF_ACT_NONE, pt, ct);
+    return ci == cin ? out : out.narrow(1, 0, cin);
+}
+
+Tensor conv3x3s2_bias_act(const Tensor& x_in, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act) {
+    Tensor x = pad_channels8(nhwc(x_in));
+    TORCH_CHECK(w.dim() == 4 && w.size(2) == 3 && w.size(3) == 3 && w.size(1) == x_in.size(1), "conv3x3s2_bias_act: w must be [Cout, Cin, 3, 3]");
+    TORCH_CHECK(w.size(0) % 2 == 0, "conv3x3s2_bias_act: even Cout");
+    const int dt = dtype_of(x);
+    const int64_t cout = w.size(0), H = x.size(2), W = x.size(3), Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    Tensor wk = x.size(1) != w.size(1) ? at::constant_pad_nd(w, {0, 0, 0, 0, 0, x.size(1) - w.size(1)}) : w;
+    auto [pt, ct] = tile_for(cout, x.size(0) * Ho * Wo);
+    return conv_generic(x, pack_3x3(wk, false, dt, ct, x), padded_bias(bias, cout, ct, x), MAF_OP_CONV3X3S2, cout, Ho, Wo, H, W, (int)act, pt, ct);
+}
+
+Tensor conv3x3s2_dgrad(const Tensor& dy_in, const Tensor& w, int64_t H, int64_t W) {
+    Tensor dy = nhwc(dy_in);
+    const int dt = dtype_of(dy);
+    const int64_t cin = w.size(1), ci = (cin + 7) / 8 * 8;
+    Tensor wk = ci != cin ? at::constant_pad_nd(w, {0, 0, 0, 0, 0, ci - cin}) : w;
+    auto [pt, ct] = tile_for(ci, dy.size(0) * H * W, true);
+    Tensor out = conv_generic(dy, pack_3x3(wk, true, dt, ct, dy), padded_bias(c10::nullopt, ci, ct, dy), MAF_OP_CONV3X3S2_DGRAD, ci, H, W, dy.size(2), dy.size(3), MAF_ACT_NONE, pt, ct);
+    return ci == cin ? out : out.narrow(1, 0, cin);
+}
+
+Tensor conv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t ksize, int64_t stride) {     // fp32 dW [Cout, Cin, k, k]
+    Tensor x = pad_channels8(nhwc(x_in)), dy = nhwc(dy_in);
+    TORCH_CHECK(x.scalar_type() == at::kHalf && dy.scalar_type() == at::kHalf, "conv_wgrad: fp16 activations and gradients (the fp32 parity mode uses the framework's GEMM)");
+    const int64_t cout = dy.size(1), co = (cout + 7) / 8 * 8;
+    if (co != cout) dy = at::constant_pad_nd(dy, {0, 0, 0, 0, 0, co - cout}).contiguous(at::MemoryFormat::ChannelsLast);
+    Tensor dw = at::zeros({co, x.size(1), ksize, ksize}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
+    check(maf_conv_wgrad(x.data_ptr(), (int)x.stride(3), dy.data_ptr(), (int)dy.stride(3), (int)x.size(0), (int)dy.size(2), (int)dy.size(3), (int)x.size(2), (int)x.size(3),
+                         (int)x.size(1), (int)co, (int)ksize, (int)stride, MAF_F16, dw.data_ptr<float>(), stream_of(x)), "conv_wgrad");
+    return dw.narrow(0, 0, cout).narrow(1, 0, x_in.size(1));
+}
+
+Tensor dw_launch(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act, int flip) {
+    const int dt = dtype_of(x);
+    const int64_t c = x.size(1), k = w.size(3);
+    TORCH_CHECK(w.size(0) == c && w.size(1) == 1 && w.size(2) == k && (k == 3 || k == 5 || k == 7 || k == 9), "dwconv: w must be [C, 1, k, k], k in {3,5,7,9}");
+    Tensor wf = w.reshape({c, k * k}).to(at::kFloat).contiguous();
+    Tensor wp = at::empty({c * k * k * (dt == MAF_F16 ? 2 : 4)}, x.options().dtype(at::kByte).memory_format(c10::nullopt));
+    check(maf_pack_dw(wf.data_ptr<float>(), (int)c, (int)k, flip, dt, wp.data_ptr(), stream_of(x)), "pack_dw");
+    Tensor b = at::zeros({c}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
+    if (bias.has_value() && bias->defined()) b.copy_(bias->to(at::kFloat));
+    Tensor out = at::empty_like(x, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    maf_op_t op = {};
+    op.kind = MAF_OP_DWCONV; op.dtype = dt; op.in_dtype = dt; op.act = (int)act;
+    op.B = (int)x.size(0); op.H = (int)x.size(2); op.W = (int)x.size(3); op.Cin = (int)c; op.Cout = (int)c; op.ksize = (int)k;
+    fill_src(op, x);
+    op.out = out.data_ptr(); op.out_stride = (int)out.stride(3);
+    op.w = wp.data_ptr(); op.bias = b.data_ptr<float>();
+    check(maf_op_launch(&op, stream_of(x)), "dwconv launch");
+    return out;
+}
+
+Tensor dwconv_bias_act(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act) { return dw_launch(nhwc(x), w, bias, act, 0); }
+Tensor dwconv_dgrad(const Tensor& dy, const Tensor& w) { return dw_launch(nhwc(dy), w, c10::nullopt, MAF_ACT_NONE, 1); }      // correlation with the flipped kernel
+
+Tensor dwconv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t k) {
+    Tensor x = nhwc(x_in), dy = nhwc(dy_in);
+    const int64_t c = x.size(1), reps = 32;
+    Tensor dw = at::zeros({reps, c, k * k}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
+    check(maf_dw_wgrad(x.data_ptr(), (int)x.stride(3), dy.data_ptr(), (int)dy.stride(3), (int)x.size(0), (int)x.size(2), (int)x.size(3), (int)c, (int)k, dtype_of(x),
+                       dw.data_ptr<float>(), (int)reps, stream_of(x)), "dw_wgrad");
+    return dw.sum(0).reshape({c, 1, k, k});
+}
+
+// cls[l] [B, nc, H_l, W_l] (probabilities), reg[l] [B, 4*(reg_max+1), H_l, W_l] (logits), any dtype / layout -> pred fp32 [B, A, 5+nc]
+Tensor head_decode(at::TensorList cls, at::TensorList reg, at::ArrayRef<double> strides) {
+    TORCH_CHECK(cls.size() == 3 && reg.size() == 3 && strides.size() == 3, "head_decode: three detection levels");
+    std::vector<Tensor> c(3), r(3);
+    maf_op_t op = {};
+    op.kind = MAF_OP_DECODE; op.nsrc = 3;
+    int64_t A = 0;
+    const int64_t B = cls[0].size(0), nc = cls[0].size(1), rs = reg[0].size(1);
+    for (int l = 0; l < 3; ++l) {
+        TORCH_CHECK(cls[l].is_cuda() && cls[l].size(1) == nc && reg[l].size(1) == rs, "head_decode: level shapes");
+        c[l] = cls[l].to(at::kFloat).permute({0, 2, 3, 1}).contiguous();          // [B, H, W, nc] fp32
+        r[l] = reg[l].to(at::kFloat).permute({0, 2, 3, 1}).contiguous();
+        op.src[l].ptr = c[l].data_ptr(); op.reg[l] = r[l].data_ptr();
+        op.lvl_h[l] = (int)cls[l].size(2); op.lvl_w[l] = (int)cls[l].size(3); op.lvl_stride[l] = (float)strides[l];
+        A += cls[l].size(2) * cls[l].size(3);
+    }
+    op.B = (int)B; op.nc = (int)nc; op.reg_stride = (int)rs; op.reg_max = (int)(rs / 4 - 1);
+    Tensor pred = at::empty({B, A, 5 + nc}, c[0].options());
+    op.out = pred.data_ptr();
+    check(maf_op_launch(&op, stream_of(pred)), "decode launch");
+    return pred;
+}
+
+// -> rows [B, max_det, 6] (x1, y1, x2, y2, conf, cls; rows past counts[b] are unspecified), counts int32 [B]
+std::tuple<Tensor, Tensor> decode_nms(const Tensor& pred_in, double conf, double iou, bool agnostic, bool multi_label, int64_t max_det, at::OptionalIntArrayRef classes) {
+    TORCH_CHECK(conf >= 0 && conf <= 1, "conf_thresh must be in 0.0 to 1.0, however ", conf, " is provided.");
+    TORCH_CHECK(iou >= 0 && iou <= 1, "iou_thres must be in 0.0 to 1.0, however ", iou, " is provided.");
+    TORCH_CHECK(pred_in.is_cuda() && pred_in.dim() == 3, "decode_nms: prediction [B, N, 5+nc] on the HIP device");
+    Tensor pred = pred_in.to(at::kFloat).contiguous();
+    const int64_t B = pred.size(0), N = pred.size(1), nc = pred.size(2) - 5;
+    Tensor ws = at::empty({maf_nms_workspace_bytes((int)B, (int)N, (int)nc)}, pred.options().dtype(at::kByte));
+    Tensor rows = at::empty({B, max_det, 6}, pred.options()), idx = at::empty({B, max_det}, pred.options().dtype(at::kLong)), cnt = at::empty({B}, pred.options().dtype(at::kInt));
+    Tensor cls_t;
+    int ncls = 0;
+    if (classes.has_value()) {
+        std::vector<int32_t> v(classes->begin(), classes->end());
+        ncls = (int)v.size();
+        if (ncls) cls_t = at::tensor(v, at::kInt).to(pred.device());
+    }
+    check(maf_nms(pred.data_ptr<float>(), (int)B, (int)N, (int)nc, conf, iou, ncls ? cls_t.data_ptr<int32_t>() : nullptr, ncls, agnostic ? 1 : 0, multi_label ? 1 : 0,
+                  (int)max_det, ws.data_ptr(), ws.numel(), rows.data_ptr<float>(), idx.data_ptr<int64_t>(), cnt.data_ptr<int32_t>(), stream_of(pred)), "nms");
+    return {rows, cnt};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(mafyolo, m) {
+    m.def("conv1x1_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
+    m.def("conv3x3s2_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
+    m.def("dwconv_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
+    m.def("conv1x1_dgrad(Tensor dy, Tensor w) -> Tensor");
+    m.def("conv3x3s2_dgrad(Tensor dy, Tensor w, int H, int W) -> Tensor");
+    m.def("conv_wgrad(Tensor x, Tensor dy, int ksize, int stride) -> Tensor");
+    m.def("dwconv_dgrad(Tensor dy, Tensor w) -> Tensor");
+    m.def("dwconv_wgrad(Tensor x, Tensor dy, int k) -> Tensor");
+    m.def("head_decode(Tensor[] cls, Tensor[] reg, float[] strides) -> Tensor");
+    m.def("decode_nms(Tensor pred, float conf_thres, float iou_thres, bool agnostic, bool multi_label, int max_det, int[]? classes) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(mafyolo, CUDA, m) {       // the HIP device is the "CUDA" dispatch key of PyTorch-ROCm
+    m.impl("conv1x1_bias_act", &conv1x1_bias_act);
+    m.impl("conv3x3s2_bias_act", &conv3x3s2_bias_act);
+    m.impl("dwconv_bias_act", &dwconv_bias_act);
+    m.impl("conv1x1_dgrad", &conv1x1_dgrad);
+    m.impl("conv3x3s2_dgrad", &conv3x3s2_dgrad);
+    m.impl("conv_wgrad", &conv_wgrad);
+    m.impl("dwconv_dgrad", &dwconv_dgrad);
+    m.impl("dwconv_wgrad", &dwconv_wgrad);
+    m.impl("head_decode", &head_decode);
+    m.impl("decode_nms", &decode_nms);
+}

@@ -377,3 +377,24 @@ def test_integration_md_ctypes_stub_is_the_c_struct(built):
     assert C.sizeof(doc_op) == C.sizeof(lib.MafOp) == built.maf_op_size()
     for n, _ in lib.MafOp._fields_:
         assert getattr(doc_op, n).offset == getattr(lib.MafOp, n).offset, n
+
+
+def test_torch_custom_op_library_loads_and_declares_the_ops(built):
+    """SURVEY.md 8(b) / north_star: the hot path as PyTorch custom ops — torch.ops.load_library works, every op has its schema, and the fake
+    (meta) kernels trace without a device (no compute here)."""
+    from maf_yolo_amd import torch_ops
+    ops = torch_ops.load()
+    for name in torch_ops.OPS:
+        assert hasattr(ops, name), name
+    assert str(torch.ops.mafyolo.decode_nms.default._schema) == ("mafyolo::decode_nms(Tensor pred, float conf_thres, float iou_thres, bool agnostic, "
+                                                                  "bool multi_label, int max_det, int[]? classes) -> (Tensor, Tensor)")
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(2, 64, 9, 12, device="cuda", dtype=torch.float16)
+        y = ops.conv3x3s2_bias_act(x, torch.empty(32, 64, 3, 3, device="cuda"), None, 0)
+        assert y.shape == (2, 32, 5, 6) and y.dtype == torch.float16 and y.is_contiguous(memory_format=torch.channels_last)
+        assert ops.conv1x1_bias_act(x, torch.empty(80, 64, 1, 1, device="cuda"), torch.empty(80, device="cuda"), 3).shape == (2, 80, 9, 12)
+        p = ops.head_decode([torch.empty(2, 80, s, s, device="cuda") for s in (8, 4, 2)], [torch.empty(2, 68, s, s, device="cuda") for s in (8, 4, 2)], [8.0, 16.0, 32.0])
+        assert p.shape == (2, 84, 85) and p.dtype == torch.float32
+    with pytest.raises(Exception):                           # a CPU tensor has no kernel: there is no CPU fallback
+        ops.conv1x1_bias_act(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1), None, 0)
