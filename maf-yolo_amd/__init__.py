@@ -9,6 +9,7 @@ from .post import convert_to_coco_format, coco_rows  # noqa: F401
 from .checkpoint import load_checkpoint, reference_state_dict  # noqa: F401
 from .loss import ComputeLoss, task_aligned_assign  # noqa: F401
 from .streams import concurrent_streams  # noqa: F401
+from .eval_loop import EvalLoop  # noqa: F401
 from .layers import RepVGGBlock, UniRepLKNetBlock  # noqa: F401  (isinstance loops of evaler.py:101-109 stay harmless)
 
 

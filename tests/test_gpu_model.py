@@ -652,3 +652,49 @@ def test_twin_conv_launch_equals_two_launches(models, half):
             _close16(tuned.cpu().numpy(), outs[tw].cpu().numpy())
     assert outs[True, "n"] == outs[False, "n"] - 2
     assert torch.equal(outs[True], outs[False])
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_eval_loop_matches_the_reference_evaler_fixture(golden, fold):
+    """SURVEY.md 8(c) / VERDICT r1 missing #4: EvalLoop.predict_model — uint8 batch -> /255 -> model(imgs)[0] -> NMS(0.03, 0.65, multi_label) ->
+    COCO rows, with the reference's pre / inference / NMS timing split — against the rows the REFERENCE's own deploy model +
+    non_max_suppression + Evaler.convert_to_coco_format produced for the same seeded uint8 batches (tools/make_golden_eval.py, fp32 on the CPU).
+    fp32 engine: same images, categories and order; boxes within 5e-3 px of the rescaled coordinates (3-decimal rounding), scores within 2e-5."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_golden_eval as G
+    g = golden("eval_loop")
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0, cls_bias=-3.0))
+    m = m.to(DEV)
+    loop = M.EvalLoop(m, conf_thres=0.03, iou_thres=0.65, half=False, ids=G.COCO_IDS, fold_preprocess=fold)
+    res = loop.predict_model(G.batches())
+    assert len(res) == int(g["counts"].sum()) == 1500
+    assert [r["image_id"] for r in res] == g["image_id"].tolist()
+    same_cat = np.asarray([r["category_id"] for r in res]) == g["category_id"]
+    bbox = np.asarray([r["bbox"] for r in res]); score = np.asarray([r["score"] for r in res])
+    # rows whose scores tie to within fp32 noise may swap places: compare row-wise where the category agrees, and bound the rest
+    assert same_cat.mean() >= 0.995, same_cat.mean()
+    assert np.abs(bbox[same_cat] - g["bbox"][same_cat]).max() <= 5e-3 + 1e-5 * np.abs(g["bbox"]).max()
+    assert np.abs(score[same_cat] - g["score"][same_cat]).max() <= 2e-5
+    sp = loop.eval_speed()
+    assert set(sp) == {"pre-process", "inference", "NMS"} and all(v >= 0 for v in sp.values()) and loop.speed_result[0].item() == 5
+    # the benchmarked precision (half=True, the reference's --half): same loop, detections of the fp16 class
+    loop16 = M.EvalLoop(m, conf_thres=0.03, iou_thres=0.65, half=True, ids=G.COCO_IDS, fold_preprocess=fold)
+    res16 = loop16.predict_model(G.batches())
+    assert len(res16) == 1500
+    from test_gpu_fused_parity import match_detections       # same-class, IoU >= 0.95, |d score| <= 1e-2, one-to-one
+
+    def rows_of(img, ids_, cats, boxes, scores):
+        k = np.asarray(ids_) == img
+        bx = np.asarray(boxes)[k]
+        return np.concatenate([bx[:, :2], bx[:, :2] + bx[:, 2:], np.asarray(scores)[k][:, None], np.asarray(cats)[k][:, None].astype(np.float64)], 1)
+    matched = 0
+    for img in sorted(set(g["image_id"].tolist())):
+        ref_rows = rows_of(img, g["image_id"], g["category_id"], g["bbox"], g["score"])
+        got_rows = rows_of(img, [r["image_id"] for r in res16], [r["category_id"] for r in res16], [r["bbox"] for r in res16], [r["score"] for r in res16])
+        pairs, miss, extra = match_detections(got_rows, ref_rows)
+        matched += len(pairs)
+    print("fp16 eval loop: %d / 1500 reference rows matched" % matched)
+    assert matched >= 1460, matched                        # measured 1481: twice the misses
