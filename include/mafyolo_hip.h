@@ -184,11 +184,19 @@ void maf_engine_destroy(maf_engine_t* e);
  * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
  * break (nms.py:101-103) is dropped.  max_det <= 1024.
  */
+enum { MAF_NMS_FLOAT_THRESHOLD = 1 };    /* maf_nms_ex flags: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`),
+                                          * which is what yolov6/utils/nms.py:96 reaches when the reference runs on a GPU — instead of with the double
+                                          * (its CPU kernel, the default here and the rule of the oracle and of the golden fixtures).  The results differ
+                                          * only for a pair whose fp32 IoU equals fl32(iou_thres) exactly where fl32(iou_thres) > iou_thres (0.6, 0.7, ...). */
 int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc);
 int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
             const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,
             int32_t max_det, void* workspace, int64_t workspace_bytes,
             float* out_rows, int64_t* out_idx, int32_t* out_count, maf_stream_t stream);
+int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
+               const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,
+               int32_t max_det, void* workspace, int64_t workspace_bytes,
+               float* out_rows, int64_t* out_idx, int32_t* out_count, int32_t flags, maf_stream_t stream);
 
 /*
  * Training-side entry points.  The train-form graph keeps conv and BatchNorm apart

@@ -800,6 +800,14 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
                        const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,
                        int32_t max_det, void* workspace, int64_t workspace_bytes,
                        float* out_rows, int64_t* out_idx, int32_t* out_count, maf_stream_t stream) {
+    return maf_nms_ex(pred, B, N, nc, conf_thres, iou_thres, classes, n_classes, agnostic, multi_label, max_det, workspace, workspace_bytes,
+                      out_rows, out_idx, out_count, 0, stream);
+}
+
+extern "C" int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
+                          const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,
+                          int32_t max_det, void* workspace, int64_t workspace_bytes,
+                          float* out_rows, int64_t* out_idx, int32_t* out_count, int32_t flags, maf_stream_t stream) {
     MAF_REQUIRE(pred && workspace && out_rows && out_idx && out_count, "nms: null pointer");
     MAF_REQUIRE(B > 0 && N > 0 && nc > 0, "nms: bad shape");
     MAF_REQUIRE((long long)N * nc < (1ll << 32), "nms: N*nc must fit 32 bits");
@@ -812,9 +820,12 @@ extern "C" int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, doub
     a.pred = pred; a.B = B; a.N = N; a.nc = nc;
     a.conf = (float)conf_thres;            // torch compares the fp32 tensor against the scalar in fp32
     a.iou = iou_thres;
-    {   // smallest fp32 strictly above the (double) threshold, its predecessor, their midpoint
+    {   // smallest fp32 strictly above the threshold, its predecessor, their midpoint.  The threshold is the double the caller passed
+        // (torchvision's CPU kernel: `ovr > iou_threshold` with a double threshold) or, with MAF_NMS_FLOAT_THRESHOLD, that double rounded
+        // to fp32 first (torchvision's CUDA kernel takes `float iou_threshold`): the two differ only for a pair whose fp32 IoU equals
+        // fl32(thr) exactly AND fl32(thr) > thr (0.6, 0.7 ...: suppressed by the CPU rule, kept by the CUDA rule).
         float f = (float)iou_thres;
-        const float tf = ((double)f > iou_thres) ? f : nextafterf(f, INFINITY);
+        const float tf = ((double)f > iou_thres && !(flags & MAF_NMS_FLOAT_THRESHOLD)) ? f : nextafterf(f, INFINITY);
         const float pf = nextafterf(tf, -INFINITY);
         a.iou_m = ((double)tf + (double)pf) * 0.5;
         uint32_t bits; memcpy(&bits, &tf, 4);

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAF_HIP_LIB") or os.path.join(_HERE, "libmafyolo_hip.so")     # MAF_HIP_LIB: an instrumented build (make prof)
 
 F16, F32, U8 = 0, 1, 2
+NMS_FLOAT_THRESHOLD = 1
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_DIRECT, SRC_UP2, SRC_POOL2, SRC_SUB2 = 0, 1, 2, 3
 OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE, OP_BOTTLENECK, OP_CONV1DW, OP_HEADTAIL, OP_STEM2, OP_CONV3X3S2_DGRAD = range(11)
@@ -30,7 +31,7 @@ class MafOp(C.Structure):
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
-           "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_dw_wgrad", "maf_bottleneck_record_bytes", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
+           "maf_engine_run", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_ex", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_dw_wgrad", "maf_bottleneck_record_bytes", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
 _lib = None
@@ -67,6 +68,8 @@ def load():
     lib.maf_nms.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32,
                             C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p]
+    lib.maf_nms_ex.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.maf_nms_debug.argtypes = [C.POINTER(C.c_uint64)]
     lib.maf_conv1x1_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.maf_conv_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_int32] * 10 + [C.c_void_p, C.c_void_p]

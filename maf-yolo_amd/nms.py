@@ -15,6 +15,12 @@ from . import lib
 
 _ws = {}
 _side = {}
+# Which torchvision.ops.nms kernel the IoU comparison follows (yolov6/utils/nms.py:96 calls whichever matches the tensor's device):
+#   "cpu"  (default) fp32 IoU > double threshold  — the rule of the oracle, of the golden fixtures and of an evaluation on the CPU
+#   "cuda"           fp32 IoU > fl32(threshold)   — torchvision's GPU kernel takes `float iou_threshold`; differs from "cpu" only for a pair whose
+#                    fp32 IoU equals fl32(thr) exactly with fl32(thr) > thr (0.6, 0.7 ...: the CPU rule suppresses it, the CUDA rule keeps it)
+# Per call: non_max_suppression(..., iou_rule="cuda"); process-wide: maf_yolo_amd.nms.IOU_RULE = "cuda".
+IOU_RULE = "cpu"
 
 
 def _workspace(dev, st, B, N, nc, need):
@@ -30,7 +36,7 @@ def _workspace(dev, st, B, N, nc, need):
     return ws
 
 
-def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, stream=None):
+def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, stream=None, iou_rule=None):
     """Device-side result without the host sync: (rows [B,max_det,6], idx int64 [B,max_det], count int32 [B]).
     Launches on `stream` (a torch.cuda.Stream) or on the current stream."""
     assert 0 <= conf_thres <= 1, f'conf_thresh must be in 0.0 to 1.0, however {conf_thres} is provided.'
@@ -58,9 +64,12 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             if classes is not None:
                 cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
                 ncls = cls_t.numel()
-            lib.check(L.maf_nms(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
-                                cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
-                                int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(), st.cuda_stream))
+            rule = iou_rule or IOU_RULE
+            assert rule in ("cpu", "cuda"), "iou_rule: 'cpu' (double threshold) or 'cuda' (float threshold)"
+            lib.check(L.maf_nms_ex(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
+                                   cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
+                                   int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                   lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0, st.cuda_stream))
         if stream is not None and pred is prediction:
             pred.record_stream(st)                    # a caller-owned tensor read on a stream it was not allocated on
     return rows, idx, cnt
@@ -83,7 +92,7 @@ class NmsHandle:
         return out
 
 
-def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, side=None):
+def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, side=None, iou_rule=None):
     """Same arguments as non_max_suppression, but the kernels go to a side stream ordered after the current one and
     the call returns at once; `handle.result()` gives the reference's list of tensors.  A serving loop calls this for
     batch i, launches the forward of batch i+1, then collects batch i: the (latency-bound, 32-workgroup) NMS of one
@@ -96,15 +105,15 @@ def non_max_suppression_async(prediction, conf_thres=0.25, iou_thres=0.45, class
             side = _side[dev.index] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     prediction.record_stream(side)                         # the caching allocator must not hand this block out again before the NMS has read it
-    rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, stream=side)
+    rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, stream=side, iou_rule=iou_rule)
     ev = torch.cuda.Event()
     ev.record(side)
     return NmsHandle(rows, idx, cnt, ev, keep=prediction)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-                        max_det=300, return_index=False):
-    rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
+                        max_det=300, return_index=False, iou_rule=None):
+    rows, idx, cnt = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, iou_rule=iou_rule)
     counts = cnt.tolist()                              # the only device->host sync
     out = [rows[b, :n] for b, n in enumerate(counts)]
     if return_index:

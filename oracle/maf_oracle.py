@@ -487,8 +487,9 @@ def predict(dw, scale, x):
 # --------------------------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------------------------
-def greedy_nms(boxes, scores, iou_threshold):
+def greedy_nms(boxes, scores, iou_threshold, float_threshold=False):
     """Restatement of torchvision.ops.nms' CPU kernel (called at nms.py:96) — PARITY UNPINNED.
+    float_threshold=True: the comparison of torchvision's CUDA kernel instead (`float iou_threshold`: fp32 IoU > fl32(threshold)).
 
     boxes [n,4] xyxy fp32, scores [n] fp32. Stable descending sort of the scores (ties: lower index
     first), areas (x2-x1)*(y2-y1) in fp32, intersection with max(0,.) clamps, suppress j when
@@ -504,7 +505,7 @@ def greedy_nms(boxes, scores, iou_threshold):
     areas = (x2 - x1) * (y2 - y1)
     suppressed = np.zeros(n, dtype=bool)
     keep = []
-    thr = float(iou_threshold)
+    thr = float(np.float32(iou_threshold)) if float_threshold else float(iou_threshold)
     for pos in range(n):
         i = order[pos]
         if suppressed[i]:
@@ -530,7 +531,7 @@ def greedy_nms_torch(boxes, scores, iou_threshold):
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                        multi_label=False, max_det=300, return_index=False):
+                        multi_label=False, max_det=300, return_index=False, float_threshold=False):
     """NumPy restatement of yolov6/utils/nms.py:31-105 (time limit :101-103 dropped).
 
     prediction [B,N,5+nc] fp32.  Returns list of [n_i,6] fp32 arrays (x1,y1,x2,y2,conf,cls).
@@ -573,7 +574,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             o = np.argsort(-rows[:, 4].astype(np.float64), kind="stable")[:max_nms]
             rows, flat = rows[o], flat[o]
         off = rows[:, 5:6] * np.float32(0 if agnostic else max_wh)              # nms.py:94
-        keep = greedy_nms(rows[:, :4] + off, rows[:, 4], iou_thres)[:max_det]   # nms.py:95-98
+        keep = greedy_nms(rows[:, :4] + off, rows[:, 4], iou_thres, float_threshold)[:max_det]   # nms.py:95-98
         out.append(rows[keep]); idx_out.append(flat[keep])
     return (out, idx_out) if return_index else out
 

@@ -698,3 +698,35 @@ def test_eval_loop_matches_the_reference_evaler_fixture(golden, fold):
         matched += len(pairs)
     print("fp16 eval loop: %d / 1500 reference rows matched" % matched)
     assert matched >= 1460, matched                        # measured 1481: twice the misses
+
+
+@pytest.mark.parametrize("thr,frac", [(0.6, (3, 5)), (0.3, (3, 10)), (0.7, (7, 10)), (0.45, (9, 20))])
+def test_nms_iou_rule_cpu_vs_cuda_kernel_of_torchvision(thr, frac):
+    """on a GPU the reference reaches torchvision's CUDA nms kernel (yolov6/utils/nms.py:96), which compares the fp32 IoU with
+    a FLOAT threshold; its CPU kernel (the oracle's and the fixtures' rule, the default here) compares with the double.  They differ exactly
+    when the fp32 IoU equals fl32(thr) and fl32(thr) > thr: 0.6 and 0.3 (a pair at IoU 3/5 or 3/10 is suppressed by the CPU rule, kept by the
+    CUDA rule); 0.7 and 0.45 round down, no difference.  Both rules are selectable (iou_rule=) and both match the oracle's restatement."""
+    num, den = frac
+    # box B nested in box A with area ratio num/den: IoU = num/den exactly, fp32 quotient = fl32(thr)
+    A = [50.0, 50.0, 50.0 + den, 60.0]; Bx = [50.0, 50.0, 50.0 + num, 60.0]
+    rs = np.random.RandomState(int(thr * 100))
+    n, nc = 300, 2
+    xy = rs.randint(0, 12, (n, 2)).astype(np.float32) * 4 + 200
+    wh = rs.randint(1, 7, (n, 2)).astype(np.float32) * 8
+    boxes = np.concatenate([xy, xy + wh], 1)
+    boxes[0], boxes[1] = A, Bx
+    xywh = np.concatenate([(boxes[:, :2] + boxes[:, 2:]) / 2, boxes[:, 2:] - boxes[:, :2]], 1).astype(np.float32)
+    cls = (0.2 + 0.7 * rs.rand(n, nc)).astype(np.float32)
+    cls[0] = [0.99, 0.001]; cls[1] = [0.98, 0.001]
+    pred = np.concatenate([xywh, np.ones((n, 1), np.float32), cls], 1)[None]
+    t = torch.from_numpy(pred).to(DEV)
+    res = {}
+    for rule in ("cpu", "cuda"):
+        got, gidx = M.non_max_suppression(t, 0.25, thr, multi_label=True, max_det=1000, return_index=True, iou_rule=rule)
+        want, widx = O.non_max_suppression(pred, 0.25, thr, multi_label=True, max_det=1000, return_index=True, float_threshold=(rule == "cuda"))
+        assert np.array_equal(gidx[0].cpu().numpy(), widx[0]) and np.array_equal(got[0].cpu().numpy(), want[0]), rule
+        res[rule] = set(gidx[0].cpu().tolist())
+    b_flat = 1 * nc + 0                                        # candidate (box 1, class 0)
+    differs = float(np.float32(thr)) > thr
+    assert (b_flat in res["cuda"]) and ((b_flat in res["cpu"]) != differs)
+    assert (res["cpu"] != res["cuda"]) == differs or not differs
