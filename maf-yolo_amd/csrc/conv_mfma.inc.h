@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         // k-step's CT fragments once (global -> registers during the previous step's MFMAs -> LDS, double-buffered, one
         // barrier per step) and every wave reads them with ds_read_b128; activations keep a private, deep register ring.
         extern __shared__ __attribute__((aligned(16))) unsigned char lb_raw[];
-        frag_t* lb = reinterpret_cast<frag_t*>(lb_raw);                   // [2][CT * 64]
+        frag_t* lb = reinterpret_cast<frag_t*>(lb_raw);                   // [3][CT * 64]: THREE buffers (see the loop)
         constexpr int NV = (CT * 64 + 255) / 256;
         const frag_t* wsrc = reinterpret_cast<const frag_t*>(w_all) + ((size_t)(n_tile * CT) * total_steps) * 64;
         constexpr int WD = 3;                                             // weight fragments leave global memory WD k-steps before their MFMAs
@@ -300,13 +300,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         constexpr int NS = 6;                                             // activation loads run NS - 1 k-steps ahead (few, long wave-chains must keep many bytes in flight)
         static_assert(NS % WD == 0, "ring indices are static");
         frag_t bst[NS][PT];
+        // Pipeline of a k-step s (one barrier per step):  weights(s + 2) registers -> LDS buffer (s + 2) % 3   |   fragments of step s + 1 read
+        // from buffer (s + 1) % 3 into registers (published by the previous barrier)   |   MFMAs of step s on fragments that are ALREADY in
+        // registers.  With two buffers the fragment read sat between the barrier and the MFMAs that need it: half of the MFMAs of the
+        // <1,4,*> instantiations (the 20x20 / 40x40 layers: 22 launches per forward) waited a full LDS round trip (`s_waitcnt lgkmcnt(0)`).
 #pragma unroll
         for (int s = 0; s < WD; ++s) gload(min(s, last_step), wreg[s]);
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s) load_b(s, bst[s]);
         lstore(0, wreg[0]);
+        lstore(1, wreg[1]);
         gload(min(WD, last_step), wreg[0]);
+        gload(min(WD + 1, last_step), wreg[1]);
         __syncthreads();
+        frag_t wf[2][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) wf[0][ct] = lb[ct * 64 + lane];                       // fragments of step 0
         // the trip count is rounded up to whole rings: padding steps multiply zero activations (zero page) with re-read weights,
         // so the loop body has no branch and every s_waitcnt counts exactly the loads that may stay in flight
         for (int step0 = 0; step0 < total_steps; step0 += NS) {
@@ -314,13 +323,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int u = 0; u < NS; ++u) {
                 const int step = step0 + u;
                 load_b(step + NS - 1, bst[(u + NS - 1) % NS]);
-                const frag_t* wl = lb + (step & 1) * (CT * 64) + lane;
-                frag_t wf[CT];
+                const frag_t* wl = lb + ((step + 1) % 3) * (CT * 64) + lane;                 // next step's fragments: in flight during this step's MFMAs
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wf[ct] = wl[ct * 64];
-                mma_stage(bst[u], wf);
-                lstore((step + 1) & 1, wreg[(u + 1) % WD]);              // weights of step + 1, loaded WD - 1 steps ago
-                gload(min(step + 1 + WD, last_step), wreg[(u + 1) % WD]);
+                for (int ct = 0; ct < CT; ++ct) wf[(u + 1) & 1][ct] = wl[ct * 64];
+                mma_stage(bst[u], wf[u & 1]);
+                lstore((step + 2) % 3, wreg[(u + 2) % WD]);                                   // weights of step + 2 (their buffer was last read two steps ago)
+                gload(min(step + 2 + WD, last_step), wreg[(u + 2) % WD]);
                 __syncthreads();
             }
         }
@@ -443,7 +451,7 @@ int launch_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
 template <int PT, int CT, int VAR>
 int launch_lb(const ConvArgs& a, hipStream_t s) {
     const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
-    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true>), dim3(grid, a.twin ? 2 : 1), dim3(256), 2 * CT * 1024, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true>), dim3(grid, a.twin ? 2 : 1), dim3(256), 3 * CT * 1024, s, a);
     return maf_check_hip(hipGetLastError(), "conv_mfma (LDS-shared weights) launch");
 }
 
