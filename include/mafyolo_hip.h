@@ -100,7 +100,7 @@ typedef struct {
  *                   tile_p = tile rows (0 / 8, or 4), tile_k = workgroups (0 = default, persistent).
  * MAF_OP_HEADTAIL   replaces, for ONE level, cls_conv_s + cls_pred + sigmoid and reg_conv_s + reg_pred (Head_DepthUni, common.py:1288-1336:
  *                   Conv.forward_fuse, nn.Conv2d) and that level's share of the Detect_yaml eval branch (yolo.py:355-396) in one launch.
- *                   src[0] / src[1] = inputs of cls_conv_s / reg_conv_s (C = Cin = head width: 64, 128 or 192); w / aux[0] = weight
+ *                   src[0] / src[1] = inputs of cls_conv_s / reg_conv_s (C = Cin = head width: 64, 128, 192 — weights LDS-resident — or 256, 384 — weights streamed from L2); w / aux[0] = weight
  *                   records of the cls / reg branch, maf_head_tail_record_bytes(Cin) bytes each (maf-yolo_amd/pack.py:pack_head_tail);
  *                   out = pred fp32 [B, A, 85] (supplied per run like DECODE's); Hin = first anchor of the level, Win = A (anchors
  *                   per image), lvl_stride[0] = stride; nc = 80, reg_max = 16; fp16 only.  tile_k = units per wave (0 = auto).

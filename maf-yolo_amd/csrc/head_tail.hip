@@ -11,9 +11,21 @@
 // 16-channel tile t — which IS the A-operand layout (pixel row, 8 consecutive k-slots per lane) of the second GEMM once the second
 // weight matrix is packed with its K axis in that order (maf-yolo_amd/pack.py:pack_head_tail).  Weights of a branch sit in LDS for the
 // whole workgroup; the epilogue goes through a wave-private LDS tile so the prediction rows are written as full contiguous runs.
+// Head widths 256 and 384 (P5 of s, every level of m): a branch's weights (172 / 356 KB) do not fit the LDS, so those instantiations
+// (WLDS = false) read the same fragment records straight from global memory — every wave streams them once per 16-pixel unit out of the
+// L2, where they stay resident (the records of a level total <= 0.7 MB).
 #include "maf_common.h"
+#include <type_traits>
 
 namespace {
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void ht_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ht_static_for<N, I + 1>(f);
+    }
+}
 
 constexpr int NT2 = 5;                 // 80 output columns of the second GEMM (80 classes; 68 DFL logits + zero padding)
 constexpr int NO = 85, NC = 80, NR = 68;
@@ -31,21 +43,49 @@ template <int C, int PT>
 __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const HtArgs a) {
     constexpr int KS = C / 32, T1 = C / 16;
     constexpr int W1B = C * C * 2, W2B = 80 * C * 2;
-    __shared__ __attribute__((aligned(16))) char s_w[W1B + W2B + C * 4 + 80 * 4];
+    constexpr bool WLDS = C <= 192;                                               // the record fits the LDS
+    constexpr int CHB = KS * 1024, CHV = (CHB / 16 + 255) / 256, NCH = T1 + NT2;     // chunked instantiations: bytes per chunk, 16-byte pieces per thread, chunks
+    __shared__ __attribute__((aligned(16))) char s_w[WLDS ? W1B + W2B + C * 4 + 80 * 4 : 2 * CHB + C * 4 + 80 * 4];
     __shared__ __attribute__((aligned(16))) float s_stage[4][16 * NC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, n = lane & 15;
     const int br = blockIdx.y;
-    {
+    if constexpr (WLDS) {
         const uint4* src = reinterpret_cast<const uint4*>(a.rec[br]);
         uint4* dst = reinterpret_cast<uint4*>(s_w);
         constexpr int NV = (W1B + W2B + C * 4 + 80 * 4) / 16;
         for (int i = tid; i < NV; i += 256) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
+    // chunked instantiations: the fragment stream of the record (W1 tiles, then W2 tiles: NCH chunks of CHB bytes, contiguous) goes through
+    // s_w[0 .. 2 CHB); the biases sit behind it
+    const uint4* const rec16 = reinterpret_cast<const uint4*>(a.rec[br]);
+    auto chunk_load = [&](int c, uint4 (&r)[CHV]) {
+#pragma unroll
+        for (int v = 0; v < CHV; ++v) {
+            const int i = tid + v * 256;
+            if (i < CHB / 16) r[v] = rec16[(size_t)c * (CHB / 16) + i];
+        }
+    };
+    auto chunk_store = [&](int buf, const uint4 (&r)[CHV]) {
+#pragma unroll
+        for (int v = 0; v < CHV; ++v) {
+            const int i = tid + v * 256;
+            if (i < CHB / 16) reinterpret_cast<uint4*>(s_w + buf * CHB)[i] = r[v];
+        }
+    };
+    if constexpr (!WLDS) {
+        uint4 r0[CHV];
+        chunk_load(0, r0);
+        chunk_store(0, r0);
+        const uint4* bsrc = reinterpret_cast<const uint4*>(a.rec[br] + W1B + W2B);
+        for (int i = tid; i < (C * 4 + 80 * 4) / 16; i += 256) reinterpret_cast<uint4*>(s_w + 2 * CHB)[i] = bsrc[i];
+        __syncthreads();
+    }
+    constexpr int BOFF = WLDS ? W1B + W2B : 2 * CHB;
     const half8_t* w1 = reinterpret_cast<const half8_t*>(s_w);
     const half8_t* w2 = reinterpret_cast<const half8_t*>(s_w + W1B);
-    const f32x4_t* b1 = reinterpret_cast<const f32x4_t*>(s_w + W1B + W2B);
-    const float* b2 = reinterpret_cast<const float*>(s_w + W1B + W2B + C * 4);
+    const f32x4_t* b1 = reinterpret_cast<const f32x4_t*>(s_w + BOFF);
+    const float* b2 = reinterpret_cast<const float*>(s_w + BOFF + C * 4);
     float bias2[NT2];
 #pragma unroll
     for (int t = 0; t < NT2; ++t) bias2[t] = b2[16 * t + n];
@@ -67,12 +107,16 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
     load_x(unit0);
     for (int it = 0; it < a.iters; ++it) {
         const int unit = unit0 + it * 4;
+        const int par = WLDS ? 0 : (it * NCH) & 1;                                // chunked: chunk c of this unit sits in buffer (c + par) & 1 (NCH is odd)
         // ---- GEMM 1 (transposed): acc1[p][t] lane (G, n) = channels 16t + 4G + r of pixel n
-        f32x4_t acc1[PT][T1];
+        constexpr int T1R = WLDS ? T1 : 1;                                        // chunked instantiations turn every pair of tiles into its fragment at once
+        f32x4_t acc1[PT][T1R];
+        half8_t a2[PT][KS];
 #pragma unroll
         for (int p = 0; p < PT; ++p)
 #pragma unroll
-            for (int t = 0; t < T1; ++t) acc1[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T1R; ++t) acc1[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (WLDS) {
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
@@ -81,9 +125,45 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
                 for (int p = 0; p < PT; ++p) acc1[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc1[p][t], 0, 0, 0);
             }
+        } else {
+            // the record does not fit the LDS: its T1 + NT2 chunks (the fragments of one 16-channel tile: KS KiB) pass through two LDS
+            // buffers — chunk c + 1 travels global -> registers -> LDS while chunk c is multiplied, one barrier per chunk
+            f32x4_t even[PT];
+            ht_static_for<T1>([&](auto idx) {
+                constexpr int t = decltype(idx)::value;
+                uint4 nxt[CHV];
+                chunk_load(t + 1, nxt);
+                const half8_t* wc = reinterpret_cast<const half8_t*>(s_w + ((t + par) & 1) * CHB);
+                f32x4_t acc[PT];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const half8_t wa = wc[ks * 64 + lane];
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc[p], 0, 0, 0);
+                }
+                if constexpr (t % 2 == 0) {
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) even[p] = acc[p];
+                } else {                                                           // tiles 2j, 2j + 1 -> A fragment j of GEMM 2 (same rounding points as below)
+                    constexpr int j = t / 2;
+                    const f32x4_t bl = b1[4 * (2 * j) + G], bh = b1[4 * (2 * j + 1) + G];
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a2[p][j][r] = (half_t)maf_act<MAF_ACT_SILU>(even[p][r] + bl[r]);
+                            a2[p][j][4 + r] = (half_t)maf_act<MAF_ACT_SILU>(acc[p][r] + bh[r]);
+                        }
+                }
+                chunk_store((t + 1 + par) & 1, nxt);
+                __syncthreads();
+            });
+        }
         if (it + 1 < a.iters) load_x(unit + 4);                                   // next unit's activations fly during the rest
         // ---- bias + SiLU -> fp16: the A fragments of GEMM 2 (k-slots q < 4 from tile 2j, q >= 4 from tile 2j + 1)
-        half8_t a2[PT][KS];
+        if constexpr (WLDS)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             const f32x4_t bl = b1[4 * (2 * j) + G], bh = b1[4 * (2 * j + 1) + G];
@@ -102,6 +182,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
         for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc2[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (WLDS) {
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
 #pragma unroll
@@ -110,6 +191,22 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
                 for (int p = 0; p < PT; ++p) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
             }
+        } else {
+            ht_static_for<NT2>([&](auto idx) {
+                constexpr int t = decltype(idx)::value, c = T1 + t;
+                uint4 nxt[CHV];
+                chunk_load(c + 1 < NCH ? c + 1 : 0, nxt);                       // after the last chunk: chunk 0 again, for the next unit
+                const half8_t* wc = reinterpret_cast<const half8_t*>(s_w + ((c + par) & 1) * CHB);
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const half8_t wb = wc[j * 64 + lane];
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
+                }
+                chunk_store((c + 1 + par) & 1, nxt);
+                __syncthreads();
+            });
+        }
         // ---- epilogue: through the wave's LDS tile to whole prediction rows
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
@@ -177,7 +274,7 @@ extern "C" int64_t maf_head_tail_record_bytes(int32_t C) { return (int64_t)C * C
 
 int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "head_tail: fp16 only");
-    MAF_REQUIRE(op->Cin == 128 || op->Cin == 192 || op->Cin == 64, "head_tail: head width must be 64, 128 or 192");
+    MAF_REQUIRE(op->Cin == 128 || op->Cin == 192 || op->Cin == 64 || op->Cin == 256 || op->Cin == 384, "head_tail: head width must be 64, 128, 192, 256 or 384");
     MAF_REQUIRE(op->nc == 80 && op->reg_max == 16, "head_tail: 80 classes and reg_max 16");
     MAF_REQUIRE(op->nsrc == 2 && op->src[0].ptr && op->src[1].ptr && op->w && op->aux[0] && op->out, "head_tail: null pointer");
     MAF_REQUIRE(op->B > 0 && op->H > 0 && op->W > 0 && (long long)op->B * op->H * op->W < (1ll << 31), "head_tail: bad dims");
@@ -199,7 +296,9 @@ int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
     switch (op->Cin) {
         case 64: hipLaunchKernelGGL((head_tail_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
         case 128: hipLaunchKernelGGL((head_tail_kernel<128, 2>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((head_tail_kernel<192, 1>), grid, dim3(256), 0, s, a); break;
+        case 192: hipLaunchKernelGGL((head_tail_kernel<192, 1>), grid, dim3(256), 0, s, a); break;
+        case 256: hipLaunchKernelGGL((head_tail_kernel<256, 1>), grid, dim3(256), 0, s, a); break;      // weights streamed from L2 (no LDS copy)
+        default: hipLaunchKernelGGL((head_tail_kernel<384, 1>), grid, dim3(256), 0, s, a); break;
     }
     return maf_check_hip(hipGetLastError(), "head_tail launch");
 }

@@ -115,7 +115,8 @@ class Plan:
         # on separate HIP streams of the engine.  Measured on MI355X (n, bs 32): heads-only lanes give -1 % on forward+NMS and
         # +1.3 % on forward alone (cross-stream event latency eats the overlap), all lanes lose 1-2 %: opt-in.
         # the tail of every detection level ({cls,reg}_conv_s -> {cls,reg}_pred -> sigmoid / DFL decode) as one launch per level
-        # (csrc/head_tail.hip, fp16, 80 classes, head width 64 / 128 / 192) instead of four 1x1 convs + the decode kernel
+        # (csrc/head_tail.hip, fp16, 80 classes, head width 64 / 128 / 192 and — weights streamed from L2 — 256 / 384: every level of n, s, m)
+        # instead of four 1x1 convs + the decode kernel
         fh = getattr(model, "fuse_head", "auto") if fuse_head is None else fuse_head
         self.fuse_head = bool(fh) and dtype == lib.F16 and model.nc == 80 and model.detect.reg_max == 16
         fs = getattr(model, "fuse_stem", True)                   # False | 1: backbone.0 + backbone.1 | True / 2: + the 1x1 that opens backbone.2
@@ -346,7 +347,9 @@ class Plan:
                 t = self._alloc(x.H, x.W, c)
                 self._conv1x1(p + ".stem", *m.stem.fused(), x, t, 0, lib.ACT_SILU)
                 tv = TV([Seg(t, c)], x.H, x.W)
-                if self.fuse_head and c in (64, 128, 192):
+                # 64 / 128 / 192: weights LDS-resident; 256: weight chunks streamed through LDS once per 16-pixel unit — pays on small levels
+                # (the bs = 1 latency path, P5 of s); 384 (P4 / P5 of m) keeps the convs + decode kernel (its instantiation spills)
+                if self.fuse_head and (c in (64, 128, 192) or (c == 256 and self.B * x.H * x.W <= 16384)):
                     # cls_conv and reg_conv read the same tensor: ONE depth-wise launch with two filters per input channel
                     (wc, bc), (wr, brg) = m.cls_conv.fused(), m.reg_conv.fused()
                     assert wc.shape == wr.shape

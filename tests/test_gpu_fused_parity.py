@@ -35,7 +35,7 @@ def _h(t):
 
 
 @pytest.mark.parametrize("c,B,H,W,lvl", [(64, 2, 21, 27, 0), (128, 2, 21, 27, 0), (192, 2, 13, 9, 2), (128, 1, 80, 80, 0), (128, 3, 40, 24, 1),
-                                         (192, 5, 20, 20, 2), (64, 1, 7, 5, 1), (128, 32, 8, 8, 1)])
+                                         (192, 5, 20, 20, 2), (64, 1, 7, 5, 1), (128, 32, 8, 8, 1), (256, 2, 13, 9, 2), (256, 1, 80, 80, 0), (384, 1, 20, 20, 2)])
 @pytest.mark.parametrize("iters", [0, 1, 3])
 def test_head_tail_vs_fp32_torch(c, B, H, W, lvl, iters):
     g = torch.Generator().manual_seed(c + H * W + lvl)

@@ -29,7 +29,7 @@ def _close32(pred, ref):
     np.testing.assert_allclose(pred[..., 4:], ref[..., 4:], rtol=0, atol=2e-5)
 
 
-_TOL16 = {"n": (0.3, 2e-3), "s": (0.3, 5e-3), "m": (2.2, 9e-3)}     # (box atol in px at rtol 5e-3, score atol): 2x the measured fp16-vs-fp32 gap
+_TOL16 = {"n": (0.3, 2e-3), "s": (0.5, 5e-3), "m": (2.2, 9e-3)}     # (box atol in px at rtol 5e-3, score atol): 2x the measured fp16-vs-fp32 gap
 
 
 def _close16(pred, ref, scale="n"):
@@ -286,7 +286,7 @@ def test_fused_head_tail_matches_unfused(shape, scale):
     B, H, W = shape
     x = O.synth_images(B, max(H, W), 21)[:, :, :H, :W].contiguous().to(DEV).half()
     outs = {}
-    nlev = {"n": 3, "s": 2}[scale]                      # s: the 256-wide P5 level keeps the four convs + the decode kernel (which skips the other two)
+    nlev = {"n": 3, "s": 3}[scale]                      # s: the 256-wide P5 level streams its weights through LDS in chunks (small levels only)
     for fh in (True, False):
         m = M.Model(scale)
         m.load_state_dict(O.synth_state_dict(scale, 0))

@@ -178,15 +178,15 @@ def test_plan_builds_on_cpu(built, scale, nops):
     ht = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)
     widths = [o.Cin for o in plan.ops if o.kind == lib.OP_CONV1X1 and o.out_f32][::2]
     assert len(widths) == 3
-    nf = sum(1 for w in widths if w in (64, 128, 192))              # levels whose width the fused tail supports (n: 3, s: 2, m: 0)
-    assert nf == {"n": 3, "s": 2, "m": 0}[scale]
+    nf = sum(1 for w in widths if w in (64, 128, 192, 256))         # levels that take the fused tail at this size (256-wide ones only while small): n 3, s 3, m 1
+    assert nf == {"n": 3, "s": 3, "m": 1}[scale]
     assert len(ht.ops) == nops - 4 * nf - (1 if nf == 3 else 0)
     assert sum(1 for o in ht.ops if o.kind == lib.OP_HEADTAIL) == nf and any(o.kind == lib.OP_DECODE for o in ht.ops) == (nf < 3)
     for o in ht.ops:
         if o.kind == lib.OP_HEADTAIL:
             assert o.nsrc == 2 and o.src[0].C == o.Cin and o.Win == ht.A and o.w and o.aux[0]
         if o.kind == lib.OP_DECODE:
-            assert [bool(o.src[l].ptr) for l in range(3)] == [w not in (64, 128, 192) for w in widths]
+            assert [bool(o.src[l].ptr) for l in range(3)] == [w not in (64, 128, 192, 256) for w in widths]
     assert [o.Hin for o in ht.ops if o.kind == lib.OP_HEADTAIL] == [0, 64, 80][:nf]
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops
     m.fuse_stem = True                             # backbone.0 + backbone.1 in one launch (scale n: 24 -> 48 channels)
