@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Copy the summaries of one tools/profile_round.sh chain from gpurun_out/<dir>/ into profiles/<prefix>_* (tracked).
+
+    python tools/collect_profiles.py gpurun_out/r2prof_b round2 [gpurun_out/pmc_a]
+"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, prefix = sys.argv[1], sys.argv[2]
+P = os.path.join(ROOT, "profiles")
+
+
+def cp(a, b):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(P, "%s_%s" % (prefix, b)))
+        print("copied", b)
+
+
+def last_json(path):
+    return json.loads([l for l in open(path) if l.startswith("{")][-1])
+
+
+cp("bench.json", "bench.json"); cp("per_op.txt", "per_op.txt"); cp("tune.json", "tune.json"); cp("train_n.json", "train_n.json")
+cp("latency_m.json", "latency_m.json"); cp("bench_s.json", "bench_s.json"); cp("bench_m.json", "bench_m.json"); cp("bench_inflight1.json", "bench_inflight1.json")
+st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    d, f = os.path.split(st[0])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), d, f[:-len("_kernel_stats.csv")], os.path.join(P, prefix), os.path.join(src, "stats_bench.json")])
+st = glob.glob(os.path.join(src, "train_stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    d, f = os.path.split(st[0])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), d, f[:-len("_kernel_stats.csv")], os.path.join(P, prefix + "_train_n")])
+    os.remove(os.path.join(P, prefix + "_train_n_kernel_stats.csv"))
+if os.path.isdir(os.path.join(src, "pmc_FETCH_SIZE")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), src, os.path.join(P, prefix + "_pmc_traffic.json")], stdout=subprocess.DEVNULL)
+    print("wrote", prefix + "_pmc_traffic.json")
+if len(sys.argv) > 3 and os.path.exists(os.path.join(sys.argv[3], "summary.txt")):
+    shutil.copy(os.path.join(sys.argv[3], "summary.txt"), os.path.join(P, prefix + "_sq_counters.txt"))
+    print("copied sq counters")
