@@ -64,6 +64,13 @@ __device__ __forceinline__ void maf_static_for(F&& f) {
 template <int OFF> __device__ __forceinline__ void bn_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void bn_ds_read_b64(u32x2_t& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int N> __device__ __forceinline__ void bn_wait_lgkm(u32x4_t& a, u32x2_t& b, u32x2_t& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
+template <int N> __device__ __forceinline__ void bn_wait_lgkm2(u32x4_t& a, u32x4_t& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+// SiLU of a value that arrives pre-multiplied by log2(e) (pack_bottleneck folds the factor into W1 / b1 / bdw and its inverse into W2):
+// returns log2(e) * silu(x) for the argument log2(e) * x — v_exp_f32 is a base-2 exponential, so no multiplication in front of it.
+__device__ __forceinline__ float bn_silu2(float v) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v)); }
+// (two at a time with the add and the multiplication as v_pk_add_f32 / v_pk_mul_f32 — 6 issue slots for two values instead of 8 — made the
+// kernel TWICE as slow: 68 -> 150 us; packed fp32 arithmetic is no full-rate path on this part.  Scalar it stays.)
 
 template <int K, int S1, int CT2>
 struct BnCfg {
@@ -81,8 +88,11 @@ struct BnCfg {
     static constexpr int OFF_TOE = REC_A, OFF_W2 = OFF_TOE + NTOE * 16, OFF_BD = OFF_W2 + CT2 * 1024;
     static constexpr int REC = OFF_BD + 128;                       // bytes per block record
     static constexpr int REC_B = REC - REC_A;
-    // LDS: T1 planes | part A of the current block | part B twice (the next block's part B arrives while this block's is being read)
-    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC + (size_t)REC_B;
+    // ZT: the 48 lanes outside the block diagonal of the Toeplitz operand read a ZERO table of the same size instead of masking what they
+    // read (4 v_and per MFMA in a VALU-bound kernel); where the extra NTOE * 16 bytes would cost a workgroup per CU the mask stays
+    static constexpr bool ZT = CT2 == 4 && K <= 5;
+    // LDS: T1 planes | part A of the current block | part B twice (the next block's part B arrives while this block's is being read) | zero table
+    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC + (size_t)REC_B + (ZT ? (size_t)NTOE * 16 : 0);
 };
 
 template <int K, int S1, int CT2>
@@ -138,6 +148,25 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
     // zero mask of the T1 values this lane writes: accumulator lane (g, p) of m-tile t owns halo pixels t*16 + 4g .. +3
     // (one row, 4 consecutive columns); bit r set = pixel r is inside the image.  interior tiles: all ones.
     const bool interior = y0 - P >= 0 && x0 - P >= 0 && y0 - P + Cf::RH <= a.H && x0 - P + RWC <= a.W;
+    // Per m-tile, for all blocks: where its 4 pixels go in a T1 plane (-1: past the halo tile) and which of them lie inside the image (the others
+    // are the depth-wise conv's zero padding).  A wave issues one vector instruction every ~6 cycles whatever the pipe could take
+    // (tools/valu_probe.py), so every instruction that can leave the block loop does.
+    uint32_t tmlo[MT], tmhi[MT];
+    int tdst[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m0 = (wave + 4 * i) * 16 + g * 4;
+        const int hr = m0 / RWC, hc0 = m0 - hr * RWC;
+        tmlo[i] = tmhi[i] = 0xffffffffu;
+        if (!interior) {
+            const int iy = y0 - P + hr, ixb = x0 - P + hc0;
+            const bool rowok = (unsigned)iy < (unsigned)a.H;
+            const uint32_t k0 = (rowok && (unsigned)(ixb + 0) < (unsigned)a.W) ? 0x0000ffffu : 0u, k1 = (rowok && (unsigned)(ixb + 1) < (unsigned)a.W) ? 0xffff0000u : 0u;
+            const uint32_t k2 = (rowok && (unsigned)(ixb + 2) < (unsigned)a.W) ? 0x0000ffffu : 0u, k3 = (rowok && (unsigned)(ixb + 3) < (unsigned)a.W) ? 0xffff0000u : 0u;
+            tmlo[i] = k0 | k1; tmhi[i] = k2 | k3;
+        }
+        tdst[i] = m0 < NHP ? p * PS + hr * RWP + hc0 : -1;
+    }
     // The next block's record travels global -> LDS by DMA (global_load_lds: no registers, no ds_write; every wave moves 1 KiB
     // per instruction to a wave-uniform LDS base + lane * 16).  The barrier that publishes it also waits for it (vmcnt).
     auto dma_part = [&](int mb, int off, int bytes, int dst) {
@@ -168,6 +197,10 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
 #endif
     dma_part(0, 0, Cf::REC, 0);
     load_x_head();
+    if constexpr (Cf::ZT) {
+        u32x4_t* z = reinterpret_cast<u32x4_t*>(rec + Cf::REC + Cf::REC_B);
+        for (int i = tid; i < Cf::NTOE; i += 256) z[i] = (u32x4_t){0u, 0u, 0u, 0u};
+    }
     __syncthreads();
     BN_STAMP(0);                                            // prologue
 
@@ -182,33 +215,36 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
 #pragma unroll
                 for (int ks = 0; ks < S1; ++ks) w1f[ct][ks] = reinterpret_cast<const half8_t*>(rec + Cf::OFF_W1)[(ct * S1 + ks) * 64 + lane];
             const float b1v0 = reinterpret_cast<const float*>(rec + Cf::OFF_B1)[p], b1v1 = reinterpret_cast<const float*>(rec + Cf::OFF_B1)[16 + p];
+            // the MFMAs of m-tile i + 1 are issued BEFORE the SiLU / store work of m-tile i: a wave issues in order, so written tile by tile the
+            // matrix pipe idles during the ~50 vector instructions of a tile and the vector pipe during the MFMAs and their result latency
+            f32x4_t accn[2];
+            auto mma_tile = [&](auto idx) {
+                constexpr int i = decltype(idx)::value;
+                if constexpr (i < MT) {
+                    accn[0] = (f32x4_t)b1v0; accn[1] = (f32x4_t)b1v1;                // bias as the accumulators' initial value: no add in the epilogue
+#pragma unroll
+                    for (int ks = 0; ks < S1; ++ks)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accn[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % (XD + 1)][ks], w1f[ct][ks], accn[ct], 0, 0, 0);
+                }
+            };
+            mma_tile(std::integral_constant<int, 0>{});
             maf_static_for<MT>([&](auto idx) {
                 constexpr int i = decltype(idx)::value;
                 const int t = wave + 4 * i;
                 load_x(std::integral_constant<int, i + XD>{});
-                f32x4_t acc1[2] = {(f32x4_t)b1v0, (f32x4_t)b1v1};                    // bias as the accumulators' initial value: no add in the epilogue
-#pragma unroll
-                for (int ks = 0; ks < S1; ++ks)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % (XD + 1)][ks], w1f[ct][ks], acc1[ct], 0, 0, 0);
-                const int m0 = t * 16 + g * 4;
-                const int hr = m0 / RWC, hc0 = m0 - hr * RWC;
-                uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;          // per-half keep masks for pixels (0,1) and (2,3)
-                if (!interior) {
-                    const int iy = y0 - P + hr, ixb = x0 - P + hc0;
-                    const bool rowok = (unsigned)iy < (unsigned)a.H;
-                    const uint32_t k0 = (rowok && (unsigned)(ixb + 0) < (unsigned)a.W) ? 0x0000ffffu : 0u, k1 = (rowok && (unsigned)(ixb + 1) < (unsigned)a.W) ? 0xffff0000u : 0u;
-                    const uint32_t k2 = (rowok && (unsigned)(ixb + 2) < (unsigned)a.W) ? 0x0000ffffu : 0u, k3 = (rowok && (unsigned)(ixb + 3) < (unsigned)a.W) ? 0xffff0000u : 0u;
-                    mlo = k0 | k1; mhi = k2 | k3;
-                }
-                half_t* dst = T1 + (size_t)p * PS + hr * RWP + hc0;
+                f32x4_t acc1[2] = {accn[0], accn[1]};
+                mma_tile(std::integral_constant<int, i + 1>{});
+                __builtin_amdgcn_sched_barrier(0);                                       // keep the next tile's MFMAs in front of this tile's vector work
+                const uint32_t mlo = tmlo[i], mhi = tmhi[i];          // keep masks and LDS address of this m-tile: the same for every block, computed once
+                half_t* dst = T1 + tdst[i];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    half2_t h01 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][0]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][1])};
-                    half2_t h23 = {(half_t)maf_act<MAF_ACT_SILU>(acc1[ct][2]), (half_t)maf_act<MAF_ACT_SILU>(acc1[ct][3])};
+                    half2_t h01 = {(half_t)bn_silu2(acc1[ct][0]), (half_t)bn_silu2(acc1[ct][1])};
+                    half2_t h23 = {(half_t)bn_silu2(acc1[ct][2]), (half_t)bn_silu2(acc1[ct][3])};
                     if (BN_KO(1)) { h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]}; }   // KO 1: no SiLU in phase A
                     const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
-                    if (m0 < NHP && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
+                    if (tdst[i] >= 0 && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
                 }
             });
         }
@@ -249,10 +285,20 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
         // The reads are inline assembly with hand-counted `s_waitcnt lgkmcnt(n)` (LDS returns in order: when step t is consumed the
         // 3 * min(BD, steps left) reads issued after its own may still be in flight); written as plain loads the compiler waits with
         // lgkmcnt(0) — a full LDS round trip — on every (BD+1)-th step.
+        // B128 (MAF_BN_B128): one ds_read_b128 per window although its address is only 8-byte aligned for the odd waves.  It works (gfx950 runs
+        // the LDS in unaligned-access mode) and it is a disaster: 68 -> 150 us — a misaligned 16-byte read is not one access.  Two ds_read_b64 stay.
+#ifdef MAF_BN_B128
+        constexpr bool B128 = true;
+#else
+        constexpr bool B128 = false;
+#endif
         constexpr int NSTEP = K * PARTS * 8, BD = CT2 == 2 ? 2 : 3;    // read-ahead depth (the c <= 32 variants run 3 workgroups per CU on 168 registers)
         u32x4_t avr[BD + 1];
+        u32x4_t bwin[BD + 1];                                  // B128: the 16-byte window in one (8-byte aligned) read; else two 8-byte halves
         u32x2_t blo[BD + 1], bhi[BD + 1];
-        const uint32_t a_toe = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)toe;
+        const half8_t* toe_src = toe;
+        if constexpr (Cf::ZT) { if (!toe_mask) toe_src = reinterpret_cast<const half8_t*>(rec + Cf::REC + Cf::REC_B) + p; }
+        const uint32_t a_toe = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)toe_src;
         const uint32_t a_t1l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1l;
         const uint32_t a_t1h = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1h;
         auto ld_step = [&](auto idx) {
@@ -262,8 +308,12 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
                 constexpr int ot = ((s * K + ky) * PARTS + part) * 256, o = (s * 4 * PS + ky * RWP + part * 4) * 2;
                 static_assert(ot < 65536 && o < 65536, "ds offset field");
                 bn_ds_read_b128<ot>(avr[t % (BD + 1)], a_toe);
-                bn_ds_read_b64<o>(blo[t % (BD + 1)], a_t1l);
-                bn_ds_read_b64<o>(bhi[t % (BD + 1)], a_t1h);
+                if constexpr (B128) {
+                    bn_ds_read_b128<o>(bwin[t % (BD + 1)], a_t1l);
+                } else {
+                    bn_ds_read_b64<o>(blo[t % (BD + 1)], a_t1l);
+                    bn_ds_read_b64<o>(bhi[t % (BD + 1)], a_t1h);
+                }
             }
         };
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the compiler's own reads (biases) are complete: the counter now counts only the reads below
@@ -273,9 +323,15 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
             constexpr int t = decltype(idx)::value, s = t % 8, sl = t % (BD + 1);
             ld_step(std::integral_constant<int, t + BD>{});
             constexpr int ahead = (NSTEP - 1 - t) < BD ? (NSTEP - 1 - t) : BD;      // steps whose reads were issued after step t's
-            bn_wait_lgkm<3 * ahead>(avr[sl], blo[sl], bhi[sl]);
-            const u32x4_t am = avr[sl] & toe_mask;
-            const u32x4_t bw = {blo[sl][0], blo[sl][1], bhi[sl][0], bhi[sl][1]};
+            u32x4_t bw;
+            if constexpr (B128) {
+                bn_wait_lgkm2<2 * ahead>(avr[sl], bwin[sl]);
+                bw = bwin[sl];
+            } else {
+                bn_wait_lgkm<3 * ahead>(avr[sl], blo[sl], bhi[sl]);
+                bw = (u32x4_t){blo[sl][0], blo[sl][1], bhi[sl][0], bhi[sl][1]};
+            }
+            const u32x4_t am = Cf::ZT ? avr[sl] : (avr[sl] & toe_mask);
             dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, am), __builtin_bit_cast(half8_t, bw), dacc[s], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);              // keep the issue order as written
         });
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
             for (int r = 0; r < 4; ++r) {
                 half8_t t2;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) t2[s] = BN_KO(3) ? (half_t)dacc[s][r] : (half_t)maf_act<MAF_ACT_SILU>(dacc[s][r]);   // KO 3: no SiLU in phase C
+                for (int s = 0; s < 8; ++s) t2[s] = BN_KO(3) ? (half_t)dacc[s][r] : (half_t)bn_silu2(dacc[s][r]);   // KO 3: no SiLU in phase C
 #pragma unroll
                 for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);   // KO 9: no second 1x1
             }

@@ -32,3 +32,53 @@ extern "C" int maf_probe_anyorder(void* stream, int n, int blocks, long long cyc
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return rc;
 }
+
+// Vector-pipe throughput probe: cycles per wave64 instruction of v_fma_f32 / v_exp_f32 / v_rcp_f32 (8 independent chains per lane, one wave
+// per SIMD x `waves` per SIMD).  kind: 0 fma, 1 exp, 2 rcp, 3 the SiLU sequence used in csrc/bottleneck.hip (exp2, add, rcp, mul).
+namespace {
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_probe_kernel(float* out, int iters, long long* cycles) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.5f + 0.001f * (float)(threadIdx.x + j);
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (KIND == 0) v[j] = __builtin_fmaf(v[j], 0.999f, 0.001f);
+            else if (KIND == 1) v[j] = __builtin_amdgcn_exp2f(v[j]) * 0.25f;        // (+1 full-rate op to keep the value bounded)
+            else if (KIND == 2) v[j] = __builtin_amdgcn_rcpf(v[j]) + 0.5f;          // (+1 full-rate op)
+            else v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v[j])) + 0.7f;
+        }
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
+}
+}  // namespace
+
+// -> shader clocks for `iters` iterations of 8 instructions (KIND 0) / 8 x (instruction + 1 full-rate op) (1, 2) / 8 SiLUs (3), measured on
+// workgroup 0 with `wgs_per_cu` workgroups of 256 threads on every CU (1 -> one wave per SIMD, 2 -> two ...)
+extern "C" int maf_probe_valu(void* stream, int kind, int iters, int wgs_per_cu, long long* host_cycles) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* out = nullptr; long long* cyc = nullptr;
+    const int blocks = 256 * wgs_per_cu;
+    int rc = maf_check_hip(hipMalloc(&out, (size_t)blocks * 256 * 4), "hipMalloc");
+    if (!rc) rc = maf_check_hip(hipMalloc(&cyc, 8), "hipMalloc");
+    if (rc) return rc;
+    for (int rep = 0; rep < 2; ++rep) {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(valu_probe_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            case 1: hipLaunchKernelGGL(valu_probe_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            case 2: hipLaunchKernelGGL(valu_probe_kernel<2>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            default: hipLaunchKernelGGL(valu_probe_kernel<3>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+        }
+    }
+    rc = maf_check_hip(hipStreamSynchronize(s), "sync");
+    if (!rc) rc = maf_check_hip(hipMemcpy(host_cycles, cyc, 8, hipMemcpyDeviceToHost), "memcpy");
+    (void)hipFree(out); (void)hipFree(cyc);
+    return rc;
+}

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Cycles per wave64 vector instruction on this device (csrc/probe.hip:maf_probe_valu): v_fma_f32, v_exp_f32, v_rcp_f32 and the SiLU sequence."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maf_yolo_amd import lib   # noqa: E402
+
+L = lib.load()
+L.maf_probe_valu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+torch.zeros(1, device="cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+iters = 4096
+for wg in (1, 2, 4):
+    row = []
+    for kind, name in ((0, "fma"), (1, "exp+mul"), (2, "rcp+add"), (3, "silu(4 ops + add)")):
+        c = C.c_longlong()
+        lib.check(L.maf_probe_valu(st, kind, iters, wg, C.byref(c)))
+        row.append("%s %.2f" % (name, c.value / (iters * 8.0)))
+    print("waves/SIMD %d: cycles per (lane-parallel) step:  %s" % (wg, "   ".join(row)))
