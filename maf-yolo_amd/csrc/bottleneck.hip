@@ -90,13 +90,22 @@ struct BnCfg {
     static constexpr int REC_B = REC - REC_A;
     // ZT: the 48 lanes outside the block diagonal of the Toeplitz operand read a ZERO table of the same size instead of masking what they
     // read (4 v_and per MFMA in a VALU-bound kernel); where the extra NTOE * 16 bytes would cost a workgroup per CU the mask stays
-    static constexpr bool ZT = CT2 == 4 && K <= 5;
+    // OCC3 (-DMAF_BN_OCC3, an experiment): three workgroups per CU for the c <= 64 instantiations too — <= 168 registers and <= 53 KB of LDS, i.e.
+    // part B single-buffered again and no zero table: one more wave per SIMD to issue vector instructions from
+#ifdef MAF_BN_OCC3
+    static constexpr bool OCC3 = true;
+#else
+    static constexpr bool OCC3 = false;
+#endif
+    static constexpr bool ZT = CT2 == 4 && K <= 5 && !OCC3;
+    static constexpr bool DB = !OCC3;                              // part B double-buffered
     // LDS: T1 planes | part A of the current block | part B twice (the next block's part B arrives while this block's is being read) | zero table
-    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC + (size_t)REC_B + (ZT ? (size_t)NTOE * 16 : 0);
+    static constexpr size_t LDS = (size_t)32 * PSB + (size_t)REC + (DB ? (size_t)REC_B : 0) + (ZT ? (size_t)NTOE * 16 : 0);
+    static constexpr int ZOFF = REC + (DB ? REC_B : 0);            // offset of the zero table behind the record buffers
 };
 
 template <int K, int S1, int CT2>
-__global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
+__global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::OCC3 && K <= 5)) ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
     typedef BnCfg<K, S1, CT2> Cf;
     constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
         xoff[i] = (uint32_t)(iy * a.W + ix) * a.x_stride;
     }
     int ko_block = 0;
-    constexpr int XD = 2;                                   // activation fragments are loaded XD m-tiles ahead of their MFMAs
+    constexpr int XD = Cf::OCC3 ? 1 : 2;                    // activation fragments are loaded XD m-tiles ahead of their MFMAs
     half8_t af[XD + 1][S1];
     auto load_x = [&](auto idx) {
         constexpr int i = decltype(idx)::value;
@@ -151,10 +160,11 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
     // Per m-tile, for all blocks: where its 4 pixels go in a T1 plane (-1: past the halo tile) and which of them lie inside the image (the others
     // are the depth-wise conv's zero padding).  A wave issues one vector instruction every ~6 cycles whatever the pipe could take
     // (tools/valu_probe.py), so every instruction that can leave the block loop does.
-    uint32_t tmlo[MT], tmhi[MT];
-    int tdst[MT];
+    constexpr int MTH = Cf::OCC3 ? 1 : MT;                  // (the three-workgroup experiment has no registers for them: computed per block)
+    uint32_t tmlo[MTH], tmhi[MTH];
+    int tdst[MTH];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < (Cf::OCC3 ? 0 : MT); ++i) {
         const int m0 = (wave + 4 * i) * 16 + g * 4;
         const int hr = m0 / RWC, hc0 = m0 - hr * RWC;
         tmlo[i] = tmhi[i] = 0xffffffffu;
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
     dma_part(0, 0, Cf::REC, 0);
     load_x_head();
     if constexpr (Cf::ZT) {
-        u32x4_t* z = reinterpret_cast<u32x4_t*>(rec + Cf::REC + Cf::REC_B);
+        u32x4_t* z = reinterpret_cast<u32x4_t*>(rec + Cf::ZOFF);
         for (int i = tid; i < Cf::NTOE; i += 256) z[i] = (u32x4_t){0u, 0u, 0u, 0u};
     }
     __syncthreads();
@@ -206,7 +216,8 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
 
     for (int mb = 0; mb < a.nMB; ++mb) {
         ko_block = mb;
-        const unsigned char* recB = rec + (mb & 1) * Cf::REC_B;    // this block's part B (offsets OFF_TOE / OFF_W2 / OFF_BD count from the record start)
+        if (!Cf::DB && mb > 0) dma_part(mb, Cf::REC_A, Cf::REC_B, Cf::REC_A);      // single buffer: free since the barrier that ended the previous block
+        const unsigned char* recB = rec + (Cf::DB ? (mb & 1) * Cf::REC_B : 0);    // this block's part B (offsets OFF_TOE / OFF_W2 / OFF_BD count from the record start)
         // ---- A. T1 = SiLU(X * W1[:, block] + b1) on the halo tile
         if (!BN_KO(8)) {                                    // KO 8: no phase A
             half8_t w1f[2][S1];
@@ -225,26 +236,45 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
 #pragma unroll
                     for (int ks = 0; ks < S1; ++ks)
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) accn[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % (XD + 1)][ks], w1f[ct][ks], accn[ct], 0, 0, 0);
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const half8_t wv = Cf::OCC3 ? reinterpret_cast<const half8_t*>(rec + Cf::OFF_W1)[(ct * S1 + ks) * 64 + lane] : w1f[ct][ks];   // OCC3: no registers to keep W1 in
+                            accn[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % (XD + 1)][ks], wv, accn[ct], 0, 0, 0);
+                        }
                 }
             };
-            mma_tile(std::integral_constant<int, 0>{});
+            if constexpr (!Cf::OCC3) mma_tile(std::integral_constant<int, 0>{});
             maf_static_for<MT>([&](auto idx) {
                 constexpr int i = decltype(idx)::value;
                 const int t = wave + 4 * i;
                 load_x(std::integral_constant<int, i + XD>{});
+                if constexpr (Cf::OCC3) mma_tile(idx);
                 f32x4_t acc1[2] = {accn[0], accn[1]};
-                mma_tile(std::integral_constant<int, i + 1>{});
+                if constexpr (!Cf::OCC3) mma_tile(std::integral_constant<int, i + 1>{});
                 __builtin_amdgcn_sched_barrier(0);                                       // keep the next tile's MFMAs in front of this tile's vector work
-                const uint32_t mlo = tmlo[i], mhi = tmhi[i];          // keep masks and LDS address of this m-tile: the same for every block, computed once
-                half_t* dst = T1 + tdst[i];
+                uint32_t mlo, mhi;                                     // keep masks and LDS address of this m-tile: the same for every block, computed once
+                int doff;
+                if constexpr (!Cf::OCC3) {
+                    mlo = tmlo[i]; mhi = tmhi[i]; doff = tdst[i];
+                } else {
+                    const int m0 = t * 16 + g * 4;
+                    const int hr = m0 / RWC, hc0 = m0 - hr * RWC;
+                    mlo = mhi = 0xffffffffu;
+                    if (!interior) {
+                        const int iy = y0 - P + hr, ixb = x0 - P + hc0;
+                        const bool rowok = (unsigned)iy < (unsigned)a.H;
+                        mlo = ((rowok && (unsigned)(ixb + 0) < (unsigned)a.W) ? 0x0000ffffu : 0u) | ((rowok && (unsigned)(ixb + 1) < (unsigned)a.W) ? 0xffff0000u : 0u);
+                        mhi = ((rowok && (unsigned)(ixb + 2) < (unsigned)a.W) ? 0x0000ffffu : 0u) | ((rowok && (unsigned)(ixb + 3) < (unsigned)a.W) ? 0xffff0000u : 0u);
+                    }
+                    doff = m0 < NHP ? p * PS + hr * RWP + hc0 : -1;
+                }
+                half_t* dst = T1 + doff;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     half2_t h01 = {(half_t)bn_silu2(acc1[ct][0]), (half_t)bn_silu2(acc1[ct][1])};
                     half2_t h23 = {(half_t)bn_silu2(acc1[ct][2]), (half_t)bn_silu2(acc1[ct][3])};
                     if (BN_KO(1)) { h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]}; }   // KO 1: no SiLU in phase A
                     const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
-                    if (tdst[i] >= 0 && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
+                    if (doff >= 0 && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
                 }
             });
         }
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
             // not for a DMA issued a few instructions earlier (the single-buffer version stalled there once per block).
             if (!BN_KO(5)) {                                 // KO 5: the first block's operands for every block
             dma_part(mb + 1, 0, Cf::REC_A, 0);
-            dma_part(mb + 1, Cf::REC_A, Cf::REC_B, Cf::REC_A + ((mb + 1) & 1) * Cf::REC_B);
+            if (Cf::DB) dma_part(mb + 1, Cf::REC_A, Cf::REC_B, Cf::REC_A + ((mb + 1) & 1) * Cf::REC_B);
             }
             load_x_head();                                  // the next phase A's first activations: in flight during phase B
         }
@@ -292,12 +322,12 @@ __global__ __launch_bounds__(256, (CT2 == 2 && K <= 5) ? 3 : 2) void bottleneck_
 #else
         constexpr bool B128 = false;
 #endif
-        constexpr int NSTEP = K * PARTS * 8, BD = CT2 == 2 ? 2 : 3;    // read-ahead depth (the c <= 32 variants run 3 workgroups per CU on 168 registers)
+        constexpr int NSTEP = K * PARTS * 8, BD = (CT2 == 2 || Cf::OCC3) ? 2 : 3;    // read-ahead depth (the c <= 32 variants run 3 workgroups per CU on 168 registers)
         u32x4_t avr[BD + 1];
         u32x4_t bwin[BD + 1];                                  // B128: the 16-byte window in one (8-byte aligned) read; else two 8-byte halves
         u32x2_t blo[BD + 1], bhi[BD + 1];
         const half8_t* toe_src = toe;
-        if constexpr (Cf::ZT) { if (!toe_mask) toe_src = reinterpret_cast<const half8_t*>(rec + Cf::REC + Cf::REC_B) + p; }
+        if constexpr (Cf::ZT) { if (!toe_mask) toe_src = reinterpret_cast<const half8_t*>(rec + Cf::ZOFF) + p; }
         const uint32_t a_toe = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)toe_src;
         const uint32_t a_t1l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1l;
         const uint32_t a_t1h = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1h;
