@@ -217,10 +217,14 @@ def train_mode(args, torch, M, dev, rank, world, dist):
                 "note": "same steps under DistributedDataParallel.no_sync(); RCCL all-reduce of the fp32 gradient buckets is overlapped with the backward by the autograd hooks"}
     # ---- roofline of the dominant training kernel: one more step with HIP events around every native launch (train_ops.profile)
     roof = None
-    if rank == 0 and not args.torch_convs:
-        train_ops.profile = {}
+    if not args.torch_convs:
+        # EVERY rank runs this step (under DDP it carries the gradient all-reduce: a step on rank 0 alone would wait for its peers forever);
+        # only rank 0 records the events
+        if rank == 0:
+            train_ops.profile = {}
         step()
         torch.cuda.synchronize(dev)
+    if rank == 0 and not args.torch_convs:
         prof = train_ops.profile_collect()
         train_ops.profile = None
         tot = sum(v[0] for v in prof.values())
@@ -270,6 +274,7 @@ def main():
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")
     args = ap.parse_args()
@@ -284,12 +289,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MAF_BENCH_ONE_DEVICE=1 + --dist-backend gloo: every rank on cuda:0 with the exchange over gloo — NOT a measurement, a way to run the N > 1 code
+    # paths (barriers, MAX over ranks, DDP hooks, the no_sync re-timing) on a 1-GPU box, where RCCL refuses two ranks on one device
+    one_dev = os.environ.get("MAF_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_dev else local_rank)
+    dev = torch.device("cuda", 0 if one_dev else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, init_method="env://")
 
     if args.latency:
         return latency_mode(args, torch, M, dev)
