@@ -16,6 +16,8 @@ CUDA tensors always take the HIP kernels (unsupported shapes raise); CPU tensors
 train-form module tree can be exercised by the CPU/gloo tests (`stats` counts which path ran)."""
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -28,12 +30,13 @@ stats = {"native_conv1x1": 0, "native_dwconv": 0, "fallback": 0}
 # Per-kernel timing of one training step (bench.py --train: the `roofline` object): while `profile` is a dict every native launch is
 # bracketed by HIP events on its stream; profile_collect() turns them into {kind: [milliseconds, algorithmic bytes, launches]}.
 profile = None
+profile_detail = None                # a list: profile_collect() also appends (kind, note, ms, bytes) per launch (tools/train_detail.py)
 _pending = []
 
 
 class _prof:
-    def __init__(self, kind, nbytes, dev):
-        self.kind, self.nbytes, self.dev = kind, int(nbytes), dev
+    def __init__(self, kind, nbytes, dev, note=None):
+        self.kind, self.nbytes, self.dev, self.note = kind, int(nbytes), dev, note
 
     def __enter__(self):
         if profile is not None:
@@ -43,21 +46,83 @@ class _prof:
     def __exit__(self, *exc):
         if profile is not None:
             self.t.stop(_stream(self.dev))
-            _pending.append((self.kind, self.nbytes, self.t))
+            _pending.append((self.kind, self.nbytes, self.t, self.note))
         return False
 
 
 def profile_collect():
     """Wait for the recorded launches and fold them into `profile` (kind -> [ms, algorithmic bytes, launches])."""
-    for kind, nbytes, t in _pending:
+    for kind, nbytes, t, note in _pending:
         rec = profile.setdefault(kind, [0.0, 0, 0])
-        rec[0] += t.elapsed_ms(); rec[1] += nbytes; rec[2] += 1
+        ms = t.elapsed_ms()
+        rec[0] += ms; rec[1] += nbytes; rec[2] += 1
+        if profile_detail is not None:
+            profile_detail.append((kind, note, ms, nbytes))
     del _pending[:]
     return profile
 
 
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+# Weight gradients run on a SIDE stream: dW of a layer depends on nothing that follows it in the backward chain (dY -> dX -> BatchNorm
+# backward -> ...), whose kernels are short and leave the chip idle while they ramp up and drain.  The side stream waits for the main
+# stream at the launch (dY is ready), the main stream waits for the side stream
+#   * at the end of the backward pass (an autograd engine callback) in a single-process run, or
+#   * before the backward of the layer returns when torch.distributed runs with more than one rank: DDP's reducer copies a gradient into
+#     its bucket from the AccumulateGrad hook on the main stream, so dW must be ordered before that hook (the overlap is then with the
+#     data gradient of the same layer only).
+wgrad_stream = os.environ.get("MAF_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_join_pending = [False]
+
+
+def _immediate_join():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _join_side():
+    _join_pending[0] = False
+    for idx, side in _side_streams.items():
+        torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(side)
+
+
+class _side:
+    """`with _side(dev, x, dy):` — the body's launches and allocations go to the device's side stream (see above); no-op when wgrad_stream is off."""
+
+    def __init__(self, dev, *tensors):
+        self.dev, self.tensors, self.ctx = dev, tensors, None
+
+    def __enter__(self):
+        if not wgrad_stream:
+            return self
+        side = _side_streams.get(self.dev.index)
+        if side is None:
+            side = _side_streams[self.dev.index] = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        for t in self.tensors:                                                   # allocated on the main stream: not to be reused before the side stream is done
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            if not _immediate_join() and not _join_pending[0]:
+                _join_pending[0] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+        return False
+
+
+def _side_done(dev):
+    """End of a layer's backward: under torch.distributed (world size > 1) the main stream waits for this layer's weight gradient here."""
+    if wgrad_stream and _side_streams and _immediate_join():
+        side = _side_streams.get(dev.index)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
 
 
 def _zero_bias(dev, n):
@@ -148,6 +213,14 @@ class _Conv1x1(torch.autograd.Function):
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            if x.dtype == torch.float16:                                        # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
+                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels)
+            else:                                                                # fp32 parity mode: the framework's TN GEMM
+                x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
+                d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
+                dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
+                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
             w2d = w.detach().reshape(cout, cin).float().contiguous()
             mult = 8 if x.dtype == torch.float16 else 4
@@ -162,33 +235,28 @@ class _Conv1x1(torch.autograd.Function):
             npad = -(-cin // (16 * ct)) * 16 * ct
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
-        if ctx.needs_input_grad[1]:
-            if x.dtype == torch.float16:                                        # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
-                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels)
-            else:                                                                # fp32 parity mode: the framework's TN GEMM
-                x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
-                d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
-                dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
-                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
+        _side_done(x.device)
         return dx, dw, db
 
 
 def _wgrad(x, dy, dys, w, ksize, stride):
-    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32."""
+    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32.  Runs on
+    the side stream (`_side`): call it BEFORE the data gradient of the layer is launched."""
     B, cin, Hs, Ws = x.shape
     cout, Ho, Wo = dy.shape[1:]
     xx, xs = nhwc(x)
-    co = -(-cout // 8) * 8
-    if co != cout:                                                              # e.g. reg_pred: 68 channels, an odd class count
-        dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
-        dys = co
-    dwf = torch.zeros(co, cin, ksize, ksize, dtype=torch.float32, device=x.device)
-    with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device):
-        lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
-    stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
-    return dwf[:cout].reshape(w.shape).to(w.dtype)
+    with _side(x.device, xx, dy):
+        co = -(-cout // 8) * 8
+        if co != cout:                                                          # e.g. reg_pred: 68 channels, an odd class count
+            dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
+            dys = co
+        dwf = torch.zeros(co, cin, ksize, ksize, dtype=torch.float32, device=x.device)
+        with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride)):
+            lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
+        stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
+        return dwf[:cout].reshape(w.shape).to(w.dtype)
 
 
 def _tile_dgrad(n, m_pixels):
@@ -248,6 +316,12 @@ class _Conv3x3s2(torch.autograd.Function):
         Ho, Wo = dy.shape[2:]
         dt = _DT[x.dtype]
         dx = dw = None
+        if ctx.needs_input_grad[1]:
+            if x.dtype == torch.float16:
+                dw = _wgrad(x, dy, dys, w, 3, 2)
+            else:                                                                # fp32 parity mode: the framework's kernel
+                dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=2, padding=1).to(w.dtype)
+                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
             pt, ct = _tile_dgrad(cin, B * H * W)
             wp = _packed_3x3(w, True, dt, ct, x.device)
@@ -262,12 +336,7 @@ class _Conv3x3s2(torch.autograd.Function):
             es = x.element_size()
             with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device):
                 lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
-        if ctx.needs_input_grad[1]:
-            if x.dtype == torch.float16:
-                dw = _wgrad(x, dy, dys, w, 3, 2)
-            else:                                                                # fp32 parity mode: the framework's kernel
-                dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=2, padding=1).to(w.dtype)
-                stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
+        _side_done(x.device)
         return dx, dw
 
 
@@ -310,13 +379,6 @@ class _Conv1x1s2(torch.autograd.Function):
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
-            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device)
-            dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
-            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
-            dx[:, :, ::2, ::2] = dxs
         if ctx.needs_input_grad[1]:
             if x.dtype == torch.float16:
                 dw = _wgrad(x, dy, dys, w, 1, 2)
@@ -324,6 +386,14 @@ class _Conv1x1s2(torch.autograd.Function):
                 xsub = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(-1, cin)
                 dw = torch.mm(dy.permute(0, 2, 3, 1).reshape(-1, cout).t(), xsub).float().reshape(w.shape).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
+        if ctx.needs_input_grad[0]:
+            ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
+            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device)
+            dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
+            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+            dx[:, :, ::2, ::2] = dxs
+        _side_done(x.device)
         return dx, dw
 
 
@@ -413,16 +483,18 @@ class _DWConv(torch.autograd.Function):
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
         dx = dw = None
-        if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
-            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
         if ctx.needs_input_grad[1]:
             xx, xs = nhwc(x)
             reps = 32                                                           # copies of dW: atomics on one cache line serialise
-            dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
-            with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
-                lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
-            dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
+            with _side(x.device, xx, dy):
+                dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
+                with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
+                    lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
+                dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
+        if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
+            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
+        _side_done(x.device)
         return dx, dw
 
 
@@ -434,15 +506,17 @@ _bn_scratch = {}
 
 
 def _bn_part(dev, c):
-    """[R][2][c] fp32 scratch, zero on entry to every BatchNorm call: the finalize kernels clear what they read, so it is allocated and
-    memset once per (device, stream, size class) — kernels on one stream are ordered, different streams get different buffers."""
+    """(scratch, phase): [2][R][2][roundup(c,256)] fp32, zeroed when it is allocated; a BatchNorm call accumulates into half `phase` and clears
+    the other one (csrc/bn_act.hip), so the phase alternates per call on a buffer — kernels on one stream are ordered, different streams get
+    different buffers."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, -(-c // 256))
-    t = _bn_scratch.get(key)
-    if t is None:
+    ent = _bn_scratch.get(key)
+    if ent is None:
         if len(_bn_scratch) > 64:
             _bn_scratch.clear()
-        t = _bn_scratch[key] = torch.zeros(_BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev)
-    return t
+        ent = _bn_scratch[key] = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
+    ent[1] ^= 1
+    return ent[0], ent[1]
 
 
 class _BNAct(torch.autograd.Function):
@@ -456,14 +530,14 @@ class _BNAct(torch.autograd.Function):
         dev = x.device
         y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
-        part = _bn_part(dev, c)
+        part, phase = _bn_part(dev, c)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        with _prof("bn_act_forward", 3 * B * H * W * c * x.element_size(), dev):       # statistics pass (read) + apply pass (read, write)
+        with _prof("bn_act_forward", 3 * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, act)):       # statistics pass (read) + apply pass (read, write)
             lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
                                                 None if running_mean is None else running_mean.data_ptr(),
                                                 None if running_var is None else running_var.data_ptr(), act,
                                                 y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
-                                                _stream(dev)))
+                                                phase, _stream(dev)))
         ctx.save_for_backward(x, g32, b32, stat)
         ctx.act = act
         stats["native_bn_act"] = stats.get("native_bn_act", 0) + 1
@@ -481,12 +555,11 @@ class _BNAct(torch.autograd.Function):
         dev = x.device
         dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         dgb = torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
-        part = _bn_part(dev, c)
-        sums = torch.empty(2, c, dtype=torch.float32, device=dev)
-        with _prof("bn_act_backward", 5 * B * H * W * c * x.element_size(), dev):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
+        part, phase = _bn_part(dev, c)
+        with _prof("bn_act_backward", 5 * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
             lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
                                                  stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
-                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, sums.data_ptr(), _stream(dev)))
+                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
         return dx, dgb[0], dgb[1], None, None, None, None, None
 
 
