@@ -151,7 +151,8 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
-    opt = torch.optim.SGD(model.parameters(), lr=0.01 / 64 * args.batch * world, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    # build.py:12-33 grouping (BatchNorm weights and biases without decay), lr0 scaled like engine.py: fused SGD keeps the AMP inf check on the device
+    opt = M.build_optimizer(model, lr0=0.01 / 64 * args.batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
     scaler = torch.amp.GradScaler("cuda")
     B = args.batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255
@@ -274,6 +275,7 @@ def main():
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
+    ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")

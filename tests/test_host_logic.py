@@ -398,3 +398,19 @@ def test_torch_custom_op_library_loads_and_declares_the_ops(built):
         assert p.shape == (2, 84, 85) and p.dtype == torch.float32
     with pytest.raises(Exception):                           # a CPU tensor has no kernel: there is no CPU fallback
         ops.conv1x1_bias_act(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1), None, 0)
+
+
+def test_build_optimizer_groups_match_the_reference_counts():
+    """yolov6/solver/build.py:12-33: BatchNorm weights (no decay), other weights (decay), biases (no decay).  The expected (count, elements) per
+    group were read off the reference's own build_optimizer on its n / s / m models in the build container (same parameter names, same order)."""
+    import importlib
+    M = importlib.import_module("maf-yolo_amd")
+    want = {"n": [(140, 25088), (131, 3964745), (146, 25532)], "s": [(203, 54336), (184, 9012625), (209, 54780)],
+            "m": [(265, 118272), (236, 24699857), (271, 118716)]}
+    for scale, groups in want.items():
+        opt = M.build_optimizer(M.Model(scale), lr0=0.02, momentum=0.9, weight_decay=5e-4)
+        got = [(len(g["params"]), sum(p.numel() for p in g["params"])) for g in opt.param_groups]
+        assert got == groups, (scale, got)
+        assert [g["weight_decay"] for g in opt.param_groups] == [0, 5e-4, 0]
+        assert all(g["nesterov"] and g["momentum"] == 0.9 and g["lr"] == 0.02 for g in opt.param_groups)
+        assert not opt.param_groups[0].get("fused")            # CPU parameters: the plain implementation
