@@ -154,6 +154,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     # build.py:12-33 grouping (BatchNorm weights and biases without decay), lr0 scaled like engine.py: fused SGD keeps the AMP inf check on the device
     opt = M.build_optimizer(model, lr0=0.01 / 64 * args.batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
     scaler = torch.amp.GradScaler("cuda")
+    ema = M.ModelEMA(model) if rank == 0 and not args.no_ema else None          # engine.py:67: the main process keeps the weight average
     B = args.batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255
     g = torch.Generator().manual_seed(100 + rank)
@@ -174,6 +175,8 @@ def train_mode(args, torch, M, dev, rank, world, dist):
         scaler.scale(loss).backward()
         scaler.step(opt)
         scaler.update()
+        if ema is not None:
+            ema.update(net)                                                     # engine.py:389-390
         return loss
 
     def timed(fn, n):
@@ -239,7 +242,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     if rank == 0 and not args.no_cpu_baseline:
         cpu = train_cpu_baseline(args, torch, M)
     if rank == 0:
-        print(json.dumps({"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD, AMP fp16)" % (args.scale, B),
+        print(json.dumps({"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD+EMA, AMP fp16)" % (args.scale, B),
                           "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -275,6 +278,7 @@ def main():
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
+    ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
     ap.add_argument("--latency", action="store_true",

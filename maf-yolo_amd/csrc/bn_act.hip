@@ -25,7 +25,7 @@ struct BnArgs2 {
     float* mean; float* rstd;                         // forward: written by workgroup 0; backward: read
     float* part;                                      // this call's half: [R][2][C]
     float* part_clear; int clear_n;                   // the other half, zeroed by the apply kernel
-    float eps, momentum; float* running_mean; float* running_var;
+    float eps, momentum; float* running_mean; float* running_var; long long* counter;
     float* dgamma; float* dbeta;
     int rev;
 };
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
             const float sc = rsf * a.gamma[c];
             cst[c] = sc; cst[a.C + c] = a.beta[c] - muf * sc;         // u = x*sc + sh
             if (blockIdx.x == 0) {
+                if (c == 0 && a.counter) *a.counter += 1;             // nn.BatchNorm2d.num_batches_tracked
                 a.mean[c] = muf; a.rstd[c] = rsf;
                 if (a.running_mean) {                                // torch: running = (1 - momentum) * running + momentum * batch (unbiased var)
                     const double unb = a.M > 1 ? var * a.M / (a.M - 1) : var;
@@ -261,8 +262,8 @@ void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
 }  // namespace
 
 extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
-                              float eps, float momentum, float* running_mean, float* running_var, int32_t act, void* y, int32_t y_stride,
-                              float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, maf_stream_t stream) {
+                              float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
+                              int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, maf_stream_t stream) {
     if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
     MAF_REQUIRE(gamma && beta && y && save_mean && save_rstd, "bn_forward: null pointer");
     MAF_REQUIRE(act == MAF_ACT_NONE || act == MAF_ACT_SILU || act == MAF_ACT_RELU, "bn_forward: act must be none / relu / silu");
@@ -270,7 +271,7 @@ extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_
     BnArgs2 a = {};
     a.x = x; a.y = y; a.xs = x_stride; a.ys = y_stride; a.M = M; a.C = C; a.act = act; a.R = R;
     a.mean = save_mean; a.rstd = save_rstd; a.gamma = gamma; a.beta = beta;
-    a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var;
+    a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.counter = reinterpret_cast<long long*>(num_batches_tracked);
     set_halves(a, part, C, R, phase);
     const int gs = bn_grid(M, C, dtype, 2048), ga = bn_grid(M, C, dtype, 8192);
     if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), dim3(gs), dim3(256), (size_t)2 * C * sizeof(float), s, a);

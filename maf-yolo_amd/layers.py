@@ -179,7 +179,7 @@ class RepHDW(nn.Module):
 
     def forward(self, x):
         t = self.conv1(x)
-        outs = [t[:, :self.c_], t[:, self.c_:]]
+        outs = list(t.split((self.c_, self.c_), 1))                              # split, not slices: its backward is ONE cat of the two gradients
         for blk in self.m:
             outs.append(blk(outs[-1]))
         return self.conv2(torch.cat(outs, 1))

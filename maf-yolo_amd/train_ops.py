@@ -523,7 +523,7 @@ class _BNAct(torch.autograd.Function):
     """act(BatchNorm2d(x)) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
@@ -535,7 +535,8 @@ class _BNAct(torch.autograd.Function):
         with _prof("bn_act_forward", 3 * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, act)):       # statistics pass (read) + apply pass (read, write)
             lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
                                                 None if running_mean is None else running_mean.data_ptr(),
-                                                None if running_var is None else running_var.data_ptr(), act,
+                                                None if running_var is None else running_var.data_ptr(),
+                                                None if counter is None else counter.data_ptr(), act,
                                                 y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
                                                 phase, _stream(dev)))
         ctx.save_for_backward(x, g32, b32, stat)
@@ -560,7 +561,7 @@ class _BNAct(torch.autograd.Function):
             lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
                                                  stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
                                                  dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
-        return dx, dgb[0], dgb[1], None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 def bn_act(x, bn, act=None):
@@ -575,11 +576,13 @@ def bn_act(x, bn, act=None):
         return y if act in (None, "none") else (F.relu(y) if act == "relu" else F.silu(y))
     if not (x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and bn.affine):
         raise lib.MafError("bn_act: unsupported input for the HIP path: %s %s (channels must be a multiple of %d, affine BatchNorm)" % (tuple(x.shape), x.dtype, mult))
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    counter = bn.num_batches_tracked if bn.track_running_stats else None        # += 1 inside the apply kernel (140 one-element launches per step otherwise)
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64):
+        counter.add_(1)
+        counter = None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act])
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter)
 
 
 def dwconv(x, w):

@@ -414,3 +414,42 @@ def test_build_optimizer_groups_match_the_reference_counts():
         assert [g["weight_decay"] for g in opt.param_groups] == [0, 5e-4, 0]
         assert all(g["nesterov"] and g["momentum"] == 0.9 and g["lr"] == 0.02 for g in opt.param_groups)
         assert not opt.param_groups[0].get("fused")            # CPU parameters: the plain implementation
+
+
+def test_model_ema_matches_the_per_tensor_rule_bit_for_bit():
+    """yolov6/utils/ema.py:29-37: every floating state_dict entry e <- e * d + (1 - d) * m with d = decay * (1 - exp(-updates / 2000)),
+    integer buffers (num_batches_tracked) untouched; the multi-tensor update must round exactly like the per-tensor loop."""
+    import copy
+    import importlib
+    import math
+    M = importlib.import_module("maf-yolo_amd")
+    torch.manual_seed(3)
+    model = M.Model("n")
+    ema = M.ModelEMA(model)
+    want = copy.deepcopy(model.state_dict())
+    assert not ema.ema.training and all(not p.requires_grad for p in ema.ema.parameters())
+    for step in range(1, 4):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
+            for name, b in model.named_buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.1)
+                else:
+                    b.add_(1)
+        ema.update(model)
+        d = 0.9999 * (1 - math.exp(-step / 2000))
+        sd = model.state_dict()
+        for k, v in want.items():
+            if v.dtype.is_floating_point:
+                v *= d
+                v += (1 - d) * sd[k]
+    assert ema.updates == 3
+    got = ema.ema.state_dict()
+    assert list(got) == list(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert int(got["backbone.0.rbr_dense.bn.num_batches_tracked"]) == 0 and int(model.state_dict()["backbone.0.rbr_dense.bn.num_batches_tracked"]) == 3
+    model.nc, model.names = 3, ["a", "b", "c"]
+    ema.update_attr(model, include=["nc", "names", "stride"])
+    assert ema.ema.nc == 3 and ema.ema.names == ["a", "b", "c"]

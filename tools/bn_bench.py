@@ -28,7 +28,7 @@ for (H, c, act) in [(320, 24, None), (160, 72, "silu"), (160, 48, None), (80, 19
 
     def fwd():
         ph[0] ^= 1
-        lib.check(L.maf_bn_forward(x.data_ptr(), c, M, c, lib.F16, g.data_ptr(), b.data_ptr(), 1e-3, 0.03, rm.data_ptr(), rv.data_ptr(), ACT[act],
+        lib.check(L.maf_bn_forward(x.data_ptr(), c, M, c, lib.F16, g.data_ptr(), b.data_ptr(), 1e-3, 0.03, rm.data_ptr(), rv.data_ptr(), None, ACT[act],
                                    y.data_ptr(), c, stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), R, ph[0], st))
 
     def bwd():
