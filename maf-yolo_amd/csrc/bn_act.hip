@@ -49,82 +49,82 @@ constexpr int kMaxR = 16;                                            // replicas
 constexpr int kU = 4;                                                // independent 16-byte loads in flight per lane and tensor
 
 // BWD = false: part += {sum x, sum x^2};  BWD = true: part += {sum g, sum g*xhat}
-// thread = one N-channel group x a strided set of pixels.  Reduction: across the lanes of a wave that hold the same channel group
-// (xor shuffles, when the group count is a power of two), then LDS atomics, then one global atomic per (channel, statistic) into
-// replica blockIdx.x % R
+// workgroup = a SLICE of at most 8 channel groups (blockIdx.y; 128 B of a pixel row) x a chunk of pixels (blockIdx.x); thread = one
+// N-channel group x a strided set of the chunk's pixels.  Reduction: across the lanes of a wave that hold the same channel group (xor
+// shuffles, when the slice has a power-of-two group count), LDS atomics, then one global atomic per (channel, statistic) into replica
+// blockIdx.x % R.  The global atomics are what bounds this kernel when a workgroup sees too few pixels (~40 G atomics/s chip-wide
+// measured, i.e. 2C atomics cost as much as streaming ~250 B per channel): slicing the channels keeps >= 512 pixels per workgroup for
+// any C at >= 2 workgroups per CU.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
-    extern __shared__ float lsum[];                                   // [2][C]
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) lsum[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float lsum[];                                   // [2][gs * N]
     const int groups = a.C / N;
-    const int gpb = groups < 256 ? groups : 256;                     // channel groups handled per pass
-    const int plan = 256 / gpb;                                      // pixel lanes
+    const int gs = (groups + gridDim.y - 1) / gridDim.y;             // channel groups per slice
+    const int gbeg = blockIdx.y * gs, gcnt = min(gs, groups - gbeg);
+    const int cs = gs * N;                                           // channels per slice (LDS row)
+    for (int i = threadIdx.x; i < 2 * cs; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    const int plan = 256 / gs;                                       // pixel lanes
     const int chunk = (a.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * chunk, m1 = min(a.M, m0 + chunk);
-    const bool wave_reduce = gpb < 64 && (gpb & (gpb - 1)) == 0;     // lane % gpb == channel group for every wave
+    const bool wave_reduce = gs < 64 && (gs & (gs - 1)) == 0;        // lane % gs == channel group for every wave
     const T* xp = static_cast<const T*>(a.x);
     const T* dp = static_cast<const T*>(a.dz);
-    for (int g0 = 0; g0 < groups; g0 += gpb) {
-        const int gi = g0 + threadIdx.x % gpb, pl = threadIdx.x / gpb;
-        const bool active = gi < groups && pl < plan;
-        float s0[N], s1[N], mu[N], rs[N], ga[N], be[N];
+    const int gl = threadIdx.x % gs, pl = threadIdx.x / gs, gi = gbeg + gl;
+    const bool active = gl < gcnt && pl < plan;
+    float s0[N], s1[N], mu[N], rs[N], ga[N], be[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            s0[j] = s1[j] = 0.f;
-            if (BWD && active) { mu[j] = a.mean[gi * N + j]; rs[j] = a.rstd[gi * N + j]; ga[j] = a.gamma[gi * N + j]; be[j] = a.beta[gi * N + j]; }
-        }
-        auto accum = [&](const V& xv, const V& dv) {
-            if (!BWD) {
+    for (int j = 0; j < N; ++j) {
+        s0[j] = s1[j] = 0.f;
+        if (BWD && active) { mu[j] = a.mean[gi * N + j]; rs[j] = a.rstd[gi * N + j]; ga[j] = a.gamma[gi * N + j]; be[j] = a.beta[gi * N + j]; }
+    }
+    auto accum = [&](const V& xv, const V& dv) {
+        if (!BWD) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) { const float f = (float)xv[j]; s0[j] += f; s1[j] = __builtin_fmaf(f, f, s1[j]); }
-            } else {
+            for (int j = 0; j < N; ++j) { const float f = (float)xv[j]; s0[j] += f; s1[j] = __builtin_fmaf(f, f, s1[j]); }
+        } else {
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const float xh = ((float)xv[j] - mu[j]) * rs[j];
-                    const float gq = (float)dv[j] * act_grad(__builtin_fmaf(xh, ga[j], be[j]), a.act);
-                    s0[j] += gq; s1[j] = __builtin_fmaf(gq, xh, s1[j]);
-                }
-            }
-        };
-        if (active) {
-            int m = m0 + pl;
-            for (; m + (kU - 1) * plan < m1; m += kU * plan) {
-                V xv[kU], dv[kU];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    xv[u] = *reinterpret_cast<const V*>(xp + (size_t)(m + u * plan) * a.xs + gi * N);
-                    if (BWD) dv[u] = *reinterpret_cast<const V*>(dp + (size_t)(m + u * plan) * a.dzs + gi * N);
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) accum(xv[u], dv[u]);
-            }
-            for (; m < m1; m += plan) {
-                const V xv = *reinterpret_cast<const V*>(xp + (size_t)m * a.xs + gi * N);
-                V dv = xv;
-                if (BWD) dv = *reinterpret_cast<const V*>(dp + (size_t)m * a.dzs + gi * N);
-                accum(xv, dv);
+            for (int j = 0; j < N; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                const float gq = (float)dv[j] * act_grad(__builtin_fmaf(xh, ga[j], be[j]), a.act);
+                s0[j] += gq; s1[j] = __builtin_fmaf(gq, xh, s1[j]);
             }
         }
-        if (wave_reduce) {
-            for (int off = gpb; off < 64; off <<= 1) {
+    };
+    if (active) {
+        int m = m0 + pl;
+        for (; m + (kU - 1) * plan < m1; m += kU * plan) {
+            V xv[kU], dv[kU];
 #pragma unroll
-                for (int j = 0; j < N; ++j) { s0[j] += __shfl_xor(s0[j], off, 64); s1[j] += __shfl_xor(s1[j], off, 64); }
+            for (int u = 0; u < kU; ++u) {
+                xv[u] = *reinterpret_cast<const V*>(xp + (size_t)(m + u * plan) * a.xs + gi * N);
+                if (BWD) dv[u] = *reinterpret_cast<const V*>(dp + (size_t)(m + u * plan) * a.dzs + gi * N);
             }
-            if (active && (threadIdx.x & 63) < gpb) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) { atomicAdd(&lsum[gi * N + j], s0[j]); atomicAdd(&lsum[a.C + gi * N + j], s1[j]); }
-            }
-        } else if (active) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) { atomicAdd(&lsum[gi * N + j], s0[j]); atomicAdd(&lsum[a.C + gi * N + j], s1[j]); }
+            for (int u = 0; u < kU; ++u) accum(xv[u], dv[u]);
+        }
+        for (; m < m1; m += plan) {
+            const V xv = *reinterpret_cast<const V*>(xp + (size_t)m * a.xs + gi * N);
+            V dv = xv;
+            if (BWD) dv = *reinterpret_cast<const V*>(dp + (size_t)m * a.dzs + gi * N);
+            accum(xv, dv);
         }
     }
+    if (wave_reduce) {
+        for (int off = gs; off < 64; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { s0[j] += __shfl_xor(s0[j], off, 64); s1[j] += __shfl_xor(s1[j], off, 64); }
+        }
+    }
+    if (active && (!wave_reduce || (threadIdx.x & 63) < gs)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) { atomicAdd(&lsum[gl * N + j], s0[j]); atomicAdd(&lsum[cs + gl * N + j], s1[j]); }
+    }
     __syncthreads();
-    float* dst = a.part + (size_t)(blockIdx.x % a.R) * 2 * a.C;
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(dst + i, lsum[i]);
+    float* dst = a.part + (size_t)(blockIdx.x % a.R) * 2 * a.C + gbeg * N;
+    for (int i = threadIdx.x; i < gcnt * N; i += 256) { atomicAdd(dst + i, lsum[i]); atomicAdd(dst + a.C + i, lsum[cs + i]); }
 }
 
 // BWD = false: y = act(xhat*gamma + beta);  BWD = true: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)
@@ -239,11 +239,23 @@ int check_common(const void* x, int32_t xs, int32_t M, int32_t C, int32_t dtype,
     return 0;
 }
 
-// ~16 pixels per lane and pass; at most `cap` workgroups
+// ~16 pixels per lane and pass; at most `cap` workgroups.  (Measured: 4 pixels per lane — four times the workgroups — is SLOWER on
+// every shape, 17.6 -> 75 us on 32x20x20x768: the per-workgroup prologue / atomics, not the streaming loop, is the fixed cost.)
 int bn_grid(int M, int C, int dtype, int cap) {
     const int groups = C / (dtype == MAF_F16 ? 8 : 4), gpb = groups < 256 ? groups : 256, plan = 256 / gpb;
     const long long g = ((long long)M + (long long)plan * 16 - 1) / ((long long)plan * 16);
     return (int)(g < 1 ? 1 : g > cap ? cap : g);
+}
+
+// statistics pass: channel slices of <= 8 groups (blockIdx.y), 32 pixels per lane (16 when that leaves fewer than ~4 workgroups per CU)
+dim3 stats_grid(int M, int C, int dtype, size_t* lds) {
+    const int groups = C / (dtype == MAF_F16 ? 8 : 4), N = dtype == MAF_F16 ? 8 : 4;
+    const int nslice = (groups + 7) / 8, gs = (groups + nslice - 1) / nslice, plan = 256 / gs;
+    long long gx = ((long long)M + plan * 32 - 1) / (plan * 32);
+    if (gx * nslice < 1024) gx = ((long long)M + plan * 16 - 1) / (plan * 16);
+    if (gx > 4096) gx = 4096;
+    *lds = (size_t)2 * gs * N * sizeof(float);
+    return dim3((unsigned)(gx < 1 ? 1 : gx), (unsigned)nslice);
 }
 
 void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
@@ -273,9 +285,11 @@ extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_
     a.mean = save_mean; a.rstd = save_rstd; a.gamma = gamma; a.beta = beta;
     a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.counter = reinterpret_cast<long long*>(num_batches_tracked);
     set_halves(a, part, C, R, phase);
-    const int gs = bn_grid(M, C, dtype, 2048), ga = bn_grid(M, C, dtype, 8192);
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), dim3(gs), dim3(256), (size_t)2 * C * sizeof(float), s, a);
-    else hipLaunchKernelGGL((bn_stats_kernel<float, false>), dim3(gs), dim3(256), (size_t)2 * C * sizeof(float), s, a);
+    size_t lds_s;
+    const dim3 gs = stats_grid(M, C, dtype, &lds_s);
+    const int ga = bn_grid(M, C, dtype, 8192);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
+    else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
     if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false>), dim3(ga), dim3(256), (size_t)2 * C * sizeof(float), s, a);
     else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(ga), dim3(256), (size_t)2 * C * sizeof(float), s, a);
     return maf_check_hip(hipGetLastError(), "bn_forward launch");
@@ -292,9 +306,11 @@ extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, 
     a.mean = const_cast<float*>(save_mean); a.rstd = const_cast<float*>(save_rstd); a.gamma = gamma; a.beta = beta;
     a.dgamma = dgamma; a.dbeta = dbeta;
     set_halves(a, part, C, R, phase);
-    const int gs = bn_grid(M, C, dtype, 2048), ga = bn_grid(M, C, dtype, 8192);
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), dim3(gs), dim3(256), (size_t)2 * C * sizeof(float), s, a);
-    else hipLaunchKernelGGL((bn_stats_kernel<float, true>), dim3(gs), dim3(256), (size_t)2 * C * sizeof(float), s, a);
+    size_t lds_s;
+    const dim3 gs = stats_grid(M, C, dtype, &lds_s);
+    const int ga = bn_grid(M, C, dtype, 8192);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), gs, dim3(256), lds_s, s, a);
+    else hipLaunchKernelGGL((bn_stats_kernel<float, true>), gs, dim3(256), lds_s, s, a);
     if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, true>), dim3(ga), dim3(256), (size_t)6 * C * sizeof(float), s, a);
     else hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(ga), dim3(256), (size_t)6 * C * sizeof(float), s, a);
     return maf_check_hip(hipGetLastError(), "bn_backward launch");

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maf_yolo_amd import lib  # noqa: E402
 
 L = lib.load()
