@@ -22,6 +22,7 @@ Extra objects in the line:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -238,6 +239,8 @@ def train_mode(args, torch, M, dev, rank, world, dist):
                 "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
                 "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3),
                 "by_kind": {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}}
+    if not math.isfinite(float(loss.detach())):
+        raise SystemExit("bench.py --train: the loss is not finite after %d steps — the run is invalid" % (args.warmup + args.steps))
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = train_cpu_baseline(args, torch, M)

@@ -40,6 +40,14 @@ def build_optimizer(model, lr0=0.01, momentum=0.937, weight_decay=5e-4, optim="S
         raise ValueError("unknown optimizer %r (SGD / Adam)" % (optim,))
     opt.add_param_group({"params": w, "weight_decay": weight_decay})
     opt.add_param_group({"params": b})
+    if fused and optim == "SGD" and momentum != 0:
+        # torch's fused SGD allocates the momentum buffers with empty_like on its first call and lets the kernel fill them (buf = grad);
+        # when the GradScaler skips that first step (found_inf — the normal start of an AMP run: the scale starts at 65536) the kernel
+        # returns early and every later step reads uninitialised memory as momentum (MAF-YOLO-m went to NaN at its first unskipped step).
+        # Zero buffers give the same arithmetic — first real step: buf = momentum * 0 + grad — without that hole.
+        for group in opt.param_groups:
+            for p in group["params"]:
+                opt.state[p]["momentum_buffer"] = torch.zeros_like(p)
     return opt
 
 

@@ -497,3 +497,33 @@ def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp):
         for i, k in enumerate(g["bn_names"].tolist()):
             np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn%d" % i], rtol=(2e-3 if amp else 1e-5), atol=(2e-3 if amp else 1e-6), err_msg=k)
         assert int(sd["backbone.0.rbr_dense.bn.num_batches_tracked"]) == int(g["bn_tracked"])
+
+
+@pytest.mark.gpu
+def test_fused_sgd_survives_a_skipped_first_step():
+    """build_optimizer's fused SGD under a GradScaler whose first step is skipped (inf gradients): the momentum buffers must not be
+    uninitialised memory afterwards — after the first applied step buf == grad and the parameters follow the nesterov rule exactly."""
+    import importlib
+    M = importlib.import_module("maf-yolo_amd")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.Conv2d(16, 4, 1)).cuda()
+    opt = M.build_optimizer(net, lr0=0.1, momentum=0.9, weight_decay=0.0)
+    assert opt.param_groups[0]["fused"]
+    scaler = torch.amp.GradScaler("cuda", init_scale=4.0)
+    x = torch.randn(2, 8, 5, 5, device="cuda")
+    before = [p.detach().clone() for p in net.parameters()]
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(net(x).square().mean()).backward()
+        if it == 0:
+            next(net.parameters()).grad.fill_(float("inf"))          # step 0 is skipped
+        grads = [p.grad.detach().clone() / scaler.get_scale() for p in net.parameters()]
+        scaler.step(opt)
+        scaler.update()
+        if it == 0:
+            for p, b in zip(net.parameters(), before):
+                assert torch.equal(p, b)                             # skipped: nothing moved
+    for p, b, g in zip(net.parameters(), before, grads):
+        assert torch.isfinite(p).all()
+        assert torch.allclose(opt.state[p]["momentum_buffer"], g, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(p, b - 0.1 * (g + 0.9 * g), rtol=1e-5, atol=1e-7)       # nesterov, first applied step
