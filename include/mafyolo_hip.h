@@ -270,9 +270,10 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
                     void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase, maf_stream_t stream);
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
-/* General form: dW [Cout][Cin][k][k] (fp32, accumulated into) of a conv with k = 1 (stride 1 / 2, pad 0) or k = 3 (stride 2, pad 1) —
- * RepVGGBlock.rbr_dense / rbr_1x1 (common.py:202-203), ConvWrapper (:76-83): x [B,Hs,Ws,Cin], dy [B,Ho,Wo,Cout], fp16 NHWC views.  The taps are
- * gathered inside the kernel (no im2col tensor); inputs wider than 256 channels run as channel chunks. */
+/* General form: dW (fp32, accumulated into) of a conv with k = 1 (stride 1 / 2, pad 0) or k = 3 (stride 2, pad 1) — RepVGGBlock.rbr_dense /
+ * rbr_1x1 (common.py:202-203), ConvWrapper (:76-83): x [B,Hs,Ws,Cin], dy [B,Ho,Wo,Cout], fp16 NHWC views.  The taps are gathered inside the
+ * kernel (no im2col tensor); inputs wider than 256 channels run as channel chunks.
+ * Layout of dW: k = 1 -> [Cout][Cin];  k = 3 -> TAP-MAJOR [3][3][Cout][Cin] (the lanes of an atomic then share a cache line). */
 int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t Ho, int32_t Wo, int32_t Hs, int32_t Ws,
                    int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,

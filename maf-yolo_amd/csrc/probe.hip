@@ -82,3 +82,26 @@ extern "C" int maf_probe_valu(void* stream, int kind, int iters, int wgs_per_cu,
     (void)hipFree(out); (void)hipFree(cyc);
     return rc;
 }
+
+// ds_read_b64_tr_b16 semantics probe (tools/tr_probe.py): LDS half i holds the value i; lane l reads at byte address addr[l];
+// out[l][0..3] = the four 16-bit values the lane receives.
+namespace {
+__global__ __launch_bounds__(64) void tr_probe_kernel(const int* addr, unsigned short* out) {
+    __shared__ __attribute__((aligned(16))) unsigned short img[8192];
+    for (int i = threadIdx.x; i < 8192; i += 64) img[i] = (unsigned short)i;
+    __syncthreads();
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    const unsigned a = (unsigned)(size_t)(&img[0]) + (unsigned)addr[threadIdx.x];
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    out[threadIdx.x * 4 + 0] = (unsigned short)(v[0] & 0xffff);
+    out[threadIdx.x * 4 + 1] = (unsigned short)(v[0] >> 16);
+    out[threadIdx.x * 4 + 2] = (unsigned short)(v[1] & 0xffff);
+    out[threadIdx.x * 4 + 3] = (unsigned short)(v[1] >> 16);
+}
+}  // namespace
+
+extern "C" int maf_probe_tr(void* stream, const int* addr_dev, unsigned short* out_dev) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), addr_dev, out_dev);
+    return maf_check_hip(hipGetLastError(), "tr probe launch");
+}

@@ -160,10 +160,13 @@ Tensor conv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t ksize, int64_
     TORCH_CHECK(x.scalar_type() == at::kHalf && dy.scalar_type() == at::kHalf, "conv_wgrad: fp16 activations and gradients (the fp32 parity mode uses the framework's GEMM)");
     const int64_t cout = dy.size(1), co = (cout + 7) / 8 * 8;
     if (co != cout) dy = at::constant_pad_nd(dy, {0, 0, 0, 0, 0, co - cout}).contiguous(at::MemoryFormat::ChannelsLast);
-    Tensor dw = at::zeros({co, x.size(1), ksize, ksize}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
+    // the kernel's 3x3 result is tap-major [3][3][Cout][Cin] (csrc/wgrad.hip): permuted to the framework's layout below
+    Tensor dw = ksize == 1 ? at::zeros({co, x.size(1), 1, 1}, x.options().dtype(at::kFloat).memory_format(c10::nullopt))
+                           : at::zeros({ksize, ksize, co, x.size(1)}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
     check(maf_conv_wgrad(x.data_ptr(), (int)x.stride(3), dy.data_ptr(), (int)dy.stride(3), (int)x.size(0), (int)dy.size(2), (int)dy.size(3), (int)x.size(2), (int)x.size(3),
                          (int)x.size(1), (int)co, (int)ksize, (int)stride, MAF_F16, dw.data_ptr<float>(), stream_of(x)), "conv_wgrad");
-    return dw.narrow(0, 0, cout).narrow(1, 0, x_in.size(1));
+    if (ksize != 1) dw = dw.permute({2, 3, 0, 1});
+    return dw.narrow(0, 0, cout).narrow(1, 0, x_in.size(1)).contiguous();
 }
 
 Tensor dw_launch(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act, int flip) {

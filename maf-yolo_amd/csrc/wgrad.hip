@@ -1,183 +1,204 @@
-// Weight gradient of the 1x1 convolutions of the train-form graph:  dW[co][ci] = sum over pixels m of dY[m][co] * X[m][ci].
+// Weight gradient of the dense convolutions of the train-form graph:  dW[co][ci] = sum over pixels m of dY[m][co] * X[m][ci].
 //
 // Backward of nn.Conv2d(k=1) inside Conv / Head_DepthUni (yolov6/layers/common.py:29-50, 1331-1335) as the reference's
 // autograd computes it in Trainer.train_in_steps (yolov6/core/engine.py:152-160).  As a GEMM it has a tiny output
-// (Cout x Cin <= 576 x 576) and a reduction over up to 819 200 pixels; vendor TN GEMMs spend ~1 ms on it.  Here the
-// pixel range is cut into chunks (one workgroup each, >= 1 per CU), a chunk is walked 64 pixels at a time: both NHWC tiles
-// are transposed into LDS ([channel][pixel], so that an MFMA operand — 8 consecutive k = pixels of one channel — is ONE
-// 16-byte LDS read), every wave owns a set of 16 x 16 output tiles whose accumulators stay in registers for the whole
-// chunk, and the partial dW of the chunk is added to the fp32 result with atomics.  fp16 operands, fp32 accumulation.
+// (Cout x Cin <= 576 x 576) and a reduction over up to 819 200 pixels; vendor TN GEMMs spend ~0.5 ms on it.  Here the
+// pixel range is cut into chunks (one workgroup each), a chunk is walked 64 pixels at a time, every wave owns a block of
+// 16 x 16 output tiles whose accumulators stay in registers for the whole chunk, and the partial dW of the chunk is added
+// to the fp32 result with atomics.  fp16 operands, fp32 accumulation.
 //
 // The same kernel is the weight gradient of the stride-2 convs (RepVGGBlock.rbr_dense / rbr_1x1 common.py:202-203, ConvWrapper :76-83):
 // blockIdx.z walks the taps, and the X tile of tap (ky, kx) is gathered from pixel (2 oy - 1 + ky, 2 ox - 1 + kx) of the full-resolution
-// input (zeros outside the image) while it is transposed into LDS — no im2col tensor, no per-tap copies.  Inputs wider than 256
+// input (zeros outside the image) while it is staged — no im2col tensor, no per-tap copies.  The 3x3 result is TAP-MAJOR,
+// [ky][kx][Cout][Cin]: the 16 lanes of an atomic instruction then hit one 64-byte line instead of 16 lines 36 bytes apart (the
+// [Cout][Cin][3][3] layout made the atomics, not the streaming, the bound: 7 us per pixel chunk on 192 -> 192).  Inputs wider than 256
 // channels are cut into channel chunks by the host wrapper (the LDS tile holds one chunk).
+//
+// NO transposing stores: both tiles stay in their NHWC orientation in LDS ([pixel][channel], 16-byte stores of what the 16-byte
+// global loads returned) and the MFMA operands — 8 consecutive k = pixels of ONE channel per lane — come out of gfx950's transposing
+// LDS read: ds_read_b64_tr_b16, where lane p of a 16-lane group passes the address of (row k0 + (p >> 2), columns 4 (p & 3) ..) and
+// receives (rows k0 .. k0 + 3, column p)  [tools/tr_probe.py].  (The first version transposed while staging — eight 2-byte LDS
+// stores per 16 bytes loaded — and ran at half the speed on every shape.)  The wave grid is WI x WJ (WI * WJ = 4): wave (wi, wj) owns
+// the TI x NJ block of output tiles at (co tile wi*TI, ci tile wj*NJ), so one k-slab costs TI + NJ operand fetches for TI * NJ MFMAs;
+// the tiles of pixel step s + 1 are loaded into registers before the MFMAs of step s and written to LDS after them.
+#include <cmath>
 #include <cstdlib>
 #include "maf_common.h"
 
 namespace {
 
-struct WgArgs {
+constexpr int kPix = 64;              // pixels per staging step
+
+struct WgArgs2 {
     const half_t* x; const half_t* dy; float* dw;
     int M, Cin, Cout, x_stride, dy_stride;
     int chunk;            // pixels per workgroup (multiple of 64)
-    int co_blk;           // output-channel rows handled by one workgroup (blockIdx.y selects the block), multiple of 16
-    // tap gather (gather != 0): pixel m = (b, oy, ox) on the Ho x Wo grid of dY reads X at (2 oy - 1 + ky, 2 ox - 1 + kx) of the Hs x Ws grid
+    int WJ;               // waves along ci (1, 2, 4); WI = 4 / WJ along co
     int gather, Ho, Wo, Hs, Ws, tap0;
-    int dw_stride;        // row length of dW in (ci) elements
-    int dw_es;            // element stride between consecutive ci of one tap (k*k), the tap index is added
-    int tpw_taps;         // taps handled inside one workgroup (1, 3 or 9): dY is staged once per pixel step and reused for all of them
+    int dw_stride;        // floats between consecutive co rows of one tap
+    long long dw_tap;     // floats between consecutive taps (3x3: tap-major result)
 };
 
-constexpr int kPix = 64;              // pixels per staging step
-constexpr int kRow = kPix + 8;        // LDS row stride in halfs (144 B): rows start on different 16-byte bank slots
+typedef __fp16 tr4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) tr4_t* lds_tr_ptr;
 
-// TPW = 16 x 16 output tiles per wave
-template <int TPW>
-__global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
+__device__ __forceinline__ half8_t tr_frag(const half_t* lo, const half_t* hi) {          // k0 .. k0+3 | k0+4 .. k0+7 of the lane's channel
+    const tr4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(lo));
+    const tr4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(hi));
+    typedef __fp16 tr8_t __attribute__((__vector_size__(8 * sizeof(__fp16))));
+    const tr8_t v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8_t, v);
+}
+
+template <int TI, int NJ>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int XR = 2 * NJ, DR = 2 * TI;                               // 16-byte chunks a thread stages per step (upper bounds)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
-    const int cinp = (a.Cin + 15) & ~15;
-    const int co0 = blockIdx.y * a.co_blk;
-    const int cob = min(a.co_blk, ((a.Cout - co0) + 15) & ~15);          // padded rows of this block
-    half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [cinp][kRow]
-    half_t* Ds = Xs + (size_t)cinp * kRow;                               // [cob][kRow]
-    const int tci = cinp >> 4, tco = cob >> 4, ntile1 = tci * tco, ntile = ntile1 * a.tpw_taps;     // virtual tiles: (tap in workgroup, co tile, ci tile)
+    const int WJ = a.WJ, WI = 4 / WJ, wj = wave % WJ, wi = wave / WJ;
+    const int cib = WJ * NJ * 16, cob = WI * TI * 16;                    // channels of X / dY staged per step
+    const int SX = cib + 8, SD = cob + 8;                                // LDS row strides in halfs
+    const int co0 = blockIdx.y * cob;
+    half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [kPix][SX]
+    half_t* Ds = Xs + kPix * SX;                                         // [kPix][SD]
+    const int tap = a.tap0 + blockIdx.z, tky = tap / 3, tkx = tap - tky * 3;
 
-    f32x4_t acc[TPW];
+    // staging items of this thread: (row, 8-channel chunk), the same for every step
+    const int xg = cib >> 3, dg = cob >> 3;
+    int xrow[XR], xch[XR], drow[DR], dch[DR];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = (f32x4_t)0.f;
+    for (int u = 0; u < XR; ++u) { const int it = tid + 256 * u; xrow[u] = it / xg; xch[u] = (it - xrow[u] * xg) * 8; if (xrow[u] >= kPix) xrow[u] = -1; }
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { const int it = tid + 256 * u; drow[u] = it / dg; dch[u] = (it - drow[u] * dg) * 8; if (drow[u] >= kPix) drow[u] = -1; }
+
+    f32x4_t acc[TI][NJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t)0.f;
 
     const int m_begin = blockIdx.x * a.chunk, m_end = min(a.M, m_begin + a.chunk);
+    half8_t xr[XR], dr[DR];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int m = m0 + xrow[u];
+            if (xrow[u] >= 0 && m < m_end && xch[u] < a.Cin) {
+                if (!a.gather) {
+                    v = *reinterpret_cast<const half8_t*>(a.x + (size_t)m * a.x_stride + xch[u]);
+                } else {
+                    const int ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
+                    const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
+                    if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
+                        v = *reinterpret_cast<const half8_t*>(a.x + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + xch[u]);
+                }
+            }
+            xr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int m = m0 + drow[u];
+            if (drow[u] >= 0 && m < m_end && co0 + dch[u] < a.Cout) v = *reinterpret_cast<const half8_t*>(a.dy + (size_t)m * a.dy_stride + co0 + dch[u]);
+            dr[u] = v;
+        }
+    };
+    // per-lane operand addresses: row g*8 + (p >> 2), column 4 (p & 3) of the wave's first tile
+    const half_t* abase = Ds + (g * 8 + (p >> 2)) * SD + wi * TI * 16 + (p & 3) * 4;
+    const half_t* bbase = Xs + (g * 8 + (p >> 2)) * SX + wj * NJ * 16 + (p & 3) * 4;
+
+    fetch(m_begin);
     for (int m0 = m_begin; m0 < m_end; m0 += kPix) {
-      for (int tt = 0; tt < a.tpw_taps; ++tt) {
-        const int tap = a.tap0 + blockIdx.z * a.tpw_taps + tt, tky = tap / 3, tkx = tap - tky * 3;
-        __syncthreads();                                                 // previous step's MFMAs have read the tiles
-        // ---- stage: lane (g, p) of an item = pixel p of a 16-pixel group, channel chunk g of a 4-chunk group
-        {
-            const int xg = cinp >> 3;                                    // 8-channel chunks of X (incl. padding)
-            for (int it = tid; it < (kPix / 16) * ((xg + 3) >> 2) * 64; it += 256) {
-                const int l = it & 63, grp = it >> 6;
-                const int pg = grp % (kPix / 16), cq = grp / (kPix / 16);
-                const int px = pg * 16 + (l & 15), ch = (cq * 4 + (l >> 4)) * 8;
-                if (ch < cinp) {
-                    half8_t v = (half8_t)(half_t)0;
-                    if (m0 + px < m_end && ch < a.Cin) {
-                        if (!a.gather) {
-                            v = *reinterpret_cast<const half8_t*>(a.x + (size_t)(m0 + px) * a.x_stride + ch);
-                        } else {
-                            const int m = m0 + px, ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
-                            const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
-                            if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
-                                v = *reinterpret_cast<const half8_t*>(a.x + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + ch);
-                        }
-                    }
+        __syncthreads();                                                 // the MFMAs of the previous step have read the tiles
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Xs[(size_t)(ch + j) * kRow + px] = v[j];
-                }
-            }
-            const int dg = tt == 0 ? cob >> 3 : 0;                        // dY: once per pixel step, shared by the taps of this workgroup
-            for (int it = tid; it < (kPix / 16) * ((dg + 3) >> 2) * 64; it += 256) {
-                const int l = it & 63, grp = it >> 6;
-                const int pg = grp % (kPix / 16), cq = grp / (kPix / 16);
-                const int px = pg * 16 + (l & 15), ch = (cq * 4 + (l >> 4)) * 8;
-                if (ch < cob) {
-                    half8_t v = (half8_t)(half_t)0;
-                    if (m0 + px < m_end && co0 + ch < a.Cout) v = *reinterpret_cast<const half8_t*>(a.dy + (size_t)(m0 + px) * a.dy_stride + co0 + ch);
+        for (int u = 0; u < XR; ++u)
+            if (xrow[u] >= 0) *reinterpret_cast<half8_t*>(Xs + xrow[u] * SX + xch[u]) = xr[u];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Ds[(size_t)(ch + j) * kRow + px] = v[j];
-                }
-            }
-        }
+        for (int u = 0; u < DR; ++u)
+            if (drow[u] >= 0) *reinterpret_cast<half8_t*>(Ds + drow[u] * SD + dch[u]) = dr[u];
         __syncthreads();
-        // ---- MFMA: D[co][ci] += sum_k dY^T[co][k] X^T... A = rows of Ds (co), B = rows of Xs (ci), k = pixel
+        if (m0 + kPix < m_end) fetch(m0 + kPix);                         // in flight during the MFMAs below
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int vt = wave + 4 * t;
-            if (vt < ntile && vt / ntile1 == tt) {
-                const int tile = vt - tt * ntile1;
-                const int ti = tile / tci, tj = tile - ti * tci;
+        for (int ks = 0; ks < kPix / 32; ++ks) {
+            half8_t av[TI], bv[NJ];
 #pragma unroll
-                for (int ks = 0; ks < kPix / 32; ++ks) {
-                    const half8_t av = *reinterpret_cast<const half8_t*>(Ds + (size_t)(ti * 16 + p) * kRow + ks * 32 + g * 8);
-                    const half8_t bv = *reinterpret_cast<const half8_t*>(Xs + (size_t)(tj * 16 + p) * kRow + ks * 32 + g * 8);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
-                }
-            }
+            for (int i = 0; i < TI; ++i) av[i] = tr_frag(abase + (ks * 32) * SD + i * 16, abase + (ks * 32 + 4) * SD + i * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[j] = tr_frag(bbase + (ks * 32) * SX + j * 16, bbase + (ks * 32 + 4) * SX + j * 16);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-      }
     }
     // ---- accumulator lane (g, p): rows co = 4g + r, column ci = p of its tile
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int vt = wave + 4 * t;
-        if (vt >= ntile) continue;
-        const int tt = vt / ntile1, tile = vt - tt * ntile1;
-        const int tap = a.tap0 + blockIdx.z * a.tpw_taps + tt;
-        const int ti = tile / tci, tj = tile - ti * tci;
-        const int ci = tj * 16 + p;
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + ti * 16 + g * 4 + r;
-            if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((size_t)co * a.dw_stride + ci) * a.dw_es + (a.gather ? tap - a.tap0 : 0), acc[t][r]);
+        for (int j = 0; j < NJ; ++j) {
+            const int ci = (wj * NJ + j) * 16 + p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wi * TI + i) * 16 + g * 4 + r;
+                if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)(tap - a.tap0) * a.dw_tap + (size_t)co * a.dw_stride + ci, acc[i][j][r]);
+            }
         }
-    }
 }
 
-template <int T>
-int launch_wg(const WgArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int TI, int NJ>
+int launch_tr(const WgArgs2& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(wgrad)");
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(wgrad)");
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad1x1_kernel<T>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((wgrad_tr_kernel<TI, NJ>), grid, dim3(256), lds, s, a);
     return 0;
 }
 
 }  // namespace
 
-static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_stride, int M, int Cin, int Cout, float* dw, int dw_stride, int dw_es,
+// one launch over a channel chunk (Cin <= 256) of X; dw points at the chunk's first input channel, rows are dw_stride floats apart,
+// taps dw_tap floats apart
+static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_stride, int M, int Cin, int Cout, float* dw, int dw_stride, long long dw_tap,
                         int gather, int Ho, int Wo, int Hs, int Ws, int tap0, int ntaps, hipStream_t s) {
-    WgArgs a;
-    a.x = x; a.dy = dy; a.dw = dw;
-    a.M = M; a.Cin = Cin; a.Cout = Cout; a.x_stride = x_stride; a.dy_stride = dy_stride;
-    a.gather = gather; a.Ho = Ho; a.Wo = Wo; a.Hs = Hs; a.Ws = Ws; a.tap0 = tap0; a.dw_stride = dw_stride; a.dw_es = dw_es;
-    const int cinp = (Cin + 15) & ~15, tci = cinp / 16;
-    // rows of dW per workgroup: at most 16 tiles per wave (64 accumulator VGPRs) and 64 KiB of LDS together with X
-    int tco = (64 / tci) > 0 ? (64 / tci) : 1;
-    const int tco_all = (Cout + 15) / 16;
-    if (tco > tco_all) tco = tco_all;
-    while (tco > 1 && (size_t)(cinp + tco * 16) * kRow * 2 > 96 * 1024) --tco;
-    MAF_REQUIRE((size_t)(cinp + tco * 16) * kRow * 2 <= 160 * 1024, "conv wgrad: Cin chunk too large for the LDS tile");
-    a.co_blk = tco * 16;
-    const int gy = maf_cdiv(tco_all, tco);
-    // taps per workgroup: as many as the accumulator budget (16 tiles per wave) allows — dY is then read once for all of them
-    // (measured on MI355X, n bs 32: looping the 9 taps inside a workgroup — dY staged once — is 20 % SLOWER than one tap per workgroup
-    //  (5.1 vs 4.3 ms per step): the strided X gather dominates and nine times fewer workgroups hide its latency worse; kept selectable)
-    a.tpw_taps = 1;
-    if (ntaps == 9 && getenv("MAF_WGRAD_TAPS_IN_WG")) a.tpw_taps = tci * tco * 9 <= 64 ? 9 : tci * tco * 3 <= 64 ? 3 : 1;
-    const int gz = ntaps / a.tpw_taps;
-    int gx = 1024 / (gy * gz) > 0 ? 1024 / (gy * gz) : 1;              // ~4 workgroups per CU
+    WgArgs2 b;
+    b.x = x; b.dy = dy; b.dw = dw; b.M = M; b.Cin = Cin; b.Cout = Cout; b.x_stride = x_stride; b.dy_stride = dy_stride;
+    b.gather = gather; b.Ho = Ho; b.Wo = Wo; b.Hs = Hs; b.Ws = Ws; b.tap0 = tap0; b.dw_stride = dw_stride; b.dw_tap = dw_tap;
+    const int tci = (Cin + 15) / 16, tco_all = (Cout + 15) / 16;            // Cin <= 256: tci <= 16
+    b.WJ = tci >= 4 ? 4 : tci >= 2 ? 2 : 1;
+    const int NJ = (tci + b.WJ - 1) / b.WJ, WI = 4 / b.WJ;                 // 1 .. 4
+    const int want = (tco_all + WI - 1) / WI;
+    const int TI = want >= 3 ? 4 : want;                                   // 1, 2, 4 (16 accumulator tiles per wave at most)
+    const int gy = (tco_all + WI * TI - 1) / (WI * TI), gz = ntaps;
+    // Pixel chunks (grid x).  A chunk costs ~3 us per 64-pixel step it walks and, at its end, Cout * Cin atomics per tap at ~120 G/s
+    // chip-wide: T(gx) ~ steps / gx * 3 us + gx * atomics / 120 G/s is smallest at gx = sqrt(steps * 3 us * 120 G/s / atomics); no more
+    // workgroups than ~4 per CU (tools/wgrad_sweep.py: 20x20 768 -> 384 wants 32 chunks, 80x80 256 -> 128 wants 256, 160x160 72 -> 48 all it can get)
     const int steps = maf_cdiv(M, kPix);
+    const double atomics = (double)(tco_all * 16) * (tci * 16);
+    int gx = (int)std::sqrt((double)steps * 3.0 * 120e3 / atomics);
+    const int fill = 1024 / (gy * gz) > 0 ? 1024 / (gy * gz) : 1;
+    if (gx > fill) gx = fill;
+    if (const char* e = getenv("MAF_WGRAD_GX")) gx = atoi(e);              // tools/wgrad_sweep.py
     if (gx > steps) gx = steps;
-    a.chunk = maf_cdiv(steps, gx) * kPix;
-    gx = maf_cdiv(M, a.chunk);
-    const size_t lds = (size_t)(cinp + a.co_blk) * kRow * 2;
-    const int tpw = maf_cdiv(tci * tco * a.tpw_taps, 4);
+    if (gx < 1) gx = 1;
+    b.chunk = maf_cdiv(steps, gx) * kPix;
+    gx = maf_cdiv(M, b.chunk);
+    const size_t lds = (size_t)kPix * (b.WJ * NJ * 16 + 8 + WI * TI * 16 + 8) * 2;
     const dim3 grid(gx, gy, gz);
-    int rc;
-    if (tpw <= 2) rc = launch_wg<2>(a, grid, lds, s);
-    else if (tpw <= 4) rc = launch_wg<4>(a, grid, lds, s);
-    else if (tpw <= 8) rc = launch_wg<8>(a, grid, lds, s);
-    else rc = launch_wg<16>(a, grid, lds, s);
+    int rc = -1;
+#define MAF_WG(T, N) if (TI == T && NJ == N) rc = launch_tr<T, N>(b, grid, lds, s);
+    MAF_WG(1, 1) MAF_WG(1, 2) MAF_WG(1, 3) MAF_WG(1, 4) MAF_WG(2, 1) MAF_WG(2, 2) MAF_WG(2, 3) MAF_WG(2, 4) MAF_WG(4, 1) MAF_WG(4, 2) MAF_WG(4, 3) MAF_WG(4, 4)
+#undef MAF_WG
     if (rc) return rc;
     return maf_check_hip(hipGetLastError(), "conv wgrad launch");
 }
 
-// dW [Cout][Cin][k][k] (fp32, ACCUMULATED into: zero it first) of a conv with kernel k in {1, 3}, stride in {1, 2} (k = 3 needs stride 2, pad 1;
-// k = 1 stride 2 is pad 0): x [B,Hs,Ws,Cin] NHWC with pixel stride x_stride, dy [B,Ho,Wo,Cout] with pixel stride dy_stride.
+// dW (fp32, ACCUMULATED into: zero it first) of a conv with kernel k in {1, 3}, stride in {1, 2} (k = 3 needs stride 2, pad 1; k = 1 stride 2
+// is pad 0): x [B,Hs,Ws,Cin] NHWC with pixel stride x_stride, dy [B,Ho,Wo,Cout] with pixel stride dy_stride.
+// Layout of dW: k = 1 -> [Cout][Cin];  k = 3 -> TAP-MAJOR [3][3][Cout][Cin] (permute(2, 3, 0, 1) gives the framework's [Cout][Cin][3][3]).
 extern "C" int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t Ho, int32_t Wo, int32_t Hs, int32_t Ws,
                               int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t dtype, float* dw, maf_stream_t stream) {
     MAF_REQUIRE(x && dy && dw && B > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad arguments");
@@ -193,7 +214,7 @@ extern "C" int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, i
     for (int c0 = 0; c0 < Cin; c0 += 256) {                             // the LDS tile holds <= 256 input channels
         const int cc = std::min(256, Cin - c0);
         int rc = wgrad_launch(static_cast<const half_t*>(x) + c0, x_stride, static_cast<const half_t*>(dy), dy_stride, M, cc, Cout,
-                              dw + (size_t)c0 * kk, Cin, kk, gather, Ho, Wo, Hs, Ws, tap0, kk, s);
+                              dw + c0, Cin, (long long)Cout * Cin, gather, Ho, Wo, Hs, Ws, tap0, kk, s);
         if (rc) return rc;
     }
     return 0;

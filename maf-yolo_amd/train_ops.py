@@ -252,10 +252,12 @@ def _wgrad(x, dy, dys, w, ksize, stride):
         if co != cout:                                                          # e.g. reg_pred: 68 channels, an odd class count
             dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
             dys = co
-        dwf = torch.zeros(co, cin, ksize, ksize, dtype=torch.float32, device=x.device)
+        dwf = torch.zeros((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)       # 3x3: tap-major (csrc/wgrad.hip)
         with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride)):
             lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
         stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
+        if ksize == 3:
+            dwf = dwf.permute(2, 3, 0, 1)
         return dwf[:cout].reshape(w.shape).to(w.dtype)
 
 
