@@ -6,7 +6,7 @@ synth = importlib.import_module("maf-yolo_amd.synth")
 B = 32
 dev = torch.device("cuda:0")
 model = M.Model("n"); model.load_state_dict(synth.synth_state_dict(model, "n", 0)); model = model.to(dev).train()
-opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+opt = M.build_optimizer(model, lr0=0.01)
 scaler = torch.amp.GradScaler("cuda")
 x = synth.synth_images(B, 640, seed=1).to(dev)
 g = torch.Generator().manual_seed(1)
