@@ -279,6 +279,25 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 
+/* Weight staging of a whole training step in one launch.  A descriptor transforms one fp32 weight tensor:
+ *   kind 0  dense conv weight [Cout][Cin][taps] (taps = 1 or 9) -> the MFMA fragment order of maf_pack_w1x1 with tile_c = CT; K runs
+ *           tap-major, every tap padded to Kp (a multiple of the k-step: 32 fp16 / 16 fp32), steps = taps * Kp / k-step for 3x3 and
+ *           ceil(K / k-step) for 1x1 (then Kp = steps * k-step); transpose = 1 packs W^T (the data gradient's operand)
+ *   kind 1  depth-wise kernel [C = Cout][taps = k*k] -> [k*k][C], flip = 1 reverses the taps (data gradient)
+ * total = packed elements, block0 = first block of the descriptor in the flattened grid (1024 elements per block; ascending),
+ * nblocks = sum of ceil(total / 1024).  The descriptor array lives in DEVICE memory. */
+typedef struct maf_pack_desc {
+    const void* src; void* dst;
+    int64_t total;
+    int32_t kind, dtype;
+    int32_t Cout, Cin, taps, transpose;
+    int32_t CT, steps, Kp, flip;
+    int32_t block0, reserved;
+} maf_pack_desc_t;
+int maf_pack_batch(const maf_pack_desc_t* descs_dev, int32_t n, int32_t nblocks, maf_stream_t stream);
+int32_t maf_pack_desc_size(void);
+
+
 /*
  * Post-NMS tail — replaces Evaler.scale_coords (yolov6/core/evaler.py:382-409, ratio_pad branch), box_convert
  * (:374-381) and the tensor part of convert_to_coco_format (:411-420) for a whole batch in one launch.

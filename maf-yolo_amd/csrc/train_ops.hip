@@ -42,6 +42,48 @@ __global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ 
     out[e] = (T)w[(size_t)c * kk + (flip ? kk - 1 - tap : tap)];
 }
 
+// All weight transforms of one training step in ONE launch (maf_pack_batch): the step needs every dense weight in fragment order twice
+// (forward, and transposed for the data gradient) and every depth-wise kernel twice (as is, and flipped) — ~250 launches of a few
+// microseconds each when issued per layer.  The descriptors live in device memory (the parameter addresses of a model do not change
+// from step to step); block b finds its descriptor by binary search over the descriptors' first-block numbers.
+__global__ __launch_bounds__(256) void pack_batch_kernel(const maf_pack_desc_t* __restrict__ descs, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                                 // last descriptor whose block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const maf_pack_desc_t d = descs[lo];
+    const float* __restrict__ w = static_cast<const float*>(d.src);
+    const long long e0 = ((long long)(blockIdx.x - d.block0) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long e = e0 + q;
+        if (e >= d.total) return;
+        float v = 0.f;
+        if (d.kind == 0) {                                            // dense: see pack_w1x1_kernel; K runs tap-major, every tap padded to Kp
+            const int CH = d.dtype == MAF_F16 ? 8 : 4;
+            const int j = (int)(e % CH);
+            long long t = e / CH;
+            const int lane = (int)(t % 64); t /= 64;
+            const int step = (int)(t % d.steps);
+            const int tile = (int)(t / d.steps);
+            const int g = lane >> 4, p = lane & 15;
+            const int nt = tile / d.CT, ct = tile - nt * d.CT;
+            const int chan = nt * 16 * d.CT + p * d.CT + ct;
+            const int kcol = step * (4 * CH) + g * CH + j;
+            const int tap = kcol / d.Kp, k = kcol - tap * d.Kp;
+            const int rows = d.transpose ? d.Cin : d.Cout, cols = d.transpose ? d.Cout : d.Cin;
+            if (chan < rows && k < cols && tap < d.taps)
+                v = d.transpose ? w[((size_t)k * d.Cin + chan) * d.taps + tap] : w[((size_t)chan * d.Cin + k) * d.taps + tap];
+        } else {                                                      // depth-wise: [C][kk] -> [kk][C], optionally flipped
+            const int c = (int)(e % d.Cout), tap = (int)(e / d.Cout);
+            v = w[(size_t)c * d.taps + (d.flip ? d.taps - 1 - tap : tap)];
+        }
+        if (d.dtype == MAF_F16) static_cast<half_t*>(d.dst)[e] = (half_t)v;
+        else static_cast<float*>(d.dst)[e] = v;
+    }
+}
+
 // Depth-wise weight gradient: dW[c][ky][kx] = sum_{b,y,x} dY[b,y,x,c] * X[b,y+ky-P,x+kx-P,c]   (zero padding).
 // Workgroup = one TH x TW tile of one image x one block of CB channels: the X halo tile and the dY tile are staged in
 // LDS once; each lane owns (16-byte channel group, tap) pairs, accumulates over the tile's pixels in fp32 and adds its
@@ -205,6 +247,14 @@ extern "C" int64_t maf_pack_w1x1_bytes(int32_t Cout, int32_t Cin, int32_t transp
     const int CH = dtype == MAF_F16 ? 8 : 4, KS = 4 * CH;
     return (int64_t)maf_cdiv(rows, 16 * tile_c) * tile_c * maf_cdiv(cols, KS) * 64 * 16;
 }
+
+extern "C" int maf_pack_batch(const maf_pack_desc_t* descs_dev, int32_t n, int32_t nblocks, maf_stream_t stream) {
+    MAF_REQUIRE(descs_dev && n > 0 && nblocks > 0, "pack_batch: bad arguments");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), descs_dev, n);
+    return maf_check_hip(hipGetLastError(), "pack_batch launch");
+}
+
+extern "C" int32_t maf_pack_desc_size(void) { return (int32_t)sizeof(maf_pack_desc_t); }
 
 extern "C" int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream) {
     MAF_REQUIRE(w && out && C > 0 && k > 0, "pack_dw: bad arguments");

@@ -17,7 +17,7 @@ from operator import attrgetter
 import torch
 import torch.nn as nn
 
-from . import arch, lib
+from . import arch, lib, train_ops
 from .engine import Plan
 from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Concat, Head_DepthUni, Out)
 
@@ -134,6 +134,7 @@ class Model(nn.Module):
         self._plans = {}
         self._plans_version = None
         self._fp_tensors = None
+        self._pack_plan = None                 # training: the staged weight transforms point at the old parameter storage
 
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .float() / .half()-style conversions replace buffers and parameter storage (yolo.py:211-215 moves
@@ -163,6 +164,7 @@ class Model(nn.Module):
     def __deepcopy__(self, memo):
         plans, self._plans = self._plans, {}
         fpt, self._fp_tensors = self._fp_tensors, None
+        pp, self._pack_plan = getattr(self, "_pack_plan", None), None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -170,17 +172,20 @@ class Model(nn.Module):
             for k, v in self.__dict__.items():
                 new.__dict__[k] = copy.deepcopy(v, memo)
         finally:
-            self._plans, self._fp_tensors = plans, fpt
+            self._plans, self._fp_tensors, self._pack_plan = plans, fpt, pp
         return new
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_plans"] = {}
-        d["_fp_tensors"] = d["_plans_version"] = None
+        d["_fp_tensors"] = d["_plans_version"] = d["_pack_plan"] = None
         return d
 
     # ------------------------------------------------------------------ forward
     def _forward_train_form(self, x):
+        if getattr(self, "_pack_plan", None) is None:
+            self._pack_plan = train_ops.PackPlan()
+        train_ops.begin_step(self._pack_plan, x.device)          # every weight transform of the step in one launch (train_ops.PackPlan)
         y = []
         for nd, m in zip(self.nodes, self.backbone):
             if nd.i > 0:

@@ -166,24 +166,131 @@ def _ok(x, cin_mult):
     return x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % cin_mult == 0
 
 
+_op_cache = {}                         # launch descriptors by geometry: only the pointers change from call to call (a ctypes field store is ~0.2 us)
+
+
 def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
-    op = lib.MafOp()
-    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
-    op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, cin, cout, 1
-    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, xs, 0, lib.SRC_DIRECT
-    op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
-    op.tile_p, op.tile_c = pack.tile_for(cout, B * H * W)[0], ct
-    op.w, op.bias = wp.data_ptr(), bias.data_ptr()
+    ys = out.stride()[3]
+    key = (1, dt, B, H, W, cin, cout, ct, xs, ys)
+    op = _op_cache.get(key)
+    if op is None:
+        op = _op_cache[key] = lib.MafOp()
+        op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
+        op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, cin, cout, 1
+        op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = cin, xs, 0, lib.SRC_DIRECT
+        op.out_stride, op.out_coff = ys, 0
+        op.tile_p, op.tile_c = pack.tile_for(cout, B * H * W)[0], ct
+    op.src[0].ptr, op.out, op.w, op.bias = x.data_ptr(), out.data_ptr(), wp.data_ptr(), bias.data_ptr()
+    if profile is None:
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        return
     es = x.element_size()
     with _prof("conv1x1", B * H * W * (cin + cout) * es + cin * cout * es, x.device):
         lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
 
 
-def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev):
-    n = lib.load().maf_pack_w1x1_bytes(cout, cin, transpose, dt, ct)
-    buf = torch.empty(n, dtype=torch.uint8, device=dev)
-    lib.check(lib.load().maf_pack_w1x1(w2d.data_ptr(), cout, cin, transpose, dt, ct, buf.data_ptr(), _stream(dev)))
-    return buf
+class PackPlan:
+    """Weight staging plan of one training model (model.py creates one per Model and calls `begin_step` at the start of every train-form
+    forward).  A step needs every dense weight in MFMA fragment order twice (forward; transposed for the data gradient) and every depth-wise
+    kernel twice (as is; flipped): ~250 pack launches of a few microseconds when issued per layer.  The plan remembers each transform the
+    layers asked for (source parameter, geometry, a persistent destination) in a descriptor table on the device, and `begin_step` runs ALL
+    of them in one launch (csrc/train_ops.hip maf_pack_batch).  A layer gets the staged buffer when the parameter's version counter still
+    is the one the batch saw; otherwise — first step, weights edited since, layers called without a Model — it packs by itself, as before."""
+
+    def __init__(self):
+        self.entries = {}                    # key -> [param, dst, desc fields, version at the last pack]
+        self.table = None
+        self.nblocks = 0
+        self.dirty = False
+
+    def clear(self):
+        self.__init__()
+
+
+_plan = None
+
+
+def begin_step(plan, dev):
+    """Make `plan` the current one and stage every weight it knows in one launch on the current stream of `dev`."""
+    global _plan
+    _plan = plan
+    if plan is None or not plan.entries or dev.type != "cuda":
+        return
+    ents = list(plan.entries.values())
+    if plan.dirty or plan.table is None:
+        arr = (lib.MafPackDesc * len(ents))()
+        blk = 0
+        for d, e in zip(arr, ents):
+            f = e[2]
+            d.src, d.dst, d.total = e[0].data_ptr(), e[1].data_ptr(), f["total"]
+            d.kind, d.dtype, d.Cout, d.Cin, d.taps, d.transpose = f["kind"], f["dtype"], f["Cout"], f["Cin"], f["taps"], f["transpose"]
+            d.CT, d.steps, d.Kp, d.flip, d.block0 = f["CT"], f["steps"], f["Kp"], f["flip"], blk
+            blk += -(-f["total"] // 1024)
+        assert C.sizeof(lib.MafPackDesc) == lib.load().maf_pack_desc_size()
+        plan.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        plan.nblocks = blk
+        plan.dirty = False
+    lib.check(lib.load().maf_pack_batch(plan.table.data_ptr(), len(ents), plan.nblocks, _stream(dev)))
+    for e in ents:
+        e[3] = e[0]._version
+    stats["pack_batches"] = stats.get("pack_batches", 0) + 1
+
+
+def _hit(param, key):
+    """The staged buffer of transform `key` of `param` if this step's batch filled it (the fast path of every layer call), else None."""
+    plan = _plan
+    if plan is None:
+        return None
+    e = plan.entries.get((param.data_ptr(),) + key)
+    if e is not None and e[3] == param._version:                              # (the entry keeps its source alive: same address == same storage)
+        return e[1]
+    return None
+
+
+def _staged(param, key, nbytes, fields, pack_now):
+    """The packed form `key` of `param`: the plan's buffer when the batch of this step filled it, else pack_now(dst) into it (and remember
+    the transform for the next step); without a plan a fresh buffer."""
+    plan = _plan
+    if plan is None:
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=param.device)
+        pack_now(dst)
+        return dst
+    k = (param.data_ptr(),) + key
+    e = plan.entries.get(k)
+    if e is not None and e[3] == param._version:
+        return e[1]
+    if e is None:
+        if len(plan.entries) >= 4096:                                            # not a model's fixed set of parameters: start over
+            plan.clear()
+        e = plan.entries[k] = [param, torch.empty(nbytes, dtype=torch.uint8, device=param.device), fields, -1]
+        plan.dirty = True
+    pack_now(e[1])
+    e[3] = -1                                                                    # valid for this call only: the batch sets the version
+    return e[1]
+
+
+def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev, param=None):
+    """Fragment-packed [cout][cin] weight (transpose: its transpose, the data gradient's operand).  `param`: the parameter w2d is a view of
+    (same storage, fp32) — then the transform goes through the staging plan."""
+    if param is not None:
+        hit = _hit(param, ("d", cout, cin, 1, transpose, dt, ct))
+        if hit is not None:
+            return hit
+    L = lib.load()
+    n = L.maf_pack_w1x1_bytes(cout, cin, transpose, dt, ct)
+
+    def now(dst):
+        lib.check(L.maf_pack_w1x1(w2d.data_ptr(), cout, cin, transpose, dt, ct, dst.data_ptr(), _stream(dev)))
+
+    if param is None or w2d.data_ptr() != param.data_ptr() or param.dtype != torch.float32 or not param.is_leaf:
+        buf = torch.empty(n, dtype=torch.uint8, device=dev)
+        now(buf)
+        return buf
+    ks = 32 if dt == lib.F16 else 16
+    steps = -(-(cout if transpose else cin) // ks)
+    fields = dict(kind=0, dtype=dt, Cout=cout, Cin=cin, taps=1, transpose=transpose, CT=ct, steps=steps, Kp=steps * ks, flip=0,
+                  total=n // (2 if dt == lib.F16 else 4))
+    return _staged(param, ("d", cout, cin, 1, transpose, dt, ct), n, fields, now)
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -193,12 +300,14 @@ class _Conv1x1(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = w.shape[0]
         dt = _DT[x.dtype]
-        w2d = w.detach().reshape(cout, cin).float().contiguous()
         co = -(-cout // 4) * 4                                                   # the kernel stores 4 channels at a time: any class count
-        if co != cout:                                                           # (cls_pred with nc % 4 != 0) runs with zero filters appended
-            w2d = F.pad(w2d, (0, 0, 0, co - cout))
         ct = pack.tile_for(co, B * H * W)[1]
-        wp = _packed_1x1(w2d, co, cin, 0, dt, ct, x.device)
+        wp = _hit(w, ("d", co, cin, 1, 0, dt, ct)) if co == cout else None       # staged by this step's batch (PackPlan)
+        if wp is None:
+            w2d = w.detach().reshape(cout, cin).float().contiguous()
+            if co != cout:                                                       # (cls_pred with nc % 4 != 0) runs with zero filters appended
+                w2d = F.pad(w2d, (0, 0, 0, co - cout))
+            wp = _packed_1x1(w2d, co, cin, 0, dt, ct, x.device, w if co == cout else None)
         npad = -(-co // (16 * ct)) * 16 * ct
         if bias is None:
             bp = _zero_bias(x.device, npad)
@@ -232,16 +341,18 @@ class _Conv1x1(torch.autograd.Function):
                 dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
-            w2d = w.detach().reshape(cout, cin).float().contiguous()
             mult = 8 if x.dtype == torch.float16 else 4
             dyk, dyks, kk = dy, dys, cout
-            if cout % mult:                                                      # e.g. reg_pred: 68 channels in fp16
-                kk = -(-cout // mult) * mult                                     # zero-pad the reduction dim to whole 16-byte chunks
-                dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
-                dyks = kk
-                w2d = F.pad(w2d, (0, 0, 0, kk - cout))
             ct = pack.tile_for(cin, B * H * W)[1]
-            wp = _packed_1x1(w2d, kk, cin, 1, dt, ct, x.device)                  # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci]
+            wp = _hit(w, ("d", cout, cin, 1, 1, dt, ct)) if cout % mult == 0 else None
+            if wp is None:
+                w2d = w.detach().reshape(cout, cin).float().contiguous()
+                if cout % mult:                                                  # e.g. reg_pred: 68 channels in fp16
+                    kk = -(-cout // mult) * mult                                 # zero-pad the reduction dim to whole 16-byte chunks
+                    dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
+                    dyks = kk
+                    w2d = F.pad(w2d, (0, 0, 0, kk - cout))
+                wp = _packed_1x1(w2d, kk, cin, 1, dt, ct, x.device, w if kk == cout else None)   # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci]
             npad = -(-cin // (16 * ct)) * 16 * ct
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
@@ -278,14 +389,29 @@ def _tile_dgrad(n, m_pixels):
 
 
 def _packed_3x3(w, transpose, dt, ct, dev):
-    """Fragment-packed 3x3 weights on the device: tap-major K, every tap padded to whole k-steps == one [N, 9*Kp] matrix for maf_pack_w1x1.
-    transpose: the data gradient's operand (N = the forward conv's input channels, K = its output channels)."""
+    """Fragment-packed 3x3 weights on the device: tap-major K, every tap padded to whole k-steps == one [N, 9*Kp] matrix in the order of
+    maf_pack_w1x1.  transpose: the data gradient's operand (N = the forward conv's input channels, K = its output channels)."""
+    cout, cin = w.shape[0], w.shape[1]
+    hit = _hit(w, ("d", cout, cin, 9, int(transpose), dt, ct))
+    if hit is not None:
+        return hit
     ks = 32 if dt == lib.F16 else 16
-    m = w.detach().float().permute(1, 2, 3, 0) if transpose else w.detach().float().permute(0, 2, 3, 1)      # [N, 3, 3, K]
-    n, k = m.shape[0], m.shape[3]
+    n, k = (cin, cout) if transpose else (cout, cin)
     kp = -(-k // ks) * ks
-    big = F.pad(m, (0, kp - k)).reshape(n, 9 * kp).contiguous()
-    return _packed_1x1(big, n, 9 * kp, 0, dt, ct, dev)
+
+    def now(dst):
+        m = w.detach().float().permute(1, 2, 3, 0) if transpose else w.detach().float().permute(0, 2, 3, 1)      # [N, 3, 3, K]
+        big = F.pad(m, (0, kp - k)).reshape(n, 9 * kp).contiguous()
+        lib.check(lib.load().maf_pack_w1x1(big.data_ptr(), n, 9 * kp, 0, dt, ct, dst.data_ptr(), _stream(dev)))
+
+    nbytes = lib.load().maf_pack_w1x1_bytes(n, 9 * kp, 0, dt, ct)
+    if not (w.dtype == torch.float32 and w.is_contiguous() and w.is_leaf):        # a temporary (e.g. the stem's channel-padded filters): no plan entry
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        now(buf)
+        return buf
+    fields = dict(kind=0, dtype=dt, Cout=cout, Cin=cin, taps=9, transpose=int(transpose), CT=ct, steps=9 * kp // ks, Kp=kp, flip=0,
+                  total=nbytes // (2 if dt == lib.F16 else 4))
+    return _staged(w, ("d", cout, cin, 9, int(transpose), dt, ct), nbytes, fields, now)
 
 
 class _Conv3x3s2(torch.autograd.Function):
@@ -365,7 +491,7 @@ class _Conv1x1s2(torch.autograd.Function):
         Ho, Wo = H // 2, W // 2
         dt = _DT[x.dtype]
         pt, ct = pack.tile_for(cout, B * Ho * Wo)
-        wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 0, dt, ct, x.device)
+        wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 0, dt, ct, x.device, w)
         out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         op = lib.MafOp()
         op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
@@ -400,7 +526,7 @@ class _Conv1x1s2(torch.autograd.Function):
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
             ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
-            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device)
+            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device, w)
             dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
@@ -454,21 +580,39 @@ def conv1x1(x, w, bias=None):
 
 
 def _launch_dw(x, xs, wp, bias, B, H, W, c, k, out, dt):
-    op = lib.MafOp()
-    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_DWCONV, dt, dt, lib.ACT_NONE
-    op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc = B, H, W, c, c, k, 1
-    op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), c, xs, 0, lib.SRC_DIRECT
-    op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
-    op.w, op.bias = wp.data_ptr(), bias.data_ptr()
+    ys = out.stride()[3]
+    key = (2, dt, B, H, W, c, k, xs, ys)
+    op = _op_cache.get(key)
+    if op is None:
+        op = _op_cache[key] = lib.MafOp()
+        op.kind, op.dtype, op.in_dtype, op.act = lib.OP_DWCONV, dt, dt, lib.ACT_NONE
+        op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc = B, H, W, c, c, k, 1
+        op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = c, xs, 0, lib.SRC_DIRECT
+        op.out_stride, op.out_coff = ys, 0
+    op.src[0].ptr, op.out, op.w, op.bias = x.data_ptr(), out.data_ptr(), wp.data_ptr(), bias.data_ptr()
+    if profile is None:
+        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+        return
     with _prof("dwconv_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
         lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
 
 
 def _packed_dw(w, c, k, flip, dt, dev):
-    buf = torch.empty(c * k * k * (2 if dt == lib.F16 else 4), dtype=torch.uint8, device=dev)
-    wf = w.detach().reshape(c, k * k).float().contiguous()
-    lib.check(lib.load().maf_pack_dw(wf.data_ptr(), c, k, flip, dt, buf.data_ptr(), _stream(dev)))
-    return buf
+    hit = _hit(w, ("w", c, k, flip, dt))
+    if hit is not None:
+        return hit
+    nbytes = c * k * k * (2 if dt == lib.F16 else 4)
+
+    def now(dst):
+        wf = w.detach().reshape(c, k * k).float().contiguous()
+        lib.check(lib.load().maf_pack_dw(wf.data_ptr(), c, k, flip, dt, dst.data_ptr(), _stream(dev)))
+
+    if not (w.dtype == torch.float32 and w.is_contiguous() and w.is_leaf):
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        now(buf)
+        return buf
+    fields = dict(kind=1, dtype=dt, Cout=c, Cin=1, taps=k * k, transpose=0, CT=0, steps=0, Kp=0, flip=flip, total=c * k * k)
+    return _staged(w, ("w", c, k, flip, dt), nbytes, fields, now)
 
 
 class _DWConv(torch.autograd.Function):

@@ -527,3 +527,65 @@ def test_fused_sgd_survives_a_skipped_first_step():
         assert torch.isfinite(p).all()
         assert torch.allclose(opt.state[p]["momentum_buffer"], g, rtol=1e-6, atol=1e-8)
         assert torch.allclose(p, b - 0.1 * (g + 0.9 * g), rtol=1e-5, atol=1e-7)       # nesterov, first applied step
+
+
+@pytest.mark.gpu
+def test_weight_staging_plan_matches_per_layer_packing():
+    """train_ops.PackPlan: from the second step on every weight transform of the model comes out of ONE maf_pack_batch launch; the staged
+    buffers must be bit-identical to what the per-layer pack kernels produce, follow optimizer updates, and be dropped by .to() / invalidate."""
+    import importlib
+    M = importlib.import_module("maf-yolo_amd")
+    synth = importlib.import_module("maf-yolo_amd.synth")
+    train_ops = importlib.import_module("maf-yolo_amd.train_ops")
+    torch.manual_seed(0)
+    model = M.Model("n")
+    model.load_state_dict(synth.synth_state_dict(model, "n", 0))
+    model = model.cuda().train()
+    x = torch.rand(2, 3, 128, 128, device="cuda")
+
+    def run():
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = model(x)
+        (cls.float().mean() + reg.float().square().mean()).backward()
+        return cls.detach().float().clone(), [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]
+
+    train_ops.stats.pop("pack_batches", None)
+    c0, g0 = run()                                                    # step 1: the layers pack by themselves and register
+    plan = model._pack_plan
+    assert plan is not None and len(plan.entries) > 200 and train_ops.stats.get("pack_batches", 0) == 0
+    model.zero_grad(set_to_none=True)
+    c1, g1 = run()                                                    # step 2: one batch launch, same weights
+    assert train_ops.stats["pack_batches"] == 1
+    assert torch.allclose(c0, c1, rtol=0, atol=5e-4)                  # (BatchNorm sums are atomics: last-bit differences run to run)
+    L = M.lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    checked = 0
+    for (ptr, *key), (param, dst, f, ver) in plan.entries.items():
+        assert ver == param._version
+        ref = torch.empty_like(dst)
+        if f["kind"] == 0 and f["taps"] == 1:
+            M.lib.check(L.maf_pack_w1x1(param.data_ptr(), f["Cout"], f["Cin"], f["transpose"], f["dtype"], f["CT"], ref.data_ptr(), st))
+        elif f["kind"] == 1:
+            M.lib.check(L.maf_pack_dw(param.data_ptr(), f["Cout"], int(round(f["taps"] ** 0.5)), f["flip"], f["dtype"], ref.data_ptr(), st))
+        else:                                                         # 3x3: the torch permute + pad + 1x1 pack of the fallback path
+            plan_saved, train_ops._plan = train_ops._plan, None
+            ref = train_ops._packed_3x3(param, bool(f["transpose"]), f["dtype"], f["CT"], param.device)
+            train_ops._plan = plan_saved
+        assert torch.equal(ref, dst), key
+        checked += 1
+    assert checked == len(plan.entries)
+    with torch.no_grad():                                             # an optimizer-like in-place update: the next batch repacks it
+        for p in model.parameters():
+            p.mul_(0.5)
+    model.zero_grad(set_to_none=True)
+    c2, _ = run()
+    assert float((c1 - c2).abs().max()) > 2e-3
+    train_ops._plan = None
+    model2 = M.Model("n")
+    model2.load_state_dict(model.state_dict())
+    model2 = model2.cuda().train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        (f2, cls2, r2), _ = model2(x)                                  # fresh model, first step: per-layer packs of the same weights
+    assert torch.allclose(cls2.detach().float(), c2, rtol=0, atol=5e-4)
+    model.float()                                                     # _apply: the staged buffers point at storage that may be replaced
+    assert model._pack_plan is None

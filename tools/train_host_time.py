@@ -36,4 +36,14 @@ for _ in range(10): step()
 th = time.perf_counter() - t0
 torch.cuda.synchronize()
 tt = time.perf_counter() - t0
-print("host %.1f ms/step, total %.1f ms/step" % (th * 100, tt * 100), {k: round(v * 100, 2) for k, v in T.items()})
+print("back to back: host %.1f ms/step, total %.1f ms/step" % (th * 100, tt * 100), {k: round(v * 100, 2) for k, v in T.items()})
+# issue time of a step against an EMPTY queue (the host never waits for the GPU): synchronise before every step
+T.clear()
+iss = 0.0
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    iss += time.perf_counter() - t0
+torch.cuda.synchronize()
+print("issue only : host %.1f ms/step" % (iss * 100), {k: round(v * 100, 2) for k, v in T.items()})
