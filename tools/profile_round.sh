@@ -20,6 +20,8 @@ done
 python bench.py --train --scale n --batch 32 --steps 20 --warmup 5 > $OUT/train_n.json 2> $OUT/train_n.err; echo "train n rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python bench.py --train --scale n --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/train_stats.err
 echo "train rocprof rc=$?"
+python bench.py --train --scale s --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_s.json 2>/dev/null; echo "train s rc=$?"
+python bench.py --train --scale m --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_m.json 2>/dev/null; echo "train m rc=$?"
 python bench.py --latency --scale m --tune-file $TUNE > $OUT/latency_m.json 2>/dev/null; echo "latency m rc=$?"
 for s in s m; do python bench.py --scale $s --steps 30 --warmup 10 --no-cpu-baseline --tune-file $OUT/tune_$s.json > $OUT/bench_$s.json 2>/dev/null; echo "bench $s rc=$?"; done
 # keep the merge under the 64 MiB limit: traces are big, the stats are what gets committed
