@@ -6,6 +6,8 @@
 //            spatially flipped kernel (both weight transforms are done on the device by the pack kernels below, one launch);
 //   wgrad  = 1x1: a plain TN GEMM  dW = dY^T X  (left to hipBLASLt through torch.mm, as a plain library GEMM);
 //            depth-wise: dw_wgrad_kernel below (per-channel k*k reductions over all pixels; MIOpen's weak spot).
+#include <cstdio>
+#include <cstdlib>
 #include "maf_common.h"
 
 namespace {
@@ -86,19 +88,23 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const maf_pack_desc_t* 
 
 // Depth-wise weight gradient: dW[c][ky][kx] = sum_{b,y,x} dY[b,y,x,c] * X[b,y+ky-P,x+kx-P,c]   (zero padding).
 // Workgroup = one TH x TW tile of one image x one block of CB channels: the X halo tile and the dY tile are staged in
-// LDS once; each lane owns (16-byte channel group, tap) pairs, accumulates over the tile's pixels in fp32 and adds its
-// partial sums to dW with fp32 atomics (dW is zeroed by the caller).
+// LDS once; the partial sums reach dW with fp32 atomics (dW is zeroed by the caller).
 struct DwWgArgs {
     const void* x; const void* dy; float* dw;
-    int B, H, W, C, x_stride, dy_stride, TH, TW, CB, tilesX, tilesY, nCB, replicas;
+    int B, H, W, C, x_stride, dy_stride, TH, TW, CB, tilesX, tilesY, nCB, replicas, RSEG;
 };
 
-// Work item = (16-byte channel group, tap row ky, strip of S = 4 output columns): for every tile row it loads the S dY vectors
-// and the S + K - 1 X vectors of the strip once and performs S x K x 8 multiply-adds (fp16 products into fp32 accumulators,
-// v_fma_mix_f32): 2S + K - 1 LDS reads per 8*S*K FMAs instead of 2 per 8.  A workgroup owns one channel block and walks many
-// (image, tile) pairs; its K x N sums per item stay in registers and reach dW with one atomic round at the end.
+// Work item = (16-byte channel group, tap row ky, strip of S = 4 output columns, row segment): for each of its tile rows it loads the
+// S dY vectors and the S + K - 1 X vectors of the strip once and performs S x K x 8 multiply-adds (fp16 products into fp32
+// accumulators, v_fma_mix_f32): 2S + K - 1 LDS reads per 8*S*K FMAs instead of 2 per 8.  One item per lane; the row segments
+// (rows rseg, rseg + RSEG, ...) exist to give EVERY lane an item — groups x K x strips alone are 96 (k = 3) to 288 (k = 9) per
+// workgroup, which left 62 % of a 256-lane workgroup idle at k = 3 and made k = 9 take two rounds — and the block size is the item
+// count rounded up to whole waves.  With 4 (k >= 7) or 8 channel groups per block the tiles take <= 56 KB of LDS: 2-4 workgroups,
+// 3-5 waves per SIMD (one wave per SIMD issues a vector instruction only every ~6 cycles).  A workgroup owns one channel block and
+// walks many (image, tile) pairs; its K x N sums per item stay in registers, are summed over strips (lane shuffles) and row segments
+// (LDS atomics) at the end and reach dW with one global atomic per (channel, tap).
 template <typename T, typename V, int N, int K>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwWgArgs a) {
+__global__ __launch_bounds__(512) void dw_wgrad_kernel(const DwWgArgs a) {
     constexpr int P = K / 2, S = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     V* xt = reinterpret_cast<V*>(smem_raw);
@@ -108,51 +114,47 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwWgArgs a) {
     const int PS = a.CB / N + 1;                               // LDS pixel stride in vectors (+16 B pad)
     const int RH = a.TH + K - 1, RW = a.TW + K - 1;
     V* dt = xt + RH * RW * PS;                                 // [TH*TW][PS]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const T* xin = static_cast<const T*>(a.x) + c0;
     const T* dyin = static_cast<const T*>(a.dy) + c0;
-    const int nstrip = a.TW / S;                               // the launch uses TW = 16
-    const int items = CGB * K * nstrip;                        // <= 8 * 9 * 4 = 288: at most 2 per lane
-    constexpr int MAXIT = 2;
-    float acc[MAXIT][K][N];
+    const int nstrip = a.TW / S;
+    const int items = CGB * K * nstrip * a.RSEG;               // <= blockDim.x
+    const bool live = tid < items;
+    const int st = tid % nstrip, r2 = tid / nstrip;            // the strips of one (group, tap row, segment) sit in adjacent lanes
+    const int cgi = r2 % CGB, r3 = r2 / CGB;
+    const int ky = r3 % K, rseg = r3 / K;
+    float acc[K][N];
 #pragma unroll
-    for (int u = 0; u < MAXIT; ++u)
+    for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-            for (int j = 0; j < N; ++j) acc[u][kx][j] = 0.f;
+        for (int j = 0; j < N; ++j) acc[kx][j] = 0.f;
     const int ntiles = a.B * a.tilesY * a.tilesX;
     for (int tile = wgi; tile < ntiles; tile += nwg) {
         const int tx = tile % a.tilesX, t2 = tile / a.tilesX;
         const int ty = t2 % a.tilesY, b = t2 / a.tilesY;
         const int y0 = ty * a.TH, x0 = tx * a.TW;
         __syncthreads();                                       // the previous tile has been consumed
-        for (int idx = tid; idx < RH * RW * CGB; idx += 256) {
-            const int cgi = idx % CGB, p = idx / CGB;
+        for (int idx = tid; idx < RH * RW * CGB; idx += nthr) {
+            const int cg = idx % CGB, p = idx / CGB;
             const int rx = p % RW, ry = p / RW;
             const int iy = y0 - P + ry, ix = x0 - P + rx;
             V v = (V)(T)0;
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const V*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cgi * N);
-            xt[p * PS + cgi] = v;
+                v = *reinterpret_cast<const V*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cg * N);
+            xt[p * PS + cg] = v;
         }
-        for (int idx = tid; idx < a.TH * a.TW * CGB; idx += 256) {
-            const int cgi = idx % CGB, p = idx / CGB;
+        for (int idx = tid; idx < a.TH * a.TW * CGB; idx += nthr) {
+            const int cg = idx % CGB, p = idx / CGB;
             const int rx = p % a.TW, ry = p / a.TW;
             const int oy = y0 + ry, ox = x0 + rx;
             V v = (V)(T)0;
             if (oy < a.H && ox < a.W)
-                v = *reinterpret_cast<const V*>(dyin + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.dy_stride + cgi * N);
-            dt[p * PS + cgi] = v;
+                v = *reinterpret_cast<const V*>(dyin + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.dy_stride + cg * N);
+            dt[p * PS + cg] = v;
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < MAXIT; ++u) {
-            const int it = tid + u * 256;
-            if (it >= items) break;
-            const int st = it % nstrip, r2 = it / nstrip;      // the strips of one (group, tap row) sit in adjacent lanes
-            const int cgi = r2 % CGB, ky = r2 / CGB;
-            for (int ry = 0; ry < a.TH; ++ry) {
+        if (live) {
+            for (int ry = rseg; ry < a.TH; ry += a.RSEG) {
                 const V* xr = xt + ((ry + ky) * RW + st * S) * PS + cgi;
                 const V* dr = dt + (ry * a.TW + st * S) * PS + cgi;
                 V xv[S + K - 1], dv[S];
@@ -168,52 +170,70 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwWgArgs a) {
                             const u32x4_t xa = __builtin_bit_cast(u32x4_t, xv[i + kx]), da = __builtin_bit_cast(u32x4_t, dv[i]);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[u][kx][2 * q]) : "v"(xa[q]), "v"(da[q]));
-                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[u][kx][2 * q + 1]) : "v"(xa[q]), "v"(da[q]));
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[kx][2 * q]) : "v"(xa[q]), "v"(da[q]));
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[kx][2 * q + 1]) : "v"(xa[q]), "v"(da[q]));
                             }
                         } else {
 #pragma unroll
-                            for (int j = 0; j < N; ++j) acc[u][kx][j] = __builtin_fmaf((float)xv[i + kx][j], (float)dv[i][j], acc[u][kx][j]);
+                            for (int j = 0; j < N; ++j) acc[kx][j] = __builtin_fmaf((float)xv[i + kx][j], (float)dv[i][j], acc[kx][j]);
                         }
                     }
             }
         }
     }
-    // Thousands of atomics on the few cache lines of dW serialise (~10 ns each per line): the 4 strips are summed with lane
-    // shuffles first, and the workgroups spread over `replicas` copies of dW that the caller adds up afterwards.
-    float* dwr = a.dw + (size_t)(wgi % a.replicas) * a.C * (K * K);
+    // strips: lane shuffles (nstrip = 4: xor 1, 2; nstrip = 5: through LDS with the segments); row segments: LDS atomics on a
+    // [channel][tap] table in the tile area; then one global atomic per (channel, tap) into replica wgi % replicas — thousands of
+    // atomics on the few cache lines of dW serialise, so the workgroups spread over `replicas` copies that the caller adds up
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);           // [CGB * N][K * K]
+    const int nred = CGB * N * K * K;
+    for (int i = tid; i < nred; i += nthr) red[i] = 0.f;
+    __syncthreads();
+    const bool pow2 = nstrip == 4;
 #pragma unroll
-    for (int u = 0; u < MAXIT; ++u) {
-        const int it = tid + u * 256;
-        const bool live = it < items;
-        const int st = it % nstrip, r2 = it / nstrip;
-        const int cgi = r2 % CGB, ky = r2 / CGB;
+    for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float v = live ? acc[u][kx][j] : 0.f;
+        for (int j = 0; j < N; ++j) {
+            float v = live ? acc[kx][j] : 0.f;
+            if (pow2) {
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
-                if (live && st == 0) atomicAdd(dwr + (size_t)(c0 + cgi * N + j) * (K * K) + ky * K + kx, v);
             }
+            if (live && (!pow2 || st == 0)) atomicAdd(red + (cgi * N + j) * (K * K) + ky * K + kx, v);
         }
     }
+    __syncthreads();
+    float* dwr = a.dw + (size_t)(wgi % a.replicas) * a.C * (K * K) + (size_t)c0 * (K * K);
+    for (int i = tid; i < nred; i += nthr) atomicAdd(dwr + i, red[i]);
 }
 
 template <typename T, typename V, int N>
 int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
-    a.TH = min(8, a.H); a.TW = 16;
-    const int groups = a.C / N, nblk = maf_cdiv(groups, 8);
-    a.CB = maf_cdiv(groups, nblk) * N;                                  // balanced channel blocks of <= 8 groups (72 channels: 40 + 32)
+    // Channel groups per block (tools/dw_wgrad_sweep.py; MAF_DWWG = "tile20,gmax,maxthreads,wgcap" overrides): 8 (128-byte pixel rows) on the
+    // 160 x 160 maps, which stream; 4 elsewhere — half the LDS, twice the workgroups per CU: 932 -> 727 us over ten shapes of a step —
+    // and 2 for the 9 x 9 kernels on 20 x 20 (199 -> 98 us).  20-wide tiles (no waste on 20 / 40 / 80-wide maps) measured slower: five
+    // strips per row are not a power of two for the lane shuffles.
+    int tile20 = 0, gmax = (long long)a.H * a.W >= 160 * 160 ? 8 : (k == 9 && a.H * a.W <= 400) ? 2 : 4, maxthr = 256, wgcap = 1024;
+    if (const char* e = getenv("MAF_DWWG")) sscanf(e, "%d,%d,%d,%d", &tile20, &gmax, &maxthr, &wgcap);
+    a.TH = (tile20 && a.H % 10 == 0 && a.H <= 40) ? 10 : min(8, a.H);
+    a.TW = (tile20 && a.W % 20 == 0) ? 20 : 16;
+    const int groups = a.C / N, nblk = maf_cdiv(groups, gmax);
+    const int cgb = maf_cdiv(groups, nblk);
+    a.CB = cgb * N;                                                     // balanced channel blocks (72 channels: 40 + 32)
     a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH); a.nCB = maf_cdiv(a.C, a.CB);
-    const size_t lds = ((size_t)(a.TH + k - 1) * (a.TW + k - 1) + (size_t)a.TH * a.TW) * (a.CB / N + 1) * 16;
-    int per = a.B * a.tilesY * a.tilesX;                                // workgroups per channel block: ~8 per CU in total
-    const int cap = maf_cdiv(1024, a.nCB);
+    const int base = cgb * k * (a.TW / 4);                              // items without row segments
+    a.RSEG = maxthr / base > a.TH ? a.TH : maxthr / base > 0 ? maxthr / base : 1;
+    MAF_REQUIRE(base * a.RSEG <= 512, "dw_wgrad: work items exceed the workgroup");
+    const int nthr = (base * a.RSEG + 63) / 64 * 64;
+    size_t lds = ((size_t)(a.TH + k - 1) * (a.TW + k - 1) + (size_t)a.TH * a.TW) * (cgb + 1) * 16;
+    const size_t red = (size_t)a.CB * k * k * 4;
+    if (lds < red) lds = red;
+    int per = a.B * a.tilesY * a.tilesX;                                // workgroups per channel block
+    const int cap = maf_cdiv(wgcap, a.nCB);
     if (per > cap) per = cap;
     const int budget = (int)(1500000ll / ((long long)a.C * k * k));      // every workgroup ends with C*k*k/nCB atomics: keep their total ~1.5 M
     if (per > budget) per = budget > 8 ? budget : 8;
-    const dim3 g(per * a.nCB), b(256);
+    const dim3 g(per * a.nCB), b(nthr);
     switch (k) {
         case 3: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 3>), g, b, lds, s, a); break;
         case 5: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 5>), g, b, lds, s, a); break;

@@ -644,7 +644,7 @@ class _DWConv(torch.autograd.Function):
             reps = 32                                                           # copies of dW: atomics on one cache line serialise
             with _side(x.device, xx, dy):
                 dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
-                with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device):
+                with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys)):
                     lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
                 dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
         if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
