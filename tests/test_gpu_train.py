@@ -589,3 +589,27 @@ def test_weight_staging_plan_matches_per_layer_packing():
     assert torch.allclose(cls2.detach().float(), c2, rtol=0, atol=5e-4)
     model.float()                                                     # _apply: the staged buffers point at storage that may be replaced
     assert model._pack_plan is None
+
+
+@pytest.mark.gpu
+def test_bench_train_two_ranks_on_one_device():
+    """The N > 1 code path of `bench.py --train` — DistributedDataParallel over the train-form modules, the weight-gradient side stream joined
+    layer by layer (the reducer reads a gradient from its hook), the profiled step running on every rank (a rank-0-only step deadlocked the
+    collective once), barrier + max-over-ranks timing — exercised with two processes sharing cuda:0 over gloo (the box has one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAF_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--train", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "ddp2"
+    assert d["config"]["native_launches"]["fallback"] == 0 and d["config"]["native_launches"]["native_wgrad"] > 0
+    import math
+    assert math.isfinite(d["config"]["final_loss"]) and d["value"] > 0
+    assert "all_reduce" in d
