@@ -1,0 +1,139 @@
+// MaxPool2d(k, stride 1, padding k/2) for the training graph — SPPF.m, three chained 5 x 5 pools on the 20 x 20 map
+// (yolov6/layers/common.py:114-129) — forward with the argmax kept as one byte per element, backward as a GATHER.
+//
+// The framework's backward scatters with atomics over the overlapping windows: 271 us per pool on 32 x 192 x 20 x 20 (0.8 ms of a
+// 31 ms step for three tiny maps).  Here an input element looks at the k*k outputs whose window contains it and takes the gradient
+// of those that chose it: k*k (8-byte index + 16-byte gradient) vector loads out of L2 per 8 channels, no atomics.
+// Tie rule = the framework's (aten max_pool2d_with_indices): the window is scanned row by row over its in-image part and an element
+// replaces the running maximum only if it is greater (or NaN) — the FIRST maximum wins.
+#include "maf_common.h"
+
+namespace {
+
+struct MpArgs {
+    const void* x; void* y; unsigned char* idx; const void* dy; void* dx;
+    int B, H, W, C, xs, ys, k;
+};
+
+template <typename T> struct MpVec;
+template <> struct MpVec<half_t> { typedef half8_t type; static constexpr int N = 8; };
+template <> struct MpVec<float> { typedef f32x4_t type; static constexpr int N = 4; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_s1_fwd_kernel(const MpArgs a) {
+    typedef typename MpVec<T>::type V;
+    constexpr int N = MpVec<T>::N;
+    const int CG = a.C / N, P = a.k / 2;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= (long long)a.B * a.H * a.W * CG) return;
+    const int cg = (int)(tid % CG);
+    long long t = tid / CG;
+    const int w = (int)(t % a.W); t /= a.W;
+    const int h = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    const T* xp = static_cast<const T*>(a.x) + cg * N;
+    float m[N];
+    int am[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { m[j] = -INFINITY; am[j] = -1; }
+    for (int i = 0; i < a.k; ++i) {
+        const int ih = h - P + i;
+        if ((unsigned)ih >= (unsigned)a.H) continue;
+        for (int jx = 0; jx < a.k; ++jx) {
+            const int iw = w - P + jx;
+            if ((unsigned)iw >= (unsigned)a.W) continue;
+            const V v = *reinterpret_cast<const V*>(xp + ((size_t)((size_t)b * a.H + ih) * a.W + iw) * a.xs);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float f = (float)v[j];
+                if (f > m[j] || f != f || am[j] < 0) { m[j] = f; am[j] = i * a.k + jx; }      // first in-image element, then strictly greater (or NaN)
+            }
+        }
+    }
+    const size_t pix = ((size_t)b * a.H + h) * a.W + w;
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (T)m[j];
+    *reinterpret_cast<V*>(static_cast<T*>(a.y) + pix * a.ys + cg * N) = o;
+    unsigned char* ip = a.idx + pix * a.C + cg * N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ip[j] = (unsigned char)am[j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_s1_bwd_kernel(const MpArgs a) {
+    typedef typename MpVec<T>::type V;
+    constexpr int N = MpVec<T>::N;
+    const int CG = a.C / N, P = a.k / 2;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= (long long)a.B * a.H * a.W * CG) return;
+    const int cg = (int)(tid % CG);
+    long long t = tid / CG;
+    const int w = (int)(t % a.W); t /= a.W;
+    const int h = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    float g[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = 0.f;
+    for (int i = 0; i < a.k; ++i) {                         // output (oh, ow) sees this input as element (i, jx) of its window
+        const int oh = h + P - i;
+        if ((unsigned)oh >= (unsigned)a.H) continue;
+        for (int jx = 0; jx < a.k; ++jx) {
+            const int ow = w + P - jx;
+            if ((unsigned)ow >= (unsigned)a.W) continue;
+            const size_t pix = ((size_t)b * a.H + oh) * a.W + ow;
+            const unsigned char* ip = a.idx + pix * a.C + cg * N;
+            const V dv = *reinterpret_cast<const V*>(static_cast<const T*>(a.dy) + pix * a.ys + cg * N);
+            const int want = i * a.k + jx;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (ip[j] == want) g[j] += (float)dv[j];
+        }
+    }
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (T)g[j];
+    *reinterpret_cast<V*>(static_cast<T*>(a.dx) + (((size_t)b * a.H + h) * a.W + w) * a.xs + cg * N) = o;
+}
+
+int mp_check(int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, int32_t s0, int32_t s1) {
+    MAF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad shape");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "maxpool: dtype must be f16/f32");
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    MAF_REQUIRE(k % 2 == 1 && k >= 3 && k <= 15, "maxpool: odd kernel 3..15 (stride 1, padding k/2; the argmax is one byte)");
+    MAF_REQUIRE(C % N == 0 && s0 % N == 0 && s1 % N == 0, "maxpool: C and pixel strides must be multiples of the 16-byte channel group");
+    MAF_REQUIRE((long long)B * H * W * (C / N) < (1ll << 31) * 256, "maxpool: too many elements");
+    return 0;
+}
+
+}  // namespace
+
+// y = maxpool(x), idx [B,H,W,C] uint8 = window element (row * k + column) that was chosen
+extern "C" int maf_maxpool_s1_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                                      void* y, int32_t y_stride, uint8_t* idx, maf_stream_t stream) {
+    if (int rc = mp_check(B, H, W, C, k, dtype, x_stride, y_stride)) return rc;
+    MAF_REQUIRE(x && y && idx, "maxpool_forward: null pointer");
+    MpArgs a = {};
+    a.x = x; a.y = y; a.idx = idx; a.B = B; a.H = H; a.W = W; a.C = C; a.xs = x_stride; a.ys = y_stride; a.k = k;
+    const long long total = (long long)B * H * W * (C / (dtype == MAF_F16 ? 8 : 4));
+    const dim3 g((unsigned)((total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) hipLaunchKernelGGL(maxpool_s1_fwd_kernel<half_t>, g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(maxpool_s1_fwd_kernel<float>, g, dim3(256), 0, s, a);
+    return maf_check_hip(hipGetLastError(), "maxpool forward launch");
+}
+
+// dx [B,H,W,C] (pixel stride dx_stride) from dy (pixel stride dy_stride) and the forward's idx
+extern "C" int maf_maxpool_s1_backward(const void* dy, int32_t dy_stride, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                                       int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream) {
+    if (int rc = mp_check(B, H, W, C, k, dtype, dx_stride, dy_stride)) return rc;
+    MAF_REQUIRE(dy && dx && idx, "maxpool_backward: null pointer");
+    MpArgs a = {};
+    a.dy = dy; a.dx = dx; a.idx = const_cast<uint8_t*>(idx); a.B = B; a.H = H; a.W = W; a.C = C; a.xs = dx_stride; a.ys = dy_stride; a.k = k;
+    const long long total = (long long)B * H * W * (C / (dtype == MAF_F16 ? 8 : 4));
+    const dim3 g((unsigned)((total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) hipLaunchKernelGGL(maxpool_s1_bwd_kernel<half_t>, g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(maxpool_s1_bwd_kernel<float>, g, dim3(256), 0, s, a);
+    return maf_check_hip(hipGetLastError(), "maxpool backward launch");
+}

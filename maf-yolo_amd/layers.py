@@ -219,9 +219,10 @@ class SPPF(nn.Module):
 
     def forward(self, x):
         x = self.cv1(x)
-        y1 = self.m(x)
-        y2 = self.m(y1)
-        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+        k = self.m.kernel_size
+        y1 = train_ops.maxpool_s1(x, k)                                          # csrc/pool_train.hip on CUDA tensors (gather backward), else F.max_pool2d
+        y2 = train_ops.maxpool_s1(y1, k)
+        return self.cv2(torch.cat((x, y1, y2, train_ops.maxpool_s1(y2, k)), 1))
 
 
 class Concat(nn.Module):

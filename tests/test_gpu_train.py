@@ -613,3 +613,36 @@ def test_bench_train_two_ranks_on_one_device():
     import math
     assert math.isfinite(d["config"]["final_loss"]) and d["value"] > 0
     assert "all_reduce" in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("k", [3, 5])
+def test_maxpool_s1_matches_the_framework_forward_and_backward(dtype, k):
+    """csrc/pool_train.hip vs F.max_pool2d on a map full of ties (values on a coarse grid): same outputs bit for bit, same gradient —
+    i.e. the same (first-in-scan-order) element of every window was credited."""
+    import importlib
+    train_ops = importlib.import_module("maf-yolo_amd.train_ops")
+    torch.manual_seed(k)
+    x = (torch.randint(-3, 4, (3, 16, 20, 13), device="cuda").to(dtype) * 0.5).contiguous(memory_format=torch.channels_last)
+    x[0, :, 3, 4] = float("-inf")
+    dy = torch.randn(3, 16, 20, 13, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = train_ops.maxpool_s1(a, k)
+    yb = torch.nn.functional.max_pool2d(b, k, 1, k // 2)
+    assert train_ops.stats.get("native_maxpool", 0) > 0
+    assert torch.equal(ya, yb)
+    ya.backward(dy)
+    yb.backward(dy)
+    assert torch.allclose(a.grad.float(), b.grad.float(), rtol=2e-3, atol=2e-3)
+    # chained like SPPF, through a strided (concat-slice) view
+    buf = torch.randn(2, 24, 10, 10, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    v1 = buf[:, 8:16].detach().requires_grad_(True)
+    v2 = buf[:, 8:16].detach().clone().requires_grad_(True)
+    o1 = train_ops.maxpool_s1(train_ops.maxpool_s1(v1, k), k)
+    o2 = torch.nn.functional.max_pool2d(torch.nn.functional.max_pool2d(v2, k, 1, k // 2), k, 1, k // 2)
+    assert torch.equal(o1, o2)
+    o1.float().square().sum().backward()
+    o2.float().square().sum().backward()
+    assert torch.allclose(v1.grad.float(), v2.grad.float(), rtol=2e-3, atol=2e-3)
