@@ -259,15 +259,20 @@ int maf_loss_terms(const void* pred_scores, const void* pred_distri, int32_t dty
  *   maf_bn_forward   batch statistics -> save_mean / save_rstd (+ running stats with torch's momentum rule, unbiased variance, and
  *                    the int64 num_batches_tracked counter += 1; each may be NULL) and y = act(xhat*gamma + beta); two launches (statistics, apply).
  *   maf_bn_backward  dz = gradient w.r.t. the activation output; recomputes u from x; dx, dgamma, dbeta; two launches.
+ *   residual         (may be NULL) a tensor like y added BEFORE the activation: y = act(xhat*gamma + beta + residual) — the branch sums of
+ *                    RepVGGBlock (common.py:224) and DilatedReparamBlock (:3028-3031) without their own pass.  Backward needs it only when the
+ *                    activation does (ReLU): then dres receives dz * act'(u); without an activation the residual's gradient IS dz (pass NULL).
  *   part             fp32 scratch of TWO halves [2][R][2][roundup(C,256)], zeroed ONCE by the caller: a call accumulates its partial sums
  *                    into half `phase` (R replicas spread the atomics) and clears half 1 - phase — the one the previous call on the stream
  *                    used — so one buffer per stream serves all BatchNorms of a step when the caller alternates phase = 0, 1, 0, ... */
 int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
-                   int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, maf_stream_t stream);
+                   int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
+                   maf_stream_t stream);
 int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
                     const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
-                    void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase, maf_stream_t stream);
+                    void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
+                    const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream);
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
 /* General form: dW (fp32, accumulated into) of a conv with k = 1 (stride 1 / 2, pad 0) or k = 3 (stride 2, pad 1) — RepVGGBlock.rbr_dense /

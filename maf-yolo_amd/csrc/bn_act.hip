@@ -28,6 +28,7 @@ struct BnArgs2 {
     float eps, momentum; float* running_mean; float* running_var; long long* counter;
     float* dgamma; float* dbeta;
     int rev;
+    const void* res; void* dres; int rs, drs;          // residual added before the activation (forward, and backward when the activation needs u); d residual out
 };
 
 template <typename T> struct Vec;
@@ -55,7 +56,7 @@ constexpr int kU = 4;                                                // independ
 // blockIdx.x % R.  The global atomics are what bounds this kernel when a workgroup sees too few pixels (~40 G atomics/s chip-wide
 // measured, i.e. 2C atomics cost as much as streaming ~250 B per channel): slicing the channels keeps >= 512 pixels per workgroup for
 // any C at >= 2 workgroups per CU.
-template <typename T, bool BWD>
+template <typename T, bool BWD, bool RES = false>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
         s0[j] = s1[j] = 0.f;
         if (BWD && active) { mu[j] = a.mean[gi * N + j]; rs[j] = a.rstd[gi * N + j]; ga[j] = a.gamma[gi * N + j]; be[j] = a.beta[gi * N + j]; }
     }
-    auto accum = [&](const V& xv, const V& dv) {
+    const T* rp = static_cast<const T*>(a.res);
+    auto accum = [&](const V& xv, const V& dv, const V& rv) {
         if (!BWD) {
 #pragma unroll
             for (int j = 0; j < N; ++j) { const float f = (float)xv[j]; s0[j] += f; s1[j] = __builtin_fmaf(f, f, s1[j]); }
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const float xh = ((float)xv[j] - mu[j]) * rs[j];
-                const float gq = (float)dv[j] * act_grad(__builtin_fmaf(xh, ga[j], be[j]), a.act);
+                float u = __builtin_fmaf(xh, ga[j], be[j]);
+                if (RES) u += (float)rv[j];
+                const float gq = (float)dv[j] * act_grad(u, a.act);
                 s0[j] += gq; s1[j] = __builtin_fmaf(gq, xh, s1[j]);
             }
         }
@@ -96,20 +100,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     if (active) {
         int m = m0 + pl;
         for (; m + (kU - 1) * plan < m1; m += kU * plan) {
-            V xv[kU], dv[kU];
+            V xv[kU], dv[kU], rv[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 xv[u] = *reinterpret_cast<const V*>(xp + (size_t)(m + u * plan) * a.xs + gi * N);
                 if (BWD) dv[u] = *reinterpret_cast<const V*>(dp + (size_t)(m + u * plan) * a.dzs + gi * N);
+                if (BWD && RES) rv[u] = *reinterpret_cast<const V*>(rp + (size_t)(m + u * plan) * a.rs + gi * N);
             }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) accum(xv[u], dv[u]);
+            for (int u = 0; u < kU; ++u) accum(xv[u], dv[u], rv[u]);
         }
         for (; m < m1; m += plan) {
             const V xv = *reinterpret_cast<const V*>(xp + (size_t)m * a.xs + gi * N);
-            V dv = xv;
+            V dv = xv, rv = xv;
             if (BWD) dv = *reinterpret_cast<const V*>(dp + (size_t)m * a.dzs + gi * N);
-            accum(xv, dv);
+            if (BWD && RES) rv = *reinterpret_cast<const V*>(rp + (size_t)m * a.rs + gi * N);
+            accum(xv, dv, rv);
         }
     }
     if (wave_reduce) {
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
 // prologue: per-channel constants from the partial sums into LDS (every workgroup; the sums are added in double, in replica order, so all
 // workgroups agree), workgroup 0 publishes the statistics / parameter gradients; the grid clears the scratch half of the previous call.
 // thread = one N-channel group (its constants live in registers) x a strided set of pixels of the workgroup's chunk
-template <typename T, bool BWD>
+template <typename T, bool BWD, bool RES = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
@@ -194,16 +200,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
                 sc[j] = rs[j] * ga[j];
             }
         }
-        auto one = [&](const V& xv, const V& dv) {
+        const T* rp = static_cast<const T*>(a.res);
+        T* drp = static_cast<T*>(a.dres);
+        auto one = [&](const V& xv, const V& dv, const V& rv, V& gv) {
             V ov;
             if (!BWD) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) ov[j] = (T)act_fwd(__builtin_fmaf((float)xv[j], sc[j], sh[j]), a.act);
+                for (int j = 0; j < N; ++j) {
+                    float u = __builtin_fmaf((float)xv[j], sc[j], sh[j]);
+                    if (RES) u += (float)rv[j];
+                    ov[j] = (T)act_fwd(u, a.act);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float xh = ((float)xv[j] - mu[j]) * rs[j];
-                    const float gq = (float)dv[j] * act_grad(__builtin_fmaf(xh, ga[j], be[j]), a.act);
+                    float u = __builtin_fmaf(xh, ga[j], be[j]);
+                    if (RES) u += (float)rv[j];
+                    const float gq = (float)dv[j] * act_grad(u, a.act);
+                    if (RES) gv[j] = (T)gq;                          // gradient of the residual input
                     ov[j] = (T)(sc[j] * (gq - k0[j] - xh * k1[j]));
                 }
             }
@@ -211,20 +226,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
         };
         int m = m0 + pl;
         for (; m + (kU - 1) * plan < m1; m += kU * plan) {
-            V xv[kU], dv[kU];
+            V xv[kU], dv[kU], rv[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 xv[u] = *reinterpret_cast<const V*>(xp + (size_t)(m + u * plan) * a.xs + gi * N);
                 if (BWD) dv[u] = *reinterpret_cast<const V*>(dp + (size_t)(m + u * plan) * a.dzs + gi * N);
+                if (RES) rv[u] = *reinterpret_cast<const V*>(rp + (size_t)(m + u * plan) * a.rs + gi * N);
             }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) *reinterpret_cast<V*>(yp + (size_t)(m + u * plan) * a.ys + gi * N) = one(xv[u], dv[u]);
+            for (int u = 0; u < kU; ++u) {
+                V gv;
+                *reinterpret_cast<V*>(yp + (size_t)(m + u * plan) * a.ys + gi * N) = one(xv[u], dv[u], rv[u], gv);
+                if (BWD && RES) *reinterpret_cast<V*>(drp + (size_t)(m + u * plan) * a.drs + gi * N) = gv;
+            }
         }
         for (; m < m1; m += plan) {
             const V xv = *reinterpret_cast<const V*>(xp + (size_t)m * a.xs + gi * N);
-            V dv = xv;
+            V dv = xv, rv = xv, gv;
             if (BWD) dv = *reinterpret_cast<const V*>(dp + (size_t)m * a.dzs + gi * N);
-            *reinterpret_cast<V*>(yp + (size_t)m * a.ys + gi * N) = one(xv, dv);
+            if (RES) rv = *reinterpret_cast<const V*>(rp + (size_t)m * a.rs + gi * N);
+            *reinterpret_cast<V*>(yp + (size_t)m * a.ys + gi * N) = one(xv, dv, rv, gv);
+            if (BWD && RES) *reinterpret_cast<V*>(drp + (size_t)m * a.drs + gi * N) = gv;
         }
     }
 }
@@ -281,9 +303,11 @@ void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
 
 extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
-                              int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, maf_stream_t stream) {
+                              int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
+                              maf_stream_t stream) {
     if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
     MAF_REQUIRE(gamma && beta && y && save_mean && save_rstd, "bn_forward: null pointer");
+    MAF_REQUIRE(!residual || res_stride % (dtype == MAF_F16 ? 8 : 4) == 0, "bn_forward: residual stride must be a multiple of the 16-byte channel group");
     MAF_REQUIRE(act == MAF_ACT_NONE || act == MAF_ACT_SILU || act == MAF_ACT_RELU, "bn_forward: act must be none / relu / silu");
     hipStream_t s = static_cast<hipStream_t>(stream);
     BnArgs2 a = {};
@@ -296,16 +320,26 @@ extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_
     const int ga = bn_grid(M, C, dtype, 8192);
     if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
     else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false>), dim3(ga), dim3(256), (size_t)2 * C * sizeof(float), s, a);
-    else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(ga), dim3(256), (size_t)2 * C * sizeof(float), s, a);
+    a.res = residual; a.rs = res_stride;
+    const size_t la = (size_t)2 * C * sizeof(float);
+    if (residual) {
+        if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false, true>), dim3(ga), dim3(256), la, s, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, false, true>), dim3(ga), dim3(256), la, s, a);
+    } else {
+        if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false>), dim3(ga), dim3(256), la, s, a);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(ga), dim3(256), la, s, a);
+    }
     return maf_check_hip(hipGetLastError(), "bn_forward launch");
 }
 
 extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
                                const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
-                               void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase, maf_stream_t stream) {
+                               void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
+                               const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream) {
     if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
     MAF_REQUIRE(dz && gamma && beta && save_mean && save_rstd && dx, "bn_backward: null pointer");
+    MAF_REQUIRE((residual == nullptr) == (dres == nullptr), "bn_backward: residual and its gradient buffer go together (an activation-free BatchNorm passes dz through: no residual here)");
+    MAF_REQUIRE(!residual || (res_stride % (dtype == MAF_F16 ? 8 : 4) == 0 && dres_stride % (dtype == MAF_F16 ? 8 : 4) == 0), "bn_backward: residual strides must be multiples of the 16-byte channel group");
     hipStream_t s = static_cast<hipStream_t>(stream);
     BnArgs2 a = {};
     a.x = x; a.dz = dz; a.y = dx; a.xs = x_stride; a.dzs = dz_stride; a.ys = dx_stride; a.M = M; a.C = C; a.act = act; a.R = R;
@@ -315,9 +349,22 @@ extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, 
     size_t lds_s;
     const dim3 gs = stats_grid(M, C, dtype, &lds_s);
     const int ga = bn_grid(M, C, dtype, 8192);
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), gs, dim3(256), lds_s, s, a);
-    else hipLaunchKernelGGL((bn_stats_kernel<float, true>), gs, dim3(256), lds_s, s, a);
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, true>), dim3(ga), dim3(256), (size_t)6 * C * sizeof(float), s, a);
-    else hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(ga), dim3(256), (size_t)6 * C * sizeof(float), s, a);
+    a.res = residual; a.rs = res_stride; a.dres = dres; a.drs = dres_stride;
+    const size_t la = (size_t)6 * C * sizeof(float);
+    if (residual) {
+        if (dtype == MAF_F16) {
+            hipLaunchKernelGGL((bn_stats_kernel<half_t, true, true>), gs, dim3(256), lds_s, s, a);
+            hipLaunchKernelGGL((bn_apply_kernel<half_t, true, true>), dim3(ga), dim3(256), la, s, a);
+        } else {
+            hipLaunchKernelGGL((bn_stats_kernel<float, true, true>), gs, dim3(256), lds_s, s, a);
+            hipLaunchKernelGGL((bn_apply_kernel<float, true, true>), dim3(ga), dim3(256), la, s, a);
+        }
+    } else if (dtype == MAF_F16) {
+        hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), gs, dim3(256), lds_s, s, a);
+        hipLaunchKernelGGL((bn_apply_kernel<half_t, true>), dim3(ga), dim3(256), la, s, a);
+    } else {
+        hipLaunchKernelGGL((bn_stats_kernel<float, true>), gs, dim3(256), lds_s, s, a);
+        hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(ga), dim3(256), la, s, a);
+    }
     return maf_check_hip(hipGetLastError(), "bn_backward launch");
 }

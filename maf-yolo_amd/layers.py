@@ -86,10 +86,10 @@ class RepVGGBlock(nn.Module):
         self.nonlinearity = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        # both branches (conv + BatchNorm each) on the HIP kernels; their sum and the ReLU are the element-wise glue left to torch
+        # both branches (conv + BatchNorm each) on the HIP kernels
         y3 = train_ops.bn_act(train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), self.rbr_dense.bn)
-        y1 = train_ops.bn_act(train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight), self.rbr_1x1.bn)
-        return self.nonlinearity(y3 + y1)
+        # ReLU(BN(1x1) + y3): the branch sum and the ReLU ride in the second BatchNorm's apply pass
+        return train_ops.bn_act(train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight), self.rbr_1x1.bn, "relu", residual=y3)
 
     def fused(self):
         """One 3x3 kernel + bias (get_equivalent_kernel_bias, common.py:226-230)."""
@@ -117,7 +117,7 @@ class DilatedReparamBlock(nn.Module):
     def forward(self, x):
         out = train_ops.bn_act(train_ops.dwconv(x, self.lk_origin.weight), self.origin_bn)            # HIP fwd / dgrad / wgrad + BN(train)
         for kk in self.kernel_sizes:
-            out = out + train_ops.bn_act(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight), getattr(self, "dil_bn_k%d_1" % kk))
+            out = train_ops.bn_act(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight), getattr(self, "dil_bn_k%d_1" % kk), residual=out)   # out + BN(...)
         return out
 
     def fused(self):

@@ -676,10 +676,10 @@ def _bn_part(dev, c):
 
 
 class _BNAct(torch.autograd.Function):
-    """act(BatchNorm2d(x)) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
+    """act(BatchNorm2d(x) [+ residual]) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None, residual=None):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
@@ -688,21 +688,33 @@ class _BNAct(torch.autograd.Function):
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
         part, phase = _bn_part(dev, c)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        with _prof("bn_act_forward", 3 * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, act)):       # statistics pass (read) + apply pass (read, write)
+        rs = 0
+        if residual is not None:
+            residual, rs = nhwc(residual)
+        npass = 3 if residual is None else 4
+        with _prof("bn_act_forward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, act)):    # statistics pass (read) + apply pass (read [, read], write)
             lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
                                                 None if running_mean is None else running_mean.data_ptr(),
                                                 None if running_var is None else running_var.data_ptr(),
                                                 None if counter is None else counter.data_ptr(), act,
                                                 y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
-                                                phase, _stream(dev)))
-        ctx.save_for_backward(x, g32, b32, stat)
+                                                phase, None if residual is None else residual.data_ptr(), rs, _stream(dev)))
+        ctx.has_res = residual is not None
+        ctx.res_in_bwd = residual is not None and act != lib.ACT_NONE          # the activation's derivative needs u = BN(x) + residual
+        if ctx.res_in_bwd:
+            ctx.save_for_backward(x, g32, b32, stat, residual)
+        else:
+            ctx.save_for_backward(x, g32, b32, stat)
         ctx.act = act
         stats["native_bn_act"] = stats.get("native_bn_act", 0) + 1
         return y
 
     @staticmethod
     def backward(ctx, dz):
-        x, g32, b32, stat = ctx.saved_tensors
+        if ctx.res_in_bwd:
+            x, g32, b32, stat, residual = ctx.saved_tensors
+        else:
+            (x, g32, b32, stat), residual = ctx.saved_tensors, None
         B, c, H, W = x.shape
         dz, dzs = nhwc(dz)
         if dz.dtype != x.dtype:
@@ -713,32 +725,51 @@ class _BNAct(torch.autograd.Function):
         dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         dgb = torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
         part, phase = _bn_part(dev, c)
-        with _prof("bn_act_backward", 5 * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
+        dres, rs = None, 0
+        if residual is not None:
+            residual, rs = nhwc(residual)
+            dres = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        npass = 5 if residual is None else 8
+        with _prof("bn_act_backward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
             lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
                                                  stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
-                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, phase,
+                                                 None if residual is None else residual.data_ptr(), rs,
+                                                 None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride()[3], _stream(dev)))
+        if ctx.has_res and dres is None:
+            dres = dz                                                            # no activation: the residual's gradient is dz itself
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres
 
 
-def bn_act(x, bn, act=None):
-    """act(bn(x)) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  Training mode on CUDA tensors runs the fused HIP kernels
-    (one statistics pass + one normalise/affine/activation pass; backward likewise); eval mode and CPU tensors run torch ops."""
+def bn_act(x, bn, act=None, residual=None):
+    """act(bn(x) [+ residual]) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  Training mode on CUDA tensors runs the fused HIP
+    kernels (one statistics pass + one normalise/affine/[add]/activation pass; backward likewise); eval mode and CPU tensors run torch ops.
+    `residual` (same shape as x; act None or 'relu'): the branch sums of RepVGGBlock / DilatedReparamBlock without a pass of their own."""
     mult = 8 if x.dtype == torch.float16 else 4
     if not (x.is_cuda and bn.training):
         # CPU tensors (CI / gloo tests) and eval-mode BatchNorm inside a train-form forward (Model.forward(val_loss=True) never comes here:
         # it runs the deploy engine): torch ops, counted so that an A/B on `stats` cannot mistake them for the HIP path
         stats["torch_bn"] = stats.get("torch_bn", 0) + 1
         y = bn(x)
+        if residual is not None:
+            y = y + residual
         return y if act in (None, "none") else (F.relu(y) if act == "relu" else F.silu(y))
     if not (x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and bn.affine):
         raise lib.MafError("bn_act: unsupported input for the HIP path: %s %s (channels must be a multiple of %d, affine BatchNorm)" % (tuple(x.shape), x.dtype, mult))
+    if residual is not None:
+        if act == "silu":
+            raise lib.MafError("bn_act: a residual goes with act None or 'relu'")
+        if residual.shape != x.shape:
+            raise lib.MafError("bn_act: residual %s must have the shape of x %s" % (tuple(residual.shape), tuple(x.shape)))
+        if residual.dtype != x.dtype:
+            residual = residual.to(x.dtype)
     counter = bn.num_batches_tracked if bn.track_running_stats else None        # += 1 inside the apply kernel (140 one-element launches per step otherwise)
     if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64):
         counter.add_(1)
         counter = None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter)
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual)
 
 
 class _MaxPoolS1(torch.autograd.Function):

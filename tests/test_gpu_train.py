@@ -646,3 +646,39 @@ def test_maxpool_s1_matches_the_framework_forward_and_backward(dtype, k):
     o1.float().square().sum().backward()
     o2.float().square().sum().backward()
     assert torch.allclose(v1.grad.float(), v2.grad.float(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,act", [(torch.float16, None), (torch.float16, "relu"), (torch.float32, "relu"), (torch.float32, None)])
+def test_bn_act_with_residual_matches_torch(dtype, act):
+    """act(BatchNorm(x) + residual) in one apply pass (RepVGGBlock: ReLU(BN(1x1) + BN(3x3)); DilatedReparamBlock: running branch sum) against
+    the same expression in torch fp32: output, gradients of x, residual, gamma, beta; the residual may be a strided view."""
+    import importlib
+    train_ops = importlib.import_module("maf-yolo_amd.train_ops")
+    torch.manual_seed(5)
+    c = 24
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.03).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.03).cuda().train()
+    ref.load_state_dict(bn.state_dict())
+    x0 = torch.randn(4, c, 9, 7, device="cuda")
+    big = torch.randn(4, 2 * c, 9, 7, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(4, c, 9, 7, device="cuda")
+    x = x0.to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = big[:, c:].detach().requires_grad_(True)                                  # a channel slice: pixel stride 2c
+    y = train_ops.bn_act(x, bn, act, residual=r)
+    y.backward(dy.to(dtype))
+    xr = x0.to(dtype).float().requires_grad_(True)
+    rr = big[:, c:].detach().float().requires_grad_(True)
+    u = ref(xr) + rr
+    yr = torch.relu(u) if act == "relu" else u
+    yr.backward(dy.to(dtype).float())
+    tol = 2e-2 if dtype == torch.float16 else 2e-4
+    assert torch.allclose(y.float(), yr, rtol=tol, atol=tol)
+    assert torch.allclose(x.grad.float(), xr.grad, rtol=tol, atol=tol * 2)
+    assert torch.allclose(r.grad.float(), rr.grad, rtol=tol, atol=tol)
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=5 * tol, atol=5 * tol)
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=5 * tol, atol=5 * tol)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-3, atol=1e-4)

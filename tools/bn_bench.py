@@ -29,12 +29,12 @@ for (H, c, act) in [(320, 24, None), (160, 72, "silu"), (160, 48, None), (80, 19
     def fwd():
         ph[0] ^= 1
         lib.check(L.maf_bn_forward(x.data_ptr(), c, M, c, lib.F16, g.data_ptr(), b.data_ptr(), 1e-3, 0.03, rm.data_ptr(), rv.data_ptr(), None, ACT[act],
-                                   y.data_ptr(), c, stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), R, ph[0], st))
+                                   y.data_ptr(), c, stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), R, ph[0], None, 0, st))
 
     def bwd():
         ph[0] ^= 1
         lib.check(L.maf_bn_backward(x.data_ptr(), c, dz.data_ptr(), c, M, c, lib.F16, g.data_ptr(), b.data_ptr(), stat[0].data_ptr(), stat[1].data_ptr(),
-                                    ACT[act], y.data_ptr(), c, dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), R, ph[0], st))
+                                    ACT[act], y.data_ptr(), c, dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), R, ph[0], None, 0, None, 0, st))
 
     res = []
     for f in (fwd, bwd):
