@@ -12,6 +12,8 @@
 //      B = the plane rows (16 image rows x the 8-wide window: two 8-byte LDS reads per lane); k instructions (2k for k > 5)
 //      accumulate [4 channels][4 x][16 rows] — see bottleneck.hip for the operand algebra and the bank layout;
 //   3. after the 8 channel sets a lane holds 8 consecutive channels of 4 pixels: bias + activation, 16-byte NHWC stores.
+#include <type_traits>
+#include <utility>
 #include "maf_common.h"
 
 namespace {
@@ -25,6 +27,18 @@ struct DwmArgs {
 };
 
 typedef half_t half4v_t __attribute__((ext_vector_type(4)));
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void dwm_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dwm_static_for<N, I + 1>(f);
+    }
+}
+// LDS reads as inline assembly: the caller counts them and waits with dwm_wait_lgkm
+template <int OFF> __device__ __forceinline__ void dwm_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void dwm_ds_read_b64(u32x2_t& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void dwm_wait_lgkm(u32x4_t& a, u32x2_t& b, u32x2_t& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
 
 template <int K>
 struct DwmCfg {
@@ -75,8 +89,11 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwmArgs a) {
     }
     __syncthreads();
 
-    // ---- 2. k (2k) MFMAs per channel set
-    const bool toe_active = (p >> 2) == g;
+    // ---- 2. k (2k) MFMAs per channel set: ONE straight line of K * PARTS * 8 steps (tap row, window, channel set), software-pipelined by
+    // hand exactly like phase B of csrc/bottleneck.hip — the three LDS reads of step t + BD are inline assembly issued before the MFMA of
+    // step t, with hand-counted `s_waitcnt lgkmcnt(n)` (as a loop of plain loads every MFMA sat behind a full LDS round trip).  All 64 lanes
+    // read a Toeplitz entry and the 48 lanes outside the block diagonal AND it to zero.
+    const uint32_t toe_mask = (p >> 2) == g ? 0xffffffffu : 0u;
     const int q4 = wave * 4;
     int hi_off = 4;
     asm volatile("" : "+v"(hi_off));                        // keep the two window halves two ds_read_b64 (see bottleneck.hip)
@@ -86,21 +103,35 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwmArgs a) {
     const half8_t* tl = toe + p;
     const half_t* t1l = T1 + (size_t)g * PS + p * RWP + q4;
     const half_t* t1h = t1l + hi_off;
-#pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-        for (int part = 0; part < PARTS; ++part) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                half8_t av = (half8_t)(half_t)0;
-                if (toe_active) av = tl[((s * K + ky) * PARTS + part) * 16];
-                const int o = s * 4 * PS + ky * RWP + part * 4;
-                const half4v_t lo = *reinterpret_cast<const half4v_t*>(t1l + o), hi = *reinterpret_cast<const half4v_t*>(t1h + o);
-                const half8_t bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, dacc[s], 0, 0, 0);
-            }
+    constexpr int NSTEP = K * PARTS * 8, BD = 3;
+    u32x4_t avr[BD + 1];
+    u32x2_t blo[BD + 1], bhi[BD + 1];
+    const uint32_t a_toe = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tl;
+    const uint32_t a_t1l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1l;
+    const uint32_t a_t1h = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)t1h;
+    auto ld_step = [&](auto idx) {
+        constexpr int t = decltype(idx)::value;
+        if constexpr (t < NSTEP) {
+            constexpr int s = t % 8, part = (t / 8) % PARTS, ky = t / (8 * PARTS);
+            constexpr int ot = ((s * K + ky) * PARTS + part) * 256, o = (s * 4 * PS + ky * RWP + part * 4) * 2;
+            static_assert(ot < 65536 && o < 65536, "ds offset field");
+            dwm_ds_read_b128<ot>(avr[t % (BD + 1)], a_toe);
+            dwm_ds_read_b64<o>(blo[t % (BD + 1)], a_t1l);
+            dwm_ds_read_b64<o>(bhi[t % (BD + 1)], a_t1h);
         }
-    }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the counter now counts only the reads below
+    dwm_static_for<BD>([&](auto idx) { ld_step(idx); });
+    dwm_static_for<NSTEP>([&](auto idx) {
+        constexpr int t = decltype(idx)::value, s = t % 8, sl = t % (BD + 1);
+        ld_step(std::integral_constant<int, t + BD>{});
+        constexpr int ahead = (NSTEP - 1 - t) < BD ? (NSTEP - 1 - t) : BD;          // steps whose reads were issued after step t's
+        dwm_wait_lgkm<3 * ahead>(avr[sl], blo[sl], bhi[sl]);
+        const u32x4_t bw = (u32x4_t){blo[sl][0], blo[sl][1], bhi[sl][0], bhi[sl][1]};
+        const u32x4_t am = avr[sl] & toe_mask;
+        dacc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, am), __builtin_bit_cast(half8_t, bw), dacc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                  // keep the issue order as written
+    });
 
     // ---- 3. lane (g, n = p): channels cb*32 + 8g .. +7 of pixels (row y0 + n, x = x0 + 4q + r)
     const int c0 = cb * 32 + g * 8;
