@@ -107,7 +107,7 @@ def _register():
         dy = dy.to(x.dtype)
         dx = ops.conv1x1_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         dw = _wgrad(x, dy, w, 1, 1) if ctx.needs_input_grad[1] else None
-        db = dy.float().sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = dy.sum((0, 2, 3), dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
     def _bwd_3x3(ctx, dy):
@@ -115,7 +115,7 @@ def _register():
         dy = dy.to(x.dtype)
         dx = ops.conv3x3s2_dgrad(dy, w, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = _wgrad(x, dy, w, 3, 2) if ctx.needs_input_grad[1] else None
-        db = dy.float().sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = dy.sum((0, 2, 3), dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
     def _bwd_dw(ctx, dy):
@@ -123,7 +123,7 @@ def _register():
         dy = dy.to(x.dtype)
         dx = ops.dwconv_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         dw = ops.dwconv_wgrad(x, dy, w.shape[-1]).to(w.dtype) if ctx.needs_input_grad[1] else None
-        db = dy.float().sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = dy.sum((0, 2, 3), dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
     L.register_autograd("mafyolo::conv1x1_bias_act", _bwd_1x1, setup_context=_setup)

@@ -169,9 +169,11 @@ def _ok(x, cin_mult):
 _op_cache = {}                         # launch descriptors by geometry: only the pointers change from call to call (a ctypes field store is ~0.2 us)
 
 
-def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
+def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, tk=1):
     ys = out.stride()[3]
-    key = (1, dt, B, H, W, cin, cout, ct, xs, ys)
+    if pt is None:
+        pt = pack.tile_for(cout, B * H * W)[0]
+    key = (1, dt, B, H, W, cin, cout, pt, ct, tk, xs, ys)
     op = _op_cache.get(key)
     if op is None:
         op = _op_cache[key] = lib.MafOp()
@@ -179,7 +181,7 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
         op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, cin, cout, 1
         op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = cin, xs, 0, lib.SRC_DIRECT
         op.out_stride, op.out_coff = ys, 0
-        op.tile_p, op.tile_c = pack.tile_for(cout, B * H * W)[0], ct
+        op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
     op.src[0].ptr, op.out, op.w, op.bias = x.data_ptr(), out.data_ptr(), wp.data_ptr(), bias.data_ptr()
     if profile is None:
         lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
@@ -187,6 +189,75 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt):
     es = x.element_size()
     with _prof("conv1x1", B * H * W * (cin + cout) * es + cin * cout * es, x.device):
         lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+
+
+# Tile / variant choice of the training 1x1 convs (forward and data gradient): the first time a shape (pixels, K, N) is seen every candidate
+# the inference tuner would try for it (engine.Plan.autotune: tile_p x tile_c of the generic kernel, split-K, LDS-shared weight fragments,
+# the persistent "stream" forms) is timed on the tensors at hand and the best one kept — the static rule (pack.tile_for) loses 10-40 % on
+# individual layers.  MAF_TRAIN_TUNE=0 turns it off.
+conv_autotune = os.environ.get("MAF_TRAIN_TUNE", "1") != "0"
+_conv_tune = {}
+
+
+def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
+    """(tile_p, tile_c, tile_k) for the single-source conv K -> Nc over x (w2d [rows][cols] as maf_pack_w1x1 takes it)."""
+    M = B * H * W
+    pt0, ct0 = pack.tile_for(Nc, M)
+    if not conv_autotune or dt != lib.F16 or not x.is_cuda:
+        return pt0, ct0, 1
+    key = (M, K, Nc, xs)
+    best = _conv_tune.get(key)
+    if best is not None:
+        return best
+    ksteps = -(-K // 32)
+    cands = []
+    for ct in (2, 4, 6, 8):
+        nt = -(-Nc // (16 * ct))
+        if nt * 16 * ct > 2 * max(Nc, 32) or (ct == 8 and Nc % 8):
+            continue
+        for pt in (1, 2, 4):
+            if (pt == 4 and ct > 4) or (pt > 1 and -(-M // (64 * pt)) * nt < 256):
+                continue
+            cands.append((pt, ct, 1))
+        if ksteps >= 8 and M <= 65536:
+            cands.append((1, ct, 4))
+        if ksteps <= 4 and ksteps * ct <= 16:
+            cands += [(1, ct, 3), (2, ct, 3)]
+        if 2 <= ksteps <= 12 and ksteps * ct <= 96:
+            cands.append((1, ct, 5))
+        if ksteps >= 4 and ct >= 4:
+            for pt in ((1, 2, 4) if ct == 4 else (1, 2)):
+                if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
+                    cands.append((pt, ct, 2))
+    if (pt0, ct0, 1) not in cands:
+        cands.append((pt0, ct0, 1))
+    out = torch.empty((B, Nc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    torch.cuda.synchronize(x.device)                                            # a quiet chip: the side stream's weight gradients would be in the timings
+    timer, st, res, packs = lib.Timer(), _stream(x.device), [], {}
+    global profile
+    saved, profile = profile, None
+    try:
+        for pt, ct, tk in cands:
+            if ct not in packs:
+                packs[ct] = _packed_1x1(w2d, rows, cols, transpose, dt, ct, x.device)
+            bp = _zero_bias(x.device, -(-Nc // (16 * ct)) * 16 * ct)
+            try:
+                _launch_conv1x1(x, xs, packs[ct], bp, B, H, W, K, Nc, ct, out, dt, pt, tk)          # warm-up (and validity)
+            except lib.MafError:
+                continue
+            ts = []
+            for _ in range(3):
+                timer.start(st)
+                _launch_conv1x1(x, xs, packs[ct], bp, B, H, W, K, Nc, ct, out, dt, pt, tk)
+                timer.stop(st)
+                ts.append(timer.elapsed_ms())
+            res.append((min(ts), pt, ct, tk))
+    finally:
+        profile = saved
+    res.sort()
+    best = _conv_tune[key] = res[0][1:] if res else (pt0, ct0, 1)
+    stats["conv_tuned"] = stats.get("conv_tuned", 0) + 1
+    return best
 
 
 class PackPlan:
@@ -301,12 +372,21 @@ class _Conv1x1(torch.autograd.Function):
         cout = w.shape[0]
         dt = _DT[x.dtype]
         co = -(-cout // 4) * 4                                                   # the kernel stores 4 channels at a time: any class count
-        ct = pack.tile_for(co, B * H * W)[1]
-        wp = _hit(w, ("d", co, cin, 1, 0, dt, ct)) if co == cout else None       # staged by this step's batch (PackPlan)
-        if wp is None:
+        M = B * H * W
+        choice = _conv_tune.get((M, cin, co, xs)) if conv_autotune and dt == lib.F16 else None
+        w2d = None
+        if choice is None:
             w2d = w.detach().reshape(cout, cin).float().contiguous()
             if co != cout:                                                       # (cls_pred with nc % 4 != 0) runs with zero filters appended
                 w2d = F.pad(w2d, (0, 0, 0, co - cout))
+            choice = _conv_choice(x, xs, B, H, W, cin, co, dt, w2d, co, cin, 0)
+        pt, ct, tk = choice
+        wp = _hit(w, ("d", co, cin, 1, 0, dt, ct)) if co == cout else None       # staged by this step's batch (PackPlan)
+        if wp is None:
+            if w2d is None:
+                w2d = w.detach().reshape(cout, cin).float().contiguous()
+                if co != cout:
+                    w2d = F.pad(w2d, (0, 0, 0, co - cout))
             wp = _packed_1x1(w2d, co, cin, 0, dt, ct, x.device, w if co == cout else None)
         npad = -(-co // (16 * ct)) * 16 * ct
         if bias is None:
@@ -315,7 +395,7 @@ class _Conv1x1(torch.autograd.Function):
             bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
             bp[:cout] = bias.detach().float()
         out = torch.empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt)
+        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt, pt, tk)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         stats["native_conv1x1"] += 1
@@ -343,21 +423,29 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             mult = 8 if x.dtype == torch.float16 else 4
             dyk, dyks, kk = dy, dys, cout
-            ct = pack.tile_for(cin, B * H * W)[1]
-            wp = _hit(w, ("d", cout, cin, 1, 1, dt, ct)) if cout % mult == 0 else None
+            w2d = None
+            if cout % mult:                                                      # e.g. reg_pred: 68 channels in fp16
+                kk = -(-cout // mult) * mult                                     # zero-pad the reduction dim to whole 16-byte chunks
+                dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
+                dyks = kk
+                w2d = F.pad(w.detach().reshape(cout, cin).float(), (0, 0, 0, kk - cout))
+            M = B * H * W
+            choice = _conv_tune.get((M, kk, cin, dyks)) if conv_autotune and dt == lib.F16 else None
+            if choice is None:
+                if w2d is None:
+                    w2d = w.detach().reshape(cout, cin).float().contiguous()
+                choice = _conv_choice(dyk, dyks, B, H, W, kk, cin, dt, w2d, kk, cin, 1)
+            pt, ct, tk = choice
+            wp = _hit(w, ("d", cout, cin, 1, 1, dt, ct)) if kk == cout else None
             if wp is None:
-                w2d = w.detach().reshape(cout, cin).float().contiguous()
-                if cout % mult:                                                  # e.g. reg_pred: 68 channels in fp16
-                    kk = -(-cout // mult) * mult                                 # zero-pad the reduction dim to whole 16-byte chunks
-                    dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
-                    dyks = kk
-                    w2d = F.pad(w2d, (0, 0, 0, kk - cout))
+                if w2d is None:
+                    w2d = w.detach().reshape(cout, cin).float().contiguous()
                 wp = _packed_1x1(w2d, kk, cin, 1, dt, ct, x.device, w if kk == cout else None)   # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci]
             npad = -(-cin // (16 * ct)) * 16 * ct
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt)
+            _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt, pt, tk)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum((0, 2, 3))
+            db = dy.sum((0, 2, 3), dtype=torch.float32)
         _side_done(x.device)
         return dx, dw, db
 
