@@ -524,7 +524,7 @@ class _Conv3x3s2(torch.autograd.Function):
         op.tile_p, op.tile_c = pt, ct
         op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
         es = x.element_size()
-        with _prof("conv3x3s2", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device):
+        with _prof("conv3x3s2", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device, (B, H, W, cin, cout, pt, ct)):
             lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
         ctx.save_for_backward(x, w)
         stats["native_conv3x3s2"] = stats.get("native_conv3x3s2", 0) + 1
@@ -560,7 +560,7 @@ class _Conv3x3s2(torch.autograd.Function):
             op.tile_p, op.tile_c = pt, ct
             op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct).data_ptr()
             es = x.element_size()
-            with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device):
+            with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device, (B, H, W, cin, cout, pt, ct)):
                 lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
         _side_done(x.device)
         return dx, dw
