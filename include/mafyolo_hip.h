@@ -284,13 +284,14 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 
-/* MaxPool2d(k, stride 1, padding k/2) of the training graph (SPPF.m, yolov6/layers/common.py:114-129), NHWC views, fp16 / fp32:
- * forward keeps the chosen window element (row * k + column, first maximum in scan order like aten) as one byte per element in
- * idx [B,H,W,C]; backward is a gather over the k*k windows that contain an input element (no atomics). */
-int maf_maxpool_s1_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
-                           void* y, int32_t y_stride, uint8_t* idx, maf_stream_t stream);
-int maf_maxpool_s1_backward(const void* dy, int32_t dy_stride, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
-                            int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream);
+/* MaxPool2d(k, stride, padding) of the training graph — SPPF.m (5, 1, 2; yolov6/layers/common.py:114-129) and MP (2, 2, 0; :667-673) —
+ * NHWC views, fp16 / fp32, floor mode: x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = floor((H + 2 pad - k) / stride) + 1.  Forward keeps the chosen
+ * window element (row * k + column, first maximum in scan order like aten) as one byte per element in idx [B,Ho,Wo,C]; backward is a
+ * gather over the windows that contain an input element (no atomics). */
+int maf_maxpool_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+                        int32_t dtype, void* y, int32_t y_stride, uint8_t* idx, maf_stream_t stream);
+int maf_maxpool_backward(const void* dy, int32_t dy_stride, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                         int32_t stride, int32_t pad, int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream);
 
 /* Weight staging of a whole training step in one launch.  A descriptor transforms one fp32 weight tensor:
  *   kind 0  dense conv weight [Cout][Cin][taps] (taps = 1 or 9) -> the MFMA fragment order of maf_pack_w1x1 with tile_c = CT; K runs

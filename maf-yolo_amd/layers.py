@@ -191,7 +191,7 @@ class MP(nn.Module):
         self.m = nn.MaxPool2d(2, 2)
 
     def forward(self, x):
-        return self.m(x)
+        return train_ops.maxpool(x, 2, 2, 0)                                     # csrc/pool_train.hip on CUDA tensors, else F.max_pool2d
 
 
 class MPRep(nn.Module):

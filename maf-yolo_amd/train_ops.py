@@ -860,40 +860,49 @@ def bn_act(x, bn, act=None, residual=None):
     return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual)
 
 
-class _MaxPoolS1(torch.autograd.Function):
-    """MaxPool2d(k, 1, k // 2) on csrc/pool_train.hip: forward keeps a one-byte argmax, backward gathers (the framework's backward scatters
-    with atomics over the overlapping windows: 271 us per SPPF pool on 32 x 192 x 20 x 20)."""
+class _MaxPool(torch.autograd.Function):
+    """MaxPool2d(k, stride, pad) on csrc/pool_train.hip: forward keeps a one-byte argmax, backward gathers (the framework's backward scatters
+    with atomics over overlapping windows — 271 us per SPPF pool on 32 x 192 x 20 x 20 — and drags int64 indices along)."""
 
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, stride, pad):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
-        y = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        idx = torch.empty((B, H, W, c), dtype=torch.uint8, device=x.device)
-        lib.check(lib.load().maf_maxpool_s1_forward(x.data_ptr(), xs, B, H, W, c, k, _DT[x.dtype], y.data_ptr(), y.stride()[3], idx.data_ptr(), _stream(x.device)))
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty((B, c, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, c), dtype=torch.uint8, device=x.device)
+        lib.check(lib.load().maf_maxpool_forward(x.data_ptr(), xs, B, H, W, c, k, stride, pad, _DT[x.dtype], y.data_ptr(), y.stride()[3], idx.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(idx)
-        ctx.k = k
+        ctx.geom = (H, W, k, stride, pad)
         stats["native_maxpool"] = stats.get("native_maxpool", 0) + 1
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
+        H, W, k, stride, pad = ctx.geom
         dy, dys = nhwc(dy)
-        B, c, H, W = dy.shape
+        B, c = dy.shape[:2]
         dx = torch.empty((B, c, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
-        lib.check(lib.load().maf_maxpool_s1_backward(dy.data_ptr(), dys, idx.data_ptr(), B, H, W, c, ctx.k, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
-        return dx, None
+        lib.check(lib.load().maf_maxpool_backward(dy.data_ptr(), dys, idx.data_ptr(), B, H, W, c, k, stride, pad, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
+        return dx, None, None, None
+
+
+def maxpool(x, k, stride=1, pad=None):
+    """F.max_pool2d(x, k, stride, pad) (pad default k // 2 for stride 1, else 0) with autograd; CUDA fp16 / fp32 tensors with channels in whole
+    16-byte groups run the HIP kernels."""
+    if pad is None:
+        pad = k // 2 if stride == 1 else 0
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and 2 <= k <= 15 and 1 <= stride <= k and 2 * pad <= k):
+        if x.is_cuda:
+            stats["torch_maxpool"] = stats.get("torch_maxpool", 0) + 1
+        return F.max_pool2d(x, k, stride, pad)
+    return _MaxPool.apply(x, k, stride, pad)
 
 
 def maxpool_s1(x, k):
-    """F.max_pool2d(x, k, 1, k // 2) with autograd; CUDA fp16 / fp32 tensors with channels in whole 16-byte groups run the HIP kernels."""
-    mult = 8 if x.dtype == torch.float16 else 4
-    if not (x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and k % 2 == 1 and 3 <= k <= 15):
-        if x.is_cuda:
-            stats["torch_maxpool"] = stats.get("torch_maxpool", 0) + 1
-        return F.max_pool2d(x, k, 1, k // 2)
-    return _MaxPoolS1.apply(x, k)
+    return maxpool(x, k, 1, k // 2)
 
 
 def dwconv(x, w):

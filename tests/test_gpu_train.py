@@ -636,6 +636,16 @@ def test_maxpool_s1_matches_the_framework_forward_and_backward(dtype, k):
     ya.backward(dy)
     yb.backward(dy)
     assert torch.allclose(a.grad.float(), b.grad.float(), rtol=2e-3, atol=2e-3)
+    # MP of MPRep: 2 x 2, stride 2
+    c = x.clone().requires_grad_(True)
+    d = x.clone().requires_grad_(True)
+    yc = train_ops.maxpool(c, 2, 2, 0)
+    yd = torch.nn.functional.max_pool2d(d, 2, 2, 0)
+    assert torch.equal(yc, yd)
+    g2 = torch.randn_like(yd)
+    yc.backward(g2)
+    yd.backward(g2)
+    assert torch.equal(c.grad, d.grad)
     # chained like SPPF, through a strided (concat-slice) view
     buf = torch.randn(2, 24, 10, 10, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
     v1 = buf[:, 8:16].detach().requires_grad_(True)
