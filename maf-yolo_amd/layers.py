@@ -87,6 +87,8 @@ class RepVGGBlock(nn.Module):
 
     def forward(self, x):
         # both branches (conv + BatchNorm each) on the HIP kernels
+        if x.is_cuda and x.shape[1] % 8:
+            x = train_ops.pad_channels8(x)                                       # the image: cast + channel padding once for both branches
         y3 = train_ops.bn_act(train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), self.rbr_dense.bn)
         # ReLU(BN(1x1) + y3): the branch sum and the ReLU ride in the second BatchNorm's apply pass
         return train_ops.bn_act(train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight), self.rbr_1x1.bn, "relu", residual=y3)

@@ -623,14 +623,27 @@ class _Conv1x1s2(torch.autograd.Function):
         return dx, dw
 
 
-def _pad8(x, w):
-    """A 3-channel image for kernels that read 16-byte channel chunks: zero channels appended to x and to the filters (their gradient slices are dropped by autograd)."""
+def pad_channels8(x):
+    """A 3-channel image for kernels that read 16-byte channel chunks: cast as a convolution would under autocast, zero channels appended.
+    RepVGGBlock does it ONCE for its two branches (32 x 3 x 640 x 640: the cast and the padded copy cost 0.15 ms each)."""
+    x = _autocast(x)
     cin = x.shape[1]
-    if cin % 8 == 0:
-        return x, w
-    extra = 8 - cin % 8
-    xp = F.pad(x, (0, 0, 0, 0, 0, extra)).contiguous(memory_format=torch.channels_last)
-    return xp, F.pad(w, (0, 0, 0, 0, 0, extra))
+    if cin % 8 == 0 or not x.is_cuda:
+        return x
+    return F.pad(x, (0, 0, 0, 0, 0, 8 - cin % 8)).contiguous(memory_format=torch.channels_last)
+
+
+def _pad8(x, w):
+    """(x, w) with the input channels of both padded to a multiple of 8 (x may come padded already: pad_channels8); the gradient slices of
+    the padding are dropped by autograd."""
+    cin = w.shape[1]
+    if x.shape[1] == cin:
+        if cin % 8 == 0:
+            return x, w
+        x = pad_channels8(x)
+    if x.shape[1] != -(-cin // 8) * 8:
+        raise lib.MafError("conv: input has %d channels, the filters %d" % (x.shape[1], cin))
+    return x, F.pad(w, (0, 0, 0, 0, 0, x.shape[1] - cin))
 
 
 def conv3x3s2(x, w):
