@@ -27,7 +27,6 @@ struct BnArgs2 {
     float* part_clear; int clear_n;                   // the other half, zeroed by the apply kernel
     float eps, momentum; float* running_mean; float* running_var; long long* counter;
     float* dgamma; float* dbeta;
-    int rev;
     const void* res; void* dres; int rs, drs;          // residual added before the activation (forward, and backward when the activation needs u); d residual out
 };
 
@@ -180,10 +179,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
     const int groups = a.C / N;
     const int gpb = groups < 256 ? groups : 256;
     const int plan = 256 / gpb;
-    // the workgroups walk the tensor from its END: the statistics pass has just streamed it front to back, so its tail is what the
-    // memory-side cache (256 MB) still holds
+    // (walking the tensor from its END — the tail is what the 256 MB memory-side cache still holds of the statistics pass — measured no different)
     const int chunk = (a.M + gridDim.x - 1) / gridDim.x;
-    const int m0 = (a.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * chunk, m1 = min(a.M, m0 + chunk);
+    const int m0 = blockIdx.x * chunk, m1 = min(a.M, m0 + chunk);
     const T* xp = static_cast<const T*>(a.x);
     const T* dp = static_cast<const T*>(a.dz);
     T* yp = static_cast<T*>(a.y);
@@ -292,8 +290,6 @@ void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
     const int want = 1024 / C > 0 ? 1024 / C : 1;
     a.R = R < want ? R : want;
     if (a.R > kMaxR) a.R = kMaxR;
-    static const bool fwd_order = getenv("MAF_BN_FORWARD_ORDER") != nullptr;
-    a.rev = !fwd_order;
     a.part = part + (size_t)phase * half;
     a.part_clear = part + (size_t)(1 - phase) * half;
     a.clear_n = half;
