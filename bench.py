@@ -262,8 +262,8 @@ def train_mode(args, torch, M, dev, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (BASELINE.md §4: >= 100)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed warm-up steps (BASELINE.md §4: >= 20)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE configs[1]: 32)")
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
