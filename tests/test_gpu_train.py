@@ -692,3 +692,41 @@ def test_bn_act_with_residual_matches_torch(dtype, act):
     assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=5 * tol, atol=5 * tol)
     assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=5 * tol, atol=5 * tol)
     assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M_hw,cin,cout", [((8, 40, 40), 64, 192), ((4, 80, 80), 192, 64), ((8, 20, 20), 288, 96), ((2, 160, 160), 24, 72)])
+def test_every_conv_variant_the_train_tuner_may_pick(M_hw, cin, cout):
+    """train_ops._conv_choice times tile_p x tile_c x {generic, LDS-shared fragments, split-K, stream, stream + LDS} candidates and keeps the
+    fastest: every candidate it can come up with for a shape must compute the same 1x1 conv (fp16 operands, fp32 accumulation)."""
+    import importlib
+    train_ops = importlib.import_module("maf-yolo_amd.train_ops")
+    lib = importlib.import_module("maf-yolo_amd.lib")
+    B, H, W = M_hw
+    torch.manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, device="cuda") / cin ** 0.5)
+    ref = torch.nn.functional.conv2d(x.float(), w.half().float().reshape(cout, cin, 1, 1))
+    M, ksteps = B * H * W, -(-cin // 32)
+    cands = set()
+    for ct in (2, 4, 6, 8):
+        nt = -(-cout // (16 * ct))
+        if nt * 16 * ct > 2 * max(cout, 32) or (ct == 8 and cout % 8):
+            continue
+        cands |= {(pt, ct, 1) for pt in (1, 2, 4) if not (pt == 4 and ct > 4)}
+        cands |= {(1, ct, 4)} if ksteps >= 8 and M <= 65536 else set()
+        cands |= {(1, ct, 3), (2, ct, 3)} if ksteps <= 4 and ksteps * ct <= 16 else set()
+        cands |= {(1, ct, 5)} if 2 <= ksteps <= 12 and ksteps * ct <= 96 else set()
+        cands |= {(pt, ct, 2) for pt in ((1, 2, 4) if ct == 4 else (1, 2))} if ksteps >= 4 and ct >= 4 else set()
+    assert len(cands) >= 6
+    ran = 0
+    for pt, ct, tk in sorted(cands):
+        wp = train_ops._packed_1x1(w.contiguous(), cout, cin, 0, lib.F16, ct, x.device)
+        bp = train_ops._zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct)
+        out = torch.full((B, cout, H, W), float("nan"), device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        train_ops._launch_conv1x1(x, cin, wp, bp, B, H, W, cin, cout, ct, out, lib.F16, pt, tk)
+        torch.cuda.synchronize()
+        err = (out.float() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 2e-3, (pt, ct, tk, err)
+        ran += 1
+    assert ran == len(cands)
