@@ -14,7 +14,7 @@ wh = torch.rand(7 * B, 2, generator=g) * 0.35 + 0.04
 ctr = wh / 2 + torch.rand(7 * B, 2, generator=g) * (1 - wh)
 targets = torch.cat([torch.arange(B).repeat_interleave(7)[:, None].float(), torch.randint(0, 80, (7 * B, 1), generator=g).float(), ctr, wh], 1).to(dev)
 crit = M.ComputeLoss(warmup_epoch=0)
-for i in range(12):
+for i in range(int(os.environ.get('STEPS', '12'))):
     with torch.autocast("cuda", dtype=torch.float16):
         (feats, cls, reg), _ = model(x)
     loss = crit((feats, cls, reg), targets, 0, 0)[0]
