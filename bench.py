@@ -137,6 +137,29 @@ def train_cpu_baseline(args, torch, M):
             "sample": "%d train steps of %d images (3x640x640 fp32): train-form module tree in plain torch + oracle.compute_loss, autograd, SGD; %.1f s wall, %d torch threads" % (n, bs, el, threads)}
 
 
+# kernels (demangled, as tools/pmc_traffic.py writes them) behind a `roofline.by_kind` entry of the train step: one "launch" of the kind is one
+# launch of EACH of them (a BatchNorm call = statistics kernel + apply kernel)
+# (the profiler leaves these anonymous-namespace templates mangled: bn_stats_kernelIDF16_Lb1ELb0E = <_Float16, BWD = true, RES = false>)
+_TRAIN_KIND_KERNELS = {"bn_act_backward": r"bn_(stats|apply)_kernel(<_Float16, true|IDF16_Lb1)", "bn_act_forward": r"bn_(stats|apply)_kernel(<_Float16, false|IDF16_Lb0)"}
+
+
+def train_pmc_traffic(kind, scale):
+    """HBM bytes per launch of `kind` from the PMC passes of a training run committed under profiles/ (tools/profile_round.sh: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs, counters only; tools/pmc_traffic.py: (FETCH_SIZE*2 + WRITE_SIZE)*1024) — n at batch 32 only."""
+    import re
+    path = os.path.join(ROOT, "profiles", "round2_train_pmc_traffic.json")
+    pat = _TRAIN_KIND_KERNELS.get(kind)
+    if pat is None or scale != "n" or not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))
+    rows = [v for k, v in pmc.items() if re.search(pat, k)]
+    calls = sum(v["launches"] for k, v in pmc.items() if re.search(pat.replace("(stats|apply)", "stats"), k))
+    if not rows or not calls:
+        return None, None
+    total = sum(v["traffic_bytes"] * v["launches"] for v in rows)
+    return int(total / calls), "profiles/round2_train_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 summed over the kind's kernels, per call (n, batch 32)"
+
+
 def train_mode(args, torch, M, dev, rank, world, dist):
     """One step = forward (autocast fp16) + backward + DDP all-reduce + SGD step on a fixed synthetic batch per rank.
     The loss is the device-side ComputeLoss (HIP task-aligned assignment + VFL / GIoU / DFL) on synthetic labels,
@@ -235,8 +258,9 @@ def train_mode(args, torch, M, dev, rank, world, dist):
         tot = sum(v[0] for v in prof.values())
         kinds = sorted(prof.items(), key=lambda kv: -kv[1][0])
         k0, (ms0, by0, n0) = kinds[0]
+        traffic, traffic_src = train_pmc_traffic(k0, args.scale)
         roof = {"bound": "hbm", "kernel": k0, "launches_per_step": n0, "avg_launch_ms": round(ms0 / n0, 5), "bytes_per_launch": int(by0 / n0),
-                "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3),
                 "by_kind": {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}}
     if not math.isfinite(float(loss.detach())):

@@ -39,6 +39,9 @@ if st:
 if os.path.isdir(os.path.join(src, "pmc_FETCH_SIZE")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), src, os.path.join(P, prefix + "_pmc_traffic.json")], stdout=subprocess.DEVNULL)
     print("wrote", prefix + "_pmc_traffic.json")
+if os.path.isdir(os.path.join(src, "trainpmc", "pmc_FETCH_SIZE")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(src, "trainpmc"), os.path.join(P, prefix + "_train_pmc_traffic.json")], stdout=subprocess.DEVNULL)
+    print("wrote", prefix + "_train_pmc_traffic.json")
 if len(sys.argv) > 3 and os.path.exists(os.path.join(sys.argv[3], "summary.txt")):
     shutil.copy(os.path.join(sys.argv[3], "summary.txt"), os.path.join(P, prefix + "_sq_counters.txt"))
     print("copied sq counters")

@@ -20,6 +20,10 @@ done
 python bench.py --train --scale n --batch 32 --steps 20 --warmup 5 > $OUT/train_n.json 2> $OUT/train_n.err; echo "train n rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python bench.py --train --scale n --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/train_stats.err
 echo "train rocprof rc=$?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/trainpmc/pmc_$c -o p -- python bench.py --train --scale n --batch 32 --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trainpmc_$c.err
+  echo "train pmc $c rc=$?"
+done
 python bench.py --train --scale s --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_s.json 2>/dev/null; echo "train s rc=$?"
 python bench.py --train --scale m --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_m.json 2>/dev/null; echo "train m rc=$?"
 python bench.py --latency --scale m --tune-file $TUNE > $OUT/latency_m.json 2>/dev/null; echo "latency m rc=$?"
