@@ -788,7 +788,8 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
         part, phase = _bn_part(dev, c)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        g32 = gamma.detach() if gamma.dtype == torch.float32 and gamma.is_contiguous() else gamma.detach().float().contiguous()
+        b32 = beta.detach() if beta.dtype == torch.float32 and beta.is_contiguous() else beta.detach().float().contiguous()
         rs = 0
         if residual is not None:
             residual, rs = nhwc(residual)
