@@ -1,4 +1,5 @@
 // Argument checking + dispatch for the MFMA conv kernels (kernels: conv_mfma.inc.h)
+#include <cstdlib>
 #include "conv_mfma.inc.h"
 
 int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
@@ -63,6 +64,12 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
         MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->H - 1) / 2 + 1 == op->Hin && (op->W - 1) / 2 + 1 == op->Win, "conv3x3s2 dgrad: Hin,Win (the dY grid) must equal floor((H-1)/2)+1");
         MAF_REQUIRE(op->tile_k <= 1 && !op->out_f32 && op->act == MAF_ACT_NONE, "conv3x3s2 dgrad: generic variant, no epilogue");
         a.act = MAF_ACT_NONE;
+        static const bool unsplit = getenv("MAF_DGRAD3_ALL_TAPS") != nullptr;          // A/B: every pixel walks all nine taps
+        if (op->H % 2 == 0 && op->W % 2 == 0 && !unsplit) {                 // parity classes of equal size: each runs only its own taps
+            a.dg_mc = op->B * (op->H / 2) * (op->W / 2);
+            a.dg_nmc = maf_cdiv(a.dg_mc, 64 * pt);
+            a.nM = 4 * a.dg_nmc;
+        }
         return maf_conv_mfma_dgrad3(a, op->dtype, pt, ct, s);
     }
     if (op->kind == MAF_OP_CONV3X3S2) {

@@ -44,6 +44,7 @@ struct ConvArgs {
     int out_stride, out_coff;
     int nM, nN;
     int act;
+    int dg_mc, dg_nmc;   // VAR_DGRAD3 with even H, W: pixels per parity class (B * H/2 * W/2) and pixel tiles per class (nM = 4 * dg_nmc); 0 = unsplit
     // twin launch (op->aux[0..3]): a SECOND conv of identical shape — same everything except these four pointers — runs as
     // blockIdx.y = 1 of the same grid (the two side convs of a MAFPN level, backbone.23 / .24 and .27 / .28: independent, equal, each too
     // small to fill the chip and each paying a kernel's fixed cost on its own)
@@ -56,8 +57,10 @@ struct ConvArgs {
 
 // VAR_DGRAD3: the DATA GRADIENT of the 3x3 stride-2 pad-1 conv (training, MAF_OP_CONV3X3S2_DGRAD): output pixel = input pixel (iy, ix)
 // of the forward conv, source = dY on the half-resolution grid; tap (ky, kx) contributes dY[(iy + 1 - ky) / 2, (ix + 1 - kx) / 2] when both
-// are even and in range, else the zero page (2.25 of the 9 taps on average: the waste is MFMA time on a memory-bound layer, and the
-// gather form needs no atomics and no scatter pass).
+// are even and in range, else the zero page — 2.25 of the 9 taps on average.  With even H, W (every layer of a 32-aligned image) the pixels
+// are therefore walked PARITY CLASS by parity class (a.dg_mc: workgroups of class (y & 1, x & 1) see only pixels of that class) and a
+// class runs only ITS taps — 1, 2, 2 or 4 of the 9, i.e. a quarter of the k-steps, loads and MFMAs of the all-taps form.  The gather
+// form needs no atomics and no scatter pass.
 enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3, VAR_DGRAD3 = 4 };
 
 int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
@@ -132,7 +135,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     if (m_tile >= a.nM) return;
     // KS4: the 4 waves of the workgroup share ONE 16-pixel tile and each takes a quarter of the k-steps (small maps with
     // long reductions are dependent-load chains; this cuts the chain 4x and puts 4x more workgroups on the chip)
-    const int m_base = KS4 ? m_tile * 16 : m_tile * (64 * PT) + wave * (16 * PT);
+    // VAR_DGRAD3, split form: this workgroup's parity class and its tile inside the class
+    const bool dgs = VAR == VAR_DGRAD3 && a.dg_mc > 0;
+    const int dg_cls = dgs ? m_tile / a.dg_nmc : 0, dg_py = dg_cls >> 1, dg_px = dg_cls & 1;
+    const int dg_nky = 1 + dg_py, dg_nkx = 1 + dg_px;                     // odd rows / columns collect two tap rows / columns, even ones the centre
+    const int m_base = KS4 ? m_tile * 16 : (dgs ? m_tile - dg_cls * a.dg_nmc : m_tile) * (64 * PT) + wave * (16 * PT);
 
     // ---- per-lane pixel bookkeeping ----
     bool pvalid[PT];
@@ -147,15 +154,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = m_base + pt * 16 + p;
-        pvalid[pt] = m < a.M;
+        pvalid[pt] = m < (dgs ? a.dg_mc : a.M);
         const int mm = pvalid[pt] ? m : 0;
         if (VAR == VAR_DIRECT) {
             off0[pt] = (uint32_t)mm * a.srcStride[0] + a.srcCoff[0];
         } else {
-            const int x = mm % a.W;
-            const int t = mm / a.W;
-            const int y = t % a.H;
-            const int b = t / a.H;
+            int x, y, b;
+            if (dgs) {                                                    // mm counts the pixels of ONE parity class
+                const int w2 = a.W >> 1, h2 = a.H >> 1;
+                const int t = mm / w2;
+                x = 2 * (mm - t * w2) + dg_px;
+                y = 2 * (t % h2) + dg_py;
+                b = t / h2;
+            } else {
+                x = mm % a.W;
+                const int t = mm / a.W;
+                y = t % a.H;
+                b = t / a.H;
+            }
             if (VAR == VAR_POOL2) {
                 off0[pt] = (uint32_t)((b * (2 * a.H) + 2 * y) * (2 * a.W) + 2 * x) * a.srcStride[0] + a.srcCoff[0];
             } else if (VAR == VAR_3X3S2) {
@@ -188,11 +204,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4_t)0.f;
 
-    const int ntaps = (VAR == VAR_3X3S2 || VAR == VAR_DGRAD3) ? 9 : 1;
+    const int ntaps = dgs ? dg_nky * dg_nkx : (VAR == VAR_3X3S2 || VAR == VAR_DGRAD3) ? 9 : 1;
     const int total_steps = ntaps * a.ksteps;
+    const int w_steps = (VAR == VAR_DGRAD3 ? 9 : ntaps) * a.ksteps;        // k-steps of the packed weights (all nine taps)
     const int s_begin = KS4 ? (total_steps * wave) / 4 : 0;
     const int s_end = KS4 ? (total_steps * (wave + 1)) / 4 : total_steps;
-    const frag_t* wbase = reinterpret_cast<const frag_t*>(w_all) + ((size_t)(n_tile * CT) * total_steps) * 64 + lane;
+    const frag_t* wbase = reinterpret_cast<const frag_t*>(w_all) + ((size_t)(n_tile * CT) * w_steps) * 64 + lane;
 
     // Activation fragments of k-step `step` (0 .. last; a step past `last` is reduction padding and reads zeros).
     // EVERY load is unconditional: a load under a branch makes the compiler wait with vmcnt(0) at the next use, which
@@ -218,7 +235,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
         } else if (VAR == VAR_DGRAD3) {
             const int tap = sc / a.ksteps, ks = sc - tap * a.ksteps;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            int ky, kx;
+            if (dgs) {                                                    // the class's own taps: both parities match by construction
+                const int ty = tap / dg_nkx, tx = tap - ty * dg_nkx;
+                ky = dg_py ? 2 * ty : 1;
+                kx = dg_px ? 2 * tx : 1;
+            } else {
+                ky = tap / 3;
+                kx = tap - ky * 3;
+            }
             int c0 = ks * F::KS + g * CH;
             c0 = c0 < a.Cin ? c0 : 0;
 #pragma unroll
@@ -261,9 +286,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
     auto load_a = [&](int step, frag_t (&af)[CT]) {                       // weights: padding steps re-read the last step (times zero activations)
-        const int sc = step > last_step ? last_step : step;
+        int sc = step > last_step ? last_step : step;
+        if (dgs) {                                                        // class tap -> its place among the nine packed taps
+            const int tap = sc / a.ksteps, ks = sc - tap * a.ksteps;
+            const int ty = tap / dg_nkx, tx = tap - ty * dg_nkx;
+            sc = ((dg_py ? 2 * ty : 1) * 3 + (dg_px ? 2 * tx : 1)) * a.ksteps + ks;
+        }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * total_steps + sc) * 64];
+        for (int ct = 0; ct < CT; ++ct) af[ct] = wbase[((size_t)ct * w_steps + sc) * 64];
     };
     auto mma_stage = [&](const frag_t (&bf)[PT], const frag_t (&af)[CT]) {
 #pragma unroll
@@ -384,8 +414,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m_base + pt * 16 + g * 4 + r;
-            if (m >= a.M) continue;
+            int m = m_base + pt * 16 + g * 4 + r;
+            if (m >= (dgs ? a.dg_mc : a.M)) continue;
+            if (dgs) {                                                    // class pixel -> linear pixel of the full-resolution output
+                const int w2 = a.W >> 1, h2 = a.H >> 1;
+                const int t = m / w2;
+                m = ((t / h2) * a.H + 2 * (t % h2) + dg_py) * a.W + 2 * (m - t * w2) + dg_px;
+            }
             float v[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[pt][ct][r] + bias[ct], a.act);
