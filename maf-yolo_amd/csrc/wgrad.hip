@@ -146,6 +146,123 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
         }
 }
 
+// NINE TAPS IN ONE WORKGROUP, for the narrowest 3x3 layer (the first stem conv, 8 -> 24 channels on 640^2: one input-channel tile).  With one tap per workgroup dY — the big operand there, 32 x 320 x 320 x 24 =
+// 157 MB — is read nine times (1.4 GB, 300 us per launch); here a pixel step stages dY once and the nine gathered X tiles next to it, and
+// the (tap, co tile, ci tile) output tiles are dealt round-robin to the four waves.
+template <int TPW>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgArgs2 a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
+    const int tci = (a.Cin + 15) >> 4, tco = (a.Cout + 15) >> 4;
+    const int cib = tci * 16, cob = tco * 16;
+    const int SX = cib + 8, SD = cob + 8;                                // LDS row strides in halfs
+    half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [9][kPix][SX]
+    half_t* Ds = Xs + 9 * kPix * SX;                                     // [kPix][SD]
+    const int ntile1 = tci * tco, ntile = 9 * ntile1;                    // virtual tile vt = (tap * tco + ti) * tci + tj, wave = vt % 4
+
+    constexpr int XR = 10, DR = 2;                                       // 16-byte chunks a thread stages per step (9 * 64 * cib / 8 / 256 <= 9 for cib = 32)
+    const int xg = cib >> 3, dg = cob >> 3;
+    const int nx = 9 * kPix * xg, nd = kPix * dg;
+
+    f32x4_t acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = (f32x4_t)0.f;
+
+    const int m_begin = blockIdx.x * a.chunk, m_end = min(a.M, m_begin + a.chunk);
+    half8_t xr[XR], dr[DR];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int it = tid + 256 * u;
+            if (it < nx) {
+                const int ch = (it % xg) * 8, r2 = it / xg;
+                const int row = r2 % kPix, tap = r2 / kPix;
+                const int m = m0 + row;
+                if (m < m_end && ch < a.Cin) {
+                    const int ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
+                    const int tky = tap / 3, tkx = tap - tky * 3;
+                    const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
+                    if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
+                        v = *reinterpret_cast<const half8_t*>(a.x + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + ch);
+                }
+            }
+            xr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int it = tid + 256 * u;
+            if (it < nd) {
+                const int ch = (it % dg) * 8, row = it / dg;
+                const int m = m0 + row;
+                if (m < m_end && ch < a.Cout) v = *reinterpret_cast<const half8_t*>(a.dy + (size_t)m * a.dy_stride + ch);
+            }
+            dr[u] = v;
+        }
+    };
+    fetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += kPix) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int it = tid + 256 * u;
+            if (it < nx) {
+                const int ch = (it % xg) * 8, r2 = it / xg;
+                *reinterpret_cast<half8_t*>(Xs + (size_t)r2 * SX + ch) = xr[u];          // r2 = tap * kPix + row
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int it = tid + 256 * u;
+            if (it < nd) *reinterpret_cast<half8_t*>(Ds + (it / dg) * SD + (it % dg) * 8) = dr[u];
+        }
+        __syncthreads();
+        if (m0 + kPix < m_end) fetch(m0 + kPix);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int vt = wave + 4 * t;
+            if (vt < ntile) {
+                const int tap = vt / ntile1, r1 = vt - tap * ntile1;
+                const int ti = r1 / tci, tj = r1 - ti * tci;
+                const half_t* ab = Ds + (g * 8 + (p >> 2)) * SD + ti * 16 + (p & 3) * 4;
+                const half_t* bb = Xs + ((size_t)tap * kPix + g * 8 + (p >> 2)) * SX + tj * 16 + (p & 3) * 4;
+#pragma unroll
+                for (int ks = 0; ks < kPix / 32; ++ks) {
+                    const half8_t av = tr_frag(ab + (ks * 32) * SD, ab + (ks * 32 + 4) * SD);
+                    const half8_t bv = tr_frag(bb + (ks * 32) * SX, bb + (ks * 32 + 4) * SX);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int vt = wave + 4 * t;
+        if (vt >= ntile) continue;
+        const int tap = vt / ntile1, r1 = vt - tap * ntile1;
+        const int ti = r1 / tci, tj = r1 - ti * tci;
+        const int ci = tj * 16 + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = ti * 16 + g * 4 + r;
+            if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)tap * a.dw_tap + (size_t)co * a.dw_stride + ci, acc[t][r]);
+        }
+    }
+}
+
+template <int TPW>
+int launch_taps(const WgArgs2& a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(wgrad)");
+        if (rc) return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_taps_kernel<TPW>), grid, dim3(256), lds, s, a);
+    return 0;
+}
+
 template <int TI, int NJ>
 int launch_tr(const WgArgs2& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr = false;
@@ -168,6 +285,20 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     b.x = x; b.dy = dy; b.dw = dw; b.M = M; b.Cin = Cin; b.Cout = Cout; b.x_stride = x_stride; b.dy_stride = dy_stride;
     b.gather = gather; b.Ho = Ho; b.Wo = Wo; b.Hs = Hs; b.Ws = Ws; b.tap0 = tap0; b.dw_stride = dw_stride; b.dw_tap = dw_tap;
     const int tci = (Cin + 15) / 16, tco_all = (Cout + 15) / 16;            // Cin <= 256: tci <= 16
+    static const bool no_taps = getenv("MAF_WGRAD_TAP_PER_WG") != nullptr;     // A/B: one tap per workgroup everywhere
+    // (measured, n at batch 32: 8 -> 24 on 640^2 422 -> 246 us; 24 -> 48 on 320^2 190 -> 252 us — with two channel tiles the nine gathers
+    //  of X outweigh the eight saved passes over dY: first stem conv only)
+    if (ntaps == 9 && tci == 1 && tco_all * 9 <= 64 && !no_taps) {
+        const int steps = maf_cdiv(M, kPix);
+        int gx = steps < 1024 ? steps : 1024;
+        b.chunk = maf_cdiv(steps, gx) * kPix;
+        gx = maf_cdiv(M, b.chunk);
+        const size_t lds = ((size_t)9 * kPix * (tci * 16 + 8) + (size_t)kPix * (tco_all * 16 + 8)) * 2;
+        const int tpw = maf_cdiv(tci * tco_all * 9, 4);
+        int rc = tpw <= 5 ? launch_taps<5>(b, dim3(gx), lds, s) : tpw <= 8 ? launch_taps<8>(b, dim3(gx), lds, s) : launch_taps<16>(b, dim3(gx), lds, s);
+        if (rc) return rc;
+        return maf_check_hip(hipGetLastError(), "conv wgrad launch");
+    }
     b.WJ = tci >= 4 ? 4 : tci >= 2 ? 2 : 1;
     const int NJ = (tci + b.WJ - 1) / b.WJ, WI = 4 / b.WJ;                 // 1 .. 4
     const int want = (tco_all + WI - 1) / WI;
