@@ -284,6 +284,10 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 
+/* Zero `bytes` bytes at p on `stream` (hipMemsetAsync): the fp32 accumulation buffers of maf_conv_wgrad / maf_dw_wgrad when those run on a stream
+ * of their own. */
+int maf_zero(void* p, int64_t bytes, maf_stream_t stream);
+
 /* MaxPool2d(k, stride, padding) of the training graph — SPPF.m (5, 1, 2; yolov6/layers/common.py:114-129) and MP (2, 2, 0; :667-673) —
  * NHWC views, fp16 / fp32, floor mode: x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = floor((H + 2 pad - k) / stride) + 1.  Forward keeps the chosen
  * window element (row * k + column, first maximum in scan order like aten) as one byte per element in idx [B,Ho,Wo,C]; backward is a

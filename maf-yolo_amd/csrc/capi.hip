@@ -14,6 +14,13 @@ int maf_check_hip(hipError_t e, const char* what) {
 }
 
 extern "C" const char* maf_last_error(void) { return g_err.c_str(); }
+// hipMemsetAsync(p, 0, bytes) on `stream`: accumulation buffers of kernels that run on a stream the framework's allocator / fill kernels are
+// not on (the weight-gradient side stream of the training layers)
+extern "C" int maf_zero(void* p, int64_t bytes, maf_stream_t stream) {
+    MAF_REQUIRE(p && bytes >= 0, "maf_zero: bad arguments");
+    return maf_check_hip(hipMemsetAsync(p, 0, (size_t)bytes, static_cast<hipStream_t>(stream)), "maf_zero");
+}
+
 extern "C" int maf_version(void) { return 200; }
 extern "C" int maf_op_size(void) { return (int)sizeof(maf_op_t); }
 

@@ -35,17 +35,17 @@ _pending = []
 
 
 class _prof:
-    def __init__(self, kind, nbytes, dev, note=None):
-        self.kind, self.nbytes, self.dev, self.note = kind, int(nbytes), dev, note
+    def __init__(self, kind, nbytes, dev, note=None, stream=None):
+        self.kind, self.nbytes, self.dev, self.note, self.stream = kind, int(nbytes), dev, note, stream
 
     def __enter__(self):
         if profile is not None:
             self.t = lib.Timer()
-            self.t.start(_stream(self.dev))
+            self.t.start(self.stream if self.stream is not None else _stream(self.dev))
 
     def __exit__(self, *exc):
         if profile is not None:
-            self.t.stop(_stream(self.dev))
+            self.t.stop(self.stream if self.stream is not None else _stream(self.dev))
             _pending.append((self.kind, self.nbytes, self.t, self.note))
         return False
 
@@ -96,35 +96,26 @@ def _join_side():
         torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(side)
 
 
-class _side:
-    """`with _side(dev, x, dy):` — the body's launches and allocations go to the device's side stream (see above); no-op when wgrad_stream is off."""
-
-    def __init__(self, dev, *tensors):
-        self.dev, self.tensors, self.ctx = dev, tensors, None
-
-    def __enter__(self):
-        if not wgrad_stream:
-            return self
-        side = _side_streams.get(self.dev.index)
-        if side is None:
-            side = _side_streams[self.dev.index] = torch.cuda.Stream(self.dev)
-            _side_events[self.dev.index] = torch.cuda.Event()
-        ev = _side_events[self.dev.index]                                       # one reusable event: a wait captures the record that precedes it
-        ev.record()                                                              # ... on the current (main) stream: dY is ready
-        side.wait_event(ev)
-        for t in self.tensors:                                                   # allocated on the main stream: not to be reused before the side stream is done
-            t.record_stream(side)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-            if not _immediate_join() and not _join_pending[0]:
-                _join_pending[0] = True
-                torch.autograd.Variable._execution_engine.queue_callback(_join_side)
-        return False
+def _fork(dev, *tensors):
+    """Raw handle of the stream a weight gradient is launched on: the device's side stream, made to wait for what the main stream has issued
+    so far (dY is ready) — or the main stream itself when wgrad_stream is off.  `tensors` (allocated on the main stream) are kept from being
+    reused before the side stream is done.  torch's current stream does not change (a torch.cuda.stream() context costs ~15 us per layer):
+    the caller passes the handle to the C-ABI and zeroes its accumulator with maf_zero on it."""
+    if not wgrad_stream:
+        return _stream(dev)
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
+        _side_events[dev.index] = torch.cuda.Event()
+    ev = _side_events[dev.index]                                                 # one reusable event: a wait captures the record that precedes it
+    ev.record()                                                                  # ... on the current (main) stream
+    side.wait_event(ev)
+    for t in tensors:
+        t.record_stream(side)
+    if not _immediate_join() and not _join_pending[0]:
+        _join_pending[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+    return side.cuda_stream
 
 
 def _side_done(dev):
@@ -451,23 +442,25 @@ class _Conv1x1(torch.autograd.Function):
 
 
 def _wgrad(x, dy, dys, w, ksize, stride):
-    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32.  Runs on
-    the side stream (`_side`): call it BEFORE the data gradient of the layer is launched."""
+    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32.  Launched on
+    the side stream (`_fork`): call it BEFORE the data gradient of the layer is launched."""
     B, cin, Hs, Ws = x.shape
     cout, Ho, Wo = dy.shape[1:]
     xx, xs = nhwc(x)
-    with _side(x.device, xx, dy):
-        co = -(-cout // 8) * 8
-        if co != cout:                                                          # e.g. reg_pred: 68 channels, an odd class count
-            dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
-            dys = co
-        dwf = torch.zeros((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)       # 3x3: tap-major (csrc/wgrad.hip)
-        with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride)):
-            lib.check(lib.load().maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), _stream(x.device)))
-        stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
-        if ksize == 3:
-            dwf = dwf.permute(2, 3, 0, 1)
-        return dwf[:cout].reshape(w.shape).to(w.dtype)
+    co = -(-cout // 8) * 8
+    if co != cout:                                                              # e.g. reg_pred: 68 channels, an odd class count
+        dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
+        dys = co
+    dwf = torch.empty((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)           # 3x3: tap-major (csrc/wgrad.hip)
+    h = _fork(x.device, xx, dy)
+    L = lib.load()
+    lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
+    with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride), h):
+        lib.check(L.maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), h))
+    stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
+    if ksize == 3:
+        dwf = dwf.permute(2, 3, 0, 1)
+    return dwf[:cout].reshape(w.shape).to(w.dtype)
 
 
 def _tile_dgrad(n, m_pixels):
@@ -742,12 +735,15 @@ class _DWConv(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[1]:
             xx, xs = nhwc(x)
-            reps = 32                                                           # copies of dW: atomics on one cache line serialise
-            with _side(x.device, xx, dy):
-                dwf = torch.zeros(reps, c, k * k, dtype=torch.float32, device=x.device)
-                with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys)):
-                    lib.check(lib.load().maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), reps, _stream(x.device)))
-                dw = dwf.sum(0).reshape(w.shape).to(w.dtype)
+            # one copy of dW: the kernel adds one value per (channel, tap) and workgroup after its own LDS reduction, so the replicas the
+            # first version spread its atomics over (and the torch sum behind them) buy <= 7 % on the 160 x 160 layers and nothing elsewhere
+            dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
+            h = _fork(x.device, xx, dy)
+            L = lib.load()
+            lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
+            with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys), h):
+                lib.check(L.maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), 1, h))
+            dw = dwf.reshape(w.shape).to(w.dtype)
         if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
             dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)

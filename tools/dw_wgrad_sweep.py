@@ -14,8 +14,9 @@ if len(sys.argv) > 1:
     for (H, C, k) in SHAPES:
         x = torch.randn(32, H, H, C, device="cuda").half()
         dy = torch.randn(32, H, H, C, device="cuda").half()
-        dw = torch.zeros(32, C, k * k, device="cuda")
-        f = lambda: lib.check(L.maf_dw_wgrad(x.data_ptr(), C, dy.data_ptr(), C, 32, H, H, C, k, lib.F16, dw.data_ptr(), 32, st))
+        R = int(os.environ.get("REPS", "32"))
+        dw = torch.zeros(R, C, k * k, device="cuda")
+        f = lambda: lib.check(L.maf_dw_wgrad(x.data_ptr(), C, dy.data_ptr(), C, 32, H, H, C, k, lib.F16, dw.data_ptr(), R, st))
         for _ in range(3):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
