@@ -758,3 +758,29 @@ def test_config4_m_bs1_640_hipgraph_latency_path(models):
     dets, idx = M.non_max_suppression(pred, 0.03, 0.65, multi_label=True, return_index=True)
     odets, oidx = O.non_max_suppression(pred.cpu().numpy(), 0.03, 0.65, multi_label=True, return_index=True)
     assert np.array_equal(dets[0].cpu().numpy(), odets[0]) and np.array_equal(idx[0].cpu().numpy(), oidx[0])
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
+    higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the roofline object of the dominant kernel; a short run at
+    batch 8 without tuning or the CPU leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "8", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-autotune"],
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "images/s" and d["dtype"] == "f16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 * 6 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["cpu_baseline"] is None                                  # --no-cpu-baseline
