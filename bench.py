@@ -160,26 +160,32 @@ def train_pmc_traffic(kind, scale):
     return int(total / calls), "profiles/round2_train_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 summed over the kind's kernels, per call (n, batch 32)"
 
 
-def train_mode(args, torch, M, dev, rank, world, dist):
-    """One step = forward (autocast fp16) + backward + DDP all-reduce + SGD step on a fixed synthetic batch per rank.
-    The loss is the device-side ComputeLoss (HIP task-aligned assignment + VFL / GIoU / DFL) on synthetic labels,
-    7 boxes per image (the COCO average); --surrogate-loss swaps in a mean over the head outputs (the first rounds' measurement)."""
+def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmup, full):
+    """The DDP train step of BASELINE configs[2]/[3] (yolov6/core/engine.py:141-167, 375-391, 477-489), timed with the bench protocol (barrier + device
+    sync on both sides, MAX over ranks): forward (autocast fp16) + ComputeLoss + backward + the gradient exchange + fused SGD + EMA on a fixed
+    synthetic batch per rank, 7 boxes per image.  EVERY world size — 1 included — runs the same schedule: maf_yolo_amd.GradExchange (weight
+    gradients -> flat buckets on the weight-gradient stream, one RCCL all-reduce per bucket launched from that stream, the main stream waits
+    once at the end of backward); at N = 1 the collectives are the only thing left out.  `--ddp` swaps in torch's DistributedDataParallel
+    (which forces a per-layer join of the weight-gradient stream) for an A/B.  Returns the dict of results on rank 0 (None elsewhere)."""
     from maf_yolo_amd import synth, train_ops
     import torch.nn.functional as F
     if args.torch_convs:                       # A/B: same module tree, convs through F.conv2d (MIOpen)
         train_ops.conv1x1 = lambda x, w, bias=None: F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
         train_ops.dwconv = lambda x, w: F.conv2d(x, w.to(x.dtype), None, 1, w.shape[-1] // 2, 1, x.shape[1])
-    model = M.Model(args.scale)
-    model.load_state_dict(synth.synth_state_dict(model, args.scale, 0))
+    stats0 = dict(train_ops.stats)
+    model = M.Model(scale)
+    model.load_state_dict(synth.synth_state_dict(model, scale, 0))
     model = model.to(dev).train()
-    net = model
-    if world > 1:
+    net, ex = model, None
+    if args.ddp and world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
+    elif not args.ddp:
+        ex = M.GradExchange(model)
     # build.py:12-33 grouping (BatchNorm weights and biases without decay), lr0 scaled like engine.py: fused SGD keeps the AMP inf check on the device
-    opt = M.build_optimizer(model, lr0=0.01 / 64 * args.batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
+    opt = M.build_optimizer(model, lr0=0.01 / 64 * batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
     scaler = torch.amp.GradScaler("cuda")
     ema = M.ModelEMA(model) if rank == 0 and not args.no_ema else None          # engine.py:67: the main process keeps the weight average
-    B = args.batch
+    B = batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255
     g = torch.Generator().manual_seed(100 + rank)
     nbox = 7 * B
@@ -195,8 +201,11 @@ def train_mode(args, torch, M, dev, rank, world, dist):
             loss = (cls.float().mean() + reg.float().pow(2).mean()) * world
         else:
             loss = crit((feats, cls, reg), targets, 0, 0)[0] * world            # engine.py:161-162 (loss scaled by the world size)
-        opt.zero_grad(set_to_none=True)
-        scaler.scale(loss).backward()
+        if ex is not None:
+            ex.zero_grad()                                                      # one memset per bucket; p.grad stays a view of its bucket
+        else:
+            opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()                                           # ex.finish() runs as the autograd engine's final callback
         scaler.step(opt)
         scaler.update()
         if ema is not None:
@@ -220,33 +229,35 @@ def train_mode(args, torch, M, dev, rank, world, dist):
             el = t_.item()
         return el
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = step()
     last = {}
 
     def one():
         last["loss"] = step()
-    elapsed = timed(one, args.steps)
+    elapsed = timed(one, steps)
     loss = last["loss"]
-    launches = dict(train_ops.stats)                            # before the CPU baseline below runs the same module tree on the host
-    # ---- exposed (non-overlapped) all-reduce time (BASELINE configs[3], yolov6/core/engine.py:477-489): the same steps with the gradient
-    # exchange switched off (DDP.no_sync: no bucket all-reduce is launched) — the difference is what the collective adds to a step after its
-    # overlap with the remaining backward
+    launches = {k: v - stats0.get(k, 0) for k, v in train_ops.stats.items()}    # before the CPU baseline runs the same module tree on the host
+    # ---- exposed (non-overlapped) all-reduce time (BASELINE configs[3], yolov6/core/engine.py:477-489): the same steps with the collectives
+    # switched off (no_sync) — the difference is what the exchange adds to a step after its overlap with the remaining backward
     comm = None
     if world > 1:
         def nosync():
-            with net.no_sync():
+            with (ex.no_sync() if ex is not None else net.no_sync()):
                 step()
-        k2 = max(5, args.steps // 2)
+        k2 = max(5, steps // 2)
         el_ns = timed(nosync, k2)
         grad_bytes = sum(p_.numel() * 4 for p_ in model.parameters() if p_.requires_grad)
-        comm = {"ms_per_step_without_all_reduce": round(1e3 * el_ns / k2, 3), "exposed_all_reduce_ms": round(1e3 * (elapsed / args.steps - el_ns / k2), 3),
+        comm = {"ms_per_step_without_all_reduce": round(1e3 * el_ns / k2, 3), "exposed_all_reduce_ms": round(1e3 * (elapsed / steps - el_ns / k2), 3),
                 "gradient_bytes_per_step": grad_bytes, "steps": k2,
-                "note": "same steps under DistributedDataParallel.no_sync(); RCCL all-reduce of the fp32 gradient buckets is overlapped with the backward by the autograd hooks"}
+                "buckets": None if ex is None else [int(b_.flat.numel() * 4) for b_ in ex.buckets],
+                "note": ("same steps under GradExchange.no_sync(); one RCCL all-reduce (AVG) per flat fp32 bucket, launched from the weight-gradient stream as soon as "
+                         "the bucket's last gradient has been issued" if ex is not None else
+                         "same steps under DistributedDataParallel.no_sync(); bucket all-reduces from the autograd hooks")}
     # ---- roofline of the dominant training kernel: one more step with HIP events around every native launch (train_ops.profile)
     roof = None
     if not args.torch_convs:
-        # EVERY rank runs this step (under DDP it carries the gradient all-reduce: a step on rank 0 alone would wait for its peers forever);
+        # EVERY rank runs this step (it carries the gradient all-reduce: a step on rank 0 alone would wait for its peers forever);
         # only rank 0 records the events
         if rank == 0:
             train_ops.profile = {}
@@ -258,26 +269,45 @@ def train_mode(args, torch, M, dev, rank, world, dist):
         tot = sum(v[0] for v in prof.values())
         kinds = sorted(prof.items(), key=lambda kv: -kv[1][0])
         k0, (ms0, by0, n0) = kinds[0]
-        traffic, traffic_src = train_pmc_traffic(k0, args.scale)
+        traffic, traffic_src = train_pmc_traffic(k0, scale)
         roof = {"bound": "hbm", "kernel": k0, "launches_per_step": n0, "avg_launch_ms": round(ms0 / n0, 5), "bytes_per_launch": int(by0 / n0),
                 "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3),
-                "by_kind": {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}}
-    if not math.isfinite(float(loss.detach())):
-        raise SystemExit("bench.py --train: the loss is not finite after %d steps — the run is invalid" % (args.warmup + args.steps))
+                "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3)}
+        if full:
+            roof["by_kind"] = {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}
+    final = float(loss.detach())
+    exs, nb = None, 0
+    if ex is not None:
+        exs, nb = dict(ex.stats), len(ex.buckets)
+        ex.close()
+    if not math.isfinite(final):
+        raise SystemExit("bench.py train leg: the loss is not finite after %d steps — the run is invalid" % (warmup + steps))
+    if rank != 0:
+        return None
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if full and not args.no_cpu_baseline:
         cpu = train_cpu_baseline(args, torch, M)
+    fallback = int(launches.get("fallback", 0) + launches.get("torch_bn", 0) + launches.get("torch_maxpool", 0) + launches.get("framework_wgrad_fp32", 0))
+    return {"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD+EMA, AMP fp16)" % (scale, B),
+            "value": round(world * B * steps / elapsed, 1), "images_per_s": round(world * B * steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, %s" % (scale, B, "surrogate loss over all head outputs" if args.surrogate_loss else "ComputeLoss (HIP task-aligned assigner + VFL/GIoU/DFL), 7 boxes/image"),
+                       "global_batch": B * world, "parallelism": "ddp%d" % world,
+                       "gradient_exchange": ("torch DistributedDataParallel" if ex is None and world > 1 else "none (plain autograd)" if ex is None else
+                                             "maf_yolo_amd.GradExchange: %d flat fp32 buckets filled on the weight-gradient stream, all-reduce per bucket from that stream%s"
+                                             % (nb, "" if world > 1 else " (world size 1: same schedule, no collective)")),
+                       "exchange_stats": exs,
+                       "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
+                       "native_launches": launches, "fallback": fallback, "final_loss": round(final, 5)},
+            "native_launches": int(sum(v for k, v in launches.items() if k.startswith("native_"))), "fallback": fallback, "final_loss": round(final, 5),
+            "roofline": roof, "cpu_baseline": cpu, "all_reduce": comm}
+
+
+def train_mode(args, torch, M, dev, rank, world, dist):
+    res = train_leg(args, torch, M, dev, rank, world, dist, args.scale, args.batch, args.steps, args.warmup, True)
     if rank == 0:
-        print(json.dumps({"metric": "train images/sec MAF-YOLO-%s 640x640 bs=%d/GPU DDP (fwd+bwd+all-reduce+SGD+EMA, AMP fp16)" % (args.scale, B),
-                          "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-                          "config": {"workload": "MAF-YOLO-%s train-form, %d x 3x640x640 per GPU, %s" % (args.scale, B, "surrogate loss over all head outputs" if args.surrogate_loss else "ComputeLoss (HIP task-aligned assigner + VFL/GIoU/DFL), 7 boxes/image"),
-                                     "global_batch": B * world, "parallelism": "ddp%d" % world,
-                                     "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
-                                     "native_launches": launches, "final_loss": round(float(loss.detach()), 5)},
-                          "roofline": roof, "cpu_baseline": cpu, "all_reduce": comm}), flush=True)
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -305,6 +335,9 @@ def main():
                     help="BASELINE configs[2]/[3] instead: DDP training step (train-form graph, AMP fp16, SGD), images/s; use with --scale s|m --batch 32|16")
     ap.add_argument("--surrogate-loss", action="store_true", help="with --train: mean over the head outputs instead of ComputeLoss")
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
+    ap.add_argument("--ddp", action="store_true", help="--train A/B: torch's DistributedDataParallel instead of maf_yolo_amd.GradExchange (N > 1; at N = 1: plain autograd)")
+    ap.add_argument("--no-train-leg", action="store_true", help="leave the short training leg (`train` object: n, bs 32/GPU) out of the default line")
+    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the training leg of the default line (after 4 warm-up steps)")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
@@ -587,6 +620,18 @@ def main():
                               "note": "the same steps with no overlap: forward, NMS, result handed to the host, next forward (rank-local); the GPU idles "
                                       "during the host hand-over, so this one follows host jitter"},
                "roofline": roofline, "cpu_baseline": cpu}
+    # ---- the training half of BASELINE's metric ("train imgs/s @1/2/4/8"): a short leg of the DDP train step (n, 32 images per GPU) inside the
+    # same driver-timed run; `--train` is the long form (any scale / batch, per-kind roofline, CPU baseline)
+    train = None
+    if not args.no_train_leg:
+        del dets
+        model._plans = {}
+        torch.cuda.empty_cache()
+        train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 4, False)
+    if rank == 0:
+        if train is not None:
+            train.pop("cpu_baseline", None)
+        out["train"] = train
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

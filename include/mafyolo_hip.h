@@ -284,6 +284,13 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
 
+/* Gradient fold of the owned gradient exchange (maf_yolo_amd/exchange.py; the reference leaves this to autograd's AccumulateGrad + the DDP
+ * reducer's bucket copy, yolov6/core/engine.py:161-164): src = what a weight-gradient kernel produced, tap-major [taps][Cout_p][Cin_p] fp32 with
+ * padded channel counts; dst = the parameter-shaped slice [Cout][Cin][taps] of a flat gradient bucket; accumulate != 0 adds (gradient
+ * accumulation over several backward passes), 0 overwrites.  Runs on `stream` (the weight-gradient stream). */
+int maf_grad_fold(const float* src, int32_t taps, int32_t Cout_p, int32_t Cin_p, float* dst, int32_t Cout, int32_t Cin, int32_t accumulate,
+                  maf_stream_t stream);
+
 /* Zero `bytes` bytes at p on `stream` (hipMemsetAsync): the fp32 accumulation buffers of maf_conv_wgrad / maf_dw_wgrad when those run on a stream
  * of their own. */
 int maf_zero(void* p, int64_t bytes, maf_stream_t stream);

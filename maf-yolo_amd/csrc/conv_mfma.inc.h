@@ -70,6 +70,13 @@ int maf_conv_mfma_dgrad3(const ConvArgs& a, int dtype, int pt, int ct, hipStream
 int maf_conv1x1_stream(const ConvArgs& a, int pt, int ct, hipStream_t s);              // persistent waves, cross-tile prefetch (tile_k = 3)
 int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s);        // the same with LDS-resident weights (tile_k = 5)
 
+// Profiling builds only (make ko KO=<bits>, tools/conv_probe.py; never the shipped library): MAF_KO knocks one piece out of conv_mfma_kernel
+// to see what it costs.  1: weight fragments are constants (no weight loads)  2: activation fragments are constants (no activation loads)
+// 4: no output stores  8: no MFMAs (operands folded into the accumulator with one add, so the loads stay live)
+#ifndef MAF_KO
+#define MAF_KO 0
+#endif
+
 namespace {
 
 // 16 zero bytes in global memory: the stride-2 3x3 conv points its out-of-image taps here, so every operand load is
@@ -219,6 +226,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int last_step = (KS4 ? (total_steps * (wave + 1)) / 4 : total_steps) - 1;
     const T* zpage = reinterpret_cast<const T*>(g_zero16);
     auto load_b = [&](int step, frag_t (&bf)[PT]) {
+        if (MAF_KO & 2) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) bf[pt] = (frag_t)(T)(0.001f * (float)(lane + step));
+            return;
+        }
         const bool pad = step > last_step;                                 // uniform
         const int sc = pad ? last_step : step;
         if (VAR == VAR_3X3S2) {
@@ -286,6 +298,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
     auto load_a = [&](int step, frag_t (&af)[CT]) {                       // weights: padding steps re-read the last step (times zero activations)
+        if (MAF_KO & 1) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) af[ct] = (frag_t)(T)(0.002f * (float)(lane + ct));
+            return;
+        }
         int sc = step > last_step ? last_step : step;
         if (dgs) {                                                        // class tap -> its place among the nine packed taps
             const int tap = sc / a.ksteps, ks = sc - tap * a.ksteps;
@@ -299,7 +316,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = F::mma(bf[pt], af[ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
+            for (int ct = 0; ct < CT; ++ct) {
+                if (MAF_KO & 8) acc[pt][ct][0] += (float)bf[pt][0] + (float)af[ct][0];
+                else acc[pt][ct] = F::mma(bf[pt], af[ct], acc[pt][ct]);   // A = activations (rows = pixels), B = weights
+            }
     };
 
     if constexpr (LB) {
@@ -317,6 +337,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int idx = tid + v * 256;
+                if (MAF_KO & 1) { wr[v] = (frag_t)(T)(0.002f * (float)(lane + v)); continue; }
                 if (idx < CT * 64) wr[v] = wsrc[((size_t)(idx >> 6) * total_steps + step) * 64 + (idx & 63)];
             }
         };
@@ -416,6 +437,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int r = 0; r < 4; ++r) {
             int m = m_base + pt * 16 + g * 4 + r;
             if (m >= (dgs ? a.dg_mc : a.M)) continue;
+            if ((MAF_KO & 4) && acc[pt][0][r] != 12345.678f) continue;
             if (dgs) {                                                    // class pixel -> linear pixel of the full-resolution output
                 const int w2 = a.W >> 1, h2 = a.H >> 1;
                 const int t = m / w2;

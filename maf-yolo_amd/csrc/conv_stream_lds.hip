@@ -8,6 +8,29 @@
 
 namespace {
 
+template <int ACT, int CT>
+__device__ __forceinline__ void sl_store(const f32x4_t (&acc)[CT], int r, half_t* op, int nvalid) {
+    float v[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) v[ct] = (MAF_KO & 16) ? acc[ct][r] : maf_act<ACT>(acc[ct][r]);
+    if (nvalid >= CT) {
+        uint32_t w[CT / 2];
+#pragma unroll
+        for (int c2 = 0; c2 < CT / 2; ++c2) {
+            const half2_t h = {(half_t)v[2 * c2], (half_t)v[2 * c2 + 1]};
+            w[c2] = __builtin_bit_cast(uint32_t, h);
+        }
+        if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
+        else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
+        else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
+        else *reinterpret_cast<uint32_t*>(op) = w[0];
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct < nvalid) op[ct] = (half_t)v[ct];
+    }
+}
+
 template <int CT, int KS, bool MULTI>
 __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs a) {
     typedef Frag<half_t> F;
@@ -19,10 +42,14 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
     const int wg = blockIdx.x / a.nN, nwg = gridDim.x / a.nN;
     const int ntiles = (a.M + 15) >> 4;
     {
-        const frag_t* wsrc = reinterpret_cast<const frag_t*>(a.w) + ((size_t)(n_tile * CT) * KS) * 64;   // [ct][ks][64]
-        for (int i = tid; i < KS * CT * 64; i += 256) {
-            const int ln = i & 63, ct = (i >> 6) % CT, ks = (i >> 6) / CT;
-            wl[i] = wsrc[((size_t)ct * KS + ks) * 64 + ln];
+        // the channel tile's fragments travel global -> LDS by DMA (global_load_lds: 1 KiB per wave-instruction to a wave-uniform base + lane * 16;
+        // no registers, no ds_write, ALL of them in flight at once — the first version walked them with a load -> wait -> ds_write loop, 18
+        // dependent L2 round trips per workgroup before the first MFMA)
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)(n_tile * CT) * KS) * 1024;   // [ct][ks][64 x 16 B]
+        for (int f = wave; f < KS * CT; f += 4) {                       // LDS order: fragment f = ks * CT + ct
+            const int ks = f / CT, ct = f - ks * CT;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + ((size_t)ct * KS + ks) * 1024 + lane * 16),
+                                             (void __attribute__((address_space(3)))*)(wl_raw + f * 1024), 16, 0, 0);
         }
     }
     const int cl = n_tile * (16 * CT) + p * CT;
@@ -30,10 +57,14 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) bias[ct] = a.bias[cl + ct];
     const int nvalid = a.Cout - cl;
-    __syncthreads();
 
     // per k-step: which source, which channel chunk (scalar; steps past a source's last chunk read chunk 0 x zero weights)
     auto load_tile = [&](int t, frag_t (&af)[KS]) {
+        if (MAF_KO & 2) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] = (frag_t)(half_t)(0.001f * (float)(lane + ks + t));
+            return;
+        }
         int m = t * 16 + p;
         m = m < a.M ? m : a.M - 1;
         if constexpr (!MULTI) {
@@ -66,6 +97,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
             }
         }
     };
+    const int act = a.act;                                               // uniform: the activation is picked once per tile, not per value
     auto compute_store = [&](int t, const frag_t (&af)[KS]) {
         f32x4_t acc[CT];
 #pragma unroll
@@ -74,42 +106,34 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
         for (int ks = 0; ks < KS; ++ks) {
             frag_t wf[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = wl[(ks * CT + ct) * 64 + lane];
+            for (int ct = 0; ct < CT; ++ct) wf[ct] = (MAF_KO & 1) ? (frag_t)(half_t)(0.002f * (float)(lane + ct)) : wl[(ks * CT + ct) * 64 + lane];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[ct] = F::mma(af[ks], wf[ct], acc[ct]);
+            for (int ct = 0; ct < CT; ++ct) {
+                if (MAF_KO & 8) acc[ct][0] += (float)af[ks][0] + (float)wf[ct][0];
+                else acc[ct] = F::mma(af[ks], wf[ct], acc[ct]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = t * 16 + g * 4 + r;
             if (m >= a.M) continue;
-            float v[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[ct][r], a.act);
+            if ((MAF_KO & 4) && acc[0][r] != 12345.678f) continue;
             half_t* op = static_cast<half_t*>(a.out) + (size_t)m * a.out_stride + a.out_coff + cl;
-            if (nvalid >= CT) {
-                uint32_t w[CT / 2];
-#pragma unroll
-                for (int c2 = 0; c2 < CT / 2; ++c2) {
-                    const half2_t h = {(half_t)v[2 * c2], (half_t)v[2 * c2 + 1]};
-                    w[c2] = __builtin_bit_cast(uint32_t, h);
-                }
-                if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
-                else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
-                else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
-                else *reinterpret_cast<uint32_t*>(op) = w[0];
-            } else {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nvalid) op[ct] = (half_t)v[ct];
-            }
+            if (act == MAF_ACT_SILU) sl_store<MAF_ACT_SILU, CT>(acc, r, op, nvalid);
+            else if (act == MAF_ACT_NONE) sl_store<MAF_ACT_NONE, CT>(acc, r, op, nvalid);
+            else if (act == MAF_ACT_RELU) sl_store<MAF_ACT_RELU, CT>(acc, r, op, nvalid);
+            else sl_store<MAF_ACT_SIGMOID, CT>(acc, r, op, nvalid);
         }
     };
 
     frag_t fa[KS], fb[KS];
     const int stride = nwg * 4;
     int t = wg * 4 + wave;
-    if (t >= ntiles) return;
-    load_tile(t, fa);
+    const bool any = t < ntiles;
+    if (any) load_tile(t, fa);                                           // in flight beside the weight DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
+    __syncthreads();                                                     // ... and everybody else's
+    if (!any) return;
     while (true) {
         const int t1 = t + stride;
         if (t1 < ntiles) load_tile(t1, fb);
@@ -127,15 +151,22 @@ template <int CT, int KS, bool MULTI>
 int launch_sl(const ConvArgs& a, hipStream_t s) {
     constexpr int lds = KS * CT * 1024;
     static_assert(lds <= 160 * 1024, "weights of one channel tile must fit LDS");
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
+    static int occ = 0;                                                  // resident workgroups per CU of this instantiation (LDS and registers)
+    if (!occ) {
+        if (lds > 64 * 1024) {
+            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
+            if (rc) return rc;
+        }
+        int nb = 0;
+        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI>, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
         if (rc) return rc;
-        attr = true;
+        occ = nb < 1 ? 1 : nb > 4 ? 4 : nb;
     }
+    // ONE round of persistent workgroups: exactly what is resident at once (a second round pays the weight DMA and the ramp-up again for a
+    // handful of tiles per wave), spread evenly over the channel tiles
     const int ntiles = (a.M + 15) >> 4;
     int per = (ntiles + 3) / 4;                                          // workgroups per channel tile that still have work
-    const int cap = 256 * 4 / a.nN > 0 ? 256 * 4 / a.nN : 1;
+    const int cap = occ * 256 / a.nN > 0 ? occ * 256 / a.nN : 1;
     if (per > cap) per = cap;
     hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI>), dim3(per * a.nN), dim3(256), lds, s, a);
     return maf_check_hip(hipGetLastError(), "conv1x1_stream_lds launch");

@@ -14,6 +14,7 @@
 // torch.library.register_autograd, registers the autocast rule (cast to the autocast dtype, like a convolution) and the fake (meta)
 // kernels.  No kernel lives here: this file only marshals tensors into the C-ABI (include/mafyolo_hip.h).
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -105,6 +106,7 @@ Tensor pad_channels8(const Tensor& x) {            // a 3-channel image for kern
 }
 
 Tensor conv1x1_bias_act(const Tensor& x_in, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act) {
+    const c10::DeviceGuard device_guard(x_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor x = pad_channels8(nhwc(x_in));
     TORCH_CHECK(w.dim() == 4 && w.size(2) == 1 && w.size(3) == 1 && w.size(1) == x_in.size(1), "conv1x1_bias_act: w must be [Cout, Cin, 1, 1]");
     const int dt = dtype_of(x);
@@ -118,6 +120,7 @@ Tensor conv1x1_bias_act(const Tensor& x_in, const Tensor& w, const c10::optional
 }
 
 Tensor conv1x1_dgrad(const Tensor& dy_in, const Tensor& w) {       // dX = dY . W
+    const c10::DeviceGuard device_guard(dy_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor dy = nhwc(dy_in);
     const int dt = dtype_of(dy);
     const int64_t cout = w.size(0), cin = w.size(1), mult = dt == MAF_F16 ? 8 : 4, kk = (cout + mult - 1) / mult * mult;
@@ -135,6 +138,7 @@ Tensor conv1x1_dgrad(const Tensor& dy_in, const Tensor& w) {       // dX = dY . 
 }
 
 Tensor conv3x3s2_bias_act(const Tensor& x_in, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act) {
+    const c10::DeviceGuard device_guard(x_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor x = pad_channels8(nhwc(x_in));
     TORCH_CHECK(w.dim() == 4 && w.size(2) == 3 && w.size(3) == 3 && w.size(1) == x_in.size(1), "conv3x3s2_bias_act: w must be [Cout, Cin, 3, 3]");
     TORCH_CHECK(w.size(0) % 2 == 0, "conv3x3s2_bias_act: even Cout");
@@ -146,6 +150,7 @@ Tensor conv3x3s2_bias_act(const Tensor& x_in, const Tensor& w, const c10::option
 }
 
 Tensor conv3x3s2_dgrad(const Tensor& dy_in, const Tensor& w, int64_t H, int64_t W) {
+    const c10::DeviceGuard device_guard(dy_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor dy = nhwc(dy_in);
     const int dt = dtype_of(dy);
     const int64_t cin = w.size(1), ci = (cin + 7) / 8 * 8;
@@ -156,6 +161,7 @@ Tensor conv3x3s2_dgrad(const Tensor& dy_in, const Tensor& w, int64_t H, int64_t 
 }
 
 Tensor conv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t ksize, int64_t stride) {     // fp32 dW [Cout, Cin, k, k]
+    const c10::DeviceGuard device_guard(x_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor x = pad_channels8(nhwc(x_in)), dy = nhwc(dy_in);
     TORCH_CHECK(x.scalar_type() == at::kHalf && dy.scalar_type() == at::kHalf, "conv_wgrad: fp16 activations and gradients (the fp32 parity mode uses the framework's GEMM)");
     const int64_t cout = dy.size(1), co = (cout + 7) / 8 * 8;
@@ -170,6 +176,7 @@ Tensor conv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t ksize, int64_
 }
 
 Tensor dw_launch(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t act, int flip) {
+    const c10::DeviceGuard device_guard(x.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     const int dt = dtype_of(x);
     const int64_t c = x.size(1), k = w.size(3);
     TORCH_CHECK(w.size(0) == c && w.size(1) == 1 && w.size(2) == k && (k == 3 || k == 5 || k == 7 || k == 9), "dwconv: w must be [C, 1, k, k], k in {3,5,7,9}");
@@ -193,6 +200,7 @@ Tensor dwconv_bias_act(const Tensor& x, const Tensor& w, const c10::optional<Ten
 Tensor dwconv_dgrad(const Tensor& dy, const Tensor& w) { return dw_launch(nhwc(dy), w, c10::nullopt, MAF_ACT_NONE, 1); }      // correlation with the flipped kernel
 
 Tensor dwconv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t k) {
+    const c10::DeviceGuard device_guard(x_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     Tensor x = nhwc(x_in), dy = nhwc(dy_in);
     const int64_t c = x.size(1), reps = 32;
     Tensor dw = at::zeros({reps, c, k * k}, x.options().dtype(at::kFloat).memory_format(c10::nullopt));
@@ -203,6 +211,8 @@ Tensor dwconv_wgrad(const Tensor& x_in, const Tensor& dy_in, int64_t k) {
 
 // cls[l] [B, nc, H_l, W_l] (probabilities), reg[l] [B, 4*(reg_max+1), H_l, W_l] (logits), any dtype / layout -> pred fp32 [B, A, 5+nc]
 Tensor head_decode(at::TensorList cls, at::TensorList reg, at::ArrayRef<double> strides) {
+    TORCH_CHECK(cls.size() > 0, "mafyolo::head_decode: empty level list");
+    const c10::DeviceGuard device_guard(cls[0].device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     TORCH_CHECK(cls.size() == 3 && reg.size() == 3 && strides.size() == 3, "head_decode: three detection levels");
     std::vector<Tensor> c(3), r(3);
     maf_op_t op = {};
@@ -226,6 +236,7 @@ Tensor head_decode(at::TensorList cls, at::TensorList reg, at::ArrayRef<double> 
 
 // -> rows [B, max_det, 6] (x1, y1, x2, y2, conf, cls; rows past counts[b] are unspecified), counts int32 [B]
 std::tuple<Tensor, Tensor> decode_nms(const Tensor& pred_in, double conf, double iou, bool agnostic, bool multi_label, int64_t max_det, at::OptionalIntArrayRef classes) {
+    const c10::DeviceGuard device_guard(pred_in.device());      // ops get no automatic device guard: kernels, allocations and the stream follow the tensor's device
     TORCH_CHECK(conf >= 0 && conf <= 1, "conf_thresh must be in 0.0 to 1.0, however ", conf, " is provided.");
     TORCH_CHECK(iou >= 0 && iou <= 1, "iou_thres must be in 0.0 to 1.0, however ", iou, " is provided.");
     TORCH_CHECK(pred_in.is_cuda() && pred_in.dim() == 3, "decode_nms: prediction [B, N, 5+nc] on the HIP device");

@@ -244,7 +244,28 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     return maf_check_hip(hipGetLastError(), "dw_wgrad launch");
 }
 
+// Gradient fold (maf_grad_fold): the weight-gradient kernels leave dW in THEIR layout — tap-major [taps][Cout_p][Cin_p] with the channel
+// counts padded to what the kernels read (8-channel chunks) — and the optimizer wants the parameter's [Cout][Cin][taps]: one small launch adds
+// (or writes) the valid part into the gradient slice, on the stream the weight gradient ran on.
+__global__ void grad_fold_kernel(const float* __restrict__ src, int taps, int co_p, int ci_p, float* __restrict__ dst, int cout, int cin, int accumulate, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int t = i % taps, r = i / taps, ci = r % cin, co = r / cin;
+    const float v = src[((size_t)t * co_p + co) * ci_p + ci];
+    dst[i] = accumulate ? dst[i] + v : v;
+}
+
 }  // namespace
+
+extern "C" int maf_grad_fold(const float* src, int32_t taps, int32_t Cout_p, int32_t Cin_p, float* dst, int32_t Cout, int32_t Cin, int32_t accumulate,
+                             maf_stream_t stream) {
+    MAF_REQUIRE(src && dst && taps > 0 && Cout > 0 && Cin > 0 && Cout <= Cout_p && Cin <= Cin_p, "grad_fold: bad arguments");
+    const long long total = (long long)taps * Cout * Cin;
+    MAF_REQUIRE(total < (1ll << 31), "grad_fold: tensor too large");
+    hipLaunchKernelGGL(grad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src, taps, Cout_p, Cin_p, dst, Cout, Cin,
+                       accumulate, (int)total);
+    return maf_check_hip(hipGetLastError(), "grad_fold launch");
+}
 
 extern "C" int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c,
                              void* out, maf_stream_t stream) {

@@ -69,15 +69,26 @@ class ModelEMA:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._pairs_of = None
+        self._sig = None
 
     def _pairs(self, model):
         src = de_parallel(model)
-        if self._pairs_of is not src:                                             # (ema tensor, model tensor) of every floating entry, state_dict order
+        stale = self._pairs_of is not src
+        if not stale:
+            # the cached tensors must still BE the model's / the average's storage: `.to()`, `.cuda()`, `p.data = ...` replace it silently.
+            # One pass over the parameter lists comparing addresses (no device work) — the reference re-reads state_dict() on every update.
+            stale = self._sig != self._signature(src)
+        if stale:                                                                 # (ema tensor, model tensor) of every floating entry, state_dict order
             sd = src.state_dict()
             self._dst = [v for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
             self._src = [sd[k].detach() for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
             self._pairs_of = src
+            self._sig = self._signature(src)
         return self._dst, self._src
+
+    def _signature(self, src):
+        return (tuple(p.data_ptr() for p in src.parameters()), tuple(b.data_ptr() for b in src.buffers()),
+                tuple(p.data_ptr() for p in self.ema.parameters()), tuple(b.data_ptr() for b in self.ema.buffers()))
 
     def update(self, model):
         with torch.no_grad():

@@ -74,56 +74,69 @@ def _stream(dev):
 
 # Weight gradients run on a SIDE stream: dW of a layer depends on nothing that follows it in the backward chain (dY -> dX -> BatchNorm
 # backward -> ...), whose kernels are short and leave the chip idle while they ramp up and drain.  The side stream waits for the main
-# stream at the launch (dY is ready), the main stream waits for the side stream
-#   * at the end of the backward pass (an autograd engine callback) in a single-process run, or
-#   * before the backward of the layer returns when torch.distributed runs with more than one rank: DDP's reducer copies a gradient into
-#     its bucket from the AccumulateGrad hook on the main stream, so dW must be ordered before that hook (the overlap is then with the
-#     data gradient of the same layer only).
+# stream at the launch (dY is ready).  Who waits for the side stream depends on where the gradient goes:
+#   * with a gradient exchange (exchange.GradExchange, `exchange.current`): the kernel accumulates straight into the parameter's slice of a
+#     flat bucket, the autograd Function returns None for the weight, nothing on the main stream reads dW, and the main stream waits ONCE at
+#     the end of backward (GradExchange.finish) — the bucket all-reduces are launched from the side stream too;
+#   * without one (plain autograd, DistributedDataParallel): the Function returns dW as a tensor that AccumulateGrad / the pad backward of the
+#     stem / the DDP reducer read on the MAIN stream straight away, so the main stream waits for the side stream before the layer's backward
+#     returns (`_side_done`) — the overlap is then with the data gradient of the same layer only.
 wgrad_stream = os.environ.get("MAF_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 _side_events = {}
-_join_pending = [False]
+_side_used = {}                                  # device index -> the side stream holds work the main stream has not waited for
 
 
-def _immediate_join():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def side_stream(dev):
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
+        _side_events[dev.index] = torch.cuda.Event()
+    return side
 
 
-def _join_side():
-    _join_pending[0] = False
-    for idx, side in _side_streams.items():
-        torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(side)
+def join_side(dev):
+    """The main (current) stream of `dev` waits for everything its side stream holds."""
+    side = _side_streams.get(dev.index)
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        _side_used[dev.index] = False
 
 
 def _fork(dev, *tensors):
     """Raw handle of the stream a weight gradient is launched on: the device's side stream, made to wait for what the main stream has issued
     so far (dY is ready) — or the main stream itself when wgrad_stream is off.  `tensors` (allocated on the main stream) are kept from being
     reused before the side stream is done.  torch's current stream does not change (a torch.cuda.stream() context costs ~15 us per layer):
-    the caller passes the handle to the C-ABI and zeroes its accumulator with maf_zero on it."""
+    the caller passes the handle to the C-ABI."""
     if not wgrad_stream:
         return _stream(dev)
-    side = _side_streams.get(dev.index)
-    if side is None:
-        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
-        _side_events[dev.index] = torch.cuda.Event()
+    side = side_stream(dev)
     ev = _side_events[dev.index]                                                 # one reusable event: a wait captures the record that precedes it
     ev.record()                                                                  # ... on the current (main) stream
     side.wait_event(ev)
     for t in tensors:
         t.record_stream(side)
-    if not _immediate_join() and not _join_pending[0]:
-        _join_pending[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+    _side_used[dev.index] = True
     return side.cuda_stream
 
 
-def _side_done(dev):
-    """End of a layer's backward: under torch.distributed (world size > 1) the main stream waits for this layer's weight gradient here."""
-    if wgrad_stream and _side_streams and _immediate_join():
-        side = _side_streams.get(dev.index)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
+def _side_done(dev, returned_dw):
+    """End of a layer's backward.  `returned_dw`: the weight gradient goes back to autograd as a tensor — its consumers run on the main
+    stream, which therefore waits for the side stream here."""
+    if returned_dw and wgrad_stream and _side_used.get(dev.index):
+        join_side(dev)
+
+
+def _grad_sink(w):
+    """(exchange, bucket view) when the weight gradient of parameter `w` goes straight into a gradient exchange, else (None, None)."""
+    from . import exchange
+    ex = exchange.current
+    if ex is None or not isinstance(w, torch.nn.Parameter):
+        return None, None
+    ent = ex.target(w)
+    if ent is None:
+        return None, None
+    return ex, ent[1]
 
 
 def _zero_bias(dev, n):
@@ -276,6 +289,9 @@ def begin_step(plan, dev):
     """Make `plan` the current one and stage every weight it knows in one launch on the current stream of `dev`."""
     global _plan
     _plan = plan
+    from . import exchange
+    if exchange.current is not None:                                            # a new forward/backward pass of the gradient exchange: per-pass state reset
+        exchange.current.begin()
     if plan is None or not plan.entries or dev.type != "cuda":
         return
     ents = list(plan.entries.values())
@@ -405,7 +421,7 @@ class _Conv1x1(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             if x.dtype == torch.float16:                                        # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
-                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels)
+                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels); None: went into the exchange
             else:                                                                # fp32 parity mode: the framework's TN GEMM
                 x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
                 d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
@@ -437,30 +453,43 @@ class _Conv1x1(torch.autograd.Function):
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt, pt, tk)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3), dtype=torch.float32)
-        _side_done(x.device)
+        _side_done(x.device, dw is not None)
         return dx, dw, db
 
 
 def _wgrad(x, dy, dys, w, ksize, stride):
-    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32.  Launched on
-    the side stream (`_fork`): call it BEFORE the data gradient of the layer is launched."""
+    """fp16 weight gradient on csrc/wgrad.hip (maf_conv_wgrad): x [B,Cin_x,Hs,Ws], dy [B,Cout,Ho,Wo] NHWC views -> dW like w, fp32 (Cin_x >= w's
+    input channels: the stem's image padded to 8).  Launched on the side stream (`_fork`): call it BEFORE the data gradient of the layer is
+    launched.  With a gradient exchange the result is accumulated into w's slice of its bucket on that stream and None is returned."""
     B, cin, Hs, Ws = x.shape
     cout, Ho, Wo = dy.shape[1:]
+    cin_w = w.shape[1]
     xx, xs = nhwc(x)
     co = -(-cout // 8) * 8
     if co != cout:                                                              # e.g. reg_pred: 68 channels, an odd class count
         dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
         dys = co
-    dwf = torch.empty((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)           # 3x3: tap-major (csrc/wgrad.hip)
-    h = _fork(x.device, xx, dy)
+    ex, view = _grad_sink(w)
+    direct = ex is not None and ksize == 1 and co == cout and cin == cin_w      # the kernel's [Cout][Cin] IS the parameter's layout: accumulate in place
     L = lib.load()
-    lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
+    if direct:
+        dwf = view
+        h = _fork(x.device, xx, dy)
+    else:
+        dwf = torch.empty((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)       # 3x3: tap-major (csrc/wgrad.hip)
+        h = _fork(x.device, xx, dy, dwf)
+        lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
     with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride), h):
         lib.check(L.maf_conv_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, Ho, Wo, Hs, Ws, cin, co, ksize, stride, lib.F16, dwf.data_ptr(), h))
     stats["native_wgrad"] = stats.get("native_wgrad", 0) + 1
+    if ex is not None:
+        if not direct:                                                          # tap-major / padded -> the parameter's [Cout][Cin][taps], added on the side stream
+            lib.check(L.maf_grad_fold(dwf.data_ptr(), ksize * ksize, co, cin, view.data_ptr(), cout, cin_w, 1, h))
+        ex.side_done(w, folded=not direct)
+        return None
     if ksize == 3:
         dwf = dwf.permute(2, 3, 0, 1)
-    return dwf[:cout].reshape(w.shape).to(w.dtype)
+    return dwf[:cout, :cin_w].reshape(w.shape).to(w.dtype)
 
 
 def _tile_dgrad(n, m_pixels):
@@ -539,9 +568,10 @@ class _Conv3x3s2(torch.autograd.Function):
             if x.dtype == torch.float16:
                 dw = _wgrad(x, dy, dys, w, 3, 2)
             else:                                                                # fp32 parity mode: the framework's kernel
-                dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=2, padding=1).to(w.dtype)
+                dw = torch.nn.grad.conv2d_weight(x[:, :w.shape[1]], w.shape, dy, stride=2, padding=1).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
+            # (an input whose channels were padded — the image — gets zeros in the padding: the packer pads W^T's rows to the channel tile)
             pt, ct = _tile_dgrad(cin, B * H * W)
             wp = _packed_3x3(w, True, dt, ct, x.device)
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -555,7 +585,7 @@ class _Conv3x3s2(torch.autograd.Function):
             es = x.element_size()
             with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device, (B, H, W, cin, cout, pt, ct)):
                 lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
-        _side_done(x.device)
+        _side_done(x.device, dw is not None)
         return dx, dw
 
 
@@ -572,7 +602,8 @@ class _Conv1x1s2(torch.autograd.Function):
         Ho, Wo = H // 2, W // 2
         dt = _DT[x.dtype]
         pt, ct = pack.tile_for(cout, B * Ho * Wo)
-        wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 0, dt, ct, x.device, w)
+        cin_w = w.shape[1]                                                       # < cin for the stem: the image's channels are padded to 8, the weight's K to whole k-steps by the packer
+        wp = _packed_1x1(w.detach().reshape(cout, cin_w).float().contiguous(), cout, cin_w, 0, dt, ct, x.device, w)
         out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         op = lib.MafOp()
         op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
@@ -602,17 +633,18 @@ class _Conv1x1s2(torch.autograd.Function):
             if x.dtype == torch.float16:
                 dw = _wgrad(x, dy, dys, w, 1, 2)
             else:
-                xsub = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(-1, cin)
+                xsub = x[:, :w.shape[1], ::2, ::2].permute(0, 2, 3, 1).reshape(-1, w.shape[1])
                 dw = torch.mm(dy.permute(0, 2, 3, 1).reshape(-1, cout).t(), xsub).float().reshape(w.shape).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
+            cin_w = w.shape[1]                                                   # < cin: padded image channels get a zero gradient (W^T's rows are padded to the channel tile)
             ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
-            wp = _packed_1x1(w.detach().reshape(cout, cin).float().contiguous(), cout, cin, 1, dt, ct, x.device, w)
+            wp = _packed_1x1(w.detach().reshape(cout, cin_w).float().contiguous(), cout, cin_w, 1, dt, ct, x.device, w)
             dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
             dx[:, :, ::2, ::2] = dxs
-        _side_done(x.device)
+        _side_done(x.device, dw is not None)
         return dx, dw
 
 
@@ -627,16 +659,17 @@ def pad_channels8(x):
 
 
 def _pad8(x, w):
-    """(x, w) with the input channels of both padded to a multiple of 8 (x may come padded already: pad_channels8); the gradient slices of
-    the padding are dropped by autograd."""
+    """x with its channels padded to a multiple of 8 (it may come padded already: pad_channels8).  The WEIGHT stays the parameter itself:
+    the packers zero-pad its K to whole k-steps, and the weight-gradient path slices the valid input channels back out (`_wgrad`), so the
+    parameter's gradient never passes through an autograd pad node on the main stream."""
     cin = w.shape[1]
     if x.shape[1] == cin:
         if cin % 8 == 0:
-            return x, w
+            return x
         x = pad_channels8(x)
     if x.shape[1] != -(-cin // 8) * 8:
         raise lib.MafError("conv: input has %d channels, the filters %d" % (x.shape[1], cin))
-    return x, F.pad(w, (0, 0, 0, 0, 0, x.shape[1] - cin))
+    return x
 
 
 def conv3x3s2(x, w):
@@ -647,7 +680,7 @@ def conv3x3s2(x, w):
     x = _autocast(x)
     if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
         raise lib.MafError("conv3x3s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
-    return _Conv3x3s2.apply(*_pad8(x, w))
+    return _Conv3x3s2.apply(_pad8(x, w), w)
 
 
 def conv1x1s2(x, w):
@@ -658,7 +691,7 @@ def conv1x1s2(x, w):
     x = _autocast(x)
     if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (1, 1)):
         raise lib.MafError("conv1x1s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
-    return _Conv1x1s2.apply(*_pad8(x, w))
+    return _Conv1x1s2.apply(_pad8(x, w), w)
 
 
 def conv1x1(x, w, bias=None):
@@ -737,17 +770,25 @@ class _DWConv(torch.autograd.Function):
             xx, xs = nhwc(x)
             # one copy of dW: the kernel adds one value per (channel, tap) and workgroup after its own LDS reduction, so the replicas the
             # first version spread its atomics over (and the torch sum behind them) buy <= 7 % on the 160 x 160 layers and nothing elsewhere
-            dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
-            h = _fork(x.device, xx, dy)
+            ex, view = _grad_sink(w)
             L = lib.load()
-            lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
+            if ex is not None:                                                    # [C][k*k] is the parameter's layout: the atomics land in its bucket slice
+                dwf = view
+                h = _fork(x.device, xx, dy)
+            else:
+                dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
+                h = _fork(x.device, xx, dy, dwf)
+                lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
             with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys), h):
                 lib.check(L.maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), 1, h))
-            dw = dwf.reshape(w.shape).to(w.dtype)
+            if ex is not None:
+                ex.side_done(w)
+            else:
+                dw = dwf.reshape(w.shape).to(w.dtype)
         if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
             dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
-        _side_done(x.device)
+        _side_done(x.device, dw is not None)
         return dx, dw
 
 
@@ -865,6 +906,10 @@ def bn_act(x, bn, act=None, residual=None):
     if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64):
         counter.add_(1)
         counter = None
+    if bn.momentum is None and bn.track_running_stats:
+        # nn.BatchNorm2d(momentum=None) = cumulative moving average (factor 1 / num_batches_tracked): not what the kernel implements, and
+        # not what the reference builds (momentum 0.03, yolov6/utils/torch_utils.py:43-45) — refuse rather than freeze the statistics
+        raise lib.MafError("bn_act: BatchNorm2d(momentum=None) (cumulative average) is not supported on the HIP path")
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual)

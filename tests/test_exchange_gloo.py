@@ -1,0 +1,131 @@
+"""The owned gradient exchange (maf_yolo_amd/exchange.py) against DistributedDataParallel, world size 2 on CPU / gloo.
+
+Reference contract (yolov6/core/engine.py:161-164, 477-489): after backward every rank holds the rank-average of the gradients of the
+world-size-scaled loss.  GradExchange must give the same numbers as torch's DDP on the same model, data and loss — with one backward pass,
+and with gradient accumulation under no_sync() (engine.py:377-388: `accumulate` backward passes per optimizer step)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _loss(model, x, world):
+    (feats, cls, reg), _ = model(x)
+    return (cls.mean() + reg.pow(2).mean()) * world
+
+
+def _worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import maf_yolo_amd as M
+    from maf_yolo_amd import exchange
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a = M.Model("n").train()
+    b = M.Model("n").train()
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(100 + rank)
+    xs = [torch.rand(2, 3, 64, 64, generator=g) for _ in range(2)]
+
+    # ---- DistributedDataParallel: one pass, then two passes with accumulation (the first under no_sync)
+    ddp = torch.nn.parallel.DistributedDataParallel(a)
+    _loss(ddp, xs[0], world).backward()
+    ref1 = {n: p.grad.clone() for n, p in a.named_parameters() if p.grad is not None}
+    ddp.zero_grad(set_to_none=True)
+    with ddp.no_sync():
+        _loss(ddp, xs[0], world).backward()
+    _loss(ddp, xs[1], world).backward()
+    ref2 = {n: p.grad.clone() for n, p in a.named_parameters() if p.grad is not None}
+
+    # ---- GradExchange on the twin model (BatchNorm running statistics differ after the passes above; gradients do not depend on them)
+    ex = M.GradExchange(b, bucket_bytes=1 << 20)
+    ex.zero_grad()
+    _loss(b, xs[0], world).backward()
+    got1 = {n: p.grad.clone() for n, p in b.named_parameters() if p.requires_grad}
+    n_coll1 = ex.stats["collectives"]
+    ex.zero_grad()
+    with ex.no_sync():
+        _loss(b, xs[0], world).backward()
+    n_coll_nosync = ex.stats["collectives"] - n_coll1
+    _loss(b, xs[1], world).backward()
+    got2 = {n: p.grad.clone() for n, p in b.named_parameters() if p.requires_grad}
+    views_ok = all(p.grad.data_ptr() == ex.slot[id(p)][1].data_ptr() for p in b.parameters() if p.requires_grad)
+
+    def worst(ref, got):
+        w = 0.0
+        for n, r in ref.items():
+            w = max(w, float((got[n] - r).abs().max() / (r.abs().max() + 1e-12)))
+        return w
+    # identical on both ranks?
+    flat = torch.cat([v.flatten() for v in got2.values()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    if rank == 0:
+        out.put(dict(err1=worst(ref1, got1), err2=worst(ref2, got2), buckets=len(ex.buckets), collectives=n_coll1, nosync=n_coll_nosync,
+                     same=bool(torch.equal(both[0], both[1])), views_ok=views_ok, missing=[n for n in ref1 if n not in got1]))
+    ex.close()
+    assert exchange.current is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_exchange_matches_ddp_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res["missing"] == []
+    assert res["buckets"] >= 4 and res["collectives"] == res["buckets"], res           # one all-reduce per bucket and pass
+    assert res["nosync"] == 0, "no_sync() must not launch collectives"
+    assert res["err1"] < 1e-5, res                                                       # same sums in a different order: fp32 round-off only
+    assert res["err2"] < 1e-5, res
+    assert res["same"], "ranks disagree after the exchange"
+    assert res["views_ok"], "p.grad must stay a view of the bucket"
+
+
+def test_grad_exchange_single_process_matches_autograd():
+    """World size 1: same schedule minus the collectives; gradients equal plain autograd's, zero_grad() survives set_to_none."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import maf_yolo_amd as M
+    torch.manual_seed(0)
+    a = M.Model("n").train()
+    b = M.Model("n").train()
+    b.load_state_dict(a.state_dict())
+    x = torch.rand(2, 3, 64, 64)
+    _loss(a, x, 1).backward()
+    ex = M.GradExchange(b)
+    try:
+        for _ in range(2):
+            ex.zero_grad()
+            _loss(b, x, 1).backward()
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            assert not p.requires_grad or torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+        torch.optim.SGD(b.parameters(), lr=0.1).zero_grad(set_to_none=True)            # an optimizer drops the views ...
+        ex.zero_grad()                                                                 # ... and the exchange puts them back
+        _loss(b, x, 1).backward()
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            if not p.requires_grad:
+                continue
+            assert q.grad.data_ptr() == ex.slot[id(q)][1].data_ptr(), n
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+        assert ex.stats["collectives"] == 0
+    finally:
+        ex.close()

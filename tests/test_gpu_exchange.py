@@ -1,0 +1,155 @@
+"""-m gpu: the owned gradient exchange on the device (maf_yolo_amd/exchange.py; reference: DDP in yolov6/core/engine.py:161-164, 477-489).
+
+Weight gradients go from the HIP kernels on the SIDE stream straight into flat buckets (p.grad = a view), autograd never sees them, and the
+main stream waits once at the end of backward.  These tests pin that path to plain autograd — including at the full 32 x 640 x 640 AMP size
+where a missing stream join shows (round-2 advisor finding: dW read on the main stream while the side stream was still adding)."""
+import math
+
+import pytest
+import torch
+
+import maf_yolo_amd as M
+from maf_yolo_amd import exchange, synth, train_ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+PROBE = ["backbone.0.rbr_dense.conv.weight", "backbone.0.rbr_1x1.conv.weight", "backbone.1.rbr_dense.conv.weight", "backbone.3.conv2.rbr_dense.conv.weight",
+         "backbone.2.conv1.conv.weight", "backbone.8.m.0.conv2.dwconv.lk_origin.weight", "backbone.18.block.conv.weight", "backbone.31.reg_pred.weight",
+         "backbone.31.cls_pred.bias", "backbone.20.conv2.bn.weight", "backbone.33.stem.conv.weight"]
+
+
+def _model(scale="n"):
+    m = M.Model(scale)
+    m.load_state_dict(synth.synth_state_dict(m, scale, 0))
+    return m.to(DEV).train()
+
+
+def _loss(model, x, amp):
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        (feats, cls, reg), _ = model(x)
+    # scaled like a GradScaler would (fp16 gradients of a mean over 10^5 outputs underflow otherwise and what is compared is noise)
+    return (cls.float().mean() * 100 + reg.float().pow(2).mean()) * 8192.0
+
+
+def _grads(model):
+    return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
+
+
+def _check(got, ref, names=None, factor=1.0, tol=3e-3):
+    """Per parameter against its own max |g| with a floor at 1e-4 of the model's largest gradient (a bias in front of a BatchNorm has a zero
+    gradient in exact arithmetic: what is there is round-off)."""
+    G = max(float(v.abs().max()) for v in ref.values()) * factor
+    worst = max((float((got[n] - factor * ref[n]).abs().max()) / (tol * factor * float(ref[n].abs().max()) + 1e-4 * G), n) for n in (names or ref))
+    assert worst[0] < 1.0, worst
+
+
+def _drop_grads(model):
+    for p in model.parameters():
+        p.grad = None
+
+
+@pytest.mark.parametrize("bs,size", [(4, 128), (32, 640)])
+def test_exchange_gradients_equal_plain_autograd_amp(bs, size):
+    """ONE forward pass, three backward passes over it (a deep fp16 net with batch statistics amplifies the run-to-run noise of the fp32 atomics
+    through its forward: two separate forwards differ by percents in the stem's gradient, which says nothing about the exchange): plain
+    autograd first, then the same graph into the exchange, then once more without zero_grad (gradient accumulation)."""
+    x = synth.synth_images(bs, size, seed=3).to(DEV)
+    m = _model()
+    assert exchange.current is None
+    loss = _loss(m, x, True)
+    loss.backward(retain_graph=True)
+    ref = _grads(m)
+    _drop_grads(m)
+    ex = M.GradExchange(m)
+    try:
+        loss.backward(retain_graph=True)                 # ex.finish() = the engine's final callback: the main stream has waited for the side stream
+        got = _grads(m)                                  # ... so these clones (main stream) see finished gradients
+        assert ex.stats["side_direct"] > 100 and ex.stats["side_folded"] >= 10 and ex.stats["main_hook"] > 100, ex.stats
+        assert set(ref) == set(got)
+        _check(got, ref)
+        ex.begin()                                       # (a training loop's next forward does this)
+        loss.backward()                                  # accumulation: every gradient doubles; stem and 3x3 layers go through the fold kernel
+        got2 = _grads(m)
+        torch.cuda.synchronize()
+        _check(got2, ref, factor=2.0)
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert p.grad.data_ptr() == ex.slot[id(p)][1].data_ptr(), n
+    finally:
+        ex.close()
+
+
+def test_plain_autograd_joins_the_side_stream_per_layer():
+    """Without an exchange dW goes back to autograd as a tensor that AccumulateGrad reads on the main stream: every layer joins the side stream
+    before its backward returns.  Two backward passes over one forward without zero_grad at the full size (the accumulate add — and the
+    non-contiguous 3x3 dW that AccumulateGrad clones — were the early readers of round 2's advisor finding)."""
+    x = synth.synth_images(32, 640, seed=5).to(DEV)
+    a = _model()
+    loss = _loss(a, x, True)
+    loss.backward(retain_graph=True)
+    g1 = _grads(a)
+    loss.backward()
+    g2 = _grads(a)
+    torch.cuda.synchronize()
+    _check(g2, g1, factor=2.0)
+
+
+def test_exchange_survives_a_failed_backward():
+    """A backward pass that raises leaves no stale state: the next forward re-arms the exchange (round-2 advisor finding on _join_pending)."""
+    x = synth.synth_images(2, 128, seed=7).to(DEV)
+    b = _model()
+    ex = M.GradExchange(b)
+    try:
+        ex.zero_grad()
+        loss = _loss(b, x, True)
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        with pytest.raises(RuntimeError):
+            (Boom.apply(b.backbone[0].rbr_dense.conv.weight.sum()) * 0 + loss).backward()
+        ex.zero_grad()
+        loss = _loss(b, x, True)                          # the forward re-arms the exchange (train_ops.begin_step -> GradExchange.begin)
+        loss.backward(retain_graph=True)
+        got = _grads(b)
+        ex.close()
+        _drop_grads(b)
+        loss.backward()
+        ref = _grads(b)
+        torch.cuda.synchronize()
+        _check(got, ref)
+    finally:
+        ex.close()
+
+
+def test_exchange_train_step_fp16_scaler_and_fused_sgd():
+    """The step bench.py times: GradScaler + fused SGD read the bucket views; the loss goes down over a few steps and stays finite."""
+    x = synth.synth_images(4, 128, seed=9).to(DEV)
+    m = _model()
+    ex = M.GradExchange(m)
+    try:
+        opt = M.build_optimizer(m, lr0=0.01, momentum=0.937, weight_decay=5e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+        fb0 = train_ops.stats["fallback"]
+        for _ in range(3):
+            loss = _loss(m, x, True)
+            ex.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        assert math.isfinite(float(loss))
+        moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.requires_grad)
+        assert moved >= 0.9 * len(before), (moved, len(before))
+        assert train_ops.stats["fallback"] == fb0
+    finally:
+        ex.close()
