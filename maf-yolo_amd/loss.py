@@ -162,8 +162,12 @@ class ComputeLoss:
         self.topk, self.alpha, self.beta = 13, 1.0, 6.0                       # loss.py:46
         self.fused = fused                     # False: same assigner kernels, loss terms as torch ops (the A/B the fused kernels are tested against)
         self._cache = {}
+        self.last_assignment = None
 
-    def __call__(self, outputs, targets, epoch_num=0, step_num=0):
+    def __call__(self, outputs, targets, epoch_num=0, step_num=0, assignment=None):
+        """(loss, items) as the reference's ComputeLoss.__call__ (loss.py:51-176).  `assignment` (not in the reference): a label assignment to use
+        instead of running the assigner — the `last_assignment` = (box row per anchor or -1 [B,A] int32, normalised metric [B,A] fp32) of an
+        earlier call on the same labels; parity tests freeze the discrete top-k choices of an fp32 pass this way when they run the fp16 pass."""
         feats, pred_scores, pred_distri = outputs
         dev = pred_scores.device
         if not pred_scores.is_cuda:
@@ -183,10 +187,13 @@ class ComputeLoss:
             boxes = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
             lib.check(lib.load().maf_loss_decode(pd.data_ptr(), lib.F16 if pd.dtype == torch.float16 else lib.F32, pts.data_ptr(), st_flat.data_ptr(),
                                                  B, A, self.reg_max, boxes.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-            if epoch_num < self.warmup_epoch:                                   # loss.py:83-91
+            if assignment is not None:
+                out_gt, out_norm = assignment
+            elif epoch_num < self.warmup_epoch:                                 # loss.py:83-91
                 out_gt, out_norm = _assign_atss(boxes, pts, levels, gts, gt_img, offs, T, 9, self.grid_cell_size)
             else:
                 out_gt, out_norm = _assign(ps, boxes, pts, levels, gts, gt_img, offs, T, self.topk, self.alpha, self.beta)
+            self.last_assignment = (out_gt, out_norm)
             out = _FusedTerms.apply(ps, pd, pts, st_flat, gts, out_gt, out_norm, self.reg_max, (float(lw["class"]), float(lw["iou"]), float(lw["dfl"])))
             return out[0], out[1:4].detach()
         loss_cls, loss_iou, loss_dfl = self._torch_terms(pred_scores, pred_distri, pts, st, levels, gts, gt_img, offs, T, epoch_num < self.warmup_epoch)

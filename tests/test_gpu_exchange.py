@@ -39,9 +39,11 @@ def _rel(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
 
 
-def _check(got, ref, names=None, factor=1.0, tol=3e-3):
+def _check(got, ref, names=None, factor=1.0, tol=1e-2):
     """Per parameter against its own max |g| with a floor at 1e-4 of the model's largest gradient (a bias in front of a BatchNorm has a zero
-    gradient in exact arithmetic: what is there is round-off)."""
+    gradient in exact arithmetic: what is there is round-off).  1e-2: the two backward passes differ by the order of the fp32 atomics in the BatchNorm
+    reductions, which moves single fp16 roundings of dx (measured: up to 1e-2 of max |g| on the 4 x 128 x 128 batch, where a layer has few pixels to
+    average over; 2e-3 at 32 x 640 x 640); a missing stream join shows as errors of order one."""
     G = max(float(v.abs().max()) for v in ref.values()) * factor
     worst = max((float((got[n] - factor * ref[n]).abs().max()) / (tol * factor * float(ref[n].abs().max()) + 1e-4 * G), n) for n in (names or ref))
     assert worst[0] < 1.0, worst

@@ -182,3 +182,32 @@ def test_fp16_engine_plus_nms_vs_reference_detections_640(golden):
         assert len(pairs) >= 294, (len(pairs), miss)
         assert len(hard) <= 2, hard
         assert ds <= 2e-3, ds
+
+
+@pytest.mark.parametrize("scale,min_pairs,max_hard,max_ds", [("s", 290, 4, 5e-3), ("m", 280, 8, 1e-2)])
+def test_fp16_engine_plus_nms_vs_reference_detections_640_s_m(golden, scale, min_pairs, max_hard, max_ds):
+    """The same end-to-end check for the graphs of BASELINE configs[2] / [3] / [4] (s, m): fp16 engine -> fp32 decode + NMS at the BASELINE size
+    against the REFERENCE's fp32 detections on the same 2 x 640 x 640 images (tools/make_golden_nms640.py).  Bars per scale at about twice what
+    the device measured (printed); the fp16 gap grows with depth and width (boxes 0.3 px at n, 2.2 px at m)."""
+    g = golden("nms640_" + scale)
+    m = M.Model(scale)
+    m.load_state_dict(O.synth_state_dict(scale, 0))
+    m = m.to(DEV).eval()
+    x = O.synth_images(2, 640, 1).to(DEV).half()
+    with torch.no_grad():
+        pred = m(x)[0]
+    rows = pred[:, ::16].float().cpu().numpy()
+    ref_rows = g["pred640_rows16"]
+    print("%s: max |d score| over every 16th anchor %.2e, max |d box| %.2f px" % (scale, np.abs(rows[..., 4:] - ref_rows[..., 4:]).max(), np.abs(rows[..., :4] - ref_rows[..., :4]).max()))
+    dets = M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
+    for b in range(2):
+        ref, got = g["nms640_eval_%d" % b], dets[b].cpu().numpy()
+        assert got.shape == ref.shape == (300, 6)
+        pairs, miss, extra = match_detections(got, ref)
+        floor = ref[:, 4].min()
+        hard = [i for i in miss if ref[i, 4] > floor + 1e-2]
+        ds = max(abs(ref[i, 4] - got[j, 4]) for i, j in pairs)
+        print("%s image %d: %d/%d matched, %d near-cut misses, %d hard misses, max |dscore| %.2e" % (scale, b, len(pairs), ref.shape[0], len(miss) - len(hard), len(hard), ds))
+        assert len(pairs) >= min_pairs, (len(pairs), miss)
+        assert len(hard) <= max_hard, hard
+        assert ds <= max_ds, ds

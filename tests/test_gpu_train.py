@@ -442,24 +442,47 @@ def _ramp_sum(t):
     return np.array([a.sum(), np.abs(a).sum(), (a * ramp).sum(), np.abs(a).max()])
 
 
+# fp16-class bars of the amp leg per scale: (sampled element error / max |g|, relative error of sum |g|), set at about twice what the device measured
+# (printed by the test).  With the assignment frozen to the fp32 pass's the gradient field differs from the fp32 fixture by fp16 arithmetic only.
+_AMP_BARS = {"n": (3e-2, 3e-2), "s": (3e-2, 3e-2), "m": (3e-2, 3e-2)}
+
+
 @pytest.mark.parametrize("tag,epoch,kw", [("tal", 5, dict(warmup_epoch=0)), ("atss", 0, dict())])
 @pytest.mark.parametrize("amp", [False, True])
-def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp):
-    """a15 pinned to the REFERENCE (VERDICT r1 missing #3): train-mode forward of the HIP-backed module tree + device ComputeLoss + backward
-    == the reference's own Model.train() + ComputeLoss + autograd on the same seeded weights, images and labels (tools/make_golden_train.py,
-    CPU fp32): loss, items, head outputs, 32 parameter gradients of every layer kind, BatchNorm running statistics.
-    fp32: summation-order noise only.  amp: the reference's recipe (autocast fp16, engine.py:149) against the same fp32 fixture, fp16-class bars."""
+@pytest.mark.parametrize("scale", ["n", "s", "m"])
+def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp, scale):
+    """a15 pinned to the REFERENCE for all three graphs of BASELINE's configs (n; s = configs[2]; m = configs[3]): train-mode forward of the
+    HIP-backed module tree + device ComputeLoss + backward == the reference's own Model.train() + ComputeLoss + autograd on the same seeded
+    weights, images and labels (tools/make_golden_train.py <scale>, CPU fp32): loss, items, head outputs, 32+ parameter gradients of every
+    layer kind, BatchNorm running statistics.
+    fp32: summation-order noise only.  amp: the reference's recipe (autocast fp16, engine.py:149) against the same fp32 fixture — with the label
+    ASSIGNMENT FROZEN to the one the fp32 pass made on the same inputs (autocast moves the head outputs by ~1e-3, which flips a few of the
+    assigner's discrete top-k choices; that is a property of the recipe, not of the kernels) — held to fp16-class bars element by element."""
     from oracle import maf_oracle as O
-    g = golden("train_n")
-    m = M.Model("n")
-    m.load_state_dict(O.synth_state_dict("n", 0))
+    g = golden("train_" + scale)
+    m = M.Model(scale)
+    m.load_state_dict(O.synth_state_dict(scale, 0))
     m = m.to(DEV).train()
     x = O.synth_images(2, 128, 7).to(DEV)
     targets = torch.tensor(_TRAIN_TARGETS, dtype=torch.float32, device=DEV)
     crit = M.ComputeLoss(ori_img_size=128, **kw)
+    frozen = None
+    if amp:                                                  # the fp32 pass: its assignment only (momentum 0: the running statistics stay put)
+        mom = {}
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mom[mod] = mod.momentum
+                mod.momentum = 0.0
+        with torch.no_grad():
+            (f0, c0, r0), _ = m(x)
+            crit((f0, c0, r0), targets, epoch, 1)
+        frozen = crit.last_assignment
+        for mod, v in mom.items():
+            mod.momentum = v
+            mod.num_batches_tracked.zero_()
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
         (feats, cls, reg), _ = m(x)
-    loss, items = crit((feats, cls, reg), targets, epoch, 1)
+    loss, items = crit((feats, cls, reg), targets, epoch, 1, assignment=frozen)
     scale_ = 1024.0 if amp else 1.0                          # GradScaler's job (engine.py:164): keep fp16 gradients out of the subnormals
     (loss * scale_).backward()
     rl, ri = (2e-2, 3e-2) if amp else (2e-4, 5e-4)
@@ -470,28 +493,25 @@ def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp):
     ref_reg = g[tag + "_reg_rows"]
     assert np.abs(reg[:, ::37].float().detach().cpu().numpy() - ref_reg).max() <= (3e-2 if amp else 2e-4) * max(1.0, np.abs(ref_reg).max())
     params = dict(m.named_parameters())
-    worst = 0.0
+    worst, worst_sum = (0.0, ""), (0.0, "")
     for i, name in enumerate(g["names"].tolist()):
         assert params[name].grad is not None, name
         gr = params[name].grad / scale_
         ref_sum, ref_smp = g["%s_g%d_sum" % (tag, i)], g["%s_g%d_sample" % (tag, i)]
-        scale = ref_sum[3]                                   # max |gradient| of this parameter in the reference
+        sc = ref_sum[3]                                      # max |gradient| of this parameter in the reference
         got_smp = gr.reshape(-1)[::max(1, gr.numel() // 64)][:64].float().cpu().numpy()
-        err = np.abs(got_smp - ref_smp).max() / max(scale, 1e-12)
-        worst = max(worst, err)
+        err = np.abs(got_smp - ref_smp).max() / max(sc, 1e-12)
         got_sum = _ramp_sum(gr)
-        if amp:
-            # autocast changes the head outputs by ~1e-3, which flips a few of the assigner's DISCRETE top-k choices: the gradients then
-            # differ structurally from the fp32 fixture (measured: sum |g| within 12 %, single elements within 31 % of max |g|, also for
-            # the layers right under the loss), so the amp leg bounds the size of the gradient field, not its elements; element-level fp16
-            # parity of every kernel is in the per-kernel tests above (2e-2 / 3e-2 against fp32 references)
-            assert abs(got_sum[1] - ref_sum[1]) <= 0.25 * ref_sum[1] + 1e-12 and err <= 0.6, (name, err)
-            continue
-        assert err <= 2e-3, (name, err)
-        # checksums over ALL elements: sum |g| within the same relative bar, max |g| likewise
-        assert abs(got_sum[1] - ref_sum[1]) <= 2e-3 * ref_sum[1] + 1e-12, name
-        assert abs(got_sum[3] - ref_sum[3]) <= 2e-3 * ref_sum[3] + 1e-12, name
-    print("%s amp=%s: worst sampled gradient error %.2e of the parameter's max |g|" % (tag, amp, worst))
+        esum = abs(got_sum[1] - ref_sum[1]) / (ref_sum[1] + 1e-12)
+        worst, worst_sum = max(worst, (err, name)), max(worst_sum, (esum, name))
+    print("%s %s amp=%s: worst sampled gradient error %.2e of the parameter's max |g| (%s), worst sum|g| error %.2e (%s)" % ((scale, tag, amp) + worst + worst_sum))
+    ebar, sbar = _AMP_BARS[scale] if amp else (2e-3, 2e-3)
+    assert worst[0] <= ebar, worst
+    assert worst_sum[0] <= sbar, worst_sum
+    if not amp:
+        for i, name in enumerate(g["names"].tolist()):      # max |g| over ALL elements likewise
+            got_sum, ref_sum = _ramp_sum(params[name].grad), g["%s_g%d_sum" % (tag, i)]
+            assert abs(got_sum[3] - ref_sum[3]) <= 2e-3 * ref_sum[3] + 1e-12, name
     if tag == "tal":
         sd = m.state_dict()
         for i, k in enumerate(g["bn_names"].tolist()):
@@ -730,3 +750,46 @@ def test_every_conv_variant_the_train_tuner_may_pick(M_hw, cin, cout):
         assert err <= 2e-3 * ref.abs().max().item() + 2e-3, (pt, ct, tk, err)
         ran += 1
     assert ran == len(cands)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,bs", [("s", 32), ("m", 16)])
+def test_full_size_amp_train_step_of_configs_2_and_3(scale, bs):
+    """BASELINE configs[2] (s, 32 images per GPU of a global batch 64 on 2 GPUs) and configs[3] (m, 16 per GPU of 128 on 8) at their real per-GPU
+    workload, 640 x 640: two AMP steps (forward + ComputeLoss + backward through the gradient exchange + fused SGD) with every conv, weight
+    gradient and BatchNorm on the HIP kernels — zero framework fallbacks, a finite loss, and (nearly) every parameter moved."""
+    import math
+    from maf_yolo_amd import synth
+    m = M.Model(scale)
+    m.load_state_dict(synth.synth_state_dict(m, scale, 0))
+    m = m.to(DEV).train()
+    ex = M.GradExchange(m)
+    try:
+        opt = M.build_optimizer(m, lr0=0.01, momentum=0.937, weight_decay=5e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        x = synth.synth_images(bs, 640, seed=2).to(DEV)
+        gen = torch.Generator().manual_seed(5)
+        wh = torch.rand(7 * bs, 2, generator=gen) * 0.35 + 0.04
+        ctr = wh / 2 + torch.rand(7 * bs, 2, generator=gen) * (1 - wh)
+        targets = torch.cat([torch.arange(bs).repeat_interleave(7)[:, None].float(), torch.randint(0, 80, (7 * bs, 1), generator=gen).float(), ctr, wh], 1).to(DEV)
+        crit = M.ComputeLoss(ori_img_size=640, warmup_epoch=0)
+        before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+        s0 = dict(train_ops.stats)
+        for _ in range(2):
+            with torch.autocast("cuda", dtype=torch.float16):
+                (feats, cls, reg), _ = m(x)
+            loss = crit((feats, cls, reg), targets, 5, 0)[0]
+            ex.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        torch.cuda.synchronize()
+        d = {k: v - s0.get(k, 0) for k, v in train_ops.stats.items()}
+        assert math.isfinite(float(loss.detach())), float(loss.detach())
+        assert d.get("fallback", 0) == 0 and d.get("torch_bn", 0) == 0 and d.get("framework_wgrad_fp32", 0) == 0 and d.get("torch_maxpool", 0) == 0, d
+        assert d["native_wgrad"] > 100 and d["native_bn_act"] > 100
+        moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in m.named_parameters() if p.requires_grad)
+        print("%s bs %d: loss %.4f, %d of %d parameters moved, launches %s" % (scale, bs, float(loss.detach()), moved, len(before), d))
+        assert moved >= 0.7 * len(before), (moved, len(before))
+    finally:
+        ex.close()

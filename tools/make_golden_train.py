@@ -3,7 +3,7 @@
 in the build container (CPU, fp32) on seeded weights, images and labels — what Trainer.train_in_steps computes up to `backward()`
 (yolov6/core/engine.py:149-164, without autocast: there is no GPU here).
 
-    python tools/make_golden_train.py    ->  tests/golden/train_n.npz
+    python tools/make_golden_train.py [n|s|m]    ->  tests/golden/train_<scale>.npz     (BASELINE configs[2] / [3] train the s and m graphs)
 
 Stored (DATA only): the loss and its items, the train-branch head outputs on a strided set of anchors, the gradient of a spread of parameters
 (every kind of layer: RepVGG 3x3 / 1x1 branches, ConvWrapper 3x3, 1x1 convs, every depth-wise kernel size, BatchNorm affine, head preds) as
@@ -45,6 +45,11 @@ def picked(names):
                  "backbone.32.reg_conv_s.conv.weight", "backbone.33.cls_pred.bias", "backbone.33.reg_pred.weight"):
         assert frag in names, frag
         want.append(frag)
+    # deeper scales (s: RepHDW depth 2, m: up to 4): the LAST bottleneck of a few stages as well
+    for frag in ("backbone.4.m.1.conv2.dwconv.lk_origin.weight", "backbone.6.m.3.one_conv.conv.weight", "backbone.12.m.2.conv1.conv.weight", "backbone.22.m.1.conv2.norm.bias",
+                 "backbone.26.m.2.one_conv.conv.weight"):
+        if frag in names:
+            want.append(frag)
     return want
 
 
@@ -55,18 +60,20 @@ def summary(t):
 
 
 def main():
+    scale = sys.argv[1] if len(sys.argv) > 1 else "n"
+    assert scale in ("n", "s", "m")
     torch.set_num_threads(os.cpu_count())
     ns = ref_import.load(lambda b, s, t: torch.zeros(0, dtype=torch.long))
     torch.nn.Module.cuda = lambda self, *a, **k: self          # ComputeLoss moves parameter-free sub-modules to the GPU in its constructor (loss.py:46-47)
     sys.path.insert(0, ref_import.REF)
     from yolov6.models.loss import ComputeLoss
-    model = ref_import.build(ns, "n")
-    model.load_state_dict(O.synth_state_dict("n", seed=0), strict=True)
+    model = ref_import.build(ns, scale)
+    model.load_state_dict(O.synth_state_dict(scale, seed=0), strict=True)
     model.train()
     x, targets = inputs()
     blob = {}
     for tag, epoch, kw in (("tal", 5, dict(warmup_epoch=0)), ("atss", 0, dict())):      # the steady-state assigner and the trainer's warm-up default (loss.py:23)
-        model.load_state_dict(O.synth_state_dict("n", seed=0), strict=True)
+        model.load_state_dict(O.synth_state_dict(scale, seed=0), strict=True)
         model.zero_grad(set_to_none=True)
         crit = ComputeLoss(num_classes=80, ori_img_size=SIZE, use_dfl=True, reg_max=16, iou_type="giou", **kw)
         preds, _ = model(x)                                     # engine.py:150
@@ -84,7 +91,7 @@ def main():
             blob["%s_g%d_sample" % (tag, i)] = gr.reshape(-1)[::max(1, gr.numel() // 64)][:64].numpy()
         print(tag, "loss", loss.item(), items.tolist(), "grad max", max(float(summary(params[n].grad)[3]) for n in names))
     # BatchNorm running statistics after ONE train-mode forward (momentum 0.03, torch_utils.py:43-45)
-    model.load_state_dict(O.synth_state_dict("n", seed=0), strict=True)
+    model.load_state_dict(O.synth_state_dict(scale, seed=0), strict=True)
     with torch.no_grad():
         model(x)
     sd = model.state_dict()
@@ -94,8 +101,8 @@ def main():
     for i, k in enumerate(pick):
         blob["bn%d" % i] = sd[k].numpy()
     blob["bn_tracked"] = np.asarray(int(sd["backbone.0.rbr_dense.bn.num_batches_tracked"]))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_n.npz"), **blob)
-    print("wrote train_n.npz", len(blob), "arrays")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_%s.npz" % scale), **blob)
+    print("wrote train_%s.npz" % scale, len(blob), "arrays")
 
 
 if __name__ == "__main__":
