@@ -73,6 +73,10 @@ typedef struct {
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
  *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
  *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).
+ *                   tile_k = 7 (fp16; (Cin, Cout) = (128, 128), (96, 96), (96, 64), (64, 64)): one workgroup per CU whose waves keep ALL weight
+ *                   fragments in registers, input patches of 4 x 8 output tiles by DMA, double-buffered (csrc/conv3s2_wreg.hip); w = record of
+ *                   maf_conv3s2_wreg_record_bytes(Cin, Cout) bytes (pack.py:pack_conv3x3_wreg), bias unused, tile_c = workgroups per conv / 32
+ *                   (0 = 256 / convs); a twin launch passes aux = {src, record, -, out} of the second conv.
  * MAF_OP_CONV3X3S2_DGRAD  backward of the above w.r.t. its input (autograd of common.py:219-224 / :44-47 in Trainer.train_in_steps,
  *                   yolov6/core/engine.py:164): src[0] = dY [B,Hin,Win,Cin] (Cin = the forward conv's OUTPUT channels, Hin x Win its output
  *                   grid), out = dX [B,H,W,Cout] (Cout = the forward conv's input channels, H x W its input grid); w = the forward weight
@@ -147,6 +151,7 @@ int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
 int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);
 int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout);
+int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout);   /* 0: no instantiation for this shape */
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

@@ -27,11 +27,10 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
     __shared__ __attribute__((aligned(16))) half_t s_out[TY * TX * COUT];
     __shared__ __attribute__((aligned(16))) char s_w[WB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.rec);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        for (int i = tid; i < WB / 16; i += 256) dst[i] = src[i];
-    }
+    // weight fragments: global -> LDS by DMA (1 KiB per wave-instruction, every piece in flight at once; published by the first barrier of the tile loop)
+    for (int v0 = wave * 64; v0 < WB / 16; v0 += 256)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.rec + (size_t)(v0 + lane) * 16),
+                                         (void __attribute__((address_space(3)))*)(s_w + v0 * 16), 16, 0, 0);
     const float* bias = reinterpret_cast<const float*>(a.rec + WB);
     f32x4_t bv[NT];
 #pragma unroll
@@ -60,6 +59,7 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
         }
     };
     if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the DMA pieces of this wave have landed (the barrier below publishes everybody's)
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
         const int Y0 = ty * TY, X0 = tx * TX;

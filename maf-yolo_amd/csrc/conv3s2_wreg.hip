@@ -1,0 +1,249 @@
+// 3x3 stride-2 pad-1 conv with the WEIGHTS IN REGISTERS (tile_k = 7 of MAF_OP_CONV3X3S2): ConvWrapper / MPRep.conv2 / RepVGGBlock in deploy form
+// (yolov6/layers/common.py:76-83, 776-792, 216-217) for the layers whose 9 * Cin * Cout weights do not fit the LDS but do fit the register
+// file of one workgroup — 128 -> 128 (the side convs of the MAFPN neck, backbone.23 / .24 / .27 / .28 of MAF-YOLO-n: 295 KB), 96 -> 96, 96 -> 64.
+//
+// Why: the generic template (conv_mfma.inc.h VAR_3X3S2) reads every input pixel 2.25 times (the taps of neighbouring outputs overlap) for
+// every channel tile and fetches its weight fragments once per wave and k-step: knock-out builds (tools/probe_ko.sh) put 40 of 79 us of the
+// twin launch 23 + 24 on the activation loads and 27 us on the weight loads.  Here
+//   * a wave OWNS one tile of 16 output channels and keeps ALL of its weight fragments — 9 taps x Cin / 32 k-steps = 144 VGPRs for Cin = 128 —
+//     in registers for the whole kernel (one workgroup of 8 waves per CU for 128 -> 128: two waves per SIMD, <= 256 registers each);
+//   * the (2 TR + 1) x (2 TC + 1) input patch of a TR x TC = 4 x 8 output tile travels global -> LDS by DMA (global_load_lds, no registers),
+//     double-buffered: the patch of the workgroup's next tile is in flight while this one is multiplied, and every input pixel is read once
+//     plus a 1.2x halo; out-of-image pixels and channel chunks past Cin read a 16-byte zero page, so the DMA stays unconditional;
+//   * the LDS image must be lane-linear for the DMA (wave-uniform base + lane * 16), so bank conflicts are avoided by permuting the SOURCE:
+//     pixel (py, px) stores its 16-byte channel chunk c in slot c ^ swz(py, px), swz = ((px >> 1) & 7) | (((py >> 1) & 1) << 3): the 16
+//     pixels of an MFMA fragment read (2 output rows x 8 output columns, input stride 2) then hit 16 different slots of the 256-byte bank row;
+//   * the product is taken transposed (A = weight fragment from registers: 16 output channels x 32 k; B = patch fragment: one ds_read_b128
+//     per lane; K = (tap, 8-channel group) pairs, tap-major, four pairs per k-step — the tap is uniform per k-step because Cin % 32 == 0), so
+//     a lane ends up with 4 consecutive output channels of one pixel: bias + activation, 8-byte store into a double-buffered LDS tile, whole
+//     NHWC pixels out as 16-byte pieces after the barrier that also publishes the next patch;
+//   * a twin launch (two convs of one shape: op->aux) gives each conv half of the workgroups.
+#include "maf_common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16w[4];
+
+struct C3wArgs {
+    const half_t* in[2];
+    const char* rec[2];
+    half_t* out[2];
+    int nconv, B, Hin, Win, H, W, in_stride, in_coff, out_stride, out_coff, act, tilesX, tilesY, ntiles;   // ntiles per conv
+};
+
+constexpr int W3_TR = 4, W3_TC = 8, W3_SR = 2 * W3_TR + 1, W3_SC = 2 * W3_TC + 1, W3_NPIX = W3_SR * W3_SC;
+constexpr int W3_SLOTS = W3_NPIX * 16;                              // 16-byte slots of a patch image (256 bytes per pixel, whatever Cin)
+
+template <int NW>
+constexpr int w3_patch_bytes() { return (W3_SLOTS + NW * 64 - 1) / (NW * 64) * (NW * 64) * 16; }   // whole DMA rounds: the last one writes past the last pixel
+
+template <int ACT, int MT, int NTW>
+__device__ __forceinline__ void w3_epilogue(const f32x4_t (&acc)[MT][NTW], const f32x4_t (&bv)[NTW], half_t* so, int cout, int ch0, int pix0, int n, int g) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            half4_t v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<ACT>(acc[m][t][q] + bv[t][q]);
+            *reinterpret_cast<half4_t*>(so + (pix0 + m * 16 + n) * cout + ch0 + t * 16 + 4 * g) = v;
+        }
+}
+
+// NWN x NWM waves: wave (wn, wm) owns the COUT / 16 / NWN channel tiles starting at wn * NTW and the 2 / NWM m-tiles (16 pixels = 2 rows x 8 columns)
+// starting at wm * MT.  Two waves per SIMD (512-thread workgroups, <= 256 registers per lane): one wave's LDS reads, address arithmetic and epilogue
+// run under the other's MFMAs — with one wave per SIMD (a first version: 4 waves holding two channel tiles each) a tile took 14k cycles.
+template <int CIN, int COUT, int NWN, int NWM, int NBUF>
+__global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_wreg_kernel(const C3wArgs a) {
+    constexpr int NW = NWN * NWM, NTW = COUT / 16 / NWN, MT = 2 / NWM;
+    static_assert(CIN % 32 == 0 && CIN <= 128 && COUT == NWN * NTW * 16 && MT * NWM == 2, "shape");
+    constexpr int KPT = CIN / 32, KS = 9 * KPT, GR = CIN / 8, NT = NW * 64;
+    constexpr int PB = w3_patch_bytes<NW>(), OB = W3_TR * W3_TC * COUT * 2;
+    constexpr int ROUNDS = (W3_SLOTS + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w3_raw[];       // [NBUF][PB] patches | [2][OB] output tiles
+    unsigned char* const s_out = w3_raw + NBUF * PB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+    const int wn = wave % NWN, wm = wave / NWN;
+    const int wgc = gridDim.x / a.nconv;                                         // workgroups per conv
+    const int conv = blockIdx.x / wgc, wg = blockIdx.x - conv * wgc;
+    const half_t* const in = a.in[conv];
+    half_t* const out = a.out[conv];
+    const char* const rec = a.rec[conv];
+
+    // ---- this wave's weight fragments and bias (record: [channel tile][k-step][64 lanes][8])
+    half8_t w[KS][NTW];
+    {
+        const half8_t* wsrc = reinterpret_cast<const half8_t*>(rec) + ((size_t)(wn * NTW) * KS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) w[s][t] = wsrc[(t * KS + s) * 64];
+    }
+    const float* bias = reinterpret_cast<const float*>(rec + (size_t)(COUT / 16) * KS * 1024);
+    f32x4_t bv[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4_t*>(bias + (wn * NTW + t) * 16 + 4 * g);
+
+    // ---- patch DMA: slot L of the image <- chunk (L & 15) ^ swz of pixel L >> 4.  What does not depend on the tile is computed once per lane
+    // and DMA round: the pixel's place in the patch and its channel chunk (packed: py << 16 | px << 8 | chunk; chunk 31 = a slot nothing maps to)
+    int dslot[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int L = wave * 64 + r * NT + lane;
+        const int p = L >> 4, slot = L & 15;
+        const int py = p / W3_SC, px = p - py * W3_SC;
+        const int chunk = slot ^ (((px >> 1) & 7) | (((py >> 1) & 1) << 3));
+        dslot[r] = (py << 16) | (px << 8) | ((p < W3_NPIX && chunk < GR) ? chunk : 31);
+    }
+    auto dma = [&](int tile, int buf) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const half_t* img = in + (size_t)b * a.Hin * a.Win * a.in_stride + a.in_coff;
+        const int iy0 = 2 * ty * W3_TR - 1, ix0 = 2 * tx * W3_TC - 1;
+        unsigned char* dst = w3_raw + buf * PB + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            // (every wave issues every round — the slots past the last pixel read the zero page into the padding of the image — so that a
+            // counted s_waitcnt vmcnt(ROUNDS) means "everything but the newest patch has landed" for every wave)
+            const int d = dslot[r], chunk = d & 255;
+            const int iy = iy0 + (d >> 16), ix = ix0 + ((d >> 8) & 255);
+            const bool ok = chunk != 31 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const half_t* src = ok ? img + ((size_t)iy * a.Win + ix) * a.in_stride + 8 * chunk : reinterpret_cast<const half_t*>(g_zero16w);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)(dst + r * (NT * 16)), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing: lane (g, n) = output pixel (row n >> 3, column n & 7) of an m-tile (2 rows x 8 columns), k-pair group 4 (s % KPT) + g
+    const int r_ = n >> 3, c_ = n & 7;
+    const int pixbase = ((4 * (wm * MT) + 2 * r_) * W3_SC + 2 * c_) * 256;
+    int swz[2][2];                                                                // [ky >> 1][kx >> 1]
+#pragma unroll
+    for (int yk = 0; yk < 2; ++yk)
+#pragma unroll
+        for (int xk = 0; xk < 2; ++xk) swz[yk][xk] = ((c_ + xk) & 7) | (((r_ + yk) & 1) << 3);
+
+    const int act = a.act;
+    int tile = wg;
+    // NBUF - 1 patches in flight ahead of the one being multiplied (NBUF = 3: a patch has two tile times to arrive)
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k)
+        if (tile + k * wgc < a.ntiles) dma(tile + k * wgc, k);
+        else dma(a.ntiles - 1, k);                                                // keep the DMA count per wave uniform (the data is never read)
+    if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; tile < a.ntiles; ++it, tile += wgc) {
+        const int cur = it % NBUF, ocur = it & 1;
+        {
+            const int nt_ = tile + (NBUF - 1) * wgc;
+            dma(nt_ < a.ntiles ? nt_ : a.ntiles - 1, (it + NBUF - 1) % NBUF);     // every wave left that buffer before the last barrier
+        }
+        const unsigned char* pb = w3_raw + cur * PB + pixbase;
+        f32x4_t acc[MT][NTW];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int tap = s / KPT, ky = tap / 3, kx = tap - 3 * ky;             // compile-time after unrolling
+            const int slot = (4 * (s % KPT) + g) ^ swz[ky >> 1][kx >> 1];
+            const unsigned char* q = pb + (ky * W3_SC + kx) * 256 + slot * 16;
+            half8_t f[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) f[m] = *reinterpret_cast<const half8_t*>(q + m * (4 * W3_SC * 256));   // m-tile m: output rows 2m, 2m + 1
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[s][t], f[m], acc[m][t], 0, 0, 0);
+        }
+        // ---- bias + activation (picked once per tile, not per value) -> the output tile in LDS: pixel (wm * MT + m) * 16 + n, channels (wn * NTW + t) * 16 + 4 g ..
+        half_t* so = reinterpret_cast<half_t*>(s_out + ocur * OB);
+        if (act == MAF_ACT_SILU) w3_epilogue<MAF_ACT_SILU, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
+        else if (act == MAF_ACT_RELU) w3_epilogue<MAF_ACT_RELU, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
+        else if (act == MAF_ACT_NONE) w3_epilogue<MAF_ACT_NONE, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
+        else w3_epilogue<MAF_ACT_SIGMOID, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
+        // the next patch has landed (this wave's pieces; with three buffers the one after it may still fly) and this wave's part of the output tile is
+        // written; the barrier publishes both (a raw s_barrier: __syncthreads() would drain the whole DMA queue with vmcnt(0))
+        if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ROUNDS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const int Y0 = ty * W3_TR, X0 = tx * W3_TC;
+        constexpr int CPP = COUT / 8;
+        for (int q = tid; q < W3_TR * W3_TC * CPP; q += NT) {
+            const int px = q / CPP, part = q - px * CPP;
+            const int oy = Y0 + (px >> 3), ox = X0 + (px & 7);
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<uint4*>(out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + 8 * part) =
+                    *reinterpret_cast<const uint4*>(so + px * COUT + 8 * part);
+        }
+    }
+}
+
+template <int CIN, int COUT, int NWN, int NWM, int NBUF>
+int launch_w3(const C3wArgs& a, int wg_per_conv, hipStream_t s) {
+    constexpr int NW = NWN * NWM;
+    constexpr int lds = NBUF * w3_patch_bytes<NW>() + 2 * W3_TR * W3_TC * COUT * 2;
+    static bool attr = false;
+    if (!attr) {
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv3s2_wreg)");
+        if (rc) return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF>), dim3(wg_per_conv * a.nconv), dim3(NW * 64), lds, s, a);
+    return maf_check_hip(hipGetLastError(), "conv3s2_wreg launch");
+}
+
+}  // namespace
+
+// (waves along the channels, waves along the pixels) of the (Cin, Cout) instantiations; 0 = none
+static int w3_shape(int cin, int cout, int* nwn, int* nwm) {
+    if (cin == 128 && cout == 128) { *nwn = 8; *nwm = 1; return 1; }
+    if (cin == 96 && cout == 96) { *nwn = 6; *nwm = 1; return 1; }
+    if (cin == 96 && cout == 64) { *nwn = 4; *nwm = 2; return 1; }
+    if (cin == 64 && cout == 64) { *nwn = 4; *nwm = 2; return 1; }
+    return 0;
+}
+
+extern "C" int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout) {
+    int nwn, nwm;
+    if (!w3_shape(Cin, Cout, &nwn, &nwm)) return 0;
+    return (int64_t)(Cout / 16) * (9 * Cin / 32) * 1024 + Cout * 4;
+}
+
+int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s) {
+    MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32, "conv3x3s2 (tile_k = 7): fp16 only");
+    const maf_src_t& sr = op->src[0];
+    MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr && sr.C == op->Cin, "conv3x3s2 (tile_k = 7): one direct source");
+    MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "conv3x3s2 (tile_k = 7): 16-byte aligned channel slices");
+    MAF_REQUIRE(op->w && op->out, "conv3x3s2 (tile_k = 7): null pointer");
+    MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && (op->Hin - 1) / 2 + 1 == op->H && (op->Win - 1) / 2 + 1 == op->W, "conv3x3s2: H,W must equal floor((Hin-1)/2)+1");
+    MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv3x3s2: bad act");
+    int nwn, nwm;
+    if (!w3_shape(op->Cin, op->Cout, &nwn, &nwm)) {
+        maf_set_error("conv3x3s2 (tile_k = 7): (Cin, Cout) must be (128, 128), (96, 96), (96, 64) or (64, 64)");
+        return MAF_E_UNSUPPORTED;
+    }
+    C3wArgs a;
+    a.in[0] = static_cast<const half_t*>(sr.ptr); a.rec[0] = static_cast<const char*>(op->w); a.out[0] = static_cast<half_t*>(op->out);
+    a.nconv = 1;
+    if (op->aux[0]) {                                              // twin: {src, record, (unused), out} of a second conv of the same shape
+        MAF_REQUIRE(op->aux[1] && op->aux[3], "conv3x3s2 (tile_k = 7) twin: aux = {src, record, -, out}");
+        a.in[1] = static_cast<const half_t*>(op->aux[0]); a.rec[1] = static_cast<const char*>(op->aux[1]); a.out[1] = static_cast<half_t*>(const_cast<void*>(op->aux[3]));
+        a.nconv = 2;
+    } else {
+        a.in[1] = a.in[0]; a.rec[1] = a.rec[0]; a.out[1] = a.out[0];
+    }
+    a.B = op->B; a.Hin = op->Hin; a.Win = op->Win; a.H = op->H; a.W = op->W;
+    a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff; a.act = op->act;
+    a.tilesX = maf_cdiv(a.W, W3_TC); a.tilesY = maf_cdiv(a.H, W3_TR); a.ntiles = a.B * a.tilesX * a.tilesY;
+    // one workgroup per CU (the weights fill the register file): tile_c = workgroups per conv / 32 (default: 256 CUs shared by the convs of the launch)
+    int per = op->tile_c > 0 ? op->tile_c * 32 : 256 / a.nconv;
+    if (per > a.ntiles) per = a.ntiles;
+    const bool two = op->tile_p == 2;                               // tile_p = 2: two patch buffers (A/B); else three
+#define MAF_W3(CI, CO, NWN_, NWM_) return two ? launch_w3<CI, CO, NWN_, NWM_, 2>(a, per, s) : launch_w3<CI, CO, NWN_, NWM_, 3>(a, per, s)
+    if (op->Cin == 128 && op->Cout == 128) MAF_W3(128, 128, 8, 1);
+    if (op->Cin == 96 && op->Cout == 96) MAF_W3(96, 96, 6, 1);
+    if (op->Cin == 96 && op->Cout == 64) MAF_W3(96, 64, 4, 2);
+    MAF_W3(64, 64, 4, 2);
+#undef MAF_W3
+}

@@ -431,54 +431,63 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int ct = 0; ct < CT; ++ct) bias[ct] = bias_all[cl + ct];          // padded to nN*16*CT on the host
     const int nvalid = a.Cout - cl;                                        // >= CT for every tile but the last
 
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int m = m_base + pt * 16 + g * 4 + r;
-            if (m >= (dgs ? a.dg_mc : a.M)) continue;
-            if ((MAF_KO & 4) && acc[pt][0][r] != 12345.678f) continue;
-            if (dgs) {                                                    // class pixel -> linear pixel of the full-resolution output
-                const int w2 = a.W >> 1, h2 = a.H >> 1;
-                const int t = m / w2;
-                m = ((t / h2) * a.H + 2 * (t % h2) + dg_py) * a.W + 2 * (m - t * w2) + dg_px;
-            }
-            float v[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[pt][ct][r] + bias[ct], a.act);
-            const size_t o = (size_t)m * a.out_stride + a.out_coff + cl;
-            if (OUTF32 || sizeof(T) == 4) {
-                float* op = static_cast<float*>(out_all) + o;
-                if (nvalid >= CT) {
-#pragma unroll
-                    for (int q = 0; q + 4 <= CT; q += 4) *reinterpret_cast<f32x4_t*>(op + q) = (f32x4_t){v[q], v[q + 1], v[q + 2], v[q + 3]};
-                    if (CT % 4 == 2) *reinterpret_cast<float2*>(op + CT - 2) = make_float2(v[CT - 2], v[CT - 1]);
-                } else {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        if (ct < nvalid) op[ct] = v[ct];
+    // the activation is picked ONCE (a scalar branch around three straight-line copies of the epilogue), not per value: with the switch inside
+    // the loops every value was its own basic block and every v_exp / v_rcp latency was exposed
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT_ = decltype(act_tag)::value;
+    #pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m_base + pt * 16 + g * 4 + r;
+                if (m >= (dgs ? a.dg_mc : a.M)) continue;
+                if ((MAF_KO & 4) && acc[pt][0][r] != 12345.678f) continue;
+                if (dgs) {                                                    // class pixel -> linear pixel of the full-resolution output
+                    const int w2 = a.W >> 1, h2 = a.H >> 1;
+                    const int t = m / w2;
+                    m = ((t / h2) * a.H + 2 * (t % h2) + dg_py) * a.W + 2 * (m - t * w2) + dg_px;
                 }
-            } else {
-                half_t* op = static_cast<half_t*>(out_all) + o;
-                if (nvalid >= CT) {
-                    uint32_t w[CT / 2];
-#pragma unroll
-                    for (int q = 0; q < CT / 2; ++q) {
-                        const half2_t h = {(half_t)v[2 * q], (half_t)v[2 * q + 1]};
-                        w[q] = __builtin_bit_cast(uint32_t, h);
+                float v[CT];
+    #pragma unroll
+                for (int ct = 0; ct < CT; ++ct) v[ct] = ACT_ < 0 ? maf_act_rt(acc[pt][ct][r] + bias[ct], a.act) : maf_act<(ACT_ < 0 ? 0 : ACT_)>(acc[pt][ct][r] + bias[ct]);
+                const size_t o = (size_t)m * a.out_stride + a.out_coff + cl;
+                if (OUTF32 || sizeof(T) == 4) {
+                    float* op = static_cast<float*>(out_all) + o;
+                    if (nvalid >= CT) {
+    #pragma unroll
+                        for (int q = 0; q + 4 <= CT; q += 4) *reinterpret_cast<f32x4_t*>(op + q) = (f32x4_t){v[q], v[q + 1], v[q + 2], v[q + 3]};
+                        if (CT % 4 == 2) *reinterpret_cast<float2*>(op + CT - 2) = make_float2(v[CT - 2], v[CT - 1]);
+                    } else {
+    #pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (ct < nvalid) op[ct] = v[ct];
                     }
-                    if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
-                    else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
-                    else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
-                    else *reinterpret_cast<uint32_t*>(op) = w[0];
                 } else {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        if (ct < nvalid) op[ct] = (half_t)v[ct];
+                    half_t* op = static_cast<half_t*>(out_all) + o;
+                    if (nvalid >= CT) {
+                        uint32_t w[CT / 2];
+    #pragma unroll
+                        for (int q = 0; q < CT / 2; ++q) {
+                            const half2_t h = {(half_t)v[2 * q], (half_t)v[2 * q + 1]};
+                            w[q] = __builtin_bit_cast(uint32_t, h);
+                        }
+                        if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
+                        else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
+                        else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
+                        else *reinterpret_cast<uint32_t*>(op) = w[0];
+                    } else {
+    #pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (ct < nvalid) op[ct] = (half_t)v[ct];
+                    }
                 }
             }
         }
-    }
+    };
+    if (a.act == MAF_ACT_SILU) epilogue(std::integral_constant<int, MAF_ACT_SILU>());
+    else if (a.act == MAF_ACT_RELU) epilogue(std::integral_constant<int, MAF_ACT_RELU>());
+    else if (a.act == MAF_ACT_NONE) epilogue(std::integral_constant<int, MAF_ACT_NONE>());
+    else epilogue(std::integral_constant<int, -1>());
 }
 
 template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false>

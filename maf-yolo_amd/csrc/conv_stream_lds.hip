@@ -1,176 +1,15 @@
-// Persistent 1x1 convolution for longer reductions (up to 12 k-steps: Cin <= 384, single source or concat of up to 4 sources,
+// Persistent 1x1 convolution for longer reductions (up to 24 k-steps: Cin <= 768, KS * CT KiB of weights <= 160 KiB of LDS; single source or concat of up to 4 sources,
 // incl. the nearest-x2 upsampled ones): the schedule of conv_stream.hip — a wave walks many 16-pixel tiles, the activation
 // fragments of its next tile are in flight while the current tile is multiplied, activated and stored — with the weight
 // fragments of the workgroup's channel tile resident in LDS for the whole kernel (KS * CT KiB, read with ds_read_b128) instead
 // of registers.  Same reference code and operand layout as conv_mfma.inc.h (Conv.forward_fuse, torch.cat, nn.Upsample:
 // yolov6/layers/common.py:49-50, 148-154; MAF-YOLO-n.yaml:21,26).
-#include "conv_mfma.inc.h"
+#include "conv_stream_lds.inc.h"
+
+int maf_conv1x1_stream_lds_wide(const ConvArgs& a, int var, int ct, hipStream_t s);
 
 namespace {
 
-template <int ACT, int CT>
-__device__ __forceinline__ void sl_store(const f32x4_t (&acc)[CT], int r, half_t* op, int nvalid) {
-    float v[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) v[ct] = (MAF_KO & 16) ? acc[ct][r] : maf_act<ACT>(acc[ct][r]);
-    if (nvalid >= CT) {
-        uint32_t w[CT / 2];
-#pragma unroll
-        for (int c2 = 0; c2 < CT / 2; ++c2) {
-            const half2_t h = {(half_t)v[2 * c2], (half_t)v[2 * c2 + 1]};
-            w[c2] = __builtin_bit_cast(uint32_t, h);
-        }
-        if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
-        else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
-        else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
-        else *reinterpret_cast<uint32_t*>(op) = w[0];
-    } else {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-            if (ct < nvalid) op[ct] = (half_t)v[ct];
-    }
-}
-
-template <int CT, int KS, bool MULTI>
-__global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs a) {
-    typedef Frag<half_t> F;
-    typedef F::type frag_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char wl_raw[];
-    frag_t* wl = reinterpret_cast<frag_t*>(wl_raw);                      // [KS][CT][64]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
-    const int n_tile = blockIdx.x % a.nN;                                // the workgroup keeps ONE channel tile
-    const int wg = blockIdx.x / a.nN, nwg = gridDim.x / a.nN;
-    const int ntiles = (a.M + 15) >> 4;
-    {
-        // the channel tile's fragments travel global -> LDS by DMA (global_load_lds: 1 KiB per wave-instruction to a wave-uniform base + lane * 16;
-        // no registers, no ds_write, ALL of them in flight at once — the first version walked them with a load -> wait -> ds_write loop, 18
-        // dependent L2 round trips per workgroup before the first MFMA)
-        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)(n_tile * CT) * KS) * 1024;   // [ct][ks][64 x 16 B]
-        for (int f = wave; f < KS * CT; f += 4) {                       // LDS order: fragment f = ks * CT + ct
-            const int ks = f / CT, ct = f - ks * CT;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + ((size_t)ct * KS + ks) * 1024 + lane * 16),
-                                             (void __attribute__((address_space(3)))*)(wl_raw + f * 1024), 16, 0, 0);
-        }
-    }
-    const int cl = n_tile * (16 * CT) + p * CT;
-    float bias[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bias[ct] = a.bias[cl + ct];
-    const int nvalid = a.Cout - cl;
-
-    // per k-step: which source, which channel chunk (scalar; steps past a source's last chunk read chunk 0 x zero weights)
-    auto load_tile = [&](int t, frag_t (&af)[KS]) {
-        if (MAF_KO & 2) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[ks] = (frag_t)(half_t)(0.001f * (float)(lane + ks + t));
-            return;
-        }
-        int m = t * 16 + p;
-        m = m < a.M ? m : a.M - 1;
-        if constexpr (!MULTI) {
-            const half_t* q = static_cast<const half_t*>(a.src[0]) + (size_t)m * a.srcStride[0] + a.srcCoff[0];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                int c = ks * 32 + g * 8;
-                c = c < a.Cin ? c : 0;
-                af[ks] = ldg16<half_t>(q + c);
-            }
-        } else {
-            const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;
-            const half_t* q[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half_t* base = static_cast<const half_t*>(a.src[s < a.nsrc ? s : 0]);
-                const int si = s < a.nsrc ? s : 0;
-                const size_t pix = a.srcMode[si] == MAF_SRC_UP2 ? (size_t)((bb * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) : (size_t)m;
-                q[s] = base + pix * a.srcStride[si] + a.srcCoff[si];
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int i1 = ks >= a.cum[1], i2 = ks >= a.cum[2], i3 = ks >= a.cum[3];
-                const int first = i3 ? a.cum[3] : i2 ? a.cum[2] : i1 ? a.cum[1] : 0;
-                const int srcC = i3 ? a.srcC[3] : i2 ? a.srcC[2] : i1 ? a.srcC[1] : a.srcC[0];
-                const half_t* qq = i3 ? q[3] : i2 ? q[2] : i1 ? q[1] : q[0];
-                int c = (ks - first) * 32 + g * 8;
-                c = c < srcC ? c : 0;
-                af[ks] = ldg16<half_t>(qq + c);
-            }
-        }
-    };
-    const int act = a.act;                                               // uniform: the activation is picked once per tile, not per value
-    auto compute_store = [&](int t, const frag_t (&af)[KS]) {
-        f32x4_t acc[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4_t){bias[ct], bias[ct], bias[ct], bias[ct]};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            frag_t wf[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = (MAF_KO & 1) ? (frag_t)(half_t)(0.002f * (float)(lane + ct)) : wl[(ks * CT + ct) * 64 + lane];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (MAF_KO & 8) acc[ct][0] += (float)af[ks][0] + (float)wf[ct][0];
-                else acc[ct] = F::mma(af[ks], wf[ct], acc[ct]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = t * 16 + g * 4 + r;
-            if (m >= a.M) continue;
-            if ((MAF_KO & 4) && acc[0][r] != 12345.678f) continue;
-            half_t* op = static_cast<half_t*>(a.out) + (size_t)m * a.out_stride + a.out_coff + cl;
-            if (act == MAF_ACT_SILU) sl_store<MAF_ACT_SILU, CT>(acc, r, op, nvalid);
-            else if (act == MAF_ACT_NONE) sl_store<MAF_ACT_NONE, CT>(acc, r, op, nvalid);
-            else if (act == MAF_ACT_RELU) sl_store<MAF_ACT_RELU, CT>(acc, r, op, nvalid);
-            else sl_store<MAF_ACT_SIGMOID, CT>(acc, r, op, nvalid);
-        }
-    };
-
-    frag_t fa[KS], fb[KS];
-    const int stride = nwg * 4;
-    int t = wg * 4 + wave;
-    const bool any = t < ntiles;
-    if (any) load_tile(t, fa);                                           // in flight beside the weight DMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
-    __syncthreads();                                                     // ... and everybody else's
-    if (!any) return;
-    while (true) {
-        const int t1 = t + stride;
-        if (t1 < ntiles) load_tile(t1, fb);
-        compute_store(t, fa);
-        if (t1 >= ntiles) break;
-        const int t2 = t1 + stride;
-        if (t2 < ntiles) load_tile(t2, fa);
-        compute_store(t1, fb);
-        if (t2 >= ntiles) break;
-        t = t2;
-    }
-}
-
-template <int CT, int KS, bool MULTI>
-int launch_sl(const ConvArgs& a, hipStream_t s) {
-    constexpr int lds = KS * CT * 1024;
-    static_assert(lds <= 160 * 1024, "weights of one channel tile must fit LDS");
-    static int occ = 0;                                                  // resident workgroups per CU of this instantiation (LDS and registers)
-    if (!occ) {
-        if (lds > 64 * 1024) {
-            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
-            if (rc) return rc;
-        }
-        int nb = 0;
-        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI>, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
-        if (rc) return rc;
-        occ = nb < 1 ? 1 : nb > 4 ? 4 : nb;
-    }
-    // ONE round of persistent workgroups: exactly what is resident at once (a second round pays the weight DMA and the ramp-up again for a
-    // handful of tiles per wave), spread evenly over the channel tiles
-    const int ntiles = (a.M + 15) >> 4;
-    int per = (ntiles + 3) / 4;                                          // workgroups per channel tile that still have work
-    const int cap = occ * 256 / a.nN > 0 ? occ * 256 / a.nN : 1;
-    if (per > cap) per = cap;
-    hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI>), dim3(per * a.nN), dim3(256), lds, s, a);
-    return maf_check_hip(hipGetLastError(), "conv1x1_stream_lds launch");
-}
 
 template <int CT, bool MULTI>
 int launch_sl_ks(const ConvArgs& a, hipStream_t s) {
@@ -179,8 +18,8 @@ int launch_sl_ks(const ConvArgs& a, hipStream_t s) {
         MAF_KS(2) MAF_KS(3) MAF_KS(4) MAF_KS(5) MAF_KS(6) MAF_KS(7) MAF_KS(8) MAF_KS(9) MAF_KS(10) MAF_KS(11) MAF_KS(12)
 #undef MAF_KS
     }
-    maf_set_error("conv: tile_k = 5 (persistent, LDS-resident weights) needs 2 <= ksteps <= 12 and ksteps * tile_c <= 96");
-    return MAF_E_UNSUPPORTED;
+    return maf_conv1x1_stream_lds_wide(a, MULTI ? VAR_MULTI : VAR_DIRECT, CT, s);     // longer reductions: conv_stream_lds_wide.hip
+
 }
 
 }  // namespace

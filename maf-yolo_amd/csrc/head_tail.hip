@@ -50,11 +50,15 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, n = lane & 15;
     const int br = blockIdx.y;
     if constexpr (WLDS) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.rec[br]);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        constexpr int NV = (W1B + W2B + C * 4 + 80 * 4) / 16;
-        for (int i = tid; i < NV; i += 256) dst[i] = src[i];
-        __syncthreads();
+        // the branch's record travels global -> LDS by DMA (1 KiB per wave-instruction, all pieces in flight at once, no registers); the
+        // barrier behind the first activation loads publishes it
+        constexpr int NB = W1B + W2B + C * 4 + 80 * 4;
+        static_assert(NB % 16 == 0, "record in 16-byte pieces");
+        const char* src = a.rec[br];
+        for (int v0 = wave * 64; v0 < NB / 16; v0 += 256)
+            if (v0 + lane < NB / 16)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(v0 + lane) * 16),
+                                                 (void __attribute__((address_space(3)))*)(s_w + v0 * 16), 16, 0, 0);
     }
     // chunked instantiations: the fragment stream of the record (W1 tiles, then W2 tiles: NCH chunks of CHB bytes, contiguous) goes through
     // s_w[0 .. 2 CHB); the biases sit behind it
@@ -86,9 +90,6 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
     const half8_t* w2 = reinterpret_cast<const half8_t*>(s_w + W1B);
     const f32x4_t* b1 = reinterpret_cast<const f32x4_t*>(s_w + BOFF);
     const float* b2 = reinterpret_cast<const float*>(s_w + BOFF + C * 4);
-    float bias2[NT2];
-#pragma unroll
-    for (int t = 0; t < NT2; ++t) bias2[t] = b2[16 * t + n];
     const half_t* xb = a.x[br] + a.xc[br] + 8 * G;
     const int xs = a.xs[br];
     float* stage = s_stage[wave];
@@ -103,10 +104,20 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             for (int ks = 0; ks < KS; ++ks) x[p][ks] = *reinterpret_cast<const half8_t*>(px + 32 * ks);
         }
     };
-    const int unit0 = blockIdx.x * a.iters * 4 + wave;
+    // persistent: the workgroups of a branch walk the 16 * PT-pixel units with the stride of the grid (a.iters rounds, the same for every
+    // workgroup: the epilogue's barriers need uniform trip counts; units past the end are computed on clamped pixels and never stored)
+    const int ustride = gridDim.x * 4;
+    const int unit0 = blockIdx.x * 4 + wave;
     load_x(unit0);
+    if constexpr (WLDS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    float bias2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) bias2[t] = b2[16 * t + n];
     for (int it = 0; it < a.iters; ++it) {
-        const int unit = unit0 + it * 4;
+        const int unit = unit0 + it * ustride;
         const int par = WLDS ? 0 : (it * NCH) & 1;                                // chunked: chunk c of this unit sits in buffer (c + par) & 1 (NCH is odd)
         // ---- GEMM 1 (transposed): acc1[p][t] lane (G, n) = channels 16t + 4G + r of pixel n
         constexpr int T1R = WLDS ? T1 : 1;                                        // chunked instantiations turn every pair of tiles into its fragment at once
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
                 __syncthreads();
             });
         }
-        if (it + 1 < a.iters) load_x(unit + 4);                                   // next unit's activations fly during the rest
+        if (it + 1 < a.iters) load_x(unit + ustride);                             // next unit's activations fly during the rest
         // ---- bias + SiLU -> fp16: the A fragments of GEMM 2 (k-slots q < 4 from tile 2j, q >= 4 from tile 2j + 1)
         if constexpr (WLDS)
 #pragma unroll
@@ -290,9 +301,13 @@ int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(a.A >= a.lvl_off + a.HW && a.lvl_off >= 0, "head_tail: Hin = first anchor of the level, Win = anchors per image");
     const int pt = op->Cin <= 128 ? 2 : 1;
     const int units = maf_cdiv(maf_cdiv(a.M, 16), pt);
-    int iters = op->tile_k > 0 ? op->tile_k : std::min(8, std::max(1, units / (4 * 512)));
-    a.iters = iters;
-    const dim3 grid(maf_cdiv(units, 4 * iters), 2);
+    // one round of resident workgroups per branch (tile_k > 0: that many workgroups per CU and branch-pair, i.e. grid.x = 128 * tile_k; default 2 per CU
+    // for the LDS-resident widths <= 128, 1 above), every workgroup walks ceil(units / (4 * grid.x)) units per wave
+    const int per_cu = op->tile_k > 0 ? op->tile_k : (op->Cin <= 128 ? 2 : 1);
+    int gx = std::min(maf_cdiv(units, 4), std::max(1, 128 * per_cu));
+    a.iters = maf_cdiv(units, 4 * gx);
+    gx = maf_cdiv(units, 4 * a.iters);                                             // same rounds, no idle workgroups
+    const dim3 grid(gx, 2);
     switch (op->Cin) {
         case 64: hipLaunchKernelGGL((head_tail_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
         case 128: hipLaunchKernelGGL((head_tail_kernel<128, 2>), grid, dim3(256), 0, s, a); break;

@@ -36,6 +36,7 @@ int maf_launch_conv1dw(const maf_op_t* op, hipStream_t s);
 int maf_launch_head_tail(const maf_op_t* op, hipStream_t s);
 int maf_launch_stem2(const maf_op_t* op, hipStream_t s);
 int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s);
+int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s);
 
 // ---- device helpers ----
 template <int ACT>

@@ -52,6 +52,13 @@ def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
     return {n: _TUNE_CACHE[sigs[n]][0] for n in names}
 
 
+def stream_lds_ok(ksteps, ct):
+    """Instantiations of the persistent 1x1 conv with LDS-resident weights (tile_k = 5: csrc/conv_stream_lds.hip, conv_stream_lds_wide.hip)."""
+    if 2 <= ksteps <= 12:
+        return ksteps * ct <= 96
+    return ct in (4, 8) and (13 <= ksteps <= 20 or ksteps == 24) and ksteps * ct <= 160
+
+
 def save_tune_cache(path):
     """Persist the tile choices found by Plan.autotune (JSON: repr(signature) -> tiles) so a later process — a profiler
     pass, a serving replica — builds byte-identical plans without re-timing."""
@@ -558,13 +565,13 @@ class Plan:
                     o.tile_p, o.tile_k = best[0], best[2]
                     changed += 1
                 continue
-            if o.kind == lib.OP_HEADTAIL:                        # head tail: pixel units per wave (weights are staged once per workgroup)
-                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin)
+            if o.kind == lib.OP_HEADTAIL:                        # head tail: persistent workgroups per CU (tile_k; the weights are staged once per workgroup)
+                sig = (o.kind, self.dtype, self.B, o.H, o.W, o.Cin, "percu")
                 best = _TUNE_CACHE.get(sig)
                 if best is None:
                     o.out = pred.data_ptr()
                     results = []
-                    for iters in (1, 2, 3, 4, 6, 8, 12):
+                    for iters in (1, 2, 3, 4, 6):
                         op = lib.MafOp.from_buffer_copy(o)
                         op.tile_k = iters
                         lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
@@ -611,6 +618,30 @@ class Plan:
                                     timer.stop(stream.cuda_stream)
                                     ts.append(timer.elapsed_ms())
                                 results.append((min(ts), t_h, t_w, cb))
+                    if self.dtype == lib.F16:                            # two taps per instruction (csrc/dwconv_dot2.hip): tile_p = -2, tile_c = columns, tile_k = rows * 256 + channels
+                        w8 = -(-o.W // 8) * 8
+                        for th in sorted({4, 8, 10, 16, 20} | ({o.H} if o.H <= 40 else set())):
+                            if th > o.H:
+                                continue
+                            for tw in sorted({16, 24, 32, 40} | ({w8} if w8 <= 40 else set())):
+                                if tw > w8:
+                                    continue
+                                for cb in (16, 32, 64):
+                                    cb = min(cb, o.Cin)
+                                    nq, np_ = cb // 4, (o.ksize + 1) // 2
+                                    lds = ((th + o.ksize - 1) * ((tw + o.ksize - 1) // 2) * (nq + 1) + o.ksize * 2 * np_ * nq) * 16
+                                    if lds > 96 * 1024 or (-2, tw, th * 256 + cb) in [r_[1:] for r_ in results]:
+                                        continue
+                                    op = lib.MafOp.from_buffer_copy(o)
+                                    op.tile_p, op.tile_c, op.tile_k = -2, tw, th * 256 + cb
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    ts = []
+                                    for _ in range(reps):
+                                        timer.start(stream.cuda_stream)
+                                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                        timer.stop(stream.cuda_stream)
+                                        ts.append(timer.elapsed_ms())
+                                    results.append((min(ts), -2, tw, th * 256 + cb))
                     if self.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
                         op = lib.MafOp.from_buffer_copy(o)
                         op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
@@ -640,8 +671,8 @@ class Plan:
             w, b, srcC = r["raw"]
 
             def packed(wt, bt, ct_, tk_):
-                wp_ = (pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
-                return wp_, pack.pack_bias(bt, ct_ if tk_ != 6 else 4).to(self.device)
+                wp_ = (pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
+                return wp_, pack.pack_bias(bt, ct_ if tk_ not in (6, 7) else 4).to(self.device)
             if best is None:
                 cands = []
                 for ct in (2, 4, 6, 8):
@@ -661,12 +692,16 @@ class Plan:
                     if direct and self.dtype == lib.F16 and not o.out_f32 and ksteps <= 4 and ksteps * ct <= 16:
                         for pt in (1, 2):                                # persistent waves, next tile's activations in flight during the epilogue
                             cands.append((pt, ct, 3))
-                    if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and 2 <= ksteps <= 12 and ksteps * ct <= 96 \
+                    if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and stream_lds_ok(ksteps, ct) \
                             and all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc)) and (direct or ct >= 4):
                         cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
                     if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and M >= 65536:
                         for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)
                             cands.append((4, wg, 6))
+                    if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and pack.conv3x3_wreg_shape(o.Cin, o.Cout) and ct == 4:
+                        for wg in (2, 4, 8):                              # weights in registers, patches by DMA: 64 / 128 / 256 workgroups per conv (tile_c = that / 32)
+                            if wg * 32 * (2 if twin else 1) <= 256:
+                                cands += [(3, wg, 7), (2, wg, 7)]         # tile_p = patch buffers (3: two patches in flight ahead of the multiply)
                     pooled = o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2
                     if ksteps >= 4 and ct >= 4 and self.dtype == lib.F16 and not o.out_f32 and not pooled:
                         for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
@@ -674,7 +709,7 @@ class Plan:
                                 cands.append((pt, ct, 2))
                 results = []
                 if twin:
-                    cands = [c_ for c_ in cands if c_[2] in (1, 2, 4)]       # the variants that take a twin launch
+                    cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7)]    # the variants that take a twin launch
                 for pt, ct, tk in cands:
                     wp, bp = packed(w, b, ct, tk)
                     op = lib.MafOp.from_buffer_copy(o)
@@ -694,7 +729,7 @@ class Plan:
                 best = (results[0][1], results[0][2], results[0][3])
                 _TUNE_CACHE[sig] = best
                 if verbose:
-                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
+                    print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
                 wp, bp = packed(w, b, ct, tk)
@@ -759,12 +794,16 @@ class Plan:
                 return "conv1x1_stream_kernel<%d, %d, %d>" % (o.tile_p, o.tile_c, -(-o.Cin // 32))
             if o.tile_k == 6:
                 return "conv3s2_lds_kernel<%d, %d, 4>" % (o.Cin, o.Cout)
+            if o.tile_k == 7:
+                return "conv3s2_wreg_kernel<%d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout))
             if o.tile_k == 5:
                 return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
         if o.kind == lib.OP_DWCONV:
             if o.tile_p == -1:
                 return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
+            if o.tile_p == -2:
+                return "dwconv_dot2_kernel<%d, 8, %d, %d>" % (o.ksize, 2 if (o.tile_k >> 8) % 2 == 0 else 1, o.act)
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:
             return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)

@@ -274,3 +274,32 @@ def pack_conv3x3_lds(w, b):
     rec = torch.cat([f.reshape(-1).view(torch.uint8), b.detach().float().cpu().contiguous().view(torch.uint8)])
     assert rec.numel() == ks * (cout // 16) * 1024 + cout * 4
     return rec
+
+
+_WREG_SHAPES = {(128, 128): (8, 1), (96, 96): (6, 1), (96, 64): (4, 2), (64, 64): (4, 2)}        # (Cin, Cout) -> (waves along the channels, waves along the pixels)
+
+
+def conv3x3_wreg_shape(cin, cout):
+    """(waves along the channels, waves along the pixels) of the register-resident 3x3 stride-2 conv (csrc/conv3s2_wreg.hip, tile_k = 7), or None."""
+    return _WREG_SHAPES.get((cin, cout))
+
+
+def pack_conv3x3_wreg(w, b):
+    """Record of the register-resident-weight 3x3 stride-2 conv (csrc/conv3s2_wreg.hip, tile_k = 7): w [Cout, Cin, 3, 3], b [Cout] -> fragments
+    [Cout / 16 channel tiles][9 * Cin / 32 k-steps][64 lanes][8] f16 — lane (g, n) of k-step s of tile t: output channel 16 t + n, pair q = 4 s + g ->
+    tap q // (Cin / 8) (tap-major: uniform per k-step since Cin % 32 == 0), channel group q % (Cin / 8), element j = input channel 8 * group + j —
+    followed by the bias, fp32 [Cout]."""
+    w = w.detach().float().cpu()
+    cout, cin = w.shape[:2]
+    assert (cin, cout) in _WREG_SHAPES and cin % 32 == 0 and cout % 16 == 0 and w.shape[2:] == (3, 3)
+    gr = cin // 8
+    ks = 9 * cin // 32
+    m1 = torch.zeros(ks * 4, 8, cout)                               # [pair][j][out channel]
+    for q in range(9 * gr):
+        tap, grp = divmod(q, gr)
+        m1[q] = w[:, 8 * grp:8 * grp + 8, tap // 3, tap % 3].t()
+    # [s][g][j][t][n] -> [t][s][g][n][j]
+    f = m1.view(ks, 4, 8, cout // 16, 16).permute(3, 0, 1, 4, 2).contiguous().half()
+    rec = torch.cat([f.reshape(-1).view(torch.uint8), b.detach().float().cpu().contiguous().view(torch.uint8)])
+    assert rec.numel() == (cout // 16) * ks * 1024 + cout * 4
+    return rec

@@ -203,6 +203,11 @@ conv_autotune = os.environ.get("MAF_TRAIN_TUNE", "1") != "0"
 _conv_tune = {}
 
 
+def _stream_lds_ok(ksteps, ct):
+    from .engine import stream_lds_ok
+    return stream_lds_ok(ksteps, ct)
+
+
 def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
     """(tile_p, tile_c, tile_k) for the single-source conv K -> Nc over x (w2d [rows][cols] as maf_pack_w1x1 takes it)."""
     M = B * H * W
@@ -227,7 +232,7 @@ def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
             cands.append((1, ct, 4))
         if ksteps <= 4 and ksteps * ct <= 16:
             cands += [(1, ct, 3), (2, ct, 3)]
-        if 2 <= ksteps <= 12 and ksteps * ct <= 96:
+        if _stream_lds_ok(ksteps, ct):
             cands.append((1, ct, 5))
         if ksteps >= 4 and ct >= 4:
             for pt in ((1, 2, 4) if ct == 4 else (1, 2)):

@@ -268,6 +268,48 @@ def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
     assert (out[..., :cout] == 0).all()
 
 
+@pytest.mark.parametrize("cin,cout,act,hw", [(128, 128, lib.ACT_SILU, (40, 40)), (128, 128, lib.ACT_RELU, (21, 35)), (96, 96, lib.ACT_RELU, (38, 50)), (96, 64, lib.ACT_SILU, (80, 80)),
+                                             (64, 64, lib.ACT_SILU, (16, 18)), (128, 128, lib.ACT_SILU, (80, 80))])
+@pytest.mark.parametrize("twin", [False, True])
+def test_conv3x3_stride2_register_resident_weights(cin, cout, act, hw, twin):
+    """tile_k = 7 (csrc/conv3s2_wreg.hip): every weight fragment in registers, the input patch of a 4 x 8 output tile by DMA into a source-permuted
+    (bank-conflict-free) LDS image, double-buffered; odd input sizes, tiles hanging over the map, channel slices on both sides, one and two convs
+    per launch, any workgroup count; against F.conv2d in fp32 on the same fp16 operands, and equal to the generic MFMA template to summation-order noise."""
+    g = torch.Generator().manual_seed(cin * 5 + cout + hw[0])
+    B, (Hin, Win) = 3, hw
+    H, W = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+    convs = []
+    for k in range(2 if twin else 1):
+        x = _q(torch.randn(B, cin, Hin, Win, generator=g), lib.F16)
+        w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), lib.F16)
+        bias = torch.randn(cout, generator=g)
+        xs = torch.zeros(B, Hin, Win, cin + 16, dtype=torch.float16, device=DEV)      # the input is a channel slice of a wider buffer
+        xs[..., 8:8 + cin] = _nhwc(x, lib.F16)
+        convs.append((xs, w, bias, _act(F.conv2d(x, w, bias, 2, 1), act)))
+    assert pack.pack_conv3x3_wreg(convs[0][1], convs[0][2]).numel() == lib.load().maf_conv3s2_wreg_record_bytes(cin, cout)
+    res = {}
+    for tk, wg in ((7, 0), (7, 1), (7, 3), (72, 3), (1, 0)):
+        tk, nbuf = (7, 2) if tk == 72 else (tk, 3)
+        outs = [torch.full((B, H, W, 2 * cout), 3.0, dtype=torch.float16, device=DEV) for _ in convs]
+        recs = [(pack.pack_conv3x3_wreg(w, b) if tk == 7 else pack.pack_conv3x3(w, 4, lib.F16)).to(DEV) for _, w, b, _ in convs]
+        biases = [pack.pack_bias(b, 4).to(DEV) for _, _, b, _ in convs]
+        op = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, cin, cout, act, [(convs[0][0], cin, cin + 16, 8, 0)], outs[0], 2 * cout, cout, recs[0], biases[0],
+                      nbuf if tk == 7 else 1, wg if tk == 7 else 4, Hin=Hin, Win=Win)
+        op.tile_k = tk
+        if twin:
+            xs2 = convs[1][0]
+            op.aux[0], op.aux[1], op.aux[2], op.aux[3] = xs2.data_ptr(), recs[1].data_ptr(), biases[1].data_ptr(), outs[1].data_ptr()     # base pointers: the slices are shared
+        _launch(op)
+        for k, (xs, w, b, ref) in enumerate(convs):
+            _check(outs[k][..., cout:], ref, lib.F16)
+            assert (outs[k][..., :cout] == 3).all(), "wrote outside its slice"
+        res[(tk, wg, nbuf)] = [o[..., cout:].float() for o in outs]
+    res = {(k_[0], k_[1] if k_[2] == 3 else 72): v for k_, v in res.items()}
+    for k in range(len(convs)):
+        assert torch.equal(res[(7, 0)][k], res[(7, 1)][k]) and torch.equal(res[(7, 0)][k], res[(7, 3)][k]) and torch.equal(res[(7, 0)][k], res[(7, 72)][k])   # neither the workgroup count nor the buffer count changes a bit
+        assert (res[(7, 0)][k] - res[(1, 0)][k]).abs().max() <= 2e-3 * convs[k][3].abs().max() + 2e-3
+
+
 @pytest.mark.parametrize("cin,cout,act,hw", [(48, 48, lib.ACT_RELU, (36, 50)), (48, 64, lib.ACT_SILU, (64, 64)), (64, 64, lib.ACT_RELU, (22, 34)), (48, 48, lib.ACT_SILU, (160, 160))])
 def test_conv3x3_stride2_lds_resident(cin, cout, act, hw):
     """tile_k = 6 (csrc/conv3s2_lds.hip): all weight fragments + the input patch of a 4 x 16 tile in LDS, persistent workgroups; odd input
@@ -314,6 +356,38 @@ def test_dwconv(dt, k, C_, H, W):
         op.ksize = k
         _launch(op)
         _check(out, ref, dt)
+
+@pytest.mark.parametrize("k,C_,H,W,th,tw,cb", [(9, 576, 20, 20, 20, 24, 32), (9, 40, 20, 20, 10, 24, 16), (7, 72, 21, 27, 8, 16, 64), (5, 64, 33, 16, 16, 16, 32),
+                                               (3, 24, 16, 40, 4, 40, 8), (9, 192, 9, 11, 3, 8, 64), (5, 128, 80, 80, 16, 16, 32), (7, 288, 40, 40, 20, 40, 16)])
+@pytest.mark.parametrize("two", [False, True])
+def test_dwconv_dot2_variant(k, C_, H, W, th, tw, cb, two):
+    """tile_p = -2 (csrc/dwconv_dot2.hip): two taps per instruction (v_dot2_f32_f16) on a pair-interleaved halo tile; odd sizes, tiles hanging over
+    the map, odd and even tile heights (one / two strips per lane), slices of wider buffers, two filters per input channel (the head's cls / reg pair);
+    against F.conv2d in fp32 on the same fp16 operands and against the v_fma_mix kernel."""
+    g = torch.Generator().manual_seed(300 + k + C_)
+    B, dt = 2, lib.F16
+    cout = 2 * C_ if two else C_
+    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, 1, k, k, generator=g) / k, dt)
+    bias = torch.randn(cout, generator=g)
+    xs = torch.zeros(B, H, W, C_ + 16, dtype=torch.float16, device=DEV)
+    xs[..., 8:8 + C_] = _nhwc(x, dt)
+    xin = torch.cat([x, x], 1) if two else x
+    for act in (lib.ACT_SILU, lib.ACT_NONE):
+        ref = _act(F.conv2d(xin, w, bias, 1, k // 2, 1, cout), act)
+        outs = []
+        for tp in (-2, 0):
+            out = torch.full((B, H, W, cout + 8), 3.0, dtype=torch.float16, device=DEV)
+            op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, act, [(xs, C_, C_ + 16, 8, 0)], out, cout + 8, 8,
+                          pack.pack_dw(w, dt).to(DEV), bias.to(DEV), tp, tw if tp else 0)
+            op.ksize = k
+            op.tile_k = th * 256 + cb if tp else 0
+            _launch(op)
+            _check(out[..., 8:], ref, dt)
+            assert (out[..., :8] == 3).all()
+            outs.append(out[..., 8:].float())
+        assert (outs[0] - outs[1]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
+
 
 @pytest.mark.parametrize("k,C_,H,W", [(7, 72, 21, 27), (9, 40, 20, 20), (5, 64, 33, 16), (3, 24, 16, 40), (9, 192, 9, 11)])
 def test_dwconv_matrix_core_variant(k, C_, H, W):
