@@ -19,6 +19,7 @@
 //     NHWC pixels out as 16-byte pieces after the barrier that also publishes the next patch;
 //   * a twin launch (two convs of one shape: op->aux) gives each conv half of the workgroups.
 #include "maf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -33,6 +34,19 @@ struct C3wArgs {
 
 constexpr int W3_TR = 4, W3_TC = 8, W3_SR = 2 * W3_TR + 1, W3_SC = 2 * W3_TC + 1, W3_NPIX = W3_SR * W3_SC;
 constexpr int W3_SLOTS = W3_NPIX * 16;                              // 16-byte slots of a patch image (256 bytes per pixel, whatever Cin)
+
+// LDS reads as inline assembly with hand-counted waits: written as plain loads the compiler issues every fragment read right in front of the MFMA that
+// needs it and waits with lgkmcnt(0) — a full LDS round trip (~130 cycles) per 17-cycle MFMA, 9.4k of the 9.6k cycles a tile took.
+template <int OFF> __device__ __forceinline__ void w3_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void w3_wait_lgkm(u32x4_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }   // "+v": the MFMA that reads `a` cannot move above the wait
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void w3_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        w3_static_for<N, I + 1>(f);
+    }
+}
 
 template <int NW>
 constexpr int w3_patch_bytes() { return (W3_SLOTS + NW * 64 - 1) / (NW * 64) * (NW * 64) * 16; }   // whole DMA rounds: the last one writes past the last pixel
@@ -137,25 +151,47 @@ __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_w
             const int nt_ = tile + (NBUF - 1) * wgc;
             dma(nt_ < a.ntiles ? nt_ : a.ntiles - 1, (it + NBUF - 1) % NBUF);     // every wave left that buffer before the last barrier
         }
-        const unsigned char* pb = w3_raw + cur * PB + pixbase;
+        // lane addresses of the fragment reads: [ky >> 1][kx >> 1][k-step within the tap] (the rest of an address is a compile-time offset)
+        uint32_t fa[2][2][KPT];
+        {
+            const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(w3_raw + cur * PB + pixbase);
+#pragma unroll
+            for (int yk = 0; yk < 2; ++yk)
+#pragma unroll
+                for (int xk = 0; xk < 2; ++xk)
+#pragma unroll
+                    for (int j = 0; j < KPT; ++j) fa[yk][xk][j] = base + (uint32_t)(((4 * j + g) ^ swz[yk][xk]) * 16);
+        }
         f32x4_t acc[MT][NTW];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // KS * MT steps (k-step s, m-tile m), ONE straight line, software-pipelined by hand: the read of step t + RD is issued before the MFMAs of
+        // step t (LDS returns in order: when step t is consumed, the min(RD, steps left) reads issued after its own may still be in flight)
+        constexpr int NSTEP = KS * MT, RD = 6;
+        u32x4_t fr[RD + 1];
+        auto ld_step = [&](auto idx) {
+            constexpr int t = decltype(idx)::value;
+            if constexpr (t < NSTEP) {
+                constexpr int s_ = t / MT, m = t % MT, tap = s_ / KPT, ky = tap / 3, kx = tap - 3 * ky;
+                constexpr int off = (ky * W3_SC + kx) * 256 + m * (4 * W3_SC * 256);
+                static_assert(off < 65536, "ds offset field");
+                w3_ds_read_b128<off>(fr[t % (RD + 1)], fa[ky >> 1][kx >> 1][s_ % KPT]);
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the counter now counts only the reads below
+        w3_static_for<RD>([&](auto idx) { ld_step(idx); });
+        w3_static_for<NSTEP>([&](auto idx) {
+            constexpr int t = decltype(idx)::value, s_ = t / MT, m = t % MT, sl = t % (RD + 1);
+            ld_step(std::integral_constant<int, t + RD>{});
+            constexpr int ahead = (NSTEP - 1 - t) < RD ? (NSTEP - 1 - t) : RD;
+            w3_wait_lgkm<ahead>(fr[sl]);
+            const half8_t f = __builtin_bit_cast(half8_t, fr[sl]);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int tap = s / KPT, ky = tap / 3, kx = tap - 3 * ky;             // compile-time after unrolling
-            const int slot = (4 * (s % KPT) + g) ^ swz[ky >> 1][kx >> 1];
-            const unsigned char* q = pb + (ky * W3_SC + kx) * 256 + slot * 16;
-            half8_t f[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) f[m] = *reinterpret_cast<const half8_t*>(q + m * (4 * W3_SC * 256));   // m-tile m: output rows 2m, 2m + 1
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[s][t], f[m], acc[m][t], 0, 0, 0);
-        }
+            for (int tt = 0; tt < NTW; ++tt) acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[s_][tt], f, acc[m][tt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                                    // keep the issue order as written
+        });
         // ---- bias + activation (picked once per tile, not per value) -> the output tile in LDS: pixel (wm * MT + m) * 16 + n, channels (wn * NTW + t) * 16 + 4 g ..
         half_t* so = reinterpret_cast<half_t*>(s_out + ocur * OB);
         if (act == MAF_ACT_SILU) w3_epilogue<MAF_ACT_SILU, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);

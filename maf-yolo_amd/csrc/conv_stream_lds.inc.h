@@ -5,6 +5,20 @@
 
 namespace {
 
+// LDS reads of the weight fragments as inline assembly with hand-counted waits: as plain loads the compiler reads two fragments into the same two
+// register quads right in front of the two MFMAs that need them and waits with lgkmcnt(1) / lgkmcnt(0) — a full LDS round trip (~130 cycles) per
+// pair of 17-cycle MFMAs, 4.7k cycles for the 72 MFMAs of a 288 -> 128 tile instead of 1.2k.
+template <int OFF> __device__ __forceinline__ void sl_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void sl_wait_lgkm(u32x4_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }   // "+v": the MFMA that reads `a` cannot move above the wait
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void sl_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sl_static_for<N, I + 1>(f);
+    }
+}
+
 template <int ACT, int CT>
 __device__ __forceinline__ void sl_store(const f32x4_t (&acc)[CT], int r, half_t* op, int nvalid) {
     float v[CT];
@@ -95,20 +109,45 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
         }
     };
     const int act = a.act;                                               // uniform: the activation is picked once per tile, not per value
+    uint32_t wbase[3];                                                   // LDS addresses of this lane's 16 bytes in fragment 0, 64, 128
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wbase[k] = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(wl_raw + k * 65536 + lane * 16);
     auto compute_store = [&](int t, const frag_t (&af)[KS]) {
         f32x4_t acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4_t){bias[ct], bias[ct], bias[ct], bias[ct]};
+        if constexpr ((MAF_KO & 9) != 0) {                                // knock-out builds: the plain form
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            frag_t wf[CT];
+            for (int ks = 0; ks < KS; ++ks) {
+                frag_t wf[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = (MAF_KO & 1) ? (frag_t)(half_t)(0.002f * (float)(lane + ct)) : wl[(ks * CT + ct) * 64 + lane];
+                for (int ct = 0; ct < CT; ++ct) wf[ct] = (MAF_KO & 1) ? (frag_t)(half_t)(0.002f * (float)(lane + ct)) : wl[(ks * CT + ct) * 64 + lane];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (MAF_KO & 8) acc[ct][0] += (float)af[ks][0] + (float)wf[ct][0];
-                else acc[ct] = F::mma(af[ks], wf[ct], acc[ct]);
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (MAF_KO & 8) acc[ct][0] += (float)af[ks][0] + (float)wf[ct][0];
+                    else acc[ct] = F::mma(af[ks], wf[ct], acc[ct]);
+                }
             }
+        } else {
+            // KS * CT steps (k-step, channel tile), ONE straight line, software-pipelined by hand: the fragment of step t + RD is read before the MFMA of
+            // step t (LDS returns in order: when step t is consumed the min(RD, steps left) reads issued after its own may still be in flight).  The
+            // offset field of a DS instruction holds 64 KiB: one base register per 64 KiB of the (up to 160 KiB) fragment array.
+            constexpr int NSTEP = KS * CT, RD = NSTEP > 6 ? 6 : NSTEP - 1;
+            u32x4_t wr[RD + 1];
+            auto ld_step = [&](auto idx) {
+                constexpr int s_ = decltype(idx)::value;
+                if constexpr (s_ < NSTEP) sl_ds_read_b128<(s_ * 1024) % 65536>(wr[s_ % (RD + 1)], wbase[(s_ * 1024) / 65536]);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the counter now counts only the reads below
+            sl_static_for<RD>([&](auto idx) { ld_step(idx); });
+            sl_static_for<NSTEP>([&](auto idx) {
+                constexpr int s_ = decltype(idx)::value, ks = s_ / CT, ct = s_ % CT, sl = s_ % (RD + 1);
+                ld_step(std::integral_constant<int, s_ + RD>{});
+                constexpr int ahead = (NSTEP - 1 - s_) < RD ? (NSTEP - 1 - s_) : RD;
+                sl_wait_lgkm<ahead>(wr[sl]);
+                acc[ct] = F::mma(af[ks], __builtin_bit_cast(frag_t, wr[sl]), acc[ct]);
+                __builtin_amdgcn_sched_barrier(0);                      // keep the issue order as written
+            });
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -15,6 +15,7 @@
 // (WLDS = false) read the same fragment records straight from global memory — every wave streams them once per 16-pixel unit out of the
 // L2, where they stay resident (the records of a level total <= 0.7 MB).
 #include "maf_common.h"
+#include "lds_pipe.h"
 #include <type_traits>
 
 namespace {
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
     constexpr int BOFF = WLDS ? W1B + W2B : 2 * CHB;
     const half8_t* w1 = reinterpret_cast<const half8_t*>(s_w);
     const half8_t* w2 = reinterpret_cast<const half8_t*>(s_w + W1B);
+    uint32_t w1a[2], w2a[2];                                                      // LDS addresses of this lane's 16 bytes of fragment 0 / 64 of W1 and W2
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { w1a[k] = lp_lds_addr(s_w + k * 65536 + lane * 16); w2a[k] = lp_lds_addr(s_w + W1B + k * 65536 + lane * 16); }
     const f32x4_t* b1 = reinterpret_cast<const f32x4_t*>(s_w + BOFF);
     const float* b2 = reinterpret_cast<const float*>(s_w + BOFF + C * 4);
     const half_t* xb = a.x[br] + a.xc[br] + 8 * G;
@@ -128,14 +132,25 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
             for (int t = 0; t < T1R; ++t) acc1[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if constexpr (WLDS) {
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8_t wa = w1[(t * KS + ks) * 64 + lane];
+            // T1 * KS steps, one straight line, the weight fragment of step s + RD read before the MFMAs of step s (lds_pipe.h)
+            constexpr int NSTEP = T1 * KS, RD = 6;
+            u32x4_t wr[RD + 1];
+            auto ld_step = [&](auto idx) {
+                constexpr int s_ = decltype(idx)::value;
+                if constexpr (s_ < NSTEP) lp_ds_read_b128<(s_ * 1024) % 65536>(wr[s_ % (RD + 1)], w1a[(s_ * 1024) / 65536]);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lp_static_for<RD>([&](auto idx) { ld_step(idx); });
+            lp_static_for<NSTEP>([&](auto idx) {
+                constexpr int s_ = decltype(idx)::value, t = s_ / KS, ks = s_ % KS, sl = s_ % (RD + 1);
+                ld_step(std::integral_constant<int, s_ + RD>{});
+                constexpr int ahead = (NSTEP - 1 - s_) < RD ? (NSTEP - 1 - s_) : RD;
+                lp_wait_lgkm<ahead>(wr[sl]);
+                const half8_t wa = __builtin_bit_cast(half8_t, wr[sl]);
 #pragma unroll
                 for (int p = 0; p < PT; ++p) acc1[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc1[p][t], 0, 0, 0);
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         } else {
             // the record does not fit the LDS: its T1 + NT2 chunks (the fragments of one 16-channel tile: KS KiB) pass through two LDS
             // buffers — chunk c + 1 travels global -> registers -> LDS while chunk c is multiplied, one barrier per chunk
@@ -194,14 +209,24 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc2[p][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if constexpr (WLDS) {
-#pragma unroll
-        for (int t = 0; t < NT2; ++t)
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const half8_t wb = w2[(t * KS + j) * 64 + lane];
+            constexpr int NSTEP = NT2 * KS, RD = 6;
+            u32x4_t wr[RD + 1];
+            auto ld_step = [&](auto idx) {
+                constexpr int s_ = decltype(idx)::value;
+                if constexpr (s_ < NSTEP) lp_ds_read_b128<(s_ * 1024) % 65536>(wr[s_ % (RD + 1)], w2a[(s_ * 1024) / 65536]);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lp_static_for<RD>([&](auto idx) { ld_step(idx); });
+            lp_static_for<NSTEP>([&](auto idx) {
+                constexpr int s_ = decltype(idx)::value, t = s_ / KS, j = s_ % KS, sl = s_ % (RD + 1);
+                ld_step(std::integral_constant<int, s_ + RD>{});
+                constexpr int ahead = (NSTEP - 1 - s_) < RD ? (NSTEP - 1 - s_) : RD;
+                lp_wait_lgkm<ahead>(wr[sl]);
+                const half8_t wb = __builtin_bit_cast(half8_t, wr[sl]);
 #pragma unroll
                 for (int p = 0; p < PT; ++p) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         } else {
             ht_static_for<NT2>([&](auto idx) {
                 constexpr int t = decltype(idx)::value, c = T1 + t;
