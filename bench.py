@@ -387,7 +387,7 @@ def main():
     from maf_yolo_amd import engine as _engine
     # tile choices (which (pixels x channels) cut, which kernel variant per layer) measured on an MI355X and frozen in the repo are the
     # default starting point: layer signatures that are not in the file are still timed here.  --tune-file none = time everything afresh.
-    frozen = os.path.join(ROOT, "profiles", "round2_tune.json")
+    frozen = os.path.join(ROOT, "profiles", "round3_tune.json")
     if args.tune_file is None and os.path.exists(frozen):
         args.tune_file = frozen
     if args.tune_file == "none":

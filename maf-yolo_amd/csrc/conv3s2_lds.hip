@@ -7,6 +7,7 @@
 // csrc/stem2.hip phase C: K = 9 taps x Cin / 8 (tap, 8-channel group) pairs, four pairs per MFMA k-step, transposed (A = weights,
 // B = patch) so a lane holds 4 consecutive output channels of one pixel; bias + activation, through LDS, whole NHWC pixels out.
 #include "maf_common.h"
+#include "lds_pipe.h"
 
 namespace {
 
@@ -82,22 +83,54 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
         for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        {
+            // KS k-steps, one straight line, the reads of step s + RD (two 8-byte halves of the patch fragment per m-tile, NT weight fragments) issued
+            // before the MFMAs of step s (lds_pipe.h: as plain loads every step waited a full LDS round trip in front of its MFMAs)
+            constexpr int RD = 2, PER = 2 * MR + NT;                          // reads per step
+            u32x2_t plo[RD + 1][MR], phi[RD + 1][MR];
+            u32x4_t wr[RD + 1][NT];
+            const uint32_t wa = lp_lds_addr(s_w + lane * 16);
+            uint32_t pa[MR];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            half8_t tf[MR];
+            for (int m = 0; m < MR; ++m) pa[m] = lp_lds_addr(s_T + ((2 * (wave * MR + m)) * SC + 2 * n) * TSH);
+            auto ld_step = [&](auto idx) {
+                constexpr int s_ = decltype(idx)::value;
+                if constexpr (s_ < KS) {
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const int yy = wave * MR + m;
-                const half_t* tp = s_T + ((2 * yy) * SC + 2 * n) * TSH + off1[s];
-                const half4_t lo = *reinterpret_cast<const half4_t*>(tp), hi = *reinterpret_cast<const half4_t*>(tp + 4);
-                tf[m] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+                    for (int m = 0; m < MR; ++m) {
+                        const uint32_t ad = pa[m] + (uint32_t)off1[s_] * 2;
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(plo[s_ % (RD + 1)][m]) : "v"(ad));
+                        asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(phi[s_ % (RD + 1)][m]) : "v"(ad));
+                    }
+                    lp_static_for<NT>([&](auto tt) {
+                        constexpr int t = decltype(tt)::value;
+                        lp_ds_read_b128<((s_ * NT + t) * 1024) % 65536>(wr[s_ % (RD + 1)][t], wa + ((s_ * NT + t) * 1024) / 65536 * 65536);
+                    });
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lp_static_for<RD>([&](auto idx) { ld_step(idx); });
+            lp_static_for<KS>([&](auto idx) {
+                constexpr int s_ = decltype(idx)::value, sl = s_ % (RD + 1);
+                ld_step(std::integral_constant<int, s_ + RD>{});
+                constexpr int ahead = ((KS - 1 - s_) < RD ? (KS - 1 - s_) : RD) * PER;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ahead < 15 ? ahead : 15) : "memory");
+                half8_t tf[MR];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const half8_t w8 = wf[(s * NT + t) * 64 + lane];
+                for (int m = 0; m < MR; ++m) {
+                    asm volatile("" : "+v"(plo[sl][m]), "+v"(phi[sl][m]));    // consumed after the wait
+                    const u32x4_t v4 = {plo[sl][m][0], plo[sl][m][1], phi[sl][m][0], phi[sl][m][1]};
+                    tf[m] = __builtin_bit_cast(half8_t, v4);
+                }
 #pragma unroll
-                for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8, tf[m], acc[m][t], 0, 0, 0);
-            }
+                for (int t = 0; t < NT; ++t) {
+                    asm volatile("" : "+v"(wr[sl][t]));
+                    const half8_t w8 = __builtin_bit_cast(half8_t, wr[sl][t]);
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8, tf[m], acc[m][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
 #pragma unroll
         for (int m = 0; m < MR; ++m)

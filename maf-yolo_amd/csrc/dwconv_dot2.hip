@@ -27,6 +27,12 @@ struct Dw2Args {
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
+__host__ __device__ inline int dw2_pair_stride(int nq) {
+    for (int ps = nq; ps < nq + 4; ++ps)
+        if ((4 * ps - nq) % 16 == 0) return ps;
+    return nq + 1;
+}
+
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
 }
@@ -52,7 +58,9 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
     const int cbe = min(a.CB, a.C - c0);
     const int NG = cbe / 8, NQ = 2 * NG;                                 // 16-byte channel groups / quads of this block
     const int RH = a.TH + K - 1, PWP = (a.TW + K - 1) / 2;               // patch rows, pixel pairs per row
-    const int PS = NQ + 1;                                               // pair stride in vectors (+16 B: strips of a wave on different banks)
+    // pair stride in vectors: the NQ lanes of a strip read NQ consecutive 16-byte slots and neighbouring strips start RX / 2 = 4 pairs apart — with
+    // 4 * PS = NQ (mod 16) the strips of a 16-lane LDS group tile the 256-byte bank row one after the other (NQ = 8: PS = 10, NQ = 4: PS = 5, NQ = 16: 16)
+    const int PS = dw2_pair_stride(NQ);
     u32x4_t* wl = tile + RH * PWP * PS;                                  // [K][2 phases][NP][NQ] weight-pair vectors
     const int tid = threadIdx.x;
 
@@ -187,7 +195,7 @@ constexpr size_t kMaxLds2 = 96 * 1024;
 
 size_t lds_bytes2(int TH, int TW, int CB, int K) {
     const int NQ = CB / 4, NP = (K + 1) / 2;
-    return ((size_t)(TH + K - 1) * ((TW + K - 1) / 2) * (NQ + 1) + (size_t)K * 2 * NP * NQ) * 16;
+    return ((size_t)(TH + K - 1) * ((TW + K - 1) / 2) * dw2_pair_stride(NQ) + (size_t)K * 2 * NP * NQ) * 16;
 }
 
 template <int K, int ACT>

@@ -629,7 +629,7 @@ class Plan:
                                 for cb in (16, 32, 64):
                                     cb = min(cb, o.Cin)
                                     nq, np_ = cb // 4, (o.ksize + 1) // 2
-                                    lds = ((th + o.ksize - 1) * ((tw + o.ksize - 1) // 2) * (nq + 1) + o.ksize * 2 * np_ * nq) * 16
+                                    lds = ((th + o.ksize - 1) * ((tw + o.ksize - 1) // 2) * (nq + 3) + o.ksize * 2 * np_ * nq) * 16      # (pair stride <= nq + 3: csrc/dwconv_dot2.hip)
                                     if lds > 96 * 1024 or (-2, tw, th * 256 + cb) in [r_[1:] for r_ in results]:
                                         continue
                                     op = lib.MafOp.from_buffer_copy(o)

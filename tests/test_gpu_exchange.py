@@ -128,7 +128,7 @@ def test_exchange_survives_a_failed_backward():
         loss.backward()
         ref = _grads(b)
         torch.cuda.synchronize()
-        _check(got, ref)
+        _check(got, ref, tol=3e-2)                        # 2 x 128 x 128: few pixels per layer to average the fp16 / atomic-order noise over; a stale state shows as O(1)
     finally:
         ex.close()
 

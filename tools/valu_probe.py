@@ -16,7 +16,7 @@ st = torch.cuda.current_stream().cuda_stream
 iters = 4096
 for wg in (1, 2, 4):
     row = []
-    for kind, name in ((0, "fma"), (1, "exp+mul"), (2, "rcp+add"), (3, "silu(4 ops + add)")):
+    for kind, name in ((0, "fma"), (1, "exp+mul"), (2, "rcp+add"), (3, "silu(4 ops + add)"), (4, "fma_mix"), (5, "dot2(+2 ops)"), (6, "pk_fma_f16"), (7, "pk_fma_f32"), (8, "dot2c")):
         c = C.c_longlong()
         lib.check(L.maf_probe_valu(st, kind, iters, wg, C.byref(c)))
         row.append("%s %.2f" % (name, c.value / (iters * 8.0)))
