@@ -147,7 +147,8 @@ def train_pmc_traffic(kind, scale):
     """HBM bytes per launch of `kind` from the PMC passes of a training run committed under profiles/ (tools/profile_round.sh: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs, counters only; tools/pmc_traffic.py: (FETCH_SIZE*2 + WRITE_SIZE)*1024) — n at batch 32 only."""
     import re
-    path = os.path.join(ROOT, "profiles", "round2_train_pmc_traffic.json")
+    path = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round3_train_pmc_traffic.json", "round2_train_pmc_traffic.json")) if os.path.exists(p_)]
+    path = path[0] if path else ""
     pat = _TRAIN_KIND_KERNELS.get(kind)
     if pat is None or scale != "n" or not os.path.exists(path):
         return None, None
@@ -157,7 +158,7 @@ def train_pmc_traffic(kind, scale):
     if not rows or not calls:
         return None, None
     total = sum(v["traffic_bytes"] * v["launches"] for v in rows)
-    return int(total / calls), "profiles/round2_train_pmc_traffic.json: (FETCH_SIZE*2 + WRITE_SIZE)*1024 summed over the kind's kernels, per call (n, batch 32)"
+    return int(total / calls), "profiles/%s: (FETCH_SIZE*2 + WRITE_SIZE)*1024 summed over the kind's kernels, per call (n, batch 32)" % os.path.basename(path)
 
 
 def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmup, full):
@@ -525,7 +526,7 @@ def main():
         fwd_img_s = B / (fwd_ms * 1e-3)
         traffic, traffic_src, pmc = None, None, {}
         try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
-            pmc_file = [f_ for f_ in ("round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            pmc_file = [f_ for f_ in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             have = [k for k in gd["inst"] if k in pmc]
             if have:                           # per launch of the template: instantiations weighted by their launches in this forward

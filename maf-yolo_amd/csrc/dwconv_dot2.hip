@@ -16,6 +16,10 @@
 // swapped pairwise at the end so that every lane stores 16 bytes (8 channels of one pixel).
 #include "maf_common.h"
 
+#ifndef MAF_KO
+#define MAF_KO 0            // profiling builds (make ko): 32 = no multiply-add loop, 64 = no halo loads (zeros are staged), 128 = no output stores
+#endif
+
 namespace {
 
 struct Dw2Args {
@@ -32,6 +36,14 @@ __host__ __device__ inline int dw2_pair_stride(int nq) {
         if ((4 * ps - nq) % 16 == 0) return ps;
     return nq + 1;
 }
+
+// n / d for n * d < 2^32 by one v_mul_hi: index decoding by runtime tile dimensions costs ~40 instructions per division otherwise, and a lane of
+// this kernel issues an instruction every ~4-7 cycles (knock-out builds: with neither loads nor multiply-adds the first version still took 24 of 47 us)
+struct FastDiv {
+    uint32_t d, m;
+    __device__ explicit FastDiv(int dd) : d((uint32_t)dd), m(dd > 1 ? (uint32_t)((0x100000000ull + (uint32_t)dd - 1) / (uint32_t)dd) : 0u) {}
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d > 1 ? __umulhi(n, m) : n; }
+};
 
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
     const int PS = dw2_pair_stride(NQ);
     u32x4_t* wl = tile + RH * PWP * PS;                                  // [K][2 phases][NP][NQ] weight-pair vectors
     const int tid = threadIdx.x;
+    const FastDiv dNG(NG), dPWP(PWP), dNQ(NQ);
 
     {   // ---- stage the halo tile pair-interleaved
         const half_t* in = a.in + a.in_coff + c0 % a.in_mod;
@@ -73,12 +86,12 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int idx = base + u * 256;
-                const int gi = idx % NG, pp = idx / NG;
-                const int pj = pp % PWP, ry = pp / PWP;
+                const int pp = (int)dNG.div((uint32_t)idx), gi = idx - pp * NG;
+                const int ry = (int)dPWP.div((uint32_t)pp), pj = pp - ry * PWP;
                 const int iy = y0 - P + ry, ix = x0 - P + 2 * pj;
                 va[u] = vb[u] = (u32x4_t){0u, 0u, 0u, 0u};
                 dst[u] = idx < total ? (ry * PWP + pj) * PS + 2 * gi : -1;
-                if (idx < total && (unsigned)iy < (unsigned)a.H) {
+                if (!(MAF_KO & 64) && idx < total && (unsigned)iy < (unsigned)a.H) {
                     const half_t* rowp = in + ((size_t)((size_t)b * a.H + iy) * a.W) * a.in_stride + gi * 8;
                     if ((unsigned)ix < (unsigned)a.W) va[u] = *reinterpret_cast<const u32x4_t*>(rowp + (size_t)ix * a.in_stride);
                     if ((unsigned)(ix + 1) < (unsigned)a.W) vb[u] = *reinterpret_cast<const u32x4_t*>(rowp + (size_t)(ix + 1) * a.in_stride);
@@ -98,30 +111,43 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
         }
         // weight pairs: wl[((ky * 2 + phase) * NP + p) * NQ + q] dword c = (W[ky][2p - phase][ch], W[ky][2p - phase + 1][ch]), zero outside 0 .. K-1
         const half_t* w = a.w + c0;                                      // [K*K][C]
-        for (int idx = tid; idx < K * 2 * NP * NQ; idx += 256) {
-            const int q = idx % NQ;
-            int r = idx / NQ;
-            const int p = r % NP; r /= NP;
-            const int ph = r & 1, ky = r >> 1;
-            const int k0 = 2 * p - ph, k1 = k0 + 1;
-            u32x4_t v;
+        // (all of a lane's loads first, then the interleave + LDS stores: as a load -> use loop every round was an L2 round trip)
+        constexpr int WR = (K * 2 * NP * 16 + 255) / 256;                 // rounds at the widest block (NQ = 16)
+        u32x2_t wlo[WR], whi[WR];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t lo = (k0 >= 0 && k0 < K) ? (uint32_t) * reinterpret_cast<const uint16_t*>(w + (size_t)(ky * K + k0) * a.C + 4 * q + c) : 0u;
-                const uint32_t hi = (k1 >= 0 && k1 < K) ? (uint32_t) * reinterpret_cast<const uint16_t*>(w + (size_t)(ky * K + k1) * a.C + 4 * q + c) : 0u;
-                v[c] = lo | (hi << 16);
+        for (int r0 = 0; r0 < WR; ++r0) {
+            const int idx = tid + r0 * 256;
+            wlo[r0] = whi[r0] = (u32x2_t){0u, 0u};
+            if (idx < K * 2 * NP * NQ) {
+                int r = (int)dNQ.div((uint32_t)idx);
+                const int q = idx - r * NQ;
+                const int p = r % NP; r /= NP;                           // (compile-time divisor)
+                const int ph = r & 1, ky = r >> 1;
+                const int k0 = 2 * p - ph, k1 = k0 + 1;
+                // the quad's 4 channels of tap k0 and of tap k1: one 8-byte load each
+                if (k0 >= 0 && k0 < K) wlo[r0] = *reinterpret_cast<const u32x2_t*>(w + (size_t)(ky * K + k0) * a.C + 4 * q);
+                if (k1 >= 0 && k1 < K) whi[r0] = *reinterpret_cast<const u32x2_t*>(w + (size_t)(ky * K + k1) * a.C + 4 * q);
             }
-            wl[idx] = v;
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < WR; ++r0) {
+            const int idx = tid + r0 * 256;
+            if (idx < K * 2 * NP * NQ) {
+                u32x4_t v;                                               // interleaved channel by channel: dword c = (tap k0, tap k1) of channel c
+                v[0] = __builtin_amdgcn_perm(whi[r0][0], wlo[r0][0], 0x05040100u); v[1] = __builtin_amdgcn_perm(whi[r0][0], wlo[r0][0], 0x07060302u);
+                v[2] = __builtin_amdgcn_perm(whi[r0][1], wlo[r0][1], 0x05040100u); v[3] = __builtin_amdgcn_perm(whi[r0][1], wlo[r0][1], 0x07060302u);
+                wl[idx] = v;
+            }
         }
     }
     __syncthreads();
 
     const int NSX = a.TW / RX, NSY = a.TH / NS;
     const int items = NSY * NSX * NQ;
+    const FastDiv dNSX(NSX);
     for (int it = tid; it < items; it += 256) {
-        const int q = it % NQ;
-        const int u = it / NQ;
-        const int sx = u % NSX, sy = u / NSX;
+        const int u = (int)dNQ.div((uint32_t)it), q = it - u * NQ;
+        const int sy = (int)dNSX.div((uint32_t)u), sx = u - sy * NSX;
         const int ry0 = sy * NS, tc0 = sx * RX;                          // first tile row / column of the lane's strips
         if (y0 + ry0 >= a.H || x0 + tc0 >= a.W) continue;
         float acc[NS][RX][4];
@@ -135,7 +161,7 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
                     for (int c = 0; c < 4; ++c) acc[s][r][c] = bv[c];
         }
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
+        for (int ky = 0; ky < ((MAF_KO & 32) ? 1 : K); ++ky) {
             u32x4_t we[NP], wo[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(256) void dwconv_dot2_kernel(const Dw2Args a) {
                 const uint32_t g0 = oddq ? mine[r][0] : mine[r + 1][0], g1 = oddq ? mine[r][1] : mine[r + 1][1];
                 const uint32_t o0 = __shfl_xor(g0, 1), o1 = __shfl_xor(g1, 1);
                 const int ox = x0 + tc0 + r + (oddq ? 1 : 0);
-                if (oy < a.H && ox < a.W) {
+                if (oy < a.H && ox < a.W && !((MAF_KO & 128) && o0 != 0x12345678u)) {
                     const u32x4_t vv = oddq ? (u32x4_t){o0, o1, k0, k1} : (u32x4_t){k0, k1, o0, o1};
                     *reinterpret_cast<u32x4_t*>(a.out + a.out_coff + c0 + 8 * (q >> 1) + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * a.out_stride) = vv;
                 }

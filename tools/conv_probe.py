@@ -26,8 +26,15 @@ tag = os.path.basename(os.environ.get("MAF_HIP_LIB", "shipped"))
 for name, cands in specs:
     i = plan.op_names.index(name)
     o, r = plan.ops[i], plan._ops[i]
-    w, b, srcC = r["raw"]
     ops = []
+    if o.kind == lib.OP_DWCONV:                      # depth-wise: (tile_p, tile_c, tile_k) as the tuner sets them (-2, columns, rows * 256 + channels = csrc/dwconv_dot2.hip)
+        for pt, ct, tk in cands:
+            op = lib.MafOp.from_buffer_copy(o)
+            op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
+            ops.append((pt, ct, tk, op, None))
+        cands = []
+    else:
+        w, b, srcC = r["raw"]
     for pt, ct, tk in cands:
         wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, lib.F16) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, lib.F16)).cuda()
         bp = pack.pack_bias(b, ct if tk != 6 else 4).cuda()

@@ -28,6 +28,12 @@ python bench.py --train --scale s --batch 32 --steps 10 --warmup 3 --no-cpu-base
 python bench.py --train --scale m --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_m.json 2>/dev/null; echo "train m rc=$?"
 python bench.py --latency --scale m --tune-file $TUNE > $OUT/latency_m.json 2>/dev/null; echo "latency m rc=$?"
 for s in s m; do python bench.py --scale $s --steps 30 --warmup 10 --no-cpu-baseline --tune-file $OUT/tune_$s.json > $OUT/bench_$s.json 2>/dev/null; echo "bench $s rc=$?"; done
+# PMC calibration (tools/pmc_calibrate.py): known byte counts per access shape, one counter per pass
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/cal/pmc_$c -o p -- python tools/pmc_calibrate.py run > /dev/null 2> $OUT/cal_$c.err
+  echo "pmc calibration $c rc=$?"
+done
+python tools/pmc_calibrate.py reduce $OUT/cal $OUT/pmc_calibration.json > $OUT/pmc_calibration.txt 2>&1; cat $OUT/pmc_calibration.txt
 # keep the merge under the 64 MiB limit: traces are big, the stats are what gets committed
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 du -sh $OUT
