@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
     ap.add_argument("--ddp", action="store_true", help="--train A/B: torch's DistributedDataParallel instead of maf_yolo_amd.GradExchange (N > 1; at N = 1: plain autograd)")
     ap.add_argument("--no-train-leg", action="store_true", help="leave the short training leg (`train` object: n, bs 32/GPU) out of the default line")
-    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the training leg of the default line (after 4 warm-up steps)")
+    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
@@ -628,7 +628,7 @@ def main():
         del dets
         model._plans = {}
         torch.cuda.empty_cache()
-        train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 4, False)
+        train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 6, False)
     if rank == 0:
         if train is not None:
             train.pop("cpu_baseline", None)

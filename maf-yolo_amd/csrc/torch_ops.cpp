@@ -256,9 +256,120 @@ std::tuple<Tensor, Tensor> decode_nms(const Tensor& pred_in, double conf, double
     return {rows, cnt};
 }
 
+// One launch of `kind` writing channels [coff, coff + cout) of an existing NHWC tensor `out` (the concat buffers of mprep / sppf)
+void conv_into(const Tensor& x, int src_mode, const Tensor& wp, const Tensor& bias, int kind, int64_t cout, int64_t Hin, int64_t Win, int act, int pt, int ct,
+               Tensor& out, int64_t coff) {
+    const int dt = dtype_of(x);
+    maf_op_t op = {};
+    op.kind = kind; op.dtype = dt; op.in_dtype = dt; op.act = act;
+    op.B = (int)out.size(0); op.H = (int)out.size(2); op.W = (int)out.size(3); op.Hin = (int)Hin; op.Win = (int)Win; op.Cin = (int)x.size(1); op.Cout = (int)cout;
+    fill_src(op, x, src_mode);
+    op.out = out.data_ptr(); op.out_stride = (int)out.stride(3); op.out_coff = (int)coff;
+    op.tile_p = pt; op.tile_c = ct;
+    op.w = wp.data_ptr(); op.bias = bias.data_ptr<float>();
+    check(maf_op_launch(&op, stream_of(x)), "conv launch");
+}
+
+Tensor pack_1x1(const Tensor& w, int64_t cin_x, int dt, int ct, const Tensor& like) {
+    const int64_t cout = w.size(0);
+    Tensor w2 = w.reshape({cout, w.size(1)}).to(at::kFloat);
+    if (cin_x != w.size(1)) w2 = at::constant_pad_nd(w2, {0, cin_x - w.size(1)});
+    return pack_matrix(w2, cout, cin_x, 0, dt, ct, like);
+}
+
+// MPRep in deploy form (yolov6/layers/common.py:776-792): cat([Conv1x1+SiLU(MaxPool2x2(x)), RepVGG3x3s2+ReLU(x)], 1) — two launches, both writing
+// their slice of ONE output tensor; the 2x2 max-pool is folded into the operand load of the 1x1 (MAF_SRC_POOL2), no pooled tensor, no cat.
+Tensor mprep(const Tensor& x_in, const Tensor& w1, const c10::optional<Tensor>& b1, const Tensor& w3, const c10::optional<Tensor>& b3) {
+    const c10::DeviceGuard device_guard(x_in.device());
+    Tensor x = nhwc(x_in);
+    TORCH_CHECK(x.size(1) % 8 == 0 && x.size(2) % 2 == 0 && x.size(3) % 2 == 0, "mprep: channels in whole 16-byte groups, even sides");
+    TORCH_CHECK(w1.dim() == 4 && w1.size(2) == 1 && w1.size(1) == x.size(1) && w3.dim() == 4 && w3.size(2) == 3 && w3.size(1) == x.size(1), "mprep: w1 [c, Cin, 1, 1], w3 [c, Cin, 3, 3]");
+    const int dt = dtype_of(x);
+    const int64_t c1 = w1.size(0), c3 = w3.size(0), Ho = x.size(2) / 2, Wo = x.size(3) / 2, M = x.size(0) * Ho * Wo;
+    TORCH_CHECK(c1 % 8 == 0 && c3 % 8 == 0, "mprep: branch widths in whole 16-byte groups");
+    Tensor out = at::empty({x.size(0), c1 + c3, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    auto [pt1, ct1] = tile_for(c1, M);
+    conv_into(x, MAF_SRC_POOL2, pack_1x1(w1, x.size(1), dt, ct1, x), padded_bias(b1, c1, ct1, x), MAF_OP_CONV1X1, c1, 0, 0, MAF_ACT_SILU, pt1, ct1, out, 0);
+    auto [pt3, ct3] = tile_for(c3, M);
+    conv_into(x, MAF_SRC_DIRECT, pack_3x3(w3, false, dt, ct3, x), padded_bias(b3, c3, ct3, x), MAF_OP_CONV3X3S2, c3, x.size(2), x.size(3), MAF_ACT_RELU, pt3, ct3, out, c1);
+    return out;
+}
+
+// SPPF in deploy form (common.py:114-129): cv2(cat([y, m(y), m(m(y)), m(m(m(y)))])) with y = cv1(x), m = MaxPool 5x5 s1 p2 — cv1 writes slice 0 of the
+// concat buffer, ONE pooling launch (three cascaded separable 5-max passes in LDS) writes the other three slices, cv2 reads the buffer.
+Tensor sppf(const Tensor& x_in, const Tensor& w1, const c10::optional<Tensor>& b1, const Tensor& w2, const c10::optional<Tensor>& b2) {
+    const c10::DeviceGuard device_guard(x_in.device());
+    Tensor x = nhwc(x_in);
+    const int dt = dtype_of(x);
+    const int64_t c_ = w1.size(0), cout = w2.size(0), H = x.size(2), W = x.size(3), M = x.size(0) * H * W;
+    TORCH_CHECK(w1.size(1) == x.size(1) && w2.size(1) == 4 * c_ && c_ % 8 == 0 && x.size(1) % 8 == 0 && cout % 2 == 0, "sppf: cv1 [c_, Cin, 1, 1], cv2 [Cout, 4 c_, 1, 1]");
+    Tensor cat = at::empty({x.size(0), 4 * c_, H, W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    auto [pt1, ct1] = tile_for(c_, M);
+    conv_into(x, MAF_SRC_DIRECT, pack_1x1(w1, x.size(1), dt, ct1, x), padded_bias(b1, c_, ct1, x), MAF_OP_CONV1X1, c_, 0, 0, MAF_ACT_SILU, pt1, ct1, cat, 0);
+    {
+        maf_op_t op = {};
+        op.kind = MAF_OP_SPPF_POOL; op.dtype = dt; op.in_dtype = dt;
+        op.B = (int)x.size(0); op.H = (int)H; op.W = (int)W; op.Cin = (int)c_; op.Cout = (int)(3 * c_);
+        op.nsrc = 1;
+        op.src[0].ptr = cat.data_ptr(); op.src[0].C = (int)c_; op.src[0].stride = (int)cat.stride(3); op.src[0].coff = 0; op.src[0].mode = MAF_SRC_DIRECT;
+        op.out = cat.data_ptr(); op.out_stride = (int)cat.stride(3); op.out_coff = (int)c_;
+        check(maf_op_launch(&op, stream_of(x)), "sppf pool launch");
+    }
+    auto [pt2, ct2] = tile_for(cout, M);
+    return conv_generic(cat, pack_1x1(w2, 4 * c_, dt, ct2, x), padded_bias(b2, cout, ct2, x), MAF_OP_CONV1X1, cout, H, W, 0, 0, MAF_ACT_SILU, pt2, ct2);
+}
+
+// BatchNorm2d(train) + activation (Conv.forward = act(bn(conv(x))), common.py:44-47) on csrc/bn_act.hip: batch statistics, running-stat update
+// (torch's momentum rule, unbiased variance) -> (y, save_mean, save_rstd, new_running_mean, new_running_var).  The op is FUNCTIONAL (autograd formulas
+// are registered for functional ops only): the updated running statistics come back as new tensors (copies of the inputs when given, else empty);
+// torch_ops.bn_act_ copies them over the module's buffers.
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> bn_act(const Tensor& x_in, const Tensor& gamma, const Tensor& beta, const c10::optional<Tensor>& running_mean,
+                                           const c10::optional<Tensor>& running_var, double eps, double momentum, int64_t act) {
+    const c10::DeviceGuard device_guard(x_in.device());
+    Tensor x = nhwc(x_in);
+    const int dt = dtype_of(x);
+    const int64_t c = x.size(1), M = x.size(0) * x.size(2) * x.size(3);
+    TORCH_CHECK(c % (dt == MAF_F16 ? 8 : 4) == 0, "bn_act: channels in whole 16-byte groups");
+    Tensor y = at::empty_like(x, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    Tensor mean = at::empty({c}, x.options().dtype(at::kFloat).memory_format(c10::nullopt)), rstd = at::empty_like(mean);
+    const int R = 16;
+    Tensor part = at::zeros({2 * R * 2 * ((c + 255) / 256 * 256)}, mean.options());
+    Tensor g = gamma.to(at::kFloat).contiguous(), b = beta.to(at::kFloat).contiguous();
+    Tensor nrm = running_mean.has_value() && running_mean->defined() ? running_mean->to(at::kFloat).clone() : at::empty({0}, mean.options());
+    Tensor nrv = running_var.has_value() && running_var->defined() ? running_var->to(at::kFloat).clone() : at::empty({0}, mean.options());
+    float* rm = nrm.numel() ? nrm.data_ptr<float>() : nullptr;
+    float* rv = nrv.numel() ? nrv.data_ptr<float>() : nullptr;
+    check(maf_bn_forward(x.data_ptr(), (int)x.stride(3), (int)M, (int)c, dt, g.data_ptr<float>(), b.data_ptr<float>(), (float)eps, (float)momentum, rm, rv, nullptr,
+                         (int)act, y.data_ptr(), (int)y.stride(3), mean.data_ptr<float>(), rstd.data_ptr<float>(), part.data_ptr<float>(), R, 0, nullptr, 0, stream_of(x)),
+          "bn_forward");
+    return {y, mean, rstd, nrm, nrv};
+}
+
+// -> (dx, dgamma, dbeta) from dz = the gradient with respect to the activation output
+std::tuple<Tensor, Tensor, Tensor> bn_act_backward(const Tensor& x_in, const Tensor& dz_in, const Tensor& gamma, const Tensor& beta, const Tensor& save_mean,
+                                                    const Tensor& save_rstd, int64_t act) {
+    const c10::DeviceGuard device_guard(x_in.device());
+    Tensor x = nhwc(x_in), dz = nhwc(dz_in.to(x_in.scalar_type()));
+    const int dt = dtype_of(x);
+    const int64_t c = x.size(1), M = x.size(0) * x.size(2) * x.size(3);
+    Tensor dx = at::empty_like(x, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    Tensor dg = at::empty({c}, x.options().dtype(at::kFloat).memory_format(c10::nullopt)), db = at::empty_like(dg);
+    const int R = 16;
+    Tensor part = at::zeros({2 * R * 2 * ((c + 255) / 256 * 256)}, dg.options());
+    Tensor g = gamma.to(at::kFloat).contiguous(), b = beta.to(at::kFloat).contiguous();
+    check(maf_bn_backward(x.data_ptr(), (int)x.stride(3), dz.data_ptr(), (int)dz.stride(3), (int)M, (int)c, dt, g.data_ptr<float>(), b.data_ptr<float>(),
+                          save_mean.data_ptr<float>(), save_rstd.data_ptr<float>(), (int)act, dx.data_ptr(), (int)dx.stride(3), dg.data_ptr<float>(), db.data_ptr<float>(),
+                          part.data_ptr<float>(), R, 0, nullptr, 0, nullptr, 0, stream_of(x)), "bn_backward");
+    return {dx, dg, db};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(mafyolo, m) {
+    m.def("mprep(Tensor x, Tensor w1, Tensor? b1, Tensor w3, Tensor? b3) -> Tensor");
+    m.def("sppf(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2) -> Tensor");
+    m.def("bn_act(Tensor x, Tensor gamma, Tensor beta, Tensor? running_mean, Tensor? running_var, float eps, float momentum, int act) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("bn_act_backward(Tensor x, Tensor dz, Tensor gamma, Tensor beta, Tensor save_mean, Tensor save_rstd, int act) -> (Tensor, Tensor, Tensor)");
     m.def("conv1x1_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
     m.def("conv3x3s2_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
     m.def("dwconv_bias_act(Tensor x, Tensor w, Tensor? bias, int act) -> Tensor");
@@ -272,6 +383,10 @@ TORCH_LIBRARY(mafyolo, m) {
 }
 
 TORCH_LIBRARY_IMPL(mafyolo, CUDA, m) {       // the HIP device is the "CUDA" dispatch key of PyTorch-ROCm
+    m.impl("mprep", &mprep);
+    m.impl("sppf", &sppf);
+    m.impl("bn_act", &bn_act);
+    m.impl("bn_act_backward", &bn_act_backward);
     m.impl("conv1x1_bias_act", &conv1x1_bias_act);
     m.impl("conv3x3s2_bias_act", &conv3x3s2_bias_act);
     m.impl("dwconv_bias_act", &dwconv_bias_act);

@@ -101,6 +101,34 @@ class TV:
         return sum(s.C for s in self.segs)
 
 
+_SW_GROUPS = ((0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27), (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
+              (32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59), (36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63))
+
+
+def sw_pitch(th, tw, k):
+    """LDS row pitch (pixels) of a dwconv_sw halo plane: csrc/dwconv_sw.hip:sw_pitch (the fewest bank-slot collisions of a ds_read_b128 lane group)."""
+    rw, spr = tw + k - 1, tw // 4
+    nstrips = th * spr
+    best, bc = rw, 1 << 30
+    for p in range(rw, rw + 8):
+        c = 0
+        for g in _SW_GROUPS:
+            cnt = {}
+            for lane in g:
+                s_ = min(lane, nstrips - 1)
+                slot = ((s_ // spr) * p + 4 * (s_ % spr)) & 15
+                cnt[slot] = cnt.get(slot, 0) + 1
+            c += max(cnt.values())
+        if c < bc:
+            best, bc = p, c
+    return best
+
+
+def sw_plane_slots(th, tw, k):
+    """16-byte slots of one wave's halo plane (a multiple of 64: whole DMA rounds)."""
+    return -(-((th + k - 1) * sw_pitch(th, tw, k)) // 64) * 64
+
+
 class Plan:
     def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None, fuse_head=None):
         assert Hin % 32 == 0 and Win % 32 == 0, "image sides must be multiples of 32 (stride of P5)"
@@ -642,6 +670,30 @@ class Plan:
                                         timer.stop(stream.cuda_stream)
                                         ts.append(timer.elapsed_ms())
                                     results.append((min(ts), -2, tw, th * 256 + cb))
+                    if self.dtype == lib.F16:                            # a wave per 8-channel group, weights as scalar operands (csrc/dwconv_sw.hip): tile_p = -3, tile_c = columns, tile_k = rows * 256 + waves per workgroup
+                        w4 = -(-o.W // 4) * 4
+                        for th in sorted({4, 5, 8, 10, 16, 20, 32} | ({o.H} if o.H <= 40 else set())):
+                            if th > o.H:
+                                continue
+                            for tw in sorted({8, 16, 20, 32, 40, 80} | ({w4} if w4 <= 80 else set())):
+                                if tw > w4:
+                                    continue
+                                plane = sw_plane_slots(th, tw, o.ksize) * 16
+                                if plane > 20 * 1024:                    # fewer than 8 waves per CU: never the fastest
+                                    continue
+                                for nw in (4, 8):
+                                    if nw * plane > 160 * 1024:
+                                        continue
+                                    op = lib.MafOp.from_buffer_copy(o)
+                                    op.tile_p, op.tile_c, op.tile_k = -3, tw, th * 256 + nw
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    ts = []
+                                    for _ in range(reps):
+                                        timer.start(stream.cuda_stream)
+                                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                        timer.stop(stream.cuda_stream)
+                                        ts.append(timer.elapsed_ms())
+                                    results.append((min(ts), -3, tw, th * 256 + nw))
                     if self.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
                         op = lib.MafOp.from_buffer_copy(o)
                         op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
@@ -795,13 +847,15 @@ class Plan:
             if o.tile_k == 6:
                 return "conv3s2_lds_kernel<%d, %d, 4>" % (o.Cin, o.Cout)
             if o.tile_k == 7:
-                return "conv3s2_wreg_kernel<%d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout))
+                return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3,))
             if o.tile_k == 5:
                 return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
         if o.kind == lib.OP_DWCONV:
             if o.tile_p == -1:
                 return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
+            if o.tile_p == -3:
+                return "dwconv_sw_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -2:
                 return "dwconv_dot2_kernel<%d, 8, %d, %d>" % (o.ksize, 2 if (o.tile_k >> 8) % 2 == 0 else 1, o.act)
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)

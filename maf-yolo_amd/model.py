@@ -76,7 +76,7 @@ _VERSION = attrgetter("_version")
 
 
 class Model(nn.Module):
-    def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None):
+    def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None, dispatch="engine"):
         super().__init__()
         assert channels == 3, "MAF-YOLO takes 3-channel images"
         self.nodes, hcfg = _nodes_from_config(config, num_classes)
@@ -123,6 +123,8 @@ class Model(nn.Module):
         self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
+        assert dispatch in ("engine", "ops")
+        self.dispatch = dispatch              # "engine": one C call per forward (engine.py) | "ops": the graph op by op through torch.ops.mafyolo (ops_forward.py)
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -145,6 +147,7 @@ class Model(nn.Module):
         self._plans_version = None
         self._fp_tensors = None
         self._pack_plan = None                 # training: the staged weight transforms point at the old parameter storage
+        self._ops_weights = (None, None)
 
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .float() / .half()-style conversions replace buffers and parameter storage (yolo.py:211-215 moves
@@ -248,12 +251,37 @@ class Model(nn.Module):
             self._plans[key] = plan
         return plan
 
+    def traceable(self, dtype=torch.float16):
+        """The eval forward as a pure function of the image — `f(x) -> pred [B, A, 5 + nc]`, x [B, 3, H, W] of `dtype` on the HIP device — made of
+        torch.ops.mafyolo.* calls only (ops_forward.py), with the deploy-form weights of the CURRENT parameters captured: what
+        `torch.compile(f, fullgraph=True)` / `torch.export` trace (Model.forward itself does weight-version bookkeeping in plain Python)."""
+        from . import ops_forward, torch_ops
+        weights = ops_forward.deploy_weights(self, dtype)
+        ops = torch_ops.load()
+        strides = [float(s) for s in self.detect.stride.tolist()]
+
+        def f(x):
+            return ops_forward.forward(self, x, weights, ops, strides)[0]
+        return f
+
     def forward(self, x, val_loss=False, slot=0):
         if self.training:
             if x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
             heads = self._forward_train_form(x)
             return [self.detect(heads), list(heads)]
+        if getattr(self, "dispatch", "engine") == "ops" and not val_loss:
+            # the same graph as a sequence of torch.ops.mafyolo.* calls (ops_forward.py): what torch.compile / export can trace
+            from . import ops_forward
+            if not x.is_cuda:
+                raise lib.MafError("MAF-YOLO eval forward runs on the HIP device only: got a %s tensor (no CPU fallback)" % x.device)
+            dt = torch.float32 if (self.precision == "fp32" or (self.precision is None and x.dtype == torch.float32)) else torch.float16
+            ver = (self.weights_version(), dt)
+            if getattr(self, "_ops_weights", (None, None))[0] != ver:
+                self._ops_weights = (ver, ops_forward.deploy_weights(self, dt))
+            xin = (x.to(dt) / 255 if x.dtype == torch.uint8 else x.to(dt)).contiguous(memory_format=torch.channels_last)
+            pred, heads = ops_forward.forward(self, xin, self._ops_weights[1])
+            return [pred, [tuple(h) for h in heads]]
         plan = self.plan_for(x, head_feats=val_loss, slot=slot)
         x = x.contiguous()
         with torch.cuda.device(x.device):

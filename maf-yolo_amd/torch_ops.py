@@ -27,7 +27,7 @@ from . import lib
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = lib.ACT_NONE, lib.ACT_RELU, lib.ACT_SILU, lib.ACT_SIGMOID
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmafyolo_torch.so")
 OPS = ("conv1x1_bias_act", "conv3x3s2_bias_act", "dwconv_bias_act", "conv1x1_dgrad", "conv3x3s2_dgrad", "conv_wgrad", "dwconv_dgrad", "dwconv_wgrad",
-       "head_decode", "decode_nms")
+       "head_decode", "decode_nms", "mprep", "sppf", "bn_act", "bn_act_backward")
 _registered = False
 
 
@@ -84,6 +84,38 @@ def _register():
     @L.register_fake("mafyolo::decode_nms")
     def _(pred, conf_thres, iou_thres, agnostic, multi_label, max_det, classes):
         return pred.new_empty((pred.shape[0], max_det, 6), dtype=torch.float32), pred.new_empty((pred.shape[0],), dtype=torch.int32)
+
+    @L.register_fake("mafyolo::mprep")
+    def _(x, w1, b1, w3, b3):
+        return _cl(x, (x.shape[0], w1.shape[0] + w3.shape[0], x.shape[2] // 2, x.shape[3] // 2))
+
+    @L.register_fake("mafyolo::sppf")
+    def _(x, w1, b1, w2, b2):
+        return _cl(x, (x.shape[0], w2.shape[0], x.shape[2], x.shape[3]))
+
+    @L.register_fake("mafyolo::bn_act")
+    def _(x, gamma, beta, running_mean, running_var, eps, momentum, act):
+        c = x.shape[1]
+        st = lambda n: x.new_empty((n,), dtype=torch.float32)
+        return (torch.empty_like(x, memory_format=torch.channels_last), st(c), st(c), st(c if running_mean is not None else 0), st(c if running_var is not None else 0))
+
+    @L.register_fake("mafyolo::bn_act_backward")
+    def _(x, dz, gamma, beta, save_mean, save_rstd, act):
+        c = x.shape[1]
+        return torch.empty_like(x, memory_format=torch.channels_last), x.new_empty((c,), dtype=torch.float32), x.new_empty((c,), dtype=torch.float32)
+
+    # ---- BatchNorm(train) + activation: backward = the bn_act_backward op (recomputes the pre-activation from x and the saved statistics)
+    def _bn_setup(ctx, inputs, output):
+        x, gamma, beta, rm, rv, eps, momentum, act = inputs
+        ctx.save_for_backward(x, gamma, beta, output[1], output[2])
+        ctx.act = act
+
+    def _bn_bwd(ctx, dy, dmean, drstd, drm, drv):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dg, db = torch.ops.mafyolo.bn_act_backward(x, dy, gamma, beta, mean, rstd, ctx.act)
+        return dx, dg.to(gamma.dtype), db.to(beta.dtype), None, None, None, None, None
+
+    L.register_autograd("mafyolo::bn_act", _bn_bwd, setup_context=_bn_setup)
 
     # ---- autograd (act = NONE only: conv, BatchNorm and activation are separate layers of the train-form graph)
     ops = torch.ops.mafyolo
@@ -146,6 +178,17 @@ def load():
         _register()
         _registered = True
     return torch.ops.mafyolo
+
+
+def bn_act_(x, bn, act=ACT_NONE):
+    """act(bn(x)) for an nn.BatchNorm2d in training mode through torch.ops.mafyolo.bn_act (functional), with the module's running statistics and
+    batch counter updated like nn.BatchNorm2d does (Conv.forward, yolov6/layers/common.py:44-47)."""
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    y, _, _, nrm, nrv = load().bn_act(x, bn.weight, bn.bias, rm, rv, float(bn.eps), float(bn.momentum), int(act))
+    if rm is not None:
+        with torch.no_grad():
+            rm.copy_(nrm); rv.copy_(nrv); bn.num_batches_tracked.add_(1)
+    return y
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):

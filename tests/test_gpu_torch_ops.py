@@ -106,3 +106,80 @@ def test_head_decode_and_decode_nms_match_the_oracle_and_the_ctypes_path(ops):
         torch_ops.non_max_suppression(pred, 1.5, 0.65)
     with pytest.raises(RuntimeError):                         # the op itself reports bad thresholds as RuntimeError (TORCH_CHECK)
         ops.decode_nms(pred, 0.03, -0.1, False, False, 300, None)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.float16, 5e-3)])
+def test_mprep_and_sppf_ops(ops, dtype, tol):
+    """SURVEY.md 8(b) op list: MPRep (common.py:776-792) and SPPF (:114-129) in deploy form as single ops against their torch definitions."""
+    g = torch.Generator().manual_seed(21)
+    q = (lambda t: t.half().float()) if dtype == torch.float16 else (lambda t: t)
+    x = torch.randn(2, 48, 20, 24, generator=g).to(dtype)
+    w1, b1 = torch.randn(32, 48, 1, 1, generator=g) / 7, torch.randn(32, generator=g)
+    w3, b3 = torch.randn(32, 48, 3, 3, generator=g) / 20, torch.randn(32, generator=g)
+    xr = x.float()
+    ref = torch.cat([F.silu(F.conv2d(F.max_pool2d(xr, 2, 2), q(w1), b1)), F.relu(F.conv2d(xr, q(w3), b3, 2, 1))], 1)
+    got = ops.mprep(x.to(DEV), w1.to(DEV).to(dtype), b1.to(DEV), w3.to(DEV).to(dtype), b3.to(DEV))
+    assert got.shape == ref.shape and got.dtype == dtype and _rel(got, ref) < tol
+    v1, c1 = torch.randn(24, 48, 1, 1, generator=g) / 7, torch.randn(24, generator=g)
+    v2, c2 = torch.randn(64, 96, 1, 1, generator=g) / 10, torch.randn(64, generator=g)
+    y = F.silu(F.conv2d(xr, q(v1), c1))
+    if dtype == torch.float16:
+        y = y.half().float()                         # cv1's output is stored in fp16 before the pools and cv2 read it
+    y1 = F.max_pool2d(y, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    ref = F.silu(F.conv2d(torch.cat([y, y1, y2, y3], 1), q(v2), c2))
+    got = ops.sppf(x.to(DEV), v1.to(DEV).to(dtype), c1.to(DEV), v2.to(DEV).to(dtype), c2.to(DEV))
+    assert got.shape == ref.shape and _rel(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 1e-2)])
+@pytest.mark.parametrize("act,name", [(torch_ops.ACT_NONE, None), (torch_ops.ACT_SILU, "silu"), (torch_ops.ACT_RELU, "relu")])
+def test_bn_act_op_forward_backward(ops, dtype, tol, act, name):
+    """BatchNorm2d(train) + activation (Conv.forward, common.py:44-47) as an op with autograd: y, running statistics, dx, dgamma, dbeta vs torch."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 48, 9, 11, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(48, generator=g) + 0.5, torch.randn(48, generator=g)
+    dy = torch.randn(3, 48, 9, 11, generator=g)
+    bn = torch.nn.BatchNorm2d(48, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    yr = bn(xr)
+    yr = yr if name is None else (F.silu(yr) if name == "silu" else F.relu(yr))
+    yr.backward(dy)
+    xd = x.detach().to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).clone().requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(48, device=DEV), torch.ones(48, device=DEV)
+    y, mean, rstd, rm, rv = ops.bn_act(xd, gd, bd, rm, rv, 1e-3, 0.03, act)
+    y.backward(dy.to(DEV).to(dtype))
+    assert _rel(y, yr) < tol and _rel(xd.grad, xr.grad) < tol * 3
+    assert _rel(gd.grad, bn.weight.grad) < tol * 3 and _rel(bd.grad, bn.bias.grad) < tol * 3
+    assert _rel(rm, bn.running_mean) < 1e-3 and _rel(rv, bn.running_var) < 1e-3
+
+
+@pytest.mark.parametrize("scale", ["n", "s"])
+def test_model_dispatch_ops_equals_the_engine_and_traces(scale):
+    """`Model(dispatch="ops")`: the eval forward as a sequence of torch.ops.mafyolo.* calls (ops_forward.py) gives the engine's prediction (fp32: the
+    same kernels in the unfused plan; fp16: against the fused plan within the fp16 bars) and traces under torch.compile(fullgraph=True) through the
+    fake kernels — the dispatcher-visible form of the hot path."""
+    from maf_yolo_amd import synth
+    eng = M.Model(scale)
+    eng.load_state_dict(synth.synth_state_dict(eng, scale, 0))
+    eng = eng.to(DEV).eval()
+    opsm = M.Model(scale, dispatch="ops")
+    opsm.load_state_dict(eng.state_dict())
+    opsm = opsm.to(DEV).eval()
+    x = synth.synth_images(2, 128, seed=3).to(DEV)
+    with torch.no_grad():
+        ref = eng(x)[0]
+        got, heads = opsm(x)
+        assert got.shape == ref.shape and len(heads) == 3
+        d = (got - ref).abs()
+        assert d[..., :4].max() <= 1e-3 + 1e-5 * ref[..., :4].abs().max() and d[..., 4:].max() <= 2e-5, (d[..., :4].max(), d[..., 4:].max())
+        xh = x.half()
+        refh, goth = eng(xh)[0], opsm(xh)[0]
+        dh = (goth - refh).abs()
+        assert dh[..., :4].max() <= 1.0 and dh[..., 4:].max() <= 1e-2, (dh[..., :4].max(), dh[..., 4:].max())
+        f = opsm.traceable(torch.float32)
+        compiled = torch.compile(f, backend="eager", fullgraph=True)
+        xin = x.contiguous(memory_format=torch.channels_last)
+        assert torch.equal(compiled(xin), got) and torch.equal(f(xin), got)

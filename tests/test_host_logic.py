@@ -400,6 +400,28 @@ def test_torch_custom_op_library_loads_and_declares_the_ops(built):
         ops.conv1x1_bias_act(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1), None, 0)
 
 
+def test_model_dispatch_ops_traces_as_one_graph_without_a_device(built):
+    """VERDICT r2 task 8: `Model(dispatch="ops").traceable()` is ONE dynamo graph (fullgraph=True: no break) of torch.ops.mafyolo.* calls + cat / upsample,
+    traced through the fake kernels alone (meta tensors: nothing is computed here)."""
+    import maf_yolo_amd as M
+    m = M.Model("n", dispatch="ops").eval()
+    stride = m.detect.stride.clone()
+    m = m.to("meta")
+    m.detect.stride = stride
+    f = m.traceable(torch.float32)
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.append([str(nd.target) for nd in gm.graph.nodes if nd.op == "call_function"])
+        return gm.forward
+    y = torch.compile(f, backend=backend, fullgraph=True)(torch.empty(2, 3, 64, 64, device="meta").contiguous(memory_format=torch.channels_last))
+    assert y.shape == (2, 84, 85) and len(seen) == 1
+    ours = [t for t in seen[0] if "mafyolo" in t]
+    assert len(ours) == 85 and {t.split(".")[1] for t in ours} == {"conv3x3s2_bias_act", "conv1x1_bias_act", "dwconv_bias_act", "mprep", "sppf", "head_decode"}
+    rest = {t for t in seen[0] if "mafyolo" not in t}
+    assert all(("cat" in t) or ("interpolate" in t) or ("getitem" in t) for t in rest), rest
+
+
 def test_build_optimizer_groups_match_the_reference_counts():
     """yolov6/solver/build.py:12-33: BatchNorm weights (no decay), other weights (decay), biases (no decay).  The expected (count, elements) per
     group were read off the reference's own build_optimizer on its n / s / m models in the build container (same parameter names, same order)."""

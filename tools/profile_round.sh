@@ -10,11 +10,11 @@ TUNE=$OUT/tune.json
 rm -f $TUNE
 python bench.py --per-op --tune-file $TUNE --steps 100 --warmup 20 > $OUT/bench.json 2> $OUT/per_op.txt
 echo "bench rc=$?"; tail -c 400 $OUT/bench.json | head -c 400; echo
-python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_inflight1.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg > $OUT/bench_inflight1.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "rocprof stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --tune-file $TUNE --inflight 1 --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --tune-file $TUNE --inflight 1 --steps 3 --warmup 2 --no-cpu-baseline --no-train-leg > /dev/null 2> $OUT/pmc_$c.err
   echo "pmc $c rc=$?"
 done
 python bench.py --train --scale n --batch 32 --steps 20 --warmup 5 > $OUT/train_n.json 2> $OUT/train_n.err; echo "train n rc=$?"
@@ -27,7 +27,7 @@ done
 python bench.py --train --scale s --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_s.json 2>/dev/null; echo "train s rc=$?"
 python bench.py --train --scale m --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_m.json 2>/dev/null; echo "train m rc=$?"
 python bench.py --latency --scale m --tune-file $TUNE > $OUT/latency_m.json 2>/dev/null; echo "latency m rc=$?"
-for s in s m; do python bench.py --scale $s --steps 30 --warmup 10 --no-cpu-baseline --tune-file $OUT/tune_$s.json > $OUT/bench_$s.json 2>/dev/null; echo "bench $s rc=$?"; done
+for s in s m; do python bench.py --scale $s --steps 30 --warmup 10 --no-cpu-baseline --no-train-leg --tune-file $OUT/tune_$s.json > $OUT/bench_$s.json 2>/dev/null; echo "bench $s rc=$?"; done
 # PMC calibration (tools/pmc_calibrate.py): known byte counts per access shape, one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/cal/pmc_$c -o p -- python tools/pmc_calibrate.py run > /dev/null 2> $OUT/cal_$c.err
