@@ -34,7 +34,10 @@ enum { MAF_ACT_NONE = 0, MAF_ACT_RELU = 1, MAF_ACT_SILU = 2, MAF_ACT_SIGMOID = 3
 enum { MAF_SRC_DIRECT = 0,               /* source has the op's H x W grid                              */
        MAF_SRC_UP2 = 1,                  /* source is H/2 x W/2, read through nearest x2 upsample       */
        MAF_SRC_POOL2 = 2,                /* source is 2H x 2W, read through MaxPool2d(2,2)              */
-       MAF_SRC_SUB2 = 3 };               /* source is 2H x 2W, pixel (2y, 2x) is read: a 1x1 conv with stride 2 (RepVGGBlock.rbr_1x1)   */
+       MAF_SRC_SUB2 = 3,                 /* source is 2H x 2W, pixel (2y, 2x) is read: a 1x1 conv with stride 2 (RepVGGBlock.rbr_1x1)   */
+       MAF_SRC_PAIRS = 4 };              /* source has the op's grid, stored as PIXEL PAIRS: [B][H][W/2][stride][2] halfs, channel c of pixel x at
+                                            ((b H + y) W + (x & ~1)) stride + 2 (coff + c) + (x & 1) — what a CONV1X1 with out_pairs = 1 writes and a
+                                            DWCONV with tile_p = -4 reads (csrc/dwconv_p2.hip); fp16, even W, the buffer holds nothing else              */
 enum { MAF_OP_STEM = 0,                  /* RepVGGBlock L0 deploy form: 3x3 s2 conv on the NCHW image   */
        MAF_OP_CONV1X1 = 1,               /* Conv 1x1 (+bias+act) over up to 4 concatenated sources      */
        MAF_OP_CONV3X3S2 = 2,             /* RepVGGBlock / ConvWrapper 3x3 stride 2 pad 1 (+bias+act)    */
@@ -138,6 +141,8 @@ typedef struct {
     int32_t lane;                /* 0 = the caller's stream; 1..7 = engine-owned side streams                          */
     int32_t n_wait;              /* ops on OTHER lanes whose results this op reads (<= 8): indices into the op list     */
     int32_t wait[8];
+    int32_t out_pairs;           /* CONV1X1 (fp16, tile_k = 5): store the output as pixel pairs (MAF_SRC_PAIRS) for a depth-wise consumer */
+    int32_t reserved0;
 } maf_op_t;
 
 const char* maf_last_error(void);

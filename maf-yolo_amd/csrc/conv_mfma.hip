@@ -89,6 +89,9 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(!outf32 || var == VAR_DIRECT, "conv: out_f32 only for single direct source");
     a.act = op->act;
     MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv: bad act");
+    a.out_pairs = op->out_pairs;
+    MAF_REQUIRE(!op->out_pairs || (op->kind == MAF_OP_CONV1X1 && op->tile_k == 5 && !a.twin && a.M % 2 == 0 && op->W % 2 == 0 && op->out_coff % 4 == 0 && op->out_stride % 4 == 0),
+                "conv: out_pairs (pixel-pair output) is a tile_k = 5 conv1x1 option: even width, out_coff and out_stride multiples of 4");
     if (stream) {
         MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32 && var == VAR_DIRECT && a.nsrc == 1, "conv: tile_k = 3 is an fp16 single-direct-source 1x1 variant");
         return maf_conv1x1_stream(a, pt, ct, s);

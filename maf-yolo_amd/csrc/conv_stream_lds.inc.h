@@ -42,6 +42,32 @@ __device__ __forceinline__ void sl_store(const f32x4_t (&acc)[CT], int r, half_t
     }
 }
 
+// The same values as a PIXEL PAIR (MAF_SRC_PAIRS, ConvArgs.out_pairs): rows r0 and r0 + 1 of the accumulators are pixels 2q and 2q + 1; channel c of
+// the pair is the dword (y[2q][c], y[2q+1][c]) at half 2 (coff + c) of the pair's 2 x stride block — CT dwords, 16-byte stores where CT allows.
+template <int ACT, int CT>
+__device__ __forceinline__ void sl_store_pair(const f32x4_t (&acc)[CT], int r0, half_t* op, int nvalid, bool second) {
+    uint32_t w[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float lo = (MAF_KO & 16) ? acc[ct][r0] : maf_act<ACT>(acc[ct][r0]);
+        const float hi = second ? ((MAF_KO & 16) ? acc[ct][r0 + 1] : maf_act<ACT>(acc[ct][r0 + 1])) : 0.f;
+        const half2_t h = {(half_t)lo, (half_t)hi};
+        w[ct] = __builtin_bit_cast(uint32_t, h);
+    }
+    uint32_t* o = reinterpret_cast<uint32_t*>(op);
+    if (nvalid >= CT) {
+        if (CT == 8) { *reinterpret_cast<u32x4_t*>(o) = (u32x4_t){w[0], w[1], w[2 % CT], w[3 % CT]}; *reinterpret_cast<u32x4_t*>(o + 4) = (u32x4_t){w[4 % CT], w[5 % CT], w[6 % CT], w[7 % CT]}; }
+        else if (CT == 6) {                                               // 24 bytes per lane: 8-byte aligned only
+            *reinterpret_cast<u32x2_t*>(o) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<u32x2_t*>(o + 2) = (u32x2_t){w[2 % CT], w[3 % CT]}; *reinterpret_cast<u32x2_t*>(o + 4) = (u32x2_t){w[4 % CT], w[5 % CT]};
+        } else if (CT == 4) *reinterpret_cast<u32x4_t*>(o) = (u32x4_t){w[0], w[1], w[2 % CT], w[3 % CT]};
+        else *reinterpret_cast<u32x2_t*>(o) = (u32x2_t){w[0], w[1 % CT]};
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct < nvalid) o[ct] = w[ct];
+    }
+}
+
 template <int CT, int KS, bool MULTI>
 __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs a) {
     typedef Frag<half_t> F;
@@ -148,6 +174,21 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
                 acc[ct] = F::mma(af[ks], __builtin_bit_cast(frag_t, wr[sl]), acc[ct]);
                 __builtin_amdgcn_sched_barrier(0);                      // keep the issue order as written
             });
+        }
+        if (a.out_pairs) {                                                // pixel pairs for a depth-wise consumer (csrc/dwconv_p2.hip); M is even
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += 2) {
+                const int m = t * 16 + g * 4 + r0;
+                if (m >= a.M) continue;
+                if ((MAF_KO & 4) && acc[0][r0] != 12345.678f) continue;
+                half_t* op = static_cast<half_t*>(a.out) + (size_t)m * a.out_stride + (size_t)(a.out_coff + cl) * 2;
+                const bool second = m + 1 < a.M;
+                if (act == MAF_ACT_SILU) sl_store_pair<MAF_ACT_SILU, CT>(acc, r0, op, nvalid, second);
+                else if (act == MAF_ACT_NONE) sl_store_pair<MAF_ACT_NONE, CT>(acc, r0, op, nvalid, second);
+                else if (act == MAF_ACT_RELU) sl_store_pair<MAF_ACT_RELU, CT>(acc, r0, op, nvalid, second);
+                else sl_store_pair<MAF_ACT_SIGMOID, CT>(acc, r0, op, nvalid, second);
+            }
+            return;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

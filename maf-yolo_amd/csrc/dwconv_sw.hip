@@ -24,7 +24,7 @@
 #include "lds_pipe.h"
 
 #ifndef MAF_KO
-#define MAF_KO 0            // profiling builds (make ko): 32 = no multiply-add loop, 64 = no halo gather, 128 = no output stores
+#define MAF_KO 0            // profiling builds (make ko): 32 = no multiply-add loop, 64 = no halo gather, 128 = no output stores, 256 = no LDS reads, 512 = one weight vector for all taps
 #endif
 
 namespace {
@@ -120,10 +120,13 @@ __global__ __launch_bounds__(512) void dwconv_sw_kernel(const DwsArgs a) {
             for (int ky = 0; ky < K; ++ky) {
                 u32x4_t wk[K];
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) wk[kx] = wp[(ky * K + kx) * C8];
+                for (int kx = 0; kx < K; ++kx) wk[kx] = wp[(MAF_KO & 512) ? 0 : (ky * K + kx) * C8];
                 u32x4_t x[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>((uintptr_t)(row + i * 16));
+                for (int i = 0; i < NX; ++i) {
+                    if (MAF_KO & 256) x[i] = u32x4_t{row, row + (uint32_t)i, row, row};
+                    else x[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>((uintptr_t)(row + i * 16));
+                }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
 #pragma unroll

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(float* out, int iters, 
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.5f + 0.001f * (float)(threadIdx.x + j);
+    const uint32_t sw = 0x2c002800u + (uint32_t)(iters & 1);                         // wave-uniform, not a literal: lives in a scalar register
     const long long t0 = clock64();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -64,8 +65,15 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(float* out, int iters, 
                 f2 x = {v[j], v[(j + 1) & 7]};
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"((f2){0.999f, 0.999f}), "v"((f2){0.001f, 0.001f}));
                 v[j] = x[0];
-            } else {                                                                 // KIND 8: v_dot2c_f32_f16 (accumulates in place)
+            } else if (KIND == 8) {                                                  // v_dot2c_f32_f16 (accumulates in place)
                 asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[j]) : "v"(0x38003c00u + (uint32_t)j), "v"(0x2c002800u));
+            } else if (KIND == 9) {                                                  // v_fma_mix_f32 with a SCALAR-register operand (csrc/dwconv_sw.hip)
+                const uint32_t a = 0x38003c00u + (uint32_t)j;
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(v[j]) : "v"(a), "s"(sw + j));
+            } else if (KIND == 10) {                                                 // v_fma_f32 with a scalar-register operand
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "s"(__builtin_bit_cast(float, 0x3f7fbe77u + (sw & 1u))), "v"(0.001f));
+            } else {                                                                 // KIND 11: v_dot2c_f32_f16 with a scalar-register operand
+                asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[j]) : "s"(sw + j), "v"(0x38003c00u + (uint32_t)j));
             }
         }
     }
@@ -80,14 +88,19 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(float* out, int iters, 
 
 // -> shader clocks for `iters` iterations of 8 instructions (KIND 0) / 8 x (instruction + 1 full-rate op) (1, 2) / 8 SiLUs (3), measured on
 // workgroup 0 with `wgs_per_cu` workgroups of 256 threads on every CU (1 -> one wave per SIMD, 2 -> two ...)
-extern "C" int maf_probe_valu(void* stream, int kind, int iters, int wgs_per_cu, long long* host_cycles) {
+extern "C" int maf_probe_valu_ms(void* stream, int kind, int iters, int wgs_per_cu, long long* host_cycles, float* ms) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* out = nullptr; long long* cyc = nullptr;
     const int blocks = 256 * wgs_per_cu;
     int rc = maf_check_hip(hipMalloc(&out, (size_t)blocks * 256 * 4), "hipMalloc");
     if (!rc) rc = maf_check_hip(hipMalloc(&cyc, 8), "hipMalloc");
     if (rc) return rc;
+    hipEvent_t e0, e1;
+    rc = maf_check_hip(hipEventCreate(&e0), "hipEventCreate");
+    if (!rc) rc = maf_check_hip(hipEventCreate(&e1), "hipEventCreate");
+    if (rc) return rc;
     for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) (void)hipEventRecord(e0, s);
         switch (kind) {
             case 0: hipLaunchKernelGGL(valu_probe_kernel<0>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
             case 1: hipLaunchKernelGGL(valu_probe_kernel<1>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
@@ -97,13 +110,23 @@ extern "C" int maf_probe_valu(void* stream, int kind, int iters, int wgs_per_cu,
             case 5: hipLaunchKernelGGL(valu_probe_kernel<5>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
             case 6: hipLaunchKernelGGL(valu_probe_kernel<6>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
             case 7: hipLaunchKernelGGL(valu_probe_kernel<7>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
-            default: hipLaunchKernelGGL(valu_probe_kernel<8>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            case 8: hipLaunchKernelGGL(valu_probe_kernel<8>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            case 9: hipLaunchKernelGGL(valu_probe_kernel<9>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            case 10: hipLaunchKernelGGL(valu_probe_kernel<10>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
+            default: hipLaunchKernelGGL(valu_probe_kernel<11>, dim3(blocks), dim3(256), 0, s, out, iters, cyc); break;
         }
     }
+    (void)hipEventRecord(e1, s);
     rc = maf_check_hip(hipStreamSynchronize(s), "sync");
+    if (!rc && ms) rc = maf_check_hip(hipEventElapsedTime(ms, e0, e1), "hipEventElapsedTime");      // the second launch alone
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (!rc) rc = maf_check_hip(hipMemcpy(host_cycles, cyc, 8, hipMemcpyDeviceToHost), "memcpy");
     (void)hipFree(out); (void)hipFree(cyc);
     return rc;
+}
+
+extern "C" int maf_probe_valu(void* stream, int kind, int iters, int wgs_per_cu, long long* host_cycles) {
+    return maf_probe_valu_ms(stream, kind, iters, wgs_per_cu, host_cycles, nullptr);
 }
 
 // ds_read_b64_tr_b16 semantics probe (tools/tr_probe.py): LDS half i holds the value i; lane l reads at byte address addr[l];

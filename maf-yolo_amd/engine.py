@@ -124,6 +124,27 @@ def sw_pitch(th, tw, k):
     return best
 
 
+def p2_wave_bytes(th, tw, k):
+    """LDS bytes of one wave of dwconv_p2 (two planes of 16-byte pair slots, whole DMA rounds): csrc/dwconv_p2.hip:p2_pitch / maf_launch_dwconv_p2."""
+    p_ = k // 2
+    pe = p_ + (p_ & 1)
+    rwp, spr = tw // 2 + pe, tw // 4
+    nstrips = th * spr
+    best, bc = rwp, 1 << 30
+    for pitch in range(rwp, rwp + 8):
+        c = 0
+        for g in _SW_GROUPS:
+            cnt = {}
+            for lane in g:
+                s_ = min(lane, nstrips - 1)
+                slot = ((s_ // spr) * pitch + 2 * (s_ % spr)) & 15
+                cnt[slot] = cnt.get(slot, 0) + 1
+            c += max(cnt.values())
+        if c < bc:
+            best, bc = pitch, c
+    return -(-(2 * (th + k - 1) * best) // 64) * 1024
+
+
 def sw_plane_slots(th, tw, k):
     """16-byte slots of one wave's halo plane (a multiple of 64: whole DMA rounds)."""
     return -(-((th + k - 1) * sw_pitch(th, tw, k)) // 64) * 64
@@ -232,7 +253,8 @@ class Plan:
         self._ops.append(dict(kind=lib.OP_DWCONV, name=name, act=act, H=src.H, W=src.W, Cin=src.C, Cout=src.C, ksize=w.shape[-1],
                               segs=src.segs, out=out, out_coff=0, w=self._wput(pack.pack_dw(w, self.dtype)),
                               b=self._wput(b.float().cpu()),
-                              aux=[self._wput(pack.pack_dw_toeplitz(w))] if self.dtype == lib.F16 else []))   # operand of the matrix-core variant
+                              # operands of the matrix-core variant (aux[0]) and of the pixel-pair variant (aux[1]: csrc/dwconv_p2.hip)
+                              aux=[self._wput(pack.pack_dw_toeplitz(w)), self._wput(pack.pack_dw_pairs(w)) if src.C % 8 == 0 else None] if self.dtype == lib.F16 else []))
 
     # ---------------------------------------------------------------- graph walk
     def _build(self, model):
@@ -391,7 +413,8 @@ class Plan:
                     u = self._alloc(x.H, x.W, 2 * c)
                     self._ops.append(dict(kind=lib.OP_DWCONV, name=p + ".cls_reg_conv", act=lib.ACT_NONE, H=x.H, W=x.W, Cin=c, Cout=2 * c, ksize=wc.shape[-1],
                                           segs=tv.segs, out=u, out_coff=0, w=self._wput(pack.pack_dw(torch.cat([wc, wr], 0), self.dtype)),
-                                          b=self._wput(torch.cat([bc, brg], 0).float().cpu()), aux=[]))
+                                          b=self._wput(torch.cat([bc, brg], 0).float().cpu()),
+                                          aux=[None, self._wput(pack.pack_dw_pairs(torch.cat([wc, wr], 0)))] if self.dtype == lib.F16 and c % 8 == 0 else []))
                     us = [(u, 0), (u, c)]
                     recs = [pack.pack_head_tail(*getattr(m, br + "_conv_s").fused(), pr.weight.detach(), pr.bias.detach())
                             for br, pr in (("cls", m.cls_pred), ("reg", m.reg_pred))]
@@ -518,7 +541,8 @@ class Plan:
             if r["kind"] == lib.OP_BOTTLENECK:
                 o.tile_k = r["tk"]
             for k_, off in enumerate(r.get("aux", [])):
-                o.aux[k_] = wbase + off
+                if off is not None:
+                    o.aux[k_] = wbase + off
             if "twin" in r:                                   # second conv of a twin launch: {src, w, bias, out}
                 tw = r["twin"]
                 o.aux[0], o.aux[1], o.aux[2], o.aux[3] = abase + tw["seg"].buf.off, wbase + tw["w"], wbase + tw["b"], abase + tw["out"].off
@@ -549,6 +573,23 @@ class Plan:
         h = C.c_void_p()
         lib.check(lib.load().maf_engine_create(ops, len(self._ops), C.byref(h)))
         self._engine = h
+
+    def _pairs_producer(self, i):
+        """The op that may hand op i (a depth-wise conv) its input as PIXEL PAIRS (lib.SRC_PAIRS, csrc/dwconv_p2.hip), or None: the 1x1 conv right in front
+        of it, running as conv1x1_stream_lds (the variant with the pair epilogue), writing exactly the buffer op i reads — and nobody else reads it."""
+        o = self.ops[i]
+        if i == 0 or self.dtype != lib.F16 or o.kind != lib.OP_DWCONV or not o.aux[1] or o.W % 2 or o.Cin % 8 or o.nsrc != 1 or o.src[0].mode not in (lib.SRC_DIRECT, lib.SRC_PAIRS):
+            return None
+        p = self.ops[i - 1]
+        if p.kind != lib.OP_CONV1X1 or p.tile_k != 5 or p.out_f32 or "twin" in self._ops[i - 1] or p.out != o.src[0].ptr or p.out_coff or o.src[0].coff \
+                or p.Cout != o.Cin or p.out_stride != o.src[0].stride or p.out_stride % 4 or (p.B, p.H, p.W) != (o.B, o.H, o.W):
+            return None
+        for j, q in enumerate(self.ops):                                    # any other reader (or writer) of the buffer keeps it NHWC
+            if j in (i, i - 1):
+                continue
+            if q.out == p.out or any(q.src[k].ptr == p.out for k in range(q.nsrc)) or any(q.aux[k] == p.out for k in range(4)):
+                return None
+        return p
 
     # ---------------------------------------------------------------- tile autotuning
     def autotune(self, x, reps=5, verbose=False):
@@ -694,6 +735,29 @@ class Plan:
                                         timer.stop(stream.cuda_stream)
                                         ts.append(timer.elapsed_ms())
                                     results.append((min(ts), -3, tw, th * 256 + nw))
+                    if self._pairs_producer(i) is not None:              # pixel-pair input, v_dot2c with scalar weight pairs (csrc/dwconv_p2.hip): tile_p = -4, tile_c = columns, tile_k = rows * 256 + waves per workgroup
+                        w4 = -(-o.W // 4) * 4
+                        for th in sorted({4, 5, 8, 10, 16, 20} | ({o.H} if o.H <= 40 else set())):
+                            if th > o.H:
+                                continue
+                            for tw in sorted({16, 20, 32, 40, 80} | ({w4} if w4 <= 80 else set())):
+                                if tw > w4:
+                                    continue
+                                plane = p2_wave_bytes(th, tw, o.ksize)
+                                if plane > 20 * 1024:                    # fewer than 8 waves per CU: never the fastest
+                                    continue
+                                for nw in (2, 4, 8):
+                                    op = lib.MafOp.from_buffer_copy(o)
+                                    op.tile_p, op.tile_c, op.tile_k = -4, tw, th * 256 + nw
+                                    op.src[0].mode = lib.SRC_PAIRS       # (the NHWC content of the buffer read as pairs: same work)
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    ts = []
+                                    for _ in range(reps):
+                                        timer.start(stream.cuda_stream)
+                                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                        timer.stop(stream.cuda_stream)
+                                        ts.append(timer.elapsed_ms())
+                                    results.append((min(ts), -4, tw, th * 256 + nw))
                     if self.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
                         op = lib.MafOp.from_buffer_copy(o)
                         op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
@@ -708,10 +772,18 @@ class Plan:
                     results.sort()
                     best = results[0][1:]
                     _TUNE_CACHE[sig] = best
+                    _TUNE_CACHE[sig + ("nhwc",)] = [r_ for r_ in results if r_[1] != -4][0][1:]      # for a plan whose producer cannot store pixel pairs
                     if verbose:
                         print("tune %-32s %dx%d C=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d,%d)%.1fus" % (a, b2, c2, t * 1e3) for t, a, b2, c2 in results[:6])))
-                if tuple(best) != (o.tile_p, o.tile_c, o.tile_k):
+                prod = self._pairs_producer(i)
+                if best[0] == -4 and prod is None:
+                    best = _TUNE_CACHE.get(sig + ("nhwc",), (0, 0, 0))
+                pairs = 1 if best[0] == -4 else 0
+                if tuple(best) != (o.tile_p, o.tile_c, o.tile_k) or (prod is not None and prod.out_pairs != pairs):
                     o.tile_p, o.tile_c, o.tile_k = best
+                    o.src[0].mode = lib.SRC_PAIRS if pairs else lib.SRC_DIRECT
+                    if prod is not None:
+                        prod.out_pairs = pairs                           # the 1x1 conv in front stores what this kernel reads
                     changed += 1
                 continue
             if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
@@ -854,6 +926,8 @@ class Plan:
         if o.kind == lib.OP_DWCONV:
             if o.tile_p == -1:
                 return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
+            if o.tile_p == -4:
+                return "dwconv_p2_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -3:
                 return "dwconv_sw_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -2:

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("MAF_HIP_LIB") or os.path.join(_HERE, "libmafyolo_hip.
 F16, F32, U8 = 0, 1, 2
 NMS_FLOAT_THRESHOLD = 1
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
-SRC_DIRECT, SRC_UP2, SRC_POOL2, SRC_SUB2 = 0, 1, 2, 3
+SRC_DIRECT, SRC_UP2, SRC_POOL2, SRC_SUB2, SRC_PAIRS = 0, 1, 2, 3, 4
 OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE, OP_BOTTLENECK, OP_CONV1DW, OP_HEADTAIL, OP_STEM2, OP_CONV3X3S2_DGRAD = range(11)
 
 
@@ -34,7 +34,8 @@ class MafOp(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("reg", C.c_void_p * 3), ("lvl_h", C.c_int32 * 3), ("lvl_w", C.c_int32 * 3),
                 ("reg_stride", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("lvl_stride", C.c_float * 3),
-                ("aux", C.c_void_p * 4), ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait", C.c_int32 * 8)]
+                ("aux", C.c_void_p * 4), ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait", C.c_int32 * 8),
+                ("out_pairs", C.c_int32), ("reserved0", C.c_int32)]
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",

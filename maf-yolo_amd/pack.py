@@ -89,6 +89,31 @@ def pack_dw(w, dtype):
     return w.float().cpu().reshape(c, k * k).t().contiguous().to(torch.float16 if dtype == lib.F16 else torch.float32)
 
 
+def pack_dw_pairs(w):
+    """w [C, 1, k, k] (C a multiple of 8) -> the weight pairs of csrc/dwconv_p2.hip, fp16 [C/8, k, 2 (half group h), 2 (set), (k+1)/2 (m), 4 (d), 2]:
+    for channel 8 g + 4 h + d and kernel row ky, the EVEN set entry m = (w[ky][2m], w[ky][2m+1]), the ODD set entry m = (w[ky][2m-1], w[ky][2m]);
+    taps outside 0..k-1 are zeros.  One dword per pair (low half = the tap of the even pixel of an input pixel pair)."""
+    c, _, k, _ = w.shape
+    assert c % 8 == 0
+    npair = (k + 1) // 2
+    wd = w.float().cpu().reshape(c // 8, 2, 4, k, k)                       # [g, h, d, ky, kx]
+    wz = torch.zeros(c // 8, 2, 4, k, k + 3)
+    wz[..., 1:k + 1] = wd                                                  # wz[..., u + 1] = w[..., u], zeros at u = -1, k, k + 1
+    out = torch.zeros(c // 8, k, 2, 2, npair, 4, 2)
+    for m in range(npair):
+        for st, u0 in ((0, 2 * m), (1, 2 * m - 1)):
+            out[:, :, :, st, m, :, 0] = wz[..., u0 + 1].permute(0, 3, 1, 2)          # [g, ky, h, d]
+            out[:, :, :, st, m, :, 1] = wz[..., u0 + 2].permute(0, 3, 1, 2)
+    return out.to(torch.float16).contiguous()
+
+
+def pairs_from_nhwc(x):
+    """[B, H, W, C] (W even) -> the pixel-pair layout [B, H, W/2, C, 2] (MAF_SRC_PAIRS): what a CONV1X1 with out_pairs = 1 writes."""
+    b, h, w_, c = x.shape
+    assert w_ % 2 == 0
+    return x.reshape(b, h, w_ // 2, 2, c).transpose(3, 4).contiguous()
+
+
 def pack_conv1dw(w1, b1, wdw, bdw):
     """Operands of MAF_OP_CONV1DW (csrc/conv1dw.hip), fp16: one record per 32 mid channels, in the order the kernel copies it to
     LDS: W1 fragments [2, S1, 64, 8] | b1 [32] f32 | Toeplitz table [8, k, parts, 16, 8] | bdw [32] f32.

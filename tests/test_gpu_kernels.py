@@ -201,6 +201,17 @@ def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     _launch(op)
     _check(out[..., 8:], ref, dt)
     assert (out[..., :8] == 5).all()
+    # the same conv storing PIXEL PAIRS (out_pairs: the layout csrc/dwconv_p2.hip reads): the same values, [B, H, W/2, stride, 2], a slice of a wider pair buffer
+    outp = torch.full((B, H, W // 2, (cout + 8) * 2), 5.0, dtype=DT[dt], device=DEV)
+    op2 = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, outp, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 1, ct)
+    op2.tile_k, op2.out_pairs = 5, 1
+    _launch(op2)
+    got, want = outp[..., 16:].reshape(B, H, W // 2, cout, 2).float(), pack.pairs_from_nhwc(out[..., 8:].contiguous()).float()
+    # the same accumulators through a differently scheduled epilogue: equal up to one fp16 rounding of the activation on a handful of values
+    assert (got - want).abs().max() <= 1e-3 * want.abs().max() and (got != want).float().mean() < 1e-3
+    assert (outp[..., :16] == 5).all()
+    op2.tile_k = 1
+    assert lib.load().maf_op_launch(C.byref(op2), torch.cuda.current_stream().cuda_stream) != 0       # only the tile_k = 5 epilogue knows the layout
 
 
 def test_conv1x1_out_f32():
@@ -421,6 +432,48 @@ def test_dwconv_scalar_weight_variant(k, C_, H, W, th, tw, nw, two):
             assert (out[..., :8] == 3).all()
             outs.append(out[..., 8:].float())
         assert (outs[0] - outs[1]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
+
+
+@pytest.mark.parametrize("k,C_,H,W,th,tw,nw", [(9, 576, 20, 20, 20, 20, 8), (9, 40, 20, 20, 10, 20, 4), (7, 72, 21, 26, 8, 16, 8), (5, 64, 33, 16, 16, 16, 4),
+                                               (3, 24, 16, 40, 4, 40, 1), (9, 192, 9, 12, 3, 8, 3), (5, 128, 80, 80, 16, 16, 8), (7, 288, 40, 40, 5, 40, 4),
+                                               (5, 128, 80, 80, 4, 80, 8), (3, 16, 6, 10, 8, 12, 2)])
+@pytest.mark.parametrize("two", [False, True])
+def test_dwconv_pixel_pair_variant(k, C_, H, W, th, tw, nw, two):
+    """tile_p = -4 (csrc/dwconv_p2.hip): input stored as pixel pairs (MAF_SRC_PAIRS, pack.pairs_from_nhwc), v_dot2c with the even / odd weight-pair
+    sets as scalar operands (pack.pack_dw_pairs), halo planes by DMA; all four kernel sizes (P even and odd: aligned and shifted windows), tiles
+    hanging over the map, ragged last pass, workgroups that are not full, a slice of a wider pair buffer, two filters per input channel from one
+    gather; against F.conv2d in fp32 on the same fp16 operands and against the v_fma_mix kernel on the NHWC form of the same tensor."""
+    g = torch.Generator().manual_seed(500 + k + C_)
+    B, dt = 2, lib.F16
+    cout = 2 * C_ if two else C_
+    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, 1, k, k, generator=g) / k, dt)
+    bias = torch.randn(cout, generator=g)
+    xs = torch.zeros(B, H, W, C_ + 16, dtype=torch.float16, device=DEV)
+    xs[..., 8:8 + C_] = _nhwc(x, dt)
+    xp = torch.full((B, H, W // 2, (C_ + 16) * 2), 7.0, dtype=torch.float16, device=DEV)           # pair buffer of stride C_ + 16, slice at channel 8
+    xp[..., 16:16 + 2 * C_] = pack.pairs_from_nhwc(_nhwc(x, dt)).reshape(B, H, W // 2, 2 * C_)
+    wpairs = pack.pack_dw_pairs(w).to(DEV)
+    xin = torch.cat([x, x], 1) if two else x
+    for act in (lib.ACT_SILU, lib.ACT_NONE):
+        ref = _act(F.conv2d(xin, w, bias, 1, k // 2, 1, cout), act)
+        outs = []
+        for tp in (-4, 0):
+            out = torch.full((B, H, W, cout + 8), 3.0, dtype=torch.float16, device=DEV)
+            op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, act, [(xp if tp else xs, C_, C_ + 16, 8, lib.SRC_PAIRS if tp else 0)], out, cout + 8, 8,
+                          pack.pack_dw(w, dt).to(DEV), bias.to(DEV), tp, tw if tp else 0)
+            op.ksize = k
+            op.tile_k = th * 256 + nw if tp else 0
+            if tp:
+                op.aux[1] = wpairs.data_ptr()
+            _launch(op)
+            _check(out[..., 8:], ref, dt)
+            assert (out[..., :8] == 3).all()
+            outs.append(out[..., 8:].float())
+        assert (outs[0] - outs[1]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
+    bad = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, 0, [(xp, C_, C_ + 16, 8, lib.SRC_PAIRS)], out, cout + 8, 8, pack.pack_dw(w, dt).to(DEV), bias.to(DEV), 0, 0)
+    bad.ksize = k
+    assert lib.load().maf_op_launch(C.byref(bad), torch.cuda.current_stream().cuda_stream) != 0      # a pair source with any other variant is refused
 
 
 @pytest.mark.parametrize("k,C_,H,W", [(7, 72, 21, 27), (9, 40, 20, 20), (5, 64, 33, 16), (3, 24, 16, 40), (9, 192, 9, 11)])

@@ -31,7 +31,13 @@ for name, cands in specs:
         for pt, ct, tk in cands:
             op = lib.MafOp.from_buffer_copy(o)
             op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
-            ops.append((pt, ct, tk, op, None))
+            keep = None
+            if pt == -4:                                # pixel-pair input (csrc/dwconv_p2.hip): the NHWC content of the buffer read as pairs times the same
+                kk = o.ksize * o.ksize
+                wkc = plan.weights[r["w"]:r["w"] + kk * o.Cout * 2].view(torch.float16).reshape(kk, o.Cout)
+                keep = pack.pack_dw_pairs(wkc.t().reshape(o.Cout, 1, o.ksize, o.ksize).float().cpu()).cuda()
+                op.src[0].mode, op.aux[1] = lib.SRC_PAIRS, keep.data_ptr()
+            ops.append((pt, ct, tk, op, keep))
         cands = []
     else:
         w, b, srcC = r["raw"]
