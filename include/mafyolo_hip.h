@@ -88,7 +88,15 @@ typedef struct {
  *                   w = [k*k][C] of the activation dtype.  tile_p / tile_c / tile_k optionally fix the workgroup tile
  *                   (rows, cols, channels per block); 0 = built-in cost model.  tile_p = -1 (fp16) selects the matrix-core
  *                   variant (csrc/dwconv_mfma.hip), whose operand is aux[0] = the Toeplitz table [C/32][8][k][parts][16][8] f16
- *                   (maf-yolo_amd/pack.py:pack_dw_toeplitz).
+ *                   (maf-yolo_amd/pack.py:pack_dw_toeplitz).  The other fp16 variants (same result, same operands unless noted):
+ *                   tile_p = -2  v_dot2_f32_f16 over tap pairs of a pair-interleaved halo tile (csrc/dwconv_dot2.hip): tile_c = tile columns
+ *                                (multiple of 8), tile_k = tile rows * 256 + channels per block (multiple of 8, <= 64);
+ *                   tile_p = -3  a wave per 8-channel group, halo plane by DMA, weights as scalar operands of v_fma_mix_f32 (csrc/dwconv_sw.hip):
+ *                                tile_c = tile columns (multiple of 4), tile_k = tile rows * 256 + waves per workgroup (1..8);
+ *                   tile_p = -4  the same work split on v_dot2c_f32_f16 with scalar weight PAIRS over an input stored as pixel pairs
+ *                                (csrc/dwconv_p2.hip): src[0].mode = MAF_SRC_PAIRS (written by the CONV1X1 in front with out_pairs = 1), even W,
+ *                                aux[1] = weight pairs [C/8][k][2][2][(k+1)/2][4] dwords (pack.py:pack_dw_pairs); tile_c / tile_k as for -3.
+ *                   Cout = 2 Cin runs two filters per input channel (output channel c reads input channel c mod Cin: the head's cls / reg pair).
  * MAF_OP_SPPF_POOL  replaces SPPF.m x3 (common.py:121-129): src[0] = x (slice 0 of the 4c_ buffer),
  *                   out/out_coff = slice 1; slices 2 and 3 follow at +C each.
  * MAF_OP_BOTTLENECK replaces one DepthBottleneckUni in deploy form (common.py:918-927: 1x1 c->3c + SiLU, depth-wise k x k + SiLU,
