@@ -202,10 +202,14 @@ void maf_engine_destroy(maf_engine_t* e);
  * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
  * break (nms.py:101-103) is dropped.  max_det <= 1024.
  */
-enum { MAF_NMS_FLOAT_THRESHOLD = 1 };    /* maf_nms_ex flags: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`),
+enum { MAF_NMS_FLOAT_THRESHOLD = 1, MAF_NMS_SINGLE_LAUNCH = 2 };    /* maf_nms_ex flags.  MAF_NMS_FLOAT_THRESHOLD: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`),
                                           * which is what yolov6/utils/nms.py:96 reaches when the reference runs on a GPU — instead of with the double
                                           * (its CPU kernel, the default here and the rule of the oracle and of the golden fixtures).  The results differ
-                                          * only for a pair whose fp32 IoU equals fl32(iou_thres) exactly where fl32(iou_thres) > iou_thres (0.6, 0.7, ...). */
+                                          * only for a pair whose fp32 IoU equals fl32(iou_thres) exactly where fl32(iou_thres) > iou_thres (0.6, 0.7, ...).
+                                          * MAF_NMS_SINGLE_LAUNCH: the whole call is ONE kernel (csrc/nms.hip:nms_single_kernel: every workgroup collects
+                                          * candidates, the last one to finish an image sorts and selects them) instead of seven; same results bit for bit.
+                                          * Measured on configs[4] (m, bs 1): 0.29 ms against 0.20 ms for the seven launches (whose pair-matrix kernels use
+                                          * the whole chip) — available, not the default. */
 int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc);
 int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
             const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,

@@ -91,7 +91,7 @@ __device__ __forceinline__ bool multi_ok(const NmsArgs& a, const float* pred, un
 // ballots, reserves the output range with ONE atomicAdd per chunk (a per-wave atomic per hit costs ~10 ns each on one contended line —
 // 64k of them were 0.65 ms) and writes the keys from the registers.  Candidate order inside the list is irrelevant: the sort key carries
 // the flat index.
-__global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a) {
+__device__ __forceinline__ void nms_collect_multi_body(const NmsArgs& a) {
     __shared__ int wave_cnt[4];
     __shared__ int s_base;
     const int b = blockIdx.y;
@@ -148,8 +148,10 @@ __global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void nms_collect_multi_kernel(const NmsArgs a) { nms_collect_multi_body(a); }
+
 // best-class mode: 16 lanes per box (4 boxes per wavefront), arg-max by shuffles within the 16-lane group.
-__global__ __launch_bounds__(256) void nms_collect_best_kernel(const NmsArgs a) {
+__device__ __forceinline__ void nms_collect_best_body(const NmsArgs& a) {
     const int b = blockIdx.y;
     const int sub = threadIdx.x & 15;
     const int no = 5 + a.nc;
@@ -178,6 +180,8 @@ __global__ __launch_bounds__(256) void nms_collect_best_kernel(const NmsArgs a) 
         }
     }
 }
+
+__global__ __launch_bounds__(256) void nms_collect_best_kernel(const NmsArgs a) { nms_collect_best_body(a); }
 
 struct alignas(16) Cand { float x1, y1, x2, y2, area, score; unsigned int flat, pad; };   // 32 B: two ds_read_b128
 
@@ -258,7 +262,7 @@ __device__ unsigned long long g_nms_dbg[8];   // phase cycle stamps of image 0 (
 // (nms.py:94-95) a box of class c sits at x + c*4096, so that holds whenever the x-extent of ALL candidates of the image
 // is <= 4095 px (also under the fp32 rounding of the offset add, which is monotone).  One reduction per image decides;
 // otherwise (or agnostic, or nc > 1024) every box goes to ONE list and every pair is tested, as torchvision does.
-__global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
+__device__ __forceinline__ void nms_select_body(const NmsArgs& a, const int b) {
     __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[kLdsKeys];   // sort buffer, then: kept list (lower half)
     // after the sort the upper half of the buffer holds: the chunk's candidates (cross-lane reads), list heads, list links
     Cand* wbox = reinterpret_cast<Cand*>(lds_keys + kLdsKeys / 2);                    // [256] x 32 B
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
     int* cfill = cstart + 1028;                                                       // [1024]   start offsets / fill cursors
     short* order = reinterpret_cast<short*>(cfill + 1024);                            // [kMaxDetCap] kept slots grouped by class
     __shared__ int s_kept, s_wide;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* keys = a.keys + (size_t)b * a.capP;
     const long long cap = (long long)a.N * a.nc;
     long long n64 = a.cnt[b * kCntStride];
@@ -448,6 +452,26 @@ __global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) {
         oidx[k] = a.multi_label ? (long long)flat : (long long)box;
     }
     if (tid == 0) a.out_count[b] = nk;
+}
+
+__global__ __launch_bounds__(kSelT) void nms_select_kernel(const NmsArgs a) { nms_select_body(a, blockIdx.x); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE launch for the whole of non_max_suppression (maf_nms_ex flag MAF_NMS_SINGLE_LAUNCH: the latency path, small batches): every workgroup
+// collects its share of the candidates; the workgroup that finishes an image LAST (a ticket per image, behind a device-scope fence: the other
+// workgroups' keys and the count are visible to it) goes on and runs that image's sort + greedy selection (the one-workgroup form above,
+// which takes any number of candidates).  No second launch, no host round trip, nobody spins: the other workgroups simply leave.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelT) void nms_single_kernel(const NmsArgs a) {
+    __shared__ int s_last;
+    if (a.multi_label) nms_collect_multi_body(a); else nms_collect_best_body(a);
+    __threadfence();                                           // release: this workgroup's keys before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&a.cnt[blockIdx.y * kCntStride + 2], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                           // acquire: everybody else's keys and the final count
+    nms_select_body(a, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -850,6 +874,14 @@ extern "C" int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, d
     a.out_rows = out_rows; a.out_idx = reinterpret_cast<long long*>(out_idx); a.out_count = out_count;
     int rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * kCntStride * 4, s), "nms memset");
     if (rc) return rc;
+    if (flags & MAF_NMS_SINGLE_LAUNCH) {                         // one launch: collect, then the last workgroup of every image selects (any candidate count)
+        a.mask = nullptr;                                        // (nms_select_body: no suppression-matrix hand-over)
+        int bx;
+        if (a.multi_label) { const long long el = (long long)N * nc; bx = (int)((el + kChunk - 1) / kChunk < 256 ? (el + kChunk - 1) / kChunk : 256); }
+        else bx = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;
+        hipLaunchKernelGGL(nms_single_kernel, dim3(bx, B), dim3(kSelT), 0, s, a);
+        return maf_check_hip(hipGetLastError(), "nms_single launch");
+    }
     if (a.multi_label) {
         const long long el = (long long)N * nc;
         const int bx = (int)((el + kChunk - 1) / kChunk < 256 ? (el + kChunk - 1) / kChunk : 256);

@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("MAF_HIP_LIB") or os.path.join(_HERE, "libmafyolo_hip.
 
 F16, F32, U8 = 0, 1, 2
 NMS_FLOAT_THRESHOLD = 1
+NMS_SINGLE_LAUNCH = 2         # maf_nms_ex flag: one launch (collect, then the last workgroup of every image sorts and selects) — the latency path
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_DIRECT, SRC_UP2, SRC_POOL2, SRC_SUB2, SRC_PAIRS = 0, 1, 2, 3, 4
 OP_STEM, OP_CONV1X1, OP_CONV3X3S2, OP_DWCONV, OP_SPPF_POOL, OP_DECODE, OP_BOTTLENECK, OP_CONV1DW, OP_HEADTAIL, OP_STEM2, OP_CONV3X3S2_DGRAD = range(11)

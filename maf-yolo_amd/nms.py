@@ -9,6 +9,8 @@ Differences, all documented in DESIGN.md: decode/NMS arithmetic is fp32 even for
 (the reference's fp16 `cls*4096` overflows for cls >= 16); the 10 s time limit
 (nms.py:101-103) is dropped; max_det <= 1024.
 """
+import os
+
 import torch
 
 from . import lib
@@ -69,10 +71,19 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             lib.check(L.maf_nms_ex(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
                                    cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
                                    int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
-                                   lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0, st.cuda_stream))
+                                   (lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0) | (lib.NMS_SINGLE_LAUNCH if _single_launch(B) else 0), st.cuda_stream))
         if stream is not None and pred is prediction:
             pred.record_stream(st)                    # a caller-owned tensor read on a stream it was not allocated on
     return rows, idx, cnt
+
+
+SINGLE_LAUNCH_MAX_BATCH = int(os.environ.get("MAF_NMS_SINGLE_MAX_BATCH", "0"))
+
+
+def _single_launch(B):
+    """One kernel for the whole NMS (csrc/nms.hip:nms_single_kernel) up to this batch size: the latency path.  Larger batches keep the
+    seven-launch form, whose suppression-matrix kernels use the whole chip."""
+    return B <= SINGLE_LAUNCH_MAX_BATCH
 
 
 class NmsHandle:

@@ -177,6 +177,22 @@ def test_nms_edge_cases_vs_reference_golden_and_oracle(golden, name):
         assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
 
 
+@pytest.mark.parametrize("name", sorted(nms_cases.cases().keys()))
+def test_nms_single_launch_form_is_bit_identical(golden, name, monkeypatch):
+    """maf_nms_ex flag MAF_NMS_SINGLE_LAUNCH (csrc/nms.hip:nms_single_kernel — collect, then the last workgroup of every image sorts and selects:
+    ONE launch for the whole of yolov6/utils/nms.py:31-105) against the same reference fixtures and oracle indices as the seven-launch form."""
+    from maf_yolo_amd import nms as nms_mod
+    monkeypatch.setattr(nms_mod, "SINGLE_LAUNCH_MAX_BATCH", 1 << 20)
+    g = golden("nms_cases")
+    pred, kw = nms_cases.cases()[name]
+    out, idx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), return_index=True, **kw)
+    _, oi = O.non_max_suppression(pred, return_index=True, **kw)
+    assert [o.shape[0] for o in out] == list(g[name + "__n"])
+    for b, o in enumerate(out):
+        assert np.array_equal(o.cpu().numpy(), g["%s__%d" % (name, b)]), (name, b)
+        assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
+
+
 def test_nms_large_candidate_set_global_sort_path():
     """> 8192 candidates per image: sort runs in global memory; > 30000: top-30000 rule."""
     rs = np.random.RandomState(3)
