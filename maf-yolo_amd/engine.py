@@ -425,8 +425,19 @@ class Plan:
                     y.append(None)
                     continue
                 outs = []
-                for br, pred, act, cpred in (("cls", m.cls_pred, lib.ACT_SIGMOID, self.nc), ("reg", m.reg_pred, lib.ACT_NONE, 4 * (self.reg_max + 1))):
-                    u, v = self._alloc(x.H, x.W, c), self._alloc(x.H, x.W, c)
+                u2 = None
+                if self.dtype == lib.F16 and c % 8 == 0:
+                    # cls_conv and reg_conv read the same tensor here too: ONE depth-wise launch with two filters per input channel (and, as the
+                    # only reader of the stem's output, a candidate for the pixel-pair variant)
+                    (wc, bc), (wr, brg) = m.cls_conv.fused(), m.reg_conv.fused()
+                    if wc.shape == wr.shape:
+                        u2 = self._alloc(x.H, x.W, 2 * c)
+                        self._ops.append(dict(kind=lib.OP_DWCONV, name=p + ".cls_reg_conv", act=lib.ACT_NONE, H=x.H, W=x.W, Cin=c, Cout=2 * c, ksize=wc.shape[-1],
+                                              segs=tv.segs, out=u2, out_coff=0, w=self._wput(pack.pack_dw(torch.cat([wc, wr], 0), self.dtype)),
+                                              b=self._wput(torch.cat([bc, brg], 0).float().cpu()),
+                                              aux=[None, self._wput(pack.pack_dw_pairs(torch.cat([wc, wr], 0)))]))
+                for bi, (br, pred, act, cpred) in enumerate((("cls", m.cls_pred, lib.ACT_SIGMOID, self.nc), ("reg", m.reg_pred, lib.ACT_NONE, 4 * (self.reg_max + 1)))):
+                    u, v = (None if u2 is not None else self._alloc(x.H, x.W, c)), self._alloc(x.H, x.W, c)
                     # any class count (the reference takes any nc): the conv kernels store 4 channels at a time, so the pred conv is
                     # padded with zero filters to a multiple of 4 and the decode kernel reads the rows with that stride
                     cpad = -(-cpred // 4) * 4
@@ -436,8 +447,10 @@ class Plan:
                     if cpad != cpred:
                         pw = torch.cat([pw, pw.new_zeros(cpad - cpred, *pw.shape[1:])], 0)
                         pb = torch.cat([pb, pb.new_zeros(cpad - cpred)], 0)
-                    self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
-                    self._conv1x1("%s.%s_conv_s" % (p, br), *getattr(m, br + "_conv_s").fused(), TV([Seg(u, c)], x.H, x.W), v, 0, lib.ACT_SILU)
+                    if u2 is None:
+                        self._dw("%s.%s_conv" % (p, br), *getattr(m, br + "_conv").fused(), tv, u, lib.ACT_NONE)
+                    self._conv1x1("%s.%s_conv_s" % (p, br), *getattr(m, br + "_conv_s").fused(),
+                                  TV([Seg(u, c)] if u2 is None else [Seg(u2, c, bi * c)], x.H, x.W), v, 0, lib.ACT_SILU)
                     self._conv1x1("%s.%s_pred" % (p, br), pw, pb, TV([Seg(v, c)], x.H, x.W), o, 0, act, out_f32=True)
                     outs.append(o)
                 self.head_bufs.append((t, outs[0], outs[1]))
