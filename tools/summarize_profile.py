@@ -34,6 +34,13 @@ def demangle(n):
     m = re.match(r"_ZN12_GLOBAL__N_1\d+(sppf_pool\w*_kernel)I(DF16_|f)", n)
     if m:
         return "%s<%s>" % (m.group(1), _T[m.group(2)])
+    if n.startswith("_Z"):                                     # everything else: the toolchain's demangler, if it is there
+        filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+        if os.path.exists(filt):
+            try:
+                return subprocess.check_output([filt, n], text=True).strip()
+            except Exception:
+                pass
     return n
 
 
@@ -43,8 +50,11 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     shutil.copy(src, out + "_kernel_stats.csv")
     rows = list(csv.DictReader(open(src)))
-    lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % os.path.basename(out), "",
-             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline` (one batch in flight: with two, launches of the two streams overlap and every kernel looks longer than it is alone)", ""]
+    if "train" in os.path.basename(out):                       # the commands of tools/profile_round.sh
+        cmd = "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --train --scale n --batch 32 --steps 5 --warmup 2 --no-cpu-baseline` (the training step; the first steps time the conv variants of every layer shape, so call counts are not multiples of the step count)"
+    else:
+        cmd = "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --tune-file <chain>/tune.json --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg` (one batch in flight: with two, launches of the two streams overlap and every kernel looks longer than it is alone)"
+    lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % os.path.basename(out), "", "Command: " + cmd, ""]
     if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
         try:
             j = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])
