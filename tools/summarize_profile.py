@@ -34,13 +34,13 @@ def demangle(n):
     m = re.match(r"_ZN12_GLOBAL__N_1\d+(sppf_pool\w*_kernel)I(DF16_|f)", n)
     if m:
         return "%s<%s>" % (m.group(1), _T[m.group(2)])
-    if n.startswith("_Z"):                                     # everything else: the toolchain's demangler, if it is there
-        filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
-        if os.path.exists(filt):
-            try:
-                return subprocess.check_output([filt, n], text=True).strip()
-            except Exception:
-                pass
+    if n.startswith("_Z"):                                     # everything else: binutils' demangler (it does not know DF16_ = _Float16: spelled as `half`, then renamed)
+        try:
+            d = subprocess.run(["c++filt", n.replace("DF16_", "Dh")], capture_output=True, text=True).stdout.strip()
+            if d and not d.startswith("_Z"):
+                return d.replace("<half", "<_Float16").replace(" half", " _Float16")
+        except Exception:
+            pass
     return n
 
 
