@@ -30,7 +30,8 @@ constexpr int kLdsKeys = 8192;       // 64 KiB of 64-bit keys
 constexpr int kMaxDetCap = 1024;     // kept-list capacity in LDS (32 B each = lower half of the sort buffer)
 constexpr int kMaskN = 4096;         // images with at most this many candidates take the suppression-matrix path
 constexpr int kMaskW = kMaskN / 64;  // 64-bit words per matrix row
-constexpr int kMaskWgs = 256;        // matrix workgroups per image
+constexpr int kMaskWgs = 1024;       // matrix workgroups (one wave each) per image: ~2000 candidates are 528 block pairs — with 256 workgroups 16 of them
+                                     // took a third pair and set the kernel's time (NMS of a 32-image batch 0.256 -> 0.224 ms with one pair per wave)
 
 struct NmsArgs {
     const float* pred;
