@@ -16,6 +16,10 @@
 // Workgroups are persistent (weights staged once).  fp16 engine only; (C0, C1) = (24, 48) [n] or (32, 64) [s].
 #include "maf_common.h"
 
+#ifndef MAF_KO
+#define MAF_KO 0            // profiling builds (make ko KO_SRCS=stem2.hip): 1 = no stem conv (phase B), 2 = no second conv (phase C), 4 = no output stores, 8 = no image loads, 16 = no third conv, 32 = no patch writes to LDS, 64 = no SiLU
+#endif
+
 namespace {
 
 struct S2Args {
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
             const int iy = iy0 + r, ix = ix0 + 4 * ch;
             pf_in[u] = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
             const size_t at = pf_in[u] ? ((size_t)c * a.Hin + iy) * a.Win + ix : 0;      // clamped: the load stays unconditional
-            pf[u] = *reinterpret_cast<const raw_t*>(img + at);
+            if (MAF_KO & 8) pf[u] = raw_t{}; else pf[u] = *reinterpret_cast<const raw_t*>(img + at);
         }
     };
     if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
@@ -123,14 +127,14 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
             if (e < NCHUNK) {
                 half4_t v = Chunk<TI>::cvt(pf[u], a.in_scale);
                 if (!pf_in[u]) v = half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-                *reinterpret_cast<half4_t*>(s_in + 4 * e) = v;   // chunk e = (c * IR + r) * NCH + ch sits at that index: rows are ICS = 4 NCH wide
+                if (!(MAF_KO & 32)) *reinterpret_cast<half4_t*>(s_in + 4 * e) = v;   // chunk e = (c * IR + r) * NCH + ch sits at that index: rows are ICS = 4 NCH wide
             }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
         // ---- B: stem outputs of the tile on the matrix cores, computed transposed (A = weights, B = gathered taps) so that a lane ends
         //      up with 4 consecutive channels of ONE pixel: one 8-byte LDS store per 16-channel tile
-        for (int mt = wave; mt < (SP + 15) / 16; mt += 4) {
+        for (int mt = wave; mt < ((MAF_KO & 1) ? 0 : (SP + 15) / 16); mt += 4) {
             const int pp = mt * 16 + n, p = min(pp, SP - 1), r = p / SC, c = p - r * SC;
             const half_t* base = s_in + (2 * r) * ICS + 2 * c;
             half8_t bf;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) {
+        for (int s = 0; s < ((MAF_KO & 2) ? 0 : KS1); ++s) {
             half8_t tf[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                 for (int t = 0; t < NT3; ++t) {
                     acc3[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < KS3; ++j) acc3[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[(t * KS3 + j) * 64 + lane], a2[j], acc3[m][t], 0, 0, 0);
+                    for (int j = 0; j < ((MAF_KO & 16) ? 0 : KS3); ++j) acc3[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[(t * KS3 + j) * 64 + lane], a2[j], acc3[m][t], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                 for (int t = 0; t < NT3; ++t) {
                     half4_t v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<MAF_ACT_SILU>(acc3[m][t][q] + b3[t][q]);
+                    for (int q = 0; q < 4; ++q) v[q] = (MAF_KO & 64) ? (half_t)(acc3[m][t][q] + b3[t][q]) : (half_t)maf_act<MAF_ACT_SILU>(acc3[m][t][q] + b3[t][q]);
                     *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C3 + 16 * t + 4 * g) = v;
                 }
         }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
         for (int q = tid; q < TY * TX * CPP; q += 256) {
             const int px = q / CPP, part = q - px * CPP;
             const int oy = Y0 + px / TX, ox = X0 + px % TX;
-            if (oy < a.H1 && ox < a.W1)
+            if (oy < a.H1 && ox < a.W1 && !(MAF_KO & 4))
                 *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H1 + oy) * a.W1 + ox) * a.out_stride + a.out_coff + 8 * part) =
                     *reinterpret_cast<const uint4*>(s_out + px * CO + 8 * part);
         }
