@@ -134,25 +134,69 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
         if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
         // ---- B: stem outputs of the tile on the matrix cores, computed transposed (A = weights, B = gathered taps) so that a lane ends
         //      up with 4 consecutive channels of ONE pixel: one 8-byte LDS store per 16-channel tile
-        for (int mt = wave; mt < ((MAF_KO & 1) ? 0 : (SP + 15) / 16); mt += 4) {
-            const int pp = mt * 16 + n, p = min(pp, SP - 1), r = p / SC, c = p - r * SC;
-            const half_t* base = s_in + (2 * r) * ICS + 2 * c;
-            half8_t bf;
+        //      Three stages in flight per wave (hipcc orders gather -> wait -> MFMA -> wait -> epilogue per tile: two exposed round trips, nine
+        //      times per wave and tile; knock-outs: phases B + C = 29 of 91 us, bound by exactly these waits): the taps of m-tile i + 1 are
+        //      gathered and the MFMAs of m-tile i issued BEFORE the bias / ReLU / store work of m-tile i - 1.
+        constexpr bool PIPE_B = C0 == 24;      // (32, 64): the extra live fragments push the kernel past 256 registers (one workgroup per CU): the plain loop below
+        if constexpr (!PIPE_B) {
+            for (int mt = wave; mt < ((MAF_KO & 1) ? 0 : (SP + 15) / 16); mt += 4) {
+                const int pp = mt * 16 + n, p = min(pp, SP - 1), r = p / SC, c = p - r * SC;
+                const half_t* base = s_in + (2 * r) * ICS + 2 * c;
+                half8_t bf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bf[j] = base[off0[j]];
-            const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0a, bf, z, 0, 0, 0);
-            const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, bf, z, 0, 0, 0);
-            if (pp < SP) {
-                const bool in = (unsigned)(2 * Y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + c) < (unsigned)a.W0;   // else: zero padding of conv 2
-                half4_t va, vb;
+                for (int j = 0; j < 8; ++j) bf[j] = base[off0[j]];
+                const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0a, bf, z, 0, 0, 0);
+                const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, bf, z, 0, 0, 0);
+                if (pp < SP) {
+                    const bool in = (unsigned)(2 * Y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + c) < (unsigned)a.W0;   // else: zero padding of conv 2
+                    half4_t va, vb;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    va[q] = (half_t)(in ? fmaxf(ca[q] + b0a[q], 0.f) : 0.f);
-                    vb[q] = (half_t)(in ? fmaxf(cb[q] + b0b[q], 0.f) : 0.f);
+                    for (int q = 0; q < 4; ++q) {
+                        va[q] = (half_t)(in ? fmaxf(ca[q] + b0a[q], 0.f) : 0.f);
+                        vb[q] = (half_t)(in ? fmaxf(cb[q] + b0b[q], 0.f) : 0.f);
+                    }
+                    *reinterpret_cast<half4_t*>(s_T + pp * TSH + 4 * g) = va;
+                    if (16 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 16 + 4 * g) = vb;
                 }
-                *reinterpret_cast<half4_t*>(s_T + pp * TSH + 4 * g) = va;
-                if (16 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 16 + 4 * g) = vb;
+            }
+        } else if (!(MAF_KO & 1)) {
+            constexpr int NMT = (SP + 15) / 16, NI = (NMT + 3) / 4;
+            half8_t bfr[2];
+            f32x4_t car[2], cbr[2];
+            auto gather = [&](int mt, half8_t& bf) {
+                const int p = min(mt * 16 + n, SP - 1), r = p / SC, c = p - r * SC;
+                const half_t* base = s_in + (2 * r) * ICS + 2 * c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bf[j] = base[off0[j]];
+            };
+            auto finish = [&](int mt, const f32x4_t& ca, const f32x4_t& cb) {
+                const int pp = mt * 16 + n, p = min(pp, SP - 1), r = p / SC, c = p - r * SC;
+                if (pp < SP) {
+                    const bool in = (unsigned)(2 * Y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + c) < (unsigned)a.W0;   // else: zero padding of conv 2
+                    half4_t va, vb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        va[q] = (half_t)(in ? fmaxf(ca[q] + b0a[q], 0.f) : 0.f);
+                        vb[q] = (half_t)(in ? fmaxf(cb[q] + b0b[q], 0.f) : 0.f);
+                    }
+                    *reinterpret_cast<half4_t*>(s_T + pp * TSH + 4 * g) = va;
+                    if (16 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 16 + 4 * g) = vb;
+                }
+            };
+            gather(wave, bfr[0]);
+#pragma unroll
+            for (int i = 0; i <= NI; ++i) {                                  // stage i: gather i + 1 | MFMAs i | finish i - 1
+                const int mt = wave + 4 * i;
+                if (i + 1 < NI && mt + 4 < NMT) gather(mt + 4, bfr[(i + 1) & 1]);
+                if (i < NI && mt < NMT) {
+                    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                    car[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0a, bfr[i & 1], z, 0, 0, 0);
+                    cbr[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, bfr[i & 1], z, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i > 0 && mt - 4 < NMT) finish(mt - 4, car[(i - 1) & 1], cbr[(i - 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
