@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--nms-filter", action="store_true", help="A/B: the forward's head tails collect the NMS candidates (Model.nms_filter) instead of non_max_suppression's own pass over the prediction")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
     ap.add_argument("--lanes", type=int, default=-1, help="engine streams: 0 one stream, 1 heads on side streams, 2 heads + neck side convs (default: the model's setting)")
     ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
@@ -401,6 +402,12 @@ def main():
     conf, iou = 0.03, 0.65
     with torch.no_grad():
         cand = (model(x)[0][..., 5:] > conf).sum((1, 2))
+    if args.nms_filter:
+        # A/B: the head tails append the NMS candidates while they hold the class scores (Model.nms_filter -> maf_engine_run_filtered;
+        # non_max_suppression then skips its own pass over the 91 MB prediction).  Same detections bit for bit
+        # (tests/test_gpu_model.py:test_candidate_filter_inside_the_forward_gives_the_same_detections); measured: no gain in this loop (the
+        # candidate pass runs on the NMS stream under the next forward anyway, the forward grows by ~10 us) — off by default.
+        model.nms_filter = conf
     cand_mean, cand_max = float(cand.float().mean()), int(cand.max())
     if args.tune_file and rank == 0 and not os.path.exists(args.tune_file):
         _engine.save_tune_cache(args.tune_file)

@@ -178,6 +178,12 @@ int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_t** out);
 int maf_engine_num_ops(const maf_engine_t* e);
 /* image / pred override the STEM input and DECODE output pointers when non-NULL. */
 int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream);
+/* maf_engine_run + the candidate filter of non_max_suppression inside the forward: the head-tail kernels (MAF_OP_HEADTAIL) append every
+ * (box, class) whose score exceeds `conf_thres` to the candidate lists of `nms_workspace` (a buffer of maf_nms_workspace_bytes(B, A, 80) bytes; its
+ * counters are reset here), so that a following maf_nms_ex(pred, ..., conf_thres, ..., multi_label = 1, workspace = nms_workspace, flags |
+ * MAF_NMS_PRECOLLECTED) skips its own pass over the prediction (yolov6/utils/nms.py:48,69,75-77 folded into yolov6/models/yolo.py:355-396).
+ * Needs every level's tail to be a MAF_OP_HEADTAIL (MAF_E_UNSUPPORTED otherwise), H * W of every level a multiple of 16, 0 <= conf_thres < 1. */
+int maf_engine_run_filtered(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream, void* nms_workspace, double conf_thres);
 /* Same launches replayed from a hipGraph captured on first use (bs=1 latency path). Pointers are
  * frozen at capture time: image/pred must be the same on every call. */
 int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream);
@@ -202,14 +208,19 @@ void maf_engine_destroy(maf_engine_t* e);
  * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
  * break (nms.py:101-103) is dropped.  max_det <= 1024.
  */
-enum { MAF_NMS_FLOAT_THRESHOLD = 1, MAF_NMS_SINGLE_LAUNCH = 2 };    /* maf_nms_ex flags.  MAF_NMS_FLOAT_THRESHOLD: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`),
-                                          * which is what yolov6/utils/nms.py:96 reaches when the reference runs on a GPU — instead of with the double
-                                          * (its CPU kernel, the default here and the rule of the oracle and of the golden fixtures).  The results differ
-                                          * only for a pair whose fp32 IoU equals fl32(iou_thres) exactly where fl32(iou_thres) > iou_thres (0.6, 0.7, ...).
-                                          * MAF_NMS_SINGLE_LAUNCH: the whole call is ONE kernel (csrc/nms.hip:nms_single_kernel: every workgroup collects
-                                          * candidates, the last one to finish an image sorts and selects them) instead of seven; same results bit for bit.
-                                          * Measured on configs[4] (m, bs 1): 0.29 ms against 0.20 ms for the seven launches (whose pair-matrix kernels use
-                                          * the whole chip) — available, not the default. */
+enum { MAF_NMS_FLOAT_THRESHOLD = 1, MAF_NMS_SINGLE_LAUNCH = 2, MAF_NMS_PRECOLLECTED = 4 };
+enum { MAF_NMS_CNT_STRIDE = 64 };       /* ints between the candidate counters of two images in the NMS workspace (one 256-byte line each) */
+/* maf_nms_ex flags.
+ * MAF_NMS_FLOAT_THRESHOLD: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`), which is what
+ *   yolov6/utils/nms.py:96 reaches when the reference runs on a GPU — instead of with the double (its CPU kernel, the default here and the rule of
+ *   the oracle and of the golden fixtures).  The results differ only for a pair whose fp32 IoU equals fl32(iou_thres) exactly where
+ *   fl32(iou_thres) > iou_thres (0.6, 0.7, ...).
+ * MAF_NMS_SINGLE_LAUNCH: the whole call is ONE kernel (csrc/nms.hip:nms_single_kernel: every workgroup collects candidates, the last one to
+ *   finish an image sorts and selects them) instead of seven; same results bit for bit.  Measured on configs[4] (m, bs 1): 0.29 ms against
+ *   0.20 ms for the seven launches (whose pair-matrix kernel uses the whole chip) — available, not the default.
+ * MAF_NMS_PRECOLLECTED: the candidate lists of `workspace` (counters + keys) are already there — written by the forward pass that produced `pred`
+ *   (maf_engine_run_filtered: the head-tail kernels test the scores they have just computed against the same conf_thres) — so the call skips its
+ *   counter reset and its pass over the prediction tensor.  Only for multi_label with nc > 1, no class filter, conf_thres < 1. */
 int64_t maf_nms_workspace_bytes(int32_t B, int32_t N, int32_t nc);
 int maf_nms(const float* pred, int32_t B, int32_t N, int32_t nc, double conf_thres, double iou_thres,
             const int32_t* classes, int32_t n_classes, int32_t agnostic, int32_t multi_label,

@@ -102,7 +102,10 @@ extern "C" int maf_engine_create(const maf_op_t* ops, int32_t n_ops, maf_engine_
 
 extern "C" int maf_engine_num_ops(const maf_engine_t* e) { return e ? (int)e->ops.size() : 0; }
 
-static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipStream_t s) {
+// where maf_nms_ex keeps its candidate lists inside a workspace (csrc/nms.hip: counters | keys | ...)
+static long long nms_cap_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; return p; }
+
+static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipStream_t s, void* cand_ws = nullptr, float cand_conf = 0.f) {
     int rc = engine_prepare_lanes(e);
     if (rc) return rc;
     const bool multi = e->n_lanes > 1;
@@ -111,10 +114,25 @@ static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipSt
         for (int l = 1; l < e->n_lanes && !rc; ++l) rc = maf_check_hip(hipStreamWaitEvent(e->side[l], e->fork, 0), "hipStreamWaitEvent(fork)");
         if (rc) return rc;
     }
+    int* cand_cnt = nullptr; unsigned long long* cand_keys = nullptr; long long cand_cap = 0;
+    if (cand_ws) {                                           // candidate filter in the head tails: every level must end in one
+        int B = 0, A = 0, tails = 0;
+        for (const maf_op_t& o : e->ops) {
+            if (o.kind == MAF_OP_DECODE) { maf_set_error("maf_engine_run_filtered: a level of this plan is decoded by MAF_OP_DECODE (no fused tail)"); return MAF_E_UNSUPPORTED; }
+            if (o.kind == MAF_OP_HEADTAIL) { B = o.B; A = o.Win; ++tails; }
+        }
+        if (!tails) { maf_set_error("maf_engine_run_filtered: the plan has no MAF_OP_HEADTAIL"); return MAF_E_UNSUPPORTED; }
+        cand_cnt = static_cast<int*>(cand_ws);
+        cand_keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(cand_ws) + 256 + (long long)B * MAF_NMS_CNT_STRIDE * 4);
+        cand_cap = nms_cap_pow2((long long)A * 80);
+        rc = maf_check_hip(hipMemsetAsync(cand_cnt, 0, (size_t)B * MAF_NMS_CNT_STRIDE * 4, s), "candidate counter reset");
+        if (rc) return rc;
+    }
     for (size_t i = 0; i < e->ops.size(); ++i) {
         maf_op_t op = e->ops[i];
         if ((op.kind == MAF_OP_STEM || op.kind == MAF_OP_STEM2) && image) op.src[0].ptr = image;
         if ((op.kind == MAF_OP_DECODE || op.kind == MAF_OP_HEADTAIL) && pred) op.out = pred;
+        if (op.kind == MAF_OP_HEADTAIL && cand_ws) { op.aux[1] = cand_cnt; op.aux[2] = cand_keys; op.lvl_h[0] = (int32_t)cand_cap; op.lvl_stride[1] = cand_conf; }
         hipStream_t st = op.lane == 0 ? s : e->side[op.lane];
         for (int k = 0; k < op.n_wait && !rc; ++k) rc = maf_check_hip(hipStreamWaitEvent(st, e->done[op.wait[k]], 0), "hipStreamWaitEvent");
         if (!rc) rc = maf_op_launch(&op, st);
@@ -136,6 +154,12 @@ static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipSt
 extern "C" int maf_engine_run(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream) {
     if (!e) { maf_set_error("maf_engine_run: null engine"); return MAF_E_ARG; }
     return engine_launch_all(e, image, pred, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int maf_engine_run_filtered(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream, void* nms_workspace, double conf_thres) {
+    if (!e || !nms_workspace || !pred) { maf_set_error("maf_engine_run_filtered: null argument"); return MAF_E_ARG; }
+    if (!(conf_thres >= 0.0 && conf_thres < 1.0)) { maf_set_error("maf_engine_run_filtered: conf_thres must be in [0, 1)"); return MAF_E_ARG; }
+    return engine_launch_all(e, image, pred, static_cast<hipStream_t>(stream), nms_workspace, (float)conf_thres);
 }
 
 extern "C" int maf_engine_run_graph(maf_engine_t* e, const void* image, void* pred, maf_stream_t stream) {

@@ -38,6 +38,12 @@ struct HtArgs {
     float* out;                        // pred [B][A][85]
     int M, HW, Wd, A, lvl_off, iters;  // pixels of the level (B*H*W), H*W, grid width, anchors per image, first anchor of the level
     float stride;
+    // fused candidate filter (op->aux[1] != 0): the class scores this kernel has just computed are tested against non_max_suppression's conf_thres
+    // and the survivors appended to the NMS workspace — what nms_collect_multi_kernel (csrc/nms.hip) otherwise re-reads the whole prediction for
+    int* cand_cnt;                     // [B][MAF_NMS_CNT_STRIDE] candidate counters of the NMS workspace
+    unsigned long long* cand_keys;     // [B][cand_cap] 64-bit keys (~score bits << 32 | box * 80 + class)
+    long long cand_cap;
+    float cand_conf;
 };
 
 template <int C, int PT>
@@ -263,14 +269,40 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             }
             __syncthreads();
             if (br == 0) {
+                unsigned int hits = 0;
+                int mine = 0;
 #pragma unroll
                 for (int q = 0; q < 16 * NC / 64; ++q) {
                     const int e = lane + 64 * q;
                     const int px = e / NC, col = e - px * NC;
                     const int m = m0 + px;
+                    bool ok = false;
                     if (m < a.M) {
                         const int b = m / a.HW, pin = m - b * a.HW;
-                        a.out[((size_t)b * a.A + a.lvl_off + pin) * NO + 5 + col] = stage[e];
+                        const float sc = stage[e];
+                        a.out[((size_t)b * a.A + a.lvl_off + pin) * NO + 5 + col] = sc;
+                        ok = a.cand_cnt != nullptr && sc > a.cand_conf;           // nms.py:48, :69, :76 with objectness 1 (written below): score = cls * 1
+                    }
+                    hits |= ok ? 1u << q : 0u;
+                    mine += __popcll(__ballot(ok));                               // wave-uniform running count
+                }
+                if (mine > 0) {                                                   // wave-uniform; the 16 pixels of a unit belong to ONE image (HW % 16 == 0: checked by the launcher)
+                    const int b = m0 / a.HW, pin0 = m0 - b * a.HW;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&a.cand_cnt[b * MAF_NMS_CNT_STRIDE], mine);
+                    int pos = __shfl(base, 0);
+                    unsigned long long* keys = a.cand_keys + (size_t)b * a.cand_cap;
+#pragma unroll
+                    for (int q = 0; q < 16 * NC / 64; ++q) {
+                        const bool ok = (hits >> q) & 1u;
+                        const unsigned long long mk = __ballot(ok);
+                        if (ok) {
+                            const int e = lane + 64 * q;
+                            const int px = e / NC, col = e - px * NC;
+                            const unsigned int flat = (unsigned int)(a.lvl_off + pin0 + px) * (unsigned int)NC + (unsigned int)col;
+                            keys[pos + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(stage[e])) << 32) | flat;
+                        }
+                        pos += __popcll(mk);
                     }
                 }
             } else {
@@ -324,6 +356,11 @@ int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
     a.out = static_cast<float*>(op->out);
     a.M = op->B * op->H * op->W; a.HW = op->H * op->W; a.Wd = op->W; a.A = op->Win; a.lvl_off = op->Hin; a.stride = op->lvl_stride[0];
     MAF_REQUIRE(a.A >= a.lvl_off + a.HW && a.lvl_off >= 0, "head_tail: Hin = first anchor of the level, Win = anchors per image");
+    a.cand_cnt = static_cast<int*>(const_cast<void*>(op->aux[1]));
+    a.cand_keys = static_cast<unsigned long long*>(const_cast<void*>(op->aux[2]));
+    a.cand_cap = op->lvl_h[0]; a.cand_conf = op->lvl_stride[1];
+    MAF_REQUIRE(!a.cand_cnt || (a.cand_keys && a.cand_cap >= (long long)a.A * NC && a.HW % 16 == 0 && a.cand_conf >= 0.f && a.cand_conf < 1.f),
+                "head_tail: candidate filter (aux[1] = counters, aux[2] = keys, lvl_h[0] = keys per image >= A * 80, lvl_stride[1] = conf in [0, 1)) needs H * W a multiple of 16");
     const int pt = op->Cin <= 128 ? 2 : 1;
     const int units = maf_cdiv(maf_cdiv(a.M, 16), pt);
     // one round of resident workgroups per branch (tile_k > 0: that many workgroups per CU and branch-pair, i.e. grid.x = 128 * tile_k; default 2 per CU

@@ -64,7 +64,7 @@ __device__ float row_rmax(const float* row, int nc) {
     return m;
 }
 
-constexpr int kCntStride = 64;       // one candidate counter per 256-byte line: atomics of different images never share a line
+constexpr int kCntStride = MAF_NMS_CNT_STRIDE;   // (64) one candidate counter per 256-byte line: atomics of different images never share a line
 constexpr int kChunk = 8192;         // elements per workgroup chunk (32 KiB of fp32: stays in L1 between the two passes)
 
 __device__ __forceinline__ bool multi_test(const NmsArgs& a, const float* pred, unsigned int e32, int no, float& sc) {
@@ -873,8 +873,16 @@ extern "C" int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, d
     a.cands = reinterpret_cast<Cand*>(ws + 256 + (long long)B * kCntStride * 4 + (long long)B * a.capP * 8);
     a.mask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.cands) + (long long)B * kMaskN * 32);
     a.out_rows = out_rows; a.out_idx = reinterpret_cast<long long*>(out_idx); a.out_count = out_count;
-    int rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * kCntStride * 4, s), "nms memset");
-    if (rc) return rc;
+    int rc = 0;
+    const bool precollected = (flags & MAF_NMS_PRECOLLECTED) != 0;      // the forward pass (maf_engine_run_filtered) has filled counters and keys
+    if (precollected) {
+        MAF_REQUIRE(a.multi_label && !a.classes && conf_thres < 1.0 && !(flags & MAF_NMS_SINGLE_LAUNCH),
+                    "nms: MAF_NMS_PRECOLLECTED needs multi_label (nc > 1), no class filter, conf_thres < 1, the multi-launch form");
+        // (the other words of an image's counter line — per-class flag, ticket — still start from zero: the filter reset the whole line)
+    } else {
+        rc = maf_check_hip(hipMemsetAsync(a.cnt, 0, (size_t)B * kCntStride * 4, s), "nms memset");
+        if (rc) return rc;
+    }
     if (flags & MAF_NMS_SINGLE_LAUNCH) {                         // one launch: collect, then the last workgroup of every image selects (any candidate count)
         a.mask = nullptr;                                        // (nms_select_body: no suppression-matrix hand-over)
         int bx;
@@ -883,7 +891,8 @@ extern "C" int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, d
         hipLaunchKernelGGL(nms_single_kernel, dim3(bx, B), dim3(kSelT), 0, s, a);
         return maf_check_hip(hipGetLastError(), "nms_single launch");
     }
-    if (a.multi_label) {
+    if (precollected) {
+    } else if (a.multi_label) {
         const long long el = (long long)N * nc;
         const int bx = (int)((el + kChunk - 1) / kChunk < 256 ? (el + kChunk - 1) / kChunk : 256);
         hipLaunchKernelGGL(nms_collect_multi_kernel, dim3(bx, B), dim3(256), 0, s, a);

@@ -891,10 +891,20 @@ class Plan:
         pred = torch.empty(self.B, self.A, 5 + self.nc, dtype=torch.float32, device=self.device)
         return self.run_into(x, pred, graph)
 
-    def run_into(self, x, pred, graph=False):
+    def filter_ok(self):
+        """True if this plan can run non_max_suppression's candidate filter inside its head tails (maf_engine_run_filtered): every level ends
+        in a fused MAF_OP_HEADTAIL with H * W a multiple of 16."""
+        tails = [o for o in self.ops if o.kind == lib.OP_HEADTAIL]
+        return len(tails) == 3 and not any(o.kind == lib.OP_DECODE for o in self.ops) and all((o.H * o.W) % 16 == 0 for o in tails)
+
+    def run_into(self, x, pred, graph=False, cand=None):
+        """`cand` = (workspace tensor, conf_thres): also fill the NMS candidate lists of that workspace (see Model.nms_filter)."""
         cur = torch.cuda.current_stream(self.device)
         if not graph:
-            lib.check(lib.load().maf_engine_run(self._engine, x.data_ptr(), pred.data_ptr(), cur.cuda_stream))
+            if cand is not None:
+                lib.check(lib.load().maf_engine_run_filtered(self._engine, x.data_ptr(), pred.data_ptr(), cur.cuda_stream, cand[0].data_ptr(), float(cand[1])))
+            else:
+                lib.check(lib.load().maf_engine_run(self._engine, x.data_ptr(), pred.data_ptr(), cur.cuda_stream))
             return pred
         # hipGraph capture is not permitted on the legacy default stream: replay on a private stream ordered
         # after / before the caller's current stream.  Pointers are frozen at capture (same x / pred buffers).

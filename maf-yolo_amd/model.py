@@ -285,7 +285,17 @@ class Model(nn.Module):
         plan = self.plan_for(x, head_feats=val_loss, slot=slot)
         x = x.contiguous()
         with torch.cuda.device(x.device):
-            pred = plan.run(x, graph=False)          # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)
+            conf = getattr(self, "nms_filter", None)
+            if conf is not None and not val_loss and 0.0 <= conf < 1.0 and plan.filter_ok():
+                # the candidate filter of the NMS call that follows (same conf_thres, multi_label) runs inside the head tails, which hold the
+                # class scores in registers anyway: nms.nms_raw finds the lists through the tensor and skips its pass over the prediction
+                from . import nms as _nms
+                pred = torch.empty(plan.B, plan.A, 5 + plan.nc, dtype=torch.float32, device=plan.device)
+                ws = _nms.candidate_workspace(plan.device, plan.B, plan.A, plan.nc, slot)
+                plan.run_into(x, pred, cand=(ws, conf))
+                pred._maf_cand = (ws, float(conf))
+            else:
+                pred = plan.run(x, graph=False)      # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)
         feats = plan.featmaps()
         if val_loss:
             return [self.detect(feats), feats]

@@ -25,6 +25,24 @@ _side = {}
 IOU_RULE = "cpu"
 
 
+_cand_ws = {}
+
+
+def candidate_workspace(dev, B, N, nc, slot=0):
+    """NMS workspace that a forward pass fills with candidates (Model.nms_filter -> maf_engine_run_filtered) and the NMS call of that prediction
+    then reads (MAF_NMS_PRECOLLECTED).  One per (device, shape, slot): the forward waits — on ITS stream — for the event the last NMS call that
+    read this workspace recorded, so a slot's next forward cannot overwrite lists a still running NMS reads (the serving loop runs the NMS of
+    batch i on a side stream while the forward of batch i + S reuses the slot)."""
+    key = (dev.index, B, N, nc, slot)
+    ws = _cand_ws.get(key)
+    if ws is None:
+        ws = _cand_ws[key] = torch.empty(lib.load().maf_nms_workspace_bytes(B, N, nc), dtype=torch.uint8, device=dev)
+        ws._maf_busy = None
+    if ws._maf_busy is not None:
+        torch.cuda.current_stream(dev).wait_event(ws._maf_busy)
+    return ws
+
+
 def _workspace(dev, st, B, N, nc, need):
     """Scratch buffer for one NMS call on stream `st`.  One buffer per (stream, shape): calls on the same stream are ordered, so they may
     share it; calls on different streams never do.  The buffer comes from the caching allocator while `st` is current, so when an entry is
@@ -58,7 +76,11 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             if pred.dtype != torch.float32:
                 pred = pred.float()
             pred = pred.contiguous()
-            ws = _workspace(dev, st, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
+            # candidate lists written by the forward pass that produced this very tensor (Model.nms_filter): usable if this call filters the same way
+            cand = getattr(prediction, "_maf_cand", None)
+            pre = (cand is not None and pred is prediction and multi_label and nc > 1 and classes is None and float(conf_thres) == cand[1]
+                   and not _single_launch(B) and cand[0].numel() >= L.maf_nms_workspace_bytes(B, N, nc))
+            ws = cand[0] if pre else _workspace(dev, st, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
             rows = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
             idx = torch.empty(B, max_det, dtype=torch.int64, device=dev)
             cnt = torch.empty(B, dtype=torch.int32, device=dev)
@@ -71,7 +93,13 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             lib.check(L.maf_nms_ex(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres),
                                    cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
                                    int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
-                                   (lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0) | (lib.NMS_SINGLE_LAUNCH if _single_launch(B) else 0), st.cuda_stream))
+                                   (lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0) | (lib.NMS_SINGLE_LAUNCH if _single_launch(B) else 0)
+                                   | (lib.NMS_PRECOLLECTED if pre else 0), st.cuda_stream))
+            if pre:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                ws._maf_busy = ev                    # the next forward that refills this workspace waits for it (candidate_workspace)
+                prediction._maf_cand = None          # the lists are consumed: the sort rewrites the keys in place
         if stream is not None and pred is prediction:
             pred.record_stream(st)                    # a caller-owned tensor read on a stream it was not allocated on
     return rows, idx, cnt

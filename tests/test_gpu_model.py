@@ -193,6 +193,41 @@ def test_nms_single_launch_form_is_bit_identical(golden, name, monkeypatch):
         assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
 
 
+@pytest.mark.parametrize("conf,kw", [(0.03, dict(iou_thres=0.65, multi_label=True)), (0.25, dict(iou_thres=0.45, multi_label=True, agnostic=True)),
+                                     (0.001, dict(iou_thres=0.65, multi_label=True, max_det=1000))])
+def test_candidate_filter_inside_the_forward_gives_the_same_detections(models, conf, kw):
+    """Model.nms_filter = conf_thres: the head tails append the candidates of the NMS call that follows to its workspace (maf_engine_run_filtered,
+    MAF_NMS_PRECOLLECTED — yolov6/utils/nms.py:48,69,75-77 folded into the kernels that compute the scores): rows and flat indices bit-identical to
+    the two-step path, for several thresholds, twice in a row on the same slot (workspace reuse), and a call that filters differently (other conf,
+    best-class mode) falls back to its own pass over the prediction."""
+    m = models["n"]
+    x = O.synth_images(2, 640, 5).to(DEV).half()
+    ref_pred = m(x)[0]
+    want, widx = M.non_max_suppression(ref_pred, conf, return_index=True, **kw)
+    m.nms_filter = conf
+    try:
+        small = m(O.synth_images(1, 320, 5).to(DEV).half())[0]              # 10 x 10 level: not a multiple of 16 pixels -> the plain forward
+        assert getattr(small, "_maf_cand", None) is None
+        for _ in range(2):
+            pred = m(x)[0]
+            assert getattr(pred, "_maf_cand", None) is not None and torch.equal(pred, ref_pred)
+            got, gidx = M.non_max_suppression(pred, conf, return_index=True, **kw)
+            assert pred._maf_cand is None                                    # consumed
+            for a_, b_, ia, ib in zip(got, want, gidx, widx):
+                assert torch.equal(a_, b_) and torch.equal(ia, ib)
+        pred = m(x)[0]
+        other = M.non_max_suppression(pred, conf * 2, iou_thres=0.5)         # different filter: the lists are not used
+        assert pred._maf_cand is not None
+        base = M.non_max_suppression(ref_pred, conf * 2, iou_thres=0.5)
+        for a_, b_ in zip(other, base):
+            assert torch.equal(a_, b_)
+        h = M.non_max_suppression_async(m(x)[0], conf, **kw)                 # the serving loop's form, NMS on a side stream
+        for a_, b_ in zip(h.result(), want):
+            assert torch.equal(a_, b_)
+    finally:
+        m.nms_filter = None
+
+
 def test_nms_large_candidate_set_global_sort_path():
     """> 8192 candidates per image: sort runs in global memory; > 30000: top-30000 rule."""
     rs = np.random.RandomState(3)
