@@ -62,6 +62,8 @@ def latency_mode(args, torch, M, dev):
     model = M.Model(args.scale)
     model.load_state_dict(synth.synth_state_dict(model, args.scale, 0))
     model = model.to(dev).eval()
+    if args.lanes >= 0:
+        model.multi_stream = args.lanes
     x = synth.synth_images(1, 640, seed=1).to(dev).half()
     calibrate_cls_bias(model, x, 2000, M, torch)
     plan = model.plan_for(x)

@@ -423,6 +423,43 @@ def test_model_dispatch_ops_traces_as_one_graph_without_a_device(built):
     assert all(("cat" in t) or ("interpolate" in t) or ("getitem" in t) for t in rest), rest
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_weight_pairs_and_pixel_pairs_reproduce_a_depthwise_row(k):
+    """pack.pack_dw_pairs / pack.pairs_from_nhwc against the index algebra of csrc/dwconv_p2.hip, evaluated on the host: output pixel t of a 4-pixel
+    strip takes, per kernel row, the pixel pairs j = m + ((t + e) >> 1) of its window (which starts PE = P + e pixels left of the strip, e = P & 1)
+    with the EVEN weight pairs if t + e is even and the ODD ones otherwise — (k + 1) / 2 two-tap products per row instead of k taps.  Must equal
+    the plain depth-wise convolution (F.conv2d) for every kernel size, both window alignments, all 8 channels of a group."""
+    g = torch.Generator().manual_seed(40 + k)
+    C_, H, W = 16, 6, 12
+    x = torch.randn(1, C_, H, W, generator=g).half().float()
+    w = (torch.randn(C_, 1, k, k, generator=g) / k).half().float()
+    ref = torch.nn.functional.conv2d(x, w, None, 1, k // 2, 1, C_)[0]                    # [C, H, W]
+    wp = pack.pack_dw_pairs(w).float()                                                   # [C/8, k, 2 (h), 2 (set), NP, 4 (d), 2]
+    xp = pack.pairs_from_nhwc(x.permute(0, 2, 3, 1).contiguous())[0].float()             # [H, W/2, C, 2]
+    P = k // 2
+    e = P & 1
+    PE, NP = P + e, (k + 1) // 2
+    assert wp.shape == (C_ // 8, k, 2, 2, NP, 4, 2)
+
+    def pair(y, q, c):                                                                   # the zero page outside the image
+        return xp[y, q, c] if 0 <= y < H and 0 <= q < W // 2 else torch.zeros(2)
+    for cg in range(C_ // 8):
+        for y in range(H):
+            for xs in range(0, W, 4):                                                    # a lane's strip
+                q0 = (xs - PE) // 2                                                      # first pair of its window
+                for t in range(4):
+                    for h in range(2):
+                        for d in range(4):
+                            c = cg * 8 + 4 * h + d
+                            acc = 0.0
+                            for ky in range(k):
+                                for m in range(NP):
+                                    px = pair(y + ky - P, q0 + m + ((t + e) >> 1), c)
+                                    wq = wp[cg, ky, h, (t + e) & 1, m, d]
+                                    acc += float(px[0] * wq[0] + px[1] * wq[1])
+                            assert abs(acc - float(ref[c, y, xs + t])) < 1e-4, (k, c, y, xs + t)
+
+
 def test_build_optimizer_groups_match_the_reference_counts():
     """yolov6/solver/build.py:12-33: BatchNorm weights (no decay), other weights (decay), biases (no decay).  The expected (count, elements) per
     group were read off the reference's own build_optimizer on its n / s / m models in the build container (same parameter names, same order)."""
