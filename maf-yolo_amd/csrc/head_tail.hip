@@ -18,6 +18,10 @@
 #include "lds_pipe.h"
 #include <type_traits>
 
+#ifndef MAF_KO
+#define MAF_KO 0            // profiling builds (make ko KO_SRCS=head_tail.hip): 1 = no activation loads, 2 = no first GEMM, 4 = no SiLU between the GEMMs, 8 = no second GEMM, 16 = no epilogue at all, 32 = no prediction stores
+#endif
+
 namespace {
 
 template <int N, int I = 0, typename F>
@@ -46,7 +50,7 @@ struct HtArgs {
     float cand_conf;
 };
 
-template <int C, int PT>
+template <int C, int PT, bool FILTER = false>      // FILTER: also append the NMS candidates (a separate instantiation: the plain one pays nothing for it)
 __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const HtArgs a) {
     constexpr int KS = C / 32, T1 = C / 16;
     constexpr int W1B = C * C * 2, W2B = 80 * C * 2;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             const int m = min((unit * PT + p) * 16 + n, a.M - 1);                // clamped: loads stay unconditional
             const half_t* px = xb + (size_t)m * xs;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) x[p][ks] = *reinterpret_cast<const half8_t*>(px + 32 * ks);
+            for (int ks = 0; ks < KS; ++ks) { if (MAF_KO & 1) x[p][ks] = (half8_t)(half_t)0.01f; else x[p][ks] = *reinterpret_cast<const half8_t*>(px + 32 * ks); }
         }
     };
     // persistent: the workgroups of a branch walk the 16 * PT-pixel units with the stride of the grid (a.iters rounds, the same for every
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
                 lp_wait_lgkm<ahead>(wr[sl]);
                 const half8_t wa = __builtin_bit_cast(half8_t, wr[sl]);
 #pragma unroll
-                for (int p = 0; p < PT; ++p) acc1[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc1[p][t], 0, 0, 0);
+                for (int p = 0; p < PT; ++p) if (!(MAF_KO & 2)) acc1[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, x[p][ks], acc1[p][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         } else {
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a2[p][j][r] = (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j][r] + bl[r]);
-                    a2[p][j][4 + r] = (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j + 1][r] + bh[r]);
+                    a2[p][j][r] = (MAF_KO & 4) ? (half_t)(acc1[p][2 * j][r] + bl[r]) : (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j][r] + bl[r]);
+                    a2[p][j][4 + r] = (MAF_KO & 4) ? (half_t)(acc1[p][2 * j + 1][r] + bh[r]) : (half_t)maf_act<MAF_ACT_SILU>(acc1[p][2 * j + 1][r] + bh[r]);
                 }
             }
         }
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
                 lp_wait_lgkm<ahead>(wr[sl]);
                 const half8_t wb = __builtin_bit_cast(half8_t, wr[sl]);
 #pragma unroll
-                for (int p = 0; p < PT; ++p) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
+                for (int p = 0; p < PT; ++p) if (!(MAF_KO & 8)) acc2[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p][j], wb, acc2[p][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         } else {
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             });
         }
         // ---- epilogue: through the wave's LDS tile to whole prediction rows
+        if ((MAF_KO & 16) && acc2[0][0][0] != 12345.678f) continue;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m0 = (unit * PT + p) * 16;
@@ -269,40 +274,44 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
             }
             __syncthreads();
             if (br == 0) {
-                unsigned int hits = 0;
-                int mine = 0;
 #pragma unroll
                 for (int q = 0; q < 16 * NC / 64; ++q) {
                     const int e = lane + 64 * q;
                     const int px = e / NC, col = e - px * NC;
                     const int m = m0 + px;
-                    bool ok = false;
                     if (m < a.M) {
                         const int b = m / a.HW, pin = m - b * a.HW;
-                        const float sc = stage[e];
-                        a.out[((size_t)b * a.A + a.lvl_off + pin) * NO + 5 + col] = sc;
-                        ok = a.cand_cnt != nullptr && sc > a.cand_conf;           // nms.py:48, :69, :76 with objectness 1 (written below): score = cls * 1
+                        if (!(MAF_KO & 32)) a.out[((size_t)b * a.A + a.lvl_off + pin) * NO + 5 + col] = stage[e];
                     }
-                    hits |= ok ? 1u << q : 0u;
-                    mine += __popcll(__ballot(ok));                               // wave-uniform running count
                 }
-                if (mine > 0) {                                                   // wave-uniform; the 16 pixels of a unit belong to ONE image (HW % 16 == 0: checked by the launcher)
-                    const int b = m0 / a.HW, pin0 = m0 - b * a.HW;
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&a.cand_cnt[b * MAF_NMS_CNT_STRIDE], mine);
-                    int pos = __shfl(base, 0);
-                    unsigned long long* keys = a.cand_keys + (size_t)b * a.cand_cap;
+                if constexpr (FILTER) {                                           // the candidate filter of the NMS call that follows: a second walk over the tile
+                    unsigned int hits = 0;
+                    int mine = 0;
 #pragma unroll
                     for (int q = 0; q < 16 * NC / 64; ++q) {
-                        const bool ok = (hits >> q) & 1u;
-                        const unsigned long long mk = __ballot(ok);
-                        if (ok) {
-                            const int e = lane + 64 * q;
-                            const int px = e / NC, col = e - px * NC;
-                            const unsigned int flat = (unsigned int)(a.lvl_off + pin0 + px) * (unsigned int)NC + (unsigned int)col;
-                            keys[pos + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(stage[e])) << 32) | flat;
+                        const int e = lane + 64 * q;
+                        const bool ok = m0 + e / NC < a.M && stage[e] > a.cand_conf;  // nms.py:48, :69, :76 with objectness 1 (written by the other branch): score = cls * 1
+                        hits |= ok ? 1u << q : 0u;
+                        mine += __popcll(__ballot(ok));                           // wave-uniform running count
+                    }
+                    if (mine > 0) {                                               // the 16 pixels of a unit belong to ONE image (HW % 16 == 0: checked by the launcher)
+                        const int b = m0 / a.HW, pin0 = m0 - b * a.HW;
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&a.cand_cnt[b * MAF_NMS_CNT_STRIDE], mine);
+                        int pos = __shfl(base, 0);
+                        unsigned long long* keys = a.cand_keys + (size_t)b * a.cand_cap;
+#pragma unroll
+                        for (int q = 0; q < 16 * NC / 64; ++q) {
+                            const bool ok = (hits >> q) & 1u;
+                            const unsigned long long mk = __ballot(ok);
+                            if (ok) {
+                                const int e = lane + 64 * q;
+                                const int px = e / NC, col = e - px * NC;
+                                const unsigned int flat = (unsigned int)(a.lvl_off + pin0 + px) * (unsigned int)NC + (unsigned int)col;
+                                keys[pos + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(stage[e])) << 32) | flat;
+                            }
+                            pos += __popcll(mk);
                         }
-                        pos += __popcll(mk);
                     }
                 }
             } else {
@@ -328,8 +337,10 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
                     const float x1 = ax - lft, y1 = ay - top, x2 = ax + rgt, y2 = ay + bot;
                     float v = side == 0 ? (x1 + x2) * 0.5f : side == 1 ? (y1 + y2) * 0.5f : side == 2 ? x2 - x1 : y2 - y1;
                     float* o = a.out + ((size_t)b * a.A + a.lvl_off + pin) * NO;
+                    if (!(MAF_KO & 32)) {
                     o[side] = v * a.stride;
                     if (side == 0) o[4] = 1.0f;
+                    }
                 }
             }
         }
@@ -370,6 +381,16 @@ int maf_launch_head_tail(const maf_op_t* op, hipStream_t s) {
     a.iters = maf_cdiv(units, 4 * gx);
     gx = maf_cdiv(units, 4 * a.iters);                                             // same rounds, no idle workgroups
     const dim3 grid(gx, 2);
+    if (a.cand_cnt) {
+        switch (op->Cin) {
+            case 64: hipLaunchKernelGGL((head_tail_kernel<64, 2, true>), grid, dim3(256), 0, s, a); break;
+            case 128: hipLaunchKernelGGL((head_tail_kernel<128, 2, true>), grid, dim3(256), 0, s, a); break;
+            case 192: hipLaunchKernelGGL((head_tail_kernel<192, 1, true>), grid, dim3(256), 0, s, a); break;
+            case 256: hipLaunchKernelGGL((head_tail_kernel<256, 1, true>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((head_tail_kernel<384, 1, true>), grid, dim3(256), 0, s, a); break;
+        }
+        return maf_check_hip(hipGetLastError(), "head_tail launch");
+    }
     switch (op->Cin) {
         case 64: hipLaunchKernelGGL((head_tail_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
         case 128: hipLaunchKernelGGL((head_tail_kernel<128, 2>), grid, dim3(256), 0, s, a); break;
