@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m0 = (unit * PT + p) * 16;
-            __syncthreads();                                                      // the tile is free again (uniform trip counts)
+            // the staging tile is PRIVATE to the wave (s_stage[wave]) and a wave's LDS operations execute in program order: nothing to wait for but
+            // the compiler's own reordering — no workgroup barrier, so the four waves drift apart and one wave's epilogue runs under another's GEMMs
+            // (the chunked instantiations keep the barriers: their chunk loop needs the waves in step)
+            if constexpr (WLDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
             if (br == 0) {
 #pragma unroll
                 for (int t = 0; t < NT2; ++t)
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
                         for (int r = 0; r < 4; ++r) stage[(4 * G + r) * NR + 16 * t + n] = acc2[p][t][r] + bias2[t];
                     }
             }
-            __syncthreads();
+            if constexpr (WLDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
             if (br == 0) {
 #pragma unroll
                 for (int q = 0; q < 16 * NC / 64; ++q) {
