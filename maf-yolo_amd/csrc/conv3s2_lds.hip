@@ -132,19 +132,30 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        // the activation is picked once per tile (a switch per VALUE made the epilogue a chain of branches)
+        auto stage_out = [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+            for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                half4_t v;
+                for (int t = 0; t < NT; ++t) {
+                    half4_t v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act_rt(acc[m][t][q] + bv[t][q], a.act);
-                *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * COUT + 16 * t + 4 * g) = v;
-            }
-        __syncthreads();
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<ACT>(acc[m][t][q] + bv[t][q]);
+                    *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * COUT + 16 * t + 4 * g) = v;
+                }
+        };
+        if (a.act == MAF_ACT_SILU) stage_out(std::integral_constant<int, MAF_ACT_SILU>{});
+        else if (a.act == MAF_ACT_RELU) stage_out(std::integral_constant<int, MAF_ACT_RELU>{});
+        else if (a.act == MAF_ACT_NONE) stage_out(std::integral_constant<int, MAF_ACT_NONE>{});
+        else stage_out(std::integral_constant<int, MAF_ACT_SIGMOID>{});
+        // a wave copies out the MR rows it staged itself: its LDS operations execute in order, no workgroup barrier (the one at the top of the
+        // tile loop still separates this tile's readers of s_T from the next tile's writers)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         constexpr int CPP = COUT / 8;
-        for (int q = tid; q < TY * TX * CPP; q += 256) {
-            const int px = q / CPP, part = q - px * CPP;
+        for (int ql = lane; ql < MR * TX * CPP; ql += 64) {
+            const int px = wave * MR * TX + ql / CPP, part = ql % CPP;
             const int oy = Y0 + px / TX, ox = X0 + px % TX;
             if (oy < a.H && ox < a.W)
                 *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + 8 * part) =

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) acc[pt][ct] = F::mma(af[pt][ks], wf[ks][ct], acc[pt][ct]);
             }
+        // the activation is picked once per tile, not per value (a per-value switch turns the epilogue into a chain of branches)
+        auto epilogue = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a) {
                 if (m >= a.M) continue;
                 float v[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act_rt(acc[pt][ct][r], a.act);
+                for (int ct = 0; ct < CT; ++ct) v[ct] = maf_act<ACT>(acc[pt][ct][r]);
                 half_t* op = static_cast<half_t*>(a.out) + (size_t)m * a.out_stride + a.out_coff + cl;
                 if (nvalid >= CT) {
                     uint32_t w[CT / 2];
@@ -85,6 +88,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a) {
                 }
             }
         }
+        };
+        if (a.act == MAF_ACT_SILU) epilogue(std::integral_constant<int, MAF_ACT_SILU>{});
+        else if (a.act == MAF_ACT_NONE) epilogue(std::integral_constant<int, MAF_ACT_NONE>{});
+        else if (a.act == MAF_ACT_RELU) epilogue(std::integral_constant<int, MAF_ACT_RELU>{});
+        else epilogue(std::integral_constant<int, MAF_ACT_SIGMOID>{});
     };
 
     // two register sets alternate: tile t is consumed from one while tile t + wstride lands in the other

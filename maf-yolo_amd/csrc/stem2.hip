@@ -268,10 +268,14 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                     *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * C3 + 16 * t + 4 * g) = v;
                 }
         }
-        __syncthreads();
+        // a wave copies out the MR rows it staged itself (its LDS operations execute in order): no workgroup barrier here; the patch this stage
+        // aliases was last read in phase B, a barrier ago for every wave, and the barrier at the top of the tile loop keeps the next tile's patch
+        // writes behind these reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         constexpr int CPP = CO / 8;                               // 16-byte pieces per pixel
-        for (int q = tid; q < TY * TX * CPP; q += 256) {
-            const int px = q / CPP, part = q - px * CPP;
+        for (int ql = lane; ql < MR * TX * CPP; ql += 64) {
+            const int px = wave * MR * TX + ql / CPP, part = ql % CPP;
             const int oy = Y0 + px / TX, ox = X0 + px % TX;
             if (oy < a.H1 && ox < a.W1 && !(MAF_KO & 4))
                 *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H1 + oy) * a.W1 + ox) * a.out_stride + a.out_coff + 8 * part) =
