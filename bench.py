@@ -580,7 +580,8 @@ def main():
                       (k, g["n"], g["ms"], g["ms"] / g["n"], g["bytes"] / (g["ms"] * 1e-3) / 1e9), file=sys.stderr)
 
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+
+        def cpu_leg():                                  # runs AFTER the training leg: 20 s of all host cores right in front of a host-bound train step cost it up to 15 %
             from oracle import maf_oracle as O          # the CPU restatement: checker / baseline only
             cores = host_cores()
             torch.set_num_threads(cores)
@@ -607,6 +608,7 @@ def main():
                        sample="oracle.predict + oracle.non_max_suppression (fp32, %d torch threads) on 3x640x640 batches of 8 and 32: 3 warm-up + 5 timed runs each, median; "
                               "value = batch %d (%.1f s timed), batch 8: %.2f images/s" % (cores, runs[32]["batch"], runs[32]["seconds"], runs[8]["images_per_s"]),
                        runs={str(k): v for k, v in runs.items()})
+            return cpu
 
         out = {"metric": "images/sec MAF-YOLO-%s 640x640 bs=%d infer (Model.forward + non_max_suppression)" % (args.scale, B),
                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -642,6 +644,8 @@ def main():
         if train is not None:
             train.pop("cpu_baseline", None)
         out["train"] = train
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_leg()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
