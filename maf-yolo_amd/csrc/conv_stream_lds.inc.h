@@ -105,12 +105,28 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
         int m = t * 16 + p;
         m = m < a.M ? m : a.M - 1;
         if constexpr (!MULTI) {
-            const half_t* q = static_cast<const half_t*>(a.src[0]) + (size_t)m * a.srcStride[0] + a.srcCoff[0];
+            if (a.srcMode[0] == MAF_SRC_DIRECT) {                        // (uniform)
+                const half_t* q = static_cast<const half_t*>(a.src[0]) + (size_t)m * a.srcStride[0] + a.srcCoff[0];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                int c = ks * 32 + g * 8;
-                c = c < a.Cin ? c : 0;
-                af[ks] = ldg16<half_t>(q + c);
+                for (int ks = 0; ks < KS; ++ks) {
+                    int c = ks * 32 + g * 8;
+                    c = c < a.Cin ? c : 0;
+                    af[ks] = ldg16<half_t>(q + c);
+                }
+            } else {
+                // MAF_SRC_POOL2 (MPRep's MaxPool2d(2, 2) in front of its 1x1, common.py:1241-1262): the source grid is 2H x 2W and a fragment is the
+                // element-wise maximum of the four pixels of its window; MAF_SRC_SUB2: the window's top-left pixel alone
+                const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;
+                const half_t* q = static_cast<const half_t*>(a.src[0]) + (size_t)((size_t)(bb * 2 * a.H + 2 * y) * (2 * a.W) + 2 * x) * a.srcStride[0] + a.srcCoff[0];
+                const bool one = a.srcMode[0] == MAF_SRC_SUB2;
+                const size_t cs = one ? 0 : (size_t)a.srcStride[0], rs = one ? 0 : (size_t)(2 * a.W) * a.srcStride[0];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    int c = ks * 32 + g * 8;
+                    c = c < a.Cin ? c : 0;
+                    const frag_t v0 = ldg16<half_t>(q + c), v1 = ldg16<half_t>(q + cs + c), v2 = ldg16<half_t>(q + rs + c), v3 = ldg16<half_t>(q + rs + cs + c);
+                    af[ks] = F::vmax(F::vmax(v0, v1), F::vmax(v2, v3));
+                }
             }
         } else {
             const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;

@@ -830,7 +830,7 @@ class Plan:
                         for pt in (1, 2):                                # persistent waves, next tile's activations in flight during the epilogue
                             cands.append((pt, ct, 3))
                     if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and stream_lds_ok(ksteps, ct) \
-                            and all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc)) and (direct or ct >= 4):
+                            and (o.nsrc == 1 or all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc))) and (direct or ct >= 4 or o.nsrc == 1):
                         cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
                     if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and M >= 65536:
                         for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)

@@ -260,6 +260,19 @@ def test_conv1x1_maxpool_source(dt):
     _launch(_conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, [(_nhwc(x, dt), cin, cin, 0, lib.SRC_POOL2)], out, cout, 0,
                      pack.pack_conv1x1(w, [cin], 4, dt).to(DEV), pack.pack_bias(bias, 4).to(DEV), 1, 4))
     _check(out, ref, dt)
+    if dt == lib.F16:
+        # the same layer on the persistent kernel with the weights in LDS (tile_k = 5): pooled and sub-sampled (1x1 stride 2) single sources, a slice of a wider buffer
+        for ct in (2, 4, 6):
+            for mode, xin in ((lib.SRC_POOL2, F.max_pool2d(x, 2, 2)), (lib.SRC_SUB2, x[:, :, ::2, ::2])):
+                xs = torch.zeros(B, 2 * H, 2 * W, cin + 16, dtype=torch.float16, device=DEV)
+                xs[..., 8:8 + cin] = _nhwc(x, dt)
+                out5 = torch.full((B, H, W, cout + 8), 5.0, dtype=torch.float16, device=DEV)
+                op = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, [(xs, cin, cin + 16, 8, mode)], out5, cout + 8, 8,
+                              pack.pack_conv1x1(w, [cin], ct, dt).to(DEV), pack.pack_bias(bias, ct).to(DEV), 1, ct)
+                op.tile_k = 5
+                _launch(op)
+                _check(out5[..., 8:], F.silu(F.conv2d(xin, w, bias)), dt)
+                assert (out5[..., :8] == 5).all()
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])
