@@ -56,7 +56,7 @@ def stream_lds_ok(ksteps, ct):
     """Instantiations of the persistent 1x1 conv with LDS-resident weights (tile_k = 5: csrc/conv_stream_lds.hip, conv_stream_lds_wide.hip)."""
     if 2 <= ksteps <= 12:
         return ksteps * ct <= 96
-    return ct in (4, 8) and (13 <= ksteps <= 20 or ksteps == 24) and ksteps * ct <= 160
+    return ct in (4, 6, 8) and (13 <= ksteps <= 20 or ksteps == 24) and ksteps * ct <= 160
 
 
 def save_tune_cache(path):

@@ -170,7 +170,7 @@ def test_conv1x1_persistent_stream(cin, cout, pt, ct, act):
     assert (out[..., :coff] == 7).all() and (out[..., coff + cout:] == 7).all(), "wrote outside its slice"
 
 
-@pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2),
+@pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2), ("direct", 576, 192, 6), ("direct", 768, 96, 6),
                                               ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4)])
 def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     """tile_k = 5: persistent waves with the channel tile's weights resident in LDS; single source or concat (with upsample)."""
