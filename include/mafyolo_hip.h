@@ -112,7 +112,10 @@ typedef struct {
  *                   ksize = C0 (channels of backbone.0), Cout = C1: (24, 48) or (32, 64); nc = C3: 0, or C1 to also apply the 1x1 conv + SiLU
  *                   that opens the next RepHDW block (backbone.2.conv1, common.py:898-946) before anything is written — out then receives
  *                   C3 channels; w = record of maf_stem2_record_bytes(C0, C1, C3) bytes (maf-yolo_amd/pack.py:pack_stem2); fp16 engine only;
- *                   tile_p = tile rows (0 / 8, or 4), tile_k = workgroups (0 = default, persistent).
+ *                   tile_p = tile rows (0 / 8, or 4), tile_k = workgroups (0 = default, persistent).  aux[0] != NULL (needs nc = C1): RepHDW
+ *                   splits that tensor in two (chunk(2), common.py:930) — channels C3/2.. then go to aux[0], a tensor of its own with
+ *                   pixel stride reg_stride (elements, a multiple of 8), and out receives channels 0..C3/2-1: a reader of ONE half then
+ *                   fetches whole cache lines of what it uses instead of every line of an interleaved buffer.
  * MAF_OP_HEADTAIL   replaces, for ONE level, cls_conv_s + cls_pred + sigmoid and reg_conv_s + reg_pred (Head_DepthUni, common.py:1288-1336:
  *                   Conv.forward_fuse, nn.Conv2d) and that level's share of the Detect_yaml eval branch (yolo.py:355-396) in one launch.
  *                   src[0] / src[1] = inputs of cls_conv_s / reg_conv_s (C = Cin = head width: 64, 128, 192 — weights LDS-resident — or 256, 384 — weights streamed from L2); w / aux[0] = weight

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
     for (int ct = 0; ct < CT; ++ct) bias[ct] = a.bias[cl + ct];
     const int nvalid = a.Cout - cl;
 
+    bool up_any = false;
+    if constexpr (MULTI) up_any = a.srcMode[0] == MAF_SRC_UP2 || (a.nsrc > 1 && a.srcMode[1] == MAF_SRC_UP2) || (a.nsrc > 2 && a.srcMode[2] == MAF_SRC_UP2) || (a.nsrc > 3 && a.srcMode[3] == MAF_SRC_UP2);
     // per k-step: which source, which channel chunk (scalar; steps past a source's last chunk read chunk 0 x zero weights)
     auto load_tile = [&](int t, frag_t (&af)[KS]) {
         if (MAF_KO & 2) {
@@ -129,13 +131,17 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
                 }
             }
         } else {
-            const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;
+            size_t pix_up = (size_t)m;                                   // the pixel of a nearest-neighbour up-sampled source: only worked out (three
+            if (up_any) {                                                // divisions per tile) when the launch has one (uniform)
+                const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;
+                pix_up = (size_t)((bb * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1));
+            }
             const half_t* q[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const half_t* base = static_cast<const half_t*>(a.src[s < a.nsrc ? s : 0]);
                 const int si = s < a.nsrc ? s : 0;
-                const size_t pix = a.srcMode[si] == MAF_SRC_UP2 ? (size_t)((bb * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) : (size_t)m;
+                const size_t pix = a.srcMode[si] == MAF_SRC_UP2 ? pix_up : (size_t)m;
                 q[s] = base + pix * a.srcStride[si] + a.srcCoff[si];
             }
 #pragma unroll

@@ -26,6 +26,8 @@ struct S2Args {
     const void* img;          // [B,3,Hin,Win]
     const char* rec;          // pack_stem2 record
     half_t* out;              // [B,H1,W1,out_stride]
+    half_t* out2;             // optional: the upper half of the channels as a tensor of its own [B,H1,W1,out2_stride] (RepHDW's chunk(2), common.py:930)
+    int out2_stride;
     int B, Hin, Win, H0, W0, H1, W1, out_stride, out_coff, tilesX, tilesY, ntiles;
     float in_scale;
 };
@@ -115,8 +117,16 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
             if (MAF_KO & 8) pf[u] = raw_t{}; else pf[u] = *reinterpret_cast<const raw_t*>(img + at);
         }
     };
-    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // XCD-contiguous tile order: workgroups go to the 8 XCDs round-robin, and a tile shares the 128-byte lines of its left halo column and its
+    // three halo rows with its neighbours — an XCD walks ONE contiguous eighth of the tiles, its resident workgroups a window of consecutive
+    // tiles (several tile rows), so those lines are hits in that XCD's L2 instead of a second fetch through another one
+    int t_first = blockIdx.x, t_end = a.ntiles, t_step = gridDim.x;
+    if ((gridDim.x & 7) == 0 && !(MAF_KO & 128)) {
+        const int xcd = blockIdx.x & 7, q = a.ntiles >> 3, r = a.ntiles & 7, base = xcd * q + min(xcd, r);
+        t_first = base + (int)(blockIdx.x >> 3); t_end = base + q + (xcd < r ? 1 : 0); t_step = gridDim.x >> 3;
+    }
+    if (t_first < t_end) prefetch(t_first);
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
         const int Y0 = ty * TY, X0 = tx * TX;
         __syncthreads();                                         // s_in (= the previous tile's output stage) and s_T are free; first pass: s_w1 is in place
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+        if (tile + t_step < t_end) prefetch(tile + t_step);
         // ---- B: stem outputs of the tile on the matrix cores, computed transposed (A = weights, B = gathered taps) so that a lane ends
         //      up with 4 consecutive channels of ONE pixel: one 8-byte LDS store per 16-channel tile
         //      Three stages in flight per wave (hipcc orders gather -> wait -> MFMA -> wait -> epilogue per tile: two exposed round trips, nine
@@ -277,9 +287,12 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
         for (int ql = lane; ql < MR * TX * CPP; ql += 64) {
             const int px = wave * MR * TX + ql / CPP, part = ql % CPP;
             const int oy = Y0 + px / TX, ox = X0 + px % TX;
-            if (oy < a.H1 && ox < a.W1 && !(MAF_KO & 4))
-                *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H1 + oy) * a.W1 + ox) * a.out_stride + a.out_coff + 8 * part) =
-                    *reinterpret_cast<const uint4*>(s_out + px * CO + 8 * part);
+            if (oy < a.H1 && ox < a.W1 && !(MAF_KO & 4)) {
+                const size_t pix = (size_t)(b * a.H1 + oy) * a.W1 + ox;
+                half_t* dst = a.out + pix * a.out_stride + a.out_coff + 8 * part;
+                if (a.out2 && part >= CPP / 2) dst = a.out2 + pix * a.out2_stride + 8 * (part - CPP / 2);   // two dense halves: whole lines for the slice readers
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(s_out + px * CO + 8 * part);
+            }
         }
     }
 }
@@ -306,6 +319,9 @@ int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     a.H1 = (a.H0 - 1) / 2 + 1; a.W1 = (a.W0 - 1) / 2 + 1;
     MAF_REQUIRE(op->Hin > 0 && op->Win > 0 && op->Win % 4 == 0 && a.H1 == op->H && a.W1 == op->W, "stem2: H,W must be the twice-halved image size, image width a multiple of 4");
     a.out_stride = op->out_stride; a.out_coff = op->out_coff;
+    a.out2 = static_cast<half_t*>(const_cast<void*>(op->aux[0])); a.out2_stride = op->reg_stride;
+    MAF_REQUIRE(!a.out2 || (op->nc == op->Cout && op->Cout % 16 == 0 && op->reg_stride % 8 == 0 && op->reg_stride >= op->Cout / 2),
+                "stem2: a second output (aux[0] = the upper half of the channels, reg_stride = its pixel stride, a multiple of 8) needs the third conv");
     const int ty_rows = op->tile_p == 4 ? 4 : 8;                  // tile height of the quarter-resolution map (tile_p: 0 / 8 = 8 rows, 4 = 4 rows: less LDS and registers, more halo)
     a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, ty_rows); a.ntiles = a.B * a.tilesX * a.tilesY;
     a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;

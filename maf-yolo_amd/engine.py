@@ -9,6 +9,7 @@ max-pool of MPRep never become ops: they turn into operand addressing of the con
 (`TV` segments below), and SPPF's three max-pools write straight into the concat buffer.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -178,6 +179,7 @@ class Plan:
         fs = getattr(model, "fuse_stem", True)                   # False | 1: backbone.0 + backbone.1 | True / 2: + the 1x1 that opens backbone.2
         self.fuse_stem = (2 if fs is True else int(fs or 0)) if dtype == lib.F16 else 0
         self._stem2 = self._stem3 = None
+        self.split_cat = bool(getattr(model, "split_cat", os.environ.get("MAF_SPLIT_CAT", "1") != "0"))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
             self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
@@ -315,27 +317,40 @@ class Plan:
                 y.append(TV([Seg(out, node.cout)], out.H, out.W))
             elif node.kind == "rephdw":
                 c_, depth = m.c_, len(m.m)
-                cat = self._alloc(x.H, x.W, c_ * (depth + 2))
+                # slot j of the concatenation (cv1's two halves, then one per block: common.py:930-935).  One interleaved buffer [.., (depth + 2) c_] —
+                # or, behind the fused stem (the only producer that can write its two halves to two places), one DENSE tensor per slot: a block reads
+                # and writes c_-channel slices, and out of an interleaved buffer whose slices are not whole 128-byte lines it fetches every line of the
+                # buffer for a third of its bytes (bottleneck<3,1,2> on 160 x 160 x 72: 121 MB fetched for 39 MB, +13 MB of partial-line writes)
+                split = (node.i == 2 and self._stem3 is not None and self.split_cat and depth + 2 <= 4 and c_ % 8 == 0
+                         and (c_ * self.es) % 128 != 0 and m.conv1.fused()[0].shape[0] == 2 * c_)
+                if split:
+                    slot = [(self._alloc(x.H, x.W, c_), 0) for _ in range(depth + 2)]
+                else:
+                    cat = self._alloc(x.H, x.W, c_ * (depth + 2))
+                    slot = [(cat, j * c_) for j in range(depth + 2)]
                 if node.i == 2 and self._stem3 is not None:
                     w0, b0, c0, w1_, b1_, c1 = self._stem3
                     w3, b3 = m.conv1.fused()
                     self._ops.append(dict(kind=lib.OP_STEM2, name="backbone.0+1+2.conv1", act=lib.ACT_RELU, H=x.H, W=x.W, Hin=self.Hin, Win=self.Win,
-                                          Cin=3, Cout=c1, ksize=c0, c3=w3.shape[0], segs=[], out=cat, out_coff=0,
+                                          Cin=3, Cout=c1, ksize=c0, c3=w3.shape[0], segs=[], out=slot[0][0], out_coff=0,
                                           w=self._wput(pack.pack_stem2(w0, b0, w1_, b1_, w3, b3)), b=0))
+                    if split:
+                        self._ops[-1]["out2"] = slot[1][0]
                 else:
                     self._conv1x1(p + ".conv1", *m.conv1.fused(), x, cat, 0, lib.ACT_SILU)
                 for d, blk in enumerate(m.m):
                     mid = blk.conv1.conv.out_channels
                     q = "%s.m.%d" % (p, d)
                     mode = self._fuse_mode(q, blk.conv2.dwconv.kernel_size, c_)
+                    (ib, ic), (ob, oc) = slot[d + 1], slot[d + 2]
                     if mode == 2:
                         # conv1 + depth-wise in one launch (the 3c-wide T1 stays in LDS), then the plain 1x1
                         rec, nmb = pack.pack_conv1dw(*blk.conv1.fused(), *blk.conv2.fused())
                         t2 = self._alloc(x.H, x.W, mid)
                         self._ops.append(dict(kind=lib.OP_CONV1DW, name=q + ".conv1dw", act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=mid,
-                                              ksize=blk.conv2.dwconv.kernel_size, segs=[Seg(cat, c_, (d + 1) * c_)], out=t2, out_coff=0, w=self._wput(rec),
+                                              ksize=blk.conv2.dwconv.kernel_size, segs=[Seg(ib, c_, ic)], out=t2, out_coff=0, w=self._wput(rec),
                                               b=self._wput(torch.zeros(8))))
-                        self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), cat, (d + 2) * c_, lib.ACT_SILU)
+                        self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), ob, oc, lib.ACT_SILU)
                         continue
                     if mode == 1:
                         # the whole DepthBottleneckUni in one launch; its 3c-channel intermediates stay in LDS
@@ -343,15 +358,16 @@ class Plan:
                         k = blk.conv2.dwconv.kernel_size
                         th, tw = 16, 16                                   # fixed by the MFMA shapes of csrc/bottleneck.hip
                         self._ops.append(dict(kind=lib.OP_BOTTLENECK, name=q, act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=c_, ksize=k, mid=mid,
-                                              segs=[Seg(cat, c_, (d + 1) * c_)], out=cat, out_coff=(d + 2) * c_, pt=th, ct=tw, tk=nmb,
+                                              segs=[Seg(ib, c_, ic)], out=ob, out_coff=oc, pt=th, ct=tw, tk=nmb,
                                               w=self._wput(rec), b=self._wput(b2p), aux=[]))
                         continue
                     t1, t2 = self._alloc(x.H, x.W, mid), self._alloc(x.H, x.W, mid)
-                    self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(cat, c_, (d + 1) * c_)], x.H, x.W), t1, 0, lib.ACT_SILU)
+                    self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(ib, c_, ic)], x.H, x.W), t1, 0, lib.ACT_SILU)
                     self._dw(q + ".conv2", *blk.conv2.fused(), TV([Seg(t1, mid)], x.H, x.W), t2, lib.ACT_SILU)
-                    self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), cat, (d + 2) * c_, lib.ACT_SILU)
+                    self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), ob, oc, lib.ACT_SILU)
                 out = self._alloc(x.H, x.W, node.cout)
-                self._conv1x1(p + ".conv2", *m.conv2.fused(), TV([Seg(cat, c_ * (depth + 2))], x.H, x.W), out, 0, lib.ACT_SILU)
+                cat_tv = TV([Seg(b_, c_, 0) for b_, _ in slot], x.H, x.W) if split else TV([Seg(cat, c_ * (depth + 2))], x.H, x.W)
+                self._conv1x1(p + ".conv2", *m.conv2.fused(), cat_tv, out, 0, lib.ACT_SILU)
                 y.append(TV([Seg(out, node.cout)], x.H, x.W))
             elif node.kind == "mprep":
                 assert len(x.segs) == 1 and x.segs[0].mode == lib.SRC_DIRECT
@@ -516,6 +532,8 @@ class Plan:
                 writes.setdefault(id(r["out"]), []).append((r["out_coff"], r["out_coff"] + r["Cout"], i))
             if "twin" in r:
                 writes.setdefault(id(r["twin"]["out"]), []).append((0, r["Cout"], i))
+            if "out2" in r:
+                writes.setdefault(id(r["out2"]), []).append((0, r["Cout"], i))
             last_on_lane[lane] = i
 
     # ---------------------------------------------------------------- materialise
@@ -568,6 +586,9 @@ class Plan:
                 o.src[0].C = 3
             if r["kind"] == lib.OP_STEM2:
                 o.nc = r.get("c3", 0)
+                if "out2" in r:              # the upper half of the channels as a tensor of its own
+                    o.aux[0] = abase + r["out2"].off
+                    o.reg_stride = r["out2"].stride
             if r["kind"] == lib.OP_HEADTAIL:
                 lvl = r["level"]
                 o.Hin, o.Win = sum(t.H * t.W for t, _, _ in self.head_bufs[:lvl]), self.A

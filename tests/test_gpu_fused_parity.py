@@ -124,6 +124,19 @@ def test_stem2_vs_fp32_torch(cfg, third, B, H, W, dt, rows):
     err = (got - ref).abs().max().item()
     assert err <= 2e-3 * scale + 2e-3, (err, scale)
     assert (out[..., :16] == 3.0).all() and (out[..., 16 + C1:] == 3.0).all()
+    if third:
+        # two outputs (aux[0] = the upper half of the channels as a tensor of its own: RepHDW's chunk(2), common.py:930): the same values, bit for bit
+        lo = torch.full((B, H1, W1, C1 // 2), 3.0, dtype=torch.float16, device=DEV)
+        hi = torch.full((B, H1, W1, C1 // 2 + 8), 3.0, dtype=torch.float16, device=DEV)
+        op.out, op.out_stride, op.out_coff = lo.data_ptr(), C1 // 2, 0
+        op.aux[0], op.reg_stride = hi.data_ptr(), C1 // 2 + 8
+        _launch(op)
+        assert torch.equal(lo, out[..., 16:16 + C1 // 2]) and torch.equal(hi[..., :C1 // 2], out[..., 16 + C1 // 2:16 + C1]) and (hi[..., C1 // 2:] == 3.0).all()
+        op.reg_stride = C1 // 2 - 8                     # too short for the half
+        assert lib.load().maf_op_launch(C.byref(op), torch.cuda.current_stream().cuda_stream) != 0
+    else:
+        op.aux[0], op.reg_stride = out.data_ptr(), C1   # a second output needs the third conv
+        assert lib.load().maf_op_launch(C.byref(op), torch.cuda.current_stream().cuda_stream) != 0
 
 
 def _iou(a, b):

@@ -383,23 +383,30 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
         # the tensor all three modes materialise: the output of backbone.2.conv1 = the first channels of node 2's concat buffer
         o = plan.ops[[i for i, nme in enumerate(plan.op_names) if nme.endswith("2.conv1")][0]]
         c3 = o.nc if o.kind == 9 else o.Cout
-        off = o.out - plan.arena.data_ptr()
-        taps[fs] = plan.arena[off:off + B * (H // 4) * (W // 4) * o.out_stride * 2].view(torch.float16).view(B, H // 4, W // 4, o.out_stride)[..., :c3].float().cpu().numpy()
+        def rd(ptr, stride, c):
+            off = ptr - plan.arena.data_ptr()
+            return plan.arena[off:off + B * (H // 4) * (W // 4) * stride * 2].view(torch.float16).view(B, H // 4, W // 4, stride)[..., :c].float().cpu()
+        if o.kind == 9 and o.aux[0]:               # the fused stem hands the two halves (RepHDW's chunk(2)) to two dense tensors
+            taps[fs] = torch.cat([rd(o.out, o.out_stride, c3 // 2), rd(o.aux[0], o.reg_stride, c3 // 2)], -1).numpy()
+        else:
+            taps[fs] = rd(o.out, o.out_stride, c3).numpy()
     assert nops[2] == nops[0] - 2 and nops[1] == nops[0] - 1
     # the 4-row tile variant (tile_p = 4: what the autotuner may pick) computes every output pixel with the same operations: bitwise equal
     m.fuse_stem = True
     plan8 = m.plan_for(x)
     o8 = plan8.ops[0]
     assert o8.kind == 9
-    nbytes = B * (H // 4) * (W // 4) * o8.out_stride * 2
-    off = o8.out - plan8.arena.data_ptr()
+    spans = [(o8.out - plan8.arena.data_ptr(), B * (H // 4) * (W // 4) * o8.out_stride * 2)]
+    if o8.aux[0]:
+        spans.append((o8.aux[0] - plan8.arena.data_ptr(), B * (H // 4) * (W // 4) * o8.reg_stride * 2))
     res = []
     for rows, wgs in ((8, 0), (4, 300)):
         o8.tile_p, o8.tile_k = rows, wgs
-        plan8.arena[off:off + nbytes].zero_()
+        for off, nbytes in spans:
+            plan8.arena[off:off + nbytes].zero_()
         plan8.launch_op(0, image_ptr=x.contiguous().data_ptr())
         torch.cuda.synchronize()
-        res.append(plan8.arena[off:off + nbytes].clone())
+        res.append(torch.cat([plan8.arena[off:off + nbytes] for off, nbytes in spans]))
     o8.tile_p, o8.tile_k = 0, 0
     assert torch.equal(res[0], res[1]) and res[0].any()
     for fs in (2, 1):
