@@ -76,6 +76,10 @@ typedef struct {
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
  *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
  *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).
+ *                   With nc = C1 > 0 ((Cin, Cout, C1) = (48, 48, 48) or (64, 64, 64), even Hin / Win) the launch is a whole MPRep (common.py:1241-1262,
+ *                   cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 windows of a tile's pixels lie inside its staged patch, so the pooled
+ *                   1x1 + SiLU branch is taken from LDS and its C1 channels go to `out` at channel offset reg_stride (beside the conv's
+ *                   out_coff .. + Cout); w = record of maf_mprep_lds_record_bytes(Cin, Cout, C1) bytes (pack.py:pack_mprep_lds).
  *                   tile_k = 7 (fp16; (Cin, Cout) = (128, 128), (96, 96), (96, 64), (64, 64)): one workgroup per CU whose waves keep ALL weight
  *                   fragments in registers, input patches of 4 x 8 output tiles by DMA, double-buffered (csrc/conv3s2_wreg.hip); w = record of
  *                   maf_conv3s2_wreg_record_bytes(Cin, Cout) bytes (pack.py:pack_conv3x3_wreg), bias unused, tile_c = workgroups per conv / 32
@@ -167,6 +171,8 @@ int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
 int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);
 int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout);
+/* ... with the pooled 1x1 branch of MPRep behind it (MAF_OP_CONV3X3S2, tile_k = 6, nc = C1; maf-yolo_amd/pack.py:pack_mprep_lds). */
+int64_t maf_mprep_lds_record_bytes(int32_t Cin, int32_t Cout, int32_t C1);
 int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout);   /* 0: no instantiation for this shape */
 
 /* Launch one op on `stream`. */

@@ -6,6 +6,9 @@
 // pixel-major with a 2 * odd dword stride so the stride-2 fragment reads of 16 lanes cover all 64 banks).  The product is taken as in
 // csrc/stem2.hip phase C: K = 9 taps x Cin / 8 (tap, 8-channel group) pairs, four pairs per MFMA k-step, transposed (A = weights,
 // B = patch) so a lane holds 4 consecutive output channels of one pixel; bias + activation, through LDS, whole NHWC pixels out.
+// C1 > 0: MPRep in ONE launch (common.py:1241-1262: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 windows of the tile's output pixels lie
+// inside the staged patch, so the pooled 1x1 + SiLU branch is taken from LDS — its (few) weight fragments live in registers — and its C1 channels
+// go to the other half of the output pixels; the input is read from HBM once instead of twice.
 #include "maf_common.h"
 #include "lds_pipe.h"
 
@@ -14,10 +17,13 @@ namespace {
 struct C3Args {
     const half_t* in; const char* rec; half_t* out;
     int B, Hin, Win, H, W, in_stride, in_coff, out_stride, out_coff, act, tilesX, tilesY, ntiles;
+    int out1_coff;                                               // C1 > 0: channel offset of the pooled branch's output
 };
 
-template <int CIN, int COUT, int TY>
+template <int CIN, int COUT, int TY, int C1>
 __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CIN / 2 + 2) | 2) * 4 + TY * 16 * COUT * 2) <= 80 * 1024 ? 2 : 1) void conv3s2_lds_kernel(const C3Args a) {
+    static_assert(C1 % 16 == 0 && C1 <= COUT, "the pooled branch is staged through the conv's own output stage");
+    constexpr int KS1 = (CIN + 31) / 32, NT1 = C1 / 16;
     constexpr int MR = TY / 4, TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC;
     constexpr int GR = CIN / 8, NP = 9 * GR, KS = (NP + 3) / 4, NT = COUT / 16;
     constexpr int TS = (CIN / 2 + 2) | 2;                        // pixel stride in dwords: 2 * odd
@@ -36,6 +42,18 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
     f32x4_t bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4_t*>(bias + 16 * t + 4 * g);
+    // pooled branch: weight fragments [KS1][NT1][64][8] f16 and the bias behind the conv's record; lane (g, n) of k-step s: output channel 16t + n,
+    // input channels 32s + 8g .. + 7 (zero rows past CIN)
+    half8_t w1f[KS1 * NT1 > 0 ? KS1 * NT1 : 1];
+    f32x4_t b1v[NT1 > 0 ? NT1 : 1];
+    if constexpr (C1 > 0) {
+        const half8_t* w1g = reinterpret_cast<const half8_t*>(a.rec + WB + COUT * 4);
+#pragma unroll
+        for (int i = 0; i < KS1 * NT1; ++i) w1f[i] = w1g[i * 64 + lane];
+        const float* bias1 = reinterpret_cast<const float*>(a.rec + WB + COUT * 4 + KS1 * NT1 * 1024);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) b1v[t] = *reinterpret_cast<const f32x4_t*>(bias1 + 16 * t + 4 * g);
+    }
     int off1[KS];                                                // patch offsets (halves) of this lane's (tap, group) pair in every k-step
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -161,6 +179,58 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
                 *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + 8 * part) =
                     *reinterpret_cast<const uint4*>(s_out + px * COUT + 8 * part);
         }
+        if constexpr (C1 > 0) {
+            // ---- the pooled branch: SiLU(W1 . max over the 2 x 2 window + b1).  Output pixel (r, n) of the tile <- patch pixels (2r + 1 + dy, 2n + 1 + dx)
+            // (the patch starts one pixel up and left of the tile's first window); the patch is still in place: the next tile's writers wait behind
+            // the barrier at the top of the loop.
+            f32x4_t acc1[MR][NT1];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) acc1[m][t] = b1v[t];
+                const half_t* p00 = s_T + ((2 * (wave * MR + m) + 1) * SC + 2 * n + 1) * TSH;
+#pragma unroll
+                for (int s_ = 0; s_ < KS1; ++s_) {
+                    const int gg = min(4 * s_ + g, GR - 1);          // groups past CIN meet zero weights; stay inside the pixel's CIN halves
+                    half8_t v[4];
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_) {
+                        const uint2* q = reinterpret_cast<const uint2*>(p00 + ((w_ >> 1) * SC + (w_ & 1)) * TSH + 8 * gg);   // 8-byte aligned
+                        const uint2 lo = q[0], hi = q[1];
+                        v[w_] = __builtin_bit_cast(half8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
+                    half8_t mx;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const half_t a0 = v[0][j] > v[1][j] ? v[0][j] : v[1][j], a1 = v[2][j] > v[3][j] ? v[2][j] : v[3][j];
+                        mx[j] = a0 > a1 ? a0 : a1;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) acc1[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[s_ * NT1 + t], mx, acc1[m][t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's copy-out reads of the conv's rows are done before it restages
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) {
+                    half4_t v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<MAF_ACT_SILU>(acc1[m][t][q]);
+                    *reinterpret_cast<half4_t*>(s_out + ((wave * MR + m) * TX + n) * COUT + 16 * t + 4 * g) = v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int CPP1 = C1 / 8;
+            for (int ql = lane; ql < MR * TX * CPP1; ql += 64) {
+                const int px = wave * MR * TX + ql / CPP1, part = ql % CPP1;
+                const int oy = Y0 + px / TX, ox = X0 + px % TX;
+                if (oy < a.H && ox < a.W)
+                    *reinterpret_cast<uint4*>(a.out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out1_coff + 8 * part) =
+                        *reinterpret_cast<const uint4*>(s_out + px * COUT + 8 * part);
+            }
+        }
     }
 }
 
@@ -169,6 +239,11 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
 extern "C" int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout) {
     const int ks = (9 * (Cin / 8) + 3) / 4;
     return (int64_t)ks * (Cout / 16) * 64 * 16 + Cout * 4;
+}
+
+// ... with the pooled 1x1 branch of MPRep (C1 output channels) behind it: fragments [ceil(Cin / 32)][C1 / 16][64][8] f16 | bias fp32 [C1]
+extern "C" int64_t maf_mprep_lds_record_bytes(int32_t Cin, int32_t Cout, int32_t C1) {
+    return maf_conv3s2_lds_record_bytes(Cin, Cout) + (int64_t)((Cin + 31) / 32) * (C1 / 16) * 64 * 16 + C1 * 4;
 }
 
 int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s) {
@@ -183,11 +258,20 @@ int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s) {
     a.in = static_cast<const half_t*>(sr.ptr); a.rec = static_cast<const char*>(op->w); a.out = static_cast<half_t*>(op->out);
     a.B = op->B; a.Hin = op->Hin; a.Win = op->Win; a.H = op->H; a.W = op->W;
     a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff; a.act = op->act;
+    a.out1_coff = op->reg_stride;
+    if (op->nc) {                                                 // MPRep: the MaxPool2d(2, 2) + 1x1 + SiLU branch rides along (nc = its channels, reg_stride = where they go)
+        MAF_REQUIRE((op->Cin == 48 || op->Cin == 64) && op->Cout == op->Cin && op->nc == op->Cin, "conv3x3s2 (tile_k = 6): the pooled 1x1 branch exists for 48 -> 48 + 48 and 64 -> 64 + 64");
+        MAF_REQUIRE(op->Hin == 2 * op->H && op->Win == 2 * op->W, "conv3x3s2 (tile_k = 6) with the pooled branch: even input size (MaxPool2d(2, 2) windows)");
+        MAF_REQUIRE(op->reg_stride >= 0 && op->reg_stride % 8 == 0 && (op->reg_stride + op->nc <= op->out_coff || op->reg_stride >= op->out_coff + op->Cout)
+                    && op->reg_stride + op->nc <= op->out_stride, "conv3x3s2 (tile_k = 6): the pooled branch's channels (reg_stride = their offset) must lie beside the conv's");
+    }
     const int ty = 4;                                             // 4 x 16 output tiles
     a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, ty); a.ntiles = a.B * a.tilesX * a.tilesY;
     const dim3 grid(std::min(a.ntiles, op->tile_c > 0 ? op->tile_c * 64 : 256)), blk(256);
-#define MAF_C3(CI, CO) hipLaunchKernelGGL((conv3s2_lds_kernel<CI, CO, 4>), grid, blk, 0, s, a)
-    if (op->Cin == 48 && op->Cout == 48) MAF_C3(48, 48);
+#define MAF_C3(CI, CO) hipLaunchKernelGGL((conv3s2_lds_kernel<CI, CO, 4, 0>), grid, blk, 0, s, a)
+    if (op->nc == 48) hipLaunchKernelGGL((conv3s2_lds_kernel<48, 48, 4, 48>), grid, blk, 0, s, a);
+    else if (op->nc == 64) hipLaunchKernelGGL((conv3s2_lds_kernel<64, 64, 4, 64>), grid, blk, 0, s, a);
+    else if (op->Cin == 48 && op->Cout == 48) MAF_C3(48, 48);
     else if (op->Cin == 48 && op->Cout == 64) MAF_C3(48, 64);
     else if (op->Cin == 64 && op->Cout == 64) MAF_C3(64, 64);
     else { maf_set_error("conv3x3s2 (tile_k = 6): (Cin, Cout) must be (48, 48), (48, 64) or (64, 64)"); return MAF_E_UNSUPPORTED; }

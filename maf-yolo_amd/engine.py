@@ -179,6 +179,10 @@ class Plan:
         fs = getattr(model, "fuse_stem", True)                   # False | 1: backbone.0 + backbone.1 | True / 2: + the 1x1 that opens backbone.2
         self.fuse_stem = (2 if fs is True else int(fs or 0)) if dtype == lib.F16 else 0
         self._stem2 = self._stem3 = None
+        # MPRep's two branches in one launch where the kernel exists: True / False / "auto" = in tuned plans only (the untuned default plan keeps one
+        # launch list for every batch size, so that an image's rows do not depend on how many images ran beside it — the fused kernel sums in another order)
+        fm = getattr(model, "fuse_mprep", "auto")
+        self.fuse_mprep = (bool(getattr(model, "autotune", False)) if fm == "auto" else bool(fm)) and os.environ.get("MAF_FUSE_MPREP", "1") != "0"
         self.split_cat = bool(getattr(model, "split_cat", os.environ.get("MAF_SPLIT_CAT", "1") != "0"))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
@@ -374,6 +378,18 @@ class Plan:
                 c_ = node.cout // 2
                 out = self._alloc(x.H // 2, x.W // 2, node.cout)
                 s0 = x.segs[0]
+                w1_, b1_ = m.conv1.fused()
+                if self.fuse_mprep and self.dtype == lib.F16 and (x.C, c_, w1_.shape[0]) in ((48, 48, 48), (64, 64, 64)) and x.H % 2 == 0 and x.W % 2 == 0 \
+                        and self.B * (x.H // 2) * (x.W // 2) >= 65536:
+                    # (big maps only — at bs 1 its 100 workgroups each pay the 42 KB weight prologue: n forward 0.702 -> 0.724 ms)
+                    # both branches in ONE launch (csrc/conv3s2_lds.hip with nc): the 2 x 2 windows of the pooled branch lie inside the patch the
+                    # 3x3 stride-2 conv stages in LDS anyway, so the input (78.6 MB at n / bs 32) is read once instead of twice
+                    w2_, b2_ = m.conv2.fused()
+                    self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=p + ".conv1+conv2", act=lib.ACT_RELU, H=x.H // 2, W=x.W // 2, Hin=x.H, Win=x.W, Cin=x.C, Cout=c_,
+                                          raw=(w2_.detach().float().cpu(), b2_.detach().float().cpu(), None), pool1=(w1_.detach().float().cpu(), b1_.detach().float().cpu()),
+                                          segs=x.segs, out=out, out_coff=c_, out_f32=0, pt=4, ct=4, w=self._wput(pack.pack_mprep_lds(w2_, b2_, w1_, b1_)), b=0))
+                    y.append(TV([Seg(out, node.cout)], out.H, out.W))
+                    continue
                 pooled = TV([Seg(s0.buf, s0.C, s0.coff, lib.SRC_POOL2)], x.H // 2, x.W // 2)
                 self._conv1x1(p + ".conv1", *m.conv1.fused(), pooled, out, 0, lib.ACT_SILU)
                 self._conv3x3s2(p + ".conv2", *m.conv2.fused(), x, out, c_, lib.ACT_RELU)
@@ -534,6 +550,8 @@ class Plan:
                 writes.setdefault(id(r["twin"]["out"]), []).append((0, r["Cout"], i))
             if "out2" in r:
                 writes.setdefault(id(r["out2"]), []).append((0, r["Cout"], i))
+            if "pool1" in r:                                  # the pooled branch of a one-launch MPRep writes channels 0 .. C1 of the same pixels
+                writes.setdefault(id(r["out"]), []).append((0, r["pool1"][0].shape[0], i))
             last_on_lane[lane] = i
 
     # ---------------------------------------------------------------- materialise
@@ -571,6 +589,8 @@ class Plan:
                 o.bias = wbase + r["b"]
             if r["kind"] == lib.OP_BOTTLENECK:
                 o.tile_k = r["tk"]
+            if "pool1" in r:                                  # one-launch MPRep: only the LDS-resident 3x3 kernel has the pooled branch
+                o.tile_k, o.nc, o.reg_stride = 6, r["pool1"][0].shape[0], 0
             for k_, off in enumerate(r.get("aux", [])):
                 if off is not None:
                     o.aux[k_] = wbase + off
@@ -824,12 +844,13 @@ class Plan:
                 continue
             M = self.B * o.H * o.W
             twin = r.get("twin")
-            sig = (o.kind, self.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32)) + (("twin",) if twin else ())
+            pool1 = r.get("pool1")
+            sig = (o.kind, self.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32)) + (("twin",) if twin else ()) + (("pool1",) if pool1 else ())
             best = _TUNE_CACHE.get(sig)
             w, b, srcC = r["raw"]
 
             def packed(wt, bt, ct_, tk_):
-                wp_ = (pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
+                wp_ = (pack.pack_mprep_lds(wt, bt, *pool1) if pool1 else pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
                 return wp_, pack.pack_bias(bt, ct_ if tk_ not in (6, 7) else 4).to(self.device)
             if best is None:
                 cands = []
@@ -853,7 +874,7 @@ class Plan:
                     if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and stream_lds_ok(ksteps, ct) \
                             and (o.nsrc == 1 or all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc))) and (direct or ct >= 4 or o.nsrc == 1):
                         cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
-                    if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and M >= 65536:
+                    if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and (M >= 65536 or pool1):
                         for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)
                             cands.append((4, wg, 6))
                     if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and pack.conv3x3_wreg_shape(o.Cin, o.Cout) and ct == 4:
@@ -868,6 +889,8 @@ class Plan:
                 results = []
                 if twin:
                     cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7)]    # the variants that take a twin launch
+                if pool1:
+                    cands = [c_ for c_ in cands if c_[2] == 6]               # only the workgroup count is open
                 for pt, ct, tk in cands:
                     wp, bp = packed(w, b, ct, tk)
                     op = lib.MafOp.from_buffer_copy(o)
@@ -889,6 +912,11 @@ class Plan:
                 if verbose:
                     print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
+            if pool1 and tk == 6:
+                if (pt, ct) != (o.tile_p, o.tile_c):
+                    o.tile_p, o.tile_c = pt, ct                       # same record, another workgroup count
+                    changed += 1
+                continue
             if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
                 wp, bp = packed(w, b, ct, tk)
                 self._tuned += [wp, bp]
@@ -961,7 +989,7 @@ class Plan:
             if o.tile_k == 3:
                 return "conv1x1_stream_kernel<%d, %d, %d>" % (o.tile_p, o.tile_c, -(-o.Cin // 32))
             if o.tile_k == 6:
-                return "conv3s2_lds_kernel<%d, %d, 4>" % (o.Cin, o.Cout)
+                return "conv3s2_lds_kernel<%d, %d, 4, %d>" % (o.Cin, o.Cout, o.nc)
             if o.tile_k == 7:
                 return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3,))
             if o.tile_k == 5:
@@ -1007,7 +1035,8 @@ class Plan:
             oes = 4 if o.out_f32 else es
             return int(rd) + px * o.Cout * oes + o.Cin * o.Cout * es
         if o.kind == lib.OP_CONV3X3S2:
-            return (2 if "twin" in self._ops[idx] else 1) * (self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es)
+            pooled = px * o.nc * es + o.Cin * o.nc * es if "pool1" in self._ops[idx] else 0      # the pooled 1x1 branch of a one-launch MPRep: its output and weights (the input is the conv's)
+            return (2 if "twin" in self._ops[idx] else 1) * (self.B * o.Hin * o.Win * o.Cin * es + px * o.Cout * es + 9 * o.Cin * o.Cout * es) + pooled
         if o.kind == lib.OP_DWCONV:
             return px * (o.Cin + o.Cout) * es + o.ksize * o.ksize * o.Cout * es
         if o.kind == lib.OP_CONV1DW:
@@ -1034,7 +1063,7 @@ class Plan:
         if o.kind == lib.OP_CONV1X1:
             return 2 * px * o.Cin * o.Cout
         if o.kind == lib.OP_CONV3X3S2:
-            return (2 if "twin" in self._ops[idx] else 1) * 2 * px * 9 * o.Cin * o.Cout
+            return (2 if "twin" in self._ops[idx] else 1) * 2 * px * 9 * o.Cin * o.Cout + (2 * px * o.Cin * o.nc if "pool1" in self._ops[idx] else 0)
         if o.kind == lib.OP_DWCONV:
             return 2 * px * o.ksize * o.ksize * o.Cout
         if o.kind == lib.OP_CONV1DW:

@@ -301,6 +301,21 @@ def pack_conv3x3_lds(w, b):
     return rec
 
 
+def pack_mprep_lds(w, b, w1, b1):
+    """Record of MPRep in one launch (csrc/conv3s2_lds.hip, tile_k = 6 with nc = C1: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)), common.py:1241-1262):
+    pack_conv3x3_lds(w, b) of conv2, then conv1 — w1 [C1, Cin, 1, 1], b1 [C1] — as fragments [ceil(Cin / 32)][C1 / 16][64 lanes][8] f16 (lane (g, n)
+    of k-step s: output channel 16t + n, input channels 32s + 8g .. + 7, zero past Cin) | bias fp32 [C1]."""
+    w1 = w1.detach().float().cpu().reshape(w1.shape[0], -1)
+    c1, cin = w1.shape
+    assert c1 % 16 == 0 and cin == w.shape[1]
+    ks1 = -(-cin // 32)
+    m1 = torch.zeros(ks1 * 32, c1)
+    m1[:cin] = w1.t()
+    f = m1.view(ks1, 4, 8, c1 // 16, 16).permute(0, 3, 1, 4, 2).contiguous().half()   # [s][t][g][n][j]
+    rec = torch.cat([pack_conv3x3_lds(w, b), f.reshape(-1).view(torch.uint8), b1.detach().float().cpu().contiguous().view(torch.uint8)])
+    return rec
+
+
 _WREG_SHAPES = {(128, 128): (8, 1), (96, 96): (6, 1), (96, 64): (4, 2), (64, 64): (4, 2)}        # (Cin, Cout) -> (waves along the channels, waves along the pixels)
 
 

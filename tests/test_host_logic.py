@@ -148,6 +148,7 @@ def test_plan_builds_on_cpu(built, scale, nops32):
     m = M.Model(scale).eval()
     m.fuse_head = False
     m.fuse_stem = False
+    m.fuse_mprep = False           # (checked at the end)
     tw = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"), fuse=False)       # default: the equal side convs 23 / 24 and 27 / 28 as twin launches
     pairs = ["backbone.23.block+backbone.24.block", "backbone.27.block+backbone.28.block"][0 if scale != "m" else 1:]    # m: nodes 22 and 20 differ in width
     assert len(tw.ops) == nops - len(pairs) and [n for n in tw.op_names if "+" in n] == pairs
@@ -210,6 +211,19 @@ def test_plan_builds_on_cpu(built, scale, nops32):
         m.fuse_stem = True
     else:
         assert len(st.ops) == len(ht.ops) and st.ops[0].kind == lib.OP_STEM
+    m.fuse_mprep = True                            # MPRep's two branches (MaxPool2d + 1x1 | 3x3 s2) in one launch where the kernel exists: 48 -> 48 + 48 / 64 -> 64 + 64 = node 3 of n / s
+    assert len(Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False).ops) == len(st.ops)     # big maps only (>= 65536 output pixels)
+    mp = Plan(m, 32, 384, 384, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
+    m.fuse_mprep = False
+    st = Plan(m, 32, 384, 384, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
+    m.fuse_mprep = True
+    assert len(mp.ops) == len(st.ops) - (scale in ("n", "s"))
+    if scale in ("n", "s"):
+        o = mp.ops[mp.op_names.index("backbone.3.conv1+conv2")]
+        c = {"n": 48, "s": 64}[scale]
+        assert (o.kind, o.tile_k, o.nc, o.reg_stride, o.out_coff, o.Cin, o.Cout, o.act) == (lib.OP_CONV3X3S2, 6, c, 0, c, c, c, lib.ACT_RELU)
+        assert "backbone.3.conv1" not in mp.op_names and "backbone.3.conv2" not in mp.op_names
+    assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops32      # the fp32 parity plan keeps them apart
 
 
 def test_product_synth_generator_equals_oracle_generator():
