@@ -83,7 +83,10 @@ typedef struct {
  *                   tile_k = 7 (fp16; (Cin, Cout) = (128, 128), (96, 96), (96, 64), (64, 64)): one workgroup per CU whose waves keep ALL weight
  *                   fragments in registers, input patches of 4 x 8 output tiles by DMA, double-buffered (csrc/conv3s2_wreg.hip); w = record of
  *                   maf_conv3s2_wreg_record_bytes(Cin, Cout) bytes (pack.py:pack_conv3x3_wreg), bias unused, tile_c = workgroups per conv / 32
- *                   (0 = 256 / convs); a twin launch passes aux = {src, record, -, out} of the second conv.
+ *                   (0 = 256 / convs); a twin launch passes aux = {src, record, -, out} of the second conv.  With nc = C1 = 96 ((96, 96), no
+ *                   twin, even Hin / Win, reg_stride + nc = out_coff) the launch is a whole MPRep as for tile_k = 6: the 2 x 2 window of an output
+ *                   pixel is taps (1,1) (1,2) (2,1) (2,2) of its 3 x 3 window, so the pooled branch's operand is the maximum of four fragments the
+ *                   conv reads anyway; w = record of maf_mprep_wreg_record_bytes(Cin, Cout, C1) bytes (pack.py:pack_mprep_wreg).
  * MAF_OP_CONV3X3S2_DGRAD  backward of the above w.r.t. its input (autograd of common.py:219-224 / :44-47 in Trainer.train_in_steps,
  *                   yolov6/core/engine.py:164): src[0] = dY [B,Hin,Win,Cin] (Cin = the forward conv's OUTPUT channels, Hin x Win its output
  *                   grid), out = dX [B,H,W,Cout] (Cout = the forward conv's input channels, H x W its input grid); w = the forward weight
@@ -173,6 +176,8 @@ int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);
 int64_t maf_conv3s2_lds_record_bytes(int32_t Cin, int32_t Cout);
 /* ... with the pooled 1x1 branch of MPRep behind it (MAF_OP_CONV3X3S2, tile_k = 6, nc = C1; maf-yolo_amd/pack.py:pack_mprep_lds). */
 int64_t maf_mprep_lds_record_bytes(int32_t Cin, int32_t Cout, int32_t C1);
+/* ... and on the tile_k = 7 kernel ((96, 96, 96); 0 = no such kernel; pack.py:pack_mprep_wreg). */
+int64_t maf_mprep_wreg_record_bytes(int32_t Cin, int32_t Cout, int32_t C1);
 int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout);   /* 0: no instantiation for this shape */
 
 /* Launch one op on `stream`. */

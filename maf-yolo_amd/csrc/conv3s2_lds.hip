@@ -199,12 +199,7 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
                         const uint2 lo = q[0], hi = q[1];
                         v[w_] = __builtin_bit_cast(half8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
                     }
-                    half8_t mx;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const half_t a0 = v[0][j] > v[1][j] ? v[0][j] : v[1][j], a1 = v[2][j] > v[3][j] ? v[2][j] : v[3][j];
-                        mx[j] = a0 > a1 ? a0 : a1;
-                    }
+                    const half8_t mx = __builtin_elementwise_max(__builtin_elementwise_max(v[0], v[1]), __builtin_elementwise_max(v[2], v[3]));   // v_pk_max_f16
 #pragma unroll
                     for (int t = 0; t < NT1; ++t) acc1[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[s_ * NT1 + t], mx, acc1[m][t], 0, 0, 0);
                 }

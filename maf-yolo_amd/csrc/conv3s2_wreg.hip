@@ -30,6 +30,7 @@ struct C3wArgs {
     const char* rec[2];
     half_t* out[2];
     int nconv, B, Hin, Win, H, W, in_stride, in_coff, out_stride, out_coff, act, tilesX, tilesY, ntiles;   // ntiles per conv
+    int out1_coff;                                                              // C1 > 0: channel offset of the pooled branch (out1_coff + C1 == out_coff)
 };
 
 constexpr int W3_TR = 4, W3_TC = 8, W3_SR = 2 * W3_TR + 1, W3_SC = 2 * W3_TC + 1, W3_NPIX = W3_SR * W3_SC;
@@ -67,12 +68,16 @@ __device__ __forceinline__ void w3_epilogue(const f32x4_t (&acc)[MT][NTW], const
 // NWN x NWM waves: wave (wn, wm) owns the COUT / 16 / NWN channel tiles starting at wn * NTW and the 2 / NWM m-tiles (16 pixels = 2 rows x 8 columns)
 // starting at wm * MT.  Two waves per SIMD (512-thread workgroups, <= 256 registers per lane): one wave's LDS reads, address arithmetic and epilogue
 // run under the other's MFMAs — with one wave per SIMD (a first version: 4 waves holding two channel tiles each) a tile took 14k cycles.
-template <int CIN, int COUT, int NWN, int NWM, int NBUF>
+// C1 = COUT: MPRep in one launch (common.py:1241-1262, cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 window of an output pixel is taps (1, 1), (1, 2),
+// (2, 1), (2, 2) of its 3 x 3 window, so the pooled branch's operand is the element-wise maximum of four fragments the conv reads anyway — no extra LDS
+// read; its 1x1 + SiLU runs on the same wave -> channel-tile assignment and its C1 channels are stored in front of the conv's (one run per pixel).
+template <int CIN, int COUT, int NWN, int NWM, int NBUF, int C1 = 0>
 __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_wreg_kernel(const C3wArgs a) {
     constexpr int NW = NWN * NWM, NTW = COUT / 16 / NWN, MT = 2 / NWM;
     static_assert(CIN % 32 == 0 && CIN <= 128 && COUT == NWN * NTW * 16 && MT * NWM == 2, "shape");
-    constexpr int KPT = CIN / 32, KS = 9 * KPT, GR = CIN / 8, NT = NW * 64;
-    constexpr int PB = w3_patch_bytes<NW>(), OB = W3_TR * W3_TC * COUT * 2;
+    static_assert(C1 == 0 || C1 == COUT, "the pooled branch shares the conv's channel tiles");
+    constexpr int KPT = CIN / 32, KS = 9 * KPT, GR = CIN / 8, NT = NW * 64, CO2 = COUT + C1;
+    constexpr int PB = w3_patch_bytes<NW>(), OB = W3_TR * W3_TC * CO2 * 2;
     constexpr int ROUNDS = (W3_SLOTS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char w3_raw[];       // [NBUF][PB] patches | [2][OB] output tiles
     unsigned char* const s_out = w3_raw + NBUF * PB;
@@ -97,6 +102,20 @@ __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_w
     f32x4_t bv[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4_t*>(bias + (wn * NTW + t) * 16 + 4 * g);
+    // pooled branch: record behind the conv's — fragments [channel tile][CIN / 32 k-steps][64 lanes][8] | bias fp32 [C1]
+    half8_t w1[KPT][NTW];
+    f32x4_t b1v[NTW];
+    if constexpr (C1 > 0) {
+        const char* rec1 = rec + (size_t)(COUT / 16) * KS * 1024 + COUT * 4;
+        const half8_t* w1src = reinterpret_cast<const half8_t*>(rec1) + ((size_t)(wn * NTW) * KPT) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) w1[j][t] = w1src[(t * KPT + j) * 64];
+        const float* bias1 = reinterpret_cast<const float*>(rec1 + (size_t)(C1 / 16) * KPT * 1024);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b1v[t] = *reinterpret_cast<const f32x4_t*>(bias1 + (wn * NTW + t) * 16 + 4 * g);
+    }
 
     // ---- patch DMA: slot L of the image <- chunk (L & 15) ^ swz of pixel L >> 4.  What does not depend on the tile is computed once per lane
     // and DMA round: the pixel's place in the patch and its channel chunk (packed: py << 16 | px << 8 | chunk; chunk 31 = a slot nothing maps to)
@@ -169,12 +188,16 @@ __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_w
             for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // KS * MT steps (k-step s, m-tile m), ONE straight line, software-pipelined by hand: the read of step t + RD is issued before the MFMAs of
         // step t (LDS returns in order: when step t is consumed, the min(RD, steps left) reads issued after its own may still be in flight)
-        constexpr int NSTEP = KS * MT, RD = 6;
+        // (C1 > 0: m-tile-major — one m-tile's pooled operand, 4 KPT registers, is complete and consumed before the next one starts — and a shorter read-ahead:
+        // with the k-step-major order and RD = 6 the kernel spilled 30 registers)
+        constexpr int NSTEP = KS * MT, RD = C1 > 0 ? 4 : 6;
         u32x4_t fr[RD + 1];
+        half8_t pool[KPT];                                                        // C1 > 0: running maximum over taps 4, 5, 7, 8 of every channel chunk
+        half_t* so = reinterpret_cast<half_t*>(s_out + ocur * OB);                // free since the barrier of the previous tile (its readers copied out two tiles ago)
         auto ld_step = [&](auto idx) {
             constexpr int t = decltype(idx)::value;
             if constexpr (t < NSTEP) {
-                constexpr int s_ = t / MT, m = t % MT, tap = s_ / KPT, ky = tap / 3, kx = tap - 3 * ky;
+                constexpr int s_ = C1 > 0 ? t % KS : t / MT, m = C1 > 0 ? t / KS : t % MT, tap = s_ / KPT, ky = tap / 3, kx = tap - 3 * ky;
                 constexpr int off = (ky * W3_SC + kx) * 256 + m * (4 * W3_SC * 256);
                 static_assert(off < 65536, "ds offset field");
                 w3_ds_read_b128<off>(fr[t % (RD + 1)], fa[ky >> 1][kx >> 1][s_ % KPT]);
@@ -183,49 +206,66 @@ __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_w
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the counter now counts only the reads below
         w3_static_for<RD>([&](auto idx) { ld_step(idx); });
         w3_static_for<NSTEP>([&](auto idx) {
-            constexpr int t = decltype(idx)::value, s_ = t / MT, m = t % MT, sl = t % (RD + 1);
+            constexpr int t = decltype(idx)::value, s_ = C1 > 0 ? t % KS : t / MT, m = C1 > 0 ? t / KS : t % MT, sl = t % (RD + 1);
             ld_step(std::integral_constant<int, t + RD>{});
             constexpr int ahead = (NSTEP - 1 - t) < RD ? (NSTEP - 1 - t) : RD;
             w3_wait_lgkm<ahead>(fr[sl]);
             const half8_t f = __builtin_bit_cast(half8_t, fr[sl]);
 #pragma unroll
             for (int tt = 0; tt < NTW; ++tt) acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[s_][tt], f, acc[m][tt], 0, 0, 0);
+            if constexpr (C1 > 0) {
+                constexpr int tap = s_ / KPT, j = s_ % KPT;
+                if constexpr (tap == 4) pool[j] = f;
+                else if constexpr (tap == 5 || tap == 7 || tap == 8) pool[j] = __builtin_elementwise_max(pool[j], f);   // 4 v_pk_max_f16 (an element-wise ternary is ~30 instructions)
+                if constexpr (s_ == KS - 1) {                                     // this m-tile's pooled branch: SiLU(W1 . max + b1) -> channels 0 .. C1 of the staged pixels
+#pragma unroll
+                    for (int tt = 0; tt < NTW; ++tt) {
+                        f32x4_t a1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int jj = 0; jj < KPT; ++jj) a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[jj][tt], pool[jj], a1, 0, 0, 0);
+                        half4_t v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = (half_t)maf_act<MAF_ACT_SILU>(a1[q] + b1v[tt][q]);
+                        *reinterpret_cast<half4_t*>(so + ((wm * MT + m) * 16 + n) * CO2 + (wn * NTW + tt) * 16 + 4 * g) = v;
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);                                    // keep the issue order as written
         });
         // ---- bias + activation (picked once per tile, not per value) -> the output tile in LDS: pixel (wm * MT + m) * 16 + n, channels (wn * NTW + t) * 16 + 4 g ..
-        half_t* so = reinterpret_cast<half_t*>(s_out + ocur * OB);
-        if (act == MAF_ACT_SILU) w3_epilogue<MAF_ACT_SILU, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
-        else if (act == MAF_ACT_RELU) w3_epilogue<MAF_ACT_RELU, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
-        else if (act == MAF_ACT_NONE) w3_epilogue<MAF_ACT_NONE, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
-        else w3_epilogue<MAF_ACT_SIGMOID, MT, NTW>(acc, bv, so, COUT, wn * NTW * 16, wm * MT * 16, n, g);
+        if (act == MAF_ACT_SILU) w3_epilogue<MAF_ACT_SILU, MT, NTW>(acc, bv, so, CO2, C1 + wn * NTW * 16, wm * MT * 16, n, g);
+        else if (act == MAF_ACT_RELU) w3_epilogue<MAF_ACT_RELU, MT, NTW>(acc, bv, so, CO2, C1 + wn * NTW * 16, wm * MT * 16, n, g);
+        else if (act == MAF_ACT_NONE) w3_epilogue<MAF_ACT_NONE, MT, NTW>(acc, bv, so, CO2, C1 + wn * NTW * 16, wm * MT * 16, n, g);
+        else w3_epilogue<MAF_ACT_SIGMOID, MT, NTW>(acc, bv, so, CO2, C1 + wn * NTW * 16, wm * MT * 16, n, g);
         // the next patch has landed (this wave's pieces; with three buffers the one after it may still fly) and this wave's part of the output tile is
         // written; the barrier publishes both (a raw s_barrier: __syncthreads() would drain the whole DMA queue with vmcnt(0))
         if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ROUNDS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
         const int Y0 = ty * W3_TR, X0 = tx * W3_TC;
-        constexpr int CPP = COUT / 8;
+        constexpr int CPP = CO2 / 8;
+        const int coff = C1 > 0 ? a.out1_coff : a.out_coff;                       // (the pooled channels sit right in front of the conv's)
         for (int q = tid; q < W3_TR * W3_TC * CPP; q += NT) {
             const int px = q / CPP, part = q - px * CPP;
             const int oy = Y0 + (px >> 3), ox = X0 + (px & 7);
             if (oy < a.H && ox < a.W)
-                *reinterpret_cast<uint4*>(out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + a.out_coff + 8 * part) =
-                    *reinterpret_cast<const uint4*>(so + px * COUT + 8 * part);
+                *reinterpret_cast<uint4*>(out + ((size_t)(b * a.H + oy) * a.W + ox) * a.out_stride + coff + 8 * part) =
+                    *reinterpret_cast<const uint4*>(so + px * CO2 + 8 * part);
         }
     }
 }
 
-template <int CIN, int COUT, int NWN, int NWM, int NBUF>
+template <int CIN, int COUT, int NWN, int NWM, int NBUF, int C1 = 0>
 int launch_w3(const C3wArgs& a, int wg_per_conv, hipStream_t s) {
     constexpr int NW = NWN * NWM;
-    constexpr int lds = NBUF * w3_patch_bytes<NW>() + 2 * W3_TR * W3_TC * COUT * 2;
+    constexpr int lds = NBUF * w3_patch_bytes<NW>() + 2 * W3_TR * W3_TC * (COUT + C1) * 2;
     static bool attr = false;
     if (!attr) {
-        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv3s2_wreg)");
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF, C1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv3s2_wreg)");
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF>), dim3(wg_per_conv * a.nconv), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv3s2_wreg_kernel<CIN, COUT, NWN, NWM, NBUF, C1>), dim3(wg_per_conv * a.nconv), dim3(NW * 64), lds, s, a);
     return maf_check_hip(hipGetLastError(), "conv3s2_wreg launch");
 }
 
@@ -244,6 +284,12 @@ extern "C" int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout) {
     int nwn, nwm;
     if (!w3_shape(Cin, Cout, &nwn, &nwm)) return 0;
     return (int64_t)(Cout / 16) * (9 * Cin / 32) * 1024 + Cout * 4;
+}
+
+// ... with the pooled 1x1 branch of MPRep behind it (C1 = Cout = Cin = 96): fragments [C1 / 16][Cin / 32][64][8] f16 | bias fp32 [C1]; 0 = no such kernel
+extern "C" int64_t maf_mprep_wreg_record_bytes(int32_t Cin, int32_t Cout, int32_t C1) {
+    if (!(Cin == 96 && Cout == 96 && C1 == 96)) return 0;
+    return maf_conv3s2_wreg_record_bytes(Cin, Cout) + (int64_t)(C1 / 16) * (Cin / 32) * 1024 + C1 * 4;
 }
 
 int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s) {
@@ -276,6 +322,13 @@ int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s) {
     int per = op->tile_c > 0 ? op->tile_c * 32 : 256 / a.nconv;
     if (per > a.ntiles) per = a.ntiles;
     const bool two = op->tile_p == 2;                               // tile_p = 2: two patch buffers (A/B); else three
+    a.out1_coff = op->reg_stride;
+    if (op->nc) {                                                   // MPRep: the MaxPool2d(2, 2) + 1x1 + SiLU branch rides along (nc = its channels, reg_stride = where they go)
+        MAF_REQUIRE(op->Cin == 96 && op->Cout == 96 && op->nc == 96 && a.nconv == 1, "conv3x3s2 (tile_k = 7): the pooled 1x1 branch exists for 96 -> 96 + 96, single launches");
+        MAF_REQUIRE(op->Hin == 2 * op->H && op->Win == 2 * op->W, "conv3x3s2 (tile_k = 7) with the pooled branch: even input size (MaxPool2d(2, 2) windows)");
+        MAF_REQUIRE(op->reg_stride >= 0 && op->reg_stride % 8 == 0 && op->reg_stride + op->nc == op->out_coff, "conv3x3s2 (tile_k = 7): the pooled branch's channels (reg_stride = their offset) must end where the conv's begin");
+        return two ? launch_w3<96, 96, 6, 1, 2, 96>(a, per, s) : launch_w3<96, 96, 6, 1, 3, 96>(a, per, s);
+    }
 #define MAF_W3(CI, CO, NWN_, NWM_) return two ? launch_w3<CI, CO, NWN_, NWM_, 2>(a, per, s) : launch_w3<CI, CO, NWN_, NWM_, 3>(a, per, s)
     if (op->Cin == 128 && op->Cout == 128) MAF_W3(128, 128, 8, 1);
     if (op->Cin == 96 && op->Cout == 96) MAF_W3(96, 96, 6, 1);

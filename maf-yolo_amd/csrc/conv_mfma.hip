@@ -3,7 +3,7 @@
 #include "conv_mfma.inc.h"
 
 int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
-    if (op->kind == MAF_OP_CONV3X3S2 && op->nc && op->tile_k != 6) { maf_set_error("conv3x3s2: the pooled 1x1 branch (nc) exists in the tile_k = 6 kernel only"); return MAF_E_UNSUPPORTED; }
+    if (op->kind == MAF_OP_CONV3X3S2 && op->nc && op->tile_k != 6 && op->tile_k != 7) { maf_set_error("conv3x3s2: the pooled 1x1 branch (nc) exists in the tile_k = 6 and 7 kernels only"); return MAF_E_UNSUPPORTED; }
     if (op->kind == MAF_OP_CONV3X3S2 && op->tile_k == 6) return maf_launch_conv3s2_lds(op, s);   // narrow layers: weights + input patch in LDS (conv3s2_lds.hip)
     if (op->kind == MAF_OP_CONV3X3S2 && op->tile_k == 7) return maf_launch_conv3s2_wreg(op, s);  // 96 / 128 channels: weights in registers, patch by DMA (conv3s2_wreg.hip)
     MAF_REQUIRE(op->dtype == MAF_F16 || op->dtype == MAF_F32, "conv: dtype must be f16/f32");

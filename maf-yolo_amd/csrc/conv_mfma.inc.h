@@ -91,12 +91,7 @@ template <> struct Frag<half_t> {
     static constexpr int CH = 8;    // channels per 16-byte lane chunk
     static constexpr int KS = 32;   // channels per k-step
     static __device__ __forceinline__ type zero() { return (type)(half_t)0; }
-    static __device__ __forceinline__ type vmax(type a, type b) {
-        type r;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
-        return r;
-    }
+    static __device__ __forceinline__ type vmax(type a, type b) { return __builtin_elementwise_max(a, b); }   // 4 v_pk_max_f16
     static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }

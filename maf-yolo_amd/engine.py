@@ -390,6 +390,16 @@ class Plan:
                                           segs=x.segs, out=out, out_coff=c_, out_f32=0, pt=4, ct=4, w=self._wput(pack.pack_mprep_lds(w2_, b2_, w1_, b1_)), b=0))
                     y.append(TV([Seg(out, node.cout)], out.H, out.W))
                     continue
+                if self.fuse_mprep and self.dtype == lib.F16 and (x.C, c_, w1_.shape[0]) == (96, 96, 96) and x.H % 2 == 0 and x.W % 2 == 0 \
+                        and self.B * (x.H // 2) * (x.W // 2) >= 65536:
+                    # (backbone.5 of n at bs 32, 51 200 pixels: 24.9 + 16.7 -> 38.8 us only — the pooled branch costs this kernel its read-ahead depth — so big maps only)
+                    # ... and on the register-resident 3x3 kernel (csrc/conv3s2_wreg.hip with nc): the pooled operand is the maximum of four fragments the conv reads anyway
+                    w2_, b2_ = m.conv2.fused()
+                    self._ops.append(dict(kind=lib.OP_CONV3X3S2, name=p + ".conv1+conv2", act=lib.ACT_RELU, H=x.H // 2, W=x.W // 2, Hin=x.H, Win=x.W, Cin=x.C, Cout=c_,
+                                          raw=(w2_.detach().float().cpu(), b2_.detach().float().cpu(), None), pool1=(w1_.detach().float().cpu(), b1_.detach().float().cpu()), pool1_tk=7,
+                                          segs=x.segs, out=out, out_coff=c_, out_f32=0, pt=2, ct=8, w=self._wput(pack.pack_mprep_wreg(w2_, b2_, w1_, b1_)), b=0))
+                    y.append(TV([Seg(out, node.cout)], out.H, out.W))
+                    continue
                 pooled = TV([Seg(s0.buf, s0.C, s0.coff, lib.SRC_POOL2)], x.H // 2, x.W // 2)
                 self._conv1x1(p + ".conv1", *m.conv1.fused(), pooled, out, 0, lib.ACT_SILU)
                 self._conv3x3s2(p + ".conv2", *m.conv2.fused(), x, out, c_, lib.ACT_RELU)
@@ -590,7 +600,7 @@ class Plan:
             if r["kind"] == lib.OP_BOTTLENECK:
                 o.tile_k = r["tk"]
             if "pool1" in r:                                  # one-launch MPRep: only the LDS-resident 3x3 kernel has the pooled branch
-                o.tile_k, o.nc, o.reg_stride = 6, r["pool1"][0].shape[0], 0
+                o.tile_k, o.nc, o.reg_stride = r.get("pool1_tk", 6), r["pool1"][0].shape[0], 0
             for k_, off in enumerate(r.get("aux", [])):
                 if off is not None:
                     o.aux[k_] = wbase + off
@@ -850,7 +860,7 @@ class Plan:
             w, b, srcC = r["raw"]
 
             def packed(wt, bt, ct_, tk_):
-                wp_ = (pack.pack_mprep_lds(wt, bt, *pool1) if pool1 else pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
+                wp_ = ((pack.pack_mprep_wreg if tk_ == 7 else pack.pack_mprep_lds)(wt, bt, *pool1) if pool1 else pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, self.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, self.dtype)).to(self.device)
                 return wp_, pack.pack_bias(bt, ct_ if tk_ not in (6, 7) else 4).to(self.device)
             if best is None:
                 cands = []
@@ -890,7 +900,7 @@ class Plan:
                 if twin:
                     cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7)]    # the variants that take a twin launch
                 if pool1:
-                    cands = [c_ for c_ in cands if c_[2] == 6]               # only the workgroup count is open
+                    cands = [c_ for c_ in cands if c_[2] == r.get("pool1_tk", 6)]   # only the workgroup count (and the patch buffers of tile_k = 7) are open
                 for pt, ct, tk in cands:
                     wp, bp = packed(w, b, ct, tk)
                     op = lib.MafOp.from_buffer_copy(o)
@@ -912,7 +922,7 @@ class Plan:
                 if verbose:
                     print("tune %-32s M=%-7d %4d->%-4d: %s" % (self.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
             pt, ct, tk = best
-            if pool1 and tk == 6:
+            if pool1:
                 if (pt, ct) != (o.tile_p, o.tile_c):
                     o.tile_p, o.tile_c = pt, ct                       # same record, another workgroup count
                     changed += 1
@@ -991,7 +1001,7 @@ class Plan:
             if o.tile_k == 6:
                 return "conv3s2_lds_kernel<%d, %d, 4, %d>" % (o.Cin, o.Cout, o.nc)
             if o.tile_k == 7:
-                return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3,))
+                return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3, o.nc))
             if o.tile_k == 5:
                 return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")

@@ -324,6 +324,17 @@ def conv3x3_wreg_shape(cin, cout):
     return _WREG_SHAPES.get((cin, cout))
 
 
+def pack_mprep_wreg(w, b, w1, b1):
+    """Record of MPRep in one launch on the register-resident 3x3 kernel (csrc/conv3s2_wreg.hip, tile_k = 7 with nc = C1; 96 -> 96 + 96): pack_conv3x3_wreg(w, b)
+    of conv2, then conv1 — w1 [C1, Cin, 1, 1], b1 [C1] — as fragments [C1 / 16 channel tiles][Cin / 32 k-steps][64 lanes][8] f16 (lane (g, n) of k-step j of
+    tile t: output channel 16t + n, input channels 32j + 8g .. + 7) | bias fp32 [C1]."""
+    w1 = w1.detach().float().cpu().reshape(w1.shape[0], -1)
+    c1, cin = w1.shape
+    assert c1 % 16 == 0 and cin % 32 == 0 and cin == w.shape[1]
+    f = w1.t().contiguous().view(cin // 32, 4, 8, c1 // 16, 16).permute(3, 0, 1, 4, 2).contiguous().half()   # [j][g][e][t][n] -> [t][j][g][n][e]
+    return torch.cat([pack_conv3x3_wreg(w, b), f.reshape(-1).view(torch.uint8), b1.detach().float().cpu().contiguous().view(torch.uint8)])
+
+
 def pack_conv3x3_wreg(w, b):
     """Record of the register-resident-weight 3x3 stride-2 conv (csrc/conv3s2_wreg.hip, tile_k = 7): w [Cout, Cin, 3, 3], b [Cout] -> fragments
     [Cout / 16 channel tiles][9 * Cin / 32 k-steps][64 lanes][8] f16 — lane (g, n) of k-step s of tile t: output channel 16 t + n, pair q = 4 s + g ->

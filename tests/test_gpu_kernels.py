@@ -363,15 +363,16 @@ def test_conv3x3_stride2_lds_resident(cin, cout, act, hw):
     assert wp.numel() * 0 == 0 and pack.pack_conv3x3_lds(w, bias).numel() == lib.load().maf_conv3s2_lds_record_bytes(cin, cout)
 
 
-@pytest.mark.parametrize("c", [48, 64])
+@pytest.mark.parametrize("c", [48, 64, 96])
 @pytest.mark.parametrize("B,hw", [(3, (36, 52)), (2, (160, 160)), (1, (8, 6)), (2, (70, 34))])
 def test_mprep_in_one_launch(B, hw, c):
-    """MAF_OP_CONV3X3S2, tile_k = 6 with nc = 48 (csrc/conv3s2_lds.hip): MPRep = cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)) (common.py:1241-1262) — the pooled
-    1x1 + SiLU branch is taken from the patch the 3x3 stride-2 conv stages in LDS.  Against torch in fp32 on the same fp16 operands, against the two separate
-    launches the plan used before (pooled-source 1x1 + tile_k = 6 conv), tiles hanging over the map, a channel slice as input, nothing written beside the
-    two halves; the conv half is bit-identical to the launch without the branch."""
+    """MAF_OP_CONV3X3S2 with nc = c: MPRep = cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)) (common.py:1241-1262) in ONE launch — tile_k = 6 (csrc/conv3s2_lds.hip, 48 / 64
+    channels: the pooled 1x1 + SiLU branch is taken from the patch the 3x3 stride-2 conv stages in LDS) and tile_k = 7 (csrc/conv3s2_wreg.hip, 96 channels: its operand
+    is the maximum of four fragments the conv reads anyway).  Against torch in fp32 on the same fp16 operands, against the two separate launches the plan used
+    before, tiles hanging over the map, a channel slice as input, nothing written beside the two halves; the conv half is bit-identical to the launch without the branch."""
     g = torch.Generator().manual_seed(B * 100 + hw[0])
     Hin, Win = hw
+    tk = 7 if c == 96 else 6
     x = _q(torch.randn(B, c, Hin, Win, generator=g), lib.F16)
     w2 = _q(torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5), lib.F16); b2 = torch.randn(c, generator=g)
     w1 = _q(torch.randn(c, c, 1, 1, generator=g) / c ** 0.5, lib.F16); b1 = torch.randn(c, generator=g)
@@ -380,35 +381,36 @@ def test_mprep_in_one_launch(B, hw, c):
     H, W = Hin // 2, Win // 2
     xs = torch.zeros(B, Hin, Win, c + 16, dtype=torch.float16, device=DEV)
     xs[..., 8:8 + c] = _nhwc(x, lib.F16)
-    rec = pack.pack_mprep_lds(w2, b2, w1, b1).to(DEV)
-    assert rec.numel() == lib.load().maf_mprep_lds_record_bytes(c, c, c)
+    rec = (pack.pack_mprep_wreg if tk == 7 else pack.pack_mprep_lds)(w2, b2, w1, b1).to(DEV)
+    assert rec.numel() == (lib.load().maf_mprep_wreg_record_bytes if tk == 7 else lib.load().maf_mprep_lds_record_bytes)(c, c, c)
     outs = []
-    for wg in (0, 1, 3):
+    for pt, wg in (((2, 0), (3, 1), (2, 8)) if tk == 7 else ((4, 0), (4, 1), (4, 3))):     # tile_k = 7: patch buffers, workgroups / 32; tile_k = 6: workgroups / 64
         out = torch.full((B, H, W, 2 * c + 8), 3.0, dtype=torch.float16, device=DEV)
-        op = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, c, c, lib.ACT_RELU, [(xs, c, c + 16, 8, 0)], out, 2 * c + 8, c, rec, pack.pack_bias(b2, 4).to(DEV), 4, wg, Hin=Hin, Win=Win)
-        op.tile_k, op.nc, op.reg_stride = 6, c, 0
+        op = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, c, c, lib.ACT_RELU, [(xs, c, c + 16, 8, 0)], out, 2 * c + 8, c, rec, pack.pack_bias(b2, 4).to(DEV), pt, wg, Hin=Hin, Win=Win)
+        op.tile_k, op.nc, op.reg_stride = tk, c, 0
         _launch(op)
         _check(out[..., c:2 * c], ref2, lib.F16)
         _check(out[..., :c], ref1, lib.F16)
         assert (out[..., 2 * c:] == 3).all(), "wrote outside its pixels' two halves"
         outs.append(out.clone())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])           # the workgroup count does not change a bit
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])           # neither the workgroup count nor the buffer count changes a bit
     # the two launches it replaces
     sep = torch.full((B, H, W, 2 * c + 8), 3.0, dtype=torch.float16, device=DEV)
-    op2 = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, c, c, lib.ACT_RELU, [(xs, c, c + 16, 8, 0)], sep, 2 * c + 8, c, pack.pack_conv3x3_lds(w2, b2).to(DEV), pack.pack_bias(b2, 4).to(DEV), 4, 0, Hin=Hin, Win=Win)
-    op2.tile_k = 6
+    op2 = _conv_op(lib.OP_CONV3X3S2, lib.F16, B, H, W, c, c, lib.ACT_RELU, [(xs, c, c + 16, 8, 0)], sep, 2 * c + 8, c,
+                   (pack.pack_conv3x3_wreg if tk == 7 else pack.pack_conv3x3_lds)(w2, b2).to(DEV), pack.pack_bias(b2, 4).to(DEV), 2 if tk == 7 else 4, 0, Hin=Hin, Win=Win)
+    op2.tile_k = tk
     _launch(op2)
     op1 = _conv_op(lib.OP_CONV1X1, lib.F16, B, H, W, c, c, lib.ACT_SILU, [(xs, c, c + 16, 8, lib.SRC_POOL2)], sep, 2 * c + 8, 0, pack.pack_conv1x1(w1, [c], 4, lib.F16).to(DEV), pack.pack_bias(b1, 4).to(DEV), 1, 4)
     _launch(op1)
     assert torch.equal(sep[..., c:2 * c], outs[0][..., c:2 * c])
     assert (sep[..., :c].float() - outs[0][..., :c].float()).abs().max() <= 2e-3 * ref1.abs().max() + 2e-3     # (the bias enters the sum first here, last there)
-    # refused: any other kernel variant, an odd input size, the branch's channels on top of the conv's
-    for tk, hin, off in ((1, Hin, 0), (7, Hin, 0), (6, Hin, c), (6, Hin, 8), (6, Hin - 1, 0)):
+    # refused: a kernel variant without the branch, the branch's channels not beside / in front of the conv's, an odd input size
+    for tk_, hin, off in ((1, Hin, 0), (13 - tk, Hin, 0), (tk, Hin, c), (tk, Hin, 8), (tk, Hin - 1, 0)):
         bad = lib.MafOp.from_buffer_copy(op)
-        bad.tile_k, bad.reg_stride, bad.Hin = tk, off, hin
-        if tk != 6:
+        bad.tile_k, bad.reg_stride, bad.Hin = tk_, off, hin
+        if tk_ == 1:
             bad.tile_p, bad.tile_c = 1, 4
-        assert lib.load().maf_op_launch(C.byref(bad), torch.cuda.current_stream().cuda_stream) != 0, (tk, off)
+        assert lib.load().maf_op_launch(C.byref(bad), torch.cuda.current_stream().cuda_stream) != 0, (tk_, off)
 
 
 @pytest.mark.parametrize("dt", [lib.F32, lib.F16])

@@ -211,17 +211,17 @@ def test_plan_builds_on_cpu(built, scale, nops32):
         m.fuse_stem = True
     else:
         assert len(st.ops) == len(ht.ops) and st.ops[0].kind == lib.OP_STEM
-    m.fuse_mprep = True                            # MPRep's two branches (MaxPool2d + 1x1 | 3x3 s2) in one launch where the kernel exists: 48 -> 48 + 48 / 64 -> 64 + 64 = node 3 of n / s
+    m.fuse_mprep = True                            # MPRep's two branches (MaxPool2d + 1x1 | 3x3 s2) in one launch where the kernel exists: 48 / 64 / 96 channels = node 3 of n / s / m (and node 5 of n on bigger batches)
     assert len(Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False).ops) == len(st.ops)     # big maps only (>= 65536 output pixels)
     mp = Plan(m, 32, 384, 384, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
     m.fuse_mprep = False
     st = Plan(m, 32, 384, 384, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
     m.fuse_mprep = True
-    assert len(mp.ops) == len(st.ops) - (scale in ("n", "s"))
-    if scale in ("n", "s"):
+    assert len(mp.ops) == len(st.ops) - 1                 # node 3 of every scale at this size: 48 / 64 channels on the LDS-resident 3x3 kernel, 96 (m) on the register-resident one
+    if True:
         o = mp.ops[mp.op_names.index("backbone.3.conv1+conv2")]
-        c = {"n": 48, "s": 64}[scale]
-        assert (o.kind, o.tile_k, o.nc, o.reg_stride, o.out_coff, o.Cin, o.Cout, o.act) == (lib.OP_CONV3X3S2, 6, c, 0, c, c, c, lib.ACT_RELU)
+        c = {"n": 48, "s": 64, "m": 96}[scale]
+        assert (o.kind, o.tile_k, o.nc, o.reg_stride, o.out_coff, o.Cin, o.Cout, o.act) == (lib.OP_CONV3X3S2, 7 if c == 96 else 6, c, 0, c, c, c, lib.ACT_RELU)
         assert "backbone.3.conv1" not in mp.op_names and "backbone.3.conv2" not in mp.op_names
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops32      # the fp32 parity plan keeps them apart
 
