@@ -76,7 +76,7 @@ typedef struct {
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
  *                   input patch of a 4 x 16 output tile in LDS (csrc/conv3s2_lds.hip); w = record of maf_conv3s2_lds_record_bytes(Cin, Cout)
  *                   bytes (maf-yolo_amd/pack.py:pack_conv3x3_lds: fragments + bias), bias unused, tile_c = workgroups / 64 (0 = 256).
- *                   With nc = C1 > 0 ((Cin, Cout, C1) = (48, 48, 48) or (64, 64, 64), even Hin / Win) the launch is a whole MPRep (common.py:1241-1262,
+ *                   With nc = C1 > 0 ((Cin, Cout, C1) = (48, 48, 48) or (64, 64, 64), even Hin / Win) the launch is a whole MPRep (common.py:776-792,
  *                   cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 windows of a tile's pixels lie inside its staged patch, so the pooled
  *                   1x1 + SiLU branch is taken from LDS and its C1 channels go to `out` at channel offset reg_stride (beside the conv's
  *                   out_coff .. + Cout); w = record of maf_mprep_lds_record_bytes(Cin, Cout, C1) bytes (pack.py:pack_mprep_lds).
@@ -120,7 +120,7 @@ typedef struct {
  *                   that opens the next RepHDW block (backbone.2.conv1, common.py:898-946) before anything is written — out then receives
  *                   C3 channels; w = record of maf_stem2_record_bytes(C0, C1, C3) bytes (maf-yolo_amd/pack.py:pack_stem2); fp16 engine only;
  *                   tile_p = tile rows (0 / 8, or 4), tile_k = workgroups (0 = default, persistent).  aux[0] != NULL (needs nc = C1): RepHDW
- *                   splits that tensor in two (chunk(2), common.py:930) — channels C3/2.. then go to aux[0], a tensor of its own with
+ *                   splits that tensor in two (x.split((c_, c_), 1), common.py:940) — channels C3/2.. then go to aux[0], a tensor of its own with
  *                   pixel stride reg_stride (elements, a multiple of 8), and out receives channels 0..C3/2-1: a reader of ONE half then
  *                   fetches whole cache lines of what it uses instead of every line of an interleaved buffer.
  * MAF_OP_HEADTAIL   replaces, for ONE level, cls_conv_s + cls_pred + sigmoid and reg_conv_s + reg_pred (Head_DepthUni, common.py:1288-1336:

@@ -6,7 +6,7 @@
 // pixel-major with a 2 * odd dword stride so the stride-2 fragment reads of 16 lanes cover all 64 banks).  The product is taken as in
 // csrc/stem2.hip phase C: K = 9 taps x Cin / 8 (tap, 8-channel group) pairs, four pairs per MFMA k-step, transposed (A = weights,
 // B = patch) so a lane holds 4 consecutive output channels of one pixel; bias + activation, through LDS, whole NHWC pixels out.
-// C1 > 0: MPRep in ONE launch (common.py:1241-1262: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 windows of the tile's output pixels lie
+// C1 > 0: MPRep in ONE launch (common.py:776-792: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 windows of the tile's output pixels lie
 // inside the staged patch, so the pooled 1x1 + SiLU branch is taken from LDS — its (few) weight fragments live in registers — and its C1 channels
 // go to the other half of the output pixels; the input is read from HBM once instead of twice.
 #include "maf_common.h"

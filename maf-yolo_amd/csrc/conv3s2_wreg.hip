@@ -68,7 +68,7 @@ __device__ __forceinline__ void w3_epilogue(const f32x4_t (&acc)[MT][NTW], const
 // NWN x NWM waves: wave (wn, wm) owns the COUT / 16 / NWN channel tiles starting at wn * NTW and the 2 / NWM m-tiles (16 pixels = 2 rows x 8 columns)
 // starting at wm * MT.  Two waves per SIMD (512-thread workgroups, <= 256 registers per lane): one wave's LDS reads, address arithmetic and epilogue
 // run under the other's MFMAs — with one wave per SIMD (a first version: 4 waves holding two channel tiles each) a tile took 14k cycles.
-// C1 = COUT: MPRep in one launch (common.py:1241-1262, cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 window of an output pixel is taps (1, 1), (1, 2),
+// C1 = COUT: MPRep in one launch (common.py:776-792, cat(conv1(MaxPool2d(2, 2)(x)), conv2(x))): the 2 x 2 window of an output pixel is taps (1, 1), (1, 2),
 // (2, 1), (2, 2) of its 3 x 3 window, so the pooled branch's operand is the element-wise maximum of four fragments the conv reads anyway — no extra LDS
 // read; its 1x1 + SiLU runs on the same wave -> channel-tile assignment and its C1 channels are stored in front of the conv's (one run per pixel).
 template <int CIN, int COUT, int NWN, int NWM, int NBUF, int C1 = 0>

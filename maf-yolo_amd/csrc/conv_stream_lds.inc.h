@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
                     af[ks] = ldg16<half_t>(q + c);
                 }
             } else {
-                // MAF_SRC_POOL2 (MPRep's MaxPool2d(2, 2) in front of its 1x1, common.py:1241-1262): the source grid is 2H x 2W and a fragment is the
+                // MAF_SRC_POOL2 (MPRep's MaxPool2d(2, 2) in front of its 1x1, common.py:776-792): the source grid is 2H x 2W and a fragment is the
                 // element-wise maximum of the four pixels of its window; MAF_SRC_SUB2: the window's top-left pixel alone
                 const int x = m % a.W, tq = m / a.W, y = tq % a.H, bb = tq / a.H;
                 const half_t* q = static_cast<const half_t*>(a.src[0]) + (size_t)((size_t)(bb * 2 * a.H + 2 * y) * (2 * a.W) + 2 * x) * a.srcStride[0] + a.srcCoff[0];

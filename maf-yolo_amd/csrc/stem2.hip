@@ -26,7 +26,7 @@ struct S2Args {
     const void* img;          // [B,3,Hin,Win]
     const char* rec;          // pack_stem2 record
     half_t* out;              // [B,H1,W1,out_stride]
-    half_t* out2;             // optional: the upper half of the channels as a tensor of its own [B,H1,W1,out2_stride] (RepHDW's chunk(2), common.py:930)
+    half_t* out2;             // optional: the upper half of the channels as a tensor of its own [B,H1,W1,out2_stride] (RepHDW's x.split((c_, c_), 1), common.py:940)
     int out2_stride;
     int B, Hin, Win, H0, W0, H1, W1, out_stride, out_coff, tilesX, tilesY, ntiles;
     float in_scale;

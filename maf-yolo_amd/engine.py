@@ -321,7 +321,7 @@ class Plan:
                 y.append(TV([Seg(out, node.cout)], out.H, out.W))
             elif node.kind == "rephdw":
                 c_, depth = m.c_, len(m.m)
-                # slot j of the concatenation (cv1's two halves, then one per block: common.py:930-935).  One interleaved buffer [.., (depth + 2) c_] —
+                # slot j of the concatenation (cv1's two halves, then one per block: common.py:938-946).  One interleaved buffer [.., (depth + 2) c_] —
                 # or, behind the fused stem (the only producer that can write its two halves to two places), one DENSE tensor per slot: a block reads
                 # and writes c_-channel slices, and out of an interleaved buffer whose slices are not whole 128-byte lines it fetches every line of the
                 # buffer for a third of its bytes (bottleneck<3,1,2> on 160 x 160 x 72: 121 MB fetched for 39 MB, +13 MB of partial-line writes)

@@ -302,7 +302,7 @@ def pack_conv3x3_lds(w, b):
 
 
 def pack_mprep_lds(w, b, w1, b1):
-    """Record of MPRep in one launch (csrc/conv3s2_lds.hip, tile_k = 6 with nc = C1: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)), common.py:1241-1262):
+    """Record of MPRep in one launch (csrc/conv3s2_lds.hip, tile_k = 6 with nc = C1: cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)), common.py:776-792):
     pack_conv3x3_lds(w, b) of conv2, then conv1 — w1 [C1, Cin, 1, 1], b1 [C1] — as fragments [ceil(Cin / 32)][C1 / 16][64 lanes][8] f16 (lane (g, n)
     of k-step s: output channel 16t + n, input channels 32s + 8g .. + 7, zero past Cin) | bias fp32 [C1]."""
     w1 = w1.detach().float().cpu().reshape(w1.shape[0], -1)

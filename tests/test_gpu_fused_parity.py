@@ -125,7 +125,7 @@ def test_stem2_vs_fp32_torch(cfg, third, B, H, W, dt, rows):
     assert err <= 2e-3 * scale + 2e-3, (err, scale)
     assert (out[..., :16] == 3.0).all() and (out[..., 16 + C1:] == 3.0).all()
     if third:
-        # two outputs (aux[0] = the upper half of the channels as a tensor of its own: RepHDW's chunk(2), common.py:930): the same values, bit for bit
+        # two outputs (aux[0] = the upper half of the channels as a tensor of its own: RepHDW's x.split((c_, c_), 1), common.py:940): the same values, bit for bit
         lo = torch.full((B, H1, W1, C1 // 2), 3.0, dtype=torch.float16, device=DEV)
         hi = torch.full((B, H1, W1, C1 // 2 + 8), 3.0, dtype=torch.float16, device=DEV)
         op.out, op.out_stride, op.out_coff = lo.data_ptr(), C1 // 2, 0

@@ -366,7 +366,7 @@ def test_conv3x3_stride2_lds_resident(cin, cout, act, hw):
 @pytest.mark.parametrize("c", [48, 64, 96])
 @pytest.mark.parametrize("B,hw", [(3, (36, 52)), (2, (160, 160)), (1, (8, 6)), (2, (70, 34))])
 def test_mprep_in_one_launch(B, hw, c):
-    """MAF_OP_CONV3X3S2 with nc = c: MPRep = cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)) (common.py:1241-1262) in ONE launch — tile_k = 6 (csrc/conv3s2_lds.hip, 48 / 64
+    """MAF_OP_CONV3X3S2 with nc = c: MPRep = cat(conv1(MaxPool2d(2, 2)(x)), conv2(x)) (common.py:776-792) in ONE launch — tile_k = 6 (csrc/conv3s2_lds.hip, 48 / 64
     channels: the pooled 1x1 + SiLU branch is taken from the patch the 3x3 stride-2 conv stages in LDS) and tile_k = 7 (csrc/conv3s2_wreg.hip, 96 channels: its operand
     is the maximum of four fragments the conv reads anyway).  Against torch in fp32 on the same fp16 operands, against the two separate launches the plan used
     before, tiles hanging over the map, a channel slice as input, nothing written beside the two halves; the conv half is bit-identical to the launch without the branch."""
