@@ -319,8 +319,8 @@ def train_mode(args, torch, M, dev, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (BASELINE.md §4: >= 100)")
-    ap.add_argument("--warmup", type=int, default=20, help="untimed warm-up steps (BASELINE.md §4: >= 20)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (BASELINE.md §4: >= 100; 300 = a 0.4 s region: one 20 ms stall of the box no longer moves the value by 15 %)")
+    ap.add_argument("--warmup", type=int, default=30, help="untimed warm-up steps (BASELINE.md §4: >= 20)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE configs[1]: 32)")
     ap.add_argument("--scale", default="n")
     ap.add_argument("--no-cpu-baseline", action="store_true")

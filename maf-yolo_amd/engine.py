@@ -391,7 +391,7 @@ class Plan:
                     y.append(TV([Seg(out, node.cout)], out.H, out.W))
                     continue
                 if self.fuse_mprep and self.dtype == lib.F16 and (x.C, c_, w1_.shape[0]) == (96, 96, 96) and x.H % 2 == 0 and x.W % 2 == 0 \
-                        and self.B * (x.H // 2) * (x.W // 2) >= 65536:
+                        and self.B * (x.H // 2) * (x.W // 2) >= int(os.environ.get("MAF_MPREP_WREG_MIN", "65536")):
                     # (backbone.5 of n at bs 32, 51 200 pixels: 24.9 + 16.7 -> 38.8 us only — the pooled branch costs this kernel its read-ahead depth — so big maps only)
                     # ... and on the register-resident 3x3 kernel (csrc/conv3s2_wreg.hip with nc): the pooled operand is the maximum of four fragments the conv reads anyway
                     w2_, b2_ = m.conv2.fused()
