@@ -12,6 +12,10 @@
 #include "maf_common.h"
 #include "lds_pipe.h"
 
+#ifndef MAF_KO
+#define MAF_KO 0            // profiling builds (make ko KO_SRCS=conv3s2_lds.hip): 128 = plain round-robin tile order
+#endif
+
 namespace {
 
 struct C3Args {
@@ -77,9 +81,16 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
             pf[u] = *reinterpret_cast<const uint4*>(img + at);
         }
     };
-    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    // XCD-contiguous tile order (as csrc/stem2.hip): workgroups go to the 8 XCDs round-robin and neighbouring tiles share halo rows / columns — an XCD
+    // walks one contiguous eighth of the tiles, so the shared lines are hits in ITS L2
+    int t_first = blockIdx.x, t_end = a.ntiles, t_step = gridDim.x;
+    if ((gridDim.x & 7) == 0 && !(MAF_KO & 128)) {
+        const int xcd = blockIdx.x & 7, q = a.ntiles >> 3, r = a.ntiles & 7, base = xcd * q + min(xcd, r);
+        t_first = base + (int)(blockIdx.x >> 3); t_end = base + q + (xcd < r ? 1 : 0); t_step = gridDim.x >> 3;
+    }
+    if (t_first < t_end) prefetch(t_first);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the DMA pieces of this wave have landed (the barrier below publishes everybody's)
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         const int tx = tile % a.tilesX, t2 = tile / a.tilesX, ty = t2 % a.tilesY, b = t2 / a.tilesY;
         const int Y0 = ty * TY, X0 = tx * TX;
         __syncthreads();                                         // s_T and s_out of the previous tile are free; first pass: s_w is in place
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256, (9 * CIN * COUT * 2 + (2 * TY + 1) * 33 * ((CI
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+        if (tile + t_step < t_end) prefetch(tile + t_step);
         f32x4_t acc[MR][NT];
 #pragma unroll
         for (int m = 0; m < MR; ++m)

@@ -19,6 +19,10 @@
 //     NHWC pixels out as 16-byte pieces after the barrier that also publishes the next patch;
 //   * a twin launch (two convs of one shape: op->aux) gives each conv half of the workgroups.
 #include "maf_common.h"
+
+#ifndef MAF_KO
+#define MAF_KO 0            // profiling builds (make ko KO_SRCS=conv3s2_wreg.hip): 128 = plain round-robin tile order
+#endif
 #include <type_traits>
 
 namespace {
@@ -155,20 +159,27 @@ __global__ __launch_bounds__(NWN * NWM * 64, (NWN * NWM + 3) / 4) void conv3s2_w
         for (int xk = 0; xk < 2; ++xk) swz[yk][xk] = ((c_ + xk) & 7) | (((r_ + yk) & 1) << 3);
 
     const int act = a.act;
-    int tile = wg;
+    // XCD-contiguous tile order (as csrc/stem2.hip): workgroups go to the 8 XCDs round-robin and neighbouring tiles share halo rows / columns — an XCD
+    // walks one contiguous eighth of a conv's tiles, so the shared lines are hits in ITS L2 (wgc % 8 == 0: the conv's workgroup index keeps blockIdx's XCD)
+    int tile = wg, t_end = a.ntiles, t_step = wgc;
+    if ((wgc & 7) == 0 && !(MAF_KO & 128)) {
+        const int xcd = wg & 7, q = a.ntiles >> 3, r = a.ntiles & 7, base = xcd * q + min(xcd, r);
+        tile = base + (wg >> 3); t_end = base + q + (xcd < r ? 1 : 0); t_step = wgc >> 3;
+    }
+    const int t_last = t_end > 0 ? t_end - 1 : 0;
     // NBUF - 1 patches in flight ahead of the one being multiplied (NBUF = 3: a patch has two tile times to arrive)
 #pragma unroll
     for (int k = 0; k < NBUF - 1; ++k)
-        if (tile + k * wgc < a.ntiles) dma(tile + k * wgc, k);
-        else dma(a.ntiles - 1, k);                                                // keep the DMA count per wave uniform (the data is never read)
+        if (tile + k * t_step < t_end) dma(tile + k * t_step, k);
+        else dma(t_last, k);                                                      // keep the DMA count per wave uniform (the data is never read)
     if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int it = 0; tile < a.ntiles; ++it, tile += wgc) {
+    for (int it = 0; tile < t_end; ++it, tile += t_step) {
         const int cur = it % NBUF, ocur = it & 1;
         {
-            const int nt_ = tile + (NBUF - 1) * wgc;
-            dma(nt_ < a.ntiles ? nt_ : a.ntiles - 1, (it + NBUF - 1) % NBUF);     // every wave left that buffer before the last barrier
+            const int nt_ = tile + (NBUF - 1) * t_step;
+            dma(nt_ < t_end ? nt_ : t_last, (it + NBUF - 1) % NBUF);              // every wave left that buffer before the last barrier
         }
         // lane addresses of the fragment reads: [ky >> 1][kx >> 1][k-step within the tap] (the rest of an address is a compile-time offset)
         uint32_t fa[2][2][KPT];
