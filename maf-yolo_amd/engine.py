@@ -775,7 +775,9 @@ class Plan:
                                         timer.stop(stream.cuda_stream)
                                         ts.append(timer.elapsed_ms())
                                     results.append((min(ts), -2, tw, th * 256 + cb))
-                    if self.dtype == lib.F16:                            # a wave per 8-channel group, weights as scalar operands (csrc/dwconv_sw.hip): tile_p = -3, tile_c = columns, tile_k = rows * 256 + waves per workgroup
+                    # (only where the pixel-pair kernel below cannot run: timed alone with warm operands the two are close on the 20 x 20 layers, inside the forward
+                    # dwconv_p2 wins every time — 21.6 against 29.1 us on backbone.12.m.0.conv2 — and a chain of the round lost 7 us to such a pick)
+                    if self.dtype == lib.F16 and self._pairs_producer(i) is None:   # a wave per 8-channel group, weights as scalar operands (csrc/dwconv_sw.hip): tile_p = -3, tile_c = columns, tile_k = rows * 256 + waves per workgroup
                         w4 = -(-o.W // 4) * 4
                         for th in sorted({4, 5, 8, 10, 16, 20, 32} | ({o.H} if o.H <= 40 else set())):
                             if th > o.H:
