@@ -415,6 +415,31 @@ def test_fused_stem_matches_unfused(shape, dt, scale):
         _close16(outs[fs], outs[0], scale)
 
 
+def test_tuned_plan_at_the_benchmark_size_matches_the_default_plan(models):
+    """BASELINE configs[1] as bench.py runs it — 32 x 640^2, fp16, autotune on: the tuned plan carries what only tuned plans have (MPRep of backbone.3 as ONE
+    launch of the LDS-resident 3x3 kernel, csrc/conv3s2_lds.hip with nc) beside the dense concat slots behind the fused stem, and its predictions equal the
+    untuned default plan's (one launch list for every batch size, generic tiles) within the fp16 class; image i of the batch equals image i run alone."""
+    x = O.synth_images(32, 640, 17).to(DEV).half()
+    with torch.no_grad():
+        ref = models["n"](x)[0].float().cpu().numpy()
+        one = models["n"](x[7:8])[0].float().cpu().numpy()
+    from maf_yolo_amd import lib
+    m = M.Model("n")
+    m.load_state_dict(O.synth_state_dict("n", 0))
+    m = m.to(DEV).eval()
+    m.autotune = True
+    with torch.no_grad():
+        got = m(x)[0].float().cpu().numpy()
+    plan = m.plan_for(x)
+    fused = [o for o, n_ in zip(plan.ops, plan.op_names) if n_ == "backbone.3.conv1+conv2"]
+    assert len(fused) == 1 and (fused[0].kind, fused[0].tile_k, fused[0].nc, fused[0].reg_stride, fused[0].out_coff) == (lib.OP_CONV3X3S2, 6, 48, 0, 48)
+    assert plan.ops[0].kind == lib.OP_STEM2 and plan.ops[0].aux[0] and plan.ops[plan.op_names.index("backbone.2.conv2")].nsrc == 3
+    assert len(plan.ops) == len(models["n"].plan_for(x).ops) - 1
+    assert np.isfinite(got).all()
+    _close16(got, ref, "n")
+    _close16(got[7:8], one, "n")
+
+
 def test_fusion_choice_is_measured_when_autotuning():
     from maf_yolo_amd import engine
     m = M.Model("n")
