@@ -621,7 +621,7 @@ def test_weight_staging_plan_matches_per_layer_packing():
     model.zero_grad(set_to_none=True)
     c1, g1 = run()                                                    # step 2: one batch launch, same weights
     assert train_ops.stats["pack_batches"] == 1
-    assert torch.allclose(c0, c1, rtol=0, atol=5e-4)                  # (BatchNorm sums are atomics: last-bit differences run to run)
+    assert torch.allclose(c0, c1, rtol=2e-3, atol=1e-3)               # (BatchNorm sums are atomics: the fp16 outputs differ by an ulp or two — 9.8e-4 relative — run to run; 5e-4 absolute failed one run in ~10)
     L = M.lib.load()
     st = torch.cuda.current_stream().cuda_stream
     checked = 0
@@ -651,7 +651,7 @@ def test_weight_staging_plan_matches_per_layer_packing():
     model2 = model2.cuda().train()
     with torch.autocast("cuda", dtype=torch.float16):
         (f2, cls2, r2), _ = model2(x)                                  # fresh model, first step: per-layer packs of the same weights
-    assert torch.allclose(cls2.detach().float(), c2, rtol=0, atol=5e-4)
+    assert torch.allclose(cls2.detach().float(), c2, rtol=2e-3, atol=1e-3)
     model.float()                                                     # _apply: the staged buffers point at storage that may be replaced
     assert model._pack_plan is None
 
