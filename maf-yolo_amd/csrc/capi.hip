@@ -109,23 +109,25 @@ static int engine_launch_all(maf_engine* e, const void* image, void* pred, hipSt
     int rc = engine_prepare_lanes(e);
     if (rc) return rc;
     const bool multi = e->n_lanes > 1;
-    if (multi) {                                             // fork: the side lanes start after everything already queued on s
-        rc = maf_check_hip(hipEventRecord(e->fork, s), "hipEventRecord(fork)");
-        for (int l = 1; l < e->n_lanes && !rc; ++l) rc = maf_check_hip(hipStreamWaitEvent(e->side[l], e->fork, 0), "hipStreamWaitEvent(fork)");
-        if (rc) return rc;
-    }
     int* cand_cnt = nullptr; unsigned long long* cand_keys = nullptr; long long cand_cap = 0;
     if (cand_ws) {                                           // candidate filter in the head tails: every level must end in one
-        int B = 0, A = 0, tails = 0;
+        int B = 0, A = 0, nc = 0, tails = 0;
         for (const maf_op_t& o : e->ops) {
             if (o.kind == MAF_OP_DECODE) { maf_set_error("maf_engine_run_filtered: a level of this plan is decoded by MAF_OP_DECODE (no fused tail)"); return MAF_E_UNSUPPORTED; }
-            if (o.kind == MAF_OP_HEADTAIL) { B = o.B; A = o.Win; ++tails; }
+            if (o.kind == MAF_OP_HEADTAIL) { B = o.B; A = o.Win; nc = o.nc; ++tails; }
         }
         if (!tails) { maf_set_error("maf_engine_run_filtered: the plan has no MAF_OP_HEADTAIL"); return MAF_E_UNSUPPORTED; }
         cand_cnt = static_cast<int*>(cand_ws);
         cand_keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(cand_ws) + 256 + (long long)B * MAF_NMS_CNT_STRIDE * 4);
-        cand_cap = nms_cap_pow2((long long)A * 80);
+        cand_cap = nms_cap_pow2((long long)A * nc);          // the key capacity maf_nms_ex derives from (N, nc) for the same workspace
+        // the counter reset is queued BEFORE the fork event: a head tail on a side lane is then ordered behind it by the fork itself, not
+        // only through its data dependencies on lane-0 ops
         rc = maf_check_hip(hipMemsetAsync(cand_cnt, 0, (size_t)B * MAF_NMS_CNT_STRIDE * 4, s), "candidate counter reset");
+        if (rc) return rc;
+    }
+    if (multi) {                                             // fork: the side lanes start after everything already queued on s
+        rc = maf_check_hip(hipEventRecord(e->fork, s), "hipEventRecord(fork)");
+        for (int l = 1; l < e->n_lanes && !rc; ++l) rc = maf_check_hip(hipStreamWaitEvent(e->side[l], e->fork, 0), "hipStreamWaitEvent(fork)");
         if (rc) return rc;
     }
     for (size_t i = 0; i < e->ops.size(); ++i) {

@@ -1,6 +1,6 @@
 // Launch-overlap probe: does a kernel launched WITHOUT the AQL barrier bit (hipExtLaunchKernel flag hipExtAnyOrderLaunch) start while its
 // predecessors in the same stream are still running?  The engine uses that to run independent ops of the graph side by side inside ONE
-// stream (no events, no extra streams); this probe measures it on the device at hand (maf_probe_anyorder, tools/anyorder_probe.py).
+// stream (no events, no extra streams); this probe measures it on the device at hand (maf_probe_anyorder; result in DESIGN.md 5a: accepted and ignored on gfx950).
 #include <hip/hip_ext.h>
 #include "maf_common.h"
 

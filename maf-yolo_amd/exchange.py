@@ -9,8 +9,9 @@ chain), so a reducer that reads them on the main stream forces a join after ever
 
 on the side stream:
 
-* every parameter owns a slice of a flat fp32 bucket; `p.grad` is a VIEW of that slice (set once; `zero_grad()` is one memset per
-  bucket, never `set_to_none`);
+* every parameter owns a slice of a flat fp32 bucket; `p.grad` is a VIEW of that slice (`zero_grad()` is one memset per bucket; an
+  `optimizer.zero_grad()` with its default `set_to_none=True` — what the reference trainer calls, engine.py:347,388 — is survived: the first
+  gradient of the next pass finds the view gone, clears the slice and re-attaches it, `_attach`);
 * the conv weight-gradient kernels accumulate straight into the slice (1x1, depth-wise: the kernel's layout is the parameter's) or go
   through one `maf_grad_fold` launch (3x3: tap-major -> [Cout][Cin][3][3]; padded channel counts) — on the side stream, and the autograd
   Function returns None for the weight, so no AccumulateGrad node touches these gradients on the main stream;
@@ -36,19 +37,28 @@ current = None                                  # the exchange train_ops hands i
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "main_contrib", "work", "launched")
+    __slots__ = ("flat", "params", "ids", "arrived", "main_contrib", "work", "launched")
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
-        self.pending, self.main_contrib, self.work, self.launched = 0, False, None, False
+        self.ids = frozenset(id(p) for p in params)
+        self.arrived, self.main_contrib, self.work, self.launched = set(), False, None, False
+
+    def reset(self):
+        self.arrived, self.main_contrib, self.work, self.launched = set(), False, None, False
 
 
 class GradExchange:
-    def __init__(self, model, bucket_bytes=None, process_group=None, world_size=None):
+    def __init__(self, model, bucket_bytes=None, process_group=None, world_size=None, force_collectives=False):
+        """`force_collectives`: issue the bucket all-reduces even when the group has ONE rank (the RCCL schedule — AVG, async, from the side
+        stream — then runs on a single GPU: tests/test_gpu_exchange.py, `bench.py --train --rccl1`)."""
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = process_group
         self.world = world_size if world_size is not None else (self.dist.get_world_size(process_group) if self.dist is not None else 1)
+        self.force = bool(force_collectives)
+        if self.force and self.dist is None:
+            raise lib.MafError("GradExchange(force_collectives=True) needs an initialised process group")
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "GradExchange: the model has no trainable parameter"
         self.device = params[0].device
@@ -71,8 +81,9 @@ class GradExchange:
             self._close(cur)
         self._sync = True
         self._armed = False
+        self._next = 0                                                           # buckets go out in bucket order on every rank (see _arrived)
         self._hooks = [p.register_post_accumulate_grad_hook(self._main_hook) for p in params]
-        self.stats = {"collectives": 0, "side_direct": 0, "side_folded": 0, "main_hook": 0}
+        self.stats = {"collectives": 0, "side_direct": 0, "side_folded": 0, "main_hook": 0, "reattached": 0}
         self.begin()                                                             # active from here on (`close()` deactivates)
 
     def _close(self, ps):
@@ -97,14 +108,19 @@ class GradExchange:
                 if p.grad is None or p.grad.data_ptr() != self.slot[id(p)][1].data_ptr():
                     p.grad = self.slot[id(p)][1]
 
+    def _reset_pass(self):
+        self._armed = False
+        self._next = 0
+        for b in self.buckets:
+            b.reset()
+
     def begin(self):
         """Start of a forward: this exchange receives the weight gradients of the next backward pass.  Resets the per-pass state, so a
-        backward pass that raised cannot leave a stale 'callback queued' flag behind."""
+        backward pass that raised cannot leave a stale 'callback queued' flag behind (`finish()` resets it too: a second backward without
+        a new forward — retain_graph, two forwards then two backwards — starts clean)."""
         global current
         current = self
-        self._armed = False
-        for b in self.buckets:
-            b.pending, b.main_contrib, b.work, b.launched = len(b.params), False, None, False
+        self._reset_pass()
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -120,16 +136,34 @@ class GradExchange:
             self._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
 
+    def _attach(self, p, view):
+        """`p.grad` must BE the bucket view.  The reference trainer calls `optimizer.zero_grad()` (yolov6/core/engine.py:347,388), whose default
+        `set_to_none=True` drops it: the slice then still holds the previous step's averaged gradient, which 'gradients were cleared' means
+        to be zero.  Runs on the main stream BEFORE the weight-gradient kernel is forked to the side stream (the fork's event orders it)."""
+        g = p.grad
+        if g is view or (g is not None and g.data_ptr() == view.data_ptr()):
+            return
+        if g is None:
+            view.zero_()
+        else:                                                                     # a foreign tensor (someone assigned p.grad): it IS the accumulated gradient
+            view.copy_(g)
+        p.grad = view
+        self.stats["reattached"] += 1
+
     def target(self, p):
-        """(bucket, view) of parameter p if it is registered (train_ops: where the weight gradient goes), else None."""
-        return self.slot.get(id(p))
+        """(bucket, view) of parameter p if it is registered (train_ops: where the weight gradient goes), else None.  Called once per
+        weight-gradient launch, before the fork to the side stream."""
+        ent = self.slot.get(id(p))
+        if ent is not None:
+            self._attach(p, ent[1])
+        return ent
 
     def side_done(self, p, folded=False):
         """train_ops: the gradient of p has been issued into its slice on the side stream."""
         self._arm()
         b = self.slot[id(p)][0]
         self.stats["side_folded" if folded else "side_direct"] += 1
-        self._arrived(b, False)
+        self._arrived(b, p, False)
 
     def _main_hook(self, p):
         ent = self.slot.get(id(p))
@@ -137,24 +171,39 @@ class GradExchange:
             return
         b, view = ent
         if p.grad is not view and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
-            # someone replaced the view (zero_grad(set_to_none=True) before this pass): fold the fresh tensor back into the bucket
-            view.add_(p.grad)
+            # autograd found `p.grad` empty (zero_grad(set_to_none=True) before this pass) and installed a fresh tensor: that tensor is the
+            # whole gradient — the slice's old content is the step before's — so it REPLACES the slice
+            view.copy_(p.grad)
             p.grad = view
+            self.stats["reattached"] += 1
         self._arm()
         self.stats["main_hook"] += 1
-        self._arrived(b, True)
+        self._arrived(b, p, True)
 
-    def _arrived(self, b, on_main):
+    def _arrived(self, b, p, on_main):
+        if b.launched and self._sync and self._collectives():
+            # the bucket has gone out with this pass's first contribution of every parameter; one more would be lost on the other ranks
+            raise lib.MafError("GradExchange: a second gradient of a parameter arrived after its bucket was reduced "
+                               "(a parameter used more than once per backward pass is not supported)")
         b.main_contrib = b.main_contrib or on_main
-        b.pending -= 1
-        if b.pending == 0 and self._sync:
-            self._launch(b)
+        b.arrived.add(id(p))
+        if not self._sync:
+            return
+        # in BUCKET ORDER on every rank: a parameter without a gradient on one rank only must not reorder the collectives between ranks
+        # (RCCL matches them by issue order) — a complete bucket waits for the ones in front of it, `finish()` flushes the rest in order
+        while self._next < len(self.buckets) and len(self.buckets[self._next].arrived) == len(self.buckets[self._next].ids):
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    def _collectives(self):
+        return self.dist is not None and (self.world > 1 or self.force)
 
     def _launch(self, b):
-        if b.launched or self.world <= 1 or self.dist is None:
-            b.launched = True
+        if b.launched:
             return
         b.launched = True
+        if not self._collectives():
+            return
         dist = self.dist
         avg = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM
         if b.flat.is_cuda:
@@ -175,23 +224,24 @@ class GradExchange:
         self.stats["collectives"] += 1
 
     def finish(self):
-        """End of backward: launch what is still open (parameters that received no gradient leave their bucket incomplete), then make the
-        main stream wait for the side stream and for every collective."""
-        if self._sync:
-            for b in self.buckets:
-                if not b.launched:
+        """End of backward: launch what is still open, in bucket order (parameters that received no gradient leave their bucket incomplete),
+        then make the main stream wait for the side stream and for every collective, and reset the per-pass state."""
+        try:
+            if self._sync:
+                for b in self.buckets[self._next:]:
                     b.main_contrib = True
                     self._launch(b)
-        for b in self.buckets:
-            if b.work is not None:
-                b.work.wait()
-                if not b.flat.is_cuda and self.dist is not None and self.dist.get_backend(self.group) != "nccl":
-                    b.flat.mul_(1.0 / self.world)
-                b.work = None
-        if self.device.type == "cuda":
-            from . import train_ops
-            train_ops.join_side(self.device)
-        self._armed = False
+            for b in self.buckets:
+                if b.work is not None:
+                    b.work.wait()
+                    if not b.flat.is_cuda and self.dist is not None and self.dist.get_backend(self.group) != "nccl":
+                        b.flat.mul_(1.0 / self.world)
+                    b.work = None
+            if self.device.type == "cuda":
+                from . import train_ops
+                train_ops.join_side(self.device)
+        finally:
+            self._reset_pass()
 
     def close(self):
         global current

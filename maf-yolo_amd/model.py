@@ -294,7 +294,7 @@ class Model(nn.Module):
                 pred = torch.empty(plan.B, plan.A, 5 + plan.nc, dtype=torch.float32, device=plan.device)
                 ws = _nms.candidate_workspace(plan.device, plan.B, plan.A, plan.nc, slot)
                 plan.run_into(x, pred, cand=(ws, conf))
-                pred._maf_cand = (ws, float(conf))
+                pred._maf_cand = (ws, float(conf), ws._maf_gen, pred._version)   # generation + version counter: nms.nms_raw checks both
             else:
                 pred = plan.run(x, graph=False)      # hipGraph replay needs fixed buffers: use Plan.run_into(x, pred, graph=True)
         feats = plan.featmaps()

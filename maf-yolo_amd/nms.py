@@ -38,9 +38,20 @@ def candidate_workspace(dev, B, N, nc, slot=0):
     if ws is None:
         ws = _cand_ws[key] = torch.empty(lib.load().maf_nms_workspace_bytes(B, N, nc), dtype=torch.uint8, device=dev)
         ws._maf_busy = None
+        ws._maf_gen = 0
     if ws._maf_busy is not None:
         torch.cuda.current_stream(dev).wait_event(ws._maf_busy)
+    # every filtered forward that refills the workspace takes a new generation: a prediction carries the generation of ITS forward, and
+    # the NMS uses the lists only while the workspace still holds that one (`p1 = model(x1); p2 = model(x2); nms(p1)` must not read
+    # forward 2's lists for p1 — it falls back to its own pass over p1)
+    ws._maf_gen += 1
     return ws
+
+
+def _cand_valid(prediction, cand):
+    """The candidate lists belong to this very tensor as its forward wrote it: same workspace generation, and nobody has written the tensor
+    in place since (torch's version counter)."""
+    return len(cand) == 4 and cand[0]._maf_gen == cand[2] and prediction._version == cand[3]
 
 
 def _workspace(dev, st, B, N, nc, need):
@@ -78,7 +89,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
             pred = pred.contiguous()
             # candidate lists written by the forward pass that produced this very tensor (Model.nms_filter): usable if this call filters the same way
             cand = getattr(prediction, "_maf_cand", None)
-            pre = (cand is not None and pred is prediction and multi_label and nc > 1 and classes is None and float(conf_thres) == cand[1]
+            pre = (cand is not None and _cand_valid(prediction, cand) and pred is prediction and multi_label and nc > 1 and classes is None and float(conf_thres) == cand[1]
                    and not _single_launch(B) and cand[0].numel() >= L.maf_nms_workspace_bytes(B, N, nc))
             ws = cand[0] if pre else _workspace(dev, st, B, N, nc, L.maf_nms_workspace_bytes(B, N, nc))
             rows = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)

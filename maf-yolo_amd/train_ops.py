@@ -30,7 +30,7 @@ stats = {"native_conv1x1": 0, "native_dwconv": 0, "fallback": 0}
 # Per-kernel timing of one training step (bench.py --train: the `roofline` object): while `profile` is a dict every native launch is
 # bracketed by HIP events on its stream; profile_collect() turns them into {kind: [milliseconds, algorithmic bytes, launches]}.
 profile = None
-profile_detail = None                # a list: profile_collect() also appends (kind, note, ms, bytes) per launch (tools/train_detail.py)
+profile_detail = None                # a list: profile_collect() also appends (kind, note, ms, bytes) per launch
 _pending = []
 
 

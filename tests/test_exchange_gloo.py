@@ -129,3 +129,108 @@ def test_grad_exchange_single_process_matches_autograd():
         assert ex.stats["collectives"] == 0
     finally:
         ex.close()
+
+
+def _models():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import maf_yolo_amd as M
+    torch.manual_seed(0)
+    a = M.Model("n").train()
+    b = M.Model("n").train()
+    b.load_state_dict(a.state_dict())
+    return M, a, b
+
+
+def test_grad_exchange_survives_the_reference_trainers_zero_grad():
+    """The reference calls `optimizer.zero_grad()` (engine.py:347,388; set_to_none=True by default) and never `ex.zero_grad()`: every step must
+    still see this step's gradients only, in the bucket views (advisor finding, round 3)."""
+    M, a, b = _models()
+    xs = [torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(i)) for i in range(3)]
+    ex = M.GradExchange(b)
+    opt = torch.optim.SGD(b.parameters(), lr=0.0)
+    try:
+        for x in xs:
+            for p in a.parameters():
+                p.grad = None
+            opt.zero_grad()                                                            # drops every view; the buckets keep last step's numbers
+            _loss(a, x, 1).backward()
+            _loss(b, x, 1).backward()
+            for (n, p), q in zip(a.named_parameters(), b.parameters()):
+                if not p.requires_grad:
+                    continue
+                assert q.grad is not None and q.grad.data_ptr() == ex.slot[id(q)][1].data_ptr(), n
+                assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+        assert ex.stats["reattached"] >= 2 * sum(1 for p in b.parameters() if p.requires_grad)
+    finally:
+        ex.close()
+
+
+def test_grad_exchange_second_backward_without_a_new_forward():
+    """retain_graph / two backward passes of one forward: the per-pass state is reset by finish(), not only by the next forward."""
+    M, a, b = _models()
+    x = torch.rand(2, 3, 64, 64)
+    ex = M.GradExchange(b)
+    try:
+        la, lb = _loss(a, x, 1), _loss(b, x, 1)
+        la.backward(retain_graph=True); la.backward()
+        ex.zero_grad()
+        lb.backward(retain_graph=True)
+        assert all(not bk.launched and not bk.arrived for bk in ex.buckets) and ex._next == 0
+        lb.backward()
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            assert not p.requires_grad or torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+    finally:
+        ex.close()
+
+
+def _order_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import maf_yolo_amd as M
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8))
+    ex = M.GradExchange(net, bucket_bytes=64)                                          # one bucket per parameter: 6 buckets
+    order = []
+    launch = ex._launch
+    ex._launch = lambda b: (order.append(ex.buckets.index(b)), launch(b))[1]
+    x = torch.full((4, 8), float(rank + 1))
+    # rank 1 does not use the LAST layer's result (its parameters get no gradient there): without the bucket-order rule its first
+    # collective would be another bucket than rank 0's and the ranks would reduce different buckets against each other
+    h = net[1](net[0](x))
+    y = net[2](h) if rank == 0 else h
+    y.sum().backward()
+    g0 = net[0].weight.grad.clone()
+    both = [torch.zeros_like(g0) for _ in range(world)]
+    dist.all_gather(both, g0)
+    if rank == 0:
+        out.put(dict(order=order, same=bool(torch.equal(both[0], both[1])), n=len(ex.buckets),
+                     # layer 0's dW = sum over the batch of dy x^T, averaged over ranks whose x are 1s and 2s
+                     finite=bool(torch.isfinite(g0).all())))
+    else:
+        out.put(dict(order1=order))
+    ex.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_exchange_collectives_go_out_in_bucket_order_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        res.update(q.get(timeout=120))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res["order"] == list(range(res["n"])) == res["order1"], res
+    assert res["same"] and res["finite"], res

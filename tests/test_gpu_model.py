@@ -224,6 +224,27 @@ def test_candidate_filter_inside_the_forward_gives_the_same_detections(models, c
         h = M.non_max_suppression_async(m(x)[0], conf, **kw)                 # the serving loop's form, NMS on a side stream
         for a_, b_ in zip(h.result(), want):
             assert torch.equal(a_, b_)
+        # the lists belong to ONE forward: a second forward into the slot before the first prediction's NMS refills them, and the NMS of the
+        # first prediction must not read forward 2's lists (advisor finding, round 3) — it falls back to its own pass
+        x2 = O.synth_images(2, 640, 6).to(DEV).half()
+        p1 = m(x)[0]
+        p2 = m(x2)[0]
+        got1 = M.non_max_suppression(p1, conf, **kw)
+        assert p1._maf_cand is not None                                      # stale generation: not used, not consumed
+        for a_, b_ in zip(got1, want):
+            assert torch.equal(a_, b_)
+        want2 = M.non_max_suppression(p2.clone(), conf, **kw)
+        got2 = M.non_max_suppression(p2, conf, **kw)
+        assert p2._maf_cand is None
+        for a_, b_ in zip(got2, want2):
+            assert torch.equal(a_, b_)
+        # ... and to the tensor AS WRITTEN: an in-place edit of the prediction invalidates them
+        p3 = m(x)[0]
+        p3[..., 5:] *= 0.5
+        got3 = M.non_max_suppression(p3, conf, **kw)
+        want3 = M.non_max_suppression(p3.clone(), conf, **kw)
+        for a_, b_ in zip(got3, want3):
+            assert torch.equal(a_, b_)
     finally:
         m.nms_filter = None
 
