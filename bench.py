@@ -149,7 +149,7 @@ def train_pmc_traffic(kind, scale):
     """HBM bytes per launch of `kind` from the PMC passes of a training run committed under profiles/ (tools/profile_round.sh: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs, counters only; tools/pmc_traffic.py: (FETCH_SIZE*2 + WRITE_SIZE)*1024) — n at batch 32 only."""
     import re
-    path = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round3_train_pmc_traffic.json", "round2_train_pmc_traffic.json")) if os.path.exists(p_)]
+    path = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round4_train_pmc_traffic.json", "round3_train_pmc_traffic.json", "round2_train_pmc_traffic.json")) if os.path.exists(p_)]
     path = path[0] if path else ""
     pat = _TRAIN_KIND_KERNELS.get(kind)
     if pat is None or scale != "n" or not os.path.exists(path):
@@ -183,7 +183,9 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
     if args.ddp and world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
     elif not args.ddp:
-        ex = M.GradExchange(model)
+        # --rccl1: a ONE-rank RCCL group and force_collectives — the all-reduces (AVG, async, from the weight-gradient stream) are really
+        # issued; what they cost on one GPU (a self-reduce per bucket) is reported as all_reduce.exposed_all_reduce_ms
+        ex = M.GradExchange(model, force_collectives=bool(getattr(args, "rccl1", False)) and dist is not None)
     # build.py:12-33 grouping (BatchNorm weights and biases without decay), lr0 scaled like engine.py: fused SGD keeps the AMP inf check on the device
     opt = M.build_optimizer(model, lr0=0.01 / 64 * batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
     scaler = torch.amp.GradScaler("cuda")
@@ -244,7 +246,7 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
     # ---- exposed (non-overlapped) all-reduce time (BASELINE configs[3], yolov6/core/engine.py:477-489): the same steps with the collectives
     # switched off (no_sync) — the difference is what the exchange adds to a step after its overlap with the remaining backward
     comm = None
-    if world > 1:
+    if world > 1 or (ex is not None and ex.force):
         def nosync():
             with (ex.no_sync() if ex is not None else net.no_sync()):
                 step()
@@ -299,7 +301,7 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
                        "global_batch": B * world, "parallelism": "ddp%d" % world,
                        "gradient_exchange": ("torch DistributedDataParallel" if ex is None and world > 1 else "none (plain autograd)" if ex is None else
                                              "maf_yolo_amd.GradExchange: %d flat fp32 buckets filled on the weight-gradient stream, all-reduce per bucket from that stream%s"
-                                             % (nb, "" if world > 1 else " (world size 1: same schedule, no collective)")),
+                                             % (nb, "" if world > 1 else " (one-rank RCCL group: the collectives ARE issued, --rccl1)" if ex.force else " (world size 1: same schedule, no collective)")),
                        "exchange_stats": exs,
                        "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
                        "native_launches": launches, "fallback": fallback, "final_loss": round(final, 5)},
@@ -344,6 +346,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
+    ap.add_argument("--rccl1", action="store_true", help="--train at N = 1: initialise a one-rank RCCL group and issue the bucket all-reduces anyway (GradExchange(force_collectives=True))")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")
@@ -365,6 +368,11 @@ def main():
     torch.cuda.set_device(0 if one_dev else local_rank)
     dev = torch.device("cuda", 0 if one_dev else local_rank)
     dist = None
+    if world == 1 and args.rccl1:
+        import socket
+        import torch.distributed as dist
+        so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
@@ -391,9 +399,9 @@ def main():
     from maf_yolo_amd import engine as _engine
     # tile choices (which (pixels x channels) cut, which kernel variant per layer) measured on an MI355X and frozen in the repo are the
     # default starting point: layer signatures that are not in the file are still timed here.  --tune-file none = time everything afresh.
-    frozen = os.path.join(ROOT, "profiles", "round3_tune.json")
-    if args.tune_file is None and os.path.exists(frozen):
-        args.tune_file = frozen
+    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round4_tune.json", "round3_tune.json")) if os.path.exists(p_)]
+    if args.tune_file is None and frozen:
+        args.tune_file = frozen[0]
     if args.tune_file == "none":
         args.tune_file = None
     if args.tune_file and os.path.exists(args.tune_file):
@@ -458,7 +466,8 @@ def main():
     # set-up, not part of the W warm-up steps: the first few dozen iterations of the loop grow the caching allocator's pools (prediction
     # tensors handed to the NMS stream return to the forward stream's pool late), and every hipMalloc that causes stalls the device —
     # measured as an occasional 2.5 ms/step first run of an otherwise 1.67 ms/step loop.  Run the loop until the pools are settled.
-    pipelined(48)
+    POOL_SETTLE_STEPS = 48                        # reported in the line as `pool_settle_steps`: untimed, on top of the W warm-up steps
+    pipelined(POOL_SETTLE_STEPS)
     if args.warmup:
         dets = pipelined(args.warmup)
     sync_all()
@@ -535,12 +544,26 @@ def main():
         fwd_img_s = B / (fwd_ms * 1e-3)
         traffic, traffic_src, pmc = None, None, {}
         try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
-            pmc_file = [f_ for f_ in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            pmc_file = [f_ for f_ in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             have = [k for k in gd["inst"] if k in pmc]
             if have:                           # per launch of the template: instantiations weighted by their launches in this forward
                 traffic = int(sum(pmc[k]["traffic_bytes"] * groups[k]["n"] for k in have) / sum(groups[k]["n"] for k in have))
                 traffic_src = "profiles/%s: (FETCH_SIZE*2 + WRITE_SIZE)*1024 per launch, gfx950 FETCH_SIZE x2 correction" % pmc_file
+        except Exception:
+            pass
+        # the same family's average launch duration in the committed rocprofv3 --kernel-trace --stats summary (tools/profile_round.sh runs this very
+        # command under the profiler): beside the live event figure, which carries ~2.5 us of event-pair overhead per launch
+        rocprof_avg_ms, rocprof_src = None, None
+        try:
+            import csv as _csv
+            stats_file = [f_ for f_ in ("round4_kernel_stats.csv", "round3_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            tot_ns = calls = 0
+            for row in _csv.DictReader(open(os.path.join(ROOT, "profiles", stats_file))):
+                if name in row["Name"]:
+                    tot_ns += int(row["TotalDurationNs"]); calls += int(row["Calls"])
+            if calls:
+                rocprof_avg_ms, rocprof_src = round(tot_ns / calls / 1e6, 5), "profiles/%s (%d calls)" % (stats_file, calls)
         except Exception:
             pass
         insts = []
@@ -562,6 +585,8 @@ def main():
         roofline = dict(bound="hbm", kernel=name + "<...> (%d instantiations)" % len(gd["inst"]), launches_per_forward=gd["n"], avg_launch_ms=round(avg_ms, 5),
                         bytes_per_launch=int(bytes_per_launch), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                        rocprof_avg_launch_ms=rocprof_avg_ms, rocprof_source=rocprof_src,
+                        frac_rocprof=None if not rocprof_avg_ms else round(bytes_per_launch / (rocprof_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         share_of_forward=round(gd["ms"] / per_op_ms.sum(), 4), largest_symbol=largest, top_instantiations=insts,
                         whole_forward=dict(algorithmic_GB=round(tot_bytes / 1e9, 4), layer_granular_GB=round(layer_gb, 4),
                                            hbm_frac_layer_granular=round(layer_gb / (fwd_ms * 1e-3) / HBM_PEAK_GBS, 4), GFLOP=round(tot_flops / 1e9, 2),
@@ -612,6 +637,8 @@ def main():
 
         out = {"metric": "images/sec MAF-YOLO-%s 640x640 bs=%d infer (Model.forward + non_max_suppression)" % (args.scale, B),
                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "pool_settle_steps": POOL_SETTLE_STEPS, "untimed_steps_before_the_timed_region": POOL_SETTLE_STEPS + args.warmup,
+               "timed_region_s": round(elapsed, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f16", "data": "synthetic",
                "config": {"workload": "MAF-YOLO-%s deploy-form inference, %d x 3x640x640 fp16 per GPU resident in HBM, "

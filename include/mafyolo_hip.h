@@ -320,6 +320,17 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
                     const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
                     void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
                     const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream);
+/* maf_bn_backward with accumulate_affine != 0: dgamma / dbeta are ADDED to what the buffers hold — the slices of a gradient-exchange bucket
+ * (maf_yolo_amd/exchange.py: `p.grad` of the BatchNorm affine parameters is a view of a flat fp32 bucket; the reference accumulates them with
+ * AccumulateGrad, i.e. 280 one-line add kernels per step of MAF-YOLO-n, yolov6/core/engine.py:164). */
+int maf_bn_backward_acc(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
+                        void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
+                        const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, int32_t accumulate_affine, maf_stream_t stream);
+/* Bit-reproducible BatchNorm statistics (a test / debugging mode, process-wide, one stream at a time): the statistics kernels of maf_bn_forward /
+ * maf_bn_backward write per-workgroup sums with plain stores and a third launch adds them in a fixed order, instead of fp32 atomics whose order
+ * changes from run to run.  With it two forward passes of the train-form graph are bit-identical (torch.use_deterministic_algorithms' role). */
+int maf_set_deterministic(int32_t on);
 int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin, int32_t Cout,
                       int32_t dtype, float* dw, maf_stream_t stream);
 /* General form: dW (fp32, accumulated into) of a conv with k = 1 (stride 1 / 2, pad 0) or k = 3 (stride 2, pad 1) — RepVGGBlock.rbr_dense /

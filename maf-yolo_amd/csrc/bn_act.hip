@@ -28,6 +28,8 @@ struct BnArgs2 {
     float eps, momentum; float* running_mean; float* running_var; long long* counter;
     float* dgamma; float* dbeta;
     const void* res; void* dres; int rs, drs;          // residual added before the activation (forward, and backward when the activation needs u); d residual out
+    int acc_affine;                                   // backward: dgamma / dbeta are ADDED to what the buffers hold (a gradient-exchange bucket slice)
+    float* det;                                       // deterministic mode (maf_set_deterministic): per-workgroup sums [gridDim.x][2][C], no atomics anywhere
 };
 
 template <typename T> struct Vec;
@@ -117,6 +119,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
             accum(xv, dv, rv);
         }
     }
+    if (a.det) {
+        // Bit-reproducible statistics (maf_set_deterministic; a test / debugging mode): no atomics — every thread parks its partial sums in LDS, one
+        // thread per (channel, statistic) adds the pixel lanes of its channel IN ORDER, the workgroup's sums go to its own slot with plain stores and
+        // bn_det_reduce_kernel adds the slots in order.  (The fp32 atomics of the normal path land in another order every run; one ulp in a
+        // BatchNorm's statistics is enough to flip a near-tied arg-max of a max-pool further down, i.e. a discrete change of the BACKWARD pass.)
+        __syncthreads();
+        float* ld = lsum;                                             // [256][2 N] (the launch sized the LDS for it)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { ld[threadIdx.x * 2 * N + j] = active ? s0[j] : 0.f; ld[threadIdx.x * 2 * N + N + j] = active ? s1[j] : 0.f; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < gcnt * N; i += 256) {
+            const int gq = i / N, j = i - gq * N;
+            double t0 = 0, t1 = 0;
+            for (int q = 0; q < plan; ++q) { t0 += ld[(q * gs + gq) * 2 * N + j]; t1 += ld[(q * gs + gq) * 2 * N + N + j]; }
+            float* slot = a.det + (size_t)blockIdx.x * 2 * a.C + gbeg * N + i;
+            slot[0] = (float)t0; slot[a.C] = (float)t1;
+        }
+        return;
+    }
     if (wave_reduce) {
         for (int off = gs; off < 64; off <<= 1) {
 #pragma unroll
@@ -130,6 +151,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     __syncthreads();
     float* dst = a.part + (size_t)(blockIdx.x % a.R) * 2 * a.C + gbeg * N;
     for (int i = threadIdx.x; i < gcnt * N; i += 256) { atomicAdd(dst + i, lsum[i]); atomicAdd(dst + a.C + i, lsum[cs + i]); }
+}
+
+// deterministic mode: part[replica 0] = the per-workgroup sums added in workgroup order (the other replicas stay zero)
+__global__ void bn_det_reduce_kernel(const float* det, int nslot, int C, float* part) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    double t = 0;
+    for (int b = 0; b < nslot; ++b) t += det[(size_t)b * 2 * C + i];
+    part[i] = (float)t;
 }
 
 // BWD = false: y = act(xhat*gamma + beta);  BWD = true: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)
@@ -171,7 +201,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
         } else {
             cst[c] = a.mean[c]; cst[a.C + c] = a.rstd[c]; cst[2 * a.C + c] = a.gamma[c]; cst[3 * a.C + c] = a.beta[c];
             cst[4 * a.C + c] = (float)s * invM; cst[5 * a.C + c] = (float)q * invM;
-            if (blockIdx.x == 0) { if (a.dbeta) a.dbeta[c] = (float)s; if (a.dgamma) a.dgamma[c] = (float)q; }
+            if (blockIdx.x == 0) {                                    // one writer per channel: a plain read-modify-write when accumulating
+                if (a.dbeta) a.dbeta[c] = (a.acc_affine ? a.dbeta[c] : 0.f) + (float)s;
+                if (a.dgamma) a.dgamma[c] = (a.acc_affine ? a.dgamma[c] : 0.f) + (float)q;
+            }
         }
     }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.clear_n; i += gridDim.x * 256) a.part_clear[i] = 0.f;
@@ -284,6 +317,31 @@ dim3 stats_grid(int M, int C, int dtype, size_t* lds) {
     return dim3((unsigned)(gx < 1 ? 1 : gx), (unsigned)nslice);
 }
 
+bool g_det = false;
+float* g_det_buf = nullptr;
+size_t g_det_cap = 0;
+
+// deterministic mode: the slot buffer (grow-only, owned by the library) and the launch geometry of the statistics kernel
+int det_prepare(BnArgs2& a, const dim3& gs, int C, int dtype, size_t* lds, hipStream_t s) {
+    a.det = nullptr;
+    if (!g_det) return 0;
+    const size_t need = (size_t)gs.x * 2 * C * sizeof(float);
+    if (need > g_det_cap) {
+        if (int rc = maf_check_hip(hipDeviceSynchronize(), "bn deterministic: hipDeviceSynchronize")) return rc;
+        if (g_det_buf) (void)hipFree(g_det_buf);
+        g_det_buf = nullptr; g_det_cap = 0;
+        if (int rc = maf_check_hip(hipMalloc(reinterpret_cast<void**>(&g_det_buf), need * 2), "bn deterministic: hipMalloc")) return rc;
+        g_det_cap = need * 2;
+    }
+    a.det = g_det_buf;
+    *lds = (size_t)256 * 2 * (dtype == MAF_F16 ? 8 : 4) * sizeof(float);
+    return 0;
+}
+
+void det_reduce(const BnArgs2& a, const dim3& gs, int C, hipStream_t s) {
+    if (a.det) hipLaunchKernelGGL(bn_det_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, a.det, (int)gs.x, C, a.part);
+}
+
 void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
     const int half = R * 2 * ((C + 255) / 256 * 256);
     // wide layers have few workgroups per address and every workgroup of the apply kernel reads all replicas: use fewer of them
@@ -296,6 +354,11 @@ void set_halves(BnArgs2& a, float* part, int C, int R, int phase) {
 }
 
 }  // namespace
+
+extern "C" int maf_set_deterministic(int32_t on) {
+    g_det = on != 0;
+    return 0;
+}
 
 extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
@@ -314,8 +377,10 @@ extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_
     size_t lds_s;
     const dim3 gs = stats_grid(M, C, dtype, &lds_s);
     const int ga = bn_grid(M, C, dtype, 8192);
+    if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
     if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
     else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
+    det_reduce(a, gs, C, s);
     a.res = residual; a.rs = res_stride;
     const size_t la = (size_t)2 * C * sizeof(float);
     if (residual) {
@@ -332,6 +397,14 @@ extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, 
                                const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
                                void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
                                const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream) {
+    return maf_bn_backward_acc(x, x_stride, dz, dz_stride, M, C, dtype, gamma, beta, save_mean, save_rstd, act, dx, dx_stride, dgamma, dbeta, part, R, phase,
+                               residual, res_stride, dres, dres_stride, 0, stream);
+}
+
+extern "C" int maf_bn_backward_acc(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
+                                   const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
+                                   void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
+                                   const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, int32_t accumulate_affine, maf_stream_t stream) {
     if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
     MAF_REQUIRE(dz && gamma && beta && save_mean && save_rstd && dx, "bn_backward: null pointer");
     MAF_REQUIRE((residual == nullptr) == (dres == nullptr), "bn_backward: residual and its gradient buffer go together (an activation-free BatchNorm passes dz through: no residual here)");
@@ -340,26 +413,31 @@ extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, 
     BnArgs2 a = {};
     a.x = x; a.dz = dz; a.y = dx; a.xs = x_stride; a.dzs = dz_stride; a.ys = dx_stride; a.M = M; a.C = C; a.act = act; a.R = R;
     a.mean = const_cast<float*>(save_mean); a.rstd = const_cast<float*>(save_rstd); a.gamma = gamma; a.beta = beta;
-    a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.acc_affine = accumulate_affine;
     set_halves(a, part, C, R, phase);
     size_t lds_s;
     const dim3 gs = stats_grid(M, C, dtype, &lds_s);
     const int ga = bn_grid(M, C, dtype, 8192);
     a.res = residual; a.rs = res_stride; a.dres = dres; a.drs = dres_stride;
     const size_t la = (size_t)6 * C * sizeof(float);
+    if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
     if (residual) {
         if (dtype == MAF_F16) {
             hipLaunchKernelGGL((bn_stats_kernel<half_t, true, true>), gs, dim3(256), lds_s, s, a);
+            det_reduce(a, gs, C, s);
             hipLaunchKernelGGL((bn_apply_kernel<half_t, true, true>), dim3(ga), dim3(256), la, s, a);
         } else {
             hipLaunchKernelGGL((bn_stats_kernel<float, true, true>), gs, dim3(256), lds_s, s, a);
+            det_reduce(a, gs, C, s);
             hipLaunchKernelGGL((bn_apply_kernel<float, true, true>), dim3(ga), dim3(256), la, s, a);
         }
     } else if (dtype == MAF_F16) {
         hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), gs, dim3(256), lds_s, s, a);
+        det_reduce(a, gs, C, s);
         hipLaunchKernelGGL((bn_apply_kernel<half_t, true>), dim3(ga), dim3(256), la, s, a);
     } else {
         hipLaunchKernelGGL((bn_stats_kernel<float, true>), gs, dim3(256), lds_s, s, a);
+        det_reduce(a, gs, C, s);
         hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(ga), dim3(256), la, s, a);
     }
     return maf_check_hip(hipGetLastError(), "bn_backward launch");

@@ -33,6 +33,7 @@ import torch
 
 from . import lib
 
+_DEBUG = __import__("os").environ.get("MAF_EXCHANGE_DEBUG") == "1"    # keep the Python stack of every arrival (shown when a late arrival raises)
 current = None                                  # the exchange train_ops hands its weight gradients to (None: plain autograd)
 
 
@@ -61,6 +62,8 @@ class GradExchange:
             raise lib.MafError("GradExchange(force_collectives=True) needs an initialised process group")
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "GradExchange: the model has no trainable parameter"
+        self.names = {id(p): n for n, p in model.named_parameters()}
+        self._via = {}                                                            # id(p) -> how its gradients of this pass arrived ("side" / "main")
         self.device = params[0].device
         total = sum(p.numel() for p in params) * 4
         if bucket_bytes is None:
@@ -83,7 +86,7 @@ class GradExchange:
         self._armed = False
         self._next = 0                                                           # buckets go out in bucket order on every rank (see _arrived)
         self._hooks = [p.register_post_accumulate_grad_hook(self._main_hook) for p in params]
-        self.stats = {"collectives": 0, "side_direct": 0, "side_folded": 0, "main_hook": 0, "reattached": 0}
+        self.stats = {"collectives": 0, "side_direct": 0, "side_folded": 0, "main_hook": 0, "main_direct": 0, "reattached": 0}
         self.begin()                                                             # active from here on (`close()` deactivates)
 
     def _close(self, ps):
@@ -111,6 +114,7 @@ class GradExchange:
     def _reset_pass(self):
         self._armed = False
         self._next = 0
+        self._via = {}
         for b in self.buckets:
             b.reset()
 
@@ -165,11 +169,25 @@ class GradExchange:
         self.stats["side_folded" if folded else "side_direct"] += 1
         self._arrived(b, p, False)
 
+    def main_done(self, p):
+        """train_ops: a kernel on the MAIN stream has added the gradient of p to its slice (the BatchNorm affine parameters: csrc/bn_act.hip adds
+        dgamma / dbeta in its apply pass; the Function returns None for them, so no AccumulateGrad add kernel — 280 per step of MAF-YOLO-n)."""
+        self._arm()
+        self.stats["main_direct"] += 1
+        self._arrived(self.slot[id(p)][0], p, True, "direct")
+
     def _main_hook(self, p):
         ent = self.slot.get(id(p))
         if ent is None:
             return
         b, view = ent
+        via = self._via.get(id(p), ())
+        if "side" in via or "direct" in via:
+            # torch calls the post-accumulate hook of a leaf whose Function returned None as well (measured on torch 2.10: all 124 conv weights of
+            # MAF-YOLO-n, tensor hooks see `None`): the gradient of this pass went into the slice from a kernel (side stream: conv weights; main
+            # stream: BatchNorm affine) and was counted there.
+            # (Round 3 counted both calls: buckets "completed" early — harmless at world size 1, wrong for N > 1; found by the one-rank RCCL test.)
+            return
         if p.grad is not view and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
             # autograd found `p.grad` empty (zero_grad(set_to_none=True) before this pass) and installed a fresh tensor: that tensor is the
             # whole gradient — the slice's old content is the step before's — so it REPLACES the slice
@@ -180,13 +198,18 @@ class GradExchange:
         self.stats["main_hook"] += 1
         self._arrived(b, p, True)
 
-    def _arrived(self, b, p, on_main):
+    def _arrived(self, b, p, on_main, tag=None):
         if b.launched and self._sync and self._collectives():
             # the bucket has gone out with this pass's first contribution of every parameter; one more would be lost on the other ranks
-            raise lib.MafError("GradExchange: a second gradient of a parameter arrived after its bucket was reduced "
-                               "(a parameter used more than once per backward pass is not supported)")
+            raise lib.MafError("GradExchange: a gradient of %s arrived (%s stream) after its bucket was reduced; earlier arrivals of this pass: %s "
+                               "(a parameter used more than once per backward pass is not supported)"
+                               % (self.names.get(id(p), "?"), "main" if on_main else "side", self._via.get(id(p))))
         b.main_contrib = b.main_contrib or on_main
         b.arrived.add(id(p))
+        self._via.setdefault(id(p), []).append(tag or ("main" if on_main else "side"))
+        if _DEBUG:
+            import traceback
+            self._via[id(p)].append("".join(traceback.format_stack(limit=8)))
         if not self._sync:
             return
         # in BUCKET ORDER on every rank: a parameter without a gradient on one rank only must not reorder the collectives between ranks

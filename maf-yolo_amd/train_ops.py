@@ -30,6 +30,17 @@ stats = {"native_conv1x1": 0, "native_dwconv": 0, "fallback": 0}
 # Per-kernel timing of one training step (bench.py --train: the `roofline` object): while `profile` is a dict every native launch is
 # bracketed by HIP events on its stream; profile_collect() turns them into {kind: [milliseconds, algorithmic bytes, launches]}.
 profile = None
+# A/B and parity tests only (never set by the product path): every entry point below takes its plain-torch branch on CUDA tensors too — the same
+# module tree on the framework's convolutions / BatchNorm / pooling (MIOpen, under whatever autocast the caller set).  tests/test_gpu_train.py
+# measures the autocast RECIPE with it, so that the HIP kernels are bounded against the recipe's own deviation from fp32.
+framework_ops = False
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible BatchNorm statistics (csrc/bn_act.hip, maf_set_deterministic): a test / debugging mode — three launches per BatchNorm pass and
+    per-workgroup slots instead of atomics.  The forward pass of the train-form graph is then bit-identical from run to run (the weight-gradient
+    kernels keep their fp32 atomics: continuous round-off only)."""
+    lib.check(lib.load().maf_set_deterministic(1 if on else 0))
 profile_detail = None                # a list: profile_collect() also appends (kind, note, ms, bytes) per launch
 _pending = []
 
@@ -679,9 +690,11 @@ def _pad8(x, w):
 
 def conv3x3s2(x, w):
     """nn.Conv2d(k=3, stride=2, padding=1, bias=False) with autograd; x [B,Cin,H,W] (NHWC in memory preferred), w [Cout,Cin,3,3]."""
-    if not x.is_cuda:                       # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
+    if not x.is_cuda or framework_ops:      # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
         stats["fallback"] += 1
-        return F.conv2d(x, w.to(x.dtype), None, 2, 1)
+        if framework_ops and x.shape[1] > w.shape[1]:      # RepVGGBlock hands the image zero-padded to 8 channels (pad_channels8)
+            x = x[:, :w.shape[1]]
+        return F.conv2d(x, w if framework_ops else w.to(x.dtype), None, 2, 1)
     x = _autocast(x)
     if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
         raise lib.MafError("conv3x3s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
@@ -690,9 +703,11 @@ def conv3x3s2(x, w):
 
 def conv1x1s2(x, w):
     """nn.Conv2d(k=1, stride=2, bias=False) with autograd."""
-    if not x.is_cuda:
+    if not x.is_cuda or framework_ops:
         stats["fallback"] += 1
-        return F.conv2d(x, w.to(x.dtype), None, 2, 0)
+        if framework_ops and x.shape[1] > w.shape[1]:
+            x = x[:, :w.shape[1]]
+        return F.conv2d(x, w if framework_ops else w.to(x.dtype), None, 2, 0)
     x = _autocast(x)
     if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (1, 1)):
         raise lib.MafError("conv1x1s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
@@ -701,8 +716,10 @@ def conv1x1s2(x, w):
 
 def conv1x1(x, w, bias=None):
     """nn.Conv2d(k=1, stride=1) forward with autograd. x [B,Cin,H,W] (NHWC in memory preferred), w [Cout,Cin,1,1]."""
-    if not x.is_cuda:                       # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
+    if not x.is_cuda or framework_ops:      # CPU tensors: the train-form module tree in plain torch (CI / gloo tests only)
         stats["fallback"] += 1
+        if framework_ops:                   # autocast (if any) casts the operands itself
+            return F.conv2d(x, w, bias)
         return F.conv2d(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
     x = _autocast(x)
     mult = 8 if x.dtype == torch.float16 else 4
@@ -850,6 +867,8 @@ class _BNAct(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, g32, b32, stat)
         ctx.act = act
+        # the Parameters themselves (not saved tensors: they are inputs of this node): backward adds dgamma / dbeta straight into their slices of a gradient exchange
+        ctx.affine = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         stats["native_bn_act"] = stats.get("native_bn_act", 0) + 1
         return y
 
@@ -867,7 +886,14 @@ class _BNAct(torch.autograd.Function):
         x, xs = nhwc(x)
         dev = x.device
         dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        dgb = torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
+        # with a gradient exchange the apply kernel ADDS dgamma / dbeta to the parameters' bucket slices (main stream) and autograd gets None:
+        # no AccumulateGrad add kernel per affine parameter (280 launches per step of n)
+        from . import exchange
+        ex, tg, tb = exchange.current, None, None
+        if ex is not None and ctx.affine is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            tg, tb = ex.target(ctx.affine[0]), ex.target(ctx.affine[1])
+        direct = tg is not None and tb is not None and tg[1].is_contiguous() and tb[1].is_contiguous()
+        dgb = None if direct else torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
         part, phase = _bn_part(dev, c)
         dres, rs = None, 0
         if residual is not None:
@@ -875,13 +901,18 @@ class _BNAct(torch.autograd.Function):
             dres = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         npass = 5 if residual is None else 8
         with _prof("bn_act_backward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
-            lib.check(lib.load().maf_bn_backward(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
-                                                 stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
-                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), part.data_ptr(), _BN_REPLICAS, phase,
-                                                 None if residual is None else residual.data_ptr(), rs,
-                                                 None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride()[3], _stream(dev)))
+            lib.check(lib.load().maf_bn_backward_acc(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
+                                                     stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
+                                                     tg[1].data_ptr() if direct else dgb[0].data_ptr(), tb[1].data_ptr() if direct else dgb[1].data_ptr(),
+                                                     part.data_ptr(), _BN_REPLICAS, phase,
+                                                     None if residual is None else residual.data_ptr(), rs,
+                                                     None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride()[3], 1 if direct else 0, _stream(dev)))
         if ctx.has_res and dres is None:
             dres = dz                                                            # no activation: the residual's gradient is dz itself
+        if direct:
+            ex.main_done(ctx.affine[0])
+            ex.main_done(ctx.affine[1])
+            return dx, None, None, None, None, None, None, None, None, dres
         return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres
 
 
@@ -890,7 +921,7 @@ def bn_act(x, bn, act=None, residual=None):
     kernels (one statistics pass + one normalise/affine/[add]/activation pass; backward likewise); eval mode and CPU tensors run torch ops.
     `residual` (same shape as x; act None or 'relu'): the branch sums of RepVGGBlock / DilatedReparamBlock without a pass of their own."""
     mult = 8 if x.dtype == torch.float16 else 4
-    if not (x.is_cuda and bn.training):
+    if not (x.is_cuda and bn.training) or framework_ops:
         # CPU tensors (CI / gloo tests) and eval-mode BatchNorm inside a train-form forward (Model.forward(val_loss=True) never comes here:
         # it runs the deploy engine): torch ops, counted so that an A/B on `stats` cannot mistake them for the HIP path
         stats["torch_bn"] = stats.get("torch_bn", 0) + 1
@@ -954,7 +985,7 @@ def maxpool(x, k, stride=1, pad=None):
     if pad is None:
         pad = k // 2 if stride == 1 else 0
     mult = 8 if x.dtype == torch.float16 else 4
-    if not (x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and 2 <= k <= 15 and 1 <= stride <= k and 2 * pad <= k):
+    if framework_ops or not (x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and 2 <= k <= 15 and 1 <= stride <= k and 2 * pad <= k):
         if x.is_cuda:
             stats["torch_maxpool"] = stats.get("torch_maxpool", 0) + 1
         return F.max_pool2d(x, k, stride, pad)
@@ -970,9 +1001,9 @@ def dwconv(x, w):
     k = w.shape[-1]
     if k == 1:                               # a 1x1 depth-wise conv is a per-channel scale
         return x * w.reshape(1, -1, 1, 1).to(x.dtype)
-    if not x.is_cuda:                        # CPU tensors: plain torch (CI / gloo tests only)
+    if not x.is_cuda or framework_ops:       # CPU tensors: plain torch (CI / gloo tests only)
         stats["fallback"] += 1
-        return F.conv2d(x, w.to(x.dtype), None, 1, k // 2, 1, x.shape[1])
+        return F.conv2d(x, w if framework_ops else w.to(x.dtype), None, 1, k // 2, 1, x.shape[1])
     x = _autocast(x)
     mult = 8 if x.dtype == torch.float16 else 4
     if not (_ok(x, mult) and k in (3, 5, 7, 9)):

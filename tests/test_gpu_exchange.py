@@ -155,3 +155,89 @@ def test_exchange_train_step_fp16_scaler_and_fused_sgd():
         assert train_ops.stats["fallback"] == fb0
     finally:
         ex.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The RCCL branch on ONE GPU (VERDICT r3 task 4): a one-rank `nccl` group + GradExchange(force_collectives=True), so that
+# dist.all_reduce(flat, AVG, async_op=True) is really issued from the weight-gradient stream during a 32 x 640 x 640 AMP backward.
+# Reference: yolov6/core/engine.py:161-164, 477-489 (DDP's bucket all-reduce during backward).  Runs in a child process: the process
+# group and its RCCL communicator stay out of the test session.
+_RCCL1 = r'''
+import json, socket, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import maf_yolo_amd as M
+from maf_yolo_amd import synth, train_ops, exchange
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1, device_id=dev)
+m = M.Model("n"); m.load_state_dict(synth.synth_state_dict(m, "n", 0)); m = m.to(dev).train()
+x = synth.synth_images(32, 640, seed=3).to(dev)
+# two streams on different hardware queues (streams that share a queue run one after the other, and the legacy default stream synchronises
+# with every other stream): the step runs on cs[0], the weight gradients and the collectives on cs[1]
+cs = M.concurrent_streams(dev, 2)
+train_ops._side_streams[dev.index] = cs[1]; train_ops._side_events[dev.index] = torch.cuda.Event()
+torch.cuda.synchronize()
+torch.cuda.set_stream(cs[0])
+with torch.autocast("cuda", dtype=torch.float16):
+    (feats, cls, reg), _ = m(x)
+loss = (cls.float().mean() * 100 + reg.float().pow(2).mean()) * 8192.0
+loss.backward(retain_graph=True)                                   # plain autograd: the reference gradients
+ref = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.requires_grad}
+for p in m.parameters(): p.grad = None
+ex = M.GradExchange(m, force_collectives=True)
+assert ex.world == 1 and dist.get_backend() == "nccl"
+loss.backward(retain_graph=True)
+got = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.requires_grad}
+torch.cuda.synchronize()
+res = {"buckets": len(ex.buckets), "collectives": ex.stats["collectives"], "stats": dict(ex.stats)}
+G = max(float(v.abs().max()) for v in ref.values())
+res["worst"] = max(float((got[n] - ref[n]).abs().max()) / (1e-2 * float(ref[n].abs().max()) + 1e-4 * G) for n in ref)
+# does the main stream wait for a collective before finish()?  A long spin kernel is queued on the side stream first: every weight
+# gradient, fold and all-reduce of the pass queues behind it.  The main stream's data-gradient chain must reach the top of finish()
+# (event `pre`) long before the spin ends (event `spin_end`, side stream), and leave finish() (event `post`) after it.
+side = train_ops.side_stream(dev)
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record(); torch.cuda._sleep(20_000_000); t1.record(); torch.cuda.synchronize()
+per_cycle = t0.elapsed_time(t1) / 20_000_000
+spin = int(250.0 / per_cycle)                                      # ~250 ms; the whole backward of this batch takes ~20 ms
+ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "spin_end", "pre", "post")}
+fin = ex.finish
+def finish():
+    ev["pre"].record()                                             # main stream, before finish() makes it wait
+    fin()
+    ev["post"].record()
+ex.finish = finish
+ex.zero_grad()
+torch.cuda.synchronize()
+ev["start"].record()
+side.wait_event(ev["start"])
+with torch.cuda.stream(side):
+    torch.cuda._sleep(spin)
+    ev["spin_end"].record()
+c0 = ex.stats["collectives"]
+loss.backward()
+torch.cuda.synchronize()
+res.update(spin_ms=ev["start"].elapsed_time(ev["spin_end"]), main_reaches_finish_ms=ev["start"].elapsed_time(ev["pre"]),
+           main_leaves_finish_ms=ev["start"].elapsed_time(ev["post"]), collectives_second_pass=ex.stats["collectives"] - c0)
+got2 = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.requires_grad}
+res["worst2"] = max(float((got2[n] - ref[n]).abs().max()) / (1e-2 * float(ref[n].abs().max()) + 1e-4 * G) for n in ref)
+ex.close()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+'''
+
+
+@pytest.mark.timeout(600)
+def test_rccl_branch_on_one_gpu_all_reduce_from_the_side_stream():
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _RCCL1 % {"root": root}], capture_output=True, text=True, timeout=540, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(res)
+    assert res["buckets"] >= 4 and res["collectives"] == res["buckets"] == res["collectives_second_pass"], res    # one RCCL all-reduce per bucket and pass
+    assert res["worst"] < 1.0 and res["worst2"] < 1.0, res                                 # AVG over one rank = plain autograd's gradients
+    # the main stream ran its whole backward chain while the side stream (weight gradients + collectives) was held up, and waited only in finish()
+    assert res["main_reaches_finish_ms"] < 0.5 * res["spin_ms"], res
+    assert res["main_leaves_finish_ms"] >= res["spin_ms"], res

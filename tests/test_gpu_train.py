@@ -461,24 +461,89 @@ _AMP_BARS_N_BY_STAGE = ((31, (0.15, 3e-2)), (9, (0.3, 4e-2)), (0, (0.7, 0.25))) 
 _AMP_HEAD = {"n": (5e-3, 6e-2), "s": (5e-3, 1e-1), "m": (1e-2, 3e-1)}
 
 
+def _reference_assignment(g, tag, targets, dev):
+    """The label assignment the REFERENCE's own assigner made in the fixture's pass (tools/make_golden_train.py stores what `warmup_assigner` /
+    `formal_assigner` returned, yolov6/models/loss.py:83-100) in the form ComputeLoss(assignment=) takes: (row of the assigned label per anchor or -1
+    [B, A] int32, target score [B, A] fp32).  The labels of the fixture are grouped by image, so a label's row is its row in `targets`."""
+    fg, box, lab, sc = g[tag + "_asg_fg"], g[tag + "_asg_box"], g[tag + "_asg_label"], g[tag + "_asg_score"]
+    t = targets.cpu().numpy()
+    xyxy = np.stack([t[:, 2] - t[:, 4] / 2, t[:, 3] - t[:, 5] / 2, t[:, 2] + t[:, 4] / 2, t[:, 3] + t[:, 5] / 2], 1) * 128.0
+    out_gt = np.full(fg.shape, -1, np.int32)
+    for b, a in zip(*np.nonzero(fg)):
+        rows = [j for j in range(len(t)) if int(t[j, 0]) == b and int(t[j, 1]) == int(lab[b, a]) and np.abs(xyxy[j] - box[b, a]).max() < 1e-2]
+        assert len(rows) == 1, (b, a, rows)
+        out_gt[b, a] = rows[0]
+    return torch.from_numpy(out_gt).to(dev), torch.from_numpy(sc * fg).float().to(dev)
+
+
 @pytest.mark.parametrize("tag,epoch,kw", [("tal", 5, dict(warmup_epoch=0)), ("atss", 0, dict())])
 @pytest.mark.parametrize("amp", [False, True])
 @pytest.mark.parametrize("scale", ["n", "s", "m"])
 def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp, scale):
-    """The step is NOT bit-reproducible from run to run (fp32 atomics in the BatchNorm statistics and the weight gradients land in another order), and the
-    assigners are discrete.  Two things follow.  The continuous spread: the bars below cover it (40 runs per leg at the end of round 3).  A rare DISCRETE
-    outcome: about once in 40 runs the fp32 ATSS leg of m gives the same alternative result — 5.0e-2 of max |g| on backbone.0.rbr_1x1.conv.weight while loss,
-    items and head outputs still agree to 2e-4 — consistent with one near-tied choice of the assigner falling the other way than in the reference's run; it was
-    not isolated further this round.  Such an event gets up to two fresh, independent repeats of the whole step; an error of the kernels
-    is systematic and fails all three."""
-    for attempt in range(3):
+    """No retries (round 3 repeated the step up to three times): both legs run with the label assignment FROZEN TO THE REFERENCE'S OWN (stored in the
+    fixture), and the fp32 leg first checks that this package's assigner makes exactly that assignment on its own head outputs and names the anchors
+    where it does not.  What round 3 called "one alternative discrete outcome in 40 runs" of the m / fp32 / ATSS leg was located with
+    tools/train_step_spread.py (60 runs: twice the same alternative — 0.22 of max |g| on backbone.9.cv1.conv.weight, 0.08 on backbone.8.m.1 ..., every
+    deviating parameter upstream of SPPF, loss and head outputs unchanged): the fp32 atomics of the BatchNorm statistics land in another order every run,
+    one ulp in SPPF's input flips a near-tied arg-max of its cascaded 5 x 5 max-pools, and the BACKWARD pass routes that gradient to the other pixel —
+    legitimate behaviour of an order-dependent reduction, and not what a parity test should sample.  The fp32 leg therefore runs with bit-reproducible
+    BatchNorm statistics (train_ops.set_deterministic: per-workgroup slots added in a fixed order instead of atomics)."""
+    if not amp:
+        train_ops.set_deterministic(True)
+    try:
+        _train_step_vs_reference(golden, tag, epoch, kw, amp, scale)
+    finally:
+        train_ops.set_deterministic(False)
+
+
+def test_deterministic_mode_makes_the_train_forward_bit_reproducible():
+    """train_ops.set_deterministic(True): two forward passes of the train-form graph (m: the deepest one) give bit-identical head outputs and BatchNorm
+    running statistics; they agree with the default (atomic) statistics to fp32 round-off."""
+    from oracle import maf_oracle as O
+    x = O.synth_images(2, 128, 7).to(DEV)
+    outs = []
+    for det in (True, True, False):
+        train_ops.set_deterministic(det)
         try:
-            _train_step_vs_reference(golden, tag, epoch, kw, amp, scale)
-            return
-        except AssertionError as e:
-            print("attempt %d of %s %s amp=%s failed: %s" % (attempt + 1, scale, tag, amp, str(e)[:300]))
-            if attempt == 2:
-                raise
+            m = M.Model("m")
+            m.load_state_dict(O.synth_state_dict("m", 0))
+            m = m.to(DEV).train()
+            with torch.no_grad():
+                (feats, cls, reg), _ = m(x)
+            sd = m.state_dict()
+            outs.append((cls.clone(), reg.clone(), sd["backbone.8.conv2.bn.running_var"].clone(), sd["backbone.30.conv2.bn.running_mean"].clone()))
+        finally:
+            train_ops.set_deterministic(False)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(outs[0], outs[2]):
+        assert torch.allclose(a_, b_, rtol=2e-3, atol=2e-3 * float(a_.abs().max()))
+
+
+def _recipe_errors_on_framework_ops(g, tag, epoch, kw, scale, frozen, x, targets):
+    """[(parameter, sampled gradient error / max |g|, relative error of sum |g|)] against the fp32 fixture for the autocast step of the same module tree run
+    on the framework's own ops (train_ops.framework_ops) — the cost of the fp16 recipe itself on this graph, weights and batch."""
+    from oracle import maf_oracle as O
+    train_ops.framework_ops = True
+    try:
+        m = M.Model(scale)
+        m.load_state_dict(O.synth_state_dict(scale, 0))
+        m = m.to(DEV).train()
+        crit = M.ComputeLoss(ori_img_size=128, **kw)
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = m(x)
+        loss, _ = crit((feats, cls, reg), targets, epoch, 1, assignment=frozen)
+        (loss * 1024.0).backward()
+    finally:
+        train_ops.framework_ops = False
+    params = dict(m.named_parameters())
+    out = []
+    for i, name in enumerate(g["names"].tolist()):
+        gr = params[name].grad / 1024.0
+        ref_sum, ref_smp = g["%s_g%d_sum" % (tag, i)], g["%s_g%d_sample" % (tag, i)]
+        got_smp = gr.reshape(-1)[::max(1, gr.numel() // 64)][:64].float().cpu().numpy()
+        out.append((name, np.abs(got_smp - ref_smp).max() / max(ref_sum[3], 1e-12), abs(_ramp_sum(gr)[1] - ref_sum[1]) / (ref_sum[1] + 1e-12)))
+    return out
 
 
 def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale):
@@ -497,22 +562,22 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale):
     x = O.synth_images(2, 128, 7).to(DEV)
     targets = torch.tensor(_TRAIN_TARGETS, dtype=torch.float32, device=DEV)
     crit = M.ComputeLoss(ori_img_size=128, **kw)
-    frozen = None
-    if amp:                                                  # the fp32 pass: its assignment only (momentum 0: the running statistics stay put)
-        mom = {}
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.BatchNorm2d):
-                mom[mod] = mod.momentum
-                mod.momentum = 0.0
-        with torch.no_grad():
-            (f0, c0, r0), _ = m(x)
-            crit((f0, c0, r0), targets, epoch, 1)
-        frozen = crit.last_assignment
-        for mod, v in mom.items():
-            mod.momentum = v
-            mod.num_batches_tracked.zero_()
+    frozen = _reference_assignment(g, tag, targets, DEV)
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
         (feats, cls, reg), _ = m(x)
+    if not amp:
+        # this package's assigner on its own fp32 head outputs must make the reference's choices: same foreground anchors, same label per anchor,
+        # same target score; a near-tied top-k choice that falls the other way is NAMED here instead of showing up as a gradient error
+        with torch.no_grad():
+            crit((feats, cls.detach(), reg.detach()), targets, epoch, 1)
+        own_gt, own_norm = crit.last_assignment
+        diff = (own_gt != frozen[0]).nonzero().tolist()
+        for b_, a_ in diff:
+            print("%s %s: anchor (%d, %d): own assigner -> label row %d (score %.5f), reference -> %d (%.5f)"
+                  % (scale, tag, b_, a_, int(own_gt[b_, a_]), float(own_norm[b_, a_]), int(frozen[0][b_, a_]), float(frozen[1][b_, a_])))
+        assert not diff, "the assignment differs from the reference's on %d anchors (listed above)" % len(diff)
+        dn = float(((own_norm - frozen[1]).abs() * (own_gt >= 0)).max())
+        assert dn <= 2e-4, dn
     loss, items = crit((feats, cls, reg), targets, epoch, 1, assignment=frozen)
     scale_ = 1024.0 if amp else 1.0                          # GradScaler's job (engine.py:164): keep fp16 gradients out of the subnormals
     (loss * scale_).backward()
@@ -551,6 +616,26 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale):
             node = int(name.split(".")[1])
             eb, sb = next(b for first, b in _AMP_BARS_N_BY_STAGE if node >= first)
             assert err <= eb and esum <= sb, (name, err, esum)
+    if amp:
+        # Bound the KERNELS, not the recipe: the same train-form tree, same weights, images and frozen assignment under the same autocast, on the
+        # FRAMEWORK's convolutions / BatchNorm / pooling (train_ops.framework_ops: torch + MIOpen on this GPU; nothing of the reference travels).
+        # Its deviation from the fp32 fixture is what fp16 arithmetic through this graph costs whoever does it (measured in round 4: n 0.03-0.27, s
+        # 0.09-0.67, m 0.22-2.1 of max |g| by stage — on m the FRAMEWORK's autocast step is 1.4-2.1 of max |g| away from fp32 in the backbone, which is why
+        # no absolute bar of 0.3 can hold there); the HIP path's deviation may be at most 2x that, per stage (+ a floor of 3 % of max |g| / 1.5 % of
+        # sum |g|).  Two realisations of the same rounding chaos differ: HIP / framework ratios of 0.66-1.6 were seen over the 18 stage rows.
+        fw = _recipe_errors_on_framework_ops(g, tag, epoch, kw, scale, frozen, x, targets)
+        rows = []
+        for first, label in ((31, "heads"), (9, "neck"), (0, "backbone")):
+            last = {31: 99, 9: 30, 0: 8}[first]
+            sel = [(n_, e_, s_) for n_, e_, s_ in per_param if first <= int(n_.split(".")[1]) <= last]
+            sel_fw = [(e_, s_) for n_, e_, s_ in fw if first <= int(n_.split(".")[1]) <= last]
+            he, hs = max(e_ for _, e_, _ in sel), max(s_ for _, _, s_ in sel)
+            fe, fs = max(e_ for e_, _ in sel_fw), max(s_ for _, s_ in sel_fw)
+            rows.append((label, he, fe, hs, fs))
+            print("%s %s amp: %-8s sampled error HIP %.3e / framework %.3e of max |g|; sum |g| error HIP %.3e / framework %.3e" % (scale, tag, label, he, fe, hs, fs))
+        for label, he, fe, hs, fs in rows:
+            assert he <= 2.0 * fe + 3e-2, (label, he, fe)
+            assert hs <= 2.0 * fs + 1.5e-2, (label, hs, fs)
     if not amp:
         for i, name in enumerate(g["names"].tolist()):      # max |g| over ALL elements likewise
             got_sum, ref_sum = _ramp_sum(params[name].grad), g["%s_g%d_sum" % (tag, i)]

@@ -5,7 +5,8 @@ in the build container (CPU, fp32) on seeded weights, images and labels — what
 
     python tools/make_golden_train.py [n|s|m]    ->  tests/golden/train_<scale>.npz     (BASELINE configs[2] / [3] train the s and m graphs)
 
-Stored (DATA only): the loss and its items, the train-branch head outputs on a strided set of anchors, the gradient of a spread of parameters
+Stored (DATA only): the reference's own label ASSIGNMENT of each pass (what its assigner returned: foreground mask, assigned box, class and
+target score per anchor — the parity test freezes both of its legs to it, so that no near-tied discrete choice can differ), the loss and its items, the train-branch head outputs on a strided set of anchors, the gradient of a spread of parameters
 (every kind of layer: RepVGG 3x3 / 1x1 branches, ConvWrapper 3x3, 1x1 convs, every depth-wise kernel size, BatchNorm affine, head preds) as
 checksums + a strided sample each, and the BatchNorm running statistics after the step.  Inputs are regenerated from seeds by the test.
 """
@@ -76,9 +77,21 @@ def main():
         model.load_state_dict(O.synth_state_dict(scale, seed=0), strict=True)
         model.zero_grad(set_to_none=True)
         crit = ComputeLoss(num_classes=80, ori_img_size=SIZE, use_dfl=True, reg_max=16, iou_type="giou", **kw)
+        seen = {}
+
+        def grab(mod, args, out):                               # (target_labels, target_bboxes px, target_scores, fg_mask): loss.py:83-100
+            seen["a"] = [t.detach().clone() for t in out]
+        hooks = [crit.warmup_assigner.register_forward_hook(grab), crit.formal_assigner.register_forward_hook(grab)]
         preds, _ = model(x)                                     # engine.py:150
         loss, items = crit(preds, targets.clone(), epoch, 1)    # engine.py:160
         loss.backward()                                         # engine.py:164 (no GradScaler on the CPU)
+        for h in hooks:
+            h.remove()
+        t_lab, t_box, t_sc, fg = seen["a"]
+        blob[tag + "_asg_fg"] = (fg > 0).numpy().astype(np.uint8)
+        blob[tag + "_asg_box"] = t_box.float().numpy()
+        blob[tag + "_asg_label"] = t_lab.long().numpy().astype(np.int32)
+        blob[tag + "_asg_score"] = t_sc.float().sum(-1).numpy()   # one_hot(label) * normalised metric: the sum is the metric
         feats, cls, reg = preds
         blob[tag + "_loss"] = np.asarray(loss.item()); blob[tag + "_items"] = items.numpy()
         blob[tag + "_cls_rows"] = cls[:, ::37].detach().numpy(); blob[tag + "_reg_rows"] = reg[:, ::37].detach().numpy()
