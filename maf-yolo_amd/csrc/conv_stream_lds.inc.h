@@ -75,8 +75,20 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_raw[];
     frag_t* wl = reinterpret_cast<frag_t*>(wl_raw);                      // [KS][CT][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
-    const int n_tile = blockIdx.x % a.nN;                                // the workgroup keeps ONE channel tile
-    const int wg = blockIdx.x / a.nN, nwg = gridDim.x / a.nN;
+    // The workgroup keeps ONE channel tile.  Which one: the nN workgroups that walk the SAME pixel tiles (one per channel tile) must sit on the same
+    // XCD, or every XCD's L2 fetches the activations once more (PMC, round 3: 576 -> 384 on 20 x 20 fetched 48 MB for a 14.7 MB input — nN = 3 —, the
+    // 96-channel-tile forms 1.25-1.36x over the family).  Workgroups go to the XCDs round-robin by blockIdx, so with a workgroup count per channel tile
+    // that is a multiple of 8 (the launcher rounds it): XCD = blockIdx & 7, inside it channel tiles fastest.
+    const int nwg = gridDim.x / a.nN;
+    int n_tile, wg;
+    if ((nwg & 7) == 0 && !(MAF_KO & 128)) {
+        const int j = blockIdx.x >> 3;
+        n_tile = j % a.nN;
+        wg = (int)(blockIdx.x & 7) + 8 * (j / a.nN);
+    } else {
+        n_tile = blockIdx.x % a.nN;
+        wg = blockIdx.x / a.nN;
+    }
     const int ntiles = (a.M + 15) >> 4;
     {
         // the channel tile's fragments travel global -> LDS by DMA (global_load_lds: 1 KiB per wave-instruction to a wave-uniform base + lane * 16;
@@ -267,6 +279,7 @@ int launch_sl(const ConvArgs& a, hipStream_t s) {
     int per = (ntiles + 3) / 4;                                          // workgroups per channel tile that still have work
     const int cap = occ * 256 / a.nN > 0 ? occ * 256 / a.nN : 1;
     if (per > cap) per = cap;
+    if (per >= 8 && a.nN > 1) per &= ~7;                                 // whole XCD rounds: the channel tiles of a pixel tile then share an XCD's L2 (see the kernel)
     hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI>), dim3(per * a.nN), dim3(256), lds, s, a);
     return maf_check_hip(hipGetLastError(), "conv1x1_stream_lds launch");
 }

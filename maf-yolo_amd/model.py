@@ -78,6 +78,7 @@ _VERSION = attrgetter("_version")
 class Model(nn.Module):
     def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None, dispatch="engine"):
         super().__init__()
+        self._maf_apply_gen = 0                # counts `_apply` calls (.to() / .cuda() / .half() ...): solver.ModelEMA's cheap staleness check
         assert channels == 3, "MAF-YOLO takes 3-channel images"
         self.nodes, hcfg = _nodes_from_config(config, num_classes)
         assert hcfg["use_dfl"] and hcfg["reg_max"] == 16 or hcfg["use_dfl"], "DFL head expected (configs/MAF-YOLO-n.py:15-16)"
@@ -154,6 +155,7 @@ class Model(nn.Module):
         # .to() / .cuda() / .float() / .half()-style conversions replace buffers and parameter storage (yolo.py:211-215 moves
         # detect.stride the same way): plans packed from the old tensors are stale
         self.invalidate()
+        self._maf_apply_gen = getattr(self, "_maf_apply_gen", 0) + 1             # solver.ModelEMA: its cached tensor lists are stale from here on
         return super()._apply(fn, *a, **k)
 
     def weights_version(self):

@@ -83,10 +83,21 @@ class ModelEMA:
             self._dst = [v for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
             self._src = [sd[k].detach() for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
             self._pairs_of = src
+            self._plist = None                                                    # (the cached Parameter objects of _signature: rebuilt with the lists)
             self._sig = self._signature(src)
         return self._dst, self._src
 
     def _signature(self, src):
+        """What must not have changed for the cached tensor lists to be the models' storage.  A maf_yolo_amd.Model counts its `_apply` calls (every
+        .to() / .cuda() / .half() / .float() goes through it and is what replaces buffers and parameter storage): generation numbers + the addresses of
+        the cached Parameter objects (~0.15 ms).  Any other module: the addresses of every parameter and buffer of both trees — four walks of the
+        module tree, 3-4 ms of host time per update on MAF-YOLO-n, which the step (issue-bound on the host) paid in full until round 4."""
+        gen, gen_e = getattr(src, "_maf_apply_gen", None), getattr(self.ema, "_maf_apply_gen", None)
+        if gen is not None and gen_e is not None and self._pairs_of is src and getattr(self, "_plist", None) is not None:
+            return ("gen", gen, gen_e, tuple([p.data_ptr() for p in self._plist]))
+        self._plist = list(src.parameters()) + list(self.ema.parameters())
+        if gen is not None and gen_e is not None:
+            return ("gen", gen, gen_e, tuple([p.data_ptr() for p in self._plist]))
         return (tuple(p.data_ptr() for p in src.parameters()), tuple(b.data_ptr() for b in src.buffers()),
                 tuple(p.data_ptr() for p in self.ema.parameters()), tuple(b.data_ptr() for b in self.ema.buffers()))
 

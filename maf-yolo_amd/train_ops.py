@@ -45,7 +45,23 @@ profile_detail = None                # a list: profile_collect() also appends (k
 _pending = []
 
 
-class _prof:
+class _NoProf:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOPROF = _NoProf()
+
+
+def _prof(kind, nbytes, dev, note=None, stream=None):
+    """Context around one native launch: HIP events while `profile` is a dict, nothing at all otherwise (~600 launches per step go through here)."""
+    return _NOPROF if profile is None else _Prof(kind, nbytes, dev, note, stream)
+
+
+class _Prof:
     def __init__(self, kind, nbytes, dev, note=None, stream=None):
         self.kind, self.nbytes, self.dev, self.note, self.stream = kind, int(nbytes), dev, note, stream
 
@@ -93,6 +109,7 @@ def _stream(dev):
 #     stem / the DDP reducer read on the MAIN stream straight away, so the main stream waits for the side stream before the layer's backward
 #     returns (`_side_done`) — the overlap is then with the data gradient of the same layer only.
 wgrad_stream = os.environ.get("MAF_WGRAD_STREAM", "1") != "0"
+bn_affine_direct = os.environ.get("MAF_BN_AFFINE_DIRECT", "1") != "0"     # A/B switch: BatchNorm dgamma / dbeta into the exchange's bucket slices by the apply kernel
 _side_streams = {}
 _side_events = {}
 _side_used = {}                                  # device index -> the side stream holds work the main stream has not waited for
@@ -890,7 +907,7 @@ class _BNAct(torch.autograd.Function):
         # no AccumulateGrad add kernel per affine parameter (280 launches per step of n)
         from . import exchange
         ex, tg, tb = exchange.current, None, None
-        if ex is not None and ctx.affine is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+        if ex is not None and ctx.affine is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and bn_affine_direct:
             tg, tb = ex.target(ctx.affine[0]), ex.target(ctx.affine[1])
         direct = tg is not None and tb is not None and tg[1].is_contiguous() and tb[1].is_contiguous()
         dgb = None if direct else torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta

@@ -554,3 +554,29 @@ def test_model_ema_follows_replaced_parameter_storage():
     d = 0.9999 * (1 - math.exp(-2 / 2000))
     want = before * d + (1 - d) * 5.0
     assert torch.allclose(ema.ema.backbone[0].rbr_dense.conv.weight, want, rtol=0, atol=1e-7)
+
+
+def test_model_ema_follows_buffers_replaced_by_apply():
+    """Round 4: ModelEMA validates its cached tensor lists with the model's `_apply` generation + the addresses of the cached Parameter objects (the
+    full walk of both module trees cost 3-4 ms of host time per step).  `_apply` (.to() / .double() / .float() ...) REPLACES buffer tensors: the running
+    statistics the average reads afterwards must be the new ones."""
+    import importlib
+    import math
+    M = importlib.import_module("maf-yolo_amd")
+    torch.manual_seed(5)
+    model = M.Model("n")
+    ema = M.ModelEMA(model)
+    ema.update(model)
+    g0 = model._maf_apply_gen if hasattr(model, "_maf_apply_gen") else 0
+    model.double().float()                                             # every buffer and every parameter's storage is a new tensor now
+    assert model._maf_apply_gen >= g0 + 2
+    key = "backbone.8.conv2.bn.running_mean"
+    before = ema.ema.state_dict()[key].clone()
+    with torch.no_grad():
+        model.state_dict()[key].fill_(3.0)
+    ema.update(model)
+    d = 0.9999 * (1 - math.exp(-2 / 2000))
+    assert torch.allclose(ema.ema.state_dict()[key], before * d + (1 - d) * 3.0, rtol=0, atol=1e-7)
+    sig = ema._sig
+    ema.update(model)
+    assert ema._sig == sig and sig[0] == "gen"                         # steady state: the cheap signature, unchanged

@@ -13,13 +13,17 @@ echo "bench rc=$?"; tail -c 400 $OUT/bench.json | head -c 400; echo
 python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg > $OUT/bench_inflight1.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python bench.py --tune-file $TUNE --inflight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "rocprof stats rc=$?"
+python tools/first_kernels.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/first_kernels.md > /dev/null 2>&1; echo "first kernels rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --tune-file $TUNE --inflight 1 --steps 3 --warmup 2 --no-cpu-baseline --no-train-leg > /dev/null 2> $OUT/pmc_$c.err
   echo "pmc $c rc=$?"
 done
-python bench.py --train --scale n --batch 32 --steps 20 --warmup 5 > $OUT/train_n.json 2> $OUT/train_n.err; echo "train n rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python bench.py --train --scale n --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/train_stats.err
+python bench.py --train --scale n --batch 32 --steps 20 --warmup 8 > $OUT/train_n.json 2> $OUT/train_n.err; echo "train n rc=$?"
+python bench.py --train --scale n --batch 32 --steps 20 --warmup 8 --rccl1 --no-cpu-baseline > $OUT/train_n_rccl1.json 2> $OUT/train_n_rccl1.err; echo "train n rccl1 rc=$?"
+python tools/train_host_profile.py 5 > $OUT/train_host_profile.txt 2>&1; echo "train host profile rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python bench.py --train --scale n --batch 32 --steps 6 --warmup 8 --no-cpu-baseline > /dev/null 2> $OUT/train_stats.err
 echo "train rocprof rc=$?"
+python tools/step_kernels.py $(find $OUT/train_stats -name "*kernel_trace.csv" | head -1) 4 $OUT/train_step_kernels.md > /dev/null 2>&1; echo "train step table rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/trainpmc/pmc_$c -o p -- python bench.py --train --scale n --batch 32 --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trainpmc_$c.err
   echo "train pmc $c rc=$?"
