@@ -320,6 +320,15 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
                     const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
                     void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
                     const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream);
+/* The parallel depth-wise branches of a train-form DilatedReparamBlock (yolov6/layers/common.py:3024-3031: lk_origin(x) and dil_conv_k*(x), NB
+ * depth-wise "same" convolutions of ONE input with kernel sizes k0, k0 - 2, ... 3 — k0 = 3: 3 and 3; the 1 x 1 branches are per-channel scales
+ * and stay apart) in one launch per direction, NHWC, no bias, no activation (a BatchNorm follows each):
+ *   dgrad = 0   dst[j] = DW(src[0], w[j]), j < nb            (the input is staged once)
+ *   dgrad = 1   dst[0] = sum_j DW(src[j], w[j])             (w[j] = the flipped filters; the sum is kept in fp32 registers and written once)
+ * (k0, nb) in {(3, 2), (5, 2), (7, 3), (9, 4)}; w[j]: [k_j * k_j][C] in `dtype` (maf_pack_dw); strides in elements, multiples of the 16-byte
+ * channel group; src / dst arrays hold 1 / nb (forward) or nb / 1 (data gradient) entries. */
+int maf_dw_branches(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
+                    int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t dgrad, maf_stream_t stream);
 /* maf_bn_backward with accumulate_affine != 0: dgamma / dbeta are ADDED to what the buffers hold — the slices of a gradient-exchange bucket
  * (maf_yolo_amd/exchange.py: `p.grad` of the BatchNorm affine parameters is a view of a flat fp32 bucket; the reference accumulates them with
  * AccumulateGrad, i.e. 280 one-line add kernels per step of MAF-YOLO-n, yolov6/core/engine.py:164). */

@@ -117,9 +117,13 @@ class DilatedReparamBlock(nn.Module):
             setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
 
     def forward(self, x):
-        out = train_ops.bn_act(train_ops.dwconv(x, self.lk_origin.weight), self.origin_bn)            # HIP fwd / dgrad / wgrad + BN(train)
+        # every k > 1 branch in ONE launch (csrc/dw_branches.hip: x staged once; their data gradients summed in one launch too); a 1 x 1 branch is a scale
+        big = [kk for kk in self.kernel_sizes if kk > 1]
+        zs = train_ops.dw_branches(x, [self.lk_origin.weight] + [getattr(self, "dil_conv_k%d_1" % kk).weight for kk in big])
+        out = train_ops.bn_act(zs[0], self.origin_bn)                                                  # HIP fwd / dgrad / wgrad + BN(train)
         for kk in self.kernel_sizes:
-            out = train_ops.bn_act(train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight), getattr(self, "dil_bn_k%d_1" % kk), residual=out)   # out + BN(...)
+            z = zs[1 + big.index(kk)] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight)
+            out = train_ops.bn_act(z, getattr(self, "dil_bn_k%d_1" % kk), residual=out)                 # out + BN(...)
         return out
 
     def fused(self):

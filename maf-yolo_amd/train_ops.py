@@ -806,29 +806,112 @@ class _DWConv(torch.autograd.Function):
         dt = _DT[x.dtype]
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            xx, xs = nhwc(x)
             # one copy of dW: the kernel adds one value per (channel, tap) and workgroup after its own LDS reduction, so the replicas the
             # first version spread its atomics over (and the torch sum behind them) buy <= 7 % on the 160 x 160 layers and nothing elsewhere
-            ex, view = _grad_sink(w)
-            L = lib.load()
-            if ex is not None:                                                    # [C][k*k] is the parameter's layout: the atomics land in its bucket slice
-                dwf = view
-                h = _fork(x.device, xx, dy)
-            else:
-                dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
-                h = _fork(x.device, xx, dy, dwf)
-                lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
-            with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys), h):
-                lib.check(L.maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), 1, h))
-            if ex is not None:
-                ex.side_done(w)
-            else:
-                dw = dwf.reshape(w.shape).to(w.dtype)
+            dw = _dw_wgrad(x, dy, dys, w)
         if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
             dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
         _side_done(x.device, dw is not None)
         return dx, dw
+
+
+def _dw_wgrad(x, dy, dys, w):
+    """Weight gradient of a depth-wise conv on the side stream (csrc/train_ops.hip: dw_wgrad_kernel): None when it went into a gradient exchange's
+    bucket slice, else dW like w."""
+    B, c, H, W = x.shape
+    k = w.shape[-1]
+    dt = _DT[x.dtype]
+    xx, xs = nhwc(x)
+    ex, view = _grad_sink(w)
+    L = lib.load()
+    if ex is not None:                                                        # [C][k*k] is the parameter's layout: the atomics land in its bucket slice
+        dwf = view
+        h = _fork(x.device, xx, dy)
+    else:
+        dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
+        h = _fork(x.device, xx, dy, dwf)
+        lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
+    with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys), h):
+        lib.check(L.maf_dw_wgrad(xx.data_ptr(), xs, dy.data_ptr(), dys, B, H, W, c, k, dt, dwf.data_ptr(), 1, h))
+    if ex is not None:
+        ex.side_done(w)
+        return None
+    return dwf.reshape(w.shape).to(w.dtype)
+
+
+_PTR4 = C.c_void_p * 4
+_INT4 = C.c_int32 * 4
+
+
+def _launch_dwb(srcs, dsts, wps, k0, B, H, W, c, dt, dgrad, dev):
+    nb = len(wps)
+    sp, ss = _PTR4(*[t.data_ptr() for t in srcs]), _INT4(*[t.stride()[3] for t in srcs])
+    dp, ds = _PTR4(*[t.data_ptr() for t in dsts]), _INT4(*[t.stride()[3] for t in dsts])
+    wp = _PTR4(*[t.data_ptr() for t in wps])
+    es = 2 if dt == lib.F16 else 4
+    with _prof("dw_branches_dgrad_k%d" % k0 if dgrad else "dw_branches_k%d" % k0, (nb + 1) * B * H * W * c * es, dev, (B, H, W, c, k0, nb)):
+        lib.check(lib.load().maf_dw_branches(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, 1 if dgrad else 0, _stream(dev)))
+
+
+class _DWBranches(torch.autograd.Function):
+    """The parallel depth-wise branches of a train-form DilatedReparamBlock (yolov6/layers/common.py:3024-3031) on csrc/dw_branches.hip: one launch
+    computes every branch's convolution of the shared input, one launch their summed data gradient; the weight gradients stay per branch on the side stream."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        x, xs = nhwc(x)
+        B, c, H, W = x.shape
+        dt = _DT[x.dtype]
+        dev = x.device
+        outs = [torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) for _ in ws]
+        _launch_dwb([x], outs, [_packed_dw(w, c, w.shape[-1], 0, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, False, dev)
+        ctx.save_for_backward(x, *ws)
+        stats["native_dwconv"] += len(ws)
+        stats["native_dw_branches"] = stats.get("native_dw_branches", 0) + 1
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *ws = ctx.saved_tensors
+        B, c, H, W = x.shape
+        dt = _DT[x.dtype]
+        dev = x.device
+        dzs = []
+        for dy in dys:
+            if dy is None:                                                       # a branch nobody used (not in the reference's graph): zero gradient
+                dy = torch.zeros((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            dy, _ = nhwc(dy)
+            dzs.append(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+        dws = [None] * len(ws)
+        returned = False
+        for j, w in enumerate(ws):
+            if ctx.needs_input_grad[1 + j]:
+                dws[j] = _dw_wgrad(x, dzs[j], dzs[j].stride()[3], w)
+                returned = returned or dws[j] is not None
+        dx = None
+        if ctx.needs_input_grad[0]:                                              # sum over the branches of the correlation with the flipped kernel
+            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            _launch_dwb(dzs, [dx], [_packed_dw(w, c, w.shape[-1], 1, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, True, dev)
+        _side_done(dev, returned)
+        return (dx, *dws)
+
+
+_DWB_SETS = {3: (3, 3), 5: (5, 3), 7: (7, 5, 3), 9: (9, 7, 5, 3)}
+dw_branches_merged = os.environ.get("MAF_DW_BRANCHES", "1") != "0"       # A/B switch: one launch per direction for the branches of a DilatedReparamBlock
+
+
+def dw_branches(x, ws):
+    """[depth-wise conv of x with w for w in ws] for the k > 1 branches of a DilatedReparamBlock (kernel sizes k0, k0 - 2, ... 3; k0 = 3: 3, 3): ONE
+    launch forward and one for the summed data gradient on CUDA tensors (csrc/dw_branches.hip); any other combination runs branch by branch."""
+    ks = tuple(int(w.shape[-1]) for w in ws)
+    mult = 8 if x.dtype == torch.float16 else 4
+    if x.is_cuda and not framework_ops and dw_branches_merged and len(ws) > 1 and _DWB_SETS.get(ks[0]) == ks:
+        x = _autocast(x)
+        mult = 8 if x.dtype == torch.float16 else 4
+        if _ok(x, mult):
+            return list(_DWBranches.apply(x, *ws))
+    return [dwconv(x, w) for w in ws]
 
 
 _ACT = {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "silu": lib.ACT_SILU}
