@@ -69,25 +69,32 @@ def latency_mode(args, torch, M, dev):
     plan = model.plan_for(x)
     pred = torch.empty(1, plan.A, 5 + plan.nc, dtype=torch.float32, device=dev)
     res = {}
+    n = max(args.steps, 200)
     for tag, graph in (("hipgraph", True), ("eager", False)):
         for _ in range(args.warmup):
             plan.run_into(x, pred, graph=graph)
             M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
         torch.cuda.synchronize(dev)
         lat_f, lat_t = [], []
-        for _ in range(max(args.steps, 200)):
+        for _ in range(n):                                   # the forward alone (device idle before and after)
             t0 = time.perf_counter()
             plan.run_into(x, pred, graph=graph)
             torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
+            lat_f.append(1e3 * (time.perf_counter() - t0))
+        for _ in range(n):                                   # the request: forward and NMS queued back to back on one stream, ONE host wait (the detections' counts)
+            t0 = time.perf_counter()
+            plan.run_into(x, pred, graph=graph)
             M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
-            t2 = time.perf_counter()
-            lat_f.append(1e3 * (t1 - t0)); lat_t.append(1e3 * (t2 - t0))
+            lat_t.append(1e3 * (time.perf_counter() - t0))
         res[tag] = {"forward_ms_p50": round(float(np.percentile(lat_f, 50)), 4), "forward_ms_p99": round(float(np.percentile(lat_f, 99)), 4),
                     "forward_plus_nms_ms_p50": round(float(np.percentile(lat_t, 50)), 4), "forward_plus_nms_ms_p99": round(float(np.percentile(lat_t, 99)), 4)}
-    print(json.dumps({"metric": "latency ms MAF-YOLO-%s 640x640 bs=1 infer (hipGraph forward + NMS)" % args.scale,
-                      "value": res["hipgraph"]["forward_plus_nms_ms_p50"], "unit": "ms", "n_gpus": 1, "higher_is_better": False,
-                      "dtype": "f16", "data": "synthetic", "config": {"workload": "bs=1 3x640x640 fp16, %d launches per forward" % len(plan.ops)},
+    # BASELINE configs[4] names hipGraph capture as the mechanism; both ways of issuing the same launch list are measured and the line's value is the
+    # faster one, named in the metric (a graph node costs ~1.1 us more than an eager launch from the C loop on this stack: DESIGN.md section 8)
+    best = min(res, key=lambda k: res[k]["forward_plus_nms_ms_p50"])
+    print(json.dumps({"metric": "latency ms MAF-YOLO-%s 640x640 bs=1 infer (forward + NMS, p50; launch path: %s)" % (args.scale, "hipGraph replay" if best == "hipgraph" else "eager launches from the C engine loop"),
+                      "value": res[best]["forward_plus_nms_ms_p50"], "unit": "ms", "n_gpus": 1, "higher_is_better": False,
+                      "dtype": "f16", "data": "synthetic", "config": {"workload": "bs=1 3x640x640 fp16, %d launches per forward" % len(plan.ops), "launch_path": best,
+                                                                      "samples": n, "warmup": args.warmup},
                       "latency": res}), flush=True)
 
 

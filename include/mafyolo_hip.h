@@ -327,8 +327,20 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
  *   dgrad = 1   dst[0] = sum_j DW(src[j], w[j])             (w[j] = the flipped filters; the sum is kept in fp32 registers and written once)
  * (k0, nb) in {(3, 2), (5, 2), (7, 3), (9, 4)}; w[j]: [k_j * k_j][C] in `dtype` (maf_pack_dw); strides in elements, multiples of the 16-byte
  * channel group; src / dst arrays hold 1 / nb (forward) or nb / 1 (data gradient) entries. */
+/* Forward of maf_dw_branches + the BatchNorm statistics of every branch: stats[j] (may be NULL per branch) = the half of the `part` scratch that the
+ * maf_bn_forward_ex(..., stats_ready = 1) call of branch j's BatchNorm will read, [replicas][2][C] fp32, zero on entry; the kernel adds the sum and
+ * the sum of squares of the (rounded) outputs it stores, spread over `replicas` = maf_bn_replicas(C, R) copies. */
+int maf_dw_branches_stats(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
+                          int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, float* const* stats, int32_t replicas, maf_stream_t stream);
 int maf_dw_branches(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
                     int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t dgrad, maf_stream_t stream);
+/* maf_bn_forward with stats_ready != 0: half `phase` of `part` already holds this call's {sum x, sum x^2} — accumulated by the kernel that produced x
+ * (maf_dw_branches_stats) into replicas [0, maf_bn_replicas(C, R)) — and the statistics launch is skipped: apply only. */
+int maf_bn_forward_ex(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
+                      int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
+                      int32_t stats_ready, maf_stream_t stream);
+int32_t maf_bn_replicas(int32_t C, int32_t R);
 /* maf_bn_backward with accumulate_affine != 0: dgamma / dbeta are ADDED to what the buffers hold — the slices of a gradient-exchange bucket
  * (maf_yolo_amd/exchange.py: `p.grad` of the BatchNorm affine parameters is a view of a flat fp32 bucket; the reference accumulates them with
  * AccumulateGrad, i.e. 280 one-line add kernels per step of MAF-YOLO-n, yolov6/core/engine.py:164). */

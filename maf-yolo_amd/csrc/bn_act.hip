@@ -360,10 +360,26 @@ extern "C" int maf_set_deterministic(int32_t on) {
     return 0;
 }
 
+// replicas of the partial sums a call with `R` requested replicas really uses for C channels (set_halves): who fills `part` from another kernel
+// (csrc/dw_branches.hip's statistics epilogue) must spread over exactly these
+extern "C" int32_t maf_bn_replicas(int32_t C, int32_t R) {
+    const int want = 1024 / C > 0 ? 1024 / C : 1;
+    int r = R < want ? R : want;
+    return r > kMaxR ? kMaxR : r;
+}
+
 extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
                               int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
                               maf_stream_t stream) {
+    return maf_bn_forward_ex(x, x_stride, M, C, dtype, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, act, y, y_stride, save_mean, save_rstd,
+                             part, R, phase, residual, res_stride, 0, stream);
+}
+
+extern "C" int maf_bn_forward_ex(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t act, void* y,
+                                 int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
+                                 int32_t stats_ready, maf_stream_t stream) {
     if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
     MAF_REQUIRE(gamma && beta && y && save_mean && save_rstd, "bn_forward: null pointer");
     MAF_REQUIRE(!residual || res_stride % (dtype == MAF_F16 ? 8 : 4) == 0, "bn_forward: residual stride must be a multiple of the 16-byte channel group");
@@ -377,10 +393,12 @@ extern "C" int maf_bn_forward(const void* x, int32_t x_stride, int32_t M, int32_
     size_t lds_s;
     const dim3 gs = stats_grid(M, C, dtype, &lds_s);
     const int ga = bn_grid(M, C, dtype, 8192);
-    if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
-    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
-    else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
-    det_reduce(a, gs, C, s);
+    if (!stats_ready) {                                      // else: the producing kernel has accumulated {sum x, sum x^2} into half `phase` already
+        if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
+        if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
+        else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
+        det_reduce(a, gs, C, s);
+    }
     a.res = residual; a.rs = res_stride;
     const size_t la = (size_t)2 * C * sizeof(float);
     if (residual) {

@@ -25,6 +25,7 @@ struct DwbArgs {
     const void* src[MAXB]; void* dst[MAXB]; const void* w[MAXB];
     int src_stride[MAXB], dst_stride[MAXB];
     int B, H, W, C, TH, TW, CB, tilesX, tilesY, nCB, nwg;
+    float* stats[MAXB]; int stats_R;         // forward only: per branch {sum, sum of squares} of the stored outputs -> [stats_R][2][C] (the BatchNorm's scratch half), or null
 };
 
 template <typename T> struct Vec;
@@ -147,12 +148,22 @@ __global__ __launch_bounds__(256) void dwb_fwd_kernel(const DwbArgs a) {
         constexpr int j = decltype(jc)::value;
         stage_weights<T, branch_k<K0, j>()>(wl + j * K0 * K0 * CG, static_cast<const T*>(a.w[j]), a, t, CGB);
     });
+    // BatchNorm statistics of the branches (a.stats): per workgroup [NB][2][CB] sums in LDS behind the weights, one global atomic per (branch, channel,
+    // statistic) and workgroup at the end — what bn_stats_kernel would compute in a pass of its own over every branch's output
+    float* lsum = reinterpret_cast<float*>(wl + NB * K0 * K0 * CG);
+    const bool st = a.stats_R > 0;
+    if (st)
+        for (int i = threadIdx.x; i < NB * 2 * a.CB; i += 256) lsum[i] = 0.f;
     __syncthreads();
     const int NSX = a.TW / R, items = a.TH * NSX * CGB;
-    for (int it = threadIdx.x; it < items; it += 256) {
+    // lanes of a wave that hold the same channel group sit CGB apart: with a power-of-two CGB their statistics are summed with xor shuffles first
+    // (one LDS atomic per channel, statistic and wave instead of one per lane — same-address LDS atomics of 32 lanes serialise: measured +1.4 ms per step)
+    const bool wave_reduce = CGB < 64 && (CGB & (CGB - 1)) == 0;
+    for (int it0 = 0; it0 < items; it0 += 256) {                      // uniform trip count: every lane takes part in the shuffles
+        const int it = min(it0 + (int)threadIdx.x, items - 1);
         const int cgi = it % CGB, u = it / CGB, s = u % NSX, ry = u / NSX;
         const int oy = t.y0 + ry, ox0 = t.x0 + s * R;
-        if (oy >= a.H || ox0 >= a.W) continue;
+        const bool live = it0 + (int)threadIdx.x < items && oy < a.H && ox0 < a.W;
         db_static_for<NB>([&](auto jc) {
             constexpr int j = decltype(jc)::value, K = branch_k<K0, j>(), off = P0 - K / 2;
             float acc[R][N];
@@ -160,18 +171,45 @@ __global__ __launch_bounds__(256) void dwb_fwd_kernel(const DwbArgs a) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int q = 0; q < N; ++q) acc[r][q] = 0.f;
-            strip_mac<T, K>(acc, tile + ((ry + off) * RW + s * R + off) * PS + cgi, RW, PS, wl + j * K0 * K0 * CG, CGB, cgi);
+            if (live) strip_mac<T, K>(acc, tile + ((ry + off) * RW + s * R + off) * PS + cgi, RW, PS, wl + j * K0 * K0 * CG, CGB, cgi);
             T* out = static_cast<T*>(a.dst[j]) + t.c0 + cgi * N + ((size_t)((size_t)t.b * a.H + oy) * a.W + ox0) * a.dst_stride[j];
+            float s0[N], s1[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q) s0[q] = s1[q] = 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (ox0 + r < a.W) {
+                if (live && ox0 + r < a.W) {
                     vec_t o;
 #pragma unroll
-                    for (int q = 0; q < N; ++q) o[q] = (T)acc[r][q];
+                    for (int q = 0; q < N; ++q) {
+                        o[q] = (T)acc[r][q];
+                        const float f = (float)o[q];                   // the statistics of the STORED (rounded) tensor, as a pass over it would see them
+                        s0[q] += f; s1[q] = __builtin_fmaf(f, f, s1[q]);
+                    }
                     *reinterpret_cast<vec_t*>(out + (size_t)r * a.dst_stride[j]) = o;
                 }
             }
+            if (st && a.stats[j]) {                                    // (uniform)
+                if (wave_reduce) {
+                    for (int o = CGB; o < 64; o <<= 1) {
+#pragma unroll
+                        for (int q = 0; q < N; ++q) { s0[q] += __shfl_xor(s0[q], o, 64); s1[q] += __shfl_xor(s1[q], o, 64); }
+                    }
+                }
+                if (!wave_reduce ? live : (int)(threadIdx.x & 63) < CGB) {
+#pragma unroll
+                    for (int q = 0; q < N; ++q) { atomicAdd(&lsum[(j * 2 + 0) * a.CB + cgi * N + q], s0[q]); atomicAdd(&lsum[(j * 2 + 1) * a.CB + cgi * N + q], s1[q]); }
+                }
+            }
         });
+    }
+    if (st) {
+        __syncthreads();
+        const int rep = blockIdx.x % a.stats_R;
+        for (int i = threadIdx.x; i < NB * 2 * t.cbe; i += 256) {
+            const int j = i / (2 * t.cbe), rem = i - j * 2 * t.cbe, which = rem / t.cbe, c = rem - which * t.cbe;
+            if (a.stats[j]) atomicAdd(a.stats[j] + (size_t)rep * 2 * a.C + which * a.C + t.c0 + c, lsum[(j * 2 + which) * a.CB + c]);
+        }
     }
 }
 
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(256) void dwb_dgrad_kernel(const DwbArgs a) {
 constexpr size_t kMaxLdsB = 96 * 1024;
 
 size_t lds_bytes(int TH, int TW, int CB, int N, int K0, int NB) {
-    return ((size_t)(TH + K0 - 1) * (TW + K0 - 1) * (CB / N + 2) + (size_t)NB * K0 * K0 * (CB / N)) * 16;
+    return ((size_t)(TH + K0 - 1) * (TW + K0 - 1) * (CB / N + 2) + (size_t)NB * K0 * K0 * (CB / N)) * 16 + (size_t)NB * 2 * CB * sizeof(float);   // tile | weights | statistics
 }
 
 // least halo amplification that fits the LDS (the cost model of dwconv.hip); max_items: work items (4-pixel strips x channel groups) a workgroup may hold
@@ -296,8 +334,25 @@ int launch_k(DwbArgs& a, int k0, int nb, bool dgrad, hipStream_t s) {
 
 }  // namespace
 
+static int dw_branches_impl(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
+                            int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t dgrad, float* const* stats, int32_t replicas,
+                            maf_stream_t stream);
+
 extern "C" int maf_dw_branches(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
                                int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t dgrad, maf_stream_t stream) {
+    return dw_branches_impl(src, src_stride, dst, dst_stride, w, nb, k0, B, H, W, C, dtype, dgrad, nullptr, 0, stream);
+}
+
+extern "C" int maf_dw_branches_stats(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
+                                     int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, float* const* stats, int32_t replicas,
+                                     maf_stream_t stream) {
+    MAF_REQUIRE(stats && replicas >= 1 && replicas <= 64, "dw_branches_stats: stats = one scratch half per branch (or NULL), 1..64 replicas");
+    return dw_branches_impl(src, src_stride, dst, dst_stride, w, nb, k0, B, H, W, C, dtype, 0, stats, replicas, stream);
+}
+
+static int dw_branches_impl(const void* const* src, const int32_t* src_stride, void* const* dst, const int32_t* dst_stride, const void* const* w,
+                            int32_t nb, int32_t k0, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t dgrad, float* const* stats, int32_t replicas,
+                            maf_stream_t stream) {
     MAF_REQUIRE(src && src_stride && dst && dst_stride && w && nb >= 1 && nb <= MAXB, "dw_branches: null argument / 1..4 branches");
     MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "dw_branches: dtype must be f16/f32");
     const int N = dtype == MAF_F16 ? 8 : 4;
@@ -317,6 +372,8 @@ extern "C" int maf_dw_branches(const void* const* src, const int32_t* src_stride
         a.dst[j] = dst[j]; a.dst_stride[j] = dst_stride[j];
     }
     a.B = B; a.H = H; a.W = W; a.C = C;
+    a.stats_R = stats ? replicas : 0;
+    for (int j = 0; j < nb; ++j) a.stats[j] = stats ? stats[j] : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == MAF_F16 ? launch_k<half_t>(a, k0, nb, dgrad != 0, s) : launch_k<float>(a, k0, nb, dgrad != 0, s);
 }

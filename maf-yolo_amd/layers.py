@@ -118,12 +118,15 @@ class DilatedReparamBlock(nn.Module):
 
     def forward(self, x):
         # every k > 1 branch in ONE launch (csrc/dw_branches.hip: x staged once; their data gradients summed in one launch too); a 1 x 1 branch is a scale
+        # ... and that launch accumulates every branch's BatchNorm statistics in its epilogue: the BatchNorms behind it are apply passes only
         big = [kk for kk in self.kernel_sizes if kk > 1]
-        zs = train_ops.dw_branches(x, [self.lk_origin.weight] + [getattr(self, "dil_conv_k%d_1" % kk).weight for kk in big])
-        out = train_ops.bn_act(zs[0], self.origin_bn)                                                  # HIP fwd / dgrad / wgrad + BN(train)
+        zs, st = train_ops.dw_branches(x, [self.lk_origin.weight] + [getattr(self, "dil_conv_k%d_1" % kk).weight for kk in big],
+                                       [self.origin_bn] + [getattr(self, "dil_bn_k%d_1" % kk) for kk in big])
+        out = train_ops.bn_act(zs[0], self.origin_bn, pre_stats=st[0])                                     # HIP fwd / dgrad / wgrad + BN(train)
         for kk in self.kernel_sizes:
-            z = zs[1 + big.index(kk)] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight)
-            out = train_ops.bn_act(z, getattr(self, "dil_bn_k%d_1" % kk), residual=out)                 # out + BN(...)
+            j = 1 + big.index(kk) if kk > 1 else -1
+            z = zs[j] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight)
+            out = train_ops.bn_act(z, getattr(self, "dil_bn_k%d_1" % kk), residual=out, pre_stats=st[j] if kk > 1 else None)   # out + BN(...)
         return out
 
     def fused(self):

@@ -40,7 +40,9 @@ def set_deterministic(on=True):
     """Bit-reproducible BatchNorm statistics (csrc/bn_act.hip, maf_set_deterministic): a test / debugging mode — three launches per BatchNorm pass and
     per-workgroup slots instead of atomics.  The forward pass of the train-form graph is then bit-identical from run to run (the weight-gradient
     kernels keep their fp32 atomics: continuous round-off only)."""
+    global _deterministic
     lib.check(lib.load().maf_set_deterministic(1 if on else 0))
+    _deterministic = bool(on)
 profile_detail = None                # a list: profile_collect() also appends (kind, note, ms, bytes) per launch
 _pending = []
 
@@ -844,14 +846,20 @@ _PTR4 = C.c_void_p * 4
 _INT4 = C.c_int32 * 4
 
 
-def _launch_dwb(srcs, dsts, wps, k0, B, H, W, c, dt, dgrad, dev):
+def _launch_dwb(srcs, dsts, wps, k0, B, H, W, c, dt, dgrad, dev, bstats=None):
     nb = len(wps)
     sp, ss = _PTR4(*[t.data_ptr() for t in srcs]), _INT4(*[t.stride()[3] for t in srcs])
     dp, ds = _PTR4(*[t.data_ptr() for t in dsts]), _INT4(*[t.stride()[3] for t in dsts])
     wp = _PTR4(*[t.data_ptr() for t in wps])
     es = 2 if dt == lib.F16 else 4
+    L = lib.load()
     with _prof("dw_branches_dgrad_k%d" % k0 if dgrad else "dw_branches_k%d" % k0, (nb + 1) * B * H * W * c * es, dev, (B, H, W, c, k0, nb)):
-        lib.check(lib.load().maf_dw_branches(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, 1 if dgrad else 0, _stream(dev)))
+        if bstats is not None:                                                   # [(scratch, phase)] per branch: the half its BatchNorm call will read
+            half = _BN_REPLICAS * 2 * (-(-c // 256) * 256)
+            stp = _PTR4(*[0 if st is None else st[0].data_ptr() + 4 * st[1] * half for st in bstats])
+            lib.check(L.maf_dw_branches_stats(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, stp, L.maf_bn_replicas(c, _BN_REPLICAS), _stream(dev)))
+        else:
+            lib.check(L.maf_dw_branches(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, 1 if dgrad else 0, _stream(dev)))
 
 
 class _DWBranches(torch.autograd.Function):
@@ -859,13 +867,13 @@ class _DWBranches(torch.autograd.Function):
     computes every branch's convolution of the shared input, one launch their summed data gradient; the weight gradients stay per branch on the side stream."""
 
     @staticmethod
-    def forward(ctx, x, *ws):
+    def forward(ctx, x, bstats, *ws):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
         dev = x.device
         outs = [torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) for _ in ws]
-        _launch_dwb([x], outs, [_packed_dw(w, c, w.shape[-1], 0, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, False, dev)
+        _launch_dwb([x], outs, [_packed_dw(w, c, w.shape[-1], 0, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, False, dev, bstats)
         ctx.save_for_backward(x, *ws)
         stats["native_dwconv"] += len(ws)
         stats["native_dw_branches"] = stats.get("native_dw_branches", 0) + 1
@@ -886,7 +894,7 @@ class _DWBranches(torch.autograd.Function):
         dws = [None] * len(ws)
         returned = False
         for j, w in enumerate(ws):
-            if ctx.needs_input_grad[1 + j]:
+            if ctx.needs_input_grad[2 + j]:
                 dws[j] = _dw_wgrad(x, dzs[j], dzs[j].stride()[3], w)
                 returned = returned or dws[j] is not None
         dx = None
@@ -894,24 +902,47 @@ class _DWBranches(torch.autograd.Function):
             dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             _launch_dwb(dzs, [dx], [_packed_dw(w, c, w.shape[-1], 1, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, True, dev)
         _side_done(dev, returned)
-        return (dx, *dws)
+        return (dx, None, *dws)
 
 
 _DWB_SETS = {3: (3, 3), 5: (5, 3), 7: (7, 5, 3), 9: (9, 7, 5, 3)}
 dw_branches_merged = os.environ.get("MAF_DW_BRANCHES", "1") != "0"       # A/B switch: one launch per direction for the branches of a DilatedReparamBlock
 
 
-def dw_branches(x, ws):
+dw_branch_stats = os.environ.get("MAF_DW_BRANCH_STATS", "1") != "0"      # A/B switch: the branches' BatchNorm statistics out of the depth-wise kernel's epilogue
+_deterministic = False
+
+
+def bn_own_scratch(bn, dev, c):
+    """(scratch, phase) of a BatchNorm whose statistics are produced by ANOTHER kernel than its own call (the depth-wise kernel of csrc/dw_branches.hip):
+    a buffer per module — the shared per-stream one alternates its halves call by call, and the apply pass of the call in front would clear the half this
+    call's producer has just filled — whose halves alternate step by step (the apply pass clears the half of the step before, as always)."""
+    ent = getattr(bn, "_maf_part", None)
+    if ent is None or ent[0].device != dev or ent[2] != c:
+        ent = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1, c]
+        bn._maf_part = ent
+    ent[1] ^= 1
+    return ent[0], ent[1]
+
+
+def dw_branches(x, ws, bns=None):
     """[depth-wise conv of x with w for w in ws] for the k > 1 branches of a DilatedReparamBlock (kernel sizes k0, k0 - 2, ... 3; k0 = 3: 3, 3): ONE
-    launch forward and one for the summed data gradient on CUDA tensors (csrc/dw_branches.hip); any other combination runs branch by branch."""
+    launch forward and one for the summed data gradient on CUDA tensors (csrc/dw_branches.hip); any other combination runs branch by branch.
+    `bns` (the BatchNorm2d behind every branch): in training mode the kernel also accumulates every branch's batch statistics; returns (outputs,
+    [per-branch `stats` argument for bn_act, or None])."""
     ks = tuple(int(w.shape[-1]) for w in ws)
-    mult = 8 if x.dtype == torch.float16 else 4
+    none = [None] * len(ws)
     if x.is_cuda and not framework_ops and dw_branches_merged and len(ws) > 1 and _DWB_SETS.get(ks[0]) == ks:
         x = _autocast(x)
         mult = 8 if x.dtype == torch.float16 else 4
         if _ok(x, mult):
-            return list(_DWBranches.apply(x, *ws))
-    return [dwconv(x, w) for w in ws]
+            bstats = None
+            if bns is not None and dw_branch_stats and not _deterministic and all(bn.training and bn.affine for bn in bns):
+                bstats = [bn_own_scratch(bn, x.device, x.shape[1]) for bn in bns]
+            outs = list(_DWBranches.apply(x, bstats, *ws))
+            return (outs, bstats or none) if bns is not None else outs
+    outs = [dwconv(x, w) for w in ws]
+    return (outs, none) if bns is not None else outs
 
 
 _ACT = {None: lib.ACT_NONE, "none": lib.ACT_NONE, "relu": lib.ACT_RELU, "silu": lib.ACT_SILU}
@@ -939,14 +970,14 @@ class _BNAct(torch.autograd.Function):
     """act(BatchNorm2d(x) [+ residual]) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None, residual=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None, residual=None, pre_stats=None):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
         dev = x.device
         y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
-        part, phase = _bn_part(dev, c)
+        part, phase = _bn_part(dev, c) if pre_stats is None else pre_stats       # pre_stats: (scratch, phase) whose half the producer of x has filled
         g32 = gamma.detach() if gamma.dtype == torch.float32 and gamma.is_contiguous() else gamma.detach().float().contiguous()
         b32 = beta.detach() if beta.dtype == torch.float32 and beta.is_contiguous() else beta.detach().float().contiguous()
         rs = 0
@@ -954,12 +985,12 @@ class _BNAct(torch.autograd.Function):
             residual, rs = nhwc(residual)
         npass = 3 if residual is None else 4
         with _prof("bn_act_forward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, act)):    # statistics pass (read) + apply pass (read [, read], write)
-            lib.check(lib.load().maf_bn_forward(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
+            lib.check(lib.load().maf_bn_forward_ex(x.data_ptr(), xs, B * H * W, c, dt, g32.data_ptr(), b32.data_ptr(), float(eps), float(momentum),
                                                 None if running_mean is None else running_mean.data_ptr(),
                                                 None if running_var is None else running_var.data_ptr(),
                                                 None if counter is None else counter.data_ptr(), act,
                                                 y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
-                                                phase, None if residual is None else residual.data_ptr(), rs, _stream(dev)))
+                                                   phase, None if residual is None else residual.data_ptr(), rs, 0 if pre_stats is None else 1, _stream(dev)))
         ctx.has_res = residual is not None
         ctx.res_in_bwd = residual is not None and act != lib.ACT_NONE          # the activation's derivative needs u = BN(x) + residual
         if ctx.res_in_bwd:
@@ -1012,12 +1043,13 @@ class _BNAct(torch.autograd.Function):
         if direct:
             ex.main_done(ctx.affine[0])
             ex.main_done(ctx.affine[1])
-            return dx, None, None, None, None, None, None, None, None, dres
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres
+            return dx, None, None, None, None, None, None, None, None, dres, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres, None
 
 
-def bn_act(x, bn, act=None, residual=None):
-    """act(bn(x) [+ residual]) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  Training mode on CUDA tensors runs the fused HIP
+def bn_act(x, bn, act=None, residual=None, pre_stats=None):
+    """act(bn(x) [+ residual]) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  `pre_stats`: what dw_branches returned for this branch (its
+    kernel has accumulated the batch statistics already: apply pass only), else None.  Training mode on CUDA tensors runs the fused HIP
     kernels (one statistics pass + one normalise/affine/[add]/activation pass; backward likewise); eval mode and CPU tensors run torch ops.
     `residual` (same shape as x; act None or 'relu'): the branch sums of RepVGGBlock / DilatedReparamBlock without a pass of their own."""
     mult = 8 if x.dtype == torch.float16 else 4
@@ -1048,7 +1080,7 @@ def bn_act(x, bn, act=None, residual=None):
         raise lib.MafError("bn_act: BatchNorm2d(momentum=None) (cumulative average) is not supported on the HIP path")
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual)
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual, pre_stats)
 
 
 class _MaxPool(torch.autograd.Function):

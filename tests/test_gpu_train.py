@@ -975,3 +975,52 @@ def test_dw_branches_one_launch_matches_the_separate_launches(k0, c, hw, dtype):
     assert _rel(dx1.float().cpu(), xr.grad.cpu()) <= _rel(dx0.float().cpu(), xr.grad.cpu()) * 1.05 + 1e-6      # never worse than rounding per branch
     for a_, b_ in zip(dw1, dw0):
         assert _rel(a_.cpu(), b_.cpu()) < (5e-3 if dtype == torch.float16 else 1e-5)
+
+
+@pytest.mark.parametrize("k,c,hw,dtype", [(9, 96, (20, 20), torch.float16), (7, 192, (40, 40), torch.float16), (5, 144, (24, 20), torch.float16), (3, 72, (40, 36), torch.float16),
+                                          (7, 24, (12, 9), torch.float32)])
+def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype):
+    """Round 4: the kernel that computes the depth-wise branches of a DilatedReparamBlock also accumulates every branch's BatchNorm statistics (sum and sum of
+    squares of the values it stores), so the BatchNorms behind it run their apply pass only (maf_dw_branches_stats + maf_bn_forward_ex(stats_ready)).  Against
+    the same block with the statistics pass: outputs within one rounding of the activations, running statistics and every gradient to round-off — over two
+    steps (the per-module scratch alternates its halves step by step)."""
+    from maf_yolo_amd.layers import UniRepLKNetBlock
+    torch.manual_seed(k * 7 + c)
+    ref = UniRepLKNetBlock(c, k).to(DEV).train()
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3)
+    import copy
+    fused = copy.deepcopy(ref)
+    g = torch.Generator().manual_seed(5)
+    tol = 3e-3 if dtype == torch.float16 else 2e-5
+    for step in range(2):
+        x = (torch.randn(4, c, *hw, generator=g) * 1.5 + 0.2).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(4, c, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for blk, on in ((ref, False), (fused, True)):
+            train_ops.dw_branch_stats = on
+            try:
+                xa = x.clone().requires_grad_(True)
+                n0 = train_ops.stats.get("native_bn_act", 0)
+                y = blk(xa, act="silu")
+                y.backward(dy)
+                torch.cuda.synchronize()
+                outs.append((y.detach().float(), xa.grad.float(), n0))
+            finally:
+                train_ops.dw_branch_stats = True
+        assert _rel(outs[1][0].cpu(), outs[0][0].cpu()) < tol, (step, _rel(outs[1][0].cpu(), outs[0][0].cpu()))
+        assert _rel(outs[1][1].cpu(), outs[0][1].cpu()) < 4 * tol, (step, _rel(outs[1][1].cpu(), outs[0][1].cpu()))
+    sa, sb = ref.state_dict(), fused.state_dict()
+    for key in sa:
+        if "running" in key:
+            assert torch.allclose(sa[key], sb[key], rtol=1e-4, atol=1e-5), key
+        if key.endswith("num_batches_tracked"):
+            assert int(sa[key]) == int(sb[key]) == 2
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), fused.named_parameters()):
+        # (a branch BatchNorm's bias gradient is the sum of the outer BatchNorm's dx — zero in exact arithmetic: a floor at 1e-3 of the largest gradient)
+        err = float((p2.grad - p1.grad).abs().max())
+        assert err <= (2e-2 if dtype == torch.float16 else 1e-4) * float(p1.grad.abs().max()) + 1e-3 * gmax, (n1, err, float(p1.grad.abs().max()), gmax)
+    assert getattr(fused.dwconv.origin_bn, "_maf_part", None) is not None and getattr(ref.dwconv.origin_bn, "_maf_part", None) is None

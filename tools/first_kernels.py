@@ -6,9 +6,15 @@ durations binned by that idle time, and the first three kernels of a few forward
     python tools/first_kernels.py <kernel_trace.csv> [out.md]
 """
 import csv
+import re
 import sys
 
 import numpy as np
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)", name)
+    return m.group(1) if m else name[:40]
 
 
 def main():
@@ -27,10 +33,24 @@ def main():
         sel = (idle >= lo) & (idle < hi)
         if sel.any():
             out.append("| %g - %g us | %d | %.1f | %.1f | %.1f |" % (lo, min(hi, 1e6), int(sel.sum()), dur[sel].mean(), dur[sel].min(), dur[sel].max()))
+    # what else runs WHILE the stem runs (kernels that start before it ends and end after it starts)
+    import collections
+    co = collections.Counter()
+    alone = []
+    for k, i in enumerate(idx):
+        s0, e0 = rows[i][0], rows[i][1]
+        others = [short(rows[j][2]) for j in range(max(0, i - 12), min(len(rows), i + 12)) if j != i and rows[j][0] < e0 and rows[j][1] > s0]
+        for o in set(others):
+            co[o] += 1
+        if not others:
+            alone.append(dur[k])
+    out += ["", "Launches with no other kernel on the device at the same time: %d, mean %.1f us; with one: %d, mean %.1f us.  Kernels seen beside it: %s" %
+            (len(alone), float(np.mean(alone)) if alone else 0.0, len(dur) - len(alone), float((dur.sum() - sum(alone)) / max(1, len(dur) - len(alone))),
+             ", ".join("%s x%d" % kv for kv in co.most_common(6)))]
     out += ["", "First kernels of five forwards (name, start relative to the stem's start, duration):", ""]
     for i in idx[len(idx) // 2: len(idx) // 2 + 5]:
         t0 = rows[i][0]
-        out.append("- " + "; ".join("%s +%.1f us, %.1f us" % (rows[j][2].split("(")[0][-42:], (rows[j][0] - t0) / 1e3, (rows[j][1] - rows[j][0]) / 1e3) for j in range(i, min(i + 3, len(rows))))
+        out.append("- " + "; ".join("%s +%.1f us, %.1f us" % (short(rows[j][2]), (rows[j][0] - t0) / 1e3, (rows[j][1] - rows[j][0]) / 1e3) for j in range(i, min(i + 3, len(rows))))
                    + " (idle before: %.0f us)" % idle[idx.index(i)])
     text = "\n".join(out) + "\n"
     if len(sys.argv) > 2:
