@@ -341,6 +341,25 @@ int maf_bn_forward_ex(const void* x, int32_t x_stride, int32_t M, int32_t C, int
                       int32_t y_stride, float* save_mean, float* save_rstd, float* part, int32_t R, int32_t phase, const void* residual, int32_t res_stride,
                       int32_t stats_ready, maf_stream_t stream);
 int32_t maf_bn_replicas(int32_t C, int32_t R);
+/* The statistics pass of maf_bn_forward alone (half `phase` of `part` += {sum x, sum x^2}; nothing is cleared). */
+int maf_bn_stats(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, float* part, int32_t R, int32_t phase, maf_stream_t stream);
+/* The SUM of the nb (2..4) training-mode BatchNorm2d of a DilatedReparamBlock (common.py:3024-3031: origin_bn(lk_origin(x)) + sum_j dil_bn_j(dil_conv_j(x)),
+ * no activation) as one apply pass per direction (csrc/bn_sum.hip):
+ *   maf_bn_sum_forward   out = sum_j BN_j(z_j).  part[j] = branch j's own scratch ([2][R][2][roundup(C,256)], the layout of maf_bn_forward), whose half
+ *                        phase[j] ALREADY holds {sum z_j, sum z_j^2} (maf_dw_branches_stats / maf_bn_stats); save_mean / save_rstd / running statistics /
+ *                        num_batches_tracked per branch as in maf_bn_forward; the other half of every scratch is cleared.
+ *   maf_bn_sum_backward  dy = gradient of the sum (the same for every branch): one statistics launch ({sum dy, sum dy xhat_j}), one apply launch writing
+ *                        every dz_j; dgamma_j / dbeta_j written, or added when accumulate_affine != 0.  bpart = [2][R][1 + nb][roundup(C,256)] fp32, zeroed
+ *                        once by the caller, halves alternating call by call (phase) like maf_bn_backward's scratch. */
+int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
+                       const float* const* gamma, const float* const* beta, float eps, float momentum,
+                       float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                       void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
+                       float* const* part, int32_t R, const int32_t* phase, maf_stream_t stream);
+int maf_bn_sum_backward(const void* dy, int32_t dy_stride, const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
+                        const float* const* gamma, const float* const* save_mean, const float* const* save_rstd,
+                        void* const* dz, const int32_t* dz_stride, float* const* dgamma, float* const* dbeta, int32_t accumulate_affine,
+                        float* bpart, int32_t R, int32_t phase, maf_stream_t stream);
 /* maf_bn_backward with accumulate_affine != 0: dgamma / dbeta are ADDED to what the buffers hold — the slices of a gradient-exchange bucket
  * (maf_yolo_amd/exchange.py: `p.grad` of the BatchNorm affine parameters is a view of a flat fp32 bucket; the reference accumulates them with
  * AccumulateGrad, i.e. 280 one-line add kernels per step of MAF-YOLO-n, yolov6/core/engine.py:164). */

@@ -411,6 +411,23 @@ extern "C" int maf_bn_forward_ex(const void* x, int32_t x_stride, int32_t M, int
     return maf_check_hip(hipGetLastError(), "bn_forward launch");
 }
 
+// The statistics pass of maf_bn_forward alone: half `phase` of `part` += {sum x, sum x^2} (for maf_bn_sum_forward's branches whose producer has no
+// statistics epilogue).  Nothing is cleared here: the apply pass that reads the half clears the other one.
+extern "C" int maf_bn_stats(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, float* part, int32_t R, int32_t phase, maf_stream_t stream) {
+    if (int rc = check_common(x, x_stride, M, C, dtype, R, phase, part)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BnArgs2 a = {};
+    a.x = x; a.xs = x_stride; a.M = M; a.C = C; a.R = R;
+    set_halves(a, part, C, R, phase);
+    size_t lds_s;
+    const dim3 gs = stats_grid(M, C, dtype, &lds_s);
+    if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
+    if (dtype == MAF_F16) hipLaunchKernelGGL((bn_stats_kernel<half_t, false>), gs, dim3(256), lds_s, s, a);
+    else hipLaunchKernelGGL((bn_stats_kernel<float, false>), gs, dim3(256), lds_s, s, a);
+    det_reduce(a, gs, C, s);
+    return maf_check_hip(hipGetLastError(), "bn_stats launch");
+}
+
 extern "C" int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, int32_t M, int32_t C, int32_t dtype,
                                const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, int32_t act,
                                void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,

@@ -122,12 +122,14 @@ class DilatedReparamBlock(nn.Module):
         big = [kk for kk in self.kernel_sizes if kk > 1]
         zs, st = train_ops.dw_branches(x, [self.lk_origin.weight] + [getattr(self, "dil_conv_k%d_1" % kk).weight for kk in big],
                                        [self.origin_bn] + [getattr(self, "dil_bn_k%d_1" % kk) for kk in big])
-        out = train_ops.bn_act(zs[0], self.origin_bn, pre_stats=st[0])                                     # HIP fwd / dgrad / wgrad + BN(train)
+        # ... and the BatchNorms of all branches are summed by ONE apply pass (csrc/bn_sum.hip; backward: one statistics + one apply launch for all of them)
+        zz, bns, pre = [zs[0]], [self.origin_bn], [st[0]]
         for kk in self.kernel_sizes:
             j = 1 + big.index(kk) if kk > 1 else -1
-            z = zs[j] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight)
-            out = train_ops.bn_act(z, getattr(self, "dil_bn_k%d_1" % kk), residual=out, pre_stats=st[j] if kk > 1 else None)   # out + BN(...)
-        return out
+            zz.append(zs[j] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight))
+            bns.append(getattr(self, "dil_bn_k%d_1" % kk))
+            pre.append(st[j] if kk > 1 else None)
+        return train_ops.bn_sum(zz, bns, pre)                                                           # origin_bn(z_0) + sum_j dil_bn_j(z_j)
 
     def fused(self):
         """merge_dilated_branches (common.py:3033-3051): centre-pad each small kernel to k x k and sum."""

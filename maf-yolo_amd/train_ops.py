@@ -977,6 +977,7 @@ class _BNAct(torch.autograd.Function):
         dev = x.device
         y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
+        sp = stat.data_ptr()                                                      # (pointer arithmetic: indexing a tensor costs ~2 us of host time, 4 per call)
         part, phase = _bn_part(dev, c) if pre_stats is None else pre_stats       # pre_stats: (scratch, phase) whose half the producer of x has filled
         g32 = gamma.detach() if gamma.dtype == torch.float32 and gamma.is_contiguous() else gamma.detach().float().contiguous()
         b32 = beta.detach() if beta.dtype == torch.float32 and beta.is_contiguous() else beta.detach().float().contiguous()
@@ -989,7 +990,7 @@ class _BNAct(torch.autograd.Function):
                                                 None if running_mean is None else running_mean.data_ptr(),
                                                 None if running_var is None else running_var.data_ptr(),
                                                 None if counter is None else counter.data_ptr(), act,
-                                                y.data_ptr(), y.stride()[3], stat[0].data_ptr(), stat[1].data_ptr(), part.data_ptr(), _BN_REPLICAS,
+                                                y.data_ptr(), y.stride()[3], sp, sp + 4 * c, part.data_ptr(), _BN_REPLICAS,
                                                    phase, None if residual is None else residual.data_ptr(), rs, 0 if pre_stats is None else 1, _stream(dev)))
         ctx.has_res = residual is not None
         ctx.res_in_bwd = residual is not None and act != lib.ACT_NONE          # the activation's derivative needs u = BN(x) + residual
@@ -1033,8 +1034,8 @@ class _BNAct(torch.autograd.Function):
         npass = 5 if residual is None else 8
         with _prof("bn_act_backward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
             lib.check(lib.load().maf_bn_backward_acc(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
-                                                     stat[0].data_ptr(), stat[1].data_ptr(), ctx.act, dx.data_ptr(), dx.stride()[3],
-                                                     tg[1].data_ptr() if direct else dgb[0].data_ptr(), tb[1].data_ptr() if direct else dgb[1].data_ptr(),
+                                                     stat.data_ptr(), stat.data_ptr() + 4 * c, ctx.act, dx.data_ptr(), dx.stride()[3],
+                                                     tg[1].data_ptr() if direct else dgb.data_ptr(), tb[1].data_ptr() if direct else dgb.data_ptr() + 4 * c,
                                                      part.data_ptr(), _BN_REPLICAS, phase,
                                                      None if residual is None else residual.data_ptr(), rs,
                                                      None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride()[3], 1 if direct else 0, _stream(dev)))
@@ -1081,6 +1082,125 @@ def bn_act(x, bn, act=None, residual=None, pre_stats=None):
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual, pre_stats)
+
+
+_bnsum_scratch = {}
+
+
+def _bnsum_part(dev, c, nb):
+    """(scratch, phase) of maf_bn_sum_backward: [2][R][1 + nb][roundup(c,256)] fp32 per (stream, width, branch count), halves alternating call by call."""
+    key = (dev.index, _stream(dev), -(-c // 256), nb)
+    ent = _bnsum_scratch.get(key)
+    if ent is None:
+        if len(_bnsum_scratch) > 64:
+            _bnsum_scratch.clear()
+        ent = _bnsum_scratch[key] = [torch.zeros(2 * _BN_REPLICAS * (1 + nb) * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
+    ent[1] ^= 1
+    return ent[0], ent[1]
+
+
+class _BNSum(torch.autograd.Function):
+    """sum_j BatchNorm2d_j(z_j) in training mode, no activation (the branch sum of a DilatedReparamBlock, yolov6/layers/common.py:3024-3031) on csrc/bn_sum.hip:
+    ONE apply pass forward (the statistics come from the depth-wise kernel's epilogue or a statistics launch per branch that lacks them), one statistics + one
+    apply launch backward for ALL branches (their upstream gradient is the same tensor)."""
+
+    @staticmethod
+    def forward(ctx, nb, cfg, *t):
+        """t = z_0 .. z_{nb-1}, gamma_0 .. gamma_{nb-1}, beta_0 .. beta_{nb-1}; cfg = (eps, momentum, [(running_mean, running_var, counter, scratch, phase, need_stats)] per branch)"""
+        zs = [nhwc(z) for z in t[:nb]]
+        gammas, betas = t[nb:2 * nb], t[2 * nb:3 * nb]
+        x0 = zs[0][0]
+        B, c, H, W = x0.shape
+        dt = _DT[x0.dtype]
+        dev = x0.device
+        eps, momentum, per = cfg
+        L = lib.load()
+        M_ = B * H * W
+        for (z, zst), (rm, rv, cnt, part, phase, need) in zip(zs, per):
+            if need:                                                             # this branch's producer has no statistics epilogue (the 1 x 1 scale branch)
+                lib.check(L.maf_bn_stats(z.data_ptr(), zst, M_, c, dt, part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
+        out = torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last)
+        stat = torch.empty(nb, 2, c, dtype=torch.float32, device=dev)            # save_mean, save_rstd per branch
+        sp = stat.data_ptr()
+        g32 = [g.detach() if g.dtype == torch.float32 and g.is_contiguous() else g.detach().float().contiguous() for g in gammas]
+        b32 = [b.detach() if b.dtype == torch.float32 and b.is_contiguous() else b.detach().float().contiguous() for b in betas]
+        with _prof("bn_sum_forward", (nb + 1) * M_ * c * x0.element_size(), dev, (B, H, W, c, nb)):
+            lib.check(L.maf_bn_sum_forward(_PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, M_, c, dt,
+                                           _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[b.data_ptr() for b in b32]), float(eps), float(momentum),
+                                           _PTR4(*[0 if p[0] is None else p[0].data_ptr() for p in per]), _PTR4(*[0 if p[1] is None else p[1].data_ptr() for p in per]),
+                                           _PTR4(*[0 if p[2] is None else p[2].data_ptr() for p in per]),
+                                           out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
+                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _INT4(*[p[4] for p in per]), _stream(dev)))
+        ctx.save_for_backward(stat, *[z for z, _ in zs], *g32)
+        ctx.nb = nb
+        ctx.affine = list(zip(gammas, betas)) if all(isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter) for g, b in zip(gammas, betas)) else None
+        stats["native_bn_act"] = stats.get("native_bn_act", 0) + nb
+        stats["native_bn_sum"] = stats.get("native_bn_sum", 0) + 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        nb = ctx.nb
+        sv = ctx.saved_tensors
+        stat, zs, g32 = sv[0], [nhwc(z) for z in sv[1:1 + nb]], sv[1 + nb:1 + 2 * nb]
+        x0 = zs[0][0]
+        B, c, H, W = x0.shape
+        dev = x0.device
+        dy, dys = nhwc(dy)
+        if dy.dtype != x0.dtype:
+            dy = dy.to(x0.dtype)
+            dys = dy.stride()[3]
+        dzs = [torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(nb)]
+        from . import exchange
+        ex, tg = exchange.current, None
+        if ex is not None and ctx.affine is not None and bn_affine_direct and all(ctx.needs_input_grad[2 + nb + j] and ctx.needs_input_grad[2 + 2 * nb + j] for j in range(nb)):
+            tg = [(ex.target(g), ex.target(b)) for g, b in ctx.affine]
+            if not all(a_ is not None and b_ is not None and a_[1].is_contiguous() and b_[1].is_contiguous() for a_, b_ in tg):
+                tg = None
+        dgb = None if tg is not None else torch.empty(nb, 2, c, dtype=torch.float32, device=dev)
+        part, phase = _bnsum_part(dev, c, nb)
+        sp = stat.data_ptr()
+        gp = None if dgb is None else dgb.data_ptr()
+        with _prof("bn_sum_backward", (2 + 3 * nb) * B * H * W * c * x0.element_size(), dev, (B, H, W, c, nb)):
+            lib.check(lib.load().maf_bn_sum_backward(dy.data_ptr(), dys, _PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, B * H * W, c, _DT[x0.dtype],
+                                                     _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
+                                                     _PTR4(*[d.data_ptr() for d in dzs]), _INT4(*[d.stride()[3] for d in dzs]),
+                                                     _PTR4(*[tg[j][0][1].data_ptr() if tg is not None else gp + 8 * c * j for j in range(nb)]),
+                                                     _PTR4(*[tg[j][1][1].data_ptr() if tg is not None else gp + 8 * c * j + 4 * c for j in range(nb)]),
+                                                     1 if tg is not None else 0, part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
+        if tg is not None:
+            for g, b in ctx.affine:
+                ex.main_done(g)
+                ex.main_done(b)
+            return (None, None, *dzs, *([None] * (2 * nb)))
+        return (None, None, *dzs, *[dgb[j, 0] for j in range(nb)], *[dgb[j, 1] for j in range(nb)])
+
+
+bn_sum_merged = os.environ.get("MAF_BN_SUM", "1") != "0"               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
+
+
+def bn_sum(zs, bns, pre_stats=None):
+    """sum_j bns[j](zs[j]) for the branches of a train-form DilatedReparamBlock (no activation).  CUDA + training mode: csrc/bn_sum.hip (one apply pass forward,
+    statistics + apply for all branches backward); otherwise — and for anything the kernel does not take — the chain of bn_act calls with `residual`.
+    `pre_stats[j]`: what dw_branches returned for branch j (its statistics are already accumulated) or None."""
+    nb = len(zs)
+    pre = list(pre_stats) if pre_stats is not None else [None] * nb
+    x = zs[0]
+    mult = 8 if x.dtype == torch.float16 else 4
+    ok = (bn_sum_merged and 2 <= nb <= 4 and x.is_cuda and not framework_ops and not _deterministic and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0
+          and all(z.shape == x.shape and z.dtype == x.dtype for z in zs)
+          and all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.eps == bns[0].eps and bn.momentum == bns[0].momentum
+                  and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64 for bn in bns))
+    if not ok:
+        out = bn_act(zs[0], bns[0], pre_stats=pre[0])
+        for z, bn, st in zip(zs[1:], bns[1:], pre[1:]):
+            out = bn_act(z, bn, residual=out, pre_stats=st)
+        return out
+    per = []
+    for bn, st in zip(bns, pre):
+        part, phase = st if st is not None else bn_own_scratch(bn, x.device, x.shape[1])
+        per.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, part, phase, st is None))
+    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
 class _MaxPool(torch.autograd.Function):

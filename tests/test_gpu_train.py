@@ -981,9 +981,10 @@ def test_dw_branches_one_launch_matches_the_separate_launches(k0, c, hw, dtype):
                                           (7, 24, (12, 9), torch.float32)])
 def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype):
     """Round 4: the kernel that computes the depth-wise branches of a DilatedReparamBlock also accumulates every branch's BatchNorm statistics (sum and sum of
-    squares of the values it stores), so the BatchNorms behind it run their apply pass only (maf_dw_branches_stats + maf_bn_forward_ex(stats_ready)).  Against
-    the same block with the statistics pass: outputs within one rounding of the activations, running statistics and every gradient to round-off — over two
-    steps (the per-module scratch alternates its halves step by step)."""
+    squares of the values it stores: maf_dw_branches_stats), and the branch BatchNorms are summed by ONE apply pass (maf_bn_sum_forward; backward: one
+    statistics + one apply launch for all branches, maf_bn_sum_backward) instead of a chain of fused BatchNorm calls.  Against the same block on the chain with
+    a statistics pass per BatchNorm: outputs within one rounding of the activations, running statistics and every gradient to round-off — over two steps (the
+    per-module scratch alternates its halves step by step)."""
     from maf_yolo_amd.layers import UniRepLKNetBlock
     torch.manual_seed(k * 7 + c)
     ref = UniRepLKNetBlock(c, k).to(DEV).train()
@@ -995,21 +996,24 @@ def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype
     fused = copy.deepcopy(ref)
     g = torch.Generator().manual_seed(5)
     tol = 3e-3 if dtype == torch.float16 else 2e-5
+    half = copy.deepcopy(ref)                                            # statistics out of the depth-wise kernel, the chain of BatchNorm calls behind it
     for step in range(2):
         x = (torch.randn(4, c, *hw, generator=g) * 1.5 + 0.2).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
         dy = torch.randn(4, c, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
         outs = []
-        for blk, on in ((ref, False), (fused, True)):
-            train_ops.dw_branch_stats = on
+        for blk, on, summed in ((ref, False, False), (fused, True, True), (half, True, False)):
+            train_ops.dw_branch_stats, train_ops.bn_sum_merged = on, summed
             try:
                 xa = x.clone().requires_grad_(True)
-                n0 = train_ops.stats.get("native_bn_act", 0)
+                n0 = train_ops.stats.get("native_bn_sum", 0)
                 y = blk(xa, act="silu")
+                assert train_ops.stats.get("native_bn_sum", 0) - n0 == (1 if summed else 0)
                 y.backward(dy)
                 torch.cuda.synchronize()
                 outs.append((y.detach().float(), xa.grad.float(), n0))
             finally:
-                train_ops.dw_branch_stats = True
+                train_ops.dw_branch_stats, train_ops.bn_sum_merged = True, True
+        assert _rel(outs[2][0].cpu(), outs[0][0].cpu()) < tol and _rel(outs[2][1].cpu(), outs[0][1].cpu()) < 4 * tol, step
         assert _rel(outs[1][0].cpu(), outs[0][0].cpu()) < tol, (step, _rel(outs[1][0].cpu(), outs[0][0].cpu()))
         assert _rel(outs[1][1].cpu(), outs[0][1].cpu()) < 4 * tol, (step, _rel(outs[1][1].cpu(), outs[0][1].cpu()))
     sa, sb = ref.state_dict(), fused.state_dict()
