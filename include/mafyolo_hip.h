@@ -321,11 +321,11 @@ int maf_bn_backward(const void* x, int32_t x_stride, const void* dz, int32_t dz_
                     void* dx, int32_t dx_stride, float* dgamma, float* dbeta, float* part, int32_t R, int32_t phase,
                     const void* residual, int32_t res_stride, void* dres, int32_t dres_stride, maf_stream_t stream);
 /* The parallel depth-wise branches of a train-form DilatedReparamBlock (yolov6/layers/common.py:3024-3031: lk_origin(x) and dil_conv_k*(x), NB
- * depth-wise "same" convolutions of ONE input with kernel sizes k0, k0 - 2, ... 3 — k0 = 3: 3 and 3; the 1 x 1 branches are per-channel scales
- * and stay apart) in one launch per direction, NHWC, no bias, no activation (a BatchNorm follows each):
+ * depth-wise "same" convolutions of ONE input with kernel sizes 3, 3, 1 / 5, 3, 1 / 7, 5, 3 / 9, 7, 5, 3 for k0 = 3 / 5 / 7 / 9 — the 1 x 1 branch is a
+ * per-channel scale) in one launch per direction, NHWC, no bias, no activation (a BatchNorm follows each):
  *   dgrad = 0   dst[j] = DW(src[0], w[j]), j < nb            (the input is staged once)
  *   dgrad = 1   dst[0] = sum_j DW(src[j], w[j])             (w[j] = the flipped filters; the sum is kept in fp32 registers and written once)
- * (k0, nb) in {(3, 2), (5, 2), (7, 3), (9, 4)}; w[j]: [k_j * k_j][C] in `dtype` (maf_pack_dw); strides in elements, multiples of the 16-byte
+ * (k0, nb) in {(3, 3), (5, 3), (7, 3), (9, 4)}; w[j]: [k_j * k_j][C] in `dtype` (maf_pack_dw); strides in elements, multiples of the 16-byte
  * channel group; src / dst arrays hold 1 / nb (forward) or nb / 1 (data gradient) entries. */
 /* Forward of maf_dw_branches + the BatchNorm statistics of every branch: stats[j] (may be NULL per branch) = the half of the `part` scratch that the
  * maf_bn_forward_ex(..., stats_ready = 1) call of branch j's BatchNorm will read, [replicas][2][C] fp32, zero on entry; the kernel adds the sum and

@@ -2,7 +2,7 @@
 // branches merged into one k x k filter, dwconv*.hip).
 //
 // Reference: yolov6/layers/common.py:3024-3031 — out = origin_bn(lk_origin(x)) + sum_j dil_bn_j(dil_conv_j(x)): NB depth-wise convolutions of the
-// SAME input with kernel sizes K0, K0 - 2, ... 3 (K0 = 3: 3 and 3; the 1 x 1 branch of K0 = 3 / 5 is a per-channel scale and stays apart), each
+// SAME input with kernel sizes K0, K0 - 2, ... (K0 = 3: 3, 3, 1; K0 = 5: 5, 3, 1 — the 1 x 1 branch, a per-channel scale, rides along), each
 // followed by its own BatchNorm.  As separate launches (round 2 / 3) a step of MAF-YOLO-n ran 46 depth-wise forward kernels that read x 2 - 4
 // times per block, 46 data-gradient kernels that each wrote a full dx_j, and 27 element-wise adds that summed them:
 //   forward   x is staged ONCE (halo of K0), the NB filters walk the same LDS tile, NB outputs                (1 + NB passes instead of 2 NB)
@@ -53,8 +53,8 @@ __device__ __forceinline__ void db_static_for(F&& f) {
     }
 }
 
-// kernel size of branch J of a block whose large kernel is K0 (common.py:2997-3008, without the 1 x 1 branches)
-template <int K0, int J> constexpr int branch_k() { return K0 == 3 ? 3 : K0 - 2 * J; }
+// kernel size of branch J of a block whose large kernel is K0 (common.py:2997-3008): 3 -> 3, 3, 1;  5 -> 5, 3, 1;  7 -> 7, 5, 3;  9 -> 9, 7, 5, 3
+template <int K0, int J> constexpr int branch_k() { return K0 == 3 ? (J < 2 ? 3 : 1) : K0 - 2 * J; }
 
 // acc[r][:] += sum over the K x K window of the strip's 4 pixels; `row0` = LDS vector of the window's top-left pixel for strip pixel 0, `rw` = tile row pitch in pixels
 template <typename T, int K>
@@ -324,11 +324,11 @@ int launch_b(DwbArgs& a, bool dgrad, hipStream_t s) {
 
 template <typename T>
 int launch_k(DwbArgs& a, int k0, int nb, bool dgrad, hipStream_t s) {
-    if (k0 == 3 && nb == 2) return launch_b<T, 3, 2>(a, dgrad, s);
-    if (k0 == 5 && nb == 2) return launch_b<T, 5, 2>(a, dgrad, s);
+    if (k0 == 3 && nb == 3) return launch_b<T, 3, 3>(a, dgrad, s);
+    if (k0 == 5 && nb == 3) return launch_b<T, 5, 3>(a, dgrad, s);
     if (k0 == 7 && nb == 3) return launch_b<T, 7, 3>(a, dgrad, s);
     if (k0 == 9 && nb == 4) return launch_b<T, 9, 4>(a, dgrad, s);
-    maf_set_error("dw_branches: (k0, branches) must be (3, 2), (5, 2), (7, 3) or (9, 4) — kernel sizes k0, k0 - 2, ... 3 (k0 = 3: 3, 3)");
+    maf_set_error("dw_branches: (k0, branches) must be (3, 3), (5, 3), (7, 3) or (9, 4) — kernel sizes 3, 3, 1 / 5, 3, 1 / 7, 5, 3 / 9, 7, 5, 3");
     return MAF_E_UNSUPPORTED;
 }
 

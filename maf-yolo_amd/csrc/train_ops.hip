@@ -235,11 +235,12 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     if (per > budget) per = budget > 8 ? budget : 8;
     const dim3 g(per * a.nCB), b(nthr);
     switch (k) {
+        case 1: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 1>), g, b, lds, s, a); break;      // the 1 x 1 branch of a DilatedReparamBlock (a per-channel scale): dW[c] = sum dy x
         case 3: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 3>), g, b, lds, s, a); break;
         case 5: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 5>), g, b, lds, s, a); break;
         case 7: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 7>), g, b, lds, s, a); break;
         case 9: hipLaunchKernelGGL((dw_wgrad_kernel<T, V, N, 9>), g, b, lds, s, a); break;
-        default: maf_set_error("dw_wgrad: k must be 3, 5, 7 or 9"); return MAF_E_UNSUPPORTED;
+        default: maf_set_error("dw_wgrad: k must be 1, 3, 5, 7 or 9"); return MAF_E_UNSUPPORTED;
     }
     return maf_check_hip(hipGetLastError(), "dw_wgrad launch");
 }

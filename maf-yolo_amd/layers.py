@@ -117,18 +117,12 @@ class DilatedReparamBlock(nn.Module):
             setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
 
     def forward(self, x):
-        # every k > 1 branch in ONE launch (csrc/dw_branches.hip: x staged once; their data gradients summed in one launch too); a 1 x 1 branch is a scale
-        # ... and that launch accumulates every branch's BatchNorm statistics in its epilogue: the BatchNorms behind it are apply passes only
-        big = [kk for kk in self.kernel_sizes if kk > 1]
-        zs, st = train_ops.dw_branches(x, [self.lk_origin.weight] + [getattr(self, "dil_conv_k%d_1" % kk).weight for kk in big],
-                                       [self.origin_bn] + [getattr(self, "dil_bn_k%d_1" % kk) for kk in big])
-        # ... and the BatchNorms of all branches are summed by ONE apply pass (csrc/bn_sum.hip; backward: one statistics + one apply launch for all of them)
-        zz, bns, pre = [zs[0]], [self.origin_bn], [st[0]]
-        for kk in self.kernel_sizes:
-            j = 1 + big.index(kk) if kk > 1 else -1
-            zz.append(zs[j] if kk > 1 else train_ops.dwconv(x, getattr(self, "dil_conv_k%d_1" % kk).weight))
-            bns.append(getattr(self, "dil_bn_k%d_1" % kk))
-            pre.append(st[j] if kk > 1 else None)
+        # every branch in ONE launch (csrc/dw_branches.hip: x staged once, the 1 x 1 scale branch rides along; their data gradients summed in one launch
+        # too), which also accumulates every branch's BatchNorm statistics in its epilogue; the BatchNorms of all branches are summed by ONE apply pass
+        # (csrc/bn_sum.hip; backward: one statistics + one apply launch for all of them)
+        names = ["lk_origin"] + ["dil_conv_k%d_1" % kk for kk in self.kernel_sizes]
+        bns = [self.origin_bn] + [getattr(self, "dil_bn_k%d_1" % kk) for kk in self.kernel_sizes]
+        zz, pre = train_ops.dw_branches(x, [getattr(self, n_).weight for n_ in names], bns)
         return train_ops.bn_sum(zz, bns, pre)                                                           # origin_bn(z_0) + sum_j dil_bn_j(z_j)
 
     def fused(self):

@@ -905,7 +905,7 @@ class _DWBranches(torch.autograd.Function):
         return (dx, None, *dws)
 
 
-_DWB_SETS = {3: (3, 3), 5: (5, 3), 7: (7, 5, 3), 9: (9, 7, 5, 3)}
+_DWB_SETS = {3: (3, 3, 1), 5: (5, 3, 1), 7: (7, 5, 3), 9: (9, 7, 5, 3)}     # lk_origin + dil_branch_kernels(k) (arch.py), common.py:2997-3008
 dw_branches_merged = os.environ.get("MAF_DW_BRANCHES", "1") != "0"       # A/B switch: one launch per direction for the branches of a DilatedReparamBlock
 
 
