@@ -344,7 +344,8 @@ int32_t maf_bn_replicas(int32_t C, int32_t R);
 /* The statistics pass of maf_bn_forward alone (half `phase` of `part` += {sum x, sum x^2}; nothing is cleared). */
 int maf_bn_stats(const void* x, int32_t x_stride, int32_t M, int32_t C, int32_t dtype, float* part, int32_t R, int32_t phase, maf_stream_t stream);
 /* The SUM of the nb (2..4) training-mode BatchNorm2d of a DilatedReparamBlock (common.py:3024-3031: origin_bn(lk_origin(x)) + sum_j dil_bn_j(dil_conv_j(x)),
- * no activation) as one apply pass per direction (csrc/bn_sum.hip):
+ * no activation; act = MAF_ACT_RELU: RepVGGBlock's ReLU(BN(3x3 s2) + BN(1x1 s2)), common.py:224 — the backward recomputes the sum for the ReLU's mask)
+ * as one apply pass per direction (csrc/bn_sum.hip):
  *   maf_bn_sum_forward   out = sum_j BN_j(z_j).  part[j] = branch j's own scratch ([2][R][2][roundup(C,256)], the layout of maf_bn_forward), whose half
  *                        phase[j] ALREADY holds {sum z_j, sum z_j^2} (maf_dw_branches_stats / maf_bn_stats); save_mean / save_rstd / running statistics /
  *                        num_batches_tracked per branch as in maf_bn_forward; the other half of every scratch is cleared.
@@ -355,11 +356,11 @@ int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride, int32_t nb
                        const float* const* gamma, const float* const* beta, float eps, float momentum,
                        float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                        void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
-                       float* const* part, int32_t R, const int32_t* phase, maf_stream_t stream);
+                       float* const* part, int32_t R, const int32_t* phase, int32_t act, maf_stream_t stream);
 int maf_bn_sum_backward(const void* dy, int32_t dy_stride, const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
-                        const float* const* gamma, const float* const* save_mean, const float* const* save_rstd,
+                        const float* const* gamma, const float* const* beta, const float* const* save_mean, const float* const* save_rstd,
                         void* const* dz, const int32_t* dz_stride, float* const* dgamma, float* const* dbeta, int32_t accumulate_affine,
-                        float* bpart, int32_t R, int32_t phase, maf_stream_t stream);
+                        float* bpart, int32_t R, int32_t phase, int32_t act, maf_stream_t stream);
 /* maf_bn_backward with accumulate_affine != 0: dgamma / dbeta are ADDED to what the buffers hold — the slices of a gradient-exchange bucket
  * (maf_yolo_amd/exchange.py: `p.grad` of the BatchNorm affine parameters is a view of a flat fp32 bucket; the reference accumulates them with
  * AccumulateGrad, i.e. 280 one-line add kernels per step of MAF-YOLO-n, yolov6/core/engine.py:164). */

@@ -1,7 +1,7 @@
 // The sum of the BatchNorms of a train-form DilatedReparamBlock as ONE apply pass per direction (training only).
 //
 // Reference: yolov6/layers/common.py:3024-3031 — out = origin_bn(lk_origin(x)) + sum_j dil_bn_j(dil_conv_j(x)): NB (3 or 4) BatchNorm2d in training mode, no
-// activation, summed.  As a chain of fused BatchNorm calls (csrc/bn_act.hip with `residual`, rounds 2-3) every branch cost an apply pass that read its z_j AND
+// activation, summed (and RepVGGBlock, common.py:224: ReLU(BN(3x3 s2) + BN(1x1 s2)), two branches with a ReLU on the sum: `act`).  As a chain of fused BatchNorm calls (csrc/bn_act.hip with `residual`, rounds 2-3) every branch cost an apply pass that read its z_j AND
 // the running sum and wrote the running sum again (3 NB - 1 tensor passes forward), and its own statistics + apply pass over (z_j, d out) backward (5 NB):
 //   forward   out = sum_j (z_j * sc_j + sh_j): NB reads, ONE write                                   (NB + 1 passes; the statistics come from the depth-wise
 //             kernel's epilogue, csrc/dw_branches.hip, or from maf_bn_stats for the 1 x 1 branch)
@@ -22,7 +22,7 @@ struct BsArgs {
     const void* dy; int dys;
     void* out; int outs;
     void* dz[MAXB]; int dzs[MAXB];
-    int nb, M, C, R;
+    int nb, M, C, R, act;                                                // act: MAF_ACT_NONE, or MAF_ACT_RELU on the sum (RepVGGBlock, common.py:224)
     const float* gamma[MAXB]; const float* beta[MAXB];
     float* mean[MAXB]; float* rstd[MAXB];
     float* part[MAXB]; float* part_clear[MAXB]; int clear_n;         // forward: every branch's own statistics scratch (this call's half / the half to clear)
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) { sc[j][q] = cst[(j * 2) * a.C + gi * N + q]; sh[q] += cst[(j * 2 + 1) * a.C + gi * N + q]; }
         }
+        const bool relu = a.act == MAF_ACT_RELU;
         auto one = [&](const V (&zv)[NB]) {
             V ov;
 #pragma unroll
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
                 float u = sh[q];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) u = __builtin_fmaf((float)zv[j][q], sc[j][q], u);
-                ov[q] = (T)u;
+                ov[q] = (T)(relu ? fmaxf(u, 0.f) : u);
             }
             return ov;
         };
@@ -130,13 +131,19 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_stats_kernel(const BsArgs a) {
     const bool wave_reduce = gs < 64 && (gs & (gs - 1)) == 0;
     const int gl = threadIdx.x % gs, pl = threadIdx.x / gs, gi = gbeg + gl;
     const bool active = gl < gcnt && pl < plan;
-    float acc[NS][N], mu[NB][N], rs[NB][N];
+    const bool relu = a.act == MAF_ACT_RELU;                         // g = dy * [u > 0], u = sum_j (xhat_j gamma_j + beta_j) recomputed
+    float acc[NS][N], mu[NB][N], rs[NB][N], ga[NB][N], bsum[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
+        bsum[q] = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k][q] = 0.f;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { mu[j][q] = active ? a.mean[j][gi * N + q] : 0.f; rs[j][q] = active ? a.rstd[j][gi * N + q] : 0.f; }
+        for (int j = 0; j < NB; ++j) {
+            mu[j][q] = active ? a.mean[j][gi * N + q] : 0.f; rs[j][q] = active ? a.rstd[j][gi * N + q] : 0.f;
+            ga[j][q] = (active && relu) ? a.gamma[j][gi * N + q] : 0.f;
+            if (active && relu) bsum[q] += a.beta[j][gi * N + q];
+        }
     }
     if (active) {
         const T* dp = static_cast<const T*>(a.dy);
@@ -156,10 +163,13 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_stats_kernel(const BsArgs a) {
                 if (!ok[u]) continue;
 #pragma unroll
                 for (int q = 0; q < N; ++q) {
-                    const float g = (float)gv[u][q];
+                    float xh[NB], uu = bsum[q];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) { xh[j] = ((float)zv[u][j][q] - mu[j][q]) * rs[j][q]; uu = __builtin_fmaf(xh[j], ga[j][q], uu); }
+                    const float g = (relu && !(uu > 0.f)) ? 0.f : (float)gv[u][q];
                     acc[0][q] += g;
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) acc[1 + j][q] = __builtin_fmaf(g, ((float)zv[u][j][q] - mu[j][q]) * rs[j][q], acc[1 + j][q]);
+                    for (int j = 0; j < NB; ++j) acc[1 + j][q] = __builtin_fmaf(g, xh[j], acc[1 + j][q]);
                 }
             }
         }
@@ -191,7 +201,7 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256) void bn_sum_bwd_apply_kernel(const BsArgs a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N, NS = 1 + NB;
-    extern __shared__ float cst[];                                    // [1 + 4 NB][C]: k0 | per branch k1, sc, mu, rs
+    extern __shared__ float cst[];                                    // [2 + 5 NB][C]: k0 | per branch k1, sc, mu, rs | sum of betas | per branch gamma
     const float invM = 1.f / (float)a.M;
     for (int c = threadIdx.x; c < a.C; c += 256) {
         double s[NS];
@@ -201,6 +211,11 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_apply_kernel(const BsArgs a) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) s[k] += a.bpart[((size_t)r * NS + k) * a.C + c];
         cst[c] = (float)s[0] * invM;
+        float bs = 0.f;
+        if (a.act == MAF_ACT_RELU)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bs += a.beta[j][c];
+        cst[(1 + 4 * NB) * a.C + c] = bs;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float rsf = a.rstd[j][c];
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_apply_kernel(const BsArgs a) {
             cst[(2 + 4 * j) * a.C + c] = rsf * a.gamma[j][c];
             cst[(3 + 4 * j) * a.C + c] = a.mean[j][c];
             cst[(4 + 4 * j) * a.C + c] = rsf;
+            cst[(2 + 4 * NB + j) * a.C + c] = a.gamma[j][c];
             if (blockIdx.x == 0) {                                    // one writer per channel
                 if (a.dbeta[j]) a.dbeta[j][c] = (a.acc_affine ? a.dbeta[j][c] : 0.f) + (float)s[0];
                 if (a.dgamma[j]) a.dgamma[j][c] = (a.acc_affine ? a.dgamma[j][c] : 0.f) + (float)s[1 + j];
@@ -223,27 +239,36 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_apply_kernel(const BsArgs a) {
     for (int g0 = 0; g0 < groups; g0 += gpb) {
         const int gi = g0 + threadIdx.x % gpb, pl = threadIdx.x / gpb;
         if (gi >= groups || pl >= plan) continue;
-        float k0[N], k1[NB][N], sc[NB][N], mu[NB][N], rs[NB][N];
+        const bool relu = a.act == MAF_ACT_RELU;
+        float k0[N], k1[NB][N], sc[NB][N], mu[NB][N], rs[NB][N], ga[NB][N], bsum[N];
 #pragma unroll
         for (int q = 0; q < N; ++q) {
             const int c = gi * N + q;
-            k0[q] = cst[c];
+            k0[q] = cst[c]; bsum[q] = cst[(1 + 4 * NB) * a.C + c];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) { k1[j][q] = cst[(1 + 4 * j) * a.C + c]; sc[j][q] = cst[(2 + 4 * j) * a.C + c]; mu[j][q] = cst[(3 + 4 * j) * a.C + c]; rs[j][q] = cst[(4 + 4 * j) * a.C + c]; }
+            for (int j = 0; j < NB; ++j) {
+                k1[j][q] = cst[(1 + 4 * j) * a.C + c]; sc[j][q] = cst[(2 + 4 * j) * a.C + c]; mu[j][q] = cst[(3 + 4 * j) * a.C + c]; rs[j][q] = cst[(4 + 4 * j) * a.C + c];
+                ga[j][q] = cst[(2 + 4 * NB + j) * a.C + c];
+            }
         }
         for (int m = m0 + pl; m < m1; m += plan) {
             const V gv = *reinterpret_cast<const V*>(dp + (size_t)m * a.dys + gi * N);
             V zv[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) zv[j] = *reinterpret_cast<const V*>(static_cast<const T*>(a.z[j]) + (size_t)m * a.zs[j] + gi * N);
+            float xh[NB][N], g[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                float uu = bsum[q];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { xh[j][q] = ((float)zv[j][q] - mu[j][q]) * rs[j][q]; uu = __builtin_fmaf(xh[j][q], ga[j][q], uu); }
+                g[q] = (relu && !(uu > 0.f)) ? 0.f : (float)gv[q];
+            }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 V ov;
 #pragma unroll
-                for (int q = 0; q < N; ++q) {
-                    const float xh = ((float)zv[j][q] - mu[j][q]) * rs[j][q];
-                    ov[q] = (T)(sc[j][q] * ((float)gv[q] - k0[q] - xh * k1[j][q]));
-                }
+                for (int q = 0; q < N; ++q) ov[q] = (T)(sc[j][q] * (g[q] - k0[q] - xh[j][q] * k1[j][q]));
                 *reinterpret_cast<V*>(static_cast<T*>(a.dz[j]) + (size_t)m * a.dzs[j] + gi * N) = ov;
             }
         }
@@ -293,12 +318,13 @@ extern "C" int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride,
                                   const float* const* gamma, const float* const* beta, float eps, float momentum,
                                   float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                                   void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
-                                  float* const* part, int32_t R, const int32_t* phase, maf_stream_t stream) {
+                                  float* const* part, int32_t R, const int32_t* phase, int32_t act, maf_stream_t stream) {
     if (int rc = check(nb, M, C, dtype, R)) return rc;
+    MAF_REQUIRE(act == MAF_ACT_NONE || act == MAF_ACT_RELU, "bn_sum: act must be none or relu");
     MAF_REQUIRE(z && z_stride && gamma && beta && out && save_mean && save_rstd && part && phase, "bn_sum_forward: null argument");
     const int N = dtype == MAF_F16 ? 8 : 4;
     BsArgs a = {};
-    a.nb = nb; a.M = M; a.C = C; a.R = replicas(C, R); a.eps = eps; a.momentum = momentum;
+    a.nb = nb; a.M = M; a.C = C; a.R = replicas(C, R); a.eps = eps; a.momentum = momentum; a.act = act;
     a.out = out; a.outs = out_stride;
     MAF_REQUIRE(out_stride % N == 0, "bn_sum_forward: output stride must be a multiple of the channel group");
     const int half = R * 2 * ((C + 255) / 256 * 256);
@@ -322,27 +348,30 @@ extern "C" int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride,
 
 // Backward: dy = gradient of the sum; bpart = [2][R][1 + nb][roundup(C,256)] fp32 scratch, zeroed once by the caller, halves alternate (phase) like maf_bn_backward's.
 extern "C" int maf_bn_sum_backward(const void* dy, int32_t dy_stride, const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
-                                   const float* const* gamma, const float* const* save_mean, const float* const* save_rstd,
+                                   const float* const* gamma, const float* const* beta, const float* const* save_mean, const float* const* save_rstd,
                                    void* const* dz, const int32_t* dz_stride, float* const* dgamma, float* const* dbeta, int32_t accumulate_affine,
-                                   float* bpart, int32_t R, int32_t phase, maf_stream_t stream) {
+                                   float* bpart, int32_t R, int32_t phase, int32_t act, maf_stream_t stream) {
     if (int rc = check(nb, M, C, dtype, R)) return rc;
+    MAF_REQUIRE(act == MAF_ACT_NONE || act == MAF_ACT_RELU, "bn_sum: act must be none or relu");
+    MAF_REQUIRE(beta, "bn_sum_backward: null argument");
     MAF_REQUIRE(dy && z && z_stride && gamma && save_mean && save_rstd && dz && dz_stride && dgamma && dbeta && bpart && (phase == 0 || phase == 1), "bn_sum_backward: null argument");
     const int N = dtype == MAF_F16 ? 8 : 4;
     MAF_REQUIRE(dy_stride % N == 0, "bn_sum_backward: gradient stride must be a multiple of the channel group");
     BsArgs a = {};
-    a.nb = nb; a.M = M; a.C = C; a.R = replicas(C, R); a.dy = dy; a.dys = dy_stride; a.acc_affine = accumulate_affine;
+    a.nb = nb; a.M = M; a.C = C; a.R = replicas(C, R); a.dy = dy; a.dys = dy_stride; a.acc_affine = accumulate_affine; a.act = act;
     const int half = R * (1 + nb) * ((C + 255) / 256 * 256);
     a.bpart = bpart + (size_t)phase * half; a.bpart_clear = bpart + (size_t)(1 - phase) * half; a.bclear_n = half;
     for (int j = 0; j < nb; ++j) {
         MAF_REQUIRE(z[j] && z_stride[j] % N == 0 && gamma[j] && save_mean[j] && save_rstd[j] && dz[j] && dz_stride[j] % N == 0, "bn_sum_backward: null / misaligned branch argument");
-        a.z[j] = z[j]; a.zs[j] = z_stride[j]; a.gamma[j] = gamma[j]; a.mean[j] = const_cast<float*>(save_mean[j]); a.rstd[j] = const_cast<float*>(save_rstd[j]);
+        MAF_REQUIRE(beta[j], "bn_sum_backward: null beta");
+        a.z[j] = z[j]; a.zs[j] = z_stride[j]; a.gamma[j] = gamma[j]; a.beta[j] = beta[j]; a.mean[j] = const_cast<float*>(save_mean[j]); a.rstd[j] = const_cast<float*>(save_rstd[j]);
         a.dz[j] = dz[j]; a.dzs[j] = dz_stride[j]; a.dgamma[j] = dgamma[j]; a.dbeta[j] = dbeta[j];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     size_t lds_s;
     const dim3 gs = stats_grid(M, C, dtype, 1 + nb, &lds_s);
     const int ga = apply_grid(M, C, dtype);
-    const size_t la = (size_t)(1 + 4 * nb) * C * sizeof(float);
+    const size_t la = (size_t)(2 + 5 * nb) * C * sizeof(float);
 #define MAF_BS_BWD(TT, NBV)                                                                        \
     {                                                                                              \
         static bool attr = false;                                                                  \

@@ -89,9 +89,10 @@ class RepVGGBlock(nn.Module):
         # both branches (conv + BatchNorm each) on the HIP kernels
         if x.is_cuda and x.shape[1] % 8:
             x = train_ops.pad_channels8(x)                                       # the image: cast + channel padding once for both branches
-        y3 = train_ops.bn_act(train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), self.rbr_dense.bn)
-        # ReLU(BN(1x1) + y3): the branch sum and the ReLU ride in the second BatchNorm's apply pass
-        return train_ops.bn_act(train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight), self.rbr_1x1.bn, "relu", residual=y3)
+        # ReLU(BN(3x3) + BN(1x1)): one apply pass over both branch tensors (csrc/bn_sum.hip; backward: one statistics + one apply launch for both BatchNorms,
+        # the ReLU's mask recomputed from the branch tensors)
+        return train_ops.bn_sum([train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight)],
+                                [self.rbr_dense.bn, self.rbr_1x1.bn], act="relu")
 
     def fused(self):
         """One 3x3 kernel + bias (get_equivalent_kernel_bias, common.py:226-230)."""

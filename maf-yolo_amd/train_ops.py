@@ -1113,7 +1113,7 @@ class _BNSum(torch.autograd.Function):
         B, c, H, W = x0.shape
         dt = _DT[x0.dtype]
         dev = x0.device
-        eps, momentum, per = cfg
+        eps, momentum, per, act = cfg
         L = lib.load()
         M_ = B * H * W
         for (z, zst), (rm, rv, cnt, part, phase, need) in zip(zs, per):
@@ -1130,9 +1130,9 @@ class _BNSum(torch.autograd.Function):
                                            _PTR4(*[0 if p[0] is None else p[0].data_ptr() for p in per]), _PTR4(*[0 if p[1] is None else p[1].data_ptr() for p in per]),
                                            _PTR4(*[0 if p[2] is None else p[2].data_ptr() for p in per]),
                                            out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
-                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _INT4(*[p[4] for p in per]), _stream(dev)))
-        ctx.save_for_backward(stat, *[z for z, _ in zs], *g32)
-        ctx.nb = nb
+                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _INT4(*[p[4] for p in per]), act, _stream(dev)))
+        ctx.save_for_backward(stat, *[z for z, _ in zs], *g32, *b32)
+        ctx.nb, ctx.act = nb, act
         ctx.affine = list(zip(gammas, betas)) if all(isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter) for g, b in zip(gammas, betas)) else None
         stats["native_bn_act"] = stats.get("native_bn_act", 0) + nb
         stats["native_bn_sum"] = stats.get("native_bn_sum", 0) + 1
@@ -1142,7 +1142,7 @@ class _BNSum(torch.autograd.Function):
     def backward(ctx, dy):
         nb = ctx.nb
         sv = ctx.saved_tensors
-        stat, zs, g32 = sv[0], [nhwc(z) for z in sv[1:1 + nb]], sv[1 + nb:1 + 2 * nb]
+        stat, zs, g32, b32 = sv[0], [nhwc(z) for z in sv[1:1 + nb]], sv[1 + nb:1 + 2 * nb], sv[1 + 2 * nb:1 + 3 * nb]
         x0 = zs[0][0]
         B, c, H, W = x0.shape
         dev = x0.device
@@ -1163,11 +1163,11 @@ class _BNSum(torch.autograd.Function):
         gp = None if dgb is None else dgb.data_ptr()
         with _prof("bn_sum_backward", (2 + 3 * nb) * B * H * W * c * x0.element_size(), dev, (B, H, W, c, nb)):
             lib.check(lib.load().maf_bn_sum_backward(dy.data_ptr(), dys, _PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, B * H * W, c, _DT[x0.dtype],
-                                                     _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
+                                                     _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[b.data_ptr() for b in b32]), _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
                                                      _PTR4(*[d.data_ptr() for d in dzs]), _INT4(*[d.stride()[3] for d in dzs]),
                                                      _PTR4(*[tg[j][0][1].data_ptr() if tg is not None else gp + 8 * c * j for j in range(nb)]),
                                                      _PTR4(*[tg[j][1][1].data_ptr() if tg is not None else gp + 8 * c * j + 4 * c for j in range(nb)]),
-                                                     1 if tg is not None else 0, part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
+                                                     1 if tg is not None else 0, part.data_ptr(), _BN_REPLICAS, phase, ctx.act, _stream(dev)))
         if tg is not None:
             for g, b in ctx.affine:
                 ex.main_done(g)
@@ -1179,8 +1179,8 @@ class _BNSum(torch.autograd.Function):
 bn_sum_merged = os.environ.get("MAF_BN_SUM", "1") != "0"               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
 
 
-def bn_sum(zs, bns, pre_stats=None):
-    """sum_j bns[j](zs[j]) for the branches of a train-form DilatedReparamBlock (no activation).  CUDA + training mode: csrc/bn_sum.hip (one apply pass forward,
+def bn_sum(zs, bns, pre_stats=None, act=None):
+    """act(sum_j bns[j](zs[j])): the branches of a train-form DilatedReparamBlock (act None) or of a RepVGGBlock (act "relu", common.py:224).  CUDA + training mode: csrc/bn_sum.hip (one apply pass forward,
     statistics + apply for all branches backward); otherwise — and for anything the kernel does not take — the chain of bn_act calls with `residual`.
     `pre_stats[j]`: what dw_branches returned for branch j (its statistics are already accumulated) or None."""
     nb = len(zs)
@@ -1191,16 +1191,18 @@ def bn_sum(zs, bns, pre_stats=None):
           and all(z.shape == x.shape and z.dtype == x.dtype for z in zs)
           and all(bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.eps == bns[0].eps and bn.momentum == bns[0].momentum
                   and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64 for bn in bns))
+    if act not in (None, "none", "relu"):
+        raise lib.MafError("bn_sum: act must be None or 'relu'")
     if not ok:
         out = bn_act(zs[0], bns[0], pre_stats=pre[0])
-        for z, bn, st in zip(zs[1:], bns[1:], pre[1:]):
-            out = bn_act(z, bn, residual=out, pre_stats=st)
+        for j in range(1, nb):
+            out = bn_act(zs[j], bns[j], act if j == nb - 1 else None, residual=out, pre_stats=pre[j])
         return out
     per = []
     for bn, st in zip(bns, pre):
         part, phase = st if st is not None else bn_own_scratch(bn, x.device, x.shape[1])
         per.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, part, phase, st is None))
-    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act]), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
 class _MaxPool(torch.autograd.Function):

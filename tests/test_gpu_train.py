@@ -1037,3 +1037,61 @@ def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype
         err = float((p2.grad - p1.grad).abs().max())
         assert err <= (2e-2 if dtype == torch.float16 else 1e-4) * float(p1.grad.abs().max()) + 1e-3 * gmax, (n1, err, float(p1.grad.abs().max()), gmax)
     assert getattr(fused.dwconv.origin_bn, "_maf_part", None) is not None and getattr(ref.dwconv.origin_bn, "_maf_part", None) is None
+
+
+@pytest.mark.parametrize("cin,cout,hw,dtype", [(3, 24, (64, 64), torch.float16), (24, 48, (40, 36), torch.float16), (96, 96, (20, 20), torch.float16), (8, 16, (12, 12), torch.float32)])
+def test_repvgg_block_branch_sum_with_relu_in_one_apply_pass(cin, cout, hw, dtype):
+    """RepVGGBlock in train form (yolov6/layers/common.py:224: ReLU(BN(conv3x3 s2) + BN(conv1x1 s2))) on maf_bn_sum_forward / _backward with act = relu — the
+    backward recomputes the sum for the ReLU's mask — against the chain of two fused BatchNorm calls (round 3), two steps."""
+    import copy
+    from maf_yolo_amd.layers import RepVGGBlock
+    torch.manual_seed(cin + cout)
+    ref = RepVGGBlock(cin, cout).to(DEV).train()
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3)
+    new = copy.deepcopy(ref)
+    exact = copy.deepcopy(ref).float()
+    g = torch.Generator().manual_seed(3)
+    tol = 3e-3 if dtype == torch.float16 else 2e-5
+    for step in range(2):
+        x = torch.randn(4, cin, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(4, cout, hw[0] // 2, hw[1] // 2, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for blk, merged in ((ref, False), (new, True)):
+            train_ops.bn_sum_merged = merged
+            try:
+                xa = x.clone().requires_grad_(True)
+                n0 = train_ops.stats.get("native_bn_sum", 0)
+                y = blk(xa)
+                assert train_ops.stats.get("native_bn_sum", 0) - n0 == (1 if merged else 0)
+                y.backward(dy)
+                torch.cuda.synchronize()
+                outs.append((y.detach().float(), xa.grad.float()))
+            finally:
+                train_ops.bn_sum_merged = True
+        assert float(outs[1][0].min()) >= 0.0
+        assert _rel(outs[1][0].cpu(), outs[0][0].cpu()) < tol, step
+        # the input gradient: the chain rounds BN(3x3) to fp16 before the sum, the one-pass form does not, so a sum within an fp16 ulp of zero takes the other
+        # side of the ReLU in the backward pass — a handful of output pixels whose whole gradient appears or vanishes; everything else agrees to round-off
+        # — judged against the block in fp32 on the framework's ops: the one-pass form must not have more outliers than the chain has
+        train_ops.framework_ops = True
+        try:
+            x32 = x.float().requires_grad_(True)
+            exact(x32).backward(dy.float())
+        finally:
+            train_ops.framework_ops = False
+        gx = x32.grad
+        frac = [float((((o[1] - gx).abs() / gx.abs().max()) > 4 * tol).float().mean()) for o in outs]
+        print("RepVGG %d -> %d step %d: share of input-gradient elements off by > %.0e of max |g| against fp32: chain %.2e, one pass %.2e" % (cin, cout, step, 4 * tol, frac[0], frac[1]))
+        assert frac[1] <= 1.5 * frac[0] + 5e-3, (step, frac)        # (one flipped output value reaches 9 x Cin input-gradient elements: 1 against 3 flips on the 10 x 10 map)
+    gmax = max(float(p.grad.abs().max()) for p in exact.parameters())
+    for (n1, p1), p2, pe in zip(ref.named_parameters(), new.parameters(), exact.parameters()):
+        e_chain, e_new = float((p1.grad - pe.grad).abs().max()), float((p2.grad - pe.grad).abs().max())      # both against the fp32 block: the mask flips move the weight gradients too
+        # (400 values per channel on the 10 x 10 map: ONE flipped ReLU moves a BatchNorm weight's gradient by 2-3 % of its maximum)
+        assert e_new <= 1.5 * e_chain + (5e-2 if dtype == torch.float16 else 1e-4) * float(pe.grad.abs().max()) + 1e-3 * gmax, (n1, e_new, e_chain, float(pe.grad.abs().max()))
+    sa, sb = ref.state_dict(), new.state_dict()
+    for key in sa:
+        if "running" in key:
+            assert torch.allclose(sa[key], sb[key], rtol=1e-4, atol=1e-5), key
