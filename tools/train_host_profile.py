@@ -59,6 +59,27 @@ def main():
         ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     print("host issue time per step (empty queue): %s ms" % ", ".join("%.2f" % (1e3 * t) for t in ts))
+    # the same, phase by phase (host clock only, no device synchronisation inside the step)
+    acc = [0.0] * 6
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t = [time.perf_counter()]
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = model(x)
+        t.append(time.perf_counter())
+        loss = crit((feats, cls, reg), targets, 0, 0)[0]
+        ex.zero_grad()
+        t.append(time.perf_counter())
+        scaler.scale(loss).backward()
+        t.append(time.perf_counter())
+        scaler.step(opt)
+        scaler.update()
+        t.append(time.perf_counter())
+        ema.update(model)
+        t.append(time.perf_counter())
+        for i in range(5):
+            acc[i] += t[i + 1] - t[i]
+    print("host issue time by phase (ms): forward %.2f, loss + zero_grad %.2f, backward %.2f, scaler + optimizer %.2f, EMA %.2f" % tuple(1e3 * a_ / steps for a_ in acc[:5]))
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
