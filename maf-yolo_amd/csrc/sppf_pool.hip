@@ -66,7 +66,16 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     V* cur = reinterpret_cast<V*>(smem_raw);                 // [H*W]
     V* tmp = cur + a.H * a.W;                                // [H*W]
-    const int b = blockIdx.y, cg = blockIdx.x, HW = a.H * a.W;
+    // one image's channel groups on ONE XCD: a pixel's 16-byte groups share 128-byte lines, and workgroups go to the XCDs round-robin by block id — with
+    // (channel group, image) = (blockIdx.x, blockIdx.y) every line was fetched by up to 8 L2s.  Block id -> XCD = id & 7; inside an XCD images in turn,
+    // channel groups fastest (the grid is 1-D: CG * B blocks, B a multiple of 8 or not: the tail images keep the plain order)
+    int b, cg;
+    {
+        const int bid = blockIdx.x, B8 = a.B & ~7;
+        if (bid < B8 * a.CG) { const int xcd = bid & 7, j = bid >> 3; b = xcd + 8 * (j / a.CG); cg = j % a.CG; }
+        else { const int r = bid - B8 * a.CG; b = B8 + r / a.CG; cg = r % a.CG; }
+    }
+    const int HW = a.H * a.W;
     const T* in = static_cast<const T*>(a.in) + (size_t)b * HW * a.in_stride + a.in_coff + cg * N;
     T* out = static_cast<T*>(a.out) + (size_t)b * HW * a.out_stride + a.out_coff + cg * N;
     for (int p = threadIdx.x; p < HW; p += blockDim.x) cur[p] = *reinterpret_cast<const V*>(in + (size_t)p * a.in_stride);
@@ -122,7 +131,7 @@ int maf_launch_sppf_pool(const maf_op_t* op, hipStream_t s) {
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
     const size_t lds = (size_t)a.H * a.W * 16 * 2;
     if (lds <= 64 * 1024) {
-        const dim3 gl(a.CG, a.B);
+        const dim3 gl(a.CG * a.B);
         if (op->dtype == MAF_F16) hipLaunchKernelGGL((sppf_pool_lds_kernel<half_t, half8_t, 8>), gl, b, lds, s, a);
         else hipLaunchKernelGGL((sppf_pool_lds_kernel<float, f32x4_t, 4>), gl, b, lds, s, a);
     } else if (op->dtype == MAF_F16) {

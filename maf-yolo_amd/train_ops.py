@@ -913,14 +913,16 @@ dw_branch_stats = os.environ.get("MAF_DW_BRANCH_STATS", "1") != "0"      # A/B s
 _deterministic = False
 
 
+_own_scratch = __import__("weakref").WeakKeyDictionary()                  # BatchNorm2d module -> [scratch, phase, channels]: outside the module (the reference pickles / deep-copies whole models)
+
+
 def bn_own_scratch(bn, dev, c):
     """(scratch, phase) of a BatchNorm whose statistics are produced by ANOTHER kernel than its own call (the depth-wise kernel of csrc/dw_branches.hip):
     a buffer per module — the shared per-stream one alternates its halves call by call, and the apply pass of the call in front would clear the half this
     call's producer has just filled — whose halves alternate step by step (the apply pass clears the half of the step before, as always)."""
-    ent = getattr(bn, "_maf_part", None)
+    ent = _own_scratch.get(bn)
     if ent is None or ent[0].device != dev or ent[2] != c:
-        ent = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1, c]
-        bn._maf_part = ent
+        ent = _own_scratch[bn] = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1, c]
     ent[1] ^= 1
     return ent[0], ent[1]
 

@@ -1036,7 +1036,8 @@ def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype
         # (a branch BatchNorm's bias gradient is the sum of the outer BatchNorm's dx — zero in exact arithmetic: a floor at 1e-3 of the largest gradient)
         err = float((p2.grad - p1.grad).abs().max())
         assert err <= (2e-2 if dtype == torch.float16 else 1e-4) * float(p1.grad.abs().max()) + 1e-3 * gmax, (n1, err, float(p1.grad.abs().max()), gmax)
-    assert getattr(fused.dwconv.origin_bn, "_maf_part", None) is not None and getattr(ref.dwconv.origin_bn, "_maf_part", None) is None
+    assert fused.dwconv.origin_bn in train_ops._own_scratch and ref.dwconv.origin_bn not in train_ops._own_scratch
+    assert not any("maf" in k for k in fused.state_dict()) and not hasattr(fused.dwconv.origin_bn, "_maf_part")        # nothing of it travels with the module
 
 
 @pytest.mark.parametrize("cin,cout,hw,dtype", [(3, 24, (64, 64), torch.float16), (24, 48, (40, 36), torch.float16), (96, 96, (20, 20), torch.float16), (8, 16, (12, 12), torch.float32)])
