@@ -271,12 +271,23 @@ size_t lds_bytes(int TH, int TW, int CB, int N, int K0, int NB) {
     return ((size_t)(TH + K0 - 1) * (TW + K0 - 1) * (CB / N + 2) + (size_t)NB * K0 * K0 * (CB / N)) * 16 + (size_t)NB * 2 * CB * sizeof(float);   // tile | weights | statistics
 }
 
-// least halo amplification that fits the LDS (the cost model of dwconv.hip); max_items: work items (4-pixel strips x channel groups) a workgroup may hold
+// least staged-pixels-per-output-pixel that fits the LDS (the cost model of dwconv.hip + the COVERAGE of the map: 16 x 32 tiles cover a 40 x 40 map
+// with 48 x 64 pixels, 1.9x — the first version ignored that and the 40 x 40 data gradients ran at 0.5 TB/s); tile sizes that divide the 20 / 40 /
+// 80 / 160-pixel maps are candidates too.  max_items: work items (4-pixel strips x channel groups) a workgroup may hold
 void choose_tile(int H, int W, int C, int N, int K0, int NB, int max_items, int& TH, int& TW, int& CB) {
+    // measured first (tools/dwb_sweep.py, MI355X, the shapes of MAF-YOLO at 640 px): 32-channel blocks; 10 x 20 tiles on the 20 / 40-pixel maps (no
+    // coverage waste), 8 x 32 on the 160-pixel maps, 16 x 16 in between — 190 -> 141 us on 160 x 160 x 72, 77 -> 68 on 80 x 80 x 144, -8 % at 20 x 20;
+    // the cost model below only where that tile does not fit
+    {
+        const int cb = std::min(8 * N, (C + N - 1) / N * N) >= 4 * N ? 4 * N : std::min(8 * N, (C + N - 1) / N * N);
+        const int th = (W % 20 == 0 && W <= 40 && H % 10 == 0) ? 10 : W >= 160 ? 8 : 16;
+        const int tw = (W % 20 == 0 && W <= 40 && H % 10 == 0) ? 20 : W >= 160 ? 32 : 16;
+        if (th <= H && tw <= (W + R - 1) / R * R && lds_bytes(th, tw, cb, N, K0, NB) <= kMaxLdsB && th * (tw / R) * (cb / N) <= max_items) { TH = th; TW = tw; CB = cb; return; }
+    }
     const int line = 8 * N;
     double best = 1e30;
     TH = 4; TW = 8; CB = 2 * N;
-    const int ths[] = {4, 8, 16, 32}, tws[] = {8, 16, 32};
+    const int ths[] = {4, 5, 8, 10, 16, 20, 32, 40}, tws[] = {8, 16, 20, 32, 40};
     for (int cbm = 8; cbm >= 2; cbm >>= 1) {
         const int cb = std::min(cbm * N, (C + N - 1) / N * N);
         for (int th0 : ths) for (int tw0 : tws) {
@@ -284,13 +295,15 @@ void choose_tile(int H, int W, int C, int N, int K0, int NB, int max_items, int&
             const size_t lds = lds_bytes(th, tw, cb, N, K0, NB);
             const int items = th * (tw / R) * (cb / N);
             if (lds > kMaxLdsB || items > max_items) continue;
-            const double rows = std::min(th + K0 - 1, H), cols = std::min(tw + K0 - 1, W);
-            double cost = rows * cols / ((double)std::min(th, H) * std::min(tw, W));
+            const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+            // staged pixels of all tiles (halo clipped at the map's border is still staged as zeros) per pixel of the map
+            double cost = (double)ty * tx * (th + K0 - 1) * (tw + K0 - 1) / ((double)H * W);
             if (cb < line && cb < C) cost *= 1.25;
             if (lds > 64 * 1024) cost *= 1.5;
             else if (lds > 40 * 1024) cost *= 1.25;
             else if (lds > 20 * 1024) cost *= 1.1;
             if (items < 256) cost *= 256.0 / items;
+            else if (items % 256) cost *= (double)((items + 255) / 256 * 256) / items;      // idle lanes of the last pass
             if (cost < best - 1e-9) { best = cost; TH = th; TW = tw; CB = cb; }
         }
     }
