@@ -421,6 +421,19 @@ typedef struct maf_pack_desc {
 int maf_pack_batch(const maf_pack_desc_t* descs_dev, int32_t n, int32_t nblocks, maf_stream_t stream);
 int32_t maf_pack_desc_size(void);
 
+/* ModelEMA.update (yolov6/utils/ema.py:25-37: `v *= d; v += (1 - d) * msd[k].detach()` for every floating-point state_dict entry) in one
+ * launch over a descriptor table in DEVICE memory: dst (the average) and src (the model) fp32, `total` elements, block0 = first block of the
+ * entry in the flattened grid (1024 elements per block; ascending), nblocks = sum of ceil(total / 1024).  decay and one_minus_decay are the
+ * two scalars as the reference's tensor ops see them (Python doubles rounded to fp32); the two products and the sum are rounded
+ * separately, so the result is bit-identical to the reference's three element-wise ops. */
+typedef struct maf_ema_desc {
+    void* dst; const void* src;
+    int64_t total;
+    int32_t block0, reserved;
+} maf_ema_desc_t;
+int maf_ema_update(const maf_ema_desc_t* descs_dev, int32_t n, int32_t nblocks, float decay, float one_minus_decay, maf_stream_t stream);
+int32_t maf_ema_desc_size(void);
+
 
 /*
  * Post-NMS tail — replaces Evaler.scale_coords (yolov6/core/evaler.py:382-409, ratio_pad branch), box_convert

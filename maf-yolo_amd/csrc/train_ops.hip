@@ -86,6 +86,32 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const maf_pack_desc_t* 
     }
 }
 
+// ModelEMA.update (yolov6/utils/ema.py:25-37) for every floating-point state_dict entry in ONE launch: e = e * d + (1 - d) * m, the two products
+// and the sum rounded separately (the reference's `v *= d; v += (1 - d) * msd[k]` — no fused multiply-add), fp32.
+__global__ __launch_bounds__(256) void ema_update_kernel(const maf_ema_desc_t* __restrict__ descs, int n, float d, float omd) {
+#pragma clang fp contract(off)                                        // (HIP's __fmul_rn / __fadd_rn are inline operators compiled with contraction on: they still fuse)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                                 // last descriptor whose block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const maf_ema_desc_t e = descs[lo];
+    float* __restrict__ dst = static_cast<float*>(e.dst);
+    const float* __restrict__ src = static_cast<const float*>(e.src);
+    const long long i0 = ((long long)(blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= e.total && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        f32x4_t a = *reinterpret_cast<const f32x4_t*>(dst + i0);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + i0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float t0 = a[q] * d, t1 = b[q] * omd; a[q] = t0 + t1; }
+        *reinterpret_cast<f32x4_t*>(dst + i0) = a;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < e.total) { const float t0 = dst[i0 + q] * d, t1 = src[i0 + q] * omd; dst[i0 + q] = t0 + t1; }
+}
+
 // Depth-wise weight gradient: dW[c][ky][kx] = sum_{b,y,x} dY[b,y,x,c] * X[b,y+ky-P,x+kx-P,c]   (zero padding).
 // Workgroup = one TH x TW tile of one image x one block of CB channels: the X halo tile and the dY tile are staged in
 // LDS once; the partial sums reach dW with fp32 atomics (dW is zeroed by the caller).
@@ -297,6 +323,14 @@ extern "C" int maf_pack_batch(const maf_pack_desc_t* descs_dev, int32_t n, int32
 }
 
 extern "C" int32_t maf_pack_desc_size(void) { return (int32_t)sizeof(maf_pack_desc_t); }
+
+extern "C" int maf_ema_update(const maf_ema_desc_t* descs_dev, int32_t n, int32_t nblocks, float decay, float one_minus_decay, maf_stream_t stream) {
+    MAF_REQUIRE(descs_dev && n > 0 && nblocks > 0, "ema_update: bad arguments");
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), descs_dev, n, decay, one_minus_decay);
+    return maf_check_hip(hipGetLastError(), "ema_update launch");
+}
+
+extern "C" int32_t maf_ema_desc_size(void) { return (int32_t)sizeof(maf_ema_desc_t); }
 
 extern "C" int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream) {
     MAF_REQUIRE(w && out && C > 0 && k > 0, "pack_dw: bad arguments");

@@ -7,8 +7,12 @@ On CUDA parameters the SGD is torch's fused implementation: one multi-tensor lau
 GradScaler's inf check stays on the device (the optimizer receives grad_scale / found_inf tensors and skips the update itself), so
 `scaler.step(opt)` does not synchronise the host with the GPU and the launches of step i+1 queue up behind step i.  Same arithmetic as the
 reference's torch.optim.SGD(nesterov=True)."""
+import os
+
 import torch
 import torch.nn as nn
+
+ema_one_launch = os.environ.get("MAF_EMA_NATIVE", "1") != "0"       # A/B switch: ModelEMA.update as one launch (csrc/train_ops.hip maf_ema_update)
 
 
 def param_groups(model):
@@ -84,6 +88,7 @@ class ModelEMA:
             self._src = [sd[k].detach() for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
             self._pairs_of = src
             self._plist = None                                                    # (the cached Parameter objects of _signature: rebuilt with the lists)
+            self._table = None                                                    # (the device descriptor table of the one-launch update)
             self._sig = self._signature(src)
         return self._dst, self._src
 
@@ -106,8 +111,36 @@ class ModelEMA:
             self.updates += 1
             d = self.decay(self.updates)
             dst, src = self._pairs(model)
+            if self._native(dst, src):
+                from . import lib
+                table, n, nblocks, dev = self._table
+                with torch.cuda.device(dev):
+                    lib.check(lib.load().maf_ema_update(table.data_ptr(), n, nblocks, d, 1 - d, torch.cuda.current_stream(dev).cuda_stream))
+                return
             torch._foreach_mul_(dst, d)
             torch._foreach_add_(dst, torch._foreach_mul(src, 1 - d))
+
+    def _native(self, dst, src):
+        """All pairs fp32, dense, on one CUDA device: the update is ONE launch over a descriptor table (csrc/train_ops.hip maf_ema_update; same
+        roundings as the three multi-tensor ops below it, which cost ~1.8 ms of host time per step on MAF-YOLO-n: ~840 tensors, a temporary
+        per tensor).  The table is rebuilt with the cached tensor lists (`_pairs`).  Anything else (CPU models, half-precision copies) takes the
+        framework's multi-tensor ops."""
+        if getattr(self, "_table", None) is None:
+            self._table = False
+            if ema_one_launch and dst and all(a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.device == b.device == dst[0].device
+                           and a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() for a, b in zip(dst, src)):
+                import ctypes as C
+                from . import lib
+                pairs = [(a, b) for a, b in zip(dst, src) if a.numel()]
+                arr = (lib.MafEmaDesc * len(pairs))()
+                blk = 0
+                for e, (a, b) in zip(arr, pairs):
+                    e.dst, e.src, e.total, e.block0 = a.data_ptr(), b.data_ptr(), a.numel(), blk
+                    blk += -(-a.numel() // 1024)
+                assert C.sizeof(lib.MafEmaDesc) == lib.load().maf_ema_desc_size()
+                if pairs:
+                    self._table = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dst[0].device), len(pairs), blk, dst[0].device)
+        return bool(self._table)
 
     def update_attr(self, model, include=(), exclude=("process_group", "reducer")):
         """ema.py:39-40 / copy_attr :43-49: plain attributes of the model copied onto the EMA model."""

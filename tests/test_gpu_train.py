@@ -695,6 +695,53 @@ def test_fused_sgd_survives_a_skipped_first_step():
 
 
 @pytest.mark.gpu
+def test_model_ema_one_launch_update_is_bit_identical_to_the_per_tensor_rule():
+    """ModelEMA.update on a CUDA model is ONE launch over a descriptor table (csrc/train_ops.hip maf_ema_update).  yolov6/utils/ema.py:29-37:
+    every floating state_dict entry `v *= d; v += (1 - d) * msd[k]` — two rounded products, one rounded sum; integer buffers untouched; the table
+    follows replaced storage (`p.data = ...`, `.to()`), and a half-precision copy of the model takes the framework's multi-tensor ops."""
+    import copy
+    import math
+    torch.manual_seed(3)
+    model = M.Model("n").cuda()
+    ema = M.ModelEMA(model)
+    want = copy.deepcopy(model.state_dict())
+    for step in range(1, 4):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
+            for name, b in model.named_buffers():
+                b.add_(0.1 if b.dtype.is_floating_point else 1)
+            if step == 3:                                              # new storage for one parameter and (through _apply) for everything
+                p = model.backbone[0].rbr_dense.conv.weight
+                p.data = p.data.clone() + 1.0
+        if step == 2:
+            model.double().float()
+        ema.update(model)
+        assert ema._table and ema._table[1] > 600, "the native one-launch path did not run"
+        d = 0.9999 * (1 - math.exp(-step / 2000))
+        sd = model.state_dict()
+        for k, v in want.items():
+            if v.dtype.is_floating_point:
+                v *= d
+                v += (1 - d) * sd[k]
+    got = ema.ema.state_dict()
+    assert list(got) == list(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert int(got["backbone.0.rbr_dense.bn.num_batches_tracked"]) == 0
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 1, bias=False), torch.nn.BatchNorm2d(16)).cuda()
+    ema2 = M.ModelEMA(net)
+    before = ema2.ema.state_dict()["0.weight"].clone()
+    half = copy.deepcopy(net).half()
+    ema2.update(half)                                                  # fp16 sources: not the native path, still the rule
+    assert not ema2._table
+    d = 0.9999 * (1 - math.exp(-1 / 2000))
+    torch.testing.assert_close(ema2.ema.state_dict()["0.weight"], before * d + (1 - d) * half.state_dict()["0.weight"], rtol=1e-6, atol=1e-7)      # (the reference's product is fp16 there too)
+    ema2.update(net)
+    assert ema2._table and ema2._table[1] == 5
+
+
+@pytest.mark.gpu
 def test_weight_staging_plan_matches_per_layer_packing():
     """train_ops.PackPlan: from the second step on every weight transform of the model comes out of ONE maf_pack_batch launch; the staged
     buffers must be bit-identical to what the per-layer pack kernels produce, follow optimizer updates, and be dropped by .to() / invalidate."""
