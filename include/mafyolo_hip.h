@@ -389,6 +389,12 @@ int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_str
  * accumulation over several backward passes), 0 overwrites.  Runs on `stream` (the weight-gradient stream). */
 int maf_grad_fold(const float* src, int32_t taps, int32_t Cout_p, int32_t Cin_p, float* dst, int32_t Cout, int32_t Cin, int32_t accumulate,
                   maf_stream_t stream);
+/* dst[b, 2y, 2x, :] += src[b, y, x, :]: src [B,Ho,Wo,C], dst [B,2Ho,2Wo,C] NHWC with pixel strides in elements — the data gradient of RepVGGBlock's stride-2 1x1
+ * branch (yolov6/layers/common.py:203, 224) added onto the 3x3 branch's data gradient in place. */
+int maf_add_sub2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, maf_stream_t stream);
+/* out[c] += sum over the M pixels of x[m * x_stride + c] (fp32 atomics; the caller zeroes or accumulates): the bias gradient of the head's prediction convs
+ * (nn.Conv2d with bias, yolov6/layers/common.py:1304-1305).  C <= 256. */
+int maf_colsum(const void* x, int32_t x_stride, int64_t M, int32_t C, int32_t dtype, float* out, maf_stream_t stream);
 
 /* Zero `bytes` bytes at p on `stream` (hipMemsetAsync): the fp32 accumulation buffers of maf_conv_wgrad / maf_dw_wgrad when those run on a stream
  * of their own. */

@@ -271,6 +271,44 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     return maf_check_hip(hipGetLastError(), "dw_wgrad launch");
 }
 
+// dst[b, 2y, 2x, :] += src[b, y, x, :] (NHWC, 16-byte channel chunks): the data gradient of a stride-2 1x1 conv (RepVGGBlock.rbr_1x1, common.py:203) added onto the
+// 3x3 branch's data gradient of the same input — instead of a zero-filled full-size tensor, a strided copy and a full-size add.
+template <typename T, typename V, int N>
+__global__ __launch_bounds__(256) void add_sub2_kernel(const T* __restrict__ src, int src_stride, T* __restrict__ dst, int dst_stride, int Ho, int Wo, int CG, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % CG);
+    long long p = i / CG;
+    const int x = (int)(p % Wo); p /= Wo;
+    const int y = (int)(p % Ho);
+    const long long b = p / Ho;
+    const V a = *reinterpret_cast<const V*>(src + ((b * Ho + y) * Wo + x) * src_stride + cg * N);
+    V* q = reinterpret_cast<V*>(dst + ((b * 2 * Ho + 2 * y) * (2ll * Wo) + 2 * x) * dst_stride + cg * N);
+    V d = *q;
+#pragma unroll
+    for (int j = 0; j < N; ++j) d[j] = (T)((float)d[j] + (float)a[j]);
+    *q = d;
+}
+
+// Per-channel sum over the pixels of an NHWC tensor into fp32 (the bias gradient of a conv with bias: cls_pred / reg_pred, common.py:1304-1305): thread = (channel,
+// pixel slab) with the channel fastest (coalesced for any channel count), slabs of a block reduced in LDS, one atomic per channel and block.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int stride, long long M, int C, float* __restrict__ out) {
+    __shared__ float s_part[256];
+    const int per = 256 / C > 0 ? 256 / C : 1;                       // pixel slabs per block (C <= 256)
+    const int c = threadIdx.x % C, slab = threadIdx.x / C;
+    float acc = 0.f;
+    if (slab < per)
+        for (long long m = (long long)blockIdx.x * per + slab; m < M; m += (long long)gridDim.x * per) acc += (float)x[m * stride + c];
+    s_part[threadIdx.x] = slab < per ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int j = 0; j < per; ++j) t += s_part[j * C + threadIdx.x];
+        atomicAdd(out + threadIdx.x, t);
+    }
+}
+
 // Gradient fold (maf_grad_fold): the weight-gradient kernels leave dW in THEIR layout — tap-major [taps][Cout_p][Cin_p] with the channel
 // counts padded to what the kernels read (8-channel chunks) — and the optimizer wants the parameter's [Cout][Cin][taps]: one small launch adds
 // (or writes) the valid part into the gradient slice, on the stream the weight gradient ran on.
@@ -292,6 +330,31 @@ extern "C" int maf_grad_fold(const float* src, int32_t taps, int32_t Cout_p, int
     hipLaunchKernelGGL(grad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src, taps, Cout_p, Cin_p, dst, Cout, Cin,
                        accumulate, (int)total);
     return maf_check_hip(hipGetLastError(), "grad_fold launch");
+}
+
+extern "C" int maf_add_sub2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, maf_stream_t stream) {
+    MAF_REQUIRE(src && dst && B > 0 && Ho > 0 && Wo > 0 && C > 0, "add_sub2: bad arguments");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "add_sub2: dtype must be f16/f32");
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    MAF_REQUIRE(C % N == 0 && src_stride % N == 0 && dst_stride % N == 0, "add_sub2: C and strides must be multiples of the 16-byte channel group");
+    const long long total = (long long)B * Ho * Wo * (C / N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((add_sub2_kernel<half_t, half8_t, 8>), g, b, 0, s, static_cast<const half_t*>(src), src_stride, static_cast<half_t*>(dst), dst_stride, Ho, Wo, C / N, total);
+    else hipLaunchKernelGGL((add_sub2_kernel<float, f32x4_t, 4>), g, b, 0, s, static_cast<const float*>(src), src_stride, static_cast<float*>(dst), dst_stride, Ho, Wo, C / N, total);
+    return maf_check_hip(hipGetLastError(), "add_sub2 launch");
+}
+
+extern "C" int maf_colsum(const void* x, int32_t x_stride, int64_t M, int32_t C, int32_t dtype, float* out, maf_stream_t stream) {
+    MAF_REQUIRE(x && out && M > 0 && C > 0 && C <= 256 && x_stride >= C, "colsum: bad arguments (C <= 256)");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "colsum: dtype must be f16/f32");
+    const int per = 256 / C > 0 ? 256 / C : 1;
+    long long nb = (M + per * 64 - 1) / (per * 64);                   // >= 64 pixels per thread
+    nb = nb < 1 ? 1 : nb > 1024 ? 1024 : nb;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((colsum_kernel<half_t>), dim3((unsigned)nb), dim3(256), 0, s, static_cast<const half_t*>(x), x_stride, (long long)M, C, out);
+    else hipLaunchKernelGGL((colsum_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, static_cast<const float*>(x), x_stride, (long long)M, C, out);
+    return maf_check_hip(hipGetLastError(), "colsum launch");
 }
 
 extern "C" int maf_pack_w1x1(const float* w, int32_t Cout, int32_t Cin, int32_t transpose, int32_t dtype, int32_t tile_c,

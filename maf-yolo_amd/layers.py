@@ -56,12 +56,18 @@ class Conv(nn.Module):
         self.bn = _bn(cout)
         self.act = nn.SiLU(inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: where the result goes when it is one input of a channel concat — a slot of a train_ops.CatBuffer, or a callable that returns the slot for the
+        conv's output tensor (the buffer is allocated when its first producer knows the spatial size); ignored off the HIP path (the concat then copies)."""
         if self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1):
-            return train_ops.bn_act(train_ops.conv1x1(x, self.conv.weight), self.bn, "silu")   # HIP conv fwd / dgrad / wgrad + fused BN(train)+SiLU
-        if self.conv.kernel_size == (3, 3) and self.conv.stride == (2, 2):
-            return train_ops.bn_act(train_ops.conv3x3s2(x, self.conv.weight), self.bn, "silu")  # ConvWrapper: the same on the 3x3 stride-2 kernels
-        return train_ops.bn_act(self.conv(x), self.bn, "silu")
+            z = train_ops.conv1x1(x, self.conv.weight)                          # HIP conv fwd / dgrad / wgrad + fused BN(train)+SiLU
+        elif self.conv.kernel_size == (3, 3) and self.conv.stride == (2, 2):
+            z = train_ops.conv3x3s2(x, self.conv.weight)                        # ConvWrapper: the same on the 3x3 stride-2 kernels
+        else:
+            z = self.conv(x)
+        if out is not None:
+            out = (out(z) if callable(out) else out) if train_ops.cat_free_ok(z, self.bn) and z.dim() == 4 and z.shape[1] % 8 == 0 else None
+        return train_ops.bn_act(z, self.bn, "silu", out=out)
 
     def fused(self):
         return fold_bn(self.conv.weight, self.bn)
@@ -72,8 +78,8 @@ class ConvWrapper(nn.Module):
         super().__init__()
         self.block = Conv(cin, cout, k, stride)
 
-    def forward(self, x):
-        return self.block(x)
+    def forward(self, x, out=None):
+        return self.block(x, out=out)
 
 
 class RepVGGBlock(nn.Module):
@@ -85,14 +91,15 @@ class RepVGGBlock(nn.Module):
         self.rbr_1x1 = ConvBN(cin, cout, 1, 2, 0)
         self.nonlinearity = nn.ReLU(inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         # both branches (conv + BatchNorm each) on the HIP kernels
         if x.is_cuda and x.shape[1] % 8:
             x = train_ops.pad_channels8(x)                                       # the image: cast + channel padding once for both branches
         # ReLU(BN(3x3) + BN(1x1)): one apply pass over both branch tensors (csrc/bn_sum.hip; backward: one statistics + one apply launch for both BatchNorms,
         # the ReLU's mask recomputed from the branch tensors)
-        return train_ops.bn_sum([train_ops.conv3x3s2(x, self.rbr_dense.conv.weight), train_ops.conv1x1s2(x, self.rbr_1x1.conv.weight)],
-                                [self.rbr_dense.bn, self.rbr_1x1.bn], act="relu")
+        # (the two convs are one autograd node: the 1x1 branch's data gradient is added onto the 3x3 branch's on the even pixels, in place)
+        return train_ops.bn_sum(list(train_ops.repvgg_convs(x, self.rbr_dense.conv.weight, self.rbr_1x1.conv.weight)),
+                                [self.rbr_dense.bn, self.rbr_1x1.bn], act="relu", out=out)
 
     def fused(self):
         """One 3x3 kernel + bias (get_equivalent_kernel_bias, common.py:226-230)."""
@@ -169,8 +176,8 @@ class DepthBottleneckUni(nn.Module):
         self.act = nn.SiLU(inplace=True)
         self.one_conv = Conv(mid, c, 1)
 
-    def forward(self, x):
-        return self.one_conv(self.conv2(self.conv1(x), act="silu"))
+    def forward(self, x, out=None):
+        return self.one_conv(self.conv2(self.conv1(x), act="silu"), out=out)
 
 
 class RepHDW(nn.Module):
@@ -183,12 +190,26 @@ class RepHDW(nn.Module):
         self.m = nn.ModuleList(DepthBottleneckUni(self.c_, k, depth_expansion) for _ in range(depth))
         self.conv2 = Conv(self.c_ * (depth + 2), cout, 1)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        c = self.c_
+        if train_ops.cat_free_ok(x, self.conv1.bn) and c % 8 == 0:
+            # no cat, no split: conv1's and every block's last BatchNorm apply pass store into their slots of one buffer (train_ops.CatBuffer)
+            z = train_ops.conv1x1(x, self.conv1.conv.weight)
+            cb = train_ops.CatBuffer(z, [c] * (len(self.m) + 2))
+            t = train_ops.bn_act(z, self.conv1.bn, "silu", out=cb.slot(0, 2))
+            part, cur = train_ops.fork(t, c)                                     # both halves go to conv2, the second one also into the first block
+            parts = [part]
+            for i, blk in enumerate(self.m):
+                y = blk(cur, out=cb.slot(2 + i))
+                if i + 1 < len(self.m):
+                    y, cur = train_ops.fork(y)
+                parts.append(y)
+            return self.conv2(train_ops.join(cb, parts), out=out)
         t = self.conv1(x)
-        outs = list(t.split((self.c_, self.c_), 1))                              # split, not slices: its backward is ONE cat of the two gradients
+        outs = list(t.split((c, c), 1))                                          # split, not slices: its backward is ONE cat of the two gradients
         for blk in self.m:
             outs.append(blk(outs[-1]))
-        return self.conv2(torch.cat(outs, 1))
+        return self.conv2(torch.cat(outs, 1), out=out)
 
 
 class MP(nn.Module):
@@ -210,6 +231,19 @@ class MPRep(nn.Module):
         self.conv2 = RepVGGBlock(cin, cout // 2)
 
     def forward(self, x):
+        if train_ops.cat_free_ok(x, self.conv1.bn) and self.conv1.conv.out_channels % 8 == 0:
+            c = self.conv1.conv.out_channels                                     # both halves store into their slots of one buffer (train_ops.CatBuffer): no cat
+            holder = []
+
+            def slot0(z):
+                holder.append(train_ops.CatBuffer(z, [c, c]))
+                return holder[0].slot(0)
+
+            a = self.conv1(self.mp(x), out=slot0)
+            if holder:
+                b = self.conv2(x, out=holder[0].slot(1))
+                return train_ops.join(holder[0], [a, b])
+            return torch.cat([a, self.conv2(x)], 1)
         return torch.cat([self.conv1(self.mp(x)), self.conv2(x)], 1)
 
 
@@ -223,12 +257,12 @@ class SPPF(nn.Module):
         self.cv2 = Conv(c_ * 4, cout, 1)
         self.m = nn.MaxPool2d(k, 1, k // 2)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = self.cv1(x)
         k = self.m.kernel_size
         y1 = train_ops.maxpool_s1(x, k)                                          # csrc/pool_train.hip on CUDA tensors (gather backward), else F.max_pool2d
         y2 = train_ops.maxpool_s1(y1, k)
-        return self.cv2(torch.cat((x, y1, y2, train_ops.maxpool_s1(y2, k)), 1))
+        return self.cv2(torch.cat((x, y1, y2, train_ops.maxpool_s1(y2, k)), 1), out=out)
 
 
 class Concat(nn.Module):

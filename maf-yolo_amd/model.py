@@ -202,12 +202,41 @@ class Model(nn.Module):
         if getattr(self, "_pack_plan", None) is None:
             self._pack_plan = train_ops.PackPlan()
         train_ops.begin_step(self._pack_plan, x.device)          # every weight transform of the step in one launch (train_ops.PackPlan)
+        # Concat nodes without a copy (train_ops.CatBuffer): an input whose producer can store anywhere (the last BatchNorm apply pass of a ConvWrapper /
+        # RepHDW / SPPF) goes straight into its slot of the concat's buffer — of the FIRST concat that lists it; every other input (up-sampled maps, a
+        # map a second concat lists) is copied into its slot by `join`.
+        res = getattr(self, "_cat_residents", None)
+        if res is None:
+            res = self._cat_residents = {}
+            for nd, m in zip(self.nodes, self.backbone):
+                if isinstance(m, Concat) and m.d == 1:
+                    srcs = nd.sources()
+                    widths = [self.nodes[s].cout for s in srcs]
+                    for slot, s in enumerate(srcs):
+                        if s not in res and isinstance(self.backbone[s], (ConvWrapper, RepHDW, SPPF)) and srcs.count(s) == 1:
+                            res[s] = (nd.i, slot, widths)
+        bufs = {}
+
+        def slot_of(j, slot, widths):
+            def f(z):
+                cb = bufs.get(j)
+                if cb is None:
+                    cb = bufs[j] = train_ops.CatBuffer(z, widths)
+                return cb.slot(slot)
+            return f
+
         y = []
         for nd, m in zip(self.nodes, self.backbone):
             if nd.i > 0:
                 src = [y[j] for j in nd.sources()]
                 x = src if isinstance(nd.f, list) else src[0]
-            x = m(x)
+            r = res.get(nd.i) if train_ops.cat_free else None
+            if r is not None:
+                x = m(x, out=slot_of(*r))
+            elif nd.i in bufs:
+                x = train_ops.join(bufs.pop(nd.i), x)
+            else:
+                x = m(x)
             y.append(x)
         return x                              # list of three (stem, cls, reg)
 

@@ -406,6 +406,9 @@ def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev, param=None):
     return _staged(param, ("d", cout, cin, 1, transpose, dt, ct), n, fields, now)
 
 
+_bias_pad = {}
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -434,12 +437,18 @@ class _Conv1x1(torch.autograd.Function):
         if bias is None:
             bp = _zero_bias(x.device, npad)
         else:
-            bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
-            bp[:cout] = bias.detach().float()
+            # one buffer per (stream, bias length, padded length), zero behind the bias: the copy and the conv that reads it are ordered on the stream, so
+            # equal-shaped layers share it (a fresh zeros + slice assignment were two launches per call)
+            key = (x.device.index, _stream(x.device), cout, npad)
+            bp = _bias_pad.get(key)
+            if bp is None:
+                bp = _bias_pad[key] = torch.zeros(npad, dtype=torch.float32, device=x.device)
+            bp[:cout].copy_(bias.detach())
         out = torch.empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt, pt, tk)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None   # (an input of this node, not a saved tensor: backward adds its gradient straight into a gradient exchange)
         stats["native_conv1x1"] += 1
         return out if co == cout else out[:, :cout]
 
@@ -454,22 +463,34 @@ class _Conv1x1(torch.autograd.Function):
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
         dx = dw = db = None
+        mult = 8 if x.dtype == torch.float16 else 4
+        dyk, dyks, kk = dy, dys, cout
+        if cout % mult and (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and x.dtype == torch.float16)):
+            kk = -(-cout // mult) * mult                                         # e.g. reg_pred: 68 channels in fp16 — dY zero-padded to whole 16-byte chunks ONCE, for
+            dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)     # the weight gradient and the data gradient's reduction dim
+            dyks = kk
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ex, view = _grad_sink(ctx.bias_param) if ctx.bias_param is not None and x.dtype == torch.float16 else (None, None)
+            if ex is not None and view.is_contiguous() and cout <= 256:
+                # the bias gradient as a column sum on the weight-gradient stream, added into the bias' slice of the gradient exchange (csrc/train_ops.hip
+                # maf_colsum) — a framework reduction + an accumulation add on the main stream otherwise
+                h = _fork(x.device, dy)
+                lib.check(lib.load().maf_colsum(dy.data_ptr(), dys, B * H * W, cout, dt, view.data_ptr(), h))
+                ex.side_done(ctx.bias_param)
+                stats["native_bias_grad"] = stats.get("native_bias_grad", 0) + 1
+            else:
+                db = dy.sum((0, 2, 3), dtype=torch.float32)
         if ctx.needs_input_grad[1]:
             if x.dtype == torch.float16:                                        # csrc/wgrad.hip: pixel chunks, LDS transpose, MFMA, fp32 atomics
-                dw = _wgrad(x, dy, dys, w, 1, 1)                                 # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels); None: went into the exchange
+                dw = _wgrad(x, dyk, dyks, w, 1, 1)                               # any Cin (channel chunks of 256), any Cout (dY padded to 8 channels); None: went into the exchange
             else:                                                                # fp32 parity mode: the framework's TN GEMM
                 x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)                      # NHWC rows (a view when x is dense)
                 d2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)
                 dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
-            mult = 8 if x.dtype == torch.float16 else 4
-            dyk, dyks, kk = dy, dys, cout
             w2d = None
-            if cout % mult:                                                      # e.g. reg_pred: 68 channels in fp16
-                kk = -(-cout // mult) * mult                                     # zero-pad the reduction dim to whole 16-byte chunks
-                dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
-                dyks = kk
+            if kk != cout:
                 w2d = F.pad(w.detach().reshape(cout, cin).float(), (0, 0, 0, kk - cout))
             M = B * H * W
             choice = _conv_tune.get((M, kk, cin, dyks)) if conv_autotune and dt == lib.F16 else None
@@ -486,8 +507,6 @@ class _Conv1x1(torch.autograd.Function):
             npad = -(-cin // (16 * ct)) * 16 * ct
             dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt, pt, tk)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3), dtype=torch.float32)
         _side_done(x.device, dw is not None)
         return dx, dw, db
 
@@ -497,12 +516,12 @@ def _wgrad(x, dy, dys, w, ksize, stride):
     input channels: the stem's image padded to 8).  Launched on the side stream (`_fork`): call it BEFORE the data gradient of the layer is
     launched.  With a gradient exchange the result is accumulated into w's slice of its bucket on that stream and None is returned."""
     B, cin, Hs, Ws = x.shape
-    cout, Ho, Wo = dy.shape[1:]
-    cin_w = w.shape[1]
+    cdy, Ho, Wo = dy.shape[1:]
+    cout, cin_w = w.shape[0], w.shape[1]
     xx, xs = nhwc(x)
-    co = -(-cout // 8) * 8
-    if co != cout:                                                              # e.g. reg_pred: 68 channels, an odd class count
-        dy = F.pad(dy, (0, 0, 0, 0, 0, co - cout)).contiguous(memory_format=torch.channels_last)
+    co = -(-cdy // 8) * 8
+    if co != cdy:                                                               # e.g. reg_pred: 68 channels, an odd class count (the 1x1 backward hands dY in padded already)
+        dy = F.pad(dy, (0, 0, 0, 0, 0, co - cdy)).contiguous(memory_format=torch.channels_last)
         dys = co
     ex, view = _grad_sink(w)
     direct = ex is not None and ksize == 1 and co == cout and cin == cin_w      # the kernel's [Cout][Cin] IS the parameter's layout: accumulate in place
@@ -677,10 +696,59 @@ class _Conv1x1s2(torch.autograd.Function):
             wp = _packed_1x1(w.detach().reshape(cout, cin_w).float().contiguous(), cout, cin_w, 1, dt, ct, x.device, w)
             dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
-            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
-            dx[:, :, ::2, ::2] = dxs
+            if getattr(ctx, "compact", False):                                   # _RepVGGConvs adds it onto the 3x3 branch's data gradient itself
+                dx = dxs
+            else:
+                dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+                dx[:, :, ::2, ::2] = dxs
         _side_done(x.device, dw is not None)
         return dx, dw
+
+
+class _Ctx:
+    """What a Function's forward / backward use of their ctx, for calling them from another Function."""
+    needs_input_grad = (True, True)
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+
+class _RepVGGConvs(torch.autograd.Function):
+    """(conv3x3 s2 (x, w3), conv1x1 s2 (x, w1)) — the two branches of a RepVGGBlock (yolov6/layers/common.py:199-203) as ONE autograd node, so that their
+    data gradients meet inside it: the 1x1 branch's gradient lives on the even pixels only and is added onto the 3x3 branch's in place (maf_add_sub2, a quarter
+    of the pixels) instead of a zero-filled full-size tensor + a strided copy + autograd's full-size add."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1):
+        c3, c1 = _Ctx(), _Ctx()
+        z3 = _Conv3x3s2.forward(c3, x, w3)
+        z1 = _Conv1x1s2.forward(c1, x, w1)
+        ctx.save_for_backward(c3.saved_tensors[0], w3, w1)
+        return z3, z1
+
+    @staticmethod
+    def backward(ctx, dz3, dz1):
+        x, w3, w1 = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        c3, c1 = _Ctx(), _Ctx()
+        c3.saved_tensors, c3.needs_input_grad = (x, w3), (need_x, ctx.needs_input_grad[1])
+        c1.saved_tensors, c1.needs_input_grad, c1.compact = (x, w1), (need_x, ctx.needs_input_grad[2]), True
+        dx, dw3 = _Conv3x3s2.backward(c3, dz3)
+        dxs, dw1 = _Conv1x1s2.backward(c1, dz1)
+        if need_x:
+            B, c, Ho, Wo = dxs.shape
+            lib.check(lib.load().maf_add_sub2(dxs.data_ptr(), dxs.stride()[3], dx.data_ptr(), dx.stride()[3], B, Ho, Wo, c, _DT[dx.dtype], _stream(dx.device)))
+        return dx, dw3, dw1
+
+
+def repvgg_convs(x, w3, w1):
+    """(conv3x3s2(x, w3), conv1x1s2(x, w1)) of one input."""
+    if not x.is_cuda or framework_ops or x.shape[2] % 2 or x.shape[3] % 2:
+        return conv3x3s2(x, w3), conv1x1s2(x, w1)
+    x = _autocast(x)
+    if not (x.dtype in _DT and x.dim() == 4 and tuple(w3.shape[2:]) == (3, 3) and tuple(w1.shape[2:]) == (1, 1)):
+        raise lib.MafError("repvgg_convs: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
+    return _RepVGGConvs.apply(_pad8(x, w3), w3, w1)
 
 
 def pad_channels8(x):
@@ -972,12 +1040,13 @@ class _BNAct(torch.autograd.Function):
     """act(BatchNorm2d(x) [+ residual]) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None, residual=None, pre_stats=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, counter=None, residual=None, pre_stats=None, out=None):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
         dev = x.device
-        y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        # out: the caller's slot of a concat buffer (an NHWC channel slice, cat_buffer below): the apply pass stores there and the cat never runs
+        y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) if out is None else out[0]      # (a tuple: not an input of the autograd node)
         stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
         sp = stat.data_ptr()                                                      # (pointer arithmetic: indexing a tensor costs ~2 us of host time, 4 per call)
         part, phase = _bn_part(dev, c) if pre_stats is None else pre_stats       # pre_stats: (scratch, phase) whose half the producer of x has filled
@@ -1046,12 +1115,13 @@ class _BNAct(torch.autograd.Function):
         if direct:
             ex.main_done(ctx.affine[0])
             ex.main_done(ctx.affine[1])
-            return dx, None, None, None, None, None, None, None, None, dres, None
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres, None
+            return dx, None, None, None, None, None, None, None, None, dres, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, dres, None, None
 
 
-def bn_act(x, bn, act=None, residual=None, pre_stats=None):
-    """act(bn(x) [+ residual]) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  `pre_stats`: what dw_branches returned for this branch (its
+def bn_act(x, bn, act=None, residual=None, pre_stats=None, out=None):
+    """act(bn(x) [+ residual]) for an nn.BatchNorm2d `bn` and act in {None, 'relu', 'silu'}.  `out`: a slot of a concat buffer (`CatBuffer.slot`; HIP path only)
+    the result is stored into — and returned as.  `pre_stats`: what dw_branches returned for this branch (its
     kernel has accumulated the batch statistics already: apply pass only), else None.  Training mode on CUDA tensors runs the fused HIP
     kernels (one statistics pass + one normalise/affine/[add]/activation pass; backward likewise); eval mode and CPU tensors run torch ops.
     `residual` (same shape as x; act None or 'relu'): the branch sums of RepVGGBlock / DilatedReparamBlock without a pass of their own."""
@@ -1060,6 +1130,8 @@ def bn_act(x, bn, act=None, residual=None, pre_stats=None):
         # CPU tensors (CI / gloo tests) and eval-mode BatchNorm inside a train-form forward (Model.forward(val_loss=True) never comes here:
         # it runs the deploy engine): torch ops, counted so that an A/B on `stats` cannot mistake them for the HIP path
         stats["torch_bn"] = stats.get("torch_bn", 0) + 1
+        if out is not None:
+            raise lib.MafError("bn_act: out= is a feature of the HIP path (the caller checks `cat_free_ok`)")
         y = bn(x)
         if residual is not None:
             y = y + residual
@@ -1083,7 +1155,94 @@ def bn_act(x, bn, act=None, residual=None, pre_stats=None):
         raise lib.MafError("bn_act: BatchNorm2d(momentum=None) (cumulative average) is not supported on the HIP path")
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual, pre_stats)
+    if out is not None and not (out.shape == x.shape and out.dtype == x.dtype and out.device == x.device and nhwc(out)[0] is out):
+        raise lib.MafError("bn_act: out= must be an NHWC (channel-slice) view of x's shape and dtype")
+    return _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, _ACT[act], counter, residual, pre_stats, None if out is None else (out,))
+
+
+# Concats without a copy.  torch.cat of the train-form graph's RepHDW is three strided copies forward (its inputs are slices: no batched kernel), and
+# backward a zero-fill + copy per slice, an add where a tensor feeds the cat AND the next block, and the split's cat of gradients: ~0.9 ms of the n step.
+# Instead the producers' apply passes store straight into their channel slots of ONE buffer (`bn_act(out=)`), `join` hands that buffer to the consumer
+# as a tensor whose gradient comes back as slot views, and `fork` (a tensor that feeds the cat and a later block) adds the block's gradient INTO the
+# slot of the cat's gradient.  The in-place add is safe for what these two are built for: the gradient buffer is the data gradient the consumer conv has
+# just written, `join.backward` is its only reader, and the slot is not read again before the add (the block's backward, which produced the addend,
+# ran on OTHER slots).
+cat_free = os.environ.get("MAF_CAT_FREE", "1") != "0"
+
+
+def cat_free_ok(x, bn):
+    """The copy-free concat needs the HIP BatchNorm path for the producers."""
+    return cat_free and x.is_cuda and bn.training and not framework_ops and x.dtype in _DT
+
+
+class CatBuffer:
+    """One NHWC tensor for a channel concat whose producers store into their slots.  `like`: a tensor with the concat's batch, spatial size, dtype, device."""
+
+    def __init__(self, like, widths):
+        B, _, H, W = like.shape
+        self.offs = [0]
+        for w in widths:
+            self.offs.append(self.offs[-1] + w)
+        self.buf = torch.empty((B, self.offs[-1], H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+    def slot(self, i, n=1):
+        """Channels of slots i .. i + n - 1 as a tensor of its own on the buffer's storage — NOT a view of `buf` for autograd: a slot becomes the output of its
+        producer's autograd node, and a view whose base is written through another view later (join's copies) is refused there."""
+        b = self.buf
+        t = torch.empty(0, dtype=b.dtype, device=b.device)
+        t.set_(b.untyped_storage(), b.storage_offset() + self.offs[i], (b.shape[0], self.offs[i + n] - self.offs[i], b.shape[2], b.shape[3]), b.stride())
+        return t
+
+
+class _Join(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cb, *parts):
+        ctx.offs = [0]
+        for p_ in parts:
+            ctx.offs.append(ctx.offs[-1] + p_.shape[1])
+        if ctx.offs[-1] != cb.buf.shape[1]:
+            raise lib.MafError("join: the parts' channels must add up to the buffer's")
+        es = cb.buf.element_size()
+        for i, (p_, o) in enumerate(zip(parts, ctx.offs)):
+            if p_.data_ptr() != cb.buf.data_ptr() + o * es or p_.stride() != cb.buf.stride():     # not stored there by its producer (e.g. an up-sampled map): one strided copy
+                cb.slot(i).copy_(p_)
+                stats["cat_copied_parts"] = stats.get("cat_copied_parts", 0) + 1
+        stats["cat_free"] = stats.get("cat_free", 0) + 1
+        return cb.buf
+
+    @staticmethod
+    def backward(ctx, d):
+        return (None,) + tuple(d[:, a:b] for a, b in zip(ctx.offs[:-1], ctx.offs[1:]))
+
+
+def join(cb, parts):
+    """The concat of `parts` along the channels in CatBuffer `cb`: parts their producer stored into their slot (`bn_act(out=cb.slot(i))`) cost nothing, any
+    other part is copied into its slot."""
+    if any(p_.dtype != cb.buf.dtype or p_.shape[0] != cb.buf.shape[0] or p_.shape[2:] != cb.buf.shape[2:] or p_.device != cb.buf.device for p_ in parts):
+        return torch.cat(parts, 1)                                               # (mixed dtypes promote: the framework's rule)
+    return _Join.apply(cb, *parts)
+
+
+class _Fork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, lo):
+        ctx.lo = lo
+        return t.view_as(t), t[:, lo:]
+
+    @staticmethod
+    def backward(ctx, d_all, d_tail):
+        if d_all is None:
+            if d_tail is None:
+                return None, None
+            d_all = torch.zeros((d_tail.shape[0], ctx.lo + d_tail.shape[1]) + tuple(d_tail.shape[2:]), dtype=d_tail.dtype, device=d_tail.device).contiguous(memory_format=torch.channels_last)
+        if d_tail is not None:
+            d_all[:, ctx.lo:].add_(d_tail)
+        return d_all, None
+
+
+def fork(t, lo=0):
+    """(t, t[:, lo:]) for a tensor that goes into a `join` AND (its channels lo..) into a later block: the block's gradient is added into the join's."""
+    return _Fork.apply(t, lo)
 
 
 _bnsum_scratch = {}
@@ -1115,13 +1274,13 @@ class _BNSum(torch.autograd.Function):
         B, c, H, W = x0.shape
         dt = _DT[x0.dtype]
         dev = x0.device
-        eps, momentum, per, act = cfg
+        eps, momentum, per, act, dst = cfg
         L = lib.load()
         M_ = B * H * W
         for (z, zst), (rm, rv, cnt, part, phase, need) in zip(zs, per):
             if need:                                                             # this branch's producer has no statistics epilogue (the 1 x 1 scale branch)
                 lib.check(L.maf_bn_stats(z.data_ptr(), zst, M_, c, dt, part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
-        out = torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last)
+        out = torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) if dst is None else dst      # dst: a concat buffer's slot (bn_act's out=)
         stat = torch.empty(nb, 2, c, dtype=torch.float32, device=dev)            # save_mean, save_rstd per branch
         sp = stat.data_ptr()
         g32 = [g.detach() if g.dtype == torch.float32 and g.is_contiguous() else g.detach().float().contiguous() for g in gammas]
@@ -1181,7 +1340,7 @@ class _BNSum(torch.autograd.Function):
 bn_sum_merged = os.environ.get("MAF_BN_SUM", "1") != "0"               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
 
 
-def bn_sum(zs, bns, pre_stats=None, act=None):
+def bn_sum(zs, bns, pre_stats=None, act=None, out=None):
     """act(sum_j bns[j](zs[j])): the branches of a train-form DilatedReparamBlock (act None) or of a RepVGGBlock (act "relu", common.py:224).  CUDA + training mode: csrc/bn_sum.hip (one apply pass forward,
     statistics + apply for all branches backward); otherwise — and for anything the kernel does not take — the chain of bn_act calls with `residual`.
     `pre_stats[j]`: what dw_branches returned for branch j (its statistics are already accumulated) or None."""
@@ -1196,15 +1355,17 @@ def bn_sum(zs, bns, pre_stats=None, act=None):
     if act not in (None, "none", "relu"):
         raise lib.MafError("bn_sum: act must be None or 'relu'")
     if not ok:
-        out = bn_act(zs[0], bns[0], pre_stats=pre[0])
+        y = bn_act(zs[0], bns[0], pre_stats=pre[0])
         for j in range(1, nb):
-            out = bn_act(zs[j], bns[j], act if j == nb - 1 else None, residual=out, pre_stats=pre[j])
-        return out
+            y = bn_act(zs[j], bns[j], act if j == nb - 1 else None, residual=y, pre_stats=pre[j], out=out if j == nb - 1 else None)
+        return y
+    if out is not None and not (out.shape == x.shape and out.dtype == x.dtype and out.device == x.device and nhwc(out)[0] is out):
+        raise lib.MafError("bn_sum: out= must be an NHWC (channel-slice) view of the branches' shape and dtype")
     per = []
     for bn, st in zip(bns, pre):
         part, phase = st if st is not None else bn_own_scratch(bn, x.device, x.shape[1])
         per.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, part, phase, st is None))
-    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act]), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act], out), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
 class _MaxPool(torch.autograd.Function):

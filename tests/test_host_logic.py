@@ -580,3 +580,39 @@ def test_model_ema_follows_buffers_replaced_by_apply():
     sig = ema._sig
     ema.update(model)
     assert ema._sig == sig and sig[0] == "gen"                         # steady state: the cheap signature, unchanged
+
+
+def test_cat_buffer_join_and_fork_are_cat_and_split_for_autograd():
+    """train_ops.CatBuffer / join / fork (the copy-free concats of the train-form graph): with parts that no producer stored into their slots `join` copies them in —
+    it IS torch.cat, forward and backward; a part that already sits in its slot is not copied; `fork` returns (t, t[:, lo:]) and adds the tail's gradient into
+    the gradient of t (what autograd's sum of the two consumers gives)."""
+    import importlib
+    to = importlib.import_module("maf-yolo_amd.train_ops")
+    torch.manual_seed(0)
+    a = torch.randn(2, 8, 3, 5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(2, 16, 3, 5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(2, 24, 3, 5)
+    cb = to.CatBuffer(a, [8, 16])
+    n0 = to.stats.get("cat_copied_parts", 0)
+    a2, tail = to.fork(a * 2.0, 4)
+    y = to.join(cb, [a2, b])
+    assert to.stats.get("cat_copied_parts", 0) - n0 == 2
+    ((y * w).sum() + (tail * 3.0).sum()).backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    t = a * 2.0
+    y2 = torch.cat([t, b], 1)
+    ((y2 * w).sum() + (t[:, 4:] * 3.0).sum()).backward()
+    assert torch.equal(y.detach(), y2.detach())
+    assert torch.allclose(ga, a.grad) and torch.allclose(gb, b.grad)
+    # a resident part: written into its slot beforehand, handed to join as the slot tensor itself
+    cb2 = to.CatBuffer(a, [8, 16])
+    s0 = cb2.slot(0)
+    s0.copy_(a.detach())
+    assert not s0._is_view() and s0.data_ptr() == cb2.buf.data_ptr()
+    n0 = to.stats.get("cat_copied_parts", 0)
+    y3 = to.join(cb2, [s0, b])
+    assert to.stats.get("cat_copied_parts", 0) - n0 == 1
+    assert torch.equal(y3.detach(), torch.cat([a, b], 1).detach())
+    # mixed dtypes: the framework's promotion rule, through torch.cat
+    assert to.join(to.CatBuffer(a, [8, 16]), [a.detach(), b.detach().double()]).dtype == torch.float64
