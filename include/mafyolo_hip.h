@@ -408,6 +408,10 @@ int maf_maxpool_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, i
                         int32_t dtype, void* y, int32_t y_stride, uint8_t* idx, maf_stream_t stream);
 int maf_maxpool_backward(const void* dy, int32_t dy_stride, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                          int32_t stride, int32_t pad, int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream);
+/* nn.Upsample(scale_factor=2, mode="nearest") of the training graph (the neck's two up-sampling nodes, configs/yaml/MAF-YOLO-n.yaml) on NHWC views with pixel strides
+ * in elements — source and destination may be channel slices (slots of a concat buffer): y [B,2H,2W,C] from x [B,H,W,C]; backward dx = the sum of the four. */
+int maf_upsample2x_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* y, int32_t y_stride, maf_stream_t stream);
+int maf_upsample2x_backward(const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream);
 
 /* Weight staging of a whole training step in one launch.  A descriptor transforms one fp32 weight tensor:
  *   kind 0  dense conv weight [Cout][Cin][taps] (taps = 1 or 9) -> the MFMA fragment order of maf_pack_w1x1 with tile_c = CT; K runs

@@ -118,7 +118,76 @@ void mp_fill(MpArgs& a, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, i
     a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;          // floor mode, like nn.MaxPool2d's default
 }
 
+// nn.Upsample(scale_factor=2, mode="nearest") of the neck (configs/yaml/MAF-YOLO-*.yaml: two per model) on NHWC views with pixel strides: forward one thread = one
+// 16-byte channel chunk of an INPUT pixel stored to its four output pixels (the source may be a slot of a concat buffer, and so may the result: the framework's
+// kernel first copies a strided source and cannot store into a slice); backward the sum of the four.
+template <typename T, typename V, int N>
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const T* __restrict__ x, int xs, T* __restrict__ y, int ys, int H, int W, int CG, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % CG);
+    long long p = i / CG;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const long long b = p / H;
+    const V v = *reinterpret_cast<const V*>(x + ((b * H + h) * W + w) * xs + cg * N);
+    T* o = y + ((b * 2 * H + 2 * h) * (2ll * W) + 2 * w) * ys + cg * N;
+    *reinterpret_cast<V*>(o) = v;
+    *reinterpret_cast<V*>(o + ys) = v;
+    *reinterpret_cast<V*>(o + 2ll * W * ys) = v;
+    *reinterpret_cast<V*>(o + 2ll * W * ys + ys) = v;
+}
+
+template <typename T, typename V, int N>
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, int dys, T* __restrict__ dx, int dxs, int H, int W, int CG, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % CG);
+    long long p = i / CG;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const long long b = p / H;
+    const T* q = dy + ((b * 2 * H + 2 * h) * (2ll * W) + 2 * w) * dys + cg * N;
+    const V a = *reinterpret_cast<const V*>(q), c = *reinterpret_cast<const V*>(q + dys), d = *reinterpret_cast<const V*>(q + 2ll * W * dys), e = *reinterpret_cast<const V*>(q + 2ll * W * dys + dys);
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (T)(((float)a[j] + (float)c[j]) + ((float)d[j] + (float)e[j]));
+    *reinterpret_cast<V*>(dx + ((b * H + h) * W + w) * dxs + cg * N) = o;
+}
+
+int up2_check(const void* a, const void* b, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t s0, int32_t s1) {
+    MAF_REQUIRE(a && b && B > 0 && H > 0 && W > 0 && C > 0, "upsample2x: bad arguments");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "upsample2x: dtype must be f16/f32");
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    MAF_REQUIRE(C % N == 0 && s0 % N == 0 && s1 % N == 0, "upsample2x: C and pixel strides must be multiples of the 16-byte channel group");
+    return 0;
+}
+
 }  // namespace
+
+// y [B,2H,2W,C] = nearest-neighbour x2 of x [B,H,W,C]
+extern "C" int maf_upsample2x_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* y, int32_t y_stride, maf_stream_t stream) {
+    if (int rc = up2_check(x, y, B, H, W, C, dtype, x_stride, y_stride)) return rc;
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    const long long total = (long long)B * H * W * (C / N);
+    const dim3 g((unsigned)((total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((up2_fwd_kernel<half_t, half8_t, 8>), g, dim3(256), 0, s, static_cast<const half_t*>(x), x_stride, static_cast<half_t*>(y), y_stride, H, W, C / N, total);
+    else hipLaunchKernelGGL((up2_fwd_kernel<float, f32x4_t, 4>), g, dim3(256), 0, s, static_cast<const float*>(x), x_stride, static_cast<float*>(y), y_stride, H, W, C / N, total);
+    return maf_check_hip(hipGetLastError(), "upsample2x forward launch");
+}
+
+// dx [B,H,W,C] = sum of the four dy [B,2H,2W,C] pixels of every input pixel
+extern "C" int maf_upsample2x_backward(const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* dx, int32_t dx_stride, maf_stream_t stream) {
+    if (int rc = up2_check(dy, dx, B, H, W, C, dtype, dy_stride, dx_stride)) return rc;
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    const long long total = (long long)B * H * W * (C / N);
+    const dim3 g((unsigned)((total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((up2_bwd_kernel<half_t, half8_t, 8>), g, dim3(256), 0, s, static_cast<const half_t*>(dy), dy_stride, static_cast<half_t*>(dx), dx_stride, H, W, C / N, total);
+    else hipLaunchKernelGGL((up2_bwd_kernel<float, f32x4_t, 4>), g, dim3(256), 0, s, static_cast<const float*>(dy), dy_stride, static_cast<float*>(dx), dx_stride, H, W, C / N, total);
+    return maf_check_hip(hipGetLastError(), "upsample2x backward launch");
+}
 
 // y [B,Ho,Wo,C] = maxpool(x [B,H,W,C]), Ho = floor((H + 2 pad - k) / stride) + 1; idx [B,Ho,Wo,C] uint8 = window element (row * k + column) chosen
 extern "C" int maf_maxpool_forward(const void* x, int32_t x_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,

@@ -27,7 +27,9 @@ class Upsample(nn.Upsample):
     torch.cat is promoted to fp32 and the conv behind it casts the whole concat back to fp16 (32 x 288 x 80 x 80: 155 us, forward and
     backward, four times per step): nearest-neighbour copies values, so staying in fp16 is bit-identical to that round trip."""
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        if self.scale_factor == 2 and self.mode == "nearest" and x.is_cuda:
+            return train_ops.upsample2x(x, out=out)                 # csrc/pool_train.hip: strided source, result straight into a concat buffer's slot
         with torch.autocast(device_type=x.device.type, enabled=False):
             return super().forward(x)
 
@@ -203,8 +205,8 @@ class Model(nn.Module):
             self._pack_plan = train_ops.PackPlan()
         train_ops.begin_step(self._pack_plan, x.device)          # every weight transform of the step in one launch (train_ops.PackPlan)
         # Concat nodes without a copy (train_ops.CatBuffer): an input whose producer can store anywhere (the last BatchNorm apply pass of a ConvWrapper /
-        # RepHDW / SPPF) goes straight into its slot of the concat's buffer — of the FIRST concat that lists it; every other input (up-sampled maps, a
-        # map a second concat lists) is copied into its slot by `join`.
+        # RepHDW / SPPF, the up-sampling kernel) goes straight into its slot of the concat's buffer — of the FIRST concat that lists it; every other input
+        # (a map a second concat lists) is copied into its slot by `join`.
         res = getattr(self, "_cat_residents", None)
         if res is None:
             res = self._cat_residents = {}
@@ -213,7 +215,7 @@ class Model(nn.Module):
                     srcs = nd.sources()
                     widths = [self.nodes[s].cout for s in srcs]
                     for slot, s in enumerate(srcs):
-                        if s not in res and isinstance(self.backbone[s], (ConvWrapper, RepHDW, SPPF)) and srcs.count(s) == 1:
+                        if s not in res and isinstance(self.backbone[s], (ConvWrapper, RepHDW, SPPF, Upsample)) and srcs.count(s) == 1:
                             res[s] = (nd.i, slot, widths)
         bufs = {}
 

@@ -1175,6 +1175,13 @@ def cat_free_ok(x, bn):
     return cat_free and x.is_cuda and bn.training and not framework_ops and x.dtype in _DT
 
 
+class Like:
+    """shape / dtype / device of a tensor that does not exist yet (what CatBuffer needs of its `like`)."""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = tuple(shape), dtype, device
+
+
 class CatBuffer:
     """One NHWC tensor for a channel concat whose producers store into their slots.  `like`: a tensor with the concat's batch, spatial size, dtype, device."""
 
@@ -1394,6 +1401,42 @@ class _MaxPool(torch.autograd.Function):
         dx = torch.empty((B, c, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         lib.check(lib.load().maf_maxpool_backward(dy.data_ptr(), dys, idx.data_ptr(), B, H, W, c, k, stride, pad, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
         return dx, None, None, None
+
+
+class _Up2(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode="nearest") on csrc/pool_train.hip: the source may be a channel slice (a concat buffer's slot), the result may go into one."""
+
+    @staticmethod
+    def forward(ctx, x, out):
+        x, xs = nhwc(x)
+        B, c, H, W = x.shape
+        y = torch.empty((B, c, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if out is None else out[0]
+        lib.check(lib.load().maf_upsample2x_forward(x.data_ptr(), xs, B, H, W, c, _DT[x.dtype], y.data_ptr(), y.stride()[3], _stream(x.device)))
+        stats["native_upsample"] = stats.get("native_upsample", 0) + 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy, dys = nhwc(dy)
+        B, c, H2, W2 = dy.shape
+        dx = torch.empty((B, c, H2 // 2, W2 // 2), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        lib.check(lib.load().maf_upsample2x_backward(dy.data_ptr(), dys, B, H2 // 2, W2 // 2, c, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
+        return dx, None
+
+
+def upsample2x(x, out=None):
+    """Nearest-neighbour x2 (the neck's nn.Upsample nodes); `out`: a concat buffer's slot or a callable that returns it for a [B, C, 2H, 2W] tensor like x.  CUDA
+    fp16 / fp32 tensors with whole 16-byte channel groups run csrc/pool_train.hip, anything else the framework's kernel (out is then ignored: the concat copies)."""
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (x.is_cuda and not framework_ops and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0):
+        return F.interpolate(x, scale_factor=2, mode="nearest")
+    if out is not None:
+        if callable(out):
+            B, c, H, W = x.shape
+            out = out(Like((B, c, 2 * H, 2 * W), x.dtype, x.device)) if cat_free else None
+        if out is not None and not (out.dtype == x.dtype and out.device == x.device and tuple(out.shape) == (x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3]) and nhwc(out)[0] is out):
+            raise lib.MafError("upsample2x: out= must be an NHWC (channel-slice) view of the result's shape and dtype")
+    return _Up2.apply(x, None if out is None else (out,))
 
 
 def maxpool(x, k, stride=1, pad=None):

@@ -1213,3 +1213,40 @@ def test_colsum_and_subsampled_add_kernels(C, stride, M, dtype):
     ref[:, ::2, ::2] += src[..., :c8].float()
     lib.check(L.maf_add_sub2(src.data_ptr(), c8 + n, dst.data_ptr(), c8, 2, 5, 7, c8, lib.F16 if dtype == torch.float16 else lib.F32, st))
     assert torch.equal(dst, ref.to(dtype))
+
+
+@pytest.mark.parametrize("c,hw,dtype", [(128, (20, 20), torch.float16), (64, (7, 5), torch.float16), (12, (6, 6), torch.float32)])
+def test_upsample2x_kernel_with_strided_source_and_concat_slot(c, hw, dtype):
+    """train_ops.upsample2x (nn.Upsample(scale_factor=2, mode="nearest") of the neck, csrc/pool_train.hip) forward and backward against F.interpolate — from a dense
+    tensor, from a channel slice (a concat buffer's slot), and storing into a slot; the model's Upsample module routes to it."""
+    g = torch.Generator().manual_seed(c)
+    wide = torch.randn(2, c + 16, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    for src in (wide[:, :c].contiguous(memory_format=torch.channels_last), wide[:, 8:8 + c]):
+        xa = src.detach().clone(memory_format=torch.preserve_format) if src.is_contiguous(memory_format=torch.channels_last) else src.detach()
+        xa = xa.requires_grad_(True) if xa.is_leaf else xa
+        leaf = src.detach().float().requires_grad_(True)
+        want = F.interpolate(leaf, scale_factor=2, mode="nearest")
+        dy = torch.randn(want.shape, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        want.backward(dy.float())
+        x2 = src.detach().requires_grad_(True) if src.is_contiguous(memory_format=torch.channels_last) else None
+        if x2 is None:                                                 # the slice: gradient through the wide leaf
+            base = wide.detach().clone().requires_grad_(True)
+            y = train_ops.upsample2x(base[:, 8:8 + c])
+            y.backward(dy)
+            got_dx = base.grad[:, 8:8 + c]
+            assert float(base.grad[:, :8].abs().max()) == 0.0
+        else:
+            y = train_ops.upsample2x(x2)
+            y.backward(dy)
+            got_dx = x2.grad
+        assert torch.equal(y.detach().float(), want.detach())
+        tol = 2e-3 if dtype == torch.float16 else 1e-6
+        assert torch.allclose(got_dx.float(), leaf.grad, rtol=tol, atol=tol)
+    cb = train_ops.CatBuffer(train_ops.Like((2, c, 2 * hw[0], 2 * hw[1]), dtype, DEV), [8, c, 8])
+    cb.buf.zero_()
+    y = train_ops.upsample2x(wide[:, :c], out=cb.slot(1))
+    assert y.data_ptr() == cb.slot(1).data_ptr()
+    assert torch.equal(cb.buf[:, 8:8 + c].float(), F.interpolate(wide[:, :c].float(), scale_factor=2, mode="nearest")) and float(cb.buf[:, :8].abs().max()) == 0.0 and float(cb.buf[:, 8 + c:].abs().max()) == 0.0
+    from maf_yolo_amd.model import Upsample
+    n0 = train_ops.stats.get("native_upsample", 0)
+    assert torch.equal(Upsample(None, 2, "nearest")(wide[:, :c]), y) and train_ops.stats["native_upsample"] == n0 + 1
