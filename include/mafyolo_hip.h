@@ -111,6 +111,12 @@ typedef struct {
  *                   32 mid channels: W1 fragments [2][S1][64][8] f16 | b1 [32] f32 | Toeplitz table of the depth-wise filter
  *                   [8][k][parts][16][8] f16 | W2 fragments [CT2][64][8] f16 | bdw [32] f32 (maf-yolo_amd/pack.py:
  *                   pack_bottleneck); bias = b2 fp32 padded to 16*CT2.  fp16 only, Cin = Cout = c <= 64, act = SiLU.
+ *                   nc = C3 > 0 (where maf_bottleneck_tail_supported(k, c, nsrc, C3)): the launch also applies the 1x1 conv + SiLU that closes the
+ *                   surrounding RepHDW block (common.py:944-946: conv2(torch.cat(y, 1)), y = [x1, x2, block outputs]) to its tile before anything is stored —
+ *                   the LAST bottleneck of a block: src[1 .. nsrc-1] = the concat slots in front of this bottleneck's input (c channels each, direct),
+ *                   src[0] = its input, then its own result from registers; aux[0] = record of maf_bottleneck_tail_record_bytes(c, nsrc, C3) bytes
+ *                   (maf-yolo_amd/pack.py:pack_bottleneck_tail); out / out_stride / out_coff = the CLOSING conv's output (C3 channels) — the
+ *                   bottleneck's own output is never written.
  * MAF_OP_CONV1DW    conv1 -> conv2 -> act of DepthBottleneckUni (common.py:905-909) for any width: Cin = c, Cout = 3c, ksize = k;
  *                   w = ceil(3c/32) block records of maf_conv1dw_record_bytes(k, c) bytes (W1 fragments [2][S1][64][8] f16 | b1 [32]
  *                   f32 | Toeplitz table [8][k][parts][16][8] f16 | bdw [32] f32; maf-yolo_amd/pack.py:pack_conv1dw); fp16, act = SiLU.
@@ -170,6 +176,10 @@ int maf_version(void);
 int maf_op_size(void);
 /* Bytes of one 32-mid-channel block record of MAF_OP_BOTTLENECK for kernel size k and c = Cin = Cout channels. */
 int64_t maf_bottleneck_record_bytes(int32_t k, int32_t Cin, int32_t Cout);
+/* MAF_OP_BOTTLENECK with nc = C3 > 0 (the closing 1x1 of the RepHDW block behind it): bytes of aux[0]'s record for c channels per concat slot and nsrc
+ * slots read from memory (0: C3 no multiple of 16 / nsrc outside 2..3), and whether the (k, c, nsrc, C3) instantiation exists. */
+int64_t maf_bottleneck_tail_record_bytes(int32_t c, int32_t nsrc, int32_t C3);
+int maf_bottleneck_tail_supported(int32_t k, int32_t c, int32_t nsrc, int32_t C3);
 int64_t maf_conv1dw_record_bytes(int32_t k, int32_t Cin);
 int64_t maf_head_tail_record_bytes(int32_t C);
 int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3);

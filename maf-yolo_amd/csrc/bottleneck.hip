@@ -23,6 +23,14 @@
 // The 1x1 on the halo is recomputed ((16+k-1)^2/256 times: its K is only c).  The remaining VALU work is the two SiLUs.
 // fp16 storage, fp32 accumulation (same arithmetic as the three separate kernels up to the fp16 rounding of T1/T2, which
 // those kernels apply when they store them; the depth-wise weights are fp16 there too).
+//
+// Fused tail (nc = C3 > 0, template C3T = C3 / 16, NX): the 1x1 conv that closes the surrounding RepHDW block (common.py:944-946:
+// conv2(cat(x1, x2, .., y)) + SiLU) is applied to the tile before anything is stored — the bottleneck's output y is never written and
+// the closing conv never launched.  Phase C then runs TRANSPOSED (operands swapped: accumulator rows = channels, columns = pixel rows), so
+// that after bias + SiLU a lane holds 8-channel runs of ONE pixel: the B fragments of the tail GEMM, no LDS round trip; the other concat
+// sources are read as B fragments straight from global (16-byte loads: the centre of the halo tile phase A has just pulled through L2) and
+// the tail's weight fragments (A operand: rows = output channels, permuted so that the four lane groups of a store instruction cover one
+// contiguous 64-byte run of a pixel) arrive by DMA in the LDS the block loop no longer needs.
 #include "maf_common.h"
 #include <type_traits>
 
@@ -35,6 +43,11 @@ struct BnArgs {
     int B, H, W, Cin, Cout, nMB, x_stride, x_coff, out_stride, out_coff;
     int tilesX, tilesY, nwg;
     int ko;
+    // fused tail: sources of the closing 1x1 in concat order (xs[NX - 1] = this bottleneck's own input), its record (pack.py:pack_bottleneck_tail)
+    const half_t* xs[3];
+    int xs_stride[3], xs_coff[3];
+    const unsigned char* w3;
+    int C3, nx;
     unsigned long long* prof;   // MAF_BN_PROFILE builds only (op->aux[3]): cycles per phase summed over all waves, see tools/bn_profile.py
 };
 
@@ -64,6 +77,7 @@ __device__ __forceinline__ void maf_static_for(F&& f) {
 template <int OFF> __device__ __forceinline__ void bn_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void bn_ds_read_b64(u32x2_t& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int N> __device__ __forceinline__ void bn_wait_lgkm(u32x4_t& a, u32x2_t& b, u32x2_t& c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
+template <int N> __device__ __forceinline__ void bn_wait_lgkm1(u32x4_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N> __device__ __forceinline__ void bn_wait_lgkm2(u32x4_t& a, u32x4_t& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
 // SiLU of a value that arrives pre-multiplied by log2(e) (pack_bottleneck folds the factor into W1 / b1 / bdw and its inverse into W2):
@@ -104,7 +118,7 @@ struct BnCfg {
     static constexpr int ZOFF = REC + (DB ? REC_B : 0);            // offset of the zero table behind the record buffers
 };
 
-template <int K, int S1, int CT2>
+template <int K, int S1, int CT2, int C3T = 0, int NX = 0>
 __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::OCC3 && K <= 5)) ? 3 : 2) void bottleneck_kernel(const BnArgs a) {
     typedef BnCfg<K, S1, CT2> Cf;
     constexpr int P = Cf::P, PARTS = Cf::PARTS, RWC = Cf::RWC, NHP = Cf::NHP, NPT = Cf::NPT, MT = Cf::MT, RWP = Cf::RWP, PS = Cf::PS;
@@ -378,7 +392,10 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
 #pragma unroll
                 for (int s = 0; s < 8; ++s) t2[s] = BN_KO(3) ? (half_t)dacc[s][r] : (half_t)bn_silu2(dacc[s][r]);   // KO 3: no SiLU in phase C
 #pragma unroll
-                for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);   // KO 9: no second 1x1
+                for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) {   // KO 9: no second 1x1
+                    if constexpr (C3T > 0) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ct], t2, acc2[r][ct], 0, 0, 0);   // transposed: rows = channels (4g + rr) CT2 + ct, columns = pixel rows
+                    else acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t2, w2f[ct], acc2[r][ct], 0, 0, 0);
+                }
             }
         }
         BN_STAMP(4);                                        // phase C
@@ -388,6 +405,120 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
         BN_STAMP(5);                                        // barrier after C
     }
 
+    if constexpr (C3T > 0) {
+    // ---- fused tail: out = SiLU(W3 * cat(xs[0..NX-1], y) + b3), y = SiLU(acc2 + b2) from the (transposed) accumulators.
+    // Lane (g, p) of acc2[r][ct], register rr: channel (4g + rr) CT2 + ct of pixel (row p, x = 4q + r) — 4 CT2 consecutive channels from 4g CT2:
+    // k-step j of the tail's y part takes channels 4g CT2 + 8j .. + 7 (pack.py:pack_bottleneck_tail orders W3's rows to match).
+    constexpr int YS = CT2 / 2, NV = 4 * C3T, PSZ = (NV % 8 == 0) ? 8 : 4, NPC = NV / PSZ, NXS = NX * S1, NFR = (NXS + YS) * C3T;
+    static_assert(NFR * 1024 + 64 * C3T <= (int)Cf::LDS, "the tail's record fits the LDS of the block loop");
+    static_assert((NFR - 1) * 1024 < 65536, "ds offset field");
+    __syncthreads();                                               // every wave has finished reading T1 and the block records
+    {
+        constexpr int nvec = (NFR * 1024 + 64 * C3T) >> 4;         // A fragments [step][t3][64 lanes] 16 B | b3 [4 g][C3T][4 rr] f32
+        for (int v0 = wave * 64; v0 < nvec; v0 += 256)
+            if (v0 + lane < nvec)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.w3 + (size_t)(v0 + lane) * 16),
+                                                 (void __attribute__((address_space(3)))*)(smem_raw + v0 * 16), 16, 0, 0);
+    }
+    // B fragments of the other concat sources: lane (g, p) = pixel (row p, x = 4q + r), channels 32 ks + 8g .. + 7 (groups past the source's
+    // c channels read group 0 against zero weight rows); item i = (half h, source s) is loaded while item i - 1 is multiplied
+    const int oy = y0 + p, oyc = min(oy, a.H - 1);
+    const size_t rowpix = ((size_t)b * a.H + oyc) * a.W;
+    int cgk[S1];
+#pragma unroll
+    for (int ks = 0; ks < S1; ++ks) cgk[ks] = 32 * ks + 8 * g < a.Cin ? 32 * ks + 8 * g : 0;
+    half8_t xf[2][2][S1];
+    auto load_item = [&](auto idx) {
+        constexpr int i = decltype(idx)::value;
+        if constexpr (i < 2 * NX) {
+            constexpr int h = i / NX, sx = i % NX;
+#pragma unroll
+            for (int rl = 0; rl < 2; ++rl) {
+                const int oxc = min(x0 + q4 + 2 * h + rl, a.W - 1);
+                const half_t* px = a.xs[sx] + (rowpix + oxc) * a.xs_stride[sx] + a.xs_coff[sx];
+#pragma unroll
+                for (int ks = 0; ks < S1; ++ks) xf[i & 1][rl][ks] = *reinterpret_cast<const half8_t*>(px + cgk[ks]);
+            }
+        }
+    };
+    load_item(std::integral_constant<int, 0>{});
+    // (bias + SiLU of the bottleneck's own output while the record and the first fragments travel)
+    half8_t yf[4][YS];
+    {
+        float b2v[4 * CT2];
+#pragma unroll
+        for (int i = 0; i < 4 * CT2; ++i) b2v[i] = a.b2[g * 4 * CT2 + i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < YS; ++j)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = 8 * j + q, rr = idx / CT2, ct = idx % CT2;
+                    yf[r][j][q] = (half_t)maf_act<MAF_ACT_SILU>(acc2[r][ct][rr] + b2v[idx]);
+                }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                               // the record has landed
+    const uint32_t a_w3 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(smem_raw + lane * 16);
+    const f32x4_t* b3l = reinterpret_cast<const f32x4_t*>(smem_raw + NFR * 1024) + g * C3T;
+    half_t* obase = a.out + a.out_coff + g * PSZ;
+    maf_static_for<2>([&](auto hidx) {
+        constexpr int h = decltype(hidx)::value;
+        f32x4_t acc3[2][C3T];                                      // [pixel x = 4q + 2h + rl][tile t3]: rows 4g + rr = output value rr C3T + t3 of this lane
+#pragma unroll
+        for (int t3 = 0; t3 < C3T; ++t3) { acc3[0][t3] = b3l[t3]; acc3[1][t3] = acc3[0][t3]; }
+        // one group of k-steps (a source, or y): NKS * C3T (k-step, tile) steps in one straight line, the A fragment of step t + RD read before the
+        // two MFMAs of step t (hand-counted waits, as in phase B)
+        auto group = [&](auto base_c, auto nks_c, auto&& getB) {
+            constexpr int FB = decltype(base_c)::value, NKS = decltype(nks_c)::value, NST = NKS * C3T, RD = NST > 4 ? 4 : NST - 1;
+            u32x4_t wr[RD + 1];
+            auto ld = [&](auto idx) {
+                constexpr int t = decltype(idx)::value;
+                if constexpr (t < NST) bn_ds_read_b128<(FB + t) * 1024>(wr[t % (RD + 1)], a_w3);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            maf_static_for<RD>([&](auto idx) { ld(idx); });
+            maf_static_for<NST>([&](auto idx) {
+                constexpr int t = decltype(idx)::value, ks = t / C3T, t3 = t % C3T, sl = t % (RD + 1);
+                ld(std::integral_constant<int, t + RD>{});
+                constexpr int ahead = (NST - 1 - t) < RD ? (NST - 1 - t) : RD;
+                bn_wait_lgkm1<ahead>(wr[sl]);
+                const half8_t wv = __builtin_bit_cast(half8_t, wr[sl]);
+                acc3[0][t3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, getB(0, ks), acc3[0][t3], 0, 0, 0);
+                acc3[1][t3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, getB(1, ks), acc3[1][t3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        maf_static_for<NX>([&](auto sidx) {
+            constexpr int sx = decltype(sidx)::value, i = h * NX + sx;
+            load_item(std::integral_constant<int, i + 1>{});
+            group(std::integral_constant<int, sx * S1 * C3T>{}, std::integral_constant<int, S1>{}, [&](int rl, int ks) { return xf[i & 1][rl][ks]; });
+        });
+        group(std::integral_constant<int, NXS * C3T>{}, std::integral_constant<int, YS>{}, [&](int rl, int j) { return yf[2 * h + rl][j]; });
+        if (!BN_KO(6)) {
+#pragma unroll
+        for (int rl = 0; rl < 2; ++rl) {
+            const int ox = x0 + q4 + 2 * h + rl;
+            if (oy < a.H && ox < a.W) {
+                half_t* op = obase + (((size_t)b * a.H + oy) * a.W + ox) * a.out_stride;
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) {
+                    uint32_t w[PSZ / 2];
+#pragma unroll
+                    for (int e = 0; e < PSZ / 2; ++e) {
+                        const int v0 = pc * PSZ + 2 * e, v1 = v0 + 1;
+                        const half2_t hv = {(half_t)maf_act<MAF_ACT_SILU>(acc3[rl][v0 % C3T][v0 / C3T]), (half_t)maf_act<MAF_ACT_SILU>(acc3[rl][v1 % C3T][v1 / C3T])};
+                        w[e] = __builtin_bit_cast(uint32_t, hv);
+                    }
+                    if constexpr (PSZ == 8) *reinterpret_cast<u32x4_t*>(op + pc * 32) = (u32x4_t){w[0], w[1], w[2 % (PSZ / 2)], w[3 % (PSZ / 2)]};
+                    else *reinterpret_cast<u32x2_t*>(op + pc * 16) = (u32x2_t){w[0], w[1]};
+                }
+            }
+        }
+        }
+    });
+    } else {
     // ---- epilogue: out = SiLU(acc2 + b2); accumulator lane (g, p), register rr: pixel (row 4g + rr, x = 4q + r), channels p*CT2 ..
     // Stored straight from the accumulators a lane would issue 16 stores of CT2 halfs (8 bytes): store-issue bound (10 us of the kernel).
     // Instead every wave stages its 16 x 4 pixels in its own slice of the (now free) T1 area, pixel-major, and writes 16-byte pieces:
@@ -426,6 +557,7 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
             *reinterpret_cast<u32x4_t*>(obase + ((size_t)oy * a.W + ox) * a.out_stride + 8 * part) = *reinterpret_cast<const u32x4_t*>(stg + px * CO + 8 * part);
     }
     }
+    }
 #ifdef MAF_BN_STAMPS
     BN_STAMP(6);                                            // epilogue
     if (a.prof && lane == 0)
@@ -433,24 +565,34 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
 #endif
 }
 
-template <int K, int S1, int CT2>
+template <int K, int S1, int CT2, int C3T = 0, int NX = 0>
 int launch_one(const BnArgs& a, hipStream_t s) {
     constexpr size_t lds = BnCfg<K, S1, CT2>::LDS;
     static_assert(lds <= 160 * 1024, "bottleneck: LDS budget");
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<K, S1, CT2>),
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_kernel<K, S1, CT2, C3T, NX>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(bottleneck)");
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((bottleneck_kernel<K, S1, CT2>), dim3(a.nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((bottleneck_kernel<K, S1, CT2, C3T, NX>), dim3(a.nwg), dim3(256), lds, s, a);
     return maf_check_hip(hipGetLastError(), "bottleneck launch");
 }
 
 template <int K>
 int launch_k(const BnArgs& a, hipStream_t s) {
     const int s1 = (a.Cin + 31) / 32, ct2 = a.Cout <= 32 ? 2 : 4;
+    if (a.w3) {
+        // with the closing 1x1 of the RepHDW block: the shapes of MAF-YOLO-n (one bottleneck per block: NX = 2) and of the first blocks of s / m (NX = 3)
+        const int c3t = a.C3 / 16;
+#define BN_TAIL(KK, SS, CC, TT, NN) if constexpr (K == KK) { if (s1 == SS && ct2 == CC && c3t == TT && a.nx == NN) return launch_one<KK, SS, CC, TT, NN>(a, s); }
+        BN_TAIL(3, 1, 2, 3, 2) BN_TAIL(5, 2, 4, 6, 2) BN_TAIL(5, 2, 4, 8, 2)
+        BN_TAIL(3, 1, 2, 4, 3) BN_TAIL(5, 2, 4, 8, 3) BN_TAIL(3, 2, 4, 6, 3)
+#undef BN_TAIL
+        maf_set_error("bottleneck: no instantiation with the fused closing conv for this (k, c, C3, sources)");
+        return MAF_E_UNSUPPORTED;
+    }
     if (s1 == 1 && ct2 == 2) return launch_one<K, 1, 2>(a, s);          // c <= 32
     if (s1 == 2 && ct2 == 4) return launch_one<K, 2, 4>(a, s);          // 32 < c <= 64
     maf_set_error("bottleneck: unsupported channel count");
@@ -458,6 +600,19 @@ int launch_k(const BnArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int64_t maf_bottleneck_tail_record_bytes(int32_t c, int32_t nsrc, int32_t c3) {
+    const int s1 = (c + 31) / 32, ys = c <= 32 ? 1 : 2, c3t = c3 / 16;
+    if (c3 % 16 || nsrc < 2 || nsrc > 3) return 0;
+    return (int64_t)(nsrc * s1 + ys) * c3t * 1024 + 64 * c3t;      /* A fragments [k-step][tile][64][8] f16 | b3 [4][c3t][4] f32 */
+}
+
+extern "C" int maf_bottleneck_tail_supported(int32_t k, int32_t c, int32_t nsrc, int32_t c3) {
+    const int s1 = (c + 31) / 32, ct2 = c <= 32 ? 2 : 4, t = c3 / 16;
+    if (c3 % 16 || c % 8 || c > 64) return 0;
+    return (k == 3 && s1 == 1 && ct2 == 2 && t == 3 && nsrc == 2) || (k == 5 && s1 == 2 && ct2 == 4 && (t == 6 || t == 8) && nsrc == 2)
+        || (k == 3 && s1 == 1 && ct2 == 2 && t == 4 && nsrc == 3) || (k == 5 && s1 == 2 && ct2 == 4 && t == 8 && nsrc == 3) || (k == 3 && s1 == 2 && ct2 == 4 && t == 6 && nsrc == 3);
+}
 
 extern "C" int64_t maf_bottleneck_record_bytes(int32_t k, int32_t cin, int32_t cout) {
     const int parts = k > 5 ? 2 : 1, s1 = (cin + 31) / 32, ct2 = cout <= 32 ? 2 : 4;
@@ -467,7 +622,8 @@ extern "C" int64_t maf_bottleneck_record_bytes(int32_t k, int32_t cin, int32_t c
 int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "bottleneck: fp16 only (the fp32 parity mode runs the three kernels separately)");
     const maf_src_t& sr = op->src[0];
-    MAF_REQUIRE(op->nsrc == 1 && sr.mode == MAF_SRC_DIRECT && sr.ptr && op->out, "bottleneck: one direct source");
+    const bool tail = op->nc > 0;
+    MAF_REQUIRE((tail ? (op->nsrc == 2 || op->nsrc == 3) : op->nsrc == 1) && sr.mode == MAF_SRC_DIRECT && sr.ptr && op->out, "bottleneck: one direct source (nc > 0: + the other 1 or 2 concat sources of the closing conv)");
     MAF_REQUIRE(op->Cin % 8 == 0 && op->Cin <= 64 && op->Cout % 8 == 0 && op->Cout <= 64, "bottleneck: c <= 64 channels in and out, multiples of 8");
     MAF_REQUIRE(sr.stride % 8 == 0 && sr.coff % 8 == 0 && op->out_stride % 8 == 0 && op->out_coff % 8 == 0, "bottleneck: stride/offset alignment (16-byte pieces)");
     MAF_REQUIRE(op->act == MAF_ACT_SILU, "bottleneck: DepthBottleneckUni applies SiLU after every stage (common.py:918-927)");
@@ -480,6 +636,19 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, 16);
     a.nwg = a.B * a.tilesX * a.tilesY;
     a.prof = nullptr; a.ko = 0;
+    a.w3 = nullptr; a.C3 = 0; a.nx = 0;
+    for (int i = 0; i < 3; ++i) { a.xs[i] = nullptr; a.xs_stride[i] = a.xs_coff[i] = 0; }
+    if (tail) {
+        // nc = C3: conv2(cat(src[1], .., src[nsrc - 1], src[0], y)) + SiLU of the surrounding RepHDW (common.py:944-946) applied before the store: out / out_stride /
+        // out_coff describe ITS output (C3 channels), the bottleneck's own output is never written; aux[0] = record of maf_bottleneck_tail_record_bytes()
+        MAF_REQUIRE(op->aux[0] && op->nc % 16 == 0, "bottleneck: nc > 0 needs aux[0] = the closing conv's record and nc a multiple of 16");
+        a.nx = op->nsrc; a.C3 = op->nc; a.w3 = static_cast<const unsigned char*>(op->aux[0]);
+        for (int i = 0; i < op->nsrc; ++i) {
+            const maf_src_t& q = op->src[i == op->nsrc - 1 ? 0 : i + 1];          // concat order: the other sources first, this bottleneck's input last
+            MAF_REQUIRE(q.ptr && q.mode == MAF_SRC_DIRECT && q.C == op->Cin && q.stride % 8 == 0 && q.coff % 8 == 0, "bottleneck: concat sources of the closing conv are direct, Cin channels each, 16-byte aligned");
+            a.xs[i] = static_cast<const half_t*>(q.ptr); a.xs_stride[i] = q.stride; a.xs_coff[i] = q.coff;
+        }
+    }
 #ifdef MAF_BN_PROFILE
     a.prof = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(op->aux[3]));
     a.ko = (int)(intptr_t)op->aux[2];

@@ -25,7 +25,8 @@ def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
     (c <= 64), conv1+depth-wise fused followed by the plain 1x1 — and return {bottleneck name: mode}.  Decisions are cached by layer
     signature next to the tile choices."""
     import numpy as np
-    plan1 = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True)           # full fusion where it exists, partial elsewhere
+    # (the three ways are compared WITHOUT the block's closing conv inside the fused launch — fuse_tail — which the final plan adds wherever mode 1 wins)
+    plan1 = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True, fuse_tail=False)           # full fusion where it exists, partial elsewhere
     names, sigs = [], {}
     for i, o in enumerate(plan1.ops):
         nm = plan1.op_names[i]
@@ -41,9 +42,9 @@ def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
             plan.run_timed(x, pred)
             t = np.min([plan.run_timed(x, pred) for _ in range(reps)], 0)
             return dict(zip(plan.op_names, t))
-        t0 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=False))
+        t0 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=False, fuse_tail=False))
         t1 = timed(plan1)
-        t2 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=2))
+        t2 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=2, fuse_tail=False))
         for n in names:
             cost = {0: t0[n + ".conv1"] + t0[n + ".conv2"] + t0[n + ".one_conv"], 2: t2[n + ".conv1dw"] + t2[n + ".one_conv"]}
             if n in t1:
@@ -152,7 +153,7 @@ def sw_plane_slots(th, tw, k):
 
 
 class Plan:
-    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None, fuse_head=None):
+    def __init__(self, model, B, Hin, Win, dtype, in_dtype, device, fuse=None, fuse_head=None, fuse_tail=None):
         assert Hin % 32 == 0 and Win % 32 == 0, "image sides must be multiples of 32 (stride of P5)"
         self.B, self.Hin, self.Win, self.dtype, self.in_dtype, self.device = B, Hin, Win, dtype, in_dtype, device
         self.es = _ESIZE[dtype]
@@ -183,6 +184,10 @@ class Plan:
         # launch list for every batch size, so that an image's rows do not depend on how many images ran beside it — the fused kernel sums in another order)
         fm = getattr(model, "fuse_mprep", "auto")
         self.fuse_mprep = (bool(getattr(model, "autotune", False)) if fm == "auto" else bool(fm)) and os.environ.get("MAF_FUSE_MPREP", "1") != "0"
+        # the conv that closes a RepHDW block inside the launch of its last (fully fused) bottleneck where that instantiation exists (csrc/bottleneck.hip, op.nc):
+        # True / False; "auto" = wherever the block's last bottleneck runs in mode 1
+        ft = getattr(model, "fuse_tail", "auto") if fuse_tail is None else fuse_tail
+        self.fuse_tail = (True if ft == "auto" else bool(ft)) and os.environ.get("MAF_FUSE_TAIL", "1") != "0" and dtype == lib.F16
         self.split_cat = bool(getattr(model, "split_cat", os.environ.get("MAF_SPLIT_CAT", "1") != "0"))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
@@ -327,11 +332,17 @@ class Plan:
                 # buffer for a third of its bytes (bottleneck<3,1,2> on 160 x 160 x 72: 121 MB fetched for 39 MB, +13 MB of partial-line writes)
                 split = (node.i == 2 and self._stem3 is not None and self.split_cat and depth + 2 <= 4 and c_ % 8 == 0
                          and (c_ * self.es) % 128 != 0 and m.conv1.fused()[0].shape[0] == 2 * c_)
+                # the block's closing conv2(cat(..)) inside the launch of its LAST bottleneck: that bottleneck's output slot is then never written (nor allocated)
+                kl = m.m[-1].conv2.dwconv.kernel_size
+                tail = (self.fuse_tail and self._fuse_mode("%s.m.%d" % (p, depth - 1), kl, c_) == 1 and 2 <= depth + 1 <= 3
+                        and m.conv2.fused()[0].shape[1] == (depth + 2) * c_
+                        and lib.load().maf_bottleneck_tail_supported(kl, c_, depth + 1, node.cout) == 1)
+                nslot = depth + 1 if tail else depth + 2
                 if split:
-                    slot = [(self._alloc(x.H, x.W, c_), 0) for _ in range(depth + 2)]
+                    slot = [(self._alloc(x.H, x.W, c_), 0) for _ in range(nslot)]
                 else:
-                    cat = self._alloc(x.H, x.W, c_ * (depth + 2))
-                    slot = [(cat, j * c_) for j in range(depth + 2)]
+                    cat = self._alloc(x.H, x.W, c_ * nslot)
+                    slot = [(cat, j * c_) for j in range(nslot)]
                 if node.i == 2 and self._stem3 is not None:
                     w0, b0, c0, w1_, b1_, c1 = self._stem3
                     w3, b3 = m.conv1.fused()
@@ -346,7 +357,17 @@ class Plan:
                     mid = blk.conv1.conv.out_channels
                     q = "%s.m.%d" % (p, d)
                     mode = self._fuse_mode(q, blk.conv2.dwconv.kernel_size, c_)
-                    (ib, ic), (ob, oc) = slot[d + 1], slot[d + 2]
+                    (ib, ic) = slot[d + 1]
+                    if tail and d == depth - 1:
+                        # the whole DepthBottleneckUni AND the block's closing 1x1 in one launch (op.nc = the block's output channels)
+                        rec, b2p, nmb, ct2 = pack.pack_bottleneck(*blk.conv1.fused(), *blk.conv2.fused(), *blk.one_conv.fused())
+                        w3, b3 = m.conv2.fused()
+                        out = self._alloc(x.H, x.W, node.cout)
+                        self._ops.append(dict(kind=lib.OP_BOTTLENECK, name=q + "+conv2", act=lib.ACT_SILU, H=x.H, W=x.W, Cin=c_, Cout=c_, ksize=kl, mid=mid,
+                                              segs=[Seg(ib, c_, ic)] + [Seg(slot[j][0], c_, slot[j][1]) for j in range(depth)], out=out, out_coff=0, pt=16, ct=16, tk=nmb,
+                                              tail_c3=node.cout, w=self._wput(rec), b=self._wput(b2p), aux=[self._wput(pack.pack_bottleneck_tail(w3, b3, c_, depth + 1))]))
+                        continue
+                    (ob, oc) = slot[d + 2]
                     if mode == 2:
                         # conv1 + depth-wise in one launch (the 3c-wide T1 stays in LDS), then the plain 1x1
                         rec, nmb = pack.pack_conv1dw(*blk.conv1.fused(), *blk.conv2.fused())
@@ -369,9 +390,10 @@ class Plan:
                     self._conv1x1(q + ".conv1", *blk.conv1.fused(), TV([Seg(ib, c_, ic)], x.H, x.W), t1, 0, lib.ACT_SILU)
                     self._dw(q + ".conv2", *blk.conv2.fused(), TV([Seg(t1, mid)], x.H, x.W), t2, lib.ACT_SILU)
                     self._conv1x1(q + ".one_conv", *blk.one_conv.fused(), TV([Seg(t2, mid)], x.H, x.W), ob, oc, lib.ACT_SILU)
-                out = self._alloc(x.H, x.W, node.cout)
-                cat_tv = TV([Seg(b_, c_, 0) for b_, _ in slot], x.H, x.W) if split else TV([Seg(cat, c_ * (depth + 2))], x.H, x.W)
-                self._conv1x1(p + ".conv2", *m.conv2.fused(), cat_tv, out, 0, lib.ACT_SILU)
+                if not tail:
+                    out = self._alloc(x.H, x.W, node.cout)
+                    cat_tv = TV([Seg(b_, c_, 0) for b_, _ in slot], x.H, x.W) if split else TV([Seg(cat, c_ * (depth + 2))], x.H, x.W)
+                    self._conv1x1(p + ".conv2", *m.conv2.fused(), cat_tv, out, 0, lib.ACT_SILU)
                 y.append(TV([Seg(out, node.cout)], x.H, x.W))
             elif node.kind == "mprep":
                 assert len(x.segs) == 1 and x.segs[0].mode == lib.SRC_DIRECT
@@ -599,6 +621,7 @@ class Plan:
                 o.bias = wbase + r["b"]
             if r["kind"] == lib.OP_BOTTLENECK:
                 o.tile_k = r["tk"]
+                o.nc = r.get("tail_c3", 0)
             if "pool1" in r:                                  # one-launch MPRep: only the LDS-resident 3x3 kernel has the pooled branch
                 o.tile_k, o.nc, o.reg_stride = r.get("pool1_tk", 6), r["pool1"][0].shape[0], 0
             for k_, off in enumerate(r.get("aux", [])):
@@ -1018,7 +1041,7 @@ class Plan:
                 return "dwconv_dot2_kernel<%d, 8, %d, %d>" % (o.ksize, 2 if (o.tile_k >> 8) % 2 == 0 else 1, o.act)
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)
         if o.kind == lib.OP_BOTTLENECK:
-            return "bottleneck_kernel<%d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4)
+            return "bottleneck_kernel<%d, %d, %d, %d, %d>" % (o.ksize, -(-o.Cin // 32), 2 if o.Cout <= 32 else 4, o.nc // 16, o.nsrc if o.nc else 0)
         if o.kind == lib.OP_CONV1DW:
             return "conv1dw_kernel<%d>" % o.ksize
         if o.kind == lib.OP_HEADTAIL:
@@ -1055,7 +1078,10 @@ class Plan:
             return px * (o.Cin + o.Cout) * es + (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout) * es
         if o.kind == lib.OP_BOTTLENECK:
             mid = o.tile_k * 32
-            return px * (o.Cin + o.Cout) * es + (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
+            wts = (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout) * es
+            if o.nc:                                            # with the block's closing conv: every concat slot read once, its output written once
+                return px * (o.nsrc * o.Cin + o.nc) * es + wts + (o.nsrc + 1) * o.Cin * o.nc * es
+            return px * (o.Cin + o.Cout) * es + wts
         if o.kind == lib.OP_SPPF_POOL:
             return 4 * px * o.src[0].C * es
         if o.kind == lib.OP_HEADTAIL:                          # both branch inputs once, the prediction rows once, the two weight records
@@ -1082,7 +1108,7 @@ class Plan:
             return 2 * px * (o.Cin * o.Cout + o.ksize * o.ksize * o.Cout)
         if o.kind == lib.OP_BOTTLENECK:
             mid = self._ops[idx]["mid"]
-            return 2 * px * (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout)
+            return 2 * px * (o.Cin * mid + o.ksize * o.ksize * mid + mid * o.Cout + (o.nsrc + 1) * o.Cin * o.nc)
         if o.kind == lib.OP_HEADTAIL:
             return 2 * px * (2 * o.Cin * o.Cin + o.Cin * (self.nc + 4 * (self.reg_max + 1)))
         return 0

@@ -123,6 +123,7 @@ class Model(nn.Module):
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.fuse_stem = True                 # True / 2: backbone.0 + backbone.1 + the 1x1 that opens backbone.2 in one launch (csrc/stem2.hip; fp16 plans of n and s); 1: without the 1x1; False
         self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
+        self.fuse_tail = "auto"               # the 1x1 conv that closes a RepHDW block inside the launch of its last fully fused bottleneck (csrc/bottleneck.hip, op.nc): True / False / "auto" = where the instantiation exists
         self.fuse_mprep = "auto"              # MPRep (MaxPool2d + 1x1 | 3x3 s2) in one launch (csrc/conv3s2_lds.hip, 48 / 64 channels, big maps): True / False / "auto" = when autotune is on
         self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
@@ -266,7 +267,7 @@ class Model(nn.Module):
         else:
             dt = lib.F32 if x.dtype == torch.float32 else lib.F16
         fuse_head = bool(getattr(self, "fuse_head", True)) and not head_feats
-        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, repr(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), self.multi_stream, bool(getattr(self, "twin_convs", True)))
+        key = (B, H, W, dt, in_dt, x.device.index, fuse_head, slot, repr(getattr(self, "fuse_stem", True)), repr(self.fuse_bottlenecks), repr(getattr(self, "fuse_tail", "auto")), self.multi_stream, bool(getattr(self, "twin_convs", True)))
         ver = self.weights_version()
         if ver != self._plans_version:         # the weights changed in place since the cached plans were packed (EMA update, optimizer step ...)
             self._plans = {}

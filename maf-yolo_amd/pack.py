@@ -213,6 +213,52 @@ def pack_bottleneck(w1, b1, wdw, bdw, w2, b2):
     return rec, b2p, nmb, ct2
 
 
+def pack_bottleneck_tail(w3, b3, c, nsrc):
+    """Record of the closing 1x1 conv fused behind MAF_OP_BOTTLENECK (op.nc = C3 > 0, csrc/bottleneck.hip): RepHDW.conv2 (common.py:944-946) over
+    cat(slot 0, .., slot nsrc-1, y) with c channels per slot, w3 [C3, (nsrc + 1) c, 1, 1], C3 a multiple of 16.
+
+    Layout: A fragments [k-step][tile t3][64 lanes][8] f16 | b3 [4 g][C3 / 16][4 rr] f32.  The GEMM runs transposed (rows = output channels):
+    row m = 4g + rr of tile t3 is output value v = rr * (C3 / 16) + t3 of lane group g, i.e. channel (v // P) * 4P + g * P + v % P with P = 8 (4 when a
+    lane's 4 C3 / 16 values are no multiple of 8): the four lane groups of one store instruction cover a contiguous 4P-channel run of a pixel.
+    k-steps: S1 = ceil(c / 32) per slot (k-slot (g, j) = channel 32 ks + 8g + j of the slot, zero past c), then the y part straight from the transposed
+    accumulators of the bottleneck's second 1x1: c > 32 (CT2 = 4) two steps with k-slot (g, j) of step j2 = channel 16g + 8 j2 + j, else one step with 8g + j."""
+    C3 = w3.shape[0]
+    assert C3 % 16 == 0 and w3.reshape(C3, -1).shape[1] == (nsrc + 1) * c and c % 8 == 0 and c <= 64
+    c3t, s1, ct2 = C3 // 16, -(-c // 32), (2 if c <= 32 else 4)
+    ys = ct2 // 2
+    nv = 4 * c3t
+    P = 8 if nv % 8 == 0 else 4
+    w = w3.detach().reshape(C3, -1).float().cpu()
+    cols = []
+    for s_ in range(nsrc):
+        for ks in range(s1):
+            for gl in range(4):
+                for j in range(8):
+                    ch = 32 * ks + 8 * gl + j
+                    cols.append(s_ * c + ch if ch < c else -1)
+    for j2 in range(ys):
+        for gl in range(4):
+            for j in range(8):
+                ch = 16 * gl + 8 * j2 + j if ct2 == 4 else 8 * gl + j
+                cols.append(nsrc * c + ch if ch < c else -1)
+    cols = torch.tensor(cols)
+    wk = torch.zeros(C3, cols.numel())
+    ok = cols >= 0
+    wk[:, ok] = w[:, cols[ok]]
+    g_, rr_, t_ = torch.meshgrid(torch.arange(4), torch.arange(4), torch.arange(c3t), indexing="ij")
+    v = rr_ * c3t + t_
+    ch_out = (v // P) * (4 * P) + g_ * P + v % P                         # [g][rr][t3]
+    assert sorted(ch_out.reshape(-1).tolist()) == list(range(C3))
+    nst = cols.numel() // 32
+    rows = ch_out.permute(2, 0, 1).reshape(c3t, 16)                      # [t3][m = 4g + rr]
+    fr = wk[rows.reshape(-1)].reshape(c3t, 16, nst, 4, 8)                # [t3][m][step][gl][j]
+    fr = fr.permute(2, 0, 3, 1, 4).contiguous().half()                  # [step][t3][gl][m][j]: lane = gl * 16 + m
+    b3p = b3.detach().float().cpu()[ch_out.permute(0, 2, 1).reshape(-1)].contiguous()      # [g][t3][rr]
+    rec = torch.cat([fr.reshape(-1).view(torch.uint8), b3p.view(torch.uint8)])
+    assert rec.numel() == nst * c3t * 1024 + 64 * c3t
+    return rec
+
+
 def pack_head_tail(w1, b1, w2, b2):
     """Weight record of one branch of MAF_OP_HEADTAIL (csrc/head_tail.hip): 1x1 conv w1 [C,C] (+ b1, SiLU) followed by 1x1 conv w2
     [n2 <= 80, C] (+ b2).  Layout: A fragments of W1 [C/16][C/32][64 lanes][8] f16 (lane (g, i): output channel 16t + i, input

@@ -678,6 +678,52 @@ def test_fused_bottleneck(c, k, H, W):
     assert torch.equal(buf[..., 8:8 + c].float().cpu().permute(0, 3, 1, 2), x)         # input slice untouched
 
 
+@pytest.mark.parametrize("c,k,c3,nsrc,H,W", [(24, 3, 48, 2, 21, 27), (48, 5, 96, 2, 32, 16), (64, 5, 128, 2, 21, 27), (64, 5, 128, 2, 80, 80),
+                                             (32, 3, 64, 3, 21, 27), (64, 5, 128, 3, 19, 33), (48, 3, 96, 3, 16, 40)])
+def test_fused_bottleneck_with_closing_conv(c, k, c3, nsrc, H, W):
+    """MAF_OP_BOTTLENECK with nc = C3: the last DepthBottleneckUni of a RepHDW block and the block's closing conv2(cat(x1, x2, .., y)) + SiLU
+    (common.py:918-927, 938-946) in one launch == the two steps on their own (y rounded to fp16 where the separate kernels store it)."""
+    g = torch.Generator().manual_seed(7 * c + k + c3)
+    B, mid = 2, 3 * c
+    slots = [torch.randn(B, c, H, W, generator=g).half().float() for _ in range(nsrc)]          # concat slots in front of y; the last one feeds the bottleneck
+    x = slots[-1]
+    w1 = (torch.randn(mid, c, 1, 1, generator=g) / c ** 0.5).half().float(); b1 = torch.randn(mid, generator=g) * 0.3
+    wd = (torch.randn(mid, 1, k, k, generator=g) / k).half().float(); bd = torch.randn(mid, generator=g) * 0.3
+    w2 = (torch.randn(c, mid, 1, 1, generator=g) / mid ** 0.5).half().float(); b2 = torch.randn(c, generator=g) * 0.3
+    w3 = (torch.randn(c3, (nsrc + 1) * c, 1, 1, generator=g) / ((nsrc + 1) * c) ** 0.5).half().float(); b3 = torch.randn(c3, generator=g) * 0.3
+    t1 = F.silu(F.conv2d(x, w1, b1)).half().float()
+    t2 = F.silu(F.conv2d(t1, wd, bd, 1, k // 2, 1, mid)).half().float()
+    y = F.silu(F.conv2d(t2, w2, b2)).half().float()
+    ref = F.silu(F.conv2d(torch.cat(slots + [y], 1), w3, b3))
+    L = lib.load()
+    assert L.maf_bottleneck_tail_supported(k, c, nsrc, c3) == 1
+    rec, b2p, nmb, ct2 = pack.pack_bottleneck(w1, b1, wd, bd, w2, b2)
+    rec3 = pack.pack_bottleneck_tail(w3, b3, c, nsrc)
+    assert rec3.numel() == L.maf_bottleneck_tail_record_bytes(c, nsrc, c3)
+    dev = [rec.to(DEV), b2p.to(DEV), rec3.to(DEV)]
+    stride = nsrc * c + 8                                               # the slots interleaved in one buffer behind 8 guard channels, as the engine lays them out
+    buf = torch.zeros(B, H, W, stride, dtype=torch.float16, device=DEV)
+    for i, t in enumerate(slots):
+        buf[..., 8 + i * c:8 + (i + 1) * c] = _nhwc(t, lib.F16)
+    keep = buf.clone()
+    out = torch.full((B, H, W, c3 + 8), 3.0, dtype=torch.float16, device=DEV)
+    op = lib.MafOp()
+    op.kind, op.dtype, op.in_dtype, op.act = lib.OP_BOTTLENECK, lib.F16, lib.F16, lib.ACT_SILU
+    op.B, op.H, op.W, op.Cin, op.Cout, op.ksize, op.nsrc, op.nc = B, H, W, c, c, k, nsrc, c3
+    order = [nsrc - 1] + list(range(nsrc - 1))                          # src[0] = the bottleneck's input, src[1..] = the slots in front of it
+    for j, i in enumerate(order):
+        op.src[j].ptr, op.src[j].C, op.src[j].stride, op.src[j].coff, op.src[j].mode = buf.data_ptr(), c, stride, 8 + i * c, lib.SRC_DIRECT
+    op.out, op.out_stride, op.out_coff = out.data_ptr(), c3 + 8, 8
+    op.tile_p, op.tile_c, op.tile_k = 16, 16, nmb
+    op.w, op.bias = dev[0].data_ptr(), dev[1].data_ptr()
+    op.aux[0] = dev[2].data_ptr()
+    _launch(op)
+    _check(out[..., 8:], ref, lib.F16)
+    assert (out[..., :8] == 3).all() and torch.equal(buf, keep)         # nothing but the closing conv's channels is written
+    op.nc = 32                                                          # no such instantiation: a clean error, no launch
+    assert L.maf_op_launch(C.byref(op), None) < 0
+
+
 @pytest.mark.parametrize("c,k,H,W", [(96, 7, 21, 27), (192, 9, 20, 20), (24, 3, 33, 18), (128, 5, 16, 32), (72, 5, 40, 40)])
 def test_conv1_dw_partial_fusion(c, k, H, W):
     """MAF_OP_CONV1DW == Conv1x1+SiLU -> DW k x k + SiLU (first half of DepthBottleneckUni, common.py:905-909) for any width."""

@@ -454,7 +454,8 @@ def test_tuned_plan_at_the_benchmark_size_matches_the_default_plan(models):
     plan = m.plan_for(x)
     fused = [o for o, n_ in zip(plan.ops, plan.op_names) if n_ == "backbone.3.conv1+conv2"]
     assert len(fused) == 1 and (fused[0].kind, fused[0].tile_k, fused[0].nc, fused[0].reg_stride, fused[0].out_coff) == (lib.OP_CONV3X3S2, 6, 48, 0, 48)
-    assert plan.ops[0].kind == lib.OP_STEM2 and plan.ops[0].aux[0] and plan.ops[plan.op_names.index("backbone.2.conv2")].nsrc == 3
+    tail = plan.ops[plan.op_names.index("backbone.2.m.0+conv2")]              # backbone.2's closing conv rides in its bottleneck's launch: the two dense slots are its sources
+    assert plan.ops[0].kind == lib.OP_STEM2 and plan.ops[0].aux[0] and tail.kind == lib.OP_BOTTLENECK and tail.nsrc == 2 and tail.nc == 48 and tail.src[0].ptr != tail.src[1].ptr
     assert len(plan.ops) == len(models["n"].plan_for(x).ops) - 1
     assert np.isfinite(got).all()
     _close16(got, ref, "n")

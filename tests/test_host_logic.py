@@ -168,7 +168,18 @@ def test_plan_builds_on_cpu(built, scale, nops32):
             assert lo <= o.out < hi, name
     assert plan.A == 8 * 8 + 4 * 4 + 2 * 2
     m.fuse_bottlenecks = True                      # fused DepthBottleneckUni: 3 launches -> 1 wherever c <= 64, -> 2 (conv1+dw | 1x1) elsewhere
+    tails = {"n": ["backbone.2.m.0+conv2", "backbone.4.m.0+conv2", "backbone.20.m.0+conv2", "backbone.22.m.0+conv2"],
+             "s": ["backbone.2.m.1+conv2", "backbone.4.m.1+conv2"], "m": ["backbone.2.m.1+conv2"]}[scale]
+    wt = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))                  # fuse_tail "auto": the block's closing conv inside its last bottleneck's launch
+    assert [n for n in wt.op_names if n.endswith("+conv2")] == tails and not any(n[:-len(".m.0+conv2")] + ".conv2" in wt.op_names for n in tails)
+    for o, name in zip(wt.ops, wt.op_names):
+        if name in tails:
+            depth = int(name.split(".m.")[1][0]) + 1
+            assert o.kind == lib.OP_BOTTLENECK and o.nc % 16 == 0 and o.nsrc == depth + 1 and o.aux[0] and all(o.src[i].C == o.Cin for i in range(o.nsrc))
+            assert built.maf_bottleneck_tail_supported(o.ksize, o.Cin, o.nsrc, o.nc) == 1 and len({(o.src[i].ptr, o.src[i].coff) for i in range(o.nsrc)}) == o.nsrc
+    m.fuse_tail = False
     fused = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))
+    assert len(wt.ops) == len(fused.ops) - len(tails)
     full, part = {"n": (6, 4), "s": (4, 16), "m": (2, 28)}[scale]
     assert len(fused.ops) == nops - 2 * full - part
     assert sum(1 for o in fused.ops if o.kind == lib.OP_BOTTLENECK) == full and sum(1 for o in fused.ops if o.kind == lib.OP_CONV1DW) == part
