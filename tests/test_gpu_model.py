@@ -351,6 +351,29 @@ def test_fused_bottleneck_plan_matches_unfused(models):
     _close16(outs[2], outs[False])
 
 
+@pytest.mark.parametrize("scale,shape,ntail", [("n", (2, 320, 320), 4), ("n", (3, 352, 288), 4), ("s", (2, 320, 256), 2), ("m", (2, 256, 256), 1)])
+def test_closing_conv_inside_the_bottleneck_launch_matches_the_two_launches(scale, shape, ntail):
+    """MAF_OP_BOTTLENECK with op.nc (the RepHDW block's conv2(cat(..)) + SiLU applied inside the launch of its last bottleneck, csrc/bottleneck.hip) against the
+    same plan with the closing conv as its own launch: same fp16 rounding points (the bottleneck's output is rounded to fp16 before the closing GEMM either
+    way), another fp32 summation order.  n takes it by default (one bottleneck per block), s / m on request (two: their second bottleneck carries the conv)."""
+    B, H, W = shape
+    x = O.synth_images(B, max(H, W), 5)[:, :, :H, :W].contiguous().to(DEV).half()
+    outs = {}
+    for ft in (True, False):
+        m = M.Model(scale)
+        m.load_state_dict(O.synth_state_dict(scale, 0))
+        m = m.to(DEV).eval()
+        m.fuse_tail = ft
+        with torch.no_grad():
+            outs[ft] = m(x)[0].float().cpu().numpy()
+        plan = m.plan_for(x)
+        assert sum(1 for o in plan.ops if o.kind == 6 and o.nc) == (ntail if ft else 0)
+        for n_ in plan.op_names:                               # a block whose bottleneck carries the conv has no conv2 launch of its own
+            if n_.endswith("+conv2"):
+                assert n_.split(".m.")[0] + ".conv2" not in plan.op_names
+    _close16(outs[True], outs[False], scale)
+
+
 @pytest.mark.parametrize("shape,scale", [((2, 320, 320), "n"), ((3, 256, 384), "n"), ((32, 640, 640), "n"), ((2, 320, 256), "s")])
 def test_fused_head_tail_matches_unfused(shape, scale):
     """MAF_OP_HEADTAIL ({cls,reg}_conv_s -> pred -> sigmoid / DFL decode, one launch per level) vs four 1x1 convs + the decode kernel:
@@ -475,7 +498,8 @@ def test_fusion_choice_is_measured_when_autotuning():
     decided = [k for k in engine._TUNE_CACHE if k[0] == "bn3" and k[2] == 2 and k[3] in (80, 40, 20, 10)]
     assert len(decided) >= 4                       # one decision per distinct bottleneck signature
     nf, npart = sum(1 for o in plan.ops if o.kind == 6), sum(1 for o in plan.ops if o.kind == 7)
-    assert len(plan.ops) == 73 - 2 * nf - npart          # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem + backbone.2.conv1: -2; twin side convs: -2
+    ntail = sum(1 for o in plan.ops if o.kind == 6 and o.nc)          # fully fused bottlenecks that also carry their block's closing conv
+    assert len(plan.ops) == 73 - 2 * nf - npart - ntail   # 90 launches unfused; fused head (one depth-wise + one tail per level): -13; fused stem + backbone.2.conv1: -2; twin side convs: -2
 
 
 def test_post_nms_tail_matches_reference_fixture(golden):
