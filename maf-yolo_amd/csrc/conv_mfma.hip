@@ -98,9 +98,10 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
         return maf_conv1x1_stream(a, pt, ct, s);
     }
     if (op->tile_k == 5) {
-        MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32 && pt == 1 && (var == VAR_DIRECT || var == VAR_MULTI || (var == VAR_POOL2 && op->kind == MAF_OP_CONV1X1)),
-                    "conv: tile_k = 5 is an fp16 1x1 variant with tile_p = 1");
+        MAF_REQUIRE(op->dtype == MAF_F16 && !op->out_f32 && (pt == 1 || pt == 2) && (var == VAR_DIRECT || var == VAR_MULTI || (var == VAR_POOL2 && op->kind == MAF_OP_CONV1X1)),
+                    "conv: tile_k = 5 is an fp16 1x1 variant with tile_p = 1 (4 waves per workgroup) or 2 (8 waves)");
         a.nM = maf_cdiv(a.M, 16);
+        a.stream_waves = pt == 2 ? 8 : 4;
         return maf_conv1x1_stream_lds(a, var == VAR_POOL2 ? VAR_DIRECT : var, ct, s);      // a pooled / sub-sampled single source: the direct form with a.srcMode[0] set
     }
     if (lb) return maf_conv_mfma_f16_lb(a, var, pt, ct, s);

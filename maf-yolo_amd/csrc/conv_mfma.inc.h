@@ -44,6 +44,7 @@ struct ConvArgs {
     int out_stride, out_coff;
     int nM, nN;
     int act;
+    int stream_waves;    // conv1x1_stream_lds only: 4, or 8 (op->tile_p = 2: 512-thread workgroups, csrc/conv_stream_lds_w8.hip)
     int out_pairs;       // conv1x1_stream_lds only: the output is stored as pixel pairs (MAF_SRC_PAIRS) for a depth-wise consumer
     int dg_mc, dg_nmc;   // VAR_DGRAD3 with even H, W: pixels per parity class (B * H/2 * W/2) and pixel tiles per class (nM = 4 * dg_nmc); 0 = unsplit
     // twin launch (op->aux[0..3]): a SECOND conv of identical shape — same everything except these four pointers — runs as

@@ -7,6 +7,7 @@
 #include "conv_stream_lds.inc.h"
 
 int maf_conv1x1_stream_lds_wide(const ConvArgs& a, int var, int ct, hipStream_t s);
+int maf_conv1x1_stream_lds_w8(const ConvArgs& a, int var, int ct, hipStream_t s);
 
 namespace {
 
@@ -25,6 +26,7 @@ int launch_sl_ks(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s) {
+    if (a.stream_waves == 8) return maf_conv1x1_stream_lds_w8(a, var, ct, s);
     if (var == VAR_DIRECT) {
         if (ct == 2) return launch_sl_ks<2, false>(a, s);
         if (ct == 4) return launch_sl_ks<4, false>(a, s);

@@ -68,8 +68,10 @@ __device__ __forceinline__ void sl_store_pair(const f32x4_t (&acc)[CT], int r0, 
     }
 }
 
-template <int CT, int KS, bool MULTI>
-__global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs a) {
+// NW = waves per workgroup (4; 8 = a.stream_waves: the instantiations whose KS * CT KiB of weights leave room for one or two workgroups per CU only — twice the
+// waves behind the same LDS copy of the weights, i.e. twice the activation tiles in flight per CU and half the tiles per wave; conv_stream_lds_w8.hip)
+template <int CT, int KS, bool MULTI, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvArgs a) {
     typedef Frag<half_t> F;
     typedef F::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_raw[];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
         // no registers, no ds_write, ALL of them in flight at once — the first version walked them with a load -> wait -> ds_write loop, 18
         // dependent L2 round trips per workgroup before the first MFMA)
         const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)(n_tile * CT) * KS) * 1024;   // [ct][ks][64 x 16 B]
-        for (int f = wave; f < KS * CT; f += 4) {                       // LDS order: fragment f = ks * CT + ct
+        for (int f = wave; f < KS * CT; f += NW) {                      // LDS order: fragment f = ks * CT + ct
             const int ks = f / CT, ct = f - ks * CT;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsrc + ((size_t)ct * KS + ks) * 1024 + lane * 16),
                                              (void __attribute__((address_space(3)))*)(wl_raw + f * 1024), 16, 0, 0);
@@ -237,14 +239,26 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
         }
     };
 
-    frag_t fa[KS], fb[KS];
-    const int stride = nwg * 4;
-    int t = wg * 4 + wave;
+    frag_t fa[KS];
+    const int stride = nwg * NW;
+    int t = wg * NW + wave;
     const bool any = t < ntiles;
     if (any) load_tile(t, fa);                                           // in flight beside the weight DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
     __syncthreads();                                                     // ... and everybody else's
     if (!any) return;
+    if constexpr (NW == 8) {
+        // two waves per SIMD: the partner's multiplies cover this wave's loads — ONE fragment set per wave (two sets of up to 24 fragments do not fit the
+        // 256 registers a wave of a 512-thread workgroup gets)
+        while (true) {
+            compute_store(t, fa);
+            t += stride;
+            if (t >= ntiles) break;
+            load_tile(t, fa);
+        }
+        return;
+    }
+    frag_t fb[KS];
     while (true) {
         const int t1 = t + stride;
         if (t1 < ntiles) load_tile(t1, fb);
@@ -258,29 +272,29 @@ __global__ __launch_bounds__(256) void conv1x1_stream_lds_kernel(const ConvArgs 
     }
 }
 
-template <int CT, int KS, bool MULTI>
+template <int CT, int KS, bool MULTI, int NW = 4>
 int launch_sl(const ConvArgs& a, hipStream_t s) {
     constexpr int lds = KS * CT * 1024;
     static_assert(lds <= 160 * 1024, "weights of one channel tile must fit LDS");
     static int occ = 0;                                                  // resident workgroups per CU of this instantiation (LDS and registers)
     if (!occ) {
         if (lds > 64 * 1024) {
-            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
+            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
             if (rc) return rc;
         }
         int nb = 0;
-        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI>, 256, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
+        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
         if (rc) return rc;
         occ = nb < 1 ? 1 : nb > 4 ? 4 : nb;
     }
     // ONE round of persistent workgroups: exactly what is resident at once (a second round pays the weight DMA and the ramp-up again for a
     // handful of tiles per wave), spread evenly over the channel tiles
     const int ntiles = (a.M + 15) >> 4;
-    int per = (ntiles + 3) / 4;                                          // workgroups per channel tile that still have work
+    int per = (ntiles + NW - 1) / NW;                                    // workgroups per channel tile that still have work
     const int cap = occ * 256 / a.nN > 0 ? occ * 256 / a.nN : 1;
     if (per > cap) per = cap;
     if (per >= 8 && a.nN > 1) per &= ~7;                                 // whole XCD rounds: the channel tiles of a pixel tile then share an XCD's L2 (see the kernel)
-    hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI>), dim3(per * a.nN), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>), dim3(per * a.nN), dim3(NW * 64), lds, s, a);
     return maf_check_hip(hipGetLastError(), "conv1x1_stream_lds launch");
 }
 

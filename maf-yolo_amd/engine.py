@@ -911,6 +911,8 @@ class Plan:
                     if o.kind == lib.OP_CONV1X1 and self.dtype == lib.F16 and not o.out_f32 and stream_lds_ok(ksteps, ct) \
                             and (o.nsrc == 1 or all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc))) and (direct or ct >= 4 or o.nsrc == 1):
                         cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
+                        if ct >= 4 and 64 <= ksteps * ct <= 160 and (8 <= ksteps <= 20 or ksteps == 24):
+                            cands.append((2, ct, 5))                     # ... eight waves behind one copy of the weights where the LDS leaves room for one or two workgroups per CU (conv_stream_lds_w8.hip)
                     if o.kind == lib.OP_CONV3X3S2 and self.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and (M >= 65536 or pool1):
                         for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)
                             cands.append((4, wg, 6))
@@ -1030,7 +1032,7 @@ class Plan:
             if o.tile_k == 7:
                 return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3, o.nc))
             if o.tile_k == 5:
-                return "conv1x1_stream_lds_kernel<%d, %d, %s>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false")
+                return "conv1x1_stream_lds_kernel<%d, %d, %s, %d>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false", 8 if o.tile_p == 2 else 4)
             return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
         if o.kind == lib.OP_DWCONV:
             if o.tile_p == -1:

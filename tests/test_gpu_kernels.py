@@ -170,8 +170,8 @@ def test_conv1x1_persistent_stream(cin, cout, pt, ct, act):
     assert (out[..., :coff] == 7).all() and (out[..., coff + cout:] == 7).all(), "wrote outside its slice"
 
 
-@pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2), ("direct", 576, 192, 6), ("direct", 768, 96, 6),
-                                              ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4)])
+@pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2), ("direct", 576, 192, 6), ("direct", 768, 96, 6), ("direct", 576, 128, 8), ("direct", 448, 64, 4),
+                                              ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4), ("multi8", 0, 128, 8), ("multi8", 0, 192, 6)])
 def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     """tile_k = 5: persistent waves with the channel tile's weights resident in LDS; single source or concat (with upsample)."""
     g = torch.Generator().manual_seed(31 + cout + ct)
@@ -184,7 +184,7 @@ def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
         xs[..., 8:] = _nhwc(x, dt)
         srcs, full = [(xs, cin, cin + 8, 8, 0)], x
     else:
-        ca, cb, cc = 40, 64, 24
+        ca, cb, cc = (40, 64, 24) if kind == "multi" else (128, 192, 128)       # multi8: a wide MAFPN concat (14 k-steps), the shapes the eight-wave form is for
         cin = ca + cb + cc
         a = _q(torch.randn(B, ca, H, W, generator=g), dt)
         bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
@@ -201,6 +201,17 @@ def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     _launch(op)
     _check(out[..., 8:], ref, dt)
     assert (out[..., :8] == 5).all()
+    # tile_p = 2: eight waves per workgroup behind one LDS copy of the weights (csrc/conv_stream_lds_w8.hip; 64 <= k-steps x tile_c <= 160): the same tiles, the
+    # same order of additions — bit-identical; a clean error where the instantiation does not exist
+    ksteps = sum(-(-s_[1] // 32) for s_ in srcs)
+    out8 = torch.full((B, H, W, cout + 8), 5.0, dtype=DT[dt], device=DEV)
+    op8 = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, out8, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 2, ct)
+    op8.tile_k = 5
+    if ct >= 4 and 64 <= ksteps * ct <= 160 and 8 <= ksteps:
+        _launch(op8)
+        assert torch.equal(out8, out)
+    else:
+        assert lib.load().maf_op_launch(C.byref(op8), torch.cuda.current_stream().cuda_stream) != 0
     # the same conv storing PIXEL PAIRS (out_pairs: the layout csrc/dwconv_p2.hip reads): the same values, [B, H, W/2, stride, 2], a slice of a wider pair buffer
     outp = torch.full((B, H, W // 2, (cout + 8) * 2), 5.0, dtype=DT[dt], device=DEV)
     op2 = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, outp, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 1, ct)
