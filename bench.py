@@ -350,7 +350,7 @@ def main():
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
     ap.add_argument("--ddp", action="store_true", help="--train A/B: torch's DistributedDataParallel instead of maf_yolo_amd.GradExchange (N > 1; at N = 1: plain autograd)")
     ap.add_argument("--no-train-leg", action="store_true", help="leave the short training leg (`train` object: n, bs 32/GPU) out of the default line")
-    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
+    ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--rccl1", action="store_true", help="--train at N = 1: initialise a one-rank RCCL group and issue the bucket all-reduces anyway (GradExchange(force_collectives=True))")
@@ -673,7 +673,7 @@ def main():
         del dets
         model._plans = {}
         torch.cuda.empty_cache()
-        train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 6, False)
+        train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 10, False)       # 30 timed steps after 10 warm-up steps: a 0.65 s region (12 after 6 moved by 2 ms per step with one host stall: 23.8 in the line, 21.8 alone, same box)
     if rank == 0:
         if train is not None:
             train.pop("cpu_baseline", None)
