@@ -68,6 +68,9 @@ typedef struct {
  * MAF_OP_CONV1X1    replaces Conv.forward_fuse (common.py:49-50) and the plain nn.Conv2d preds
  *                   (common.py:1331,1335).  w = MFMA-fragment-packed (maf_pack_* in pack.py),
  *                   K = concat of the sources' channels in order (= torch.cat order).
+ *                   tile_k = 5 (fp16, 2 <= K / 32 <= 24, K / 32 * tile_c <= 160): persistent workgroups with the channel tile's weight fragments resident
+ *                   in LDS (csrc/conv_stream_lds.inc.h); tile_p = 1: four waves per workgroup, 2 (64 <= K / 32 * tile_c, K / 32 >= 8, tile_c in {4, 6, 8}):
+ *                   eight waves behind the same LDS copy (csrc/conv_stream_lds_w8.hip) — same result bit for bit.
  * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
  *                   2H x 2W input (Hin, Win below); w packed per tap.
  *                   Twin launch (CONV1X1 with one direct / pooled source, CONV3X3S2; tile_k 0 / 1 / 2 / 4): aux[0] != NULL runs a SECOND conv of
