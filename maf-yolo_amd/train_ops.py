@@ -264,6 +264,8 @@ def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
             cands += [(1, ct, 3), (2, ct, 3)]
         if _stream_lds_ok(ksteps, ct):
             cands.append((1, ct, 5))
+            if ct >= 4 and 64 <= ksteps * ct <= 160 and (8 <= ksteps <= 20 or ksteps == 24):
+                cands.append((2, ct, 5))                                         # eight waves behind one LDS copy of the weights (csrc/conv_stream_lds_w8.hip)
         if ksteps >= 4 and ct >= 4:
             for pt in ((1, 2, 4) if ct == 4 else (1, 2)):
                 if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
