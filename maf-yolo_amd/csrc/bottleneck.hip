@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
         xoff[i] = (uint32_t)(iy * a.W + ix) * a.x_stride;
     }
     int ko_block = 0;
-    constexpr int XD = Cf::OCC3 ? 1 : 2;                    // activation fragments are loaded XD m-tiles ahead of their MFMAs
+#ifndef MAF_BN_XD
+#define MAF_BN_XD 3         // 2 -> 3: -1 ... -3 us per launch (the MFMAs of m-tile i + 1 waited for loads issued one m-tile section earlier); 4 spills the 168-register forms, 5 gains nothing
+#endif
+    constexpr int XD = Cf::OCC3 ? 1 : (MAF_BN_XD < MT ? MAF_BN_XD : MT - 1);   // activation fragments are loaded XD m-tiles ahead of their MFMAs
     half8_t af[XD + 1][S1];
     auto load_x = [&](auto idx) {
         constexpr int i = decltype(idx)::value;
@@ -165,8 +168,7 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
         }
     };
     auto load_x_head = [&]() {
-        load_x(std::integral_constant<int, 0>{});
-        load_x(std::integral_constant<int, 1>{});
+        maf_static_for<XD>([&](auto idx) { load_x(idx); });
     };
     // zero mask of the T1 values this lane writes: accumulator lane (g, p) of m-tile t owns halo pixels t*16 + 4g .. +3
     // (one row, 4 consecutive columns); bit r set = pixel r is inside the image.  interior tiles: all ones.
