@@ -286,9 +286,13 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
                 half_t* dst = T1 + doff;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    half2_t h01 = {(half_t)bn_silu2(acc1[ct][0]), (half_t)bn_silu2(acc1[ct][1])};
-                    half2_t h23 = {(half_t)bn_silu2(acc1[ct][2]), (half_t)bn_silu2(acc1[ct][3])};
-                    if (BN_KO(1)) { h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]}; }   // KO 1: no SiLU in phase A
+                    half2_t h01, h23;
+                    if (BN_KO(1)) {                                                        // KO 1: no SiLU in phase A (a branch: as a select both sides were computed and the switch measured nothing)
+                        h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]};
+                    } else {
+                        h01 = half2_t{(half_t)bn_silu2(acc1[ct][0]), (half_t)bn_silu2(acc1[ct][1])};
+                        h23 = half2_t{(half_t)bn_silu2(acc1[ct][2]), (half_t)bn_silu2(acc1[ct][3])};
+                    }
                     const u32x2_t w = {__builtin_bit_cast(uint32_t, h01) & mlo, __builtin_bit_cast(uint32_t, h23) & mhi};
                     if (doff >= 0 && !BN_KO(4)) *reinterpret_cast<u32x2_t*>(dst + (size_t)(16 * ct) * PS) = w;                                        // KO 4: no T1 stores
                 }
@@ -392,7 +396,11 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
             for (int r = 0; r < 4; ++r) {
                 half8_t t2;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) t2[s] = BN_KO(3) ? (half_t)dacc[s][r] : (half_t)bn_silu2(dacc[s][r]);   // KO 3: no SiLU in phase C
+                for (int s = 0; s < 8; ++s) t2[s] = (half_t)dacc[s][r];
+                if (!BN_KO(3)) {                                                           // KO 3: no SiLU in phase C
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) t2[s] = (half_t)bn_silu2(dacc[s][r]);
+                }
 #pragma unroll
                 for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) {   // KO 9: no second 1x1
                     if constexpr (C3T > 0) acc2[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ct], t2, acc2[r][ct], 0, 0, 0);   // transposed: rows = channels (4g + rr) CT2 + ct, columns = pixel rows
