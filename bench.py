@@ -186,6 +186,8 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
     model = M.Model(scale)
     model.load_state_dict(synth.synth_state_dict(model, scale, 0))
     model = model.to(dev).train()
+    if getattr(args, "no_tape", False):
+        model.step_tape = False                # A/B: every step issued op by op from the autograd Functions (the path the step tape records)
     net, ex = model, None
     if args.ddp and world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
@@ -288,6 +290,10 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
         if full:
             roof["by_kind"] = {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}
     final = float(loss.detach())
+    tapes = [e_[1] for e_ in getattr(model, "_tapes", {}).values() if e_[1] is not None]
+    tape_info = {"replayed_steps": int(launches.get("tape_replays", 0)), "ready": bool(tapes and tapes[0].ready), "dropped_because": tapes[0].failed if tapes else None,
+                 "launches_forward": tapes[0].n.get("fwd") if tapes else None, "launches_backward": tapes[0].n.get("bwd") if tapes else None,
+                 "what": "maf_yolo_amd/tape.py: the step's C-ABI calls recorded once per batch shape (third step) and replayed by maf_tape_run, eager launches from one C loop"}
     exs, nb = None, 0
     if ex is not None:
         exs, nb = dict(ex.stats), len(ex.buckets)
@@ -309,7 +315,7 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
                        "gradient_exchange": ("torch DistributedDataParallel" if ex is None and world > 1 else "none (plain autograd)" if ex is None else
                                              "maf_yolo_amd.GradExchange: %d flat fp32 buckets filled on the weight-gradient stream, all-reduce per bucket from that stream%s"
                                              % (nb, "" if world > 1 else " (one-rank RCCL group: the collectives ARE issued, --rccl1)" if ex.force else " (world size 1: same schedule, no collective)")),
-                       "exchange_stats": exs,
+                       "exchange_stats": exs, "step_tape": tape_info,
                        "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
                        "native_launches": launches, "fallback": fallback, "final_loss": round(final, 5)},
             "native_launches": int(sum(v for k, v in launches.items() if k.startswith("native_"))), "fallback": fallback, "final_loss": round(final, 5),
@@ -328,7 +334,7 @@ def train_mode(args, torch, M, dev, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed steps (BASELINE.md §4: >= 100; 300 = a 0.4 s region: one 20 ms stall of the box no longer moves the value by 15 %)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (BASELINE.md §4: >= 100; 300 = a 0.4 s region: one 20 ms stall of the box no longer moves the value by 15 %%)")
     ap.add_argument("--warmup", type=int, default=30, help="untimed warm-up steps (BASELINE.md §4: >= 20)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE configs[1]: 32)")
     ap.add_argument("--scale", default="n")
@@ -351,6 +357,7 @@ def main():
     ap.add_argument("--ddp", action="store_true", help="--train A/B: torch's DistributedDataParallel instead of maf_yolo_amd.GradExchange (N > 1; at N = 1: plain autograd)")
     ap.add_argument("--no-train-leg", action="store_true", help="leave the short training leg (`train` object: n, bs 32/GPU) out of the default line")
     ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
+    ap.add_argument("--no-tape", action="store_true", help="--train A/B: no step tape (maf_yolo_amd/tape.py): every step issued op by op from Python")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--rccl1", action="store_true", help="--train at N = 1: initialise a one-rank RCCL group and issue the bucket all-reduces anyway (GradExchange(force_collectives=True))")

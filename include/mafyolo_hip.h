@@ -431,6 +431,7 @@ int maf_upsample2x_backward(const void* dy, int32_t dy_stride, int32_t B, int32_
  *           tap-major, every tap padded to Kp (a multiple of the k-step: 32 fp16 / 16 fp32), steps = taps * Kp / k-step for 3x3 and
  *           ceil(K / k-step) for 1x1 (then Kp = steps * k-step); transpose = 1 packs W^T (the data gradient's operand)
  *   kind 1  depth-wise kernel [C = Cout][taps = k*k] -> [k*k][C], flip = 1 reverses the taps (data gradient)
+ *   kind 2  fp32 vector of Cout values -> `total` fp32 values, zero behind the Cout-th (the bias of a prediction conv padded to the conv's channel tile)
  * total = packed elements, block0 = first block of the descriptor in the flattened grid (1024 elements per block; ascending),
  * nblocks = sum of ceil(total / 1024).  The descriptor array lives in DEVICE memory. */
 typedef struct maf_pack_desc {
@@ -457,6 +458,46 @@ typedef struct maf_ema_desc {
 int maf_ema_update(const maf_ema_desc_t* descs_dev, int32_t n, int32_t nblocks, float decay, float one_minus_decay, maf_stream_t stream);
 int32_t maf_ema_desc_size(void);
 
+
+/* dst = [dst +] sum_i src[i] over NHWC views with pixel strides in elements (channel slices of wider buffers are fine): n = 1, accumulate = 0 is a strided copy
+ * (a concat input its producer could not store in place: torch.cat of the neck, configs/yaml/MAF-YOLO-n.yaml:16-42), n = 1, accumulate = 1 an in-place add
+ * (a tensor that feeds a concat AND a later block: the block's gradient added into the concat's), n = 2..4 the gradient of a tensor with several consumers
+ * (what autograd's engine does with one add kernel per extra consumer).  fp16 (fp32 sums, one rounding) / fp32; C and strides in whole 16-byte groups. */
+int maf_nhwc_sum(const void* const* src, const int32_t* src_stride, int32_t n, void* dst, int32_t dst_stride, int64_t M, int32_t C, int32_t dtype,
+                 int32_t accumulate, maf_stream_t stream);
+/* `side` waits for what `main` holds now (an event record + a stream wait: the fork of a weight gradient to its own stream); join: `main` waits for `side`. */
+int maf_stream_fork(maf_stream_t main, maf_stream_t side);
+int maf_stream_join(maf_stream_t main, maf_stream_t side);
+
+/*
+ * Step tape: a recorded launch list of the C-ABI calls of one training step (yolov6/core/engine.py:141-167: forward, backward), replayed by ONE call.
+ * The train-form graph is ~420 launches forward and ~470 backward of kernels that take 5-60 us each; issued one by one from Python autograd
+ * Functions the host needs 19-27 ms per step — the step itself.  The Python side (maf_yolo_amd/tape.py) records every call of a step — entry point,
+ * arguments, stream — once per (model, batch shape) while it runs the step the normal way with every buffer kept alive, and later steps replay the list:
+ * the kernels, their order and their streams are exactly the recorded ones, launched eagerly (a hipGraph node costs ~1.1 us more than an eager launch
+ * on this part).
+ *   fn      index into the table of tape-able entry points (maf_tape_fn_id(name)); MAF_TAPE_FORK / MAF_TAPE_JOIN = maf_stream_fork / _join(main, side)
+ *   stream  0: the entry's last argument (its maf_stream_t) becomes `main`, 1: `side`
+ *   a[]     the arguments in declaration order, one 64-bit slot each: pointers and integers as they are, a float as its 32 bits; pointer-to-array
+ *           arguments point at host arrays the recorder keeps alive
+ * Toggles: words that alternate from step to step (the phase of a BatchNorm scratch: which half this step accumulates into) are XOR-ed with their
+ * mask by maf_tape_toggle between two runs.
+ */
+#define MAF_TAPE_MAX_ARGS 28
+#define MAF_TAPE_FORK (-1)
+#define MAF_TAPE_JOIN (-2)
+typedef struct maf_tape_rec {
+    int32_t fn, stream;
+    uint64_t a[MAF_TAPE_MAX_ARGS];
+} maf_tape_rec_t;
+typedef struct maf_tape_toggle {
+    void* addr; uint64_t mask; int32_t width, reserved;     /* width 4 or 8 bytes */
+} maf_tape_toggle_t;
+int32_t maf_tape_fn_id(const char* name);                   /* -1000: not a tape-able entry point */
+int32_t maf_tape_fn_nargs(int32_t fn);
+int32_t maf_tape_rec_size(void);
+int maf_tape_run(const maf_tape_rec_t* recs, int32_t first, int32_t last, maf_stream_t main, maf_stream_t side, int32_t* failed_at);
+int maf_tape_toggle(const maf_tape_toggle_t* t, int32_t n);
 
 /*
  * Post-NMS tail — replaces Evaler.scale_coords (yolov6/core/evaler.py:382-409, ratio_pad branch), box_convert

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const maf_pack_desc_t* 
             const int rows = d.transpose ? d.Cin : d.Cout, cols = d.transpose ? d.Cout : d.Cin;
             if (chan < rows && k < cols && tap < d.taps)
                 v = d.transpose ? w[((size_t)k * d.Cin + chan) * d.taps + tap] : w[((size_t)chan * d.Cin + k) * d.taps + tap];
+        } else if (d.kind == 2) {                                     // fp32 vector, zero-padded to `total` (a prediction conv's bias on the conv's channel tile)
+            v = e < d.Cout ? w[e] : 0.f;
         } else {                                                      // depth-wise: [C][kk] -> [kk][C], optionally flipped
             const int c = (int)(e % d.Cout), tap = (int)(e / d.Cout);
             v = w[(size_t)c * d.taps + (d.flip ? d.taps - 1 - tap : tap)];
@@ -320,7 +322,78 @@ __global__ void grad_fold_kernel(const float* __restrict__ src, int taps, int co
     dst[i] = accumulate ? dst[i] + v : v;
 }
 
+// dst = [dst +] sum_i src[i] on NHWC views (maf_nhwc_sum): thread = one 16-byte channel group of one pixel, the group index fastest (a pixel's groups are one contiguous run)
+struct SumArgs {
+    const void* src[4]; int ss[4]; void* dst; int ds, n, acc, CG; long long total;
+};
+template <typename T, typename V, int N>
+__global__ __launch_bounds__(256) void nhwc_sum_kernel(const SumArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.total) return;
+    const int cg = (int)(i % a.CG);
+    const long long m = i / a.CG;
+    V* q = reinterpret_cast<V*>(static_cast<T*>(a.dst) + m * a.ds + cg * N);
+    if (a.n == 1 && !a.acc) { *q = *reinterpret_cast<const V*>(static_cast<const T*>(a.src[0]) + m * a.ss[0] + cg * N); return; }
+    float s[N];
+    V v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < a.n) v[k] = *reinterpret_cast<const V*>(static_cast<const T*>(a.src[k]) + m * a.ss[k] + cg * N);
+    if (a.acc) { const V d = *q;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = (float)d[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < a.n) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) s[j] += (float)v[k][j];
+        }
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (T)s[j];
+    *q = o;
+}
+
+hipEvent_t g_fork_ev[16] = {};
+
 }  // namespace
+
+extern "C" int maf_nhwc_sum(const void* const* src, const int32_t* src_stride, int32_t n, void* dst, int32_t dst_stride, int64_t M, int32_t C, int32_t dtype,
+                            int32_t accumulate, maf_stream_t stream) {
+    MAF_REQUIRE(src && src_stride && dst && n >= 1 && n <= 4 && M > 0 && C > 0, "nhwc_sum: bad arguments (1..4 sources)");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "nhwc_sum: dtype must be f16/f32");
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    MAF_REQUIRE(C % N == 0 && dst_stride % N == 0, "nhwc_sum: C and strides must be multiples of the 16-byte channel group");
+    SumArgs a = {};
+    for (int i = 0; i < n; ++i) {
+        MAF_REQUIRE(src[i] && src_stride[i] % N == 0, "nhwc_sum: null source / stride not a multiple of the 16-byte channel group");
+        a.src[i] = src[i]; a.ss[i] = src_stride[i];
+    }
+    a.dst = dst; a.ds = dst_stride; a.n = n; a.acc = accumulate ? 1 : 0; a.CG = C / N; a.total = (long long)M * a.CG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)((a.total + 255) / 256)), b(256);
+    if (dtype == MAF_F16) hipLaunchKernelGGL((nhwc_sum_kernel<half_t, half8_t, 8>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((nhwc_sum_kernel<float, f32x4_t, 4>), g, b, 0, s, a);
+    return maf_check_hip(hipGetLastError(), "nhwc_sum launch");
+}
+
+// fork / join of the weight-gradient stream by raw handles: one reusable event per device (a wait captures the record that precedes it)
+extern "C" int maf_stream_fork(maf_stream_t main, maf_stream_t side) {
+    if (main == side) return 0;
+    int dev = 0;
+    if (int rc = maf_check_hip(hipGetDevice(&dev), "stream_fork: hipGetDevice")) return rc;
+    MAF_REQUIRE(dev >= 0 && dev < 16, "stream_fork: device index out of range");
+    if (!g_fork_ev[dev])
+        if (int rc = maf_check_hip(hipEventCreateWithFlags(&g_fork_ev[dev], hipEventDisableTiming), "stream_fork: hipEventCreate")) return rc;
+    if (int rc = maf_check_hip(hipEventRecord(g_fork_ev[dev], static_cast<hipStream_t>(main)), "stream_fork: hipEventRecord")) return rc;
+    return maf_check_hip(hipStreamWaitEvent(static_cast<hipStream_t>(side), g_fork_ev[dev], 0), "stream_fork: hipStreamWaitEvent");
+}
+
+extern "C" int maf_stream_join(maf_stream_t main, maf_stream_t side) { return maf_stream_fork(side, main); }
 
 extern "C" int maf_grad_fold(const float* src, int32_t taps, int32_t Cout_p, int32_t Cin_p, float* dst, int32_t Cout, int32_t Cin, int32_t accumulate,
                              maf_stream_t stream) {

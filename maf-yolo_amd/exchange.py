@@ -225,6 +225,9 @@ class GradExchange:
         if b.launched:
             return
         b.launched = True
+        from . import train_ops
+        if train_ops._rec is not None:                                           # a recording step tape (tape.py) cuts its backward list here: a replay launches the bucket from the same place
+            train_ops._rec.mark_bucket(self.buckets.index(b), b.main_contrib)
         if not self._collectives():
             return
         dist = self.dist
@@ -245,6 +248,23 @@ class GradExchange:
         else:
             b.work = dist.all_reduce(b.flat, op=avg, group=self.group, async_op=True)
         self.stats["collectives"] += 1
+
+    # ------------------------------------------------------------------ replayed passes (tape.py)
+    def ensure_attached(self):
+        """Before a replayed backward: its kernels add into the bucket slices by address, so `p.grad` must be the views — an `optimizer.zero_grad()` with
+        set_to_none=True (the reference trainer's, engine.py:347,388) has dropped them and means 'the gradients are zero'."""
+        if any(b.params[0].grad is None for b in self.buckets):
+            self.zero_grad()
+            self.stats["reattached"] += 1
+
+    def replay_launch(self, index, main_contrib):
+        """A replayed backward has issued every gradient of bucket `index` (the point the recording marked): its all-reduce goes out, as in `_arrived`."""
+        if not self._sync:
+            return
+        b = self.buckets[index]
+        b.main_contrib = bool(main_contrib)
+        self._launch(b)
+        self._next = max(self._next, index + 1)
 
     def finish(self):
         """End of backward: launch what is still open, in bucket order (parameters that received no gradient leave their bucket incomplete),

@@ -205,6 +205,8 @@ class RepHDW(nn.Module):
                     y, cur = train_ops.fork(y)
                 parts.append(y)
             return self.conv2(train_ops.join(cb, parts), out=out)
+        if x.is_cuda:
+            train_ops._glue()                                                    # (split / cat as torch kernels: not a step a tape may record)
         t = self.conv1(x)
         outs = list(t.split((c, c), 1))                                          # split, not slices: its backward is ONE cat of the two gradients
         for blk in self.m:
@@ -239,11 +241,16 @@ class MPRep(nn.Module):
                 holder.append(train_ops.CatBuffer(z, [c, c]))
                 return holder[0].slot(0)
 
-            a = self.conv1(self.mp(x), out=slot0)
-            if holder:
-                b = self.conv2(x, out=holder[0].slot(1))
+            xa, xb = train_ops.fanout(x, 2)                                      # two readers: their gradients meet in one launch (train_ops._Fanout)
+            a = self.conv1(self.mp(xa), out=slot0)
+            if holder and train_ops.cat_free_ok(x, self.conv2.rbr_dense.bn) and train_ops.cat_free_ok(x, self.conv2.rbr_1x1.bn):
+                b = self.conv2(xb, out=holder[0].slot(1))
                 return train_ops.join(holder[0], [a, b])
-            return torch.cat([a, self.conv2(x)], 1)
+            if x.is_cuda:
+                train_ops._glue()
+            return torch.cat([a, self.conv2(xb)], 1)
+        if x.is_cuda:
+            train_ops._glue()
         return torch.cat([self.conv1(self.mp(x)), self.conv2(x)], 1)
 
 
@@ -258,8 +265,32 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(k, 1, k // 2)
 
     def forward(self, x, out=None):
-        x = self.cv1(x)
         k = self.m.kernel_size
+        c = self.cv1.conv.out_channels
+        if train_ops.cat_free_ok(x, self.cv1.bn) and c % 8 == 0 and x.dtype in (torch.float16, torch.float32) and 2 <= k <= 15:
+            # no cat: cv1's apply pass and the three pooling kernels store into their slots of one buffer; a map that feeds the concat AND the next pool gets the
+            # pool's gradient added into its slot of the concat's gradient (train_ops.fork)
+            holder = []
+
+            def slot0(z):
+                holder.append(train_ops.CatBuffer(z, [c] * 4))
+                return holder[0].slot(0)
+
+            t = self.cv1(x, out=slot0)
+            if holder and train_ops.maxpool_native_ok(t, k):
+                cb = holder[0]
+                parts = []
+                for i in range(3):
+                    keep, nxt = train_ops.fork(t)
+                    parts.append(keep)
+                    t = train_ops.maxpool_s1(nxt, k, out=cb.slot(i + 1))
+                parts.append(t)
+                return self.cv2(train_ops.join(cb, parts), out=out)
+            x = t
+        else:
+            x = self.cv1(x)
+        if x.is_cuda:
+            train_ops._glue()
         y1 = train_ops.maxpool_s1(x, k)                                          # csrc/pool_train.hip on CUDA tensors (gather backward), else F.max_pool2d
         y2 = train_ops.maxpool_s1(y1, k)
         return self.cv2(torch.cat((x, y1, y2, train_ops.maxpool_s1(y2, k)), 1), out=out)
@@ -271,6 +302,8 @@ class Concat(nn.Module):
         self.d = dimension
 
     def forward(self, xs):
+        if xs[0].is_cuda:
+            train_ops._glue()
         return torch.cat(xs, self.d)
 
 
@@ -293,11 +326,13 @@ class Head_DepthUni(nn.Module):
             self.reg_pred.weight.zero_()
             self.reg_pred.bias.fill_(1.0)
 
-    def forward(self, x):
+    def forward(self, x, raw=False):
+        """(stem features, class probabilities, box distributions); raw=True: the class LOGITS (Model applies the sigmoid behind a step tape's boundary)."""
         x = self.stem(x)
-        cls = torch.sigmoid(train_ops.conv1x1(self.cls_conv_s(self.cls_conv(x)), self.cls_pred.weight, self.cls_pred.bias))
-        reg = train_ops.conv1x1(self.reg_conv_s(self.reg_conv(x)), self.reg_pred.weight, self.reg_pred.bias)
-        return x, cls, reg
+        xc, xr = train_ops.fanout(x, 2)                                          # two branches read the stem: one launch sums their gradients
+        cls = train_ops.conv1x1(self.cls_conv_s(self.cls_conv(xc)), self.cls_pred.weight, self.cls_pred.bias)
+        reg = train_ops.conv1x1(self.reg_conv_s(self.reg_conv(xr)), self.reg_pred.weight, self.reg_pred.bias)
+        return x, (cls if raw else torch.sigmoid(cls)), reg
 
 
 class Out(nn.Module):

@@ -32,6 +32,23 @@ class MafEmaDesc(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("total", C.c_int64), ("block0", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Phase(int):
+    """The `phase` argument of a BatchNorm scratch (csrc/bn_act.hip: which half this call accumulates into) as a step tape sees it: a word that alternates
+    from replay to replay (tape.py registers a toggle for the argument slot it is passed in)."""
+
+
+TAPE_MAX_ARGS = 28
+
+
+class MafTapeRec(C.Structure):
+    """maf_tape_rec_t (include/mafyolo_hip.h): one recorded C-ABI call of a step tape."""
+    _fields_ = [("fn", C.c_int32), ("stream", C.c_int32), ("a", C.c_uint64 * TAPE_MAX_ARGS)]
+
+
+class MafTapeToggle(C.Structure):
+    _fields_ = [("addr", C.c_void_p), ("mask", C.c_uint64), ("width", C.c_int32), ("reserved", C.c_int32)]
+
+
 class MafOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("in_dtype", C.c_int32), ("act", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
@@ -47,9 +64,11 @@ class MafOp(C.Structure):
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
            "maf_engine_run", "maf_engine_run_filtered", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_ex", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_pack_batch", "maf_pack_desc_size", "maf_ema_update", "maf_ema_desc_size", "maf_maxpool_forward", "maf_maxpool_backward", "maf_upsample2x_forward", "maf_upsample2x_backward", "maf_zero", "maf_grad_fold", "maf_add_sub2", "maf_colsum", "maf_dw_wgrad", "maf_bottleneck_record_bytes", "maf_bottleneck_tail_record_bytes", "maf_bottleneck_tail_supported", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_mprep_lds_record_bytes", "maf_mprep_wreg_record_bytes", "maf_conv3s2_wreg_record_bytes", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_bn_backward_acc", "maf_set_deterministic", "maf_dw_branches", "maf_dw_branches_stats", "maf_bn_forward_ex", "maf_bn_replicas", "maf_bn_stats", "maf_bn_sum_forward", "maf_bn_sum_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
+           "maf_nhwc_sum", "maf_stream_fork", "maf_stream_join", "maf_tape_fn_id", "maf_tape_fn_nargs", "maf_tape_rec_size", "maf_tape_run", "maf_tape_toggle",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
 _lib = None
+_recorder = None              # while a step tape records (tape.py): load() hands out a proxy that notes every tape-able call beside making it
 
 
 class MafError(RuntimeError):
@@ -59,6 +78,8 @@ class MafError(RuntimeError):
 def load():
     """Load the HIP library (once). Raises MafError if it has not been built (run __graft_entry__.build())."""
     global _lib
+    if _recorder is not None:
+        return _recorder
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -154,6 +175,18 @@ def load():
     lib.maf_pack_desc_size.restype = C.c_int32
     lib.maf_ema_desc_size.restype = C.c_int32
     lib.maf_dw_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.maf_nhwc_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.maf_stream_fork.argtypes = [C.c_void_p, C.c_void_p]
+    lib.maf_stream_join.argtypes = [C.c_void_p, C.c_void_p]
+    lib.maf_tape_fn_id.argtypes = [C.c_char_p]
+    lib.maf_tape_fn_id.restype = C.c_int32
+    lib.maf_tape_fn_nargs.argtypes = [C.c_int32]
+    lib.maf_tape_fn_nargs.restype = C.c_int32
+    lib.maf_tape_rec_size.restype = C.c_int32
+    lib.maf_tape_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.maf_tape_toggle.argtypes = [C.c_void_p, C.c_int32]
+    if lib.maf_tape_rec_size() != C.sizeof(MafTapeRec):
+        raise MafError("libmafyolo_hip.so was built for a maf_tape_rec_t of %d bytes, this binding declares %d: rebuild" % (lib.maf_tape_rec_size(), C.sizeof(MafTapeRec)))
     lib.maf_timer_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.maf_timer_start.argtypes = [C.c_void_p, C.c_void_p]
     lib.maf_timer_stop.argtypes = [C.c_void_p, C.c_void_p]

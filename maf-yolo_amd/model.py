@@ -77,6 +77,10 @@ def _nodes_from_config(config, num_classes):
 _VERSION = attrgetter("_version")
 
 
+class _Aliases(list):
+    """The aliases train_ops.fanout made of a node's output: every reader pops one."""
+
+
 class Model(nn.Module):
     def __init__(self, config="n", channels=3, num_classes=80, anchors=1, precision=None, dispatch="engine"):
         super().__init__()
@@ -128,6 +132,7 @@ class Model(nn.Module):
         self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
+        self.step_tape = "auto"               # training: replay the recorded launch lists of a step (tape.py) once a batch shape has been seen RECORD_AT times under a GradExchange; False: always eager
         assert dispatch in ("engine", "ops")
         self.dispatch = dispatch              # "engine": one C call per forward (engine.py) | "ops": the graph op by op through torch.ops.mafyolo (ops_forward.py)
 
@@ -152,6 +157,7 @@ class Model(nn.Module):
         self._plans_version = None
         self._fp_tensors = None
         self._pack_plan = None                 # training: the staged weight transforms point at the old parameter storage
+        self._tapes = {}                       # ... and so do the recorded launch lists
         self._ops_weights = (None, None)
 
     def _apply(self, fn, *a, **k):
@@ -184,6 +190,7 @@ class Model(nn.Module):
         plans, self._plans = self._plans, {}
         fpt, self._fp_tensors = self._fp_tensors, None
         pp, self._pack_plan = getattr(self, "_pack_plan", None), None
+        tp, self._tapes = getattr(self, "_tapes", {}), {}
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -191,17 +198,18 @@ class Model(nn.Module):
             for k, v in self.__dict__.items():
                 new.__dict__[k] = copy.deepcopy(v, memo)
         finally:
-            self._plans, self._fp_tensors, self._pack_plan = plans, fpt, pp
+            self._plans, self._fp_tensors, self._pack_plan, self._tapes = plans, fpt, pp, tp
         return new
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_plans"] = {}
         d["_fp_tensors"] = d["_plans_version"] = d["_pack_plan"] = None
+        d["_tapes"] = {}
         return d
 
     # ------------------------------------------------------------------ forward
-    def _forward_train_form(self, x):
+    def _forward_train_form(self, x, raw_heads=False):
         if getattr(self, "_pack_plan", None) is None:
             self._pack_plan = train_ops.PackPlan()
         train_ops.begin_step(self._pack_plan, x.device)          # every weight transform of the step in one launch (train_ops.PackPlan)
@@ -228,20 +236,84 @@ class Model(nn.Module):
                 return cb.slot(slot)
             return f
 
+        # a map several later nodes read (every backbone level feeds the neck two to four times): one alias per reader, their gradients summed by ONE launch
+        # (train_ops.fanout) instead of the autograd engine's add kernel per extra reader
+        uses = getattr(self, "_node_uses", None)
+        if uses is None:
+            uses = self._node_uses = {}
+            for nd in self.nodes:
+                if nd.i > 0:
+                    for j in nd.sources():
+                        uses[j] = uses.get(j, 0) + 1
         y = []
         for nd, m in zip(self.nodes, self.backbone):
             if nd.i > 0:
-                src = [y[j] for j in nd.sources()]
+                src = [y[j].pop() if isinstance(y[j], _Aliases) else y[j] for j in nd.sources()]
                 x = src if isinstance(nd.f, list) else src[0]
             r = res.get(nd.i) if train_ops.cat_free else None
             if r is not None:
                 x = m(x, out=slot_of(*r))
             elif nd.i in bufs:
                 x = train_ops.join(bufs.pop(nd.i), x)
+            elif raw_heads and isinstance(m, Head_DepthUni):
+                x = m(x, raw=True)
             else:
                 x = m(x)
+            n_use = uses.get(nd.i, 0)
+            if n_use > 1 and isinstance(x, torch.Tensor) and x.is_cuda and x.requires_grad and train_ops.cat_free:
+                x = _Aliases(train_ops.fanout(x, n_use))
             y.append(x)
         return x                              # list of three (stem, cls, reg)
+
+    def _train_heads(self, x):
+        """[(stem features, class probabilities, box distributions)] per level of a train-mode forward: eager (layers.py op by op), or — steady state of a
+        training loop under a GradExchange — the recorded launch lists of tape.py."""
+        tape = self._tape_for(x)
+        if tape is None:
+            if x.is_cuda:
+                x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
+            return self._forward_train_form(x)
+        if tape.ready:
+            heads = tape.replay_forward(x)
+        else:
+            heads = tape.record_forward(self, x)
+        return [(f, torch.sigmoid(c), r) for f, c, r in heads]
+
+    def _tape_for(self, x):
+        """The step tape this forward runs on (ready: replay; not ready: this call records), or None for the eager path."""
+        from . import exchange, tape as _tape
+        ex = exchange.current
+        if (not getattr(self, "step_tape", "auto") or ex is None or not x.is_cuda or x.dim() != 4 or x.shape[1] != 3 or not torch.is_grad_enabled()
+                or train_ops.profile is not None or train_ops.framework_ops or train_ops._deterministic or not train_ops.cat_free or train_ops._rec is not None):
+            return None
+        half = x.dtype == torch.float16 or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)
+        if not half or x.dtype not in (torch.float16, torch.float32) or x.shape[2] % 32 or x.shape[3] % 32:
+            return None
+        if not hasattr(self, "_tapes"):
+            self._tapes = {}
+        key = (tuple(x.shape), x.dtype, x.device.index, id(ex), train_ops._stream(x.device), train_ops.wgrad_stream)
+        ent = self._tapes.get(key)
+        if ent is None:
+            if len(self._tapes) >= 4:
+                self._tapes.pop(next(iter(self._tapes)))
+            ent = self._tapes[key] = [0, None, 0]                            # forwards seen, tape, recordings tried
+        ent[0] += 1
+        tp = ent[1]
+        if tp is not None:
+            if tp.ready:
+                if tp.pending_backward:                                          # a second forward before the first one's backward: the static buffers are taken
+                    return None
+                return tp
+            if tp.failed is not None or tp.phase is not None:
+                return None                                                      # the recording was dropped (tp.failed says why): eager from here on
+            ent[1] = tp = None                                                   # recorded forward whose backward never ran: try again
+        pp = getattr(self, "_pack_plan", None)
+        if (ent[0] < _tape.RECORD_AT or ent[2] >= 2 or pp is None or pp.dirty or pp.table is None                # (the staging plan of the weights must have settled:
+                or any(not p_.is_cuda for p_ in self.parameters())):                                             #  its table upload is a torch copy)
+            return None
+        ent[2] += 1
+        ent[1] = _tape.StepTape(ex, x.device)
+        return ent[1]
 
     def plan_for(self, x, head_feats=False, slot=0):
         """head_feats: the caller wants the per-level cls / reg tensors (featmaps): plan without the fused head tail.
@@ -301,9 +373,7 @@ class Model(nn.Module):
 
     def forward(self, x, val_loss=False, slot=0):
         if self.training:
-            if x.is_cuda:
-                x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
-            heads = self._forward_train_form(x)
+            heads = self._train_heads(x)
             return [self.detect(heads), list(heads)]
         if getattr(self, "dispatch", "engine") == "ops" and not val_loss:
             # the same graph as a sequence of torch.ops.mafyolo.* calls (ops_forward.py): what torch.compile / export can trace

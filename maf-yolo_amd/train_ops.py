@@ -36,6 +36,38 @@ profile = None
 framework_ops = False
 
 
+# A step tape that is recording (tape.py) keeps every buffer a recorded launch may touch alive: the replays use the recorded addresses.
+_keep = None
+_rec = None                  # the recording tape itself (BatchNorm scratches get a buffer per call site and a toggled phase word)
+
+
+def _empty(*a, **k):
+    t = torch.empty(*a, **k)
+    if _keep is not None:
+        _keep.append(t)
+    return t
+
+
+_in_alloc = False             # (the fill kernel of a zeroed allocation is not glue: tape.py's debug check skips it)
+
+
+def _tzeros(*a, **k):
+    global _in_alloc
+    _in_alloc = True
+    try:
+        t = torch.zeros(*a, **k)
+    finally:
+        _in_alloc = False
+    if _keep is not None:
+        _keep.append(t)
+    return t
+
+
+def _glue(n=1):
+    """A torch kernel ran where the HIP path has none (an unusual layout, a fall-back branch): counted — a step tape refuses a step that contains one."""
+    stats["glue"] = stats.get("glue", 0) + n
+
+
 def set_deterministic(on=True):
     """Bit-reproducible BatchNorm statistics (csrc/bn_act.hip, maf_set_deterministic): a test / debugging mode — three launches per BatchNorm pass and
     per-workgroup slots instead of atomics.  The forward pass of the train-form graph is then bit-identical from run to run (the weight-gradient
@@ -141,13 +173,13 @@ def _fork(dev, *tensors):
     if not wgrad_stream:
         return _stream(dev)
     side = side_stream(dev)
-    ev = _side_events[dev.index]                                                 # one reusable event: a wait captures the record that precedes it
-    ev.record()                                                                  # ... on the current (main) stream
-    side.wait_event(ev)
-    for t in tensors:
-        t.record_stream(side)
+    h = side.cuda_stream
+    lib.check(lib.load().maf_stream_fork(_stream(dev), h))                       # event record on the main stream + wait on the side stream, by raw handles (a step tape records it)
+    if _keep is None:                                                            # (a recording tape keeps every buffer alive itself)
+        for t in tensors:
+            t.record_stream(side)
     _side_used[dev.index] = True
-    return side.cuda_stream
+    return h
 
 
 def _side_done(dev, returned_dw):
@@ -172,7 +204,7 @@ def _grad_sink(w):
 def _zero_bias(dev, n):
     z = _zeros.get(dev.index)
     if z is None or z.numel() < n:
-        z = _zeros[dev.index] = torch.zeros(max(n, 4096), dtype=torch.float32, device=dev)
+        z = _zeros[dev.index] = _tzeros(max(n, 4096), dtype=torch.float32, device=dev)
     return z
 
 
@@ -182,6 +214,8 @@ def nhwc(t):
     s = t.stride()
     if s[1] == 1 and s[3] >= Cc and s[2] == W * s[3] and s[0] == H * W * s[3]:
         return t, s[3]
+    if t.is_cuda:
+        _glue()
     t = t.contiguous(memory_format=torch.channels_last)
     return t, t.stride()[3]
 
@@ -272,7 +306,7 @@ def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
                     cands.append((pt, ct, 2))
     if (pt0, ct0, 1) not in cands:
         cands.append((pt0, ct0, 1))
-    out = torch.empty((B, Nc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    out = _empty((B, Nc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     torch.cuda.synchronize(x.device)                                            # a quiet chip: the side stream's weight gradients would be in the timings
     timer, st, res, packs = lib.Timer(), _stream(x.device), [], {}
     global profile
@@ -367,7 +401,7 @@ def _staged(param, key, nbytes, fields, pack_now):
     the transform for the next step); without a plan a fresh buffer."""
     plan = _plan
     if plan is None:
-        dst = torch.empty(nbytes, dtype=torch.uint8, device=param.device)
+        dst = _empty(nbytes, dtype=torch.uint8, device=param.device)
         pack_now(dst)
         return dst
     k = (param.data_ptr(),) + key
@@ -377,7 +411,7 @@ def _staged(param, key, nbytes, fields, pack_now):
     if e is None:
         if len(plan.entries) >= 4096:                                            # not a model's fixed set of parameters: start over
             plan.clear()
-        e = plan.entries[k] = [param, torch.empty(nbytes, dtype=torch.uint8, device=param.device), fields, -1]
+        e = plan.entries[k] = [param, _empty(nbytes, dtype=torch.uint8, device=param.device), fields, -1]
         plan.dirty = True
     pack_now(e[1])
     e[3] = -1                                                                    # valid for this call only: the batch sets the version
@@ -398,7 +432,7 @@ def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev, param=None):
         lib.check(L.maf_pack_w1x1(w2d.data_ptr(), cout, cin, transpose, dt, ct, dst.data_ptr(), _stream(dev)))
 
     if param is None or w2d.data_ptr() != param.data_ptr() or param.dtype != torch.float32 or not param.is_leaf:
-        buf = torch.empty(n, dtype=torch.uint8, device=dev)
+        buf = _empty(n, dtype=torch.uint8, device=dev)
         now(buf)
         return buf
     ks = 32 if dt == lib.F16 else 16
@@ -408,7 +442,28 @@ def _packed_1x1(w2d, cout, cin, transpose, dt, ct, dev, param=None):
     return _staged(param, ("d", cout, cin, 1, transpose, dt, ct), n, fields, now)
 
 
-_bias_pad = {}
+def _staged_bias(bias, cout, npad, dev):
+    """fp32 [npad]: the bias of a prediction conv followed by zeros (the conv reads its whole channel tile).  A parameter's copy is one more transform of the step's
+    pack batch (kind 2); anything else is padded here."""
+    def now(dst):
+        d = dst.view(torch.float32)
+        d.zero_()
+        d[:cout].copy_(bias.detach())
+
+    if not (isinstance(bias, torch.nn.Parameter) and bias.dtype == torch.float32 and bias.is_contiguous() and bias.is_leaf):
+        buf = _empty(npad * 4, dtype=torch.uint8, device=dev)
+        now(buf)
+        return buf
+    hit = _hit(bias, ("b", cout, npad))
+    if hit is not None:
+        return hit
+    fields = dict(kind=2, dtype=lib.F32, Cout=cout, Cin=1, taps=1, transpose=0, CT=0, steps=0, Kp=0, flip=0, total=npad)
+    return _staged(bias, ("b", cout, npad), npad * 4, fields, now)
+
+
+# data_ptr -> channels: gradient buffers whose channels [C, that many) are kept zero by their producer (a step tape's boundary pads the 68 channels of a
+# reg_pred gradient to 72 once): _Conv1x1.backward reads them as they are instead of padding a copy
+zero_padded = {}
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -439,14 +494,8 @@ class _Conv1x1(torch.autograd.Function):
         if bias is None:
             bp = _zero_bias(x.device, npad)
         else:
-            # one buffer per (stream, bias length, padded length), zero behind the bias: the copy and the conv that reads it are ordered on the stream, so
-            # equal-shaped layers share it (a fresh zeros + slice assignment were two launches per call)
-            key = (x.device.index, _stream(x.device), cout, npad)
-            bp = _bias_pad.get(key)
-            if bp is None:
-                bp = _bias_pad[key] = torch.zeros(npad, dtype=torch.float32, device=x.device)
-            bp[:cout].copy_(bias.detach())
-        out = torch.empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            bp = _staged_bias(bias, cout, npad, x.device)                       # the bias on the conv's channel tile, zero behind it: staged by the step's pack batch
+        out = _empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt, pt, tk)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
@@ -461,6 +510,7 @@ class _Conv1x1(torch.autograd.Function):
         cout = w.shape[0]
         dy, dys = nhwc(dy)
         if dy.dtype != x.dtype:
+            _glue()
             dy = dy.to(x.dtype)
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
@@ -469,8 +519,12 @@ class _Conv1x1(torch.autograd.Function):
         dyk, dyks, kk = dy, dys, cout
         if cout % mult and (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and x.dtype == torch.float16)):
             kk = -(-cout // mult) * mult                                         # e.g. reg_pred: 68 channels in fp16 — dY zero-padded to whole 16-byte chunks ONCE, for
-            dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)     # the weight gradient and the data gradient's reduction dim
-            dyks = kk
+            if dys >= kk and zero_padded.get(dy.data_ptr(), 0) >= kk:            # the weight gradient and the data gradient's reduction dim
+                dyk = dy.as_strided((B, kk, H, W), dy.stride())                  # its producer keeps the padding channels zero: no copy
+            else:
+                _glue()
+                dyk = F.pad(dy, (0, 0, 0, 0, 0, kk - cout)).contiguous(memory_format=torch.channels_last)
+                dyks = kk
         if ctx.has_bias and ctx.needs_input_grad[2]:
             ex, view = _grad_sink(ctx.bias_param) if ctx.bias_param is not None and x.dtype == torch.float16 else (None, None)
             if ex is not None and view.is_contiguous() and cout <= 256:
@@ -491,23 +545,22 @@ class _Conv1x1(torch.autograd.Function):
                 dw = torch.mm(d2.t(), x2).float().reshape(w.shape).to(w.dtype)
                 stats["framework_wgrad_fp32"] = stats.get("framework_wgrad_fp32", 0) + 1
         if ctx.needs_input_grad[0]:
+            # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci].  A dY padded to kk > cout channels needs no padded weight: the packer zero-fills K up to whole k-steps,
+            # and rounding cout up to 8 never crosses one — the fragment record of [cout] rows IS the one of [kk] rows
             w2d = None
-            if kk != cout:
-                w2d = F.pad(w.detach().reshape(cout, cin).float(), (0, 0, 0, kk - cout))
             M = B * H * W
             choice = _conv_tune.get((M, kk, cin, dyks)) if conv_autotune and dt == lib.F16 else None
             if choice is None:
-                if w2d is None:
-                    w2d = w.detach().reshape(cout, cin).float().contiguous()
-                choice = _conv_choice(dyk, dyks, B, H, W, kk, cin, dt, w2d, kk, cin, 1)
+                w2d = w.detach().reshape(cout, cin).float().contiguous()
+                choice = _conv_choice(dyk, dyks, B, H, W, kk, cin, dt, w2d, cout, cin, 1)
             pt, ct, tk = choice
-            wp = _hit(w, ("d", cout, cin, 1, 1, dt, ct)) if kk == cout else None
+            wp = _hit(w, ("d", cout, cin, 1, 1, dt, ct))
             if wp is None:
                 if w2d is None:
                     w2d = w.detach().reshape(cout, cin).float().contiguous()
-                wp = _packed_1x1(w2d, kk, cin, 1, dt, ct, x.device, w if kk == cout else None)   # W^T: dX[m, ci] = sum_co dY[m, co] W[co, ci]
+                wp = _packed_1x1(w2d, cout, cin, 1, dt, ct, x.device, w)
             npad = -(-cin // (16 * ct)) * 16 * ct
-            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            dx = _empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt, pt, tk)
         _side_done(x.device, dw is not None)
         return dx, dw, db
@@ -532,7 +585,7 @@ def _wgrad(x, dy, dys, w, ksize, stride):
         dwf = view
         h = _fork(x.device, xx, dy)
     else:
-        dwf = torch.empty((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)       # 3x3: tap-major (csrc/wgrad.hip)
+        dwf = _empty((co, cin) if ksize == 1 else (3, 3, co, cin), dtype=torch.float32, device=x.device)       # 3x3: tap-major (csrc/wgrad.hip)
         h = _fork(x.device, xx, dy, dwf)
         lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
     with _prof("conv_wgrad_k%d" % ksize, (B * Hs * Ws * cin + B * Ho * Wo * co) * 2 + dwf.numel() * 4, x.device, (B, Hs, Ws, cin, co, xs, dys, stride), h):
@@ -572,7 +625,7 @@ def _packed_3x3(w, transpose, dt, ct, dev):
 
     nbytes = lib.load().maf_pack_w1x1_bytes(n, 9 * kp, 0, dt, ct)
     if not (w.dtype == torch.float32 and w.is_contiguous() and w.is_leaf):        # a temporary (e.g. the stem's channel-padded filters): no plan entry
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        buf = _empty(nbytes, dtype=torch.uint8, device=dev)
         now(buf)
         return buf
     fields = dict(kind=0, dtype=dt, Cout=cout, Cin=cin, taps=9, transpose=int(transpose), CT=ct, steps=9 * kp // ks, Kp=kp, flip=0,
@@ -593,7 +646,7 @@ class _Conv3x3s2(torch.autograd.Function):
         dt = _DT[x.dtype]
         pt, ct = pack.tile_for(cout, B * Ho * Wo)
         wp = _packed_3x3(w, False, dt, ct, x.device)
-        out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        out = _empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         op = lib.MafOp()
         op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2, dt, dt, lib.ACT_NONE
         op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, Ho, Wo, H, W, cin, cout, 1
@@ -615,6 +668,7 @@ class _Conv3x3s2(torch.autograd.Function):
         cout = w.shape[0]
         dy, dys = nhwc(dy)
         if dy.dtype != x.dtype:
+            _glue()
             dy = dy.to(x.dtype)
             dys = dy.stride()[3]
         Ho, Wo = dy.shape[2:]
@@ -630,7 +684,7 @@ class _Conv3x3s2(torch.autograd.Function):
             # (an input whose channels were padded — the image — gets zeros in the padding: the packer pads W^T's rows to the channel tile)
             pt, ct = _tile_dgrad(cin, B * H * W)
             wp = _packed_3x3(w, True, dt, ct, x.device)
-            dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            dx = _empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             op = lib.MafOp()
             op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2_DGRAD, dt, dt, lib.ACT_NONE
             op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, H, W, Ho, Wo, cout, cin, 1
@@ -660,7 +714,7 @@ class _Conv1x1s2(torch.autograd.Function):
         pt, ct = pack.tile_for(cout, B * Ho * Wo)
         cin_w = w.shape[1]                                                       # < cin for the stem: the image's channels are padded to 8, the weight's K to whole k-steps by the packer
         wp = _packed_1x1(w.detach().reshape(cout, cin_w).float().contiguous(), cout, cin_w, 0, dt, ct, x.device, w)
-        out = torch.empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        out = _empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         op = lib.MafOp()
         op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, dt, dt, lib.ACT_NONE
         op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, Ho, Wo, cin, cout, 1
@@ -681,6 +735,7 @@ class _Conv1x1s2(torch.autograd.Function):
         cout = w.shape[0]
         dy, dys = nhwc(dy)
         if dy.dtype != x.dtype:
+            _glue()
             dy = dy.to(x.dtype)
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
@@ -696,12 +751,13 @@ class _Conv1x1s2(torch.autograd.Function):
             cin_w = w.shape[1]                                                   # < cin: padded image channels get a zero gradient (W^T's rows are padded to the channel tile)
             ct = pack.tile_for(cin, B * (H // 2) * (W // 2))[1]
             wp = _packed_1x1(w.detach().reshape(cout, cin_w).float().contiguous(), cout, cin_w, 1, dt, ct, x.device, w)
-            dxs = torch.empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            dxs = _empty((B, cin, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dy, dys, wp, _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct), B, H // 2, W // 2, cout, cin, ct, dxs, dt)
             if getattr(ctx, "compact", False):                                   # _RepVGGConvs adds it onto the 3x3 branch's data gradient itself
                 dx = dxs
             else:
-                dx = torch.empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+                _glue(2)
+                dx = _empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
                 dx[:, :, ::2, ::2] = dxs
         _side_done(x.device, dw is not None)
         return dx, dw
@@ -846,7 +902,7 @@ def _packed_dw(w, c, k, flip, dt, dev):
         lib.check(lib.load().maf_pack_dw(wf.data_ptr(), c, k, flip, dt, dst.data_ptr(), _stream(dev)))
 
     if not (w.dtype == torch.float32 and w.is_contiguous() and w.is_leaf):
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        buf = _empty(nbytes, dtype=torch.uint8, device=dev)
         now(buf)
         return buf
     fields = dict(kind=1, dtype=dt, Cout=c, Cin=1, taps=k * k, transpose=0, CT=0, steps=0, Kp=0, flip=flip, total=c * k * k)
@@ -860,7 +916,7 @@ class _DWConv(torch.autograd.Function):
         B, c, H, W = x.shape
         k = w.shape[-1]
         dt = _DT[x.dtype]
-        out = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        out = _empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _launch_dw(x, xs, _packed_dw(w, c, k, 0, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, out, dt)
         ctx.save_for_backward(x, w)
         stats["native_dwconv"] += 1
@@ -873,6 +929,7 @@ class _DWConv(torch.autograd.Function):
         k = w.shape[-1]
         dy, dys = nhwc(dy)
         if dy.dtype != x.dtype:
+            _glue()
             dy = dy.to(x.dtype)
             dys = dy.stride()[3]
         dt = _DT[x.dtype]
@@ -882,7 +939,7 @@ class _DWConv(torch.autograd.Function):
             # first version spread its atomics over (and the torch sum behind them) buy <= 7 % on the 160 x 160 layers and nothing elsewhere
             dw = _dw_wgrad(x, dy, dys, w)
         if ctx.needs_input_grad[0]:                                              # correlation with the flipped kernel
-            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            dx = _empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_dw(dy, dys, _packed_dw(w, c, k, 1, dt, x.device), _zero_bias(x.device, c), B, H, W, c, k, dx, dt)
         _side_done(x.device, dw is not None)
         return dx, dw
@@ -901,7 +958,7 @@ def _dw_wgrad(x, dy, dys, w):
         dwf = view
         h = _fork(x.device, xx, dy)
     else:
-        dwf = torch.empty(c, k * k, dtype=torch.float32, device=x.device)
+        dwf = _empty(c, k * k, dtype=torch.float32, device=x.device)
         h = _fork(x.device, xx, dy, dwf)
         lib.check(L.maf_zero(dwf.data_ptr(), dwf.numel() * 4, h))
     with _prof("dw_wgrad_k%d" % k, 2 * B * H * W * c * x.element_size(), x.device, (B, H, W, c, k, xs, dys), h):
@@ -927,6 +984,8 @@ def _launch_dwb(srcs, dsts, wps, k0, B, H, W, c, dt, dgrad, dev, bstats=None):
         if bstats is not None:                                                   # [(scratch, phase)] per branch: the half its BatchNorm call will read
             half = _BN_REPLICAS * 2 * (-(-c // 256) * 256)
             stp = _PTR4(*[0 if st is None else st[0].data_ptr() + 4 * st[1] * half for st in bstats])
+            if _rec is not None:                                                 # the half alternates from replay to replay: the pointer words toggle between the two
+                _rec.toggle_array(stp, [(j, st[0].data_ptr() ^ (st[0].data_ptr() + 4 * half), 8) for j, st in enumerate(bstats) if st is not None])
             lib.check(L.maf_dw_branches_stats(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, stp, L.maf_bn_replicas(c, _BN_REPLICAS), _stream(dev)))
         else:
             lib.check(L.maf_dw_branches(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, 1 if dgrad else 0, _stream(dev)))
@@ -942,7 +1001,7 @@ class _DWBranches(torch.autograd.Function):
         B, c, H, W = x.shape
         dt = _DT[x.dtype]
         dev = x.device
-        outs = [torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) for _ in ws]
+        outs = [_empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) for _ in ws]
         _launch_dwb([x], outs, [_packed_dw(w, c, w.shape[-1], 0, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, False, dev, bstats)
         ctx.save_for_backward(x, *ws)
         stats["native_dwconv"] += len(ws)
@@ -958,7 +1017,8 @@ class _DWBranches(torch.autograd.Function):
         dzs = []
         for dy in dys:
             if dy is None:                                                       # a branch nobody used (not in the reference's graph): zero gradient
-                dy = torch.zeros((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+                _glue()
+                dy = _tzeros((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             dy, _ = nhwc(dy)
             dzs.append(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dws = [None] * len(ws)
@@ -969,7 +1029,7 @@ class _DWBranches(torch.autograd.Function):
                 returned = returned or dws[j] is not None
         dx = None
         if ctx.needs_input_grad[0]:                                              # sum over the branches of the correlation with the flipped kernel
-            dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            dx = _empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             _launch_dwb(dzs, [dx], [_packed_dw(w, c, w.shape[-1], 1, dt, dev) for w in ws], ws[0].shape[-1], B, H, W, c, dt, True, dev)
         _side_done(dev, returned)
         return (dx, None, *dws)
@@ -990,9 +1050,11 @@ def bn_own_scratch(bn, dev, c):
     """(scratch, phase) of a BatchNorm whose statistics are produced by ANOTHER kernel than its own call (the depth-wise kernel of csrc/dw_branches.hip):
     a buffer per module — the shared per-stream one alternates its halves call by call, and the apply pass of the call in front would clear the half this
     call's producer has just filled — whose halves alternate step by step (the apply pass clears the half of the step before, as always)."""
+    if _rec is not None:                                                         # a recording step tape: a scratch of its own per call site, the phase a toggled word
+        return _tzeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), lib.Phase(0)
     ent = _own_scratch.get(bn)
     if ent is None or ent[0].device != dev or ent[2] != c:
-        ent = _own_scratch[bn] = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1, c]
+        ent = _own_scratch[bn] = [_tzeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1, c]
     ent[1] ^= 1
     return ent[0], ent[1]
 
@@ -1028,12 +1090,14 @@ def _bn_part(dev, c):
     """(scratch, phase): [2][R][2][roundup(c,256)] fp32, zeroed when it is allocated; a BatchNorm call accumulates into half `phase` and clears
     the other one (csrc/bn_act.hip), so the phase alternates per call on a buffer — kernels on one stream are ordered, different streams get
     different buffers."""
+    if _rec is not None:
+        return _tzeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), lib.Phase(0)
     key = (dev.index, _stream(dev), -(-c // 256))
     ent = _bn_scratch.get(key)
     if ent is None:
         if len(_bn_scratch) > 64:
             _bn_scratch.clear()
-        ent = _bn_scratch[key] = [torch.zeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
+        ent = _bn_scratch[key] = [_tzeros(2 * _BN_REPLICAS * 2 * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
     ent[1] ^= 1
     return ent[0], ent[1]
 
@@ -1048,8 +1112,8 @@ class _BNAct(torch.autograd.Function):
         dt = _DT[x.dtype]
         dev = x.device
         # out: the caller's slot of a concat buffer (an NHWC channel slice, cat_buffer below): the apply pass stores there and the cat never runs
-        y = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) if out is None else out[0]      # (a tuple: not an input of the autograd node)
-        stat = torch.empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
+        y = _empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last) if out is None else out[0]      # (a tuple: not an input of the autograd node)
+        stat = _empty(2, c, dtype=torch.float32, device=dev)                 # save_mean, save_rstd
         sp = stat.data_ptr()                                                      # (pointer arithmetic: indexing a tensor costs ~2 us of host time, 4 per call)
         part, phase = _bn_part(dev, c) if pre_stats is None else pre_stats       # pre_stats: (scratch, phase) whose half the producer of x has filled
         g32 = gamma.detach() if gamma.dtype == torch.float32 and gamma.is_contiguous() else gamma.detach().float().contiguous()
@@ -1090,7 +1154,7 @@ class _BNAct(torch.autograd.Function):
             dzs = dz.stride()[3]
         x, xs = nhwc(x)
         dev = x.device
-        dx = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        dx = _empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         # with a gradient exchange the apply kernel ADDS dgamma / dbeta to the parameters' bucket slices (main stream) and autograd gets None:
         # no AccumulateGrad add kernel per affine parameter (280 launches per step of n)
         from . import exchange
@@ -1098,12 +1162,12 @@ class _BNAct(torch.autograd.Function):
         if ex is not None and ctx.affine is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and bn_affine_direct:
             tg, tb = ex.target(ctx.affine[0]), ex.target(ctx.affine[1])
         direct = tg is not None and tb is not None and tg[1].is_contiguous() and tb[1].is_contiguous()
-        dgb = None if direct else torch.empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
+        dgb = None if direct else _empty(2, c, dtype=torch.float32, device=dev)                  # dgamma, dbeta
         part, phase = _bn_part(dev, c)
         dres, rs = None, 0
         if residual is not None:
             residual, rs = nhwc(residual)
-            dres = torch.empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            dres = _empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         npass = 5 if residual is None else 8
         with _prof("bn_act_backward", npass * B * H * W * c * x.element_size(), dev, (B, H, W, c, xs, dzs, ctx.act)):      # reduction pass (x, dz read) + apply pass (x, dz read, dx written)
             lib.check(lib.load().maf_bn_backward_acc(x.data_ptr(), xs, dz.data_ptr(), dzs, B * H * W, c, _DT[x.dtype], g32.data_ptr(), b32.data_ptr(),
@@ -1192,13 +1256,13 @@ class CatBuffer:
         self.offs = [0]
         for w in widths:
             self.offs.append(self.offs[-1] + w)
-        self.buf = torch.empty((B, self.offs[-1], H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+        self.buf = _empty((B, self.offs[-1], H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
 
     def slot(self, i, n=1):
         """Channels of slots i .. i + n - 1 as a tensor of its own on the buffer's storage — NOT a view of `buf` for autograd: a slot becomes the output of its
         producer's autograd node, and a view whose base is written through another view later (join's copies) is refused there."""
         b = self.buf
-        t = torch.empty(0, dtype=b.dtype, device=b.device)
+        t = _empty(0, dtype=b.dtype, device=b.device)
         t.set_(b.untyped_storage(), b.storage_offset() + self.offs[i], (b.shape[0], self.offs[i + n] - self.offs[i], b.shape[2], b.shape[3]), b.stride())
         return t
 
@@ -1213,8 +1277,17 @@ class _Join(torch.autograd.Function):
             raise lib.MafError("join: the parts' channels must add up to the buffer's")
         es = cb.buf.element_size()
         for i, (p_, o) in enumerate(zip(parts, ctx.offs)):
-            if p_.data_ptr() != cb.buf.data_ptr() + o * es or p_.stride() != cb.buf.stride():     # not stored there by its producer (e.g. an up-sampled map): one strided copy
-                cb.slot(i).copy_(p_)
+            if p_.data_ptr() != cb.buf.data_ptr() + o * es or p_.stride() != cb.buf.stride():     # not stored there by its producer (e.g. a map a second concat lists): one strided copy
+                # (the channel range comes from the parts' own widths — ctx.offs, what backward slices by — not from the buffer's slot table: a part may span several slots)
+                b_ = cb.buf
+                dst = _empty(0, dtype=b_.dtype, device=b_.device)
+                dst.set_(b_.untyped_storage(), b_.storage_offset() + o, (b_.shape[0], p_.shape[1], b_.shape[2], b_.shape[3]), b_.stride())
+                mult = 8 if b_.dtype == torch.float16 else 4
+                if b_.is_cuda and not framework_ops and b_.dtype in _DT and p_.shape[1] % mult == 0 and o % mult == 0 and nhwc(p_)[0] is p_:
+                    nhwc_sum([p_], dst)
+                else:
+                    _glue()
+                    dst.copy_(p_)
                 stats["cat_copied_parts"] = stats.get("cat_copied_parts", 0) + 1
         stats["cat_free"] = stats.get("cat_free", 0) + 1
         return cb.buf
@@ -1228,6 +1301,8 @@ def join(cb, parts):
     """The concat of `parts` along the channels in CatBuffer `cb`: parts their producer stored into their slot (`bn_act(out=cb.slot(i))`) cost nothing, any
     other part is copied into its slot."""
     if any(p_.dtype != cb.buf.dtype or p_.shape[0] != cb.buf.shape[0] or p_.shape[2:] != cb.buf.shape[2:] or p_.device != cb.buf.device for p_ in parts):
+        if cb.buf.is_cuda:
+            _glue()
         return torch.cat(parts, 1)                                               # (mixed dtypes promote: the framework's rule)
     return _Join.apply(cb, *parts)
 
@@ -1243,10 +1318,66 @@ class _Fork(torch.autograd.Function):
         if d_all is None:
             if d_tail is None:
                 return None, None
-            d_all = torch.zeros((d_tail.shape[0], ctx.lo + d_tail.shape[1]) + tuple(d_tail.shape[2:]), dtype=d_tail.dtype, device=d_tail.device).contiguous(memory_format=torch.channels_last)
+            d_all = _tzeros((d_tail.shape[0], ctx.lo + d_tail.shape[1]) + tuple(d_tail.shape[2:]), dtype=d_tail.dtype, device=d_tail.device).contiguous(memory_format=torch.channels_last)
         if d_tail is not None:
-            d_all[:, ctx.lo:].add_(d_tail)
+            tgt = d_all[:, ctx.lo:]
+            mult = 8 if d_all.dtype == torch.float16 else 4
+            if (d_all.is_cuda and not framework_ops and d_all.dtype in _DT and d_tail.dtype == d_all.dtype and d_tail.shape[1] % mult == 0 and ctx.lo % mult == 0
+                    and nhwc(tgt)[0] is tgt and nhwc(d_tail)[0] is d_tail):
+                nhwc_sum([d_tail], tgt, accumulate=True)                          # one launch on NHWC views (csrc/train_ops.hip maf_nhwc_sum), recordable by a step tape
+            else:
+                _glue()
+                tgt.add_(d_tail)
         return d_all, None
+
+
+def nhwc_sum(srcs, dst, accumulate=False):
+    """dst = [dst +] sum(srcs) on NHWC views of one shape and dtype (csrc/train_ops.hip maf_nhwc_sum: 1..4 sources, channel slices welcome)."""
+    B, c, H, W = dst.shape
+    n = len(srcs)
+    lib.check(lib.load().maf_nhwc_sum(_PTR4(*[t.data_ptr() for t in srcs]), _INT4(*[t.stride()[3] for t in srcs]), n, dst.data_ptr(), dst.stride()[3],
+                                      B * H * W, c, _DT[dst.dtype], 1 if accumulate else 0, _stream(dst.device)))
+    stats["native_nhwc_sum"] = stats.get("native_nhwc_sum", 0) + 1
+
+
+class _Fanout(torch.autograd.Function):
+    """n aliases of one tensor for n consumers; backward = the sum of their gradients in ONE launch (fp32 sum, one rounding) instead of the autograd
+    engine's add kernel per extra consumer — and a launch a step tape can record."""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        ctx.n = n
+        return tuple(t.view_as(t) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *ds):
+        live = [d for d in ds if d is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        d0 = live[0]
+        mult = 8 if d0.dtype == torch.float16 else 4
+        if (d0.is_cuda and not framework_ops and d0.dtype in _DT and d0.dim() == 4 and d0.shape[1] % mult == 0 and len(live) <= 4
+                and all(d.dtype == d0.dtype and d.shape == d0.shape for d in live)):
+            views = [nhwc(d)[0] for d in live]
+            out = _empty(d0.shape, dtype=d0.dtype, device=d0.device, memory_format=torch.channels_last)
+            nhwc_sum(views, out)
+            return out, None
+        _glue(len(live) - 1)
+        out = live[0] + live[1]
+        for d in live[2:]:
+            out = out + d
+        return out, None
+
+
+def fanout(t, n):
+    """[t] * n for a tensor with n consumers inside the train-form graph (a backbone map the neck reads several times, the input of MPRep, the stem of a head)."""
+    if n <= 1:
+        return [t]
+    if not (t.is_cuda and t.requires_grad and not framework_ops):
+        return [t] * n
+    return list(_Fanout.apply(t, n))
 
 
 def fork(t, lo=0):
@@ -1257,14 +1388,23 @@ def fork(t, lo=0):
 _bnsum_scratch = {}
 
 
+def _phase_array(phases):
+    arr = _INT4(*[int(p_) for p_ in phases])
+    if _rec is not None:
+        _rec.toggle_array(arr, [(j, 1, 4) for j, p_ in enumerate(phases) if isinstance(p_, lib.Phase)])
+    return arr
+
+
 def _bnsum_part(dev, c, nb):
     """(scratch, phase) of maf_bn_sum_backward: [2][R][1 + nb][roundup(c,256)] fp32 per (stream, width, branch count), halves alternating call by call."""
+    if _rec is not None:
+        return _tzeros(2 * _BN_REPLICAS * (1 + nb) * (-(-c // 256) * 256), dtype=torch.float32, device=dev), lib.Phase(0)
     key = (dev.index, _stream(dev), -(-c // 256), nb)
     ent = _bnsum_scratch.get(key)
     if ent is None:
         if len(_bnsum_scratch) > 64:
             _bnsum_scratch.clear()
-        ent = _bnsum_scratch[key] = [torch.zeros(2 * _BN_REPLICAS * (1 + nb) * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
+        ent = _bnsum_scratch[key] = [_tzeros(2 * _BN_REPLICAS * (1 + nb) * (-(-c // 256) * 256), dtype=torch.float32, device=dev), 1]
     ent[1] ^= 1
     return ent[0], ent[1]
 
@@ -1289,8 +1429,8 @@ class _BNSum(torch.autograd.Function):
         for (z, zst), (rm, rv, cnt, part, phase, need) in zip(zs, per):
             if need:                                                             # this branch's producer has no statistics epilogue (the 1 x 1 scale branch)
                 lib.check(L.maf_bn_stats(z.data_ptr(), zst, M_, c, dt, part.data_ptr(), _BN_REPLICAS, phase, _stream(dev)))
-        out = torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) if dst is None else dst      # dst: a concat buffer's slot (bn_act's out=)
-        stat = torch.empty(nb, 2, c, dtype=torch.float32, device=dev)            # save_mean, save_rstd per branch
+        out = _empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) if dst is None else dst      # dst: a concat buffer's slot (bn_act's out=)
+        stat = _empty(nb, 2, c, dtype=torch.float32, device=dev)            # save_mean, save_rstd per branch
         sp = stat.data_ptr()
         g32 = [g.detach() if g.dtype == torch.float32 and g.is_contiguous() else g.detach().float().contiguous() for g in gammas]
         b32 = [b.detach() if b.dtype == torch.float32 and b.is_contiguous() else b.detach().float().contiguous() for b in betas]
@@ -1300,7 +1440,7 @@ class _BNSum(torch.autograd.Function):
                                            _PTR4(*[0 if p[0] is None else p[0].data_ptr() for p in per]), _PTR4(*[0 if p[1] is None else p[1].data_ptr() for p in per]),
                                            _PTR4(*[0 if p[2] is None else p[2].data_ptr() for p in per]),
                                            out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
-                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _INT4(*[p[4] for p in per]), act, _stream(dev)))
+                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _phase_array([p[4] for p in per]), act, _stream(dev)))
         ctx.save_for_backward(stat, *[z for z, _ in zs], *g32, *b32)
         ctx.nb, ctx.act = nb, act
         ctx.affine = list(zip(gammas, betas)) if all(isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter) for g, b in zip(gammas, betas)) else None
@@ -1320,14 +1460,14 @@ class _BNSum(torch.autograd.Function):
         if dy.dtype != x0.dtype:
             dy = dy.to(x0.dtype)
             dys = dy.stride()[3]
-        dzs = [torch.empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(nb)]
+        dzs = [_empty((B, c, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(nb)]
         from . import exchange
         ex, tg = exchange.current, None
         if ex is not None and ctx.affine is not None and bn_affine_direct and all(ctx.needs_input_grad[2 + nb + j] and ctx.needs_input_grad[2 + 2 * nb + j] for j in range(nb)):
             tg = [(ex.target(g), ex.target(b)) for g, b in ctx.affine]
             if not all(a_ is not None and b_ is not None and a_[1].is_contiguous() and b_[1].is_contiguous() for a_, b_ in tg):
                 tg = None
-        dgb = None if tg is not None else torch.empty(nb, 2, c, dtype=torch.float32, device=dev)
+        dgb = None if tg is not None else _empty(nb, 2, c, dtype=torch.float32, device=dev)
         part, phase = _bnsum_part(dev, c, nb)
         sp = stat.data_ptr()
         gp = None if dgb is None else dgb.data_ptr()
@@ -1382,12 +1522,12 @@ class _MaxPool(torch.autograd.Function):
     with atomics over overlapping windows — 271 us per SPPF pool on 32 x 192 x 20 x 20 — and drags int64 indices along)."""
 
     @staticmethod
-    def forward(ctx, x, k, stride, pad):
+    def forward(ctx, x, k, stride, pad, out=None):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        y = torch.empty((B, c, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        idx = torch.empty((B, Ho, Wo, c), dtype=torch.uint8, device=x.device)
+        y = _empty((B, c, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if out is None else out[0]      # out: a concat buffer's slot (SPPF)
+        idx = _empty((B, Ho, Wo, c), dtype=torch.uint8, device=x.device)
         lib.check(lib.load().maf_maxpool_forward(x.data_ptr(), xs, B, H, W, c, k, stride, pad, _DT[x.dtype], y.data_ptr(), y.stride()[3], idx.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(idx)
         ctx.geom = (H, W, k, stride, pad)
@@ -1400,9 +1540,9 @@ class _MaxPool(torch.autograd.Function):
         H, W, k, stride, pad = ctx.geom
         dy, dys = nhwc(dy)
         B, c = dy.shape[:2]
-        dx = torch.empty((B, c, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        dx = _empty((B, c, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         lib.check(lib.load().maf_maxpool_backward(dy.data_ptr(), dys, idx.data_ptr(), B, H, W, c, k, stride, pad, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _Up2(torch.autograd.Function):
@@ -1412,7 +1552,7 @@ class _Up2(torch.autograd.Function):
     def forward(ctx, x, out):
         x, xs = nhwc(x)
         B, c, H, W = x.shape
-        y = torch.empty((B, c, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if out is None else out[0]
+        y = _empty((B, c, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if out is None else out[0]
         lib.check(lib.load().maf_upsample2x_forward(x.data_ptr(), xs, B, H, W, c, _DT[x.dtype], y.data_ptr(), y.stride()[3], _stream(x.device)))
         stats["native_upsample"] = stats.get("native_upsample", 0) + 1
         return y
@@ -1421,7 +1561,7 @@ class _Up2(torch.autograd.Function):
     def backward(ctx, dy):
         dy, dys = nhwc(dy)
         B, c, H2, W2 = dy.shape
-        dx = torch.empty((B, c, H2 // 2, W2 // 2), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        dx = _empty((B, c, H2 // 2, W2 // 2), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         lib.check(lib.load().maf_upsample2x_backward(dy.data_ptr(), dys, B, H2 // 2, W2 // 2, c, _DT[dy.dtype], dx.data_ptr(), dx.stride()[3], _stream(dy.device)))
         return dx, None
 
@@ -1441,21 +1581,34 @@ def upsample2x(x, out=None):
     return _Up2.apply(x, None if out is None else (out,))
 
 
-def maxpool(x, k, stride=1, pad=None):
-    """F.max_pool2d(x, k, stride, pad) (pad default k // 2 for stride 1, else 0) with autograd; CUDA fp16 / fp32 tensors with channels in whole
-    16-byte groups run the HIP kernels."""
+def maxpool_native_ok(x, k, stride=1, pad=None):
+    """maxpool(x, ...) would run csrc/pool_train.hip (and take `out=`)."""
     if pad is None:
         pad = k // 2 if stride == 1 else 0
     mult = 8 if x.dtype == torch.float16 else 4
-    if framework_ops or not (x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and 2 <= k <= 15 and 1 <= stride <= k and 2 * pad <= k):
+    return not framework_ops and x.is_cuda and x.dtype in _DT and x.dim() == 4 and x.shape[1] % mult == 0 and 2 <= k <= 15 and 1 <= stride <= k and 2 * pad <= k
+
+
+def maxpool(x, k, stride=1, pad=None, out=None):
+    """F.max_pool2d(x, k, stride, pad) (pad default k // 2 for stride 1, else 0) with autograd; CUDA fp16 / fp32 tensors with channels in whole
+    16-byte groups run the HIP kernels.  `out`: a concat buffer's slot of the result's shape (HIP path only: ask `maxpool_native_ok` first)."""
+    if pad is None:
+        pad = k // 2 if stride == 1 else 0
+    if not maxpool_native_ok(x, k, stride, pad):
+        if out is not None:
+            raise lib.MafError("maxpool: out= is a feature of the HIP path")
         if x.is_cuda:
             stats["torch_maxpool"] = stats.get("torch_maxpool", 0) + 1
         return F.max_pool2d(x, k, stride, pad)
-    return _MaxPool.apply(x, k, stride, pad)
+    if out is not None:
+        Ho, Wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
+        if not (out.dtype == x.dtype and out.device == x.device and tuple(out.shape) == (x.shape[0], x.shape[1], Ho, Wo) and nhwc(out)[0] is out):
+            raise lib.MafError("maxpool: out= must be an NHWC (channel-slice) view of the result's shape and dtype")
+    return _MaxPool.apply(x, k, stride, pad, None if out is None else (out,))
 
 
-def maxpool_s1(x, k):
-    return maxpool(x, k, 1, k // 2)
+def maxpool_s1(x, k, out=None):
+    return maxpool(x, k, 1, k // 2, out=out)
 
 
 def dwconv(x, w):
