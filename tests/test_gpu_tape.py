@@ -72,7 +72,7 @@ def test_tape_records_a_step_without_torch_kernels_between_its_launches():
         assert tp.glue == [], sorted(set(tp.glue))
         assert tp.seen["fwd"] > 0 and tp.seen["bwd"] > 0, tp.seen
         assert tp.ready
-        assert tp.n["fwd"] > 300 and tp.n["bwd"] > 300, tp.n
+        assert tp.n["fwd"] > 150 and tp.n["bwd"] > 300, tp.n       # C-ABI calls (a BatchNorm call is two kernels)
         assert len(tp.marks) == len(ex.buckets), (tp.marks, len(ex.buckets))
         before = train_ops.stats.get("tape_replays", 0)
         loss = _pass(model, ex, crit, x, t)

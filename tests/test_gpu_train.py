@@ -782,6 +782,10 @@ def test_weight_staging_plan_matches_per_layer_packing():
             M.lib.check(L.maf_pack_w1x1(param.data_ptr(), f["Cout"], f["Cin"], f["transpose"], f["dtype"], f["CT"], ref.data_ptr(), st))
         elif f["kind"] == 1:
             M.lib.check(L.maf_pack_dw(param.data_ptr(), f["Cout"], int(round(f["taps"] ** 0.5)), f["flip"], f["dtype"], ref.data_ptr(), st))
+        elif f["kind"] == 2:                                          # the bias of a prediction conv on the conv's channel tile, zeros behind it
+            r32 = ref.view(torch.float32)
+            r32.zero_()
+            r32[:f["Cout"]].copy_(param.detach())
         else:                                                         # 3x3: the torch permute + pad + 1x1 pack of the fallback path
             plan_saved, train_ops._plan = train_ops._plan, None
             ref = train_ops._packed_3x3(param, bool(f["transpose"]), f["dtype"], f["CT"], param.device)
