@@ -55,23 +55,23 @@ def calibrate_cls_bias(model, x, target_per_img, M, torch):
     return shift
 
 
-def latency_mode(args, torch, M, dev):
-    """bs=1, 640x640 fp16: forward replayed from a captured hipGraph (fixed input/output buffers) + NMS, per-call latency."""
+def latency_leg(torch, M, dev, scale, n, warmup, lanes=-1):
+    """BASELINE configs[4]: bs=1, 640x640 fp16 — the forward issued eagerly from the C engine loop and replayed from a captured hipGraph (fixed input / output
+    buffers), + NMS; per-call latency of n requests each.  Returns the result line as a dict."""
     import numpy as np
     from maf_yolo_amd import synth
-    model = M.Model(args.scale)
-    model.load_state_dict(synth.synth_state_dict(model, args.scale, 0))
+    model = M.Model(scale)
+    model.load_state_dict(synth.synth_state_dict(model, scale, 0))
     model = model.to(dev).eval()
-    if args.lanes >= 0:
-        model.multi_stream = args.lanes
+    if lanes >= 0:
+        model.multi_stream = lanes
     x = synth.synth_images(1, 640, seed=1).to(dev).half()
     calibrate_cls_bias(model, x, 2000, M, torch)
     plan = model.plan_for(x)
     pred = torch.empty(1, plan.A, 5 + plan.nc, dtype=torch.float32, device=dev)
     res = {}
-    n = max(args.steps, 200)
     for tag, graph in (("hipgraph", True), ("eager", False)):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             plan.run_into(x, pred, graph=graph)
             M.non_max_suppression(pred, 0.03, 0.65, multi_label=True)
         torch.cuda.synchronize(dev)
@@ -91,11 +91,68 @@ def latency_mode(args, torch, M, dev):
     # BASELINE configs[4] names hipGraph capture as the mechanism; both ways of issuing the same launch list are measured and the line's value is the
     # faster one, named in the metric (a graph node costs ~1.1 us more than an eager launch from the C loop on this stack: DESIGN.md section 8)
     best = min(res, key=lambda k: res[k]["forward_plus_nms_ms_p50"])
-    print(json.dumps({"metric": "latency ms MAF-YOLO-%s 640x640 bs=1 infer (forward + NMS, p50; launch path: %s)" % (args.scale, "hipGraph replay" if best == "hipgraph" else "eager launches from the C engine loop"),
-                      "value": res[best]["forward_plus_nms_ms_p50"], "unit": "ms", "n_gpus": 1, "higher_is_better": False,
-                      "dtype": "f16", "data": "synthetic", "config": {"workload": "bs=1 3x640x640 fp16, %d launches per forward" % len(plan.ops), "launch_path": best,
-                                                                      "samples": n, "warmup": args.warmup},
-                      "latency": res}), flush=True)
+    return {"metric": "latency ms MAF-YOLO-%s 640x640 bs=1 infer (forward + NMS, p50; launch path: %s)" % (scale, "hipGraph replay" if best == "hipgraph" else "eager launches from the C engine loop"),
+            "value": res[best]["forward_plus_nms_ms_p50"], "unit": "ms", "n_gpus": 1, "higher_is_better": False,
+            "dtype": "f16", "data": "synthetic", "config": {"workload": "bs=1 3x640x640 fp16, %d launches per forward" % len(plan.ops), "launch_path": best,
+                                                            "samples": n, "warmup": warmup},
+            "latency": res}
+
+
+def latency_mode(args, torch, M, dev):
+    print(json.dumps(latency_leg(torch, M, dev, args.scale, max(args.steps, 200), args.warmup, args.lanes)), flush=True)
+
+
+def infer_leg(torch, M, dev, scale, batch, steps, warmup):
+    """The headline workload (forward + NMS of resident 640 x 640 fp16 batches, three batches in flight) for another scale, compact: the same serving loop as the
+    main line's timed region with fewer steps, plus the forward alone.  Tile choices: the frozen file of the scale under profiles/ when there is one."""
+    import numpy as np
+    from maf_yolo_amd import synth, engine as _engine
+    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_ % scale) for f_ in ("round5_tune_%s.json", "round4_tune_%s.json", "round3_tune_%s.json")) if os.path.exists(p_)]
+    if frozen:
+        _engine.load_tune_cache(frozen[0])
+    model = M.Model(scale)
+    model.load_state_dict(synth.synth_state_dict(model, scale, 0))
+    model = model.to(dev).eval()
+    model.autotune = True
+    S = 3
+    xs = [synth.synth_images(batch, 640, seed=1 + 7 * k).to(dev).half() for k in range(S)]
+    calibrate_cls_bias(model, xs[0], 2000, M, torch)
+    cs = M.concurrent_streams(dev, S + 1)
+    streams, nms_stream = cs[:S], cs[S]
+
+    def loop(n):
+        pending, dets = [], None
+        for i in range(n):
+            k = i % S
+            with torch.cuda.stream(streams[k]), torch.no_grad():
+                pending.append(M.non_max_suppression_async(model(xs[k], slot=k)[0], 0.03, 0.65, multi_label=True, side=nms_stream))
+            if len(pending) > S:
+                dets = pending.pop(0).result()
+        for h in pending:
+            dets = h.result()
+        return dets
+    loop(48 + warmup)                                          # allocator pools + warm-up (untimed)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dets = loop(steps)
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        for _ in range(5):
+            model(xs[0])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(xs[0])
+        torch.cuda.synchronize(dev)
+    fwd = 1e3 * (time.perf_counter() - t0) / steps
+    plan = model.plan_for(xs[0])
+    tot = sum(plan.algorithmic_bytes(i) for i in range(len(plan.ops)))
+    return {"metric": "images/sec MAF-YOLO-%s 640x640 bs=%d infer (Model.forward + non_max_suppression)" % (scale, batch), "value": round(batch * 1e3 / ms, 1), "unit": "images/s",
+            "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup, "untimed_steps_before_the_timed_region": 48 + warmup, "batches_in_flight": S,
+            "forward_only_ms": round(fwd, 4), "launches_per_forward": len(plan.ops), "whole_forward_hbm_frac": round(tot / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_GB_per_forward": round(tot / 1e9, 4), "detections_per_image_mean": round(float(np.mean([d.shape[0] for d in dets])), 1),
+            "tiles": os.path.relpath(frozen[0], ROOT) if frozen else "timed at start-up"}
 
 
 def host_cores():
@@ -287,6 +344,11 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
         roof = {"bound": "hbm", "kernel": k0, "launches_per_step": n0, "avg_launch_ms": round(ms0 / n0, 5), "bytes_per_launch": int(by0 / n0),
                 "achieved": round(by0 / ms0 / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by0 / ms0 / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "share_of_native_kernel_time": round(ms0 / tot, 4), "native_kernel_ms_per_step": round(tot, 3)}
+        # the whole step against the HBM roofline: the algorithmic bytes of every native launch of the step (each kernel reads its inputs once and writes its outputs
+        # once: the per-launch figures above, summed over both streams) over the step's wall time
+        step_gb = sum(v[1] for v in prof.values()) / 1e9
+        roof["whole_step"] = {"algorithmic_GB": round(step_gb, 3), "ms_per_step": round(1e3 * elapsed / steps, 3),
+                              "hbm_frac": round(step_gb / (elapsed / steps) / HBM_PEAK_GBS, 4), "native_launches": int(sum(v[2] for v in prof.values()))}
         if full:
             roof["by_kind"] = {k: {"ms": round(v[0], 3), "launches": v[2], "achieved_GBs": round(v[1] / v[0] / 1e6, 1)} for k, v in kinds}
     final = float(loss.detach())
@@ -356,6 +418,7 @@ def main():
     ap.add_argument("--torch-convs", action="store_true", help="with --train: run the 1x1 / depth-wise convs on stock PyTorch-ROCm (MIOpen) for an A/B")
     ap.add_argument("--ddp", action="store_true", help="--train A/B: torch's DistributedDataParallel instead of maf_yolo_amd.GradExchange (N > 1; at N = 1: plain autograd)")
     ap.add_argument("--no-train-leg", action="store_true", help="leave the short training leg (`train` object: n, bs 32/GPU) out of the default line")
+    ap.add_argument("--no-extra-legs", action="store_true", help="leave the compact legs of the other BASELINE configs (train_s, train_m, latency_m, infer_s, infer_m) out of the default line")
     ap.add_argument("--train-steps", type=int, default=30, help="timed steps of the training leg of the default line (after 6 warm-up steps: the first ones time the conv variants per shape)")
     ap.add_argument("--no-tape", action="store_true", help="--train A/B: no step tape (maf_yolo_amd/tape.py): every step issued op by op from Python")
     ap.add_argument("--no-ema", action="store_true", help="--train A/B: leave the ModelEMA update of rank 0 out of the step")
@@ -681,10 +744,31 @@ def main():
         model._plans = {}
         torch.cuda.empty_cache()
         train = train_leg(args, torch, M, dev, rank, world, dist, "n", 32, args.train_steps, 10, False)       # 30 timed steps after 10 warm-up steps: a 0.65 s region (12 after 6 moved by 2 ms per step with one host stall: 23.8 in the line, 21.8 alone, same box)
+    # ---- every other BASELINE config at N = 1 in the same driver-timed run, compact: configs[2] / [3] at one GPU (s bs 32, m bs 16 per GPU),
+    # configs[4] (m, bs 1, latency: eager launches and hipGraph replay), and the headline workload for s and m.  ~10 s each; --no-extra-legs leaves them out.
+    extra = {}
+    if world == 1 and not args.no_extra_legs and not args.no_train_leg:
+        def leg(name, fn):
+            t_ = time.perf_counter()
+            try:
+                r_ = fn()
+            except Exception as e_:                                  # a leg must not take the headline line with it
+                r_ = {"error": "%s: %s" % (type(e_).__name__, e_)}
+            if isinstance(r_, dict):
+                r_.pop("cpu_baseline", None)
+                r_["leg_wall_s"] = round(time.perf_counter() - t_, 1)
+            extra[name] = r_
+            torch.cuda.empty_cache()
+        leg("train_s", lambda: train_leg(args, torch, M, dev, rank, world, dist, "s", 32, 15, 8, False))
+        leg("train_m", lambda: train_leg(args, torch, M, dev, rank, world, dist, "m", 16, 15, 8, False))
+        leg("latency_m", lambda: latency_leg(torch, M, dev, "m", 300, 30))
+        leg("infer_s", lambda: infer_leg(torch, M, dev, "s", 32, 100, 20))
+        leg("infer_m", lambda: infer_leg(torch, M, dev, "m", 32, 60, 20))
     if rank == 0:
         if train is not None:
             train.pop("cpu_baseline", None)
         out["train"] = train
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg()
         print(json.dumps(out), flush=True)
