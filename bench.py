@@ -102,7 +102,7 @@ def latency_mode(args, torch, M, dev):
     print(json.dumps(latency_leg(torch, M, dev, args.scale, max(args.steps, 200), args.warmup, args.lanes)), flush=True)
 
 
-def infer_leg(torch, M, dev, scale, batch, steps, warmup):
+def infer_leg(torch, M, dev, scale, batch, steps, warmup, cs=None):
     """The headline workload (forward + NMS of resident 640 x 640 fp16 batches, three batches in flight) for another scale, compact: the same serving loop as the
     main line's timed region with fewer steps, plus the forward alone.  Tile choices: the frozen file of the scale under profiles/ when there is one."""
     import numpy as np
@@ -117,7 +117,8 @@ def infer_leg(torch, M, dev, scale, batch, steps, warmup):
     S = 3
     xs = [synth.synth_images(batch, 640, seed=1 + 7 * k).to(dev).half() for k in range(S)]
     calibrate_cls_bias(model, xs[0], 2000, M, torch)
-    cs = M.concurrent_streams(dev, S + 1)
+    if cs is None or len(cs) < S + 1:                          # (the main line hands over ITS streams: every new stream takes another slot of the few hardware queues)
+        cs = M.concurrent_streams(dev, S + 1)
     streams, nms_stream = cs[:S], cs[S]
 
     def loop(n):
@@ -403,6 +404,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--nms-filter", action="store_true", help="A/B: the forward's head tails collect the NMS candidates (Model.nms_filter) instead of non_max_suppression's own pass over the prediction")
+    ap.add_argument("--nms-cus", type=int, default=0, help="A/B: run the NMS stream on this many compute units only (hipExtStreamCreateWithCUMask); 0 = the whole chip")
     ap.add_argument("--per-op", action="store_true", help="also print the per-op table to stderr")
     ap.add_argument("--lanes", type=int, default=-1, help="engine streams: 0 one stream, 1 heads on side streams, 2 heads + neck side convs (default: the model's setting)")
     ap.add_argument("--fuse", type=int, default=-1, help="1/0: force the fused DepthBottleneckUni kernel on/off (default: the model's setting)")
@@ -519,6 +521,10 @@ def main():
     # streams that share a hardware queue run their kernels one after the other: take streams that demonstrably overlap (streams.py)
     cs = M.concurrent_streams(dev, S + 1)                      # S forward streams + the NMS stream, on different hardware queues
     streams, nms_stream = (cs[:S] if S > 1 else [torch.cuda.current_stream(dev)]), cs[S]
+    if args.nms_cus > 0:
+        # the NMS stream confined to a slice of the chip (streams.masked_stream): its kernels no longer spread over every CU beside the next forward's first kernels
+        from maf_yolo_amd.streams import masked_stream
+        nms_stream = masked_stream(dev, args.nms_cus)
     probe0 = M.concurrent_streams.last_ratio
 
     def pipelined(n):
@@ -762,8 +768,8 @@ def main():
         leg("train_s", lambda: train_leg(args, torch, M, dev, rank, world, dist, "s", 32, 15, 8, False))
         leg("train_m", lambda: train_leg(args, torch, M, dev, rank, world, dist, "m", 16, 15, 8, False))
         leg("latency_m", lambda: latency_leg(torch, M, dev, "m", 300, 30))
-        leg("infer_s", lambda: infer_leg(torch, M, dev, "s", 32, 100, 20))
-        leg("infer_m", lambda: infer_leg(torch, M, dev, "m", 32, 60, 20))
+        leg("infer_s", lambda: infer_leg(torch, M, dev, "s", 32, 100, 20, cs))
+        leg("infer_m", lambda: infer_leg(torch, M, dev, "m", 32, 60, 20, cs))
     if rank == 0:
         if train is not None:
             train.pop("cpu_baseline", None)

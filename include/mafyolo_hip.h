@@ -469,6 +469,11 @@ int maf_nhwc_sum(const void* const* src, const int32_t* src_stride, int32_t n, v
 int maf_stream_fork(maf_stream_t main, maf_stream_t side);
 int maf_stream_join(maf_stream_t main, maf_stream_t side);
 
+/* A stream restricted to the compute units of a bit mask (n_words x 32 bits; bit i = CU i in the driver's numbering): bench.py's serving loop can confine the
+ * NMS of batch i (yolov6/utils/nms.py:31-105) to a slice of the chip while the forward of batch i + 1 runs on the rest.  Destroy with maf_stream_destroy. */
+int maf_stream_create_masked(const uint32_t* mask_words, int32_t n_words, maf_stream_t* out);
+int maf_stream_destroy(maf_stream_t s);
+
 /*
  * Step tape: a recorded launch list of the C-ABI calls of one training step (yolov6/core/engine.py:141-167: forward, backward), replayed by ONE call.
  * The train-form graph is ~420 launches forward and ~470 backward of kernels that take 5-60 us each; issued one by one from Python autograd

@@ -68,13 +68,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     const int cs = gs * N;                                           // channels per slice (LDS row)
     for (int i = threadIdx.x; i < 2 * cs; i += 256) lsum[i] = 0.f;
     __syncthreads();
-    const int plan = 256 / gs;                                       // pixel lanes
+    // lane map: gsl = gs rounded up to a power of two (gs <= 8: slices of <= 8 groups) group lanes x 256 / gsl pixel lanes, the group lanes past the slice idle.
+    // With gs itself (6 for C = 48 / 96 / 144, 5 for 72, 3 for 24 — the widths of the 160 x 160 and 80 x 80 maps) the lanes of a channel group do not line up
+    // across a wave, the xor-shuffle reduction below is off and every lane issued 2 N LDS atomics onto gs N addresses, 42-fold same-address: tools/bn_bench.py —
+    // the statistics pass of 32 x 160 x 160 x 48 ran at 2.2 TB/s, of x 128 at 3.9.
+    // (the backward pass is bound by its SiLU-gradient arithmetic, where idle lanes cost: it keeps the dense lane map and parks its partial sums in LDS instead — below)
+    const int gsl = BWD ? gs : (gs <= 1 ? 1 : gs <= 2 ? 2 : gs <= 4 ? 4 : gs <= 8 ? 8 : gs);
+    const int plan = 256 / gsl;                                      // pixel lanes
     const int chunk = (a.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * chunk, m1 = min(a.M, m0 + chunk);
-    const bool wave_reduce = gs < 64 && (gs & (gs - 1)) == 0;        // lane % gs == channel group for every wave
+    const bool wave_reduce = gsl < 64 && (gsl & (gsl - 1)) == 0;     // lane % gsl == channel group for every wave
     const T* xp = static_cast<const T*>(a.x);
     const T* dp = static_cast<const T*>(a.dz);
-    const int gl = threadIdx.x % gs, pl = threadIdx.x / gs, gi = gbeg + gl;
+    const int gl = threadIdx.x % gsl, pl = threadIdx.x / gsl, gi = gbeg + gl;
     const bool active = gl < gcnt && pl < plan;
     float s0[N], s1[N], mu[N], rs[N], ga[N], be[N];
 #pragma unroll
@@ -132,19 +138,36 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
         for (int i = threadIdx.x; i < gcnt * N; i += 256) {
             const int gq = i / N, j = i - gq * N;
             double t0 = 0, t1 = 0;
-            for (int q = 0; q < plan; ++q) { t0 += ld[(q * gs + gq) * 2 * N + j]; t1 += ld[(q * gs + gq) * 2 * N + N + j]; }
+            for (int q = 0; q < plan; ++q) { t0 += ld[(q * gsl + gq) * 2 * N + j]; t1 += ld[(q * gsl + gq) * 2 * N + N + j]; }
             float* slot = a.det + (size_t)blockIdx.x * 2 * a.C + gbeg * N + i;
             slot[0] = (float)t0; slot[a.C] = (float)t1;
         }
         return;
     }
+    if (!wave_reduce) {
+        // group count of the slice not a power of two (backward pass): the lanes of a channel group do not line up across a wave.  Every thread parks its sums
+        // in LDS ([256][2 N]: the launch sized it), one thread per (statistic, channel) adds its column — plan values, conflict-free — and issues the one global atomic.
+        __syncthreads();
+        float* ld = lsum;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { ld[threadIdx.x * 2 * N + j] = active ? s0[j] : 0.f; ld[threadIdx.x * 2 * N + N + j] = active ? s1[j] : 0.f; }
+        __syncthreads();
+        float* dstp = a.part + (size_t)(blockIdx.x % a.R) * 2 * a.C + gbeg * N;
+        for (int i = threadIdx.x; i < 2 * gcnt * N; i += 256) {
+            const int which = i / (gcnt * N), c = i - which * gcnt * N, gq = c / N, j = c - gq * N;
+            float t = 0.f;
+            for (int q = 0; q < plan; ++q) t += ld[(q * gsl + gq) * 2 * N + which * N + j];
+            atomicAdd(dstp + (size_t)which * a.C + c, t);
+        }
+        return;
+    }
     if (wave_reduce) {
-        for (int off = gs; off < 64; off <<= 1) {
+        for (int off = gsl; off < 64; off <<= 1) {
 #pragma unroll
             for (int j = 0; j < N; ++j) { s0[j] += __shfl_xor(s0[j], off, 64); s1[j] += __shfl_xor(s1[j], off, 64); }
         }
     }
-    if (active && (!wave_reduce || (threadIdx.x & 63) < gs)) {
+    if (active && (!wave_reduce || (threadIdx.x & 63) < gsl)) {
 #pragma unroll
         for (int j = 0; j < N; ++j) { atomicAdd(&lsum[gl * N + j], s0[j]); atomicAdd(&lsum[cs + gl * N + j], s1[j]); }
     }
@@ -305,7 +328,7 @@ int bn_grid(int M, int C, int dtype, int cap) {
 // statistics pass: channel slices of <= 8 groups (blockIdx.y), 32 pixels per lane (16 when that leaves fewer than ~4 workgroups per CU)
 dim3 stats_grid(int M, int C, int dtype, size_t* lds) {
     const int groups = C / (dtype == MAF_F16 ? 8 : 4), N = dtype == MAF_F16 ? 8 : 4;
-    const int nslice = (groups + 7) / 8, gs = (groups + nslice - 1) / nslice, plan = 256 / gs;
+    const int nslice = (groups + 7) / 8, gs = (groups + nslice - 1) / nslice, plan = 256 / (gs <= 1 ? 1 : gs <= 2 ? 2 : gs <= 4 ? 4 : 8);      // pixel lanes of bn_stats_kernel's lane map
     long long gx = ((long long)M + plan * 32 - 1) / (plan * 32);
     // tensors of <= 7 M elements (the 20 x 20 maps, narrow 40 x 40 ones) are latency-bound — 100 workgroups, each lane walking 16 pixels of
     // SiLU-gradient arithmetic at one wave per SIMD: 8 pixels per lane there (32x20x20x256: 16.5 / 30.2 -> 13.3 / 21.0 us forward /
@@ -314,6 +337,7 @@ dim3 stats_grid(int M, int C, int dtype, size_t* lds) {
     for (int ppl = 16; gx * nslice < 1024 && ppl >= ppl_small; ppl >>= 1) gx = ((long long)M + plan * ppl - 1) / (plan * ppl);
     if (gx > 4096) gx = 4096;
     *lds = (size_t)2 * gs * N * sizeof(float);
+    if (gs & (gs - 1)) *lds = (size_t)256 * 2 * N * sizeof(float);          // the backward statistics kernel parks its per-thread sums (dense lane map)
     return dim3((unsigned)(gx < 1 ? 1 : gx), (unsigned)nslice);
 }
 

@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_stats_kernel(const BsArgs a) {
     const int gbeg = blockIdx.y * gs, gcnt = min(gs, groups - gbeg), cs = gs * N;
     for (int i = threadIdx.x; i < NS * cs; i += 256) lsum[i] = 0.f;
     __syncthreads();
-    const int plan = 256 / gs;
+    const int gsl = gs;                                                               // dense lane map; a group count that is not a power of two parks its sums in LDS (below; csrc/bn_act.hip)
+    const int plan = 256 / gsl;
     const int chunk = (a.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * chunk, m1 = min(a.M, m0 + chunk);
-    const bool wave_reduce = gs < 64 && (gs & (gs - 1)) == 0;
-    const int gl = threadIdx.x % gs, pl = threadIdx.x / gs, gi = gbeg + gl;
+    const bool wave_reduce = gsl < 64 && (gsl & (gsl - 1)) == 0;
+    const int gl = threadIdx.x % gsl, pl = threadIdx.x / gsl, gi = gbeg + gl;
     const bool active = gl < gcnt && pl < plan;
     const bool relu = a.act == MAF_ACT_RELU;                         // g = dy * [u > 0], u = sum_j (xhat_j gamma_j + beta_j) recomputed
     float acc[NS][N], mu[NB][N], rs[NB][N], ga[NB][N], bsum[N];
@@ -174,15 +175,32 @@ __global__ __launch_bounds__(256) void bn_sum_bwd_stats_kernel(const BsArgs a) {
             }
         }
     }
+    if (!wave_reduce) {
+        __syncthreads();
+        float* ld = lsum;                                             // [256][NS N]
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < N; ++q) ld[threadIdx.x * NS * N + k * N + q] = active ? acc[k][q] : 0.f;
+        __syncthreads();
+        float* dstp = a.bpart + (size_t)(blockIdx.x % a.R) * NS * a.C + gbeg * N;
+        for (int i = threadIdx.x; i < NS * gcnt * N; i += 256) {
+            const int k = i / (gcnt * N), c = i - k * gcnt * N, gq = c / N, q = c - gq * N;
+            float t = 0.f;
+            for (int pq = 0; pq < plan; ++pq) t += ld[(pq * gsl + gq) * NS * N + k * N + q];
+            atomicAdd(dstp + (size_t)k * a.C + c, t);
+        }
+        return;
+    }
     if (wave_reduce) {
-        for (int off = gs; off < 64; off <<= 1) {
+        for (int off = gsl; off < 64; off <<= 1) {
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
                 for (int q = 0; q < N; ++q) acc[k][q] += __shfl_xor(acc[k][q], off, 64);
         }
     }
-    if (active && (!wave_reduce || (threadIdx.x & 63) < gs)) {
+    if (active && (!wave_reduce || (threadIdx.x & 63) < gsl)) {
 #pragma unroll
         for (int k = 0; k < NS; ++k)
 #pragma unroll
@@ -292,6 +310,7 @@ dim3 stats_grid(int M, int C, int dtype, int NS, size_t* lds) {
     for (int ppl = 16; gx * nslice < 1024 && ppl >= ppl_small; ppl >>= 1) gx = ((long long)M + plan * ppl - 1) / (plan * ppl);
     if (gx > 4096) gx = 4096;
     *lds = (size_t)NS * gs * N * sizeof(float);
+    if (gs & (gs - 1)) *lds = (size_t)256 * NS * N * sizeof(float);         // the parking area of a slice whose group count is not a power of two
     return dim3((unsigned)(gx < 1 ? 1 : gx), (unsigned)nslice);
 }
 

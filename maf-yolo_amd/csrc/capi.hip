@@ -248,3 +248,14 @@ extern "C" void maf_timer_destroy(void* t) {
     (void)hipEventDestroy(m->a); (void)hipEventDestroy(m->b);
     delete m;
 }
+
+// A stream whose kernels may only run on the compute units of a bit mask (hipExtStreamCreateWithCUMask; bit i = CU i in the driver's numbering, which
+// deals consecutive bits round-robin to the 8 XCDs): the NMS of batch i on a slice of the chip while the forward of batch i + 1 has the rest.
+extern "C" int maf_stream_create_masked(const uint32_t* mask_words, int32_t n_words, maf_stream_t* out) {
+    if (!mask_words || n_words <= 0 || !out) { maf_set_error("stream_create_masked: bad arguments"); return MAF_E_ARG; }
+    hipStream_t s = nullptr;
+    if (int rc = maf_check_hip(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words), "hipExtStreamCreateWithCUMask")) return rc;
+    *out = s;
+    return 0;
+}
+extern "C" int maf_stream_destroy(maf_stream_t s) { return maf_check_hip(hipStreamDestroy(static_cast<hipStream_t>(s)), "hipStreamDestroy"); }

@@ -50,3 +50,18 @@ def concurrent_streams(device, n=2, tries=16, cycles=2_000_000):
         concurrent_streams._keep = getattr(concurrent_streams, "_keep", []) + rejected
         concurrent_streams.last_ratio = overlap_ratio(picked, cycles) if n > 1 else 1.0
     return picked
+
+
+def masked_stream(device, n_cus, total_cus=256):
+    """A torch stream whose kernels run on `n_cus` of the device's compute units only (csrc/capi.hip maf_stream_create_masked): the LAST n_cus bits of the
+    driver's CU numbering, which deals consecutive bits round-robin to the XCDs — n_cus / 8 units of every XCD.  The handle lives as long as the process."""
+    import ctypes as C
+    from . import lib
+    device = torch.device(device)
+    words = (C.c_uint32 * (total_cus // 32))()
+    for i in range(total_cus - n_cus, total_cus):
+        words[i // 32] |= 1 << (i % 32)
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        lib.check(lib.load().maf_stream_create_masked(words, len(words), C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device)
