@@ -481,8 +481,9 @@ int maf_stream_destroy(maf_stream_t s);
  * arguments, stream — once per (model, batch shape) while it runs the step the normal way with every buffer kept alive, and later steps replay the list:
  * the kernels, their order and their streams are exactly the recorded ones, launched eagerly (a hipGraph node costs ~1.1 us more than an eager launch
  * on this part).
- *   fn      index into the table of tape-able entry points (maf_tape_fn_id(name)); MAF_TAPE_FORK / MAF_TAPE_JOIN = maf_stream_fork / _join(main, side)
- *   stream  0: the entry's last argument (its maf_stream_t) becomes `main`, 1: `side`
+ *   fn      index into the table of tape-able entry points (maf_tape_fn_id(name)); MAF_TAPE_FORK = maf_stream_fork(streams[a[0]], streams[a[1]])
+ *   stream  index into the `streams` array of maf_tape_run the entry's last argument (its maf_stream_t) is taken from: 0 the main stream, 1 the weight-gradient
+ *           stream, 2.. lanes (independent branches of the graph — the two branches of a detection head — recorded on streams of their own)
  *   a[]     the arguments in declaration order, one 64-bit slot each: pointers and integers as they are, a float as its 32 bits; pointer-to-array
  *           arguments point at host arrays the recorder keeps alive
  * Toggles: words that alternate from step to step (the phase of a BatchNorm scratch: which half this step accumulates into) are XOR-ed with their
@@ -490,7 +491,6 @@ int maf_stream_destroy(maf_stream_t s);
  */
 #define MAF_TAPE_MAX_ARGS 28
 #define MAF_TAPE_FORK (-1)
-#define MAF_TAPE_JOIN (-2)
 typedef struct maf_tape_rec {
     int32_t fn, stream;
     uint64_t a[MAF_TAPE_MAX_ARGS];
@@ -501,7 +501,7 @@ typedef struct maf_tape_toggle {
 int32_t maf_tape_fn_id(const char* name);                   /* -1000: not a tape-able entry point */
 int32_t maf_tape_fn_nargs(int32_t fn);
 int32_t maf_tape_rec_size(void);
-int maf_tape_run(const maf_tape_rec_t* recs, int32_t first, int32_t last, maf_stream_t main, maf_stream_t side, int32_t* failed_at);
+int maf_tape_run(const maf_tape_rec_t* recs, int32_t first, int32_t last, const maf_stream_t* streams, int32_t n_streams, int32_t* failed_at);
 int maf_tape_toggle(const maf_tape_toggle_t* t, int32_t n);
 
 /*

@@ -71,35 +71,36 @@ constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 extern "C" int32_t maf_tape_fn_id(const char* name) {
     if (!name) return -1000;
     if (!strcmp(name, "maf_stream_fork")) return MAF_TAPE_FORK;
-    if (!strcmp(name, "maf_stream_join")) return MAF_TAPE_JOIN;
     for (int i = 0; i < kNumEntries; ++i)
         if (!strcmp(name, kEntries[i].name)) return i;
     return -1000;
 }
 
 extern "C" int32_t maf_tape_fn_nargs(int32_t fn) {
-    if (fn == MAF_TAPE_FORK || fn == MAF_TAPE_JOIN) return 2;
+    if (fn == MAF_TAPE_FORK) return 2;
     return fn >= 0 && fn < kNumEntries ? kEntries[fn].nargs : -1;
 }
 
 extern "C" int32_t maf_tape_rec_size(void) { return (int32_t)sizeof(maf_tape_rec_t); }
 
-// records [first, last) in order; the first failing record's index goes to *failed_at (maf_last_error holds its message)
-extern "C" int maf_tape_run(const maf_tape_rec_t* recs, int32_t first, int32_t last, maf_stream_t main, maf_stream_t side, int32_t* failed_at) {
-    MAF_REQUIRE(recs && first >= 0 && last >= first, "tape_run: bad arguments");
+// records [first, last) in order; streams[0] = the main stream, [1] = the weight-gradient stream, [2..] = lanes of independent branches; the first failing
+// record's index goes to *failed_at (maf_last_error holds its message)
+extern "C" int maf_tape_run(const maf_tape_rec_t* recs, int32_t first, int32_t last, const maf_stream_t* streams, int32_t n_streams, int32_t* failed_at) {
+    MAF_REQUIRE(recs && first >= 0 && last >= first && streams && n_streams >= 1, "tape_run: bad arguments");
     uint64_t a[MAF_TAPE_MAX_ARGS];
     for (int32_t i = first; i < last; ++i) {
         const maf_tape_rec_t& r = recs[i];
         int rc;
-        if (r.fn == MAF_TAPE_FORK) rc = maf_stream_fork(main, side);
-        else if (r.fn == MAF_TAPE_JOIN) rc = maf_stream_join(main, side);
-        else if (r.fn >= 0 && r.fn < kNumEntries) {
+        if (r.fn == MAF_TAPE_FORK) {                        // a[0] -> a[1]: stream a[1] waits for what stream a[0] holds
+            if (r.a[0] >= (uint64_t)n_streams || r.a[1] >= (uint64_t)n_streams) { maf_set_error("tape_run: stream index out of range in a fork record"); rc = MAF_E_ARG; }
+            else rc = maf_stream_fork(streams[r.a[0]], streams[r.a[1]]);
+        } else if (r.fn >= 0 && r.fn < kNumEntries && r.stream >= 0 && r.stream < n_streams) {
             const Entry& e = kEntries[r.fn];
             memcpy(a, r.a, sizeof(uint64_t) * e.nargs);
-            a[e.nargs - 1] = reinterpret_cast<uint64_t>(r.stream ? side : main);
+            a[e.nargs - 1] = reinterpret_cast<uint64_t>(streams[r.stream]);
             rc = e.call(a);
         } else {
-            maf_set_error("tape_run: unknown entry point in a record");
+            maf_set_error("tape_run: unknown entry point or stream in a record");
             rc = MAF_E_ARG;
         }
         if (rc) {

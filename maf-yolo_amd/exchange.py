@@ -236,6 +236,7 @@ class GradExchange:
             from . import train_ops
             side = train_ops.side_stream(b.flat.device)
             if b.main_contrib:                                                    # gradients autograd accumulated on the main stream
+                train_ops.join_lanes(b.flat.device)                               # ... or kernels added on a lane of a step tape (BatchNorm affine gradients of the head branches)
                 ev = torch.cuda.Event()
                 ev.record()
                 side.wait_event(ev)

@@ -242,13 +242,14 @@ class MPRep(nn.Module):
                 return holder[0].slot(0)
 
             xa, xb = train_ops.fanout(x, 2)                                      # two readers: their gradients meet in one launch (train_ops._Fanout)
-            a = self.conv1(self.mp(xa), out=slot0)
+            # (the pooled branch on a lane of a recording step tape, beside the 3 x 3 branch on the main stream)
+            a, lane = train_ops.lane_run(1, lambda t: self.conv1(self.mp(t), out=slot0), xa)
             if holder and train_ops.cat_free_ok(x, self.conv2.rbr_dense.bn) and train_ops.cat_free_ok(x, self.conv2.rbr_1x1.bn):
                 b = self.conv2(xb, out=holder[0].slot(1))
-                return train_ops.join(holder[0], [a, b])
+                return train_ops.join(holder[0], [train_ops.lane_join(a, lane), b])
             if x.is_cuda:
                 train_ops._glue()
-            return torch.cat([a, self.conv2(xb)], 1)
+            return torch.cat([train_ops.lane_join(a, lane), self.conv2(xb)], 1)
         if x.is_cuda:
             train_ops._glue()
         return torch.cat([self.conv1(self.mp(x)), self.conv2(x)], 1)
@@ -326,12 +327,24 @@ class Head_DepthUni(nn.Module):
             self.reg_pred.weight.zero_()
             self.reg_pred.bias.fill_(1.0)
 
-    def forward(self, x, raw=False):
-        """(stem features, class probabilities, box distributions); raw=True: the class LOGITS (Model applies the sigmoid behind a step tape's boundary)."""
+    def forward(self, x, raw=False, lanes=None):
+        """(stem features, class probabilities, box distributions); raw=True: the class LOGITS (Model applies the sigmoid behind a step tape's boundary).
+        lanes = (a, b): the two branches on lanes a and b of a recording step tape (train_ops.lane_run) — then (stem, logits, box, lane of the logits, lane of the
+        box tensor) comes back and the caller joins the lanes (train_ops.lane_join) before the main stream reads the two tensors."""
         x = self.stem(x)
         xc, xr = train_ops.fanout(x, 2)                                          # two branches read the stem: one launch sums their gradients
-        cls = train_ops.conv1x1(self.cls_conv_s(self.cls_conv(xc)), self.cls_pred.weight, self.cls_pred.bias)
-        reg = train_ops.conv1x1(self.reg_conv_s(self.reg_conv(xr)), self.reg_pred.weight, self.reg_pred.bias)
+
+        def cls_branch(t):
+            return train_ops.conv1x1(self.cls_conv_s(self.cls_conv(t)), self.cls_pred.weight, self.cls_pred.bias)
+
+        def reg_branch(t):
+            return train_ops.conv1x1(self.reg_conv_s(self.reg_conv(t)), self.reg_pred.weight, self.reg_pred.bias)
+
+        if lanes is not None:
+            cls, kc = train_ops.lane_run(lanes[0], cls_branch, xc)
+            reg, kr = train_ops.lane_run(lanes[1], reg_branch, xr)
+            return x, (cls if raw else torch.sigmoid(cls)), reg, kc, kr
+        cls, reg = cls_branch(xc), reg_branch(xr)
         return x, (cls if raw else torch.sigmoid(cls)), reg
 
 

@@ -186,7 +186,7 @@ def load():
     lib.maf_tape_fn_nargs.argtypes = [C.c_int32]
     lib.maf_tape_fn_nargs.restype = C.c_int32
     lib.maf_tape_rec_size.restype = C.c_int32
-    lib.maf_tape_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.maf_tape_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.maf_tape_toggle.argtypes = [C.c_void_p, C.c_int32]
     if lib.maf_tape_rec_size() != C.sizeof(MafTapeRec):
         raise MafError("libmafyolo_hip.so was built for a maf_tape_rec_t of %d bytes, this binding declares %d: rebuild" % (lib.maf_tape_rec_size(), C.sizeof(MafTapeRec)))

@@ -246,23 +246,40 @@ class Model(nn.Module):
                     for j in nd.sources():
                         uses[j] = uses.get(j, 0) + 1
         y = []
+        n_head, n_cw, on_lane = 0, 0, {}
         for nd, m in zip(self.nodes, self.backbone):
             if nd.i > 0:
+                for j in nd.sources():
+                    if j in on_lane:                                              # its producer ran on a lane: the main stream takes the tensor over
+                        y[j] = train_ops.lane_join(y[j], on_lane.pop(j))
                 src = [y[j].pop() if isinstance(y[j], _Aliases) else y[j] for j in nd.sources()]
                 x = src if isinstance(nd.f, list) else src[0]
             r = res.get(nd.i) if train_ops.cat_free else None
-            if r is not None:
+            if raw_heads and isinstance(m, ConvWrapper) and isinstance(x, torch.Tensor):
+                # a recording step tape: the side convs of the neck (two equal, independent ones per level: backbone.23 / .24, .27 / .28) take turns on a lane and the
+                # main stream; whoever reads the result first joins the lane (below)
+                n_cw += 1
+                out_ = None if r is None else slot_of(*r)
+                x, ln = train_ops.lane_run(n_cw % 2, (lambda t, m=m, o=out_: m(t) if o is None else m(t, out=o)), x)
+                if ln and uses.get(nd.i, 0) > 1:
+                    x = train_ops.lane_join(x, ln)
+                elif ln:
+                    on_lane[nd.i] = ln
+            elif r is not None:
                 x = m(x, out=slot_of(*r))
             elif nd.i in bufs:
                 x = train_ops.join(bufs.pop(nd.i), x)
             elif raw_heads and isinstance(m, Head_DepthUni):
-                x = m(x, raw=True)
+                x = m(x, raw=True, lanes=(2 * n_head + 1, 2 * n_head + 2))      # a recording step tape: the six head branches on lanes of their own
+                n_head += 1
             else:
                 x = m(x)
             n_use = uses.get(nd.i, 0)
             if n_use > 1 and isinstance(x, torch.Tensor) and x.is_cuda and x.requires_grad and train_ops.cat_free:
                 x = _Aliases(train_ops.fanout(x, n_use))
             y.append(x)
+        if raw_heads:                         # (stem, logits, box, lane, lane): the main stream takes the two tensors over from their lanes
+            x = [(h[0], train_ops.lane_join(h[1], h[3]), train_ops.lane_join(h[2], h[4])) for h in x]
         return x                              # list of three (stem, cls, reg)
 
     def _train_heads(self, x):

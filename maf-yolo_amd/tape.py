@@ -94,24 +94,23 @@ class StepTape:
         recs = self.lists[self.phase]
         r = lib.MafTapeRec()
         r.fn = fid
-        if fid in (-1, -2):                      # maf_stream_fork / _join(main, side): the executor passes its own two handles
-            if (args[0], args[1]) != ((self.main, self.side) if fid == -1 else (self.main, self.side)):
-                raise lib.MafError("step tape: %s between streams the tape does not know" % name)
+        if fid == -1:                            # maf_stream_fork(src, dst): the record holds the two stream indices
+            r.a[0], r.a[1] = self._sidx(args[0], name), self._sidx(args[1], name)
             recs.append(r)
             return
         if len(args) != len(argtypes) or len(args) > lib.TAPE_MAX_ARGS:
             raise lib.MafError("step tape: %s called with %d arguments (declared: %d)" % (name, len(args), len(argtypes)))
-        st = args[-1]
-        st = st.value if isinstance(st, C.c_void_p) else st
-        if st == self.main:
-            r.stream = 0
-        elif st == self.side:
-            r.stream = 1
-        else:
-            raise lib.MafError("step tape: %s on a stream that is neither the main nor the weight-gradient stream of the recording" % name)
+        r.stream = self._sidx(args[-1], name)
         for i, (a, at) in enumerate(zip(args, argtypes)):
             r.a[i] = self._word(a, at, len(recs), i)
         recs.append(r)
+
+    def _sidx(self, st, name):
+        st = st.value if isinstance(st, C.c_void_p) else st
+        i = self.sidx.get(st or 0)
+        if i is None:
+            raise lib.MafError("step tape: %s on a stream the recording does not know (main, weight-gradient stream, lanes)" % name)
+        return i
 
     def _word(self, a, at, ri, slot):
         if isinstance(a, lib.Phase):
@@ -156,11 +155,20 @@ class StepTape:
 
     def begin(self, which):
         """Start recording region `which` ("fwd": from the step's pack batch to the head outputs; "bwd": from the boundary node to the end of the engine's pass)."""
-        self.main = train_ops._stream(self.dev)
-        self.side = train_ops.side_stream(self.dev).cuda_stream if train_ops.wgrad_stream else self.main
+        self._set_streams()
         self.phase = which
         lib._recorder = _Proxy(lib._lib, self)
         train_ops._keep, train_ops._rec = self.keep, self
+
+    def _set_streams(self):
+        """[main, weight-gradient stream, lanes ...] as raw handles: what the records' stream indices mean (the main stream is whatever is current now)."""
+        self.main = train_ops._stream(self.dev) or 0
+        self.side = (train_ops.side_stream(self.dev).cuda_stream or 0) if train_ops.wgrad_stream else self.main
+        hs = [self.main, self.side] + [h or 0 for h in train_ops.lane_handles(self.dev)]
+        self.sidx = {}
+        for i, h in enumerate(hs):
+            self.sidx.setdefault(h, i)
+        self.harr = (C.c_void_p * len(hs))(*hs)
 
     def end(self):
         self.phase = None
@@ -256,7 +264,7 @@ class StepTape:
     # ------------------------------------------------------------------ replay
     def _run(self, which, first, last):
         bad = C.c_int32(-1)
-        rc = lib._lib.maf_tape_run(self.arr[which], first, last, self.main, self.side, C.byref(bad))
+        rc = lib._lib.maf_tape_run(self.arr[which], first, last, self.harr, len(self.harr), C.byref(bad))
         if rc:
             raise lib.MafError("step tape: %s record %d failed: %s" % (which, bad.value, lib._lib.maf_last_error().decode()))
 
@@ -320,7 +328,6 @@ class _TapeStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tape, anchor):
         ctx.tape = tape
-        tape.main = train_ops._stream(tape.dev)
         tape._run("fwd", 0, tape.n["fwd"])
         tape._toggle("fwd")
         tape.pending_backward = True

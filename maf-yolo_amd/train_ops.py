@@ -126,8 +126,54 @@ def profile_collect():
 _raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, "_cuda_getCurrentRawStream") else None
 
 
+# Lanes: independent branches of the train-form graph (the class / box branch of every detection head, common.py:1288-1336) on streams of their own while a
+# step tape records — and therefore in every replay.  Their kernels are small (20 x 20 ... 80 x 80 maps, 5-50 us each, bound by launch latency and fixed
+# costs, not by the chip), so two or three such chains side by side cost little more than one.  Only a recording step uses them: the tape keeps every buffer
+# alive, so memory handed from one stream to another needs no allocator bookkeeping; eager steps run everything on the current stream.
+n_lanes = int(os.environ.get("MAF_TRAIN_LANES", "2"))      # (3 lanes + main + weight-gradient stream are more streams than the runtime's 4 default hardware queues: streams that share a queue serialise — measured 35.8 ms per step against 20.5 with 2)
+_cur_lane = 0                                    # 0: the current (main) stream; k: lane k
+_lane_streams = {}
+_lane_rejects = []
+
+
+def lane_handles(dev):
+    """Raw handles of the lane streams of `dev` (created on first use, on hardware queues of their own where the runtime has any left)."""
+    if n_lanes <= 0:
+        return []
+    ls = _lane_streams.get(dev.index)
+    if ls is None:
+        # streams that demonstrably overlap with each other AND with the weight-gradient stream (streams.concurrent_streams: timed spin kernels; two streams on
+        # one hardware queue run strictly one after the other)
+        from .streams import concurrent_streams, overlap_ratio
+        side = side_stream(dev)
+        picked = []
+        for _ in range(4):
+            cand = concurrent_streams(dev, n_lanes)
+            if overlap_ratio([side] + cand) < 1.5:
+                picked = cand
+                break
+            _lane_rejects.append(cand)                                           # kept alive: a destroyed stream's queue slot would be handed out again
+        ls = _lane_streams[dev.index] = picked or cand
+    return [s_.cuda_stream for s_ in ls]
+
+
+def join_lanes(dev):
+    """The current stream waits for every lane of `dev` (host-side: the gradient exchange calls it before a bucket's all-reduce is ordered behind the main stream)."""
+    ls = _lane_streams.get(dev.index)
+    if ls:
+        main = _lane_handle(dev, 0)
+        for s_ in ls:
+            lib.check(lib._lib.maf_stream_fork(s_.cuda_stream, main))
+
+
+def lanes_on(dev):
+    return _rec is not None and n_lanes > 0 and dev.type == "cuda"
+
+
 def _stream(dev):
     """Raw handle of the device's current stream (torch.cuda.current_stream builds a Stream object per call: 4.5 us, ~600 calls per step)."""
+    if _cur_lane:
+        return _lane_streams[dev.index][_cur_lane - 1].cuda_stream
     if _raw_stream is not None:
         return _raw_stream(dev.index)
     return torch.cuda.current_stream(dev).cuda_stream
@@ -466,6 +512,77 @@ def _staged_bias(bias, cout, npad, dev):
 zero_padded = {}
 
 
+def _laned(cls):
+    """Class decorator of the autograd Functions below: forward remembers the lane it ran on, backward issues its kernels on the same one."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a, **k):
+        ctx._lane = _cur_lane
+        return fwd(ctx, *a, **k)
+
+    def backward(ctx, *g):
+        global _cur_lane
+        old, _cur_lane = _cur_lane, getattr(ctx, "_lane", _cur_lane)
+        try:
+            return bwd(ctx, *g)
+        finally:
+            _cur_lane = old
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+def _lane_handle(dev, k):
+    if k == 0:
+        global _cur_lane
+        old, _cur_lane = _cur_lane, 0
+        try:
+            return _stream(dev)
+        finally:
+            _cur_lane = old
+    return _lane_streams[dev.index][k - 1].cuda_stream
+
+
+class _LaneSwitch(torch.autograd.Function):
+    """Identity that hands a tensor from stream `src` to stream `dst` (0: the main stream, k: lane k): forward, `dst` waits for what `src` holds; backward, `src`
+    waits for what `dst` holds (the gradient comes the other way)."""
+
+    @staticmethod
+    def forward(ctx, x, src, dst):
+        ctx.src, ctx.dst, ctx.dev = src, dst, x.device
+        lib.check(lib.load().maf_stream_fork(_lane_handle(x.device, src), _lane_handle(x.device, dst)))
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib.check(lib.load().maf_stream_fork(_lane_handle(ctx.dev, ctx.dst), _lane_handle(ctx.dev, ctx.src)))
+        return g, None, None
+
+
+def lane_run(k, fn, x):
+    """fn(x) with its kernels on lane k (k = 0 or no recording tape: plain fn(x)).  The result lives on that lane: `lane_join` before anything on the main stream reads it."""
+    global _cur_lane
+    if k <= 0 or _cur_lane or not isinstance(x, torch.Tensor) or not lanes_on(x.device):
+        return fn(x), 0
+    lane_handles(x.device)
+    k = k % (n_lanes + 1)                                                        # chains 1, 2, 3 ... go round lane 1 .. lane n and the main stream (0)
+    if k == 0:
+        return fn(x), 0
+    x = _LaneSwitch.apply(x, 0, k)
+    _cur_lane = k
+    try:
+        y = fn(x)
+    finally:
+        _cur_lane = 0
+    return y, k
+
+
+def lane_join(y, k):
+    """The main stream waits for lane k (what `lane_run` returned beside y); backward: the lane waits for the main stream's gradient."""
+    return y if k <= 0 else _LaneSwitch.apply(y, k, 0)
+
+
+@_laned
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -633,6 +750,7 @@ def _packed_3x3(w, transpose, dt, ct, dev):
     return _staged(w, ("d", cout, cin, 9, int(transpose), dt, ct), nbytes, fields, now)
 
 
+@_laned
 class _Conv3x3s2(torch.autograd.Function):
     """nn.Conv2d(k=3, stride=2, padding=1, bias=False): forward csrc/conv_mfma.inc.h VAR_3X3S2, data gradient VAR_DGRAD3 (gather form),
     weight gradient csrc/wgrad.hip with the taps gathered in the kernel."""
@@ -699,6 +817,7 @@ class _Conv3x3s2(torch.autograd.Function):
         return dx, dw
 
 
+@_laned
 class _Conv1x1s2(torch.autograd.Function):
     """nn.Conv2d(k=1, stride=2, bias=False) (RepVGGBlock.rbr_1x1, common.py:203): the 1x1 kernel reading pixel (2y, 2x) of its source
     (MAF_SRC_SUB2); data gradient = the 1x1 data gradient scattered onto the even pixels; weight gradient csrc/wgrad.hip, one gathered tap."""
@@ -771,6 +890,7 @@ class _Ctx:
         self.saved_tensors = t
 
 
+@_laned
 class _RepVGGConvs(torch.autograd.Function):
     """(conv3x3 s2 (x, w3), conv1x1 s2 (x, w1)) — the two branches of a RepVGGBlock (yolov6/layers/common.py:199-203) as ONE autograd node, so that their
     data gradients meet inside it: the 1x1 branch's gradient lives on the even pixels only and is added onto the 3x3 branch's in place (maf_add_sub2, a quarter
@@ -909,6 +1029,7 @@ def _packed_dw(w, c, k, flip, dt, dev):
     return _staged(w, ("w", c, k, flip, dt), nbytes, fields, now)
 
 
+@_laned
 class _DWConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
@@ -991,6 +1112,7 @@ def _launch_dwb(srcs, dsts, wps, k0, B, H, W, c, dt, dgrad, dev, bstats=None):
             lib.check(L.maf_dw_branches(sp, ss, dp, ds, wp, nb, k0, B, H, W, c, dt, 1 if dgrad else 0, _stream(dev)))
 
 
+@_laned
 class _DWBranches(torch.autograd.Function):
     """The parallel depth-wise branches of a train-form DilatedReparamBlock (yolov6/layers/common.py:3024-3031) on csrc/dw_branches.hip: one launch
     computes every branch's convolution of the shared input, one launch their summed data gradient; the weight gradients stay per branch on the side stream."""
@@ -1102,6 +1224,7 @@ def _bn_part(dev, c):
     return ent[0], ent[1]
 
 
+@_laned
 class _BNAct(torch.autograd.Function):
     """act(BatchNorm2d(x) [+ residual]) in training mode on the HIP kernels of csrc/bn_act.hip (batch statistics, running-stat update)."""
 
@@ -1267,6 +1390,7 @@ class CatBuffer:
         return t
 
 
+@_laned
 class _Join(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cb, *parts):
@@ -1307,6 +1431,7 @@ def join(cb, parts):
     return _Join.apply(cb, *parts)
 
 
+@_laned
 class _Fork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, lo):
@@ -1340,6 +1465,7 @@ def nhwc_sum(srcs, dst, accumulate=False):
     stats["native_nhwc_sum"] = stats.get("native_nhwc_sum", 0) + 1
 
 
+@_laned
 class _Fanout(torch.autograd.Function):
     """n aliases of one tensor for n consumers; backward = the sum of their gradients in ONE launch (fp32 sum, one rounding) instead of the autograd
     engine's add kernel per extra consumer — and a launch a step tape can record."""
@@ -1409,6 +1535,7 @@ def _bnsum_part(dev, c, nb):
     return ent[0], ent[1]
 
 
+@_laned
 class _BNSum(torch.autograd.Function):
     """sum_j BatchNorm2d_j(z_j) in training mode, no activation (the branch sum of a DilatedReparamBlock, yolov6/layers/common.py:3024-3031) on csrc/bn_sum.hip:
     ONE apply pass forward (the statistics come from the depth-wise kernel's epilogue or a statistics launch per branch that lacks them), one statistics + one
@@ -1517,6 +1644,7 @@ def bn_sum(zs, bns, pre_stats=None, act=None, out=None):
     return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act], out), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
+@_laned
 class _MaxPool(torch.autograd.Function):
     """MaxPool2d(k, stride, pad) on csrc/pool_train.hip: forward keeps a one-byte argmax, backward gathers (the framework's backward scatters
     with atomics over overlapping windows — 271 us per SPPF pool on 32 x 192 x 20 x 20 — and drags int64 indices along)."""
@@ -1545,6 +1673,7 @@ class _MaxPool(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+@_laned
 class _Up2(torch.autograd.Function):
     """nn.Upsample(scale_factor=2, mode="nearest") on csrc/pool_train.hip: the source may be a channel slice (a concat buffer's slot), the result may go into one."""
 
