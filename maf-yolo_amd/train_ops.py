@@ -130,30 +130,40 @@ _raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, "_cuda_get
 # step tape records — and therefore in every replay.  Their kernels are small (20 x 20 ... 80 x 80 maps, 5-50 us each, bound by launch latency and fixed
 # costs, not by the chip), so two or three such chains side by side cost little more than one.  Only a recording step uses them: the tape keeps every buffer
 # alive, so memory handed from one stream to another needs no allocator bookkeeping; eager steps run everything on the current stream.
-n_lanes = int(os.environ.get("MAF_TRAIN_LANES", "2"))      # (3 lanes + main + weight-gradient stream are more streams than the runtime's 4 default hardware queues: streams that share a queue serialise — measured 35.8 ms per step against 20.5 with 2)
+n_lanes = int(os.environ.get("MAF_TRAIN_LANES", "2"))      # at most (lane_handles: four hardware queues for main, weight gradients, lanes and RCCL)
 _cur_lane = 0                                    # 0: the current (main) stream; k: lane k
 _lane_streams = {}
 _lane_rejects = []
 
 
 def lane_handles(dev):
-    """Raw handles of the lane streams of `dev` (created on first use, on hardware queues of their own where the runtime has any left)."""
+    """Raw handles of the lane streams of `dev`, created on first use.  The runtime multiplexes a process's streams onto FOUR hardware queues and streams that
+    share one serialise — with cross-stream waits between them a step then takes 35 ms instead of 20 (measured twice: three lanes; two lanes beside RCCL's own
+    stream) — so the lanes are few (main + weight-gradient stream + lanes [+ RCCL's stream] <= 4) and PROBED: a set is taken only if spin kernels on the main
+    stream, the weight-gradient stream and the lanes at once take about as long as one alone (streams.overlap_ratio); else one lane fewer, down to none."""
     if n_lanes <= 0:
         return []
     ls = _lane_streams.get(dev.index)
     if ls is None:
-        # streams that demonstrably overlap with each other AND with the weight-gradient stream (streams.concurrent_streams: timed spin kernels; two streams on
-        # one hardware queue run strictly one after the other)
         from .streams import concurrent_streams, overlap_ratio
-        side = side_stream(dev)
+        want = min(n_lanes, 2)
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                want = min(want, 1)
+        except Exception:
+            pass
+        main, side = torch.cuda.current_stream(dev), side_stream(dev)
         picked = []
-        for _ in range(4):
-            cand = concurrent_streams(dev, n_lanes)
-            if overlap_ratio([side] + cand) < 1.5:
-                picked = cand
-                break
-            _lane_rejects.append(cand)                                           # kept alive: a destroyed stream's queue slot would be handed out again
-        ls = _lane_streams[dev.index] = picked or cand
+        while want > 0 and not picked:
+            for _ in range(3):
+                cand = concurrent_streams(dev, want)
+                if overlap_ratio([main, side] + cand) < 1.5:
+                    picked = cand
+                    break
+                _lane_rejects.append(cand)                                       # kept alive: a destroyed stream's queue slot would be handed out again
+            want -= 1
+        ls = _lane_streams[dev.index] = picked
     return [s_.cuda_stream for s_ in ls]
 
 
@@ -167,7 +177,7 @@ def join_lanes(dev):
 
 
 def lanes_on(dev):
-    return _rec is not None and n_lanes > 0 and dev.type == "cuda"
+    return _rec is not None and n_lanes > 0 and dev.type == "cuda" and bool(_lane_streams.get(dev.index))
 
 
 def _stream(dev):
@@ -564,8 +574,7 @@ def lane_run(k, fn, x):
     global _cur_lane
     if k <= 0 or _cur_lane or not isinstance(x, torch.Tensor) or not lanes_on(x.device):
         return fn(x), 0
-    lane_handles(x.device)
-    k = k % (n_lanes + 1)                                                        # chains 1, 2, 3 ... go round lane 1 .. lane n and the main stream (0)
+    k = k % (len(_lane_streams[x.device.index]) + 1)                             # chains 1, 2, 3 ... go round lane 1 .. lane n and the main stream (0)
     if k == 0:
         return fn(x), 0
     x = _LaneSwitch.apply(x, 0, k)
