@@ -342,13 +342,19 @@ dim3 stats_grid(int M, int C, int dtype, size_t* lds) {
 }
 
 bool g_det = false;
-float* g_det_buf = nullptr;
-size_t g_det_cap = 0;
+constexpr int kMaxDev = 16;
+float* g_det_bufs[kMaxDev] = {};                                     // one slot buffer per device (a process may drive several)
+size_t g_det_caps[kMaxDev] = {};
 
 // deterministic mode: the slot buffer (grow-only, owned by the library) and the launch geometry of the statistics kernel
 int det_prepare(BnArgs2& a, const dim3& gs, int C, int dtype, size_t* lds, hipStream_t s) {
     a.det = nullptr;
     if (!g_det) return 0;
+    int dev = 0;
+    if (int rc = maf_check_hip(hipGetDevice(&dev), "bn deterministic: hipGetDevice")) return rc;
+    MAF_REQUIRE(dev >= 0 && dev < kMaxDev, "bn deterministic: device index out of range");
+    float*& g_det_buf = g_det_bufs[dev];
+    size_t& g_det_cap = g_det_caps[dev];
     const size_t need = (size_t)gs.x * 2 * C * sizeof(float);
     if (need > g_det_cap) {
         if (int rc = maf_check_hip(hipDeviceSynchronize(), "bn deterministic: hipDeviceSynchronize")) return rc;

@@ -272,7 +272,18 @@ class GradExchange:
         then make the main stream wait for the side stream and for every collective, and reset the per-pass state."""
         try:
             if self._sync:
-                for b in self.buckets[self._next:]:
+                late = self.buckets[self._next:]
+                if late and any(b_.arrived for b_ in self.buckets):
+                    # buckets that never completed during backward (a parameter without a gradient in this pass holds its bucket AND every later one: they
+                    # go out in bucket order) are reduced only here, with no backward left to hide them behind: counted, and named once
+                    self.stats["late_buckets"] = self.stats.get("late_buckets", 0) + len(late)
+                    if not getattr(self, "_late_warned", False):
+                        self._late_warned = True
+                        missing = [self.names.get(id(p_), "?") for b_ in late for p_ in b_.params if id(p_) not in b_.arrived][:8]
+                        import warnings
+                        warnings.warn("GradExchange: %d of %d buckets were reduced only at the end of backward (no overlap); parameters without a gradient in this pass: %s"
+                                      % (len(late), len(self.buckets), missing))
+                for b in late:
                     b.main_contrib = True
                     self._launch(b)
             for b in self.buckets:

@@ -95,6 +95,10 @@ class RepVGGBlock(nn.Module):
         # both branches (conv + BatchNorm each) on the HIP kernels
         if x.is_cuda and x.shape[1] % 8:
             x = train_ops.pad_channels8(x)                                       # the image: cast + channel padding once for both branches
+        if out is not None and not (train_ops.cat_free_ok(x, self.rbr_dense.bn) and train_ops.cat_free_ok(x, self.rbr_1x1.bn) and self.rbr_dense.conv.out_channels % 8 == 0):
+            out = None                                                           # (a frozen branch BatchNorm: the torch path cannot store into a slot — the concat copies, as in Conv.forward)
+        elif callable(out):
+            out = None                                                           # (a slot that does not exist yet needs the output's shape first: only Conv resolves those)
         # ReLU(BN(3x3) + BN(1x1)): one apply pass over both branch tensors (csrc/bn_sum.hip; backward: one statistics + one apply launch for both BatchNorms,
         # the ReLU's mask recomputed from the branch tensors)
         # (the two convs are one autograd node: the 1x1 branch's data gradient is added onto the 3x3 branch's on the even pixels, in place)

@@ -56,10 +56,11 @@ def _the_tape(model):
     return ent[1]
 
 
-def test_tape_records_a_step_without_torch_kernels_between_its_launches():
+@pytest.mark.parametrize("scale", ["n", "s", "m"])
+def test_tape_records_a_step_without_torch_kernels_between_its_launches(scale):
     """Steps 1-2 run eagerly (conv variants timed, weight staging plan filled), step 3 is recorded under the dispatch-mode check: no device op of torch's inside the
     recorded regions (it would be missing from a replay), the check did see both regions (also on the autograd engine's thread), the lists hold the step's launches."""
-    model = _model()
+    model = _model(scale)
     ex = M.GradExchange(model)
     crit = M.ComputeLoss(ori_img_size=128, warmup_epoch=0)
     x, t = _batch(4, 128)
