@@ -331,6 +331,8 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
     if not args.torch_convs:
         # EVERY rank runs this step (it carries the gradient all-reduce: a step on rank 0 alone would wait for its peers forever);
         # only rank 0 records the events
+        model.step_tape = False                # the event pairs need the eager path (one autograd Function per launch); one untimed eager step first: after the
+        step()                                 # replayed steps its weight staging plan and Python paths are cold, and a host-bound step inflates what the event pairs see
         if rank == 0:
             train_ops.profile = {}
         step()

@@ -1570,13 +1570,15 @@ class _BNSum(torch.autograd.Function):
         sp = stat.data_ptr()
         g32 = [g.detach() if g.dtype == torch.float32 and g.is_contiguous() else g.detach().float().contiguous() for g in gammas]
         b32 = [b.detach() if b.dtype == torch.float32 and b.is_contiguous() else b.detach().float().contiguous() for b in betas]
+        # (the argument arrays are built OUTSIDE the timed region: on a host-bound eager step the event pair would measure their construction)
+        args = (_PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, M_, c, dt,
+                _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[b.data_ptr() for b in b32]), float(eps), float(momentum),
+                _PTR4(*[0 if p[0] is None else p[0].data_ptr() for p in per]), _PTR4(*[0 if p[1] is None else p[1].data_ptr() for p in per]),
+                _PTR4(*[0 if p[2] is None else p[2].data_ptr() for p in per]),
+                out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
+                _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _phase_array([p[4] for p in per]), act, _stream(dev))
         with _prof("bn_sum_forward", (nb + 1) * M_ * c * x0.element_size(), dev, (B, H, W, c, nb)):
-            lib.check(L.maf_bn_sum_forward(_PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, M_, c, dt,
-                                           _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[b.data_ptr() for b in b32]), float(eps), float(momentum),
-                                           _PTR4(*[0 if p[0] is None else p[0].data_ptr() for p in per]), _PTR4(*[0 if p[1] is None else p[1].data_ptr() for p in per]),
-                                           _PTR4(*[0 if p[2] is None else p[2].data_ptr() for p in per]),
-                                           out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
-                                           _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _phase_array([p[4] for p in per]), act, _stream(dev)))
+            lib.check(L.maf_bn_sum_forward(*args))
         ctx.save_for_backward(stat, *[z for z, _ in zs], *g32, *b32)
         ctx.nb, ctx.act = nb, act
         ctx.affine = list(zip(gammas, betas)) if all(isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter) for g, b in zip(gammas, betas)) else None
@@ -1607,13 +1609,14 @@ class _BNSum(torch.autograd.Function):
         part, phase = _bnsum_part(dev, c, nb)
         sp = stat.data_ptr()
         gp = None if dgb is None else dgb.data_ptr()
-        with _prof("bn_sum_backward", (2 + 3 * nb) * B * H * W * c * x0.element_size(), dev, (B, H, W, c, nb)):
-            lib.check(lib.load().maf_bn_sum_backward(dy.data_ptr(), dys, _PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, B * H * W, c, _DT[x0.dtype],
+        args = (dy.data_ptr(), dys, _PTR4(*[z.data_ptr() for z, _ in zs]), _INT4(*[zst for _, zst in zs]), nb, B * H * W, c, _DT[x0.dtype],
                                                      _PTR4(*[g.data_ptr() for g in g32]), _PTR4(*[b.data_ptr() for b in b32]), _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
                                                      _PTR4(*[d.data_ptr() for d in dzs]), _INT4(*[d.stride()[3] for d in dzs]),
                                                      _PTR4(*[tg[j][0][1].data_ptr() if tg is not None else gp + 8 * c * j for j in range(nb)]),
                                                      _PTR4(*[tg[j][1][1].data_ptr() if tg is not None else gp + 8 * c * j + 4 * c for j in range(nb)]),
-                                                     1 if tg is not None else 0, part.data_ptr(), _BN_REPLICAS, phase, ctx.act, _stream(dev)))
+                                                     1 if tg is not None else 0, part.data_ptr(), _BN_REPLICAS, phase, ctx.act, _stream(dev))
+        with _prof("bn_sum_backward", (2 + 3 * nb) * B * H * W * c * x0.element_size(), dev, (B, H, W, c, nb)):
+            lib.check(lib.load().maf_bn_sum_backward(*args))
         if tg is not None:
             for g, b in ctx.affine:
                 ex.main_done(g)
