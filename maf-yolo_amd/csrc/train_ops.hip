@@ -241,10 +241,11 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     // 160 x 160 maps, which stream; 4 elsewhere — half the LDS, twice the workgroups per CU: 932 -> 727 us over ten shapes of a step —
     // and 2 for the 9 x 9 kernels on 20 x 20 (199 -> 98 us).  20-wide tiles (no waste on 20 / 40 / 80-wide maps) measured slower: five
     // strips per row are not a power of two for the lane shuffles.
-    int tile20 = 0, gmax = (long long)a.H * a.W >= 160 * 160 ? 8 : (k == 9 && a.H * a.W <= 400) ? 2 : 4, maxthr = 256, wgcap = 1024;
-    if (const char* e = getenv("MAF_DWWG")) sscanf(e, "%d,%d,%d,%d", &tile20, &gmax, &maxthr, &wgcap);
+    int tile20 = 0, gmax = (long long)a.H * a.W >= 160 * 160 ? 8 : (k == 9 && a.H * a.W <= 400) ? 2 : 4, maxthr = 256, wgcap = 1024, th = 0, tw = 0, abudget = 1500000;
+    if (const char* e = getenv("MAF_DWWG")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &tile20, &gmax, &maxthr, &wgcap, &th, &tw, &abudget);
     a.TH = (tile20 && a.H % 10 == 0 && a.H <= 40) ? 10 : min(8, a.H);
     a.TW = (tile20 && a.W % 20 == 0) ? 20 : 16;
+    if (th > 0 && tw > 0 && tw % 4 == 0) { a.TH = min(th, a.H); a.TW = tw; }      // sweep override (tools/dw_wgrad_sweep.py)
     const int groups = a.C / N, nblk = maf_cdiv(groups, gmax);
     const int cgb = maf_cdiv(groups, nblk);
     a.CB = cgb * N;                                                     // balanced channel blocks (72 channels: 40 + 32)
@@ -259,7 +260,7 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     int per = a.B * a.tilesY * a.tilesX;                                // workgroups per channel block
     const int cap = maf_cdiv(wgcap, a.nCB);
     if (per > cap) per = cap;
-    const int budget = (int)(1500000ll / ((long long)a.C * k * k));      // every workgroup ends with C*k*k/nCB atomics: keep their total ~1.5 M
+    const int budget = (int)((long long)abudget / ((long long)a.C * k * k));      // every workgroup ends with C*k*k/nCB atomics: keep their total ~1.5 M
     if (per > budget) per = budget > 8 ? budget : 8;
     const dim3 g(per * a.nCB), b(nthr);
     switch (k) {

@@ -7,6 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(160, 72, 3), (80, 192, 3), (80, 192, 5), (80, 128, 5), (40, 288, 7), (40, 192, 7), (20, 576, 9), (20, 288, 9), (20, 192, 5), (40, 128, 3)]
+if os.environ.get("SMALL"):                   # the small maps only (round 5: whole-plane tiles)
+    SHAPES = [(20, 576, 9), (20, 576, 7), (20, 576, 5), (20, 576, 3), (20, 288, 9), (20, 288, 7), (20, 192, 9), (20, 192, 7), (40, 288, 7), (40, 288, 5), (40, 192, 7), (40, 192, 5), (40, 128, 7), (40, 128, 3)]
 if len(sys.argv) > 1:
     from maf_yolo_amd import lib
     L = lib.load()
