@@ -37,6 +37,7 @@ struct WgArgs2 {
     int gather, Ho, Wo, Hs, Ws, tap0;
     int dw_stride;        // floats between consecutive co rows of one tap
     long long dw_tap;     // floats between consecutive taps (3x3: tap-major result)
+    int ntaps, cchunk, Cin_all;   // blockIdx.z = channel chunk * ntaps + tap: chunk z / ntaps covers input channels [chunk * cchunk, min(Cin_all, (chunk + 1) * cchunk))
 };
 
 typedef __fp16 tr4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -61,7 +62,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
     const int co0 = blockIdx.y * cob;
     half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [kPix][SX]
     half_t* Ds = Xs + kPix * SX;                                         // [kPix][SD]
-    const int tap = a.tap0 + blockIdx.z, tky = tap / 3, tkx = tap - tky * 3;
+    const int zc = blockIdx.z / a.ntaps, zt = blockIdx.z - zc * a.ntaps;
+    const int tap = a.tap0 + zt, tky = tap / 3, tkx = tap - tky * 3;
+    // channel chunk of this workgroup (inputs wider than 256 channels: the LDS tile holds one chunk; all chunks are ONE grid — as separate launches of ~150 workgroups each
+    // the 20 x 20 layers ran their three chunks one after the other on a chip they could not fill)
+    const half_t* xbase = a.x + zc * a.cchunk;
+    float* dwbase = a.dw + zc * a.cchunk;
+    const int Cin = min(a.cchunk, a.Cin_all - zc * a.cchunk);
 
     // staging items of this thread: (row, 8-channel chunk), the same for every step
     const int xg = cib >> 3, dg = cob >> 3;
@@ -84,14 +91,14 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
         for (int u = 0; u < XR; ++u) {
             half8_t v = (half8_t)(half_t)0;
             const int m = m0 + xrow[u];
-            if (xrow[u] >= 0 && m < m_end && xch[u] < a.Cin) {
+            if (xrow[u] >= 0 && m < m_end && xch[u] < Cin) {
                 if (!a.gather) {
-                    v = *reinterpret_cast<const half8_t*>(a.x + (size_t)m * a.x_stride + xch[u]);
+                    v = *reinterpret_cast<const half8_t*>(xbase + (size_t)m * a.x_stride + xch[u]);
                 } else {
                     const int ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
                     const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
                     if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
-                        v = *reinterpret_cast<const half8_t*>(a.x + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + xch[u]);
+                        v = *reinterpret_cast<const half8_t*>(xbase + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + xch[u]);
                 }
             }
             xr[u] = v;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + (wi * TI + i) * 16 + g * 4 + r;
-                if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)(tap - a.tap0) * a.dw_tap + (size_t)co * a.dw_stride + ci, acc[i][j][r]);
+                if (co < a.Cout && ci < Cin) atomicAdd(dwbase + (size_t)(tap - a.tap0) * a.dw_tap + (size_t)co * a.dw_stride + ci, acc[i][j][r]);
             }
         }
 }
@@ -279,11 +286,13 @@ int launch_tr(const WgArgs2& a, dim3 grid, size_t lds, hipStream_t s) {
 
 // one launch over a channel chunk (Cin <= 256) of X; dw points at the chunk's first input channel, rows are dw_stride floats apart,
 // taps dw_tap floats apart
-static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_stride, int M, int Cin, int Cout, float* dw, int dw_stride, long long dw_tap,
+static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_stride, int M, int Cin_all, int cchunk, int Cout, float* dw, int dw_stride, long long dw_tap,
                         int gather, int Ho, int Wo, int Hs, int Ws, int tap0, int ntaps, hipStream_t s) {
     WgArgs2 b;
+    const int Cin = cchunk < Cin_all ? cchunk : Cin_all, nchunk = (Cin_all + cchunk - 1) / cchunk;
     b.x = x; b.dy = dy; b.dw = dw; b.M = M; b.Cin = Cin; b.Cout = Cout; b.x_stride = x_stride; b.dy_stride = dy_stride;
     b.gather = gather; b.Ho = Ho; b.Wo = Wo; b.Hs = Hs; b.Ws = Ws; b.tap0 = tap0; b.dw_stride = dw_stride; b.dw_tap = dw_tap;
+    b.ntaps = ntaps; b.cchunk = cchunk; b.Cin_all = Cin_all;
     const int tci = (Cin + 15) / 16, tco_all = (Cout + 15) / 16;            // Cin <= 256: tci <= 16
     static const bool no_taps = getenv("MAF_WGRAD_TAP_PER_WG") != nullptr;     // A/B: one tap per workgroup everywhere
     // (measured, n at batch 32: 8 -> 24 on 640^2 422 -> 246 us; 24 -> 48 on 320^2 190 -> 252 us — with two channel tiles the nine gathers
@@ -303,7 +312,7 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     const int NJ = (tci + b.WJ - 1) / b.WJ, WI = 4 / b.WJ;                 // 1 .. 4
     const int want = (tco_all + WI - 1) / WI;
     const int TI = want >= 3 ? 4 : want;                                   // 1, 2, 4 (16 accumulator tiles per wave at most)
-    const int gy = (tco_all + WI * TI - 1) / (WI * TI), gz = ntaps;
+    const int gy = (tco_all + WI * TI - 1) / (WI * TI), gz = ntaps * nchunk;
     // Pixel chunks (grid x).  A chunk costs ~3 us per 64-pixel step it walks and, at its end, Cout * Cin atomics per tap at ~120 G/s
     // chip-wide: T(gx) ~ steps / gx * 3 us + gx * atomics / 120 G/s is smallest at gx = sqrt(steps * 3 us * 120 G/s / atomics); no more
     // workgroups than ~4 per CU (tools/wgrad_sweep.py: 20x20 768 -> 384 wants 32 chunks, 80x80 256 -> 128 wants 256, 160x160 72 -> 48 all it can get)
@@ -342,13 +351,10 @@ extern "C" int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = B * Ho * Wo, kk = ksize * ksize;
     const int gather = stride == 2, tap0 = ksize == 1 ? 4 : 0;          // 1x1 stride 2 pad 0 reads (2 oy, 2 ox): the centre tap of the pad-1 geometry
-    for (int c0 = 0; c0 < Cin; c0 += 256) {                             // the LDS tile holds <= 256 input channels
-        const int cc = std::min(256, Cin - c0);
-        int rc = wgrad_launch(static_cast<const half_t*>(x) + c0, x_stride, static_cast<const half_t*>(dy), dy_stride, M, cc, Cout,
-                              dw + c0, Cin, (long long)Cout * Cin, gather, Ho, Wo, Hs, Ws, tap0, kk, s);
-        if (rc) return rc;
-    }
-    return 0;
+    // the LDS tile holds <= 256 input channels: wider inputs as equal channel chunks (whole 16-channel tiles) of ONE grid
+    const int nchunk = (Cin + 255) / 256, cchunk = ((Cin + nchunk - 1) / nchunk + 15) / 16 * 16;
+    return wgrad_launch(static_cast<const half_t*>(x), x_stride, static_cast<const half_t*>(dy), dy_stride, M, Cin, cchunk, Cout,
+                        dw, Cin, (long long)Cout * Cin, gather, Ho, Wo, Hs, Ws, tap0, kk, s);
 }
 
 extern "C" int maf_conv1x1_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t M, int32_t Cin,
