@@ -363,4 +363,7 @@ class check(torch.utils._python_dispatch.TorchDispatchMode):
                 return False
             if dev(args) or dev(out) or dev(list((kwargs or {}).values())):
                 tape.glue.append(name)
+                if len(tape.glue) <= 4:                                          # where it came from (the first few): the Python frames of the call
+                    import traceback
+                    tape.glue_where = getattr(tape, "glue_where", []) + ["".join(traceback.format_stack(limit=14)[:-1])]
         return out

@@ -320,6 +320,7 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, t
 # the persistent "stream" forms) is timed on the tensors at hand and the best one kept — the static rule (pack.tile_for) loses 10-40 % on
 # individual layers.  MAF_TRAIN_TUNE=0 turns it off.
 conv_autotune = os.environ.get("MAF_TRAIN_TUNE", "1") != "0"
+conv3_autotune = conv_autotune and os.environ.get("MAF_TRAIN_TUNE3", "1") != "0"        # the 3 x 3 stride-2 launches (forward, data gradient) alone
 _conv_tune = {}
 
 
@@ -759,6 +760,80 @@ def _packed_3x3(w, transpose, dt, ct, dev):
     return _staged(w, ("d", cout, cin, 9, int(transpose), dt, ct), nbytes, fields, now)
 
 
+_conv3_tune = {}
+
+
+def _conv3_choice(op, key, cands, w, transpose, dt, dev):
+    """(tile_p, tile_c, tile_k) of a 3 x 3 stride-2 launch (forward: MAF_OP_CONV3X3S2, data gradient: MAF_OP_CONV3X3S2_DGRAD): like `_conv_choice`, every
+    candidate is timed once per shape on the tensors at hand (the static rule — pack.tile_for / _tile_dgrad — left the neck's 128 -> 128 side convs at 1.2 TB/s)."""
+    best = _conv3_tune.get(key)
+    if best is not None:
+        return best
+    torch.cuda.synchronize(dev)
+    timer, st, res = lib.Timer(), _stream(dev), []
+    global profile, _plan
+    saved, profile = profile, None
+    saved_plan, _plan = _plan, None                                             # the candidates' weight forms are packed here and now: only the winner's joins the staging plan
+    L = lib._lib if lib._lib is not None else lib.load()                        # (never through a recording tape's proxy)
+    try:
+        for pt, ct, tk in cands:
+            n = op.Cout
+            op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
+            op.w, op.bias = _packed_3x3(w, transpose, dt, ct, dev).data_ptr(), _zero_bias(dev, -(-n // (16 * ct)) * 16 * ct).data_ptr()
+            if L.maf_op_launch(C.byref(op), st) != 0:
+                continue
+            ts = []
+            for _ in range(3):
+                timer.start(st)
+                L.maf_op_launch(C.byref(op), st)
+                timer.stop(st)
+                ts.append(timer.elapsed_ms())
+            res.append((min(ts), pt, ct, tk))
+    finally:
+        profile, _plan = saved, saved_plan
+    res.sort()
+    best = _conv3_tune[key] = res[0][1:] if res else cands[-1]
+    stats["conv_tuned"] = stats.get("conv_tuned", 0) + 1
+    return best
+
+
+def _conv3_fwd_cands(cin, cout, M, static):
+    cands = []
+    ksteps = 9 * -(-cin // 32)
+    for ct in (2, 4, 6, 8):
+        nt = -(-cout // (16 * ct))
+        if nt * 16 * ct > 2 * max(cout, 32) or (ct == 8 and cout % 8):
+            continue
+        for pt in (1, 2, 4):
+            if (pt == 4 and ct > 4) or (pt > 1 and -(-M // (64 * pt)) * nt < 256):
+                continue
+            cands.append((pt, ct, 1))
+        if M <= 65536:
+            cands.append((1, ct, 4))                                             # split-K across the four waves
+        if ct >= 4:
+            for pt in ((1, 2, 4) if ct == 4 else (1, 2)):                        # each k-step's weight fragments through LDS once per workgroup
+                if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
+                    cands.append((pt, ct, 2))
+    if static not in cands:
+        cands.append(static)
+    return cands
+
+
+def _conv3_dgrad_cands(cin, M, static):
+    cands = []
+    for ct in (2, 4, 8):
+        nt = -(-cin // (16 * ct))
+        if nt * 16 * ct > 2 * max(cin, 32):
+            continue
+        for pt in (1, 2, 4):
+            if (pt == 4 and ct > 4) or (pt > 1 and -(-M // (128 * pt)) * nt < 256):
+                continue
+            cands.append((pt, ct, 0))
+    if static not in cands:
+        cands.append(static)
+    return cands
+
+
 @_laned
 class _Conv3x3s2(torch.autograd.Function):
     """nn.Conv2d(k=3, stride=2, padding=1, bias=False): forward csrc/conv_mfma.inc.h VAR_3X3S2, data gradient VAR_DGRAD3 (gather form),
@@ -772,14 +847,22 @@ class _Conv3x3s2(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dt = _DT[x.dtype]
         pt, ct = pack.tile_for(cout, B * Ho * Wo)
-        wp = _packed_3x3(w, False, dt, ct, x.device)
+        tk = 1
         out = _empty((B, cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         op = lib.MafOp()
         op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2, dt, dt, lib.ACT_NONE
         op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, Ho, Wo, H, W, cin, cout, 1
         op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, xs, 0, lib.SRC_DIRECT
         op.out, op.out_stride, op.out_coff = out.data_ptr(), out.stride()[3], 0
-        op.tile_p, op.tile_c = pt, ct
+        if conv3_autotune and dt == lib.F16 and w.dtype == torch.float32 and w.is_leaf:
+            key = ("f", B * Ho * Wo, cin, cout, xs)
+            ch = _conv3_tune.get(key)
+            if ch is None and _rec is None:                                      # (never timed inside a recording step: the static tile then)
+                ch = _conv3_choice(op, key, _conv3_fwd_cands(cin, cout, B * Ho * Wo, (pt, ct, 1)), w, False, dt, x.device)
+            if ch is not None:
+                pt, ct, tk = ch
+        wp = _packed_3x3(w, False, dt, ct, x.device)
+        op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
         op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cout // (16 * ct)) * 16 * ct).data_ptr()
         es = x.element_size()
         with _prof("conv3x3s2", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device, (B, H, W, cin, cout, pt, ct)):
@@ -810,14 +893,21 @@ class _Conv3x3s2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # (an input whose channels were padded — the image — gets zeros in the padding: the packer pads W^T's rows to the channel tile)
             pt, ct = _tile_dgrad(cin, B * H * W)
-            wp = _packed_3x3(w, True, dt, ct, x.device)
             dx = _empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             op = lib.MafOp()
             op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV3X3S2_DGRAD, dt, dt, lib.ACT_NONE
             op.B, op.H, op.W, op.Hin, op.Win, op.Cin, op.Cout, op.nsrc = B, H, W, Ho, Wo, cout, cin, 1
             op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = dy.data_ptr(), cout, dys, 0, lib.SRC_DIRECT
             op.out, op.out_stride, op.out_coff = dx.data_ptr(), dx.stride()[3], 0
-            op.tile_p, op.tile_c = pt, ct
+            if conv3_autotune and dt == lib.F16 and w.dtype == torch.float32 and w.is_leaf:
+                key = ("d", B * H * W, cin, cout, dys)
+                ch = _conv3_tune.get(key)
+                if ch is None and _rec is None:
+                    ch = _conv3_choice(op, key, _conv3_dgrad_cands(cin, B * H * W, (pt, ct, 0)), w, True, dt, x.device)
+                if ch is not None:
+                    pt, ct = ch[0], ch[1]
+            wp = _packed_3x3(w, True, dt, ct, x.device)
+            op.tile_p, op.tile_c, op.tile_k = pt, ct, 0
             op.w, op.bias = wp.data_ptr(), _zero_bias(x.device, -(-cin // (16 * ct)) * 16 * ct).data_ptr()
             es = x.element_size()
             with _prof("conv3x3s2_dgrad", (B * H * W * cin + B * Ho * Wo * cout + 9 * cin * cout) * es, x.device, (B, H, W, cin, cout, pt, ct)):

@@ -69,7 +69,7 @@ def test_tape_records_a_step_without_torch_kernels_between_its_launches(scale):
             for _ in range(tape_mod.RECORD_AT):
                 _pass(model, ex, crit, x, t)
         tp = _the_tape(model)
-        assert tp is not None and tp.failed is None, tp and tp.failed
+        assert tp is not None and tp.failed is None, (tp and tp.failed, tp and getattr(tp, "glue_where", None))
         assert tp.glue == [], sorted(set(tp.glue))
         assert tp.seen["fwd"] > 0 and tp.seen["bwd"] > 0, tp.seen
         assert tp.ready
