@@ -37,6 +37,8 @@ int maf_launch_head_tail(const maf_op_t* op, hipStream_t s);
 int maf_launch_stem2(const maf_op_t* op, hipStream_t s);
 int maf_launch_conv3s2_lds(const maf_op_t* op, hipStream_t s);
 int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s);
+// depth-wise weight gradient on the matrix cores (dw_wgrad_mfma.hip); MAF_E_UNSUPPORTED = shape not covered, nothing launched
+int maf_dw_wgrad_mfma(const void* x, int x_stride, const void* dy, int dy_stride, int B, int H, int W, int C, int k, float* dw, int replicas, hipStream_t s);
 
 // ---- device helpers ----
 template <int ACT>

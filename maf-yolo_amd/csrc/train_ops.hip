@@ -489,6 +489,15 @@ extern "C" int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int
     DwWgArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C; a.x_stride = x_stride; a.dy_stride = dy_stride; a.replicas = replicas;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16 && k >= 3) {
+        static const int mf = getenv("MAF_DWWG_MFMA") ? atoi(getenv("MAF_DWWG_MFMA")) : -1;      // 1: wherever it fits, 0: never, default: the maps it wins on
+        // tools/dw_wgrad_ab.py, batch 32: 20 x 20 k 9 / 7 / 5 / 3: 101 / 57 / 45 / 27 -> 22 / 20 / 16 / 15 us (576 channels), 40 x 40 k 7 / 5: 56 / 41 -> 28 / 27 (192), 80 x 80 k 5: 97 -> 71 (192);
+        // k = 3 on the 80 x 80 maps and on 40 x 40 x 288 stays with the vector kernel (62 / 32 us against 62 - 70 / 35)
+        if (mf == 1 || (mf < 0 && W <= 96 && (k >= 5 || H * W <= 400 || (H * W <= 1600 && C <= 192)))) {
+            const int rc = maf_dw_wgrad_mfma(x, x_stride, dy, dy_stride, B, H, W, C, k, dw, replicas, s);
+            if (rc != MAF_E_UNSUPPORTED) return rc;
+        }
+    }
     if (dtype == MAF_F16) return launch_dw_wgrad<half_t, half8_t, 8>(a, k, s);
     return launch_dw_wgrad<float, f32x4_t, 4>(a, k, s);
 }

@@ -1036,6 +1036,26 @@ def test_full_size_amp_train_step_of_configs_2_and_3(scale, bs):
         ex.close()
 
 
+@pytest.mark.parametrize("B,H,W,C,k,pad,reps", [(3, 50, 70, 24, 7, 16, 4), (2, 20, 20, 72, 9, 0, 1), (5, 33, 96, 16, 5, 8, 3), (2, 40, 40, 136, 3, 0, 8), (4, 7, 5, 8, 9, 0, 2),
+                                                 (2, 80, 80, 40, 5, 24, 8), (1, 97, 33, 8, 7, 0, 1), (2, 12, 100, 16, 5, 0, 2)])
+def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, reps):
+    """maf_dw_wgrad straight through the C-ABI on fp16 NHWC tensors that are channel slices of wider buffers (pixel stride C + pad), several row bands / column segments
+    / replicas: the matrix-core kernel (csrc/dw_wgrad_mfma.hip: W <= 96, k >= 5 or small maps) and the vector kernel (W = 100) against the framework's fp32 weight
+    gradient of the same fp16 values.  Reference: the depth-wise convs of yolov6/layers/common.py:806-896 under autograd."""
+    from maf_yolo_amd import lib
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + k)
+    xb = torch.randn(B, H, W, C + pad, generator=g).half().to(DEV)
+    db = torch.randn(B, H, W, C + pad, generator=g).half().to(DEV)
+    x, dy = xb[..., pad:], db[..., :C]                                 # slices: the kernel sees base pointers and the pixel stride
+    dw = torch.zeros(reps, C, k * k, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.load().maf_dw_wgrad(x.data_ptr(), C + pad, dy.data_ptr(), C + pad, B, H, W, C, k, lib.F16, dw.data_ptr(), reps, st))
+    torch.cuda.synchronize()
+    got = dw.sum(0).view(C, 1, k, k)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (C, 1, k, k), dy.permute(0, 3, 1, 2).float(), padding=k // 2, groups=C)
+    assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("k0,c,hw,dtype", [(3, 72, (40, 40), torch.float16), (5, 144, (20, 24), torch.float16), (7, 192, (20, 20), torch.float16),
                                             (9, 96, (13, 20), torch.float16), (9, 288, (20, 20), torch.float16), (7, 24, (9, 12), torch.float32), (5, 8, (6, 8), torch.float32)])
 def test_dw_branches_one_launch_matches_the_separate_launches(k0, c, hw, dtype):
