@@ -72,9 +72,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
 
     // staging items of this thread: (row, 8-channel chunk), the same for every step
     const int xg = cib >> 3, dg = cob >> 3;
-    int xrow[XR], xch[XR], drow[DR], dch[DR];
+    int xrow[XR], xch[XR], drow[DR], dch[DR], xdx[XR], xdy[XR];       // gather: (xdx, xdy) = the item's row as (columns, rows) of the output grid, added to the step's first pixel
 #pragma unroll
-    for (int u = 0; u < XR; ++u) { const int it = tid + 256 * u; xrow[u] = it / xg; xch[u] = (it - xrow[u] * xg) * 8; if (xrow[u] >= kPix) xrow[u] = -1; }
+    for (int u = 0; u < XR; ++u) {
+        const int it = tid + 256 * u; xrow[u] = it / xg; xch[u] = (it - xrow[u] * xg) * 8;
+        xdy[u] = a.gather ? xrow[u] / a.Wo : 0; xdx[u] = xrow[u] - xdy[u] * a.Wo;
+        if (xrow[u] >= kPix) xrow[u] = -1;
+    }
 #pragma unroll
     for (int u = 0; u < DR; ++u) { const int it = tid + 256 * u; drow[u] = it / dg; dch[u] = (it - drow[u] * dg) * 8; if (drow[u] >= kPix) drow[u] = -1; }
 
@@ -87,6 +91,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
     const int m_begin = blockIdx.x * a.chunk, m_end = min(a.M, m_begin + a.chunk);
     half8_t xr[XR], dr[DR];
     auto fetch = [&](int m0) {
+        // the step's first pixel as (image, row, column) of the output grid: ONE pair of divisions per step (m0 is uniform), not one per 16-byte item
+        // (the 3 x 3 stride-2 layers spent more vector instructions on these quotients than on everything else)
+        int ox0 = 0, oy0 = 0, bb0 = 0;
+        if (a.gather) { const int t2 = m0 / a.Wo; ox0 = m0 - t2 * a.Wo; bb0 = t2 / a.Ho; oy0 = t2 - bb0 * a.Ho; }
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
             half8_t v = (half8_t)(half_t)0;
@@ -95,7 +103,9 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
                 if (!a.gather) {
                     v = *reinterpret_cast<const half8_t*>(xbase + (size_t)m * a.x_stride + xch[u]);
                 } else {
-                    const int ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
+                    int ox = ox0 + xdx[u], oy = oy0 + xdy[u], bb = bb0;
+                    if (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+                    while (oy >= a.Ho) { oy -= a.Ho; ++bb; }
                     const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
                     if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
                         v = *reinterpret_cast<const half8_t*>(xbase + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + xch[u]);
@@ -177,19 +187,32 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgArgs2 a) {
 
     const int m_begin = blockIdx.x * a.chunk, m_end = min(a.M, m_begin + a.chunk);
     half8_t xr[XR], dr[DR];
+    // staging items of this thread, the same for every step: (tap, row, channel chunk) and the row as (columns, rows) of the output grid
+    int xch[XR], xrw[XR], xdx[XR], xdy[XR], xky[XR], xkx[XR], xso[XR], drw[DR], dch[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { const int it = tid + 256 * u; drw[u] = it < nd ? it / dg : -1; dch[u] = (it % dg) * 8; }
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+        const int it = tid + 256 * u;
+        const int r2 = it / xg, tap = r2 / kPix;
+        xch[u] = (it - r2 * xg) * 8; xrw[u] = it < nx ? r2 - tap * kPix : -1;
+        xso[u] = r2 * SX + xch[u];                                           // r2 = tap * kPix + row
+        xky[u] = tap / 3; xkx[u] = tap - xky[u] * 3;
+        xdy[u] = (r2 - tap * kPix) / a.Wo; xdx[u] = (r2 - tap * kPix) - xdy[u] * a.Wo;
+    }
     auto fetch = [&](int m0) {
+        const int t0 = m0 / a.Wo, ox0 = m0 - t0 * a.Wo, bb0 = t0 / a.Ho, oy0 = t0 - bb0 * a.Ho;      // one pair of divisions per step, not per item
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
             half8_t v = (half8_t)(half_t)0;
-            const int it = tid + 256 * u;
-            if (it < nx) {
-                const int ch = (it % xg) * 8, r2 = it / xg;
-                const int row = r2 % kPix, tap = r2 / kPix;
-                const int m = m0 + row;
+            if (xrw[u] >= 0) {
+                const int ch = xch[u];
+                const int m = m0 + xrw[u];
                 if (m < m_end && ch < a.Cin) {
-                    const int ox = m % a.Wo, t2 = m / a.Wo, oy = t2 % a.Ho, bb = t2 / a.Ho;
-                    const int tky = tap / 3, tkx = tap - tky * 3;
-                    const int iy = 2 * oy - 1 + tky, ix = 2 * ox - 1 + tkx;
+                    int ox = ox0 + xdx[u], oy = oy0 + xdy[u], bb = bb0;
+                    if (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+                    while (oy >= a.Ho) { oy -= a.Ho; ++bb; }
+                    const int iy = 2 * oy - 1 + xky[u], ix = 2 * ox - 1 + xkx[u];
                     if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws)
                         v = *reinterpret_cast<const half8_t*>(a.x + ((size_t)(bb * a.Hs + iy) * a.Ws + ix) * a.x_stride + ch);
                 }
@@ -199,11 +222,9 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgArgs2 a) {
 #pragma unroll
         for (int u = 0; u < DR; ++u) {
             half8_t v = (half8_t)(half_t)0;
-            const int it = tid + 256 * u;
-            if (it < nd) {
-                const int ch = (it % dg) * 8, row = it / dg;
-                const int m = m0 + row;
-                if (m < m_end && ch < a.Cout) v = *reinterpret_cast<const half8_t*>(a.dy + (size_t)m * a.dy_stride + ch);
+            if (drw[u] >= 0) {
+                const int m = m0 + drw[u];
+                if (m < m_end && dch[u] < a.Cout) v = *reinterpret_cast<const half8_t*>(a.dy + (size_t)m * a.dy_stride + dch[u]);
             }
             dr[u] = v;
         }
@@ -212,18 +233,11 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgArgs2 a) {
     for (int m0 = m_begin; m0 < m_end; m0 += kPix) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < XR; ++u) {
-            const int it = tid + 256 * u;
-            if (it < nx) {
-                const int ch = (it % xg) * 8, r2 = it / xg;
-                *reinterpret_cast<half8_t*>(Xs + (size_t)r2 * SX + ch) = xr[u];          // r2 = tap * kPix + row
-            }
-        }
+        for (int u = 0; u < XR; ++u)
+            if (xrw[u] >= 0) *reinterpret_cast<half8_t*>(Xs + xso[u]) = xr[u];
 #pragma unroll
-        for (int u = 0; u < DR; ++u) {
-            const int it = tid + 256 * u;
-            if (it < nd) *reinterpret_cast<half8_t*>(Ds + (it / dg) * SD + (it % dg) * 8) = dr[u];
-        }
+        for (int u = 0; u < DR; ++u)
+            if (drw[u] >= 0) *reinterpret_cast<half8_t*>(Ds + drw[u] * SD + dch[u]) = dr[u];
         __syncthreads();
         if (m0 + kPix < m_end) fetch(m0 + kPix);
 #pragma unroll
@@ -256,6 +270,193 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgArgs2 a) {
             if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)tap * a.dw_tap + (size_t)co * a.dw_stride + ci, acc[t][r]);
         }
     }
+}
+
+// PATCH FORM of the 3x3 stride-2 weight gradient, for the narrow layers on the big maps (the stem: 8 -> 24 on 640^2, 24 -> 48 on 320^2, 48 -> 64 / 48 on 160^2).  One tap
+// per workgroup re-reads dY nine times and gathers X per tap (1 GB of L2 traffic for 236 MB of tensors on 24 -> 48: 194 us); nine gathered tiles per step (above) read dY
+// once but still pull every input pixel 2.25 times through the address path, 5.5 KB of new bytes per workgroup and step — too little in flight to cover the latency.
+// Here a workgroup stages the INPUT PATCH of a TH x 16 tile of output pixels once ((2 TH + 1) x 33 pixels, 1.10 - 1.16x the tile's own input) next to the dY tile, and the
+// nine taps read it in place: the transposing LDS read takes a row address per lane, so the X operand of tap (ky, kx) for output pixel (ty, tx) is simply the patch pixel
+// (2 ty + ky, 2 tx + kx).  The (tap, ci tile) items are dealt to the four waves, each item multiplies with all co tiles (dY fragments loaded once per k-step and wave);
+// the next tile's patch and dY are in registers while the instructions of this one run.
+struct Wg3Args {
+    const half_t* x; const half_t* dy; float* dw;
+    int B, Ho, Wo, Hs, Ws, Cin, Cout, x_stride, dy_stride;
+    int tilesX, tilesY, ntile, ntj, nti, SX, SD;
+    float* ws; int replicas;        // partial sums go to copy blockIdx.x % replicas of ws ([replicas][9][Cout][Cin], zero on entry); wgrad3_fold_kernel adds the copies to dw
+};
+
+template <int NIT, int NTI, int KS, int MAXXI, int MAXDI, int OCC, int NW>
+__global__ __launch_bounds__(64 * NW, OCC) void wgrad3_patch_kernel(const Wg3Args a) {
+    constexpr int TW = 16, TH = 2 * KS, PIX = 32 * KS, PW = 2 * TW + 1, PH = 2 * TH + 1, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
+    const int SX = a.SX, SD = a.SD;
+    half_t* Xs = reinterpret_cast<half_t*>(smem_raw);                    // [PH * PW][SX]   the input patch, NHWC pixels
+    half_t* Ds = Xs + PH * PW * SX;                                      // [PIX][SD]       the dY tile, pixel k = ty * 16 + tx
+    {
+        half8_t* z = reinterpret_cast<half8_t*>(smem_raw);
+        const int n8 = (PH * PW * SX + PIX * SD) >> 3;
+        for (int i = tid; i < n8; i += NT) z[i] = (half8_t)(half_t)0;  // channel padding (to whole 16-column tiles) stays zero
+    }
+    // staging items of this thread: 16-byte chunks of the patch / of the dY tile
+    const int ncx = a.Cin >> 3, ncd = a.Cout >> 3;
+    int xm[MAXXI], dm[MAXDI];                                           // (row << 20 | column << 8 | chunk) of the item, -1: none
+#pragma unroll
+    for (int u = 0; u < MAXXI; ++u) {
+        const int idx = tid + NT * u, pp = idx / ncx, cq = idx - pp * ncx, py = pp / PW, px = pp - py * PW;
+        xm[u] = pp < PH * PW ? (py << 20) | (px << 8) | cq : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXDI; ++u) {
+        const int idx = tid + NT * u, k = idx / ncd, cq = idx - k * ncd;
+        dm[u] = k < PIX ? ((k >> 4) << 20) | ((k & 15) << 8) | cq : -1;
+    }
+    half8_t xr[MAXXI], dr[MAXDI];
+    auto fetch = [&](int tile) {
+        const int b = tile / (a.tilesY * a.tilesX), t2 = tile - b * (a.tilesY * a.tilesX), tyi = t2 / a.tilesX, txi = t2 - tyi * a.tilesX;
+        const int oy0 = tyi * TH, ox0 = txi * TW, iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+        const half_t* xb = a.x + ((long long)((long long)b * a.Hs + iy0) * a.Ws + ix0) * a.x_stride;
+        const half_t* db = a.dy + ((long long)((long long)b * a.Ho + oy0) * a.Wo + ox0) * a.dy_stride;
+#pragma unroll
+        for (int u = 0; u < MAXXI; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int py = xm[u] >> 20, px = (xm[u] >> 8) & 0xfff, cq = xm[u] & 0xff;
+            if (xm[u] >= 0 && (unsigned)(iy0 + py) < (unsigned)a.Hs && (unsigned)(ix0 + px) < (unsigned)a.Ws)
+                v = *reinterpret_cast<const half8_t*>(xb + (py * a.Ws + px) * a.x_stride + cq * 8);
+            xr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXDI; ++u) {
+            half8_t v = (half8_t)(half_t)0;
+            const int ty = dm[u] >> 20, tx = (dm[u] >> 8) & 0xfff, cq = dm[u] & 0xff;
+            if (dm[u] >= 0 && oy0 + ty < a.Ho && ox0 + tx < a.Wo) v = *reinterpret_cast<const half8_t*>(db + (ty * a.Wo + tx) * a.dy_stride + cq * 8);
+            dr[u] = v;
+        }
+    };
+    // operand addresses.  A (dY^T): rows k = 32 ks + 8 g + (p >> 2) (+ 4), columns 4 (p & 3) of co tile i.  B (X): the patch pixel of output pixel k, moved by the tap.
+    const half_t* abase = Ds + (g * 8 + (p >> 2)) * SD + (p & 3) * 4;
+    int plo[KS], phi[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = ks * 32 + g * 8 + (p >> 2), k1 = k0 + 4;
+        plo[ks] = ((2 * (k0 >> 4)) * PW + 2 * (k0 & 15)) * SX;
+        phi[ks] = ((2 * (k1 >> 4)) * PW + 2 * (k1 & 15)) * SX;
+    }
+    const int nitems = 9 * a.ntj;
+    int boff[NIT];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int item = wave + NW * n, tap = item / a.ntj, tj = item - tap * a.ntj, ky = tap / 3, kx = tap - ky * 3;
+        boff[n] = (ky * PW + kx) * SX + tj * 16 + (p & 3) * 4;
+    }
+    f32x4_t acc[NIT][NTI];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n)
+#pragma unroll
+        for (int i = 0; i < NTI; ++i) acc[n][i] = (f32x4_t)0.f;
+
+    int tile = blockIdx.x;
+    if (tile < a.ntile) fetch(tile);
+    for (; tile < a.ntile; tile += gridDim.x) {
+        __syncthreads();                                                 // the previous tile's instructions have read the LDS tiles (first pass: the clear)
+#pragma unroll
+        for (int u = 0; u < MAXXI; ++u)
+            if (xm[u] >= 0) *reinterpret_cast<half8_t*>(Xs + ((xm[u] >> 20) * PW + ((xm[u] >> 8) & 0xfff)) * SX + (xm[u] & 0xff) * 8) = xr[u];
+#pragma unroll
+        for (int u = 0; u < MAXDI; ++u)
+            if (dm[u] >= 0) *reinterpret_cast<half8_t*>(Ds + ((dm[u] >> 20) * 16 + ((dm[u] >> 8) & 0xfff)) * SD + (dm[u] & 0xff) * 8) = dr[u];
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntile) fetch(tile + gridDim.x);    // in flight during the instructions below
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8_t av[NTI];
+#pragma unroll
+            for (int i = 0; i < NTI; ++i)
+                if (i < a.nti) av[i] = tr_frag(abase + (ks * 32) * SD + i * 16, abase + (ks * 32 + 4) * SD + i * 16);
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) {
+                if (wave + NW * n < nitems) {
+                    const half8_t bv = tr_frag(Xs + plo[ks] + boff[n], Xs + phi[ks] + boff[n]);
+#pragma unroll
+                    for (int i = 0; i < NTI; ++i)
+                        if (i < a.nti) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[i], bv, acc[n][i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // accumulator lane (g, p): rows co = 4 g + r, column ci = p of its tile; tap-major result [9][Cout][Cin]
+    float* out = a.ws + (size_t)(blockIdx.x % a.replicas) * 9 * a.Cout * a.Cin;
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int item = wave + NW * n;
+        if (item < nitems) {
+            const int tap = item / a.ntj, tj = item - tap * a.ntj, ci = tj * 16 + p;
+#pragma unroll
+            for (int i = 0; i < NTI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = i * 16 + g * 4 + r;
+                    if (i < a.nti && co < a.Cout && ci < a.Cin) atomicAdd(out + ((size_t)tap * a.Cout + co) * a.Cin + ci, acc[n][i][r]);
+                }
+        }
+    }
+}
+
+// dw += sum of the copies; the copies are left zero for the next launch on this stream
+__global__ __launch_bounds__(256) void wgrad3_fold_kernel(float* __restrict__ ws, int replicas, int n, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int r = 0; r < replicas; ++r) { v += ws[(size_t)r * n + i]; ws[(size_t)r * n + i] = 0.f; }
+    dw[i] += v;
+}
+
+// The workgroups of the patch form end with 9 * Cout * Cin atomics each; a thousand workgroups adding into the same few hundred cache lines serialise (24 -> 48: 8 M atomics,
+// 66 us at the ~120 G/s of that pattern), so they add into kWsCopies copies (workgroup index modulo) kept by the library per (device, stream), folded by one small launch.
+constexpr int kWsCopies = 8, kWsFloats = 9 * 64 * 48;
+struct WsSlot { int dev; hipStream_t s; float* p; };
+static WsSlot g_ws[16];
+static int g_nws = 0;
+
+static float* patch_workspace(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < g_nws; ++i)
+        if (g_ws[i].dev == dev && g_ws[i].s == s) return g_ws[i].p;
+    if (g_nws == 16) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc(&p, sizeof(float) * kWsCopies * kWsFloats) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, sizeof(float) * kWsCopies * kWsFloats, s) != hipSuccess) return nullptr;
+    g_ws[g_nws++] = {dev, s, p};
+    return p;
+}
+
+template <int NIT, int NTI, int KS, int MAXXI, int MAXDI, int OCC, int NW>
+int launch_patch(Wg3Args& a, int gx, hipStream_t s) {
+    constexpr int TW = 16, TH = 2 * KS, PIX = 32 * KS, PW = 2 * TW + 1, PH = 2 * TH + 1;
+    a.tilesX = maf_cdiv(a.Wo, TW); a.tilesY = maf_cdiv(a.Ho, TH); a.ntile = a.B * a.tilesY * a.tilesX;
+    const size_t lds = ((size_t)PH * PW * a.SX + (size_t)PIX * a.SD) * 2;
+    static bool attr = false;
+    if (!attr) {
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_patch_kernel<NIT, NTI, KS, MAXXI, MAXDI, OCC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(wgrad3)");
+        if (rc) return rc;
+        attr = true;
+    }
+    if (const char* e = getenv("MAF_WGRAD3_GX")) gx = atoi(e);
+    if (gx > a.ntile) gx = a.ntile;
+    a.replicas = kWsCopies;
+    if (const char* e = getenv("MAF_WGRAD3_R")) a.replicas = atoi(e);
+    if (a.replicas > 1) {
+        a.ws = patch_workspace(s);
+        if (!a.ws) { maf_set_error("conv_wgrad: no workspace for the partial sums"); return MAF_E_HIP; }
+    } else { a.replicas = 1; a.ws = a.dw; }
+    hipLaunchKernelGGL((wgrad3_patch_kernel<NIT, NTI, KS, MAXXI, MAXDI, OCC, NW>), dim3(gx), dim3(64 * NW), lds, s, a);
+    if (a.replicas > 1) {
+        const int n = 9 * a.Cout * a.Cin;
+        hipLaunchKernelGGL(wgrad3_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.ws, a.replicas, n, a.dw);
+    }
+    return maf_check_hip(hipGetLastError(), "conv wgrad (patch) launch");
 }
 
 template <int TPW>
@@ -351,6 +552,18 @@ extern "C" int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = B * Ho * Wo, kk = ksize * ksize;
     const int gather = stride == 2, tap0 = ksize == 1 ? 4 : 0;          // 1x1 stride 2 pad 0 reads (2 oy, 2 ox): the centre tap of the pad-1 geometry
+    static const int patch = getenv("MAF_WGRAD3_PATCH") ? atoi(getenv("MAF_WGRAD3_PATCH")) : -1;      // 0: never, 1: wherever it fits, default: the big maps
+    if (ksize == 3 && Cin <= 48 && Cout <= 64 && patch != 0 && (patch == 1 || M >= 100000)) {
+        Wg3Args b;
+        b.x = static_cast<const half_t*>(x); b.dy = static_cast<const half_t*>(dy); b.dw = dw; b.B = B; b.Ho = Ho; b.Wo = Wo; b.Hs = Hs; b.Ws = Ws;
+        b.Cin = Cin; b.Cout = Cout; b.x_stride = x_stride; b.dy_stride = dy_stride;
+        b.ntj = (Cin + 15) / 16; b.nti = (Cout + 15) / 16; b.SX = b.ntj * 16 + 8; b.SD = b.nti * 16 + 8;
+        // (items per wave, co tiles, k-steps per tile, patch / dY chunks per thread, workgroups per CU, waves): the wider layers on eight waves and fewer workgroups —
+        // every workgroup ends with 9 * Cout * Cin atomics (tools/conv_wgrad_bench.py with MAF_WGRAD3_GX: 48 -> 64 on 160^2 105 us with 1024 workgroups, 52 with 256)
+        if (b.ntj <= 1 && b.nti <= 2) return launch_patch<3, 2, 4, 3, 2, 4, 4>(b, 1024, s);      // 17 x 33 patch pixels x 1 chunk = 561 items / 256 threads; dY 128 x 3 / 256
+        if (b.ntj <= 2 && b.nti <= 3) return launch_patch<3, 3, 2, 2, 1, 2, 8>(b, 448, s);       // 9 x 33 x <= 3 chunks = 891 / 512; 64 x 6 / 512
+        return launch_patch<4, 4, 2, 4, 1, 2, 8>(b, 256, s);                                      // 9 x 33 x <= 6 = 1782 / 512; 64 x 8 / 512
+    }
     // the LDS tile holds <= 256 input channels: wider inputs as equal channel chunks (whole 16-channel tiles) of ONE grid
     const int nchunk = (Cin + 255) / 256, cchunk = ((Cin + nchunk - 1) / nchunk + 15) / 16 * 16;
     return wgrad_launch(static_cast<const half_t*>(x), x_stride, static_cast<const half_t*>(dy), dy_stride, M, Cin, cchunk, Cout,

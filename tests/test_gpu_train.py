@@ -1036,6 +1036,27 @@ def test_full_size_amp_train_step_of_configs_2_and_3(scale, bs):
         ex.close()
 
 
+@pytest.mark.parametrize("B,Hs,Ws,cin,cout,k,s,xpad,dpad", [(2, 451, 500, 8, 24, 3, 2, 0, 8), (2, 452, 450, 24, 48, 3, 2, 8, 0), (2, 450, 455, 48, 64, 3, 2, 0, 0), (3, 372, 370, 48, 48, 3, 2, 16, 16),
+                                                             (2, 41, 40, 96, 64, 3, 2, 0, 0), (2, 40, 40, 576, 136, 1, 1, 0, 8), (2, 21, 20, 768, 384, 1, 1, 0, 0), (2, 61, 64, 24, 48, 1, 2, 8, 0)])
+def test_conv_wgrad_c_abi_matches_framework_weight_gradient(B, Hs, Ws, cin, cout, k, s, xpad, dpad):
+    """maf_conv_wgrad straight through the C-ABI on channel slices of wider fp16 NHWC buffers: the patch form of the 3x3 stride-2 gradient (csrc/wgrad.hip
+    wgrad3_patch_kernel: >= 100 000 output pixels, Cin <= 48, Cout <= 64; odd map sizes, so the last tile row / column is ragged), the tap-per-workgroup form, the
+    channel chunks of inputs wider than 256 channels as one grid, the stride-2 1x1 — against the framework's fp32 weight gradient of the same fp16 values.
+    Reference: the convs of yolov6/layers/common.py:29-50, 202-203 under autograd (yolov6/core/engine.py:152-160)."""
+    from maf_yolo_amd import lib
+    Ho, Wo = (Hs - 1) // s + 1, (Ws - 1) // s + 1
+    g = torch.Generator().manual_seed(Hs + cin + cout)
+    xb = torch.randn(B, Hs, Ws, cin + xpad, generator=g).half().to(DEV)
+    db = torch.randn(B, Ho, Wo, cout + dpad, generator=g).half().to(DEV)
+    x, dy = xb[..., xpad:], db[..., :cout]
+    dw = torch.zeros(k, k, cout, cin, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.load().maf_conv_wgrad(x.data_ptr(), cin + xpad, dy.data_ptr(), cout + dpad, B, Ho, Wo, Hs, Ws, cin, cout, k, s, lib.F16, dw.data_ptr(), st))
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (cout, cin, k, k), dy.permute(0, 3, 1, 2).float(), stride=s, padding=k // 2)
+    assert float((dw.permute(2, 3, 0, 1) - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("B,H,W,C,k,pad,reps", [(3, 50, 70, 24, 7, 16, 4), (2, 20, 20, 72, 9, 0, 1), (5, 33, 96, 16, 5, 8, 3), (2, 40, 40, 136, 3, 0, 8), (4, 7, 5, 8, 9, 0, 2),
                                                  (2, 80, 80, 40, 5, 24, 8), (1, 97, 33, 8, 7, 0, 1), (2, 12, 100, 16, 5, 0, 2)])
 def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, reps):
