@@ -37,6 +37,7 @@ struct WgArgs2 {
     int gather, Ho, Wo, Hs, Ws, tap0;
     int dw_stride;        // floats between consecutive co rows of one tap
     long long dw_tap;     // floats between consecutive taps (3x3: tap-major result)
+    float* ws; int replicas; long long rsize;      // partial sums go to copy blockIdx.x % replicas of ws (rsize floats each, same layout as dw, zero on entry; folded into dw by wgrad3_fold_kernel); replicas = 1: ws = dw
     int ntaps, cchunk, Cin_all;   // blockIdx.z = channel chunk * ntaps + tap: chunk z / ntaps covers input channels [chunk * cchunk, min(Cin_all, (chunk + 1) * cchunk))
 };
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgArgs2 a) {
     // channel chunk of this workgroup (inputs wider than 256 channels: the LDS tile holds one chunk; all chunks are ONE grid — as separate launches of ~150 workgroups each
     // the 20 x 20 layers ran their three chunks one after the other on a chip they could not fill)
     const half_t* xbase = a.x + zc * a.cchunk;
-    float* dwbase = a.dw + zc * a.cchunk;
+    float* dwbase = a.ws + (size_t)(blockIdx.x % a.replicas) * a.rsize + zc * a.cchunk;
     const int Cin = min(a.cchunk, a.Cin_all - zc * a.cchunk);
 
     // staging items of this thread: (row, 8-channel chunk), the same for every step
@@ -493,7 +494,7 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     const int Cin = cchunk < Cin_all ? cchunk : Cin_all, nchunk = (Cin_all + cchunk - 1) / cchunk;
     b.x = x; b.dy = dy; b.dw = dw; b.M = M; b.Cin = Cin; b.Cout = Cout; b.x_stride = x_stride; b.dy_stride = dy_stride;
     b.gather = gather; b.Ho = Ho; b.Wo = Wo; b.Hs = Hs; b.Ws = Ws; b.tap0 = tap0; b.dw_stride = dw_stride; b.dw_tap = dw_tap;
-    b.ntaps = ntaps; b.cchunk = cchunk; b.Cin_all = Cin_all;
+    b.ntaps = ntaps; b.cchunk = cchunk; b.Cin_all = Cin_all; b.ws = dw; b.replicas = 1; b.rsize = 0;
     const int tci = (Cin + 15) / 16, tco_all = (Cout + 15) / 16;            // Cin <= 256: tci <= 16
     static const bool no_taps = getenv("MAF_WGRAD_TAP_PER_WG") != nullptr;     // A/B: one tap per workgroup everywhere
     // (measured, n at batch 32: 8 -> 24 on 640^2 422 -> 246 us; 24 -> 48 on 320^2 190 -> 252 us — with two channel tiles the nine gathers
@@ -527,6 +528,20 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     if (gx < 1) gx = 1;
     b.chunk = maf_cdiv(steps, gx) * kPix;
     gx = maf_cdiv(M, b.chunk);
+    // many pixel chunks adding into a small dW: copies (see patch_workspace), folded behind the launch
+    const long long nout = (long long)ntaps * Cout * Cin_all;
+    // (tools/conv_wgrad_bench.py, MAF_WGRAD_R = 1 / 8: 72 -> 48 on 160^2 82 -> 59 us, 72 -> 24 67 -> 34, the stem's 1x1 stride 2 97 -> 64; the 40 x 40 layers walk
+    //  ~150 chunks and lose 1 - 3 us to the fold: copies only from 256 chunks on; 64 copies are slower than 8)
+    static const int rep_max = getenv("MAF_WGRAD_R") ? atoi(getenv("MAF_WGRAD_R")) : kWsCopies;
+    long long R = (long long)kWsCopies * kWsFloats / nout;
+    if (R > rep_max) R = rep_max;
+    if (gx < 256 || R < kWsCopies) R = 1;
+    b.ws = dw; b.replicas = 1; b.rsize = nout;
+    if (R >= 2 && dw_stride == Cin_all && dw_tap == (long long)Cout * Cin_all) {
+        b.ws = patch_workspace(s);
+        if (!b.ws) { maf_set_error("conv_wgrad: no workspace for the partial sums"); return MAF_E_HIP; }
+        b.replicas = (int)R;
+    }
     const size_t lds = (size_t)kPix * (b.WJ * NJ * 16 + 8 + WI * TI * 16 + 8) * 2;
     const dim3 grid(gx, gy, gz);
     int rc = -1;
@@ -534,6 +549,7 @@ static int wgrad_launch(const half_t* x, int x_stride, const half_t* dy, int dy_
     MAF_WG(1, 1) MAF_WG(1, 2) MAF_WG(1, 3) MAF_WG(1, 4) MAF_WG(2, 1) MAF_WG(2, 2) MAF_WG(2, 3) MAF_WG(2, 4) MAF_WG(4, 1) MAF_WG(4, 2) MAF_WG(4, 3) MAF_WG(4, 4)
 #undef MAF_WG
     if (rc) return rc;
+    if (b.replicas > 1) hipLaunchKernelGGL(wgrad3_fold_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, b.ws, b.replicas, (int)nout, dw);
     return maf_check_hip(hipGetLastError(), "conv wgrad launch");
 }
 
