@@ -48,6 +48,8 @@ struct BnArgs {
     int xs_stride[3], xs_coff[3];
     const unsigned char* w3;
     int C3, nx;
+    unsigned* ctr;              // MAF_BN_PERSIST builds: [8] next dynamic tile of an XCD's segment, [8] = workgroups that have left (the last one resets the set)
+    int ntiles;
     unsigned long long* prof;   // MAF_BN_PROFILE builds only (op->aux[3]): cycles per phase summed over all waves, see tools/bn_profile.py
 };
 
@@ -85,6 +87,49 @@ template <int N> __device__ __forceinline__ void bn_wait_lgkm2(u32x4_t& a, u32x4
 __device__ __forceinline__ float bn_silu2(float v) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v)); }
 // (two at a time with the add and the multiplication as v_pk_add_f32 / v_pk_mul_f32 — 6 issue slots for two values instead of 8 — made the
 // kernel TWICE as slow: 68 -> 150 us; packed fp32 arithmetic is no full-rate path on this part.  Scalar it stays.)
+// MAF_BN_PKSILU (round 5, an experiment build: `make var VAR=pk VARFLAGS=-DMAF_BN_PKSILU`): the two SiLUs of a pixel pair in PACKED fp16 — the operand is
+// rounded to fp16 first (what the unfused path does when it stores the conv output, common.py:44-50 under --half), then v_exp_f16 x2, ONE v_pk_add_f16,
+// v_rcp_f16 x2, ONE v_pk_mul_f16: 7 instructions per pair instead of 9, within 2 fp16 ulp of the fp32 form.  Measured (tools/ab_lib.sh, one box, two runs each):
+// <5,2,4,8,2> 83.8 -> 81.8 us, <3,1,2,3,2> 92.1 -> 90.2, <5,2,4,6,2> 70.4 -> 67.8; value 25 780 -> 25 960 images/s.  The 19 kernel / model tests of the fused
+// bottleneck pass with it, but the extra rounding noise pushed the 32 x 640^2 cross-plan comparison (test_fused_stem_matches_unfused[u8-n], boxes within 0.3 px
+// over 268 800 rows) over its bar: 2 us per launch do not buy a wider parity bar, so the product keeps the fp32 form.
+// The compiler splits such code into scalar converts and v_pack_b32_f16 (22 instructions for four values); written with SDWA sub-dword selects:
+// (two pairs interleaved: a sub-dword write needs a wait state in front of its reader, which the other pair's instruction fills)
+__device__ __forceinline__ void bn_silu2_pk4(float v0, float v1, float v2, float v3, half2_t& o01, half2_t& o23) {
+    const half2_t xa = {(half_t)v0, (half_t)v1}, xb = {(half_t)v2, (half_t)v3};      // v_cvt_pk_f16_f32
+    const uint32_t ua = __builtin_bit_cast(uint32_t, xa), ub = __builtin_bit_cast(uint32_t, xb);
+    uint32_t ea, eb, ra, rb;
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(ea) : "v"(ua));
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(eb) : "v"(ub));
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(ea) : "v"(ua));
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(eb) : "v"(ub));
+    const half2_t one = {(half_t)1.f, (half_t)1.f};
+    const uint32_t da = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, ea) + one), db = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, eb) + one);   // v_pk_add_f16
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(ra) : "v"(da));
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(rb) : "v"(db));
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(ra) : "v"(da));
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(rb) : "v"(db));
+    o01 = xa * __builtin_bit_cast(half2_t, ra);                                       // v_pk_mul_f16
+    o23 = xb * __builtin_bit_cast(half2_t, rb);
+}
+// MAF_BN_PERSIST (round 5, an experiment build: `make var VAR=ps VARFLAGS=-DMAF_BN_PERSIST`; VERDICT r4 #2a): resident workgroups (occupancy x 256 CUs) that pull
+// tiles dynamically — first tile = blockIdx's own, then one atomicAdd per tile on the counter of the workgroup's XCD segment (64 counter sets handed out
+// round-robin so launches in flight on different streams never share one; the workgroup that leaves last re-arms its set); the next tile's index is requested
+// when a tile starts, the zero table is written once.  No spills (the lane index is made opaque per tile, else the tile loop keeps 53 hoisted registers), +120
+// instructions.  Measured: SLOWER on every instantiation — <5,2,4,8,2> 83.8 -> 103.5 us, <3,1,2,3,2> 92.1 -> 125.5, <5,2,4,6,2> 70.4 -> 89.3 (round 4's static
+// stride: 94.6 -> 101.6).  800 tiles on 512 slots take two tile times either way; a likely reason is that the resident form loses the hardware dispatcher's overlap of a
+// finishing workgroup's epilogue (stores in flight) with its successor's prologue on the freed half of the CU, while a resident workgroup serialises the two behind
+// its own barriers.  Dropped; the switch stays for the measurement.
+#ifdef MAF_BN_PERSIST
+constexpr bool BN_PERSIST = true;
+#else
+constexpr bool BN_PERSIST = false;
+#endif
+#ifdef MAF_BN_PKSILU           // make var VAR=pk VARFLAGS=-DMAF_BN_PKSILU
+constexpr bool BN_PK = true;
+#else
+constexpr bool BN_PK = false;
+#endif
 
 template <int K, int S1, int CT2>
 struct BnCfg {
@@ -128,11 +173,29 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
     int lid;
+    __shared__ int s_next;
+    const int my_xcd = blockIdx.x & 7;
+    const int seg_q = a.ntiles >> 3, seg_r = a.ntiles & 7;              // XCD x owns tiles [seg_start(x), + seg_len(x)) of the XCD-contiguous order
+    auto seg_start = [&](int x) { return x < seg_r ? x * (seg_q + 1) : seg_r * (seg_q + 1) + (x - seg_r) * seg_q; };
+    auto seg_stat = [&](int x) { return ((int)gridDim.x >> 3) + (x < ((int)gridDim.x & 7) ? 1 : 0); };      // tiles of the segment taken statically (one per resident workgroup)
+    auto fetch_tile = [&]() -> int {                                    // thread 0: the next tile of this XCD's segment (segments differ by one tile at most: no stealing)
+        const int j = seg_stat(my_xcd) + (int)atomicAdd(a.ctr + my_xcd, 1u);
+        return j < seg_q + (my_xcd < seg_r ? 1 : 0) ? seg_start(my_xcd) + j : -1;
+    };
     {   // XCD-contiguous tile order: neighbouring tiles (shared halos) run on the same XCD's L2
         const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-        const int q = a.nwg >> 3, r = a.nwg & 7;
+        const int q = a.ntiles >> 3, r = a.ntiles & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    bool first_tile = true;
+    for (;;) {                                                          // (one pass unless BN_PERSIST)
+    // (the lane index is made opaque per tile: otherwise every lane-derived address and mask of the body is hoisted out of the tile loop and kept in
+    // registers across it — 53 more than the kernel has)
+    int tid_l = threadIdx.x;
+    if constexpr (BN_PERSIST) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, wave = tid >> 6, lane = tid & 63, g = lane >> 4, p = lane & 15;
+    int next_tile = -1;
+    if (BN_PERSIST && tid == 0) next_tile = fetch_tile();
     const int tx = lid % a.tilesX;
     const int tt = lid / a.tilesX;
     const int ty = tt % a.tilesY;
@@ -224,8 +287,10 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
     dma_part(0, 0, Cf::REC, 0);
     load_x_head();
     if constexpr (Cf::ZT) {
-        u32x4_t* z = reinterpret_cast<u32x4_t*>(rec + Cf::ZOFF);
-        for (int i = tid; i < Cf::NTOE; i += 256) z[i] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (first_tile) {
+            u32x4_t* z = reinterpret_cast<u32x4_t*>(rec + Cf::ZOFF);
+            for (int i = tid; i < Cf::NTOE; i += 256) z[i] = (u32x4_t){0u, 0u, 0u, 0u};
+        }
     }
     __syncthreads();
     BN_STAMP(0);                                            // prologue
@@ -289,6 +354,8 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
                     half2_t h01, h23;
                     if (BN_KO(1)) {                                                        // KO 1: no SiLU in phase A (a branch: as a select both sides were computed and the switch measured nothing)
                         h01 = half2_t{(half_t)acc1[ct][0], (half_t)acc1[ct][1]}; h23 = half2_t{(half_t)acc1[ct][2], (half_t)acc1[ct][3]};
+                    } else if constexpr (BN_PK) {
+                        bn_silu2_pk4(acc1[ct][0], acc1[ct][1], acc1[ct][2], acc1[ct][3], h01, h23);
                     } else {
                         h01 = half2_t{(half_t)bn_silu2(acc1[ct][0]), (half_t)bn_silu2(acc1[ct][1])};
                         h23 = half2_t{(half_t)bn_silu2(acc1[ct][2]), (half_t)bn_silu2(acc1[ct][3])};
@@ -398,8 +465,17 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
 #pragma unroll
                 for (int s = 0; s < 8; ++s) t2[s] = (half_t)dacc[s][r];
                 if (!BN_KO(3)) {                                                           // KO 3: no SiLU in phase C
+                    if constexpr (BN_PK) {
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) t2[s] = (half_t)bn_silu2(dacc[s][r]);
+                        for (int s = 0; s < 8; s += 4) {
+                            half2_t ha, hb;
+                            bn_silu2_pk4(dacc[s][r], dacc[s + 1][r], dacc[s + 2][r], dacc[s + 3][r], ha, hb);
+                            t2[s] = ha[0]; t2[s + 1] = ha[1]; t2[s + 2] = hb[0]; t2[s + 3] = hb[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) t2[s] = (half_t)bn_silu2(dacc[s][r]);
+                    }
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT2; ++ct) if (!BN_KO(9)) {   // KO 9: no second 1x1
@@ -568,6 +644,20 @@ __global__ __launch_bounds__(256, ((CT2 == 2 && K <= 5) || (BnCfg<K, S1, CT2>::O
     }
     }
     }
+    if constexpr (!BN_PERSIST) break;
+    __syncthreads();                                        // every wave has left the staging / record areas of this tile
+    if (tid == 0) s_next = next_tile;
+    __syncthreads();
+    lid = s_next;
+    first_tile = false;
+    if (lid < 0) break;
+    }
+    if (BN_PERSIST && tid == 0) {                           // the workgroup that leaves last re-arms the counter set for the next launch that uses it
+        __threadfence();
+        if (atomicAdd(a.ctr + 8, 1u) == gridDim.x - 1) {
+            for (int i = 0; i < 9; ++i) atomicExch(a.ctr + i, 0u);
+        }
+    }
 #ifdef MAF_BN_STAMPS
     BN_STAMP(6);                                            // epilogue
     if (a.prof && lane == 0)
@@ -586,7 +676,24 @@ int launch_one(const BnArgs& a, hipStream_t s) {
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((bottleneck_kernel<K, S1, CT2, C3T, NX>), dim3(a.nwg), dim3(256), lds, s, a);
+    int grid = a.nwg;
+    BnArgs b = a;
+    if (BN_PERSIST) {
+        static int per_cu = 0;
+        static unsigned* ctrs = nullptr;                    // 64 counter sets handed out round-robin: launches in flight on different streams do not share one
+        static unsigned seq = 0;
+        if (!per_cu) {
+            int n = 0;
+            if (maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&bottleneck_kernel<K, S1, CT2, C3T, NX>), 256, lds), "occupancy(bottleneck)")) return MAF_E_HIP;
+            if (maf_check_hip(hipMalloc(reinterpret_cast<void**>(&ctrs), 64 * 16 * sizeof(unsigned)), "hipMalloc(bottleneck counters)")) return MAF_E_HIP;
+            if (maf_check_hip(hipMemset(ctrs, 0, 64 * 16 * sizeof(unsigned)), "hipMemset(bottleneck counters)")) return MAF_E_HIP;
+            per_cu = n > 0 ? n : 1;
+        }
+        const int slots = per_cu * 256;
+        if (grid > slots) grid = slots;
+        b.ctr = ctrs + (seq++ & 63) * 16;
+    }
+    hipLaunchKernelGGL((bottleneck_kernel<K, S1, CT2, C3T, NX>), dim3(grid), dim3(256), lds, s, b);
     return maf_check_hip(hipGetLastError(), "bottleneck launch");
 }
 
@@ -645,6 +752,7 @@ int maf_launch_bottleneck(const maf_op_t* op, hipStream_t s) {
     a.x_stride = sr.stride; a.x_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     a.tilesX = maf_cdiv(a.W, 16); a.tilesY = maf_cdiv(a.H, 16);
     a.nwg = a.B * a.tilesX * a.tilesY;
+    a.ntiles = a.nwg; a.ctr = nullptr;
     a.prof = nullptr; a.ko = 0;
     a.w3 = nullptr; a.C3 = 0; a.nx = 0;
     for (int i = 0; i < 3; ++i) { a.xs[i] = nullptr; a.xs_stride[i] = a.xs_coff[i] = 0; }
