@@ -192,6 +192,12 @@ int64_t maf_mprep_lds_record_bytes(int32_t Cin, int32_t Cout, int32_t C1);
 /* ... and on the tile_k = 7 kernel ((96, 96, 96); 0 = no such kernel; pack.py:pack_mprep_wreg). */
 int64_t maf_mprep_wreg_record_bytes(int32_t Cin, int32_t Cout, int32_t C1);
 int64_t maf_conv3s2_wreg_record_bytes(int32_t Cin, int32_t Cout);   /* 0: no instantiation for this shape */
+/* MAF_OP_CONV1X1 with tile_k = 5, tile_p = 1, ONE direct source, act = NONE and aux[0] = NULL takes aux[2] = half of the scratch of the training-mode BatchNorm
+ * behind the conv ([reserved0 replicas][2][Cout] fp32, the layout maf_dw_branches_stats fills; reserved0 = maf_bn_replicas(Cout, R)): the conv's epilogue adds
+ * the sum and the sum of squares of the outputs it stores (after their rounding to the activation dtype), and the BatchNorm call runs as
+ * maf_bn_forward_ex(..., stats_ready = 1) — no statistics pass (Conv.forward in training mode, yolov6/layers/common.py:44-47: conv -> bn -> act;
+ * csrc/conv_stream_lds_st.hip).  Whether the (K / 32, tile_c) instantiation exists: */
+int maf_conv1x1_stats_supported(int32_t ksteps, int32_t tile_c);
 
 /* Launch one op on `stream`. */
 int maf_op_launch(const maf_op_t* op, maf_stream_t stream);

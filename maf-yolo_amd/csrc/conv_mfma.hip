@@ -102,6 +102,14 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
                     "conv: tile_k = 5 is an fp16 1x1 variant with tile_p = 1 (4 waves per workgroup) or 2 (8 waves)");
         a.nM = maf_cdiv(a.M, 16);
         a.stream_waves = pt == 2 ? 8 : 4;
+        if (op->aux[2]) {
+            // aux[2] = half of the scratch of the training-mode BatchNorm behind this conv, [reserved0 replicas][2][Cout] fp32: the epilogue adds the sum and the sum
+            // of squares of the stored outputs (csrc/conv_stream_lds_st.hip); the BatchNorm call then runs with stats_ready = 1
+            MAF_REQUIRE(var == VAR_DIRECT && op->src[0].mode == MAF_SRC_DIRECT && pt == 1 && op->act == MAF_ACT_NONE && !op->out_pairs && op->reserved0 >= 1 && op->reserved0 <= 64,
+                        "conv: the statistics epilogue (aux[2]) needs one direct source, tile_p = 1, no activation, NHWC output, reserved0 = 1..64 replicas");
+            a.stats = const_cast<float*>(static_cast<const float*>(op->aux[2])); a.stats_R = op->reserved0;
+            return maf_conv1x1_stream_lds_st(a, ct, s);
+        }
         return maf_conv1x1_stream_lds(a, var == VAR_POOL2 ? VAR_DIRECT : var, ct, s);      // a pooled / sub-sampled single source: the direct form with a.srcMode[0] set
     }
     if (lb) return maf_conv_mfma_f16_lb(a, var, pt, ct, s);

@@ -46,6 +46,8 @@ struct ConvArgs {
     int act;
     int stream_waves;    // conv1x1_stream_lds only: 4, or 8 (op->tile_p = 2: 512-thread workgroups, csrc/conv_stream_lds_w8.hip)
     int out_pairs;       // conv1x1_stream_lds only: the output is stored as pixel pairs (MAF_SRC_PAIRS) for a depth-wise consumer
+    float* stats;        // conv1x1_stream_lds, training (csrc/conv_stream_lds_st.hip): the BatchNorm behind the conv reads its batch statistics from here —
+    int stats_R;         //   [stats_R][2][Cout] fp32 {sum, sum of squares} of the ROUNDED outputs, added to by every workgroup (replica = blockIdx % stats_R); null: none
     int dg_mc, dg_nmc;   // VAR_DGRAD3 with even H, W: pixels per parity class (B * H/2 * W/2) and pixel tiles per class (nM = 4 * dg_nmc); 0 = unsplit
     // twin launch (op->aux[0..3]): a SECOND conv of identical shape — same everything except these four pointers — runs as
     // blockIdx.y = 1 of the same grid (the two side convs of a MAFPN level, backbone.23 / .24 and .27 / .28: independent, equal, each too
@@ -71,6 +73,7 @@ int maf_conv_mfma_f16_lb(const ConvArgs& a, int var, int pt, int ct, hipStream_t
 int maf_conv_mfma_dgrad3(const ConvArgs& a, int dtype, int pt, int ct, hipStream_t s);  // VAR_DGRAD3 (conv_mfma_dgrad.hip)
 int maf_conv1x1_stream(const ConvArgs& a, int pt, int ct, hipStream_t s);              // persistent waves, cross-tile prefetch (tile_k = 3)
 int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s);        // the same with LDS-resident weights (tile_k = 5)
+int maf_conv1x1_stream_lds_st(const ConvArgs& a, int ct, hipStream_t s);              // ... that also accumulates the statistics of the BatchNorm behind it (a.stats)
 
 // Profiling builds only (make ko KO=<bits>, tools/conv_probe.py; never the shipped library): MAF_KO knocks one piece out of conv_mfma_kernel
 // to see what it costs.  1: weight fragments are constants (no weight loads)  2: activation fragments are constants (no activation loads)

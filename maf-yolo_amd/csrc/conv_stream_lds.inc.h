@@ -70,8 +70,14 @@ __device__ __forceinline__ void sl_store_pair(const f32x4_t (&acc)[CT], int r0, 
 
 // NW = waves per workgroup (4; 8 = a.stream_waves: the instantiations whose KS * CT KiB of weights leave room for one or two workgroups per CU only — twice the
 // waves behind the same LDS copy of the weights, i.e. twice the activation tiles in flight per CU and half the tiles per wave; conv_stream_lds_w8.hip)
-template <int CT, int KS, bool MULTI, int NW = 4>
+// ST (training, conv_stream_lds_st.hip; single direct source, four waves): the conv is followed by a training-mode BatchNorm whose first pass would read the
+// whole output again for sum x and sum x^2.  Here every lane keeps the two sums of ITS channels over the tiles its wave walks — of the values as stored,
+// i.e. after the rounding to fp16: what a pass over the tensor would see — and at the end the lane groups are folded with two cross-lane adds, the four waves
+// through the (by then idle) weight area of the LDS, and the workgroup adds 2 x 16 CT values to replica blockIdx % stats_R of the BatchNorm's scratch
+// (maf_bn_forward_ex(..., stats_ready = 1) folds the replicas): one atomic per channel, statistic and workgroup.
+template <int CT, int KS, bool MULTI, int NW = 4, bool ST = false>
 __global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvArgs a) {
+    static_assert(!ST || (!MULTI && NW == 4), "the statistics epilogue exists for the single-source four-wave form");
     typedef Frag<half_t> F;
     typedef F::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_raw[];
@@ -171,6 +177,9 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvA
         }
     };
     const int act = a.act;                                               // uniform: the activation is picked once per tile, not per value
+    float ssum[ST ? CT : 1], ssq[ST ? CT : 1];
+#pragma unroll
+    for (int ct = 0; ct < (ST ? CT : 1); ++ct) ssum[ct] = ssq[ct] = 0.f;
     uint32_t wbase[3];                                                   // LDS addresses of this lane's 16 bytes in fragment 0, 64, 128
 #pragma unroll
     for (int k = 0; k < 3; ++k) wbase[k] = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(wl_raw + k * 65536 + lane * 16);
@@ -226,6 +235,36 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvA
             }
             return;
         }
+        if constexpr (ST) {                                               // no activation in front of a BatchNorm (launcher); out-of-range rows add nothing
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = t * 16 + g * 4 + r;
+                if (m >= a.M) continue;
+                half_t* op = static_cast<half_t*>(a.out) + (size_t)m * a.out_stride + a.out_coff + cl;
+                half_t hv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    hv[ct] = (half_t)acc[ct][r];
+                    const float f = (float)hv[ct];
+                    ssum[ct] += f;
+                    ssq[ct] = __builtin_fmaf(f, f, ssq[ct]);
+                }
+                if (nvalid >= CT) {
+                    uint32_t w[CT / 2];
+#pragma unroll
+                    for (int c2 = 0; c2 < CT / 2; ++c2) w[c2] = __builtin_bit_cast(uint32_t, (half2_t){hv[2 * c2], hv[2 * c2 + 1]});
+                    if (CT == 8) *reinterpret_cast<u32x4_t*>(op) = (u32x4_t){w[0], w[1], w[2], w[3 % (CT / 2)]};
+                    else if (CT == 6) { *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1]}; *reinterpret_cast<uint32_t*>(op + 4) = w[2 % (CT / 2)]; }
+                    else if (CT == 4) *reinterpret_cast<u32x2_t*>(op) = (u32x2_t){w[0], w[1 % (CT / 2)]};
+                    else *reinterpret_cast<uint32_t*>(op) = w[0];
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        if (ct < nvalid) op[ct] = hv[ct];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = t * 16 + g * 4 + r;
@@ -246,6 +285,45 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvA
     if (any) load_tile(t, fa);                                           // in flight beside the weight DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's DMA pieces have landed ...
     __syncthreads();                                                     // ... and everybody else's
+    if constexpr (ST) {
+        frag_t fb2[KS];
+        if (any) {
+            while (true) {
+                const int t1 = t + stride;
+                if (t1 < ntiles) load_tile(t1, fb2);
+                compute_store(t, fa);
+                if (t1 >= ntiles) break;
+                const int t2 = t1 + stride;
+                if (t2 < ntiles) load_tile(t2, fa);
+                compute_store(t1, fb2);
+                if (t2 >= ntiles) break;
+                t = t2;
+            }
+        }
+        // lane (g, p) holds the sums of channels cl .. cl + CT - 1 over rows 4g .. 4g + 3 of its tiles: fold the four lane groups, then the four waves
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            ssum[ct] += __shfl_xor(ssum[ct], 16); ssum[ct] += __shfl_xor(ssum[ct], 32);
+            ssq[ct] += __shfl_xor(ssq[ct], 16); ssq[ct] += __shfl_xor(ssq[ct], 32);
+        }
+        __syncthreads();                                                 // nobody reads weight fragments any more
+        float* red = reinterpret_cast<float*>(wl_raw);                   // [4 waves][2][16 CT]  (KS * CT KiB >= 2 KiB: fits for every instantiation)
+        static_assert(KS * CT * 1024 >= 4 * 2 * 16 * CT * 4, "reduction area inside the weight area");
+        if (g == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                red[(wave * 2 + 0) * 16 * CT + p * CT + ct] = ssum[ct];
+                red[(wave * 2 + 1) * 16 * CT + p * CT + ct] = ssq[ct];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * 16 * CT) {
+            const int which = tid / (16 * CT), j = tid - which * 16 * CT, c = n_tile * 16 * CT + j;
+            const float v = red[(0 * 2 + which) * 16 * CT + j] + red[(1 * 2 + which) * 16 * CT + j] + red[(2 * 2 + which) * 16 * CT + j] + red[(3 * 2 + which) * 16 * CT + j];
+            if (c < a.Cout) atomicAdd(a.stats + ((size_t)(blockIdx.x % a.stats_R) * 2 + which) * a.Cout + c, v);
+        }
+        return;
+    }
     if (!any) return;
     if constexpr (NW == 8) {
         // two waves per SIMD: the partner's multiplies cover this wave's loads — ONE fragment set per wave (two sets of up to 24 fragments do not fit the
@@ -272,18 +350,18 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_lds_kernel(const ConvA
     }
 }
 
-template <int CT, int KS, bool MULTI, int NW = 4>
+template <int CT, int KS, bool MULTI, int NW = 4, bool ST = false>
 int launch_sl(const ConvArgs& a, hipStream_t s) {
     constexpr int lds = KS * CT * 1024;
     static_assert(lds <= 160 * 1024, "weights of one channel tile must fit LDS");
     static int occ = 0;                                                  // resident workgroups per CU of this instantiation (LDS and registers)
     if (!occ) {
         if (lds > 64 * 1024) {
-            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
+            int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_lds_kernel<CT, KS, MULTI, NW, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(conv1x1_stream_lds)");
             if (rc) return rc;
         }
         int nb = 0;
-        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
+        int rc = maf_check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv1x1_stream_lds_kernel<CT, KS, MULTI, NW, ST>, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv1x1_stream_lds)");
         if (rc) return rc;
         occ = nb < 1 ? 1 : nb > 4 ? 4 : nb;
     }
@@ -294,7 +372,7 @@ int launch_sl(const ConvArgs& a, hipStream_t s) {
     const int cap = occ * 256 / a.nN > 0 ? occ * 256 / a.nN : 1;
     if (per > cap) per = cap;
     if (per >= 8 && a.nN > 1) per &= ~7;                                 // whole XCD rounds: the channel tiles of a pixel tile then share an XCD's L2 (see the kernel)
-    hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI, NW>), dim3(per * a.nN), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_stream_lds_kernel<CT, KS, MULTI, NW, ST>), dim3(per * a.nN), dim3(NW * 64), lds, s, a);
     return maf_check_hip(hipGetLastError(), "conv1x1_stream_lds launch");
 }
 

@@ -59,15 +59,16 @@ class Conv(nn.Module):
     def forward(self, x, out=None):
         """out: where the result goes when it is one input of a channel concat — a slot of a train_ops.CatBuffer, or a callable that returns the slot for the
         conv's output tensor (the buffer is allocated when its first producer knows the spatial size); ignored off the HIP path (the concat then copies)."""
+        pre = None
         if self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1):
-            z = train_ops.conv1x1(x, self.conv.weight)                          # HIP conv fwd / dgrad / wgrad + fused BN(train)+SiLU
+            z, pre = train_ops.conv1x1_bn(x, self.conv.weight, self.bn)         # HIP conv fwd / dgrad / wgrad; pre: the BatchNorm's batch statistics out of the conv's epilogue
         elif self.conv.kernel_size == (3, 3) and self.conv.stride == (2, 2):
             z = train_ops.conv3x3s2(x, self.conv.weight)                        # ConvWrapper: the same on the 3x3 stride-2 kernels
         else:
             z = self.conv(x)
         if out is not None:
             out = (out(z) if callable(out) else out) if train_ops.cat_free_ok(z, self.bn) and z.dim() == 4 and z.shape[1] % 8 == 0 else None
-        return train_ops.bn_act(z, self.bn, "silu", out=out)
+        return train_ops.bn_act(z, self.bn, "silu", out=out, pre_stats=pre)
 
     def fused(self):
         return fold_bn(self.conv.weight, self.bn)

@@ -134,7 +134,10 @@ class StepTape:
         obj = getattr(a, "_obj", None)          # C.byref(x)
         if obj is not None:
             if isinstance(obj, lib.MafOp):       # train_ops caches launch descriptors by geometry and rewrites their pointers per call: the tape keeps its own copy
+                tog = getattr(obj, "_tape_toggles", None)
                 obj = lib.MafOp.from_buffer_copy(obj)
+                for off, mask, width in tog or ():                               # words of the descriptor that alternate between replays (a BatchNorm scratch half)
+                    self.toggles[self.phase].append((None, C.addressof(obj) + off, mask, width))
             self.keep.append(obj)
             return C.addressof(obj)
         if isinstance(a, C._SimpleCData):

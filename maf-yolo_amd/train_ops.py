@@ -293,7 +293,9 @@ def _ok(x, cin_mult):
 _op_cache = {}                         # launch descriptors by geometry: only the pointers change from call to call (a ctypes field store is ~0.2 us)
 
 
-def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, tk=1):
+def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, tk=1, bstat=None):
+    """bstat: (scratch, phase) of the training-mode BatchNorm behind the conv (bn_own_scratch) — the conv's epilogue accumulates its batch statistics
+    (csrc/conv_stream_lds_st.hip; the caller has checked `_conv_stats_ok` for the tile)."""
     ys = out.stride()[3]
     if pt is None:
         pt = pack.tile_for(cout, B * H * W)[0]
@@ -307,12 +309,32 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, t
         op.out_stride, op.out_coff = ys, 0
         op.tile_p, op.tile_c, op.tile_k = pt, ct, tk
     op.src[0].ptr, op.out, op.w, op.bias = x.data_ptr(), out.data_ptr(), wp.data_ptr(), bias.data_ptr()
-    if profile is None:
-        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
-        return
-    es = x.element_size()
-    with _prof("conv1x1", B * H * W * (cin + cout) * es + cin * cout * es, x.device):
-        lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+    op.aux[2], op.reserved0, op._tape_toggles = None, 0, None
+    if bstat is not None:
+        half = _BN_REPLICAS * 2 * (-(-cout // 256) * 256)
+        p0 = bstat[0].data_ptr()
+        op.aux[2], op.reserved0 = p0 + 4 * bstat[1] * half, lib.load().maf_bn_replicas(cout, _BN_REPLICAS)
+        if _rec is not None:                                                     # the half alternates from replay to replay: the tape toggles the word in ITS copy of the descriptor
+            op._tape_toggles = [(lib.MafOp.aux.offset + 2 * C.sizeof(C.c_void_p), p0 ^ (p0 + 4 * half), 8)]
+    try:
+        if profile is None:
+            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+            return
+        es = x.element_size()
+        with _prof("conv1x1", B * H * W * (cin + cout) * es + cin * cout * es, x.device):
+            lib.check(lib.load().maf_op_launch(C.byref(op), _stream(x.device)))
+    finally:
+        if bstat is not None:
+            op.aux[2], op.reserved0, op._tape_toggles = None, 0, None
+
+
+conv_bn_stats = os.environ.get("MAF_CONV_BN_STATS", "1") != "0"           # A/B switch: BatchNorm statistics out of the 1x1 conv's epilogue (csrc/conv_stream_lds_st.hip)
+
+
+def _conv_stats_ok(choice, cin, co, cout, dt, bias):
+    pt, ct, tk = choice
+    return (conv_bn_stats and not _deterministic and tk == 5 and pt == 1 and dt == lib.F16 and bias is None and co == cout
+            and bool(lib.load().maf_conv1x1_stats_supported(-(-cin // 32), ct)))
 
 
 # Tile / variant choice of the training 1x1 convs (forward and data gradient): the first time a shape (pixels, K, N) is seen every candidate
@@ -595,7 +617,9 @@ def lane_join(y, k):
 @_laned
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, bnslot=None):
+        """bnslot: (bn, holder) — the training-mode BatchNorm2d behind the conv and an empty list: when the conv's tile has the statistics epilogue, the
+        (scratch, phase) the BatchNorm call must be given as `pre_stats` is appended to the list."""
         x, xs = nhwc(x)
         B, cin, H, W = x.shape
         cout = w.shape[0]
@@ -623,7 +647,12 @@ class _Conv1x1(torch.autograd.Function):
         else:
             bp = _staged_bias(bias, cout, npad, x.device)                       # the bias on the conv's channel tile, zero behind it: staged by the step's pack batch
         out = _empty((B, co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt, pt, tk)
+        bstat = None
+        if bnslot is not None and _conv_stats_ok(choice, cin, co, cout, dt, bias):
+            bstat = bn_own_scratch(bnslot[0], x.device, cout)
+            bnslot[1].append(bstat)
+            stats["conv_bn_stats"] = stats.get("conv_bn_stats", 0) + 1
+        _launch_conv1x1(x, xs, wp, bp, B, H, W, cin, co, ct, out, dt, pt, tk, bstat)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None   # (an input of this node, not a saved tensor: backward adds its gradient straight into a gradient exchange)
@@ -690,7 +719,7 @@ class _Conv1x1(torch.autograd.Function):
             dx = _empty((B, cin, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             _launch_conv1x1(dyk, dyks, wp, _zero_bias(x.device, npad), B, H, W, kk, cin, ct, dx, dt, pt, tk)
         _side_done(x.device, dw is not None)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def _wgrad(x, dy, dys, w, ksize, stride):
@@ -1076,6 +1105,21 @@ def conv1x1s2(x, w):
     if not (x.dtype in _DT and x.dim() == 4 and tuple(w.shape[2:]) == (1, 1)):
         raise lib.MafError("conv1x1s2: unsupported input for the HIP path: %s %s" % (tuple(x.shape), x.dtype))
     return _Conv1x1s2.apply(_pad8(x, w), w)
+
+
+def conv1x1_bn(x, w, bn):
+    """(conv1x1(x, w), pre_stats): the 1x1 conv in front of the BatchNorm2d `bn` (Conv.forward, yolov6/layers/common.py:44-47).  When `bn` normalises with batch
+    statistics on the HIP path and the conv runs on the persistent LDS-weight kernel, the conv's epilogue accumulates them and `pre_stats` is what
+    bn_act(..., pre_stats=) takes (apply pass only); otherwise None."""
+    if not (x.is_cuda and bn.training and bn.affine) or framework_ops or not conv_bn_stats or _deterministic:
+        return conv1x1(x, w), None
+    x = _autocast(x)
+    mult = 8 if x.dtype == torch.float16 else 4
+    if not (_ok(x, mult) and w.shape[2] == 1):
+        raise lib.MafError("conv1x1: unsupported input for the HIP path: %s %s -> %d channels" % (tuple(x.shape), x.dtype, w.shape[0]))
+    holder = []
+    z = _Conv1x1.apply(x, w, None, (bn, holder))
+    return z, (holder[0] if holder else None)
 
 
 def conv1x1(x, w, bias=None):

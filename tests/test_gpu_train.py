@@ -1173,6 +1173,101 @@ def test_branch_batchnorm_statistics_out_of_the_depthwise_kernel(k, c, hw, dtype
     assert not any("maf" in k for k in fused.state_dict()) and not hasattr(fused.dwconv.origin_bn, "_maf_part")        # nothing of it travels with the module
 
 
+@pytest.mark.parametrize("cin,cout,B,hw,ct", [(96, 288, 4, (20, 20), 6), (64, 192, 3, (40, 40), 4), (288, 96, 32, (20, 20), 6), (384, 128, 2, (40, 36), 8), (48, 48, 2, (160, 160), 2),
+                                              (192, 72, 5, (13, 11), 6), (64, 24, 2, (80, 80), 4)])
+def test_conv1x1_statistics_epilogue_through_the_c_abi(cin, cout, B, hw, ct):
+    """Round 5 (csrc/conv_stream_lds_st.hip): MAF_OP_CONV1X1 on the persistent LDS-weight kernel with aux[2] = a BatchNorm scratch half adds, per output channel,
+    the sum and the sum of squares of the values it STORES (fp16-rounded) to the replicas of that half.  Against torch on the stored tensor (fp64 sums); the
+    outputs themselves are bit-identical to the launch without the epilogue; channel counts that do not fill the last channel tile and pixel counts that do not
+    fill the last 16-pixel tile included."""
+    import ctypes as C
+    from maf_yolo_amd import lib
+    L = lib.load()
+    H, W = hw
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = (torch.randn(B, cin, H, W, generator=g) * 1.3 + 0.1).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    ks = -(-cin // 32)
+    assert L.maf_conv1x1_stats_supported(ks, ct) == 1
+    wp = train_ops._packed_1x1(w.float().contiguous(), cout, cin, 0, lib.F16, ct, DEV)
+    npad = -(-cout // (16 * ct)) * 16 * ct
+    bias = torch.zeros(npad, device=DEV)
+    outs = []
+    R = L.maf_bn_replicas(cout, train_ops._BN_REPLICAS)
+    part = torch.zeros(R * 2 * cout, device=DEV)
+    for with_stats in (False, True):
+        out = torch.empty((B, cout, H, W), dtype=torch.float16, device=DEV).contiguous(memory_format=torch.channels_last)
+        op = lib.MafOp()
+        op.kind, op.dtype, op.in_dtype, op.act = lib.OP_CONV1X1, lib.F16, lib.F16, lib.ACT_NONE
+        op.B, op.H, op.W, op.Cin, op.Cout, op.nsrc = B, H, W, cin, cout, 1
+        op.src[0].ptr, op.src[0].C, op.src[0].stride, op.src[0].coff, op.src[0].mode = x.data_ptr(), cin, cin, 0, lib.SRC_DIRECT
+        op.out, op.out_stride, op.out_coff = out.data_ptr(), cout, 0
+        op.tile_p, op.tile_c, op.tile_k = 1, ct, 5
+        op.w, op.bias = wp.data_ptr(), bias.data_ptr()
+        if with_stats:
+            op.aux[2], op.reserved0 = part.data_ptr(), R
+        lib.check(L.maf_op_launch(C.byref(op), None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    z = outs[1].permute(0, 2, 3, 1).reshape(-1, cout).double()
+    got = part.view(R, 2, cout).double().sum(0).cpu()
+    ref = torch.stack([z.sum(0), (z * z).sum(0)]).cpu()
+    scale = torch.stack([z.abs().sum(0), (z * z).sum(0)]).cpu() + 1e-6
+    assert ((got - ref).abs() / scale).max() < 2e-6, ((got - ref).abs() / scale).max()
+    # a tile without the instantiation is refused, not silently run without the statistics
+    op.tile_p = 2
+    assert L.maf_op_launch(C.byref(op), None) != 0
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(96, 288, (20, 20)), (64, 192, (40, 40)), (288, 96, (20, 20)), (48, 96, (80, 80)), (576, 192, (20, 20))])
+def test_conv_batchnorm_statistics_out_of_the_conv_epilogue(cin, cout, hw):
+    """Conv (1x1 conv -> BatchNorm2d -> SiLU, yolov6/layers/common.py:29-47) in training mode with the BatchNorm's batch statistics accumulated by the conv's own
+    epilogue (train_ops.conv1x1_bn) against the same module with the statistics pass (MAF_CONV_BN_STATS off): outputs within one rounding of the
+    activations, running statistics, num_batches_tracked and every gradient to round-off, over three steps (the per-module scratch alternates its halves);
+    a K beyond the instantiations (576) keeps the statistics pass."""
+    import copy
+    from maf_yolo_amd.layers import Conv
+    torch.manual_seed(cin + cout)
+    ref = Conv(cin, cout, 1, 1).to(DEV).train()
+    with torch.no_grad():
+        ref.bn.weight.uniform_(0.5, 1.5); ref.bn.bias.uniform_(-0.3, 0.3)
+    new = copy.deepcopy(ref)
+    g = torch.Generator().manual_seed(9)
+    used = 0
+    train_ops._conv_tune[(8 * hw[0] * hw[1], cin, cout, cin)] = (1, 4, 5)    # the persistent LDS-weight kernel for the forward conv (what the step's tuner picks for these layers)
+    for step in range(3):
+        x = (torch.randn(8, cin, *hw, generator=g) * 1.2 + 0.1).to(DEV).half().contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(8, cout, *hw, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)
+        outs = []
+        for blk, on in ((ref, False), (new, True)):
+            train_ops.conv_bn_stats = on
+            try:
+                xa = x.clone().requires_grad_(True)
+                n0 = train_ops.stats.get("conv_bn_stats", 0)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    y = blk(xa)
+                used += train_ops.stats.get("conv_bn_stats", 0) - n0
+                assert on or train_ops.stats.get("conv_bn_stats", 0) == n0
+                y.backward(dy)
+                torch.cuda.synchronize()
+                outs.append((y.detach().float(), xa.grad.float()))
+            finally:
+                train_ops.conv_bn_stats = True
+        assert _rel(outs[1][0].cpu(), outs[0][0].cpu()) < 2e-3, (step, _rel(outs[1][0].cpu(), outs[0][0].cpu()))
+        assert _rel(outs[1][1].cpu(), outs[0][1].cpu()) < 6e-3, (step, _rel(outs[1][1].cpu(), outs[0][1].cpu()))
+    assert used == (0 if cin > 384 else 3), used
+    sa, sb = ref.state_dict(), new.state_dict()
+    for key in sa:
+        if "running" in key:
+            assert torch.allclose(sa[key], sb[key], rtol=1e-4, atol=1e-5), key
+        if key.endswith("num_batches_tracked"):
+            assert int(sa[key]) == int(sb[key]) == 3
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+        err = float((p2.grad - p1.grad).abs().max())
+        assert err <= 1e-2 * float(p1.grad.abs().max()) + 1e-4, (n1, err, float(p1.grad.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,hw,dtype", [(3, 24, (64, 64), torch.float16), (24, 48, (40, 36), torch.float16), (96, 96, (20, 20), torch.float16), (8, 16, (12, 12), torch.float32)])
 def test_repvgg_block_branch_sum_with_relu_in_one_apply_pass(cin, cout, hw, dtype):
     """RepVGGBlock in train form (yolov6/layers/common.py:224: ReLU(BN(conv3x3 s2) + BN(conv1x1 s2))) on maf_bn_sum_forward / _backward with act = relu — the
