@@ -351,13 +351,15 @@ def _stream_lds_ok(ksteps, ct):
     return stream_lds_ok(ksteps, ct)
 
 
-def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
-    """(tile_p, tile_c, tile_k) for the single-source conv K -> Nc over x (w2d [rows][cols] as maf_pack_w1x1 takes it)."""
+def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose, want_stats=False):
+    """(tile_p, tile_c, tile_k) for the single-source conv K -> Nc over x (w2d [rows][cols] as maf_pack_w1x1 takes it).  want_stats: the conv feeds a training-mode
+    BatchNorm — a tile with the statistics epilogue (csrc/conv_stream_lds_st.hip) may cost what the statistics pass it removes would (launch + one read of the
+    output) more than the fastest tile and still be chosen; kept under a key of its own (a data-gradient conv of the same shape has no use for it)."""
     M = B * H * W
     pt0, ct0 = pack.tile_for(Nc, M)
     if not conv_autotune or dt != lib.F16 or not x.is_cuda:
         return pt0, ct0, 1
-    key = (M, K, Nc, xs)
+    key = (M, K, Nc, xs, "st") if want_stats else (M, K, Nc, xs)
     best = _conv_tune.get(key)
     if best is not None:
         return best
@@ -409,7 +411,13 @@ def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose):
     finally:
         profile = saved
     res.sort()
-    best = _conv_tune[key] = res[0][1:] if res else (pt0, ct0, 1)
+    best = res[0][1:] if res else (pt0, ct0, 1)
+    if want_stats and res:
+        allow = 0.006 + M * Nc * 2 / 5.0e9                                       # ms: a statistics launch alone, tools/bn_bench.py (launch + bytes / 5 TB/s)
+        elig = [r for r in res if _conv_stats_ok(r[1:], K, Nc, Nc, dt, None)]
+        if elig and elig[0][0] <= res[0][0] + allow:
+            best = elig[0][1:]
+    _conv_tune[key] = best
     stats["conv_tuned"] = stats.get("conv_tuned", 0) + 1
     return best
 
@@ -626,13 +634,14 @@ class _Conv1x1(torch.autograd.Function):
         dt = _DT[x.dtype]
         co = -(-cout // 4) * 4                                                   # the kernel stores 4 channels at a time: any class count
         M = B * H * W
-        choice = _conv_tune.get((M, cin, co, xs)) if conv_autotune and dt == lib.F16 else None
+        want = bnslot is not None and conv_bn_stats and not _deterministic and bias is None and co == cout
+        choice = _conv_tune.get((M, cin, co, xs, "st") if want else (M, cin, co, xs)) if conv_autotune and dt == lib.F16 else None
         w2d = None
         if choice is None:
             w2d = w.detach().reshape(cout, cin).float().contiguous()
             if co != cout:                                                       # (cls_pred with nc % 4 != 0) runs with zero filters appended
                 w2d = F.pad(w2d, (0, 0, 0, co - cout))
-            choice = _conv_choice(x, xs, B, H, W, cin, co, dt, w2d, co, cin, 0)
+            choice = _conv_choice(x, xs, B, H, W, cin, co, dt, w2d, co, cin, 0, want)
         pt, ct, tk = choice
         wp = _hit(w, ("d", co, cin, 1, 0, dt, ct)) if co == cout else None       # staged by this step's batch (PackPlan)
         if wp is None:

@@ -1235,7 +1235,7 @@ def test_conv_batchnorm_statistics_out_of_the_conv_epilogue(cin, cout, hw):
     new = copy.deepcopy(ref)
     g = torch.Generator().manual_seed(9)
     used = 0
-    train_ops._conv_tune[(8 * hw[0] * hw[1], cin, cout, cin)] = (1, 4, 5)    # the persistent LDS-weight kernel for the forward conv (what the step's tuner picks for these layers)
+    train_ops._conv_tune[(8 * hw[0] * hw[1], cin, cout, cin, "st")] = train_ops._conv_tune[(8 * hw[0] * hw[1], cin, cout, cin)] = (1, 4, 5)    # the persistent LDS-weight kernel for the forward conv (what the step's tuner picks for these layers)
     for step in range(3):
         x = (torch.randn(8, cin, *hw, generator=g) * 1.2 + 0.1).to(DEV).half().contiguous(memory_format=torch.channels_last)
         dy = torch.randn(8, cout, *hw, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)

@@ -25,7 +25,7 @@ def last_json(path):
     return json.loads([l for l in open(path) if l.startswith("{")][-1])
 
 
-cp("first_kernels.md", "first_kernels.md"); cp("train_step_kernels.md", "train_step_kernels.md"); cp("train_n_rccl1.json", "train_n_rccl1.json"); cp("train_host_profile.txt", "train_host_profile.txt")
+cp("train_timeline.md", "train_timeline.md"); cp("train_launches_isolated.md", "train_launches_isolated.md"); cp("first_kernels.md", "first_kernels.md"); cp("train_step_kernels.md", "train_step_kernels.md"); cp("train_n_rccl1.json", "train_n_rccl1.json"); cp("train_host_profile.txt", "train_host_profile.txt")
 cp("bench.json", "bench.json"); cp("per_op.txt", "per_op.txt"); cp("tune.json", "tune.json"); cp("train_n.json", "train_n.json")
 cp("train_s.json", "train_s.json"); cp("train_m.json", "train_m.json"); cp("latency_m.json", "latency_m.json"); cp("bench_s.json", "bench_s.json"); cp("bench_m.json", "bench_m.json"); cp("bench_inflight1.json", "bench_inflight1.json"); cp("pmc_calibration.json", "pmc_calibration.json"); cp("tune_s.json", "tune_s.json"); cp("tune_m.json", "tune_m.json")
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)

@@ -24,6 +24,8 @@ python tools/train_host_profile.py 5 > $OUT/train_host_profile.txt 2>&1; echo "t
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python bench.py --train --scale n --batch 32 --steps 6 --warmup 8 --no-cpu-baseline > /dev/null 2> $OUT/train_stats.err
 echo "train rocprof rc=$?"
 python tools/step_kernels.py $(find $OUT/train_stats -name "*kernel_trace.csv" | head -1) 4 $OUT/train_step_kernels.md > /dev/null 2>&1; echo "train step table rc=$?"
+python tools/step_timeline.py $(find $OUT/train_stats -name "*kernel_trace.csv" | head -1) 3 $OUT/train_timeline.md > /dev/null 2>&1; echo "train timeline rc=$?"
+python tools/tape_times.py n 32 10 > $OUT/train_launches_isolated.md 2> /dev/null; echo "isolated launches rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/trainpmc/pmc_$c -o p -- python bench.py --train --scale n --batch 32 --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trainpmc_$c.err
   echo "train pmc $c rc=$?"

@@ -27,9 +27,13 @@ def main():
             cuts.append(i)
     if len(cuts) < n + 1:
         raise SystemExit("only %d optimizer steps in the trace" % len(cuts))
-    cuts = cuts[-(n + 1):]
+    # the trailing steps of `bench.py --train` are its by-kind timing pass (eager launches between event pairs, no step tape, no lanes): the steady-state steps
+    # are the ones on the most queues — take the last n of those
+    pairs = list(zip(cuts[:-1], cuts[1:]))
+    nq = [len({r[3] for r in rows[a:b]}) for a, b in pairs]
+    pairs = [pr for pr, q in zip(pairs, nq) if q == max(nq)][-n:]
     agg, span = {}, 0.0
-    for a, b in zip(cuts[:-1], cuts[1:]):
+    for a, b in pairs:
         span += (rows[b][0] - rows[a][0]) / 1e6
         for s, e, name, q in rows[a:b]:
             d = agg.setdefault(demangle(name), [0, 0.0])
