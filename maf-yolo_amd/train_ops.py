@@ -60,6 +60,13 @@ def _tzeros(*a, **k):
         _in_alloc = False
     if _keep is not None:
         _keep.append(t)
+    if _cur_lane and t.is_cuda:
+        # torch's fill kernel went to the MAIN stream, the kernels that are about to use the buffer go to lane _cur_lane, which forked from the main stream
+        # BEFORE this fill was queued: without a wait the lane may accumulate into the buffer before (or while) it is zeroed.  Seen as a non-finite loss in about
+        # every second run of two processes sharing one GPU (tests/test_gpu_train.py::test_bench_train_two_ranks_on_one_device — a BatchNorm scratch of a
+        # recording step tape, allocated per call site inside a lane); a process that has the GPU to itself wins the race.  Host-side wait, not a tape record:
+        # replays never allocate.
+        lib.check(lib._lib.maf_stream_fork(_lane_handle(t.device, 0), _lane_handle(t.device, _cur_lane)))
     return t
 
 

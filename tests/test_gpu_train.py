@@ -861,9 +861,12 @@ def test_bench_train_two_ranks_on_one_device():
     env = dict(os.environ, MAF_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(root, "bench.py"), "--gpus", "2", "--train", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    # three times: the step tape's recording step once raced its lanes against the zero-fill of their BatchNorm scratches (train_ops._tzeros) — a non-finite
+    # loss in about every second run of THIS command (two processes time-slicing one GPU), never in a process alone
+    for _ in range(3):
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, "\n".join(l for l in out.stderr.splitlines() if "Warning" not in l and "amdgpu.ids" not in l)[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "ddp2"
     assert d["config"]["native_launches"]["fallback"] == 0 and d["config"]["native_launches"]["native_wgrad"] > 0
