@@ -401,6 +401,11 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
                    int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
+/* The 3x3 (+ second 3x3) + 1x1 branches of a train-form DilatedReparamBlock (kernel sets 3,3,1 / 5,3,1: yolov6/layers/common.py:2997-3008, 3024-3031) share their
+ * input: ONE launch stages the X halo tile once and multiplies it with dYa (and dYb, may be null together with dwb) for the 3x3 gradients [C][9] and — the items of
+ * the centre tap row — with dY1 for the 1x1 branch's per-channel scale gradient dw1[C].  Same contract as maf_dw_wgrad otherwise (zeroed fp32 results, `replicas` copies). */
+int maf_dw_wgrad31(const void* x, int32_t x_stride, const void* dya, int32_t dya_stride, const void* dyb, int32_t dyb_stride, const void* dy1, int32_t dy1_stride,
+                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, float* dwa, float* dwb, float* dw1, int32_t replicas, maf_stream_t stream);
 
 /* Gradient fold of the owned gradient exchange (maf_yolo_amd/exchange.py; the reference leaves this to autograd's AccumulateGrad + the DDP
  * reducer's bucket copy, yolov6/core/engine.py:161-164): src = what a weight-gradient kernel produced, tap-major [taps][Cout_p][Cin_p] fp32 with

@@ -274,6 +274,190 @@ int launch_dw_wgrad(DwWgArgs& a, int k, hipStream_t s) {
     return maf_check_hip(hipGetLastError(), "dw_wgrad launch");
 }
 
+// The 3 x 3 (+ 3 x 3) + 1 x 1 branches of a train-form DilatedReparamBlock that share ONE input (kernel sets 3,3,1 and 5,3,1: common.py:2997-3008) in one launch.
+// As separate launches every branch stages the X halo tile again: 80 x 80 x 192, batch 32: k3 61.7 us + k1 50.6 us for 3 x 78.6 MB of X + dY reads each way; the 1 x 1
+// branch — dW1[c] = sum dY1 * X, a per-channel scale — needs nothing but the centre tap of the tile the 3 x 3 item already holds.  Work items as in dw_wgrad_kernel with
+// K = 3 (channel group, tap row, strip, row segment); an item multiplies its X strip with the strip of dYa (and dYb); the items of the CENTRE tap row also take dY1.
+struct DwWg31Args {
+    const void* x; const void* dya; const void* dyb; const void* dy1;
+    float* dwa; float* dwb; float* dw1;
+    int B, H, W, C, x_stride, dya_stride, dyb_stride, dy1_stride, TH, TW, CB, tilesX, tilesY, nCB, replicas, RSEG;
+};
+
+template <typename T, typename V, int N, bool HASB>
+__global__ __launch_bounds__(512) void dw_wgrad31_kernel(const DwWg31Args a) {
+    constexpr int K = 3, P = 1, S = 4, NT = HASB ? 3 : 2;        // dY tiles in LDS: a, [b,] 1
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    V* xt = reinterpret_cast<V*>(smem_raw);
+    const int cb = blockIdx.x % a.nCB, wgi = blockIdx.x / a.nCB, nwg = gridDim.x / a.nCB;
+    const int c0 = cb * a.CB;
+    const int CGB = min(a.CB, a.C - c0) / N;
+    const int PS = a.CB / N + 1;
+    const int RH = a.TH + K - 1, RW = a.TW + K - 1, TP = a.TH * a.TW;
+    V* dt = xt + RH * RW * PS;                                 // [NT][TH*TW][PS]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const T* xin = static_cast<const T*>(a.x) + c0;
+    const T* dsrc[3] = {static_cast<const T*>(a.dya) + c0, HASB ? static_cast<const T*>(a.dyb) + c0 : static_cast<const T*>(a.dy1) + c0, static_cast<const T*>(a.dy1) + c0};
+    const int dstr[3] = {a.dya_stride, HASB ? a.dyb_stride : a.dy1_stride, a.dy1_stride};
+    const int nstrip = a.TW / S;
+    const int items = CGB * K * nstrip * a.RSEG;
+    const bool live = tid < items;
+    const int st = tid % nstrip, r2 = tid / nstrip;
+    const int cgi = r2 % CGB, r3 = r2 / CGB;
+    const int ky = r3 % K, rseg = r3 / K;
+    const bool mid = live && ky == P;
+    float acca[K][N], accb[HASB ? K : 1][N], acc1[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        acc1[j] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) { acca[kx][j] = 0.f; if constexpr (HASB) accb[kx][j] = 0.f; }
+    }
+    auto fma8 = [](float* acc, const V& xv, const V& dv) {
+        if constexpr (N == 8) {
+            const u32x4_t xa = __builtin_bit_cast(u32x4_t, xv), da = __builtin_bit_cast(u32x4_t, dv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q]) : "v"(xa[q]), "v"(da[q]));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * q + 1]) : "v"(xa[q]), "v"(da[q]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = __builtin_fmaf((float)xv[j], (float)dv[j], acc[j]);
+        }
+    };
+    const int ntiles = a.B * a.tilesY * a.tilesX;
+    for (int tile = wgi; tile < ntiles; tile += nwg) {
+        const int tx = tile % a.tilesX, t2 = tile / a.tilesX;
+        const int ty = t2 % a.tilesY, b = t2 / a.tilesY;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        __syncthreads();
+        for (int idx = tid; idx < RH * RW * CGB; idx += nthr) {
+            const int cg = idx % CGB, p = idx / CGB;
+            const int rx = p % RW, ry = p / RW;
+            const int iy = y0 - P + ry, ix = x0 - P + rx;
+            V v = (V)(T)0;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const V*>(xin + ((size_t)((size_t)b * a.H + iy) * a.W + ix) * a.x_stride + cg * N);
+            xt[p * PS + cg] = v;
+        }
+        for (int idx = tid; idx < NT * TP * CGB; idx += nthr) {
+            const int cg = idx % CGB, q = idx / CGB;
+            const int p = q % TP, t = q / TP;
+            const int rx = p % a.TW, ry = p / a.TW;
+            const int oy = y0 + ry, ox = x0 + rx;
+            V v = (V)(T)0;
+            if (oy < a.H && ox < a.W)
+                v = *reinterpret_cast<const V*>(dsrc[t] + ((size_t)((size_t)b * a.H + oy) * a.W + ox) * dstr[t] + cg * N);
+            dt[(t * TP + p) * PS + cg] = v;
+        }
+        __syncthreads();
+        if (live) {
+            for (int ry = rseg; ry < a.TH; ry += a.RSEG) {
+                const V* xr = xt + ((ry + ky) * RW + st * S) * PS + cgi;
+                const V* dr = dt + (ry * a.TW + st * S) * PS + cgi;
+                V xv[S + K - 1], dv[S];
+#pragma unroll
+                for (int i = 0; i < S + K - 1; ++i) xv[i] = xr[i * PS];
+#pragma unroll
+                for (int i = 0; i < S; ++i) dv[i] = dr[i * PS];
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) fma8(acca[kx], xv[i + kx], dv[i]);
+                if constexpr (HASB) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) dv[i] = dr[(TP + i) * PS];
+#pragma unroll
+                    for (int i = 0; i < S; ++i)
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) fma8(accb[kx], xv[i + kx], dv[i]);
+                }
+                if (mid) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) dv[i] = dr[((NT - 1) * TP + i) * PS];
+#pragma unroll
+                    for (int i = 0; i < S; ++i) fma8(acc1, xv[i + P], dv[i]);
+                }
+            }
+        }
+    }
+    // reduction as in dw_wgrad_kernel: strips by lane shuffles, row segments by LDS atomics, one global atomic per (channel, tap) and branch
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);           // [CGB * N][9] a, [CGB * N][9] b, [CGB * N] 1
+    const int n9 = CGB * N * K * K, nred = (HASB ? 2 : 1) * n9 + CGB * N;
+    for (int i = tid; i < nred; i += nthr) red[i] = 0.f;
+    __syncthreads();
+    const bool pow2 = nstrip == 4;
+    auto fold = [&](float v, int slot, bool on) {
+        if (!on) v = 0.f;
+        if (pow2) {
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+        }
+        if (on && (!pow2 || st == 0)) atomicAdd(red + slot, v);
+    };
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            fold(acca[kx][j], (cgi * N + j) * (K * K) + ky * K + kx, live);
+            if constexpr (HASB) fold(accb[kx][j], n9 + (cgi * N + j) * (K * K) + ky * K + kx, live);
+        }
+        fold(acc1[j], (HASB ? 2 : 1) * n9 + cgi * N + j, mid);
+    }
+    __syncthreads();
+    const size_t rep = (size_t)(wgi % a.replicas);
+    float* da = a.dwa + rep * a.C * (K * K) + (size_t)c0 * (K * K);
+    for (int i = tid; i < n9; i += nthr) atomicAdd(da + i, red[i]);
+    if constexpr (HASB) {
+        float* db = a.dwb + rep * a.C * (K * K) + (size_t)c0 * (K * K);
+        for (int i = tid; i < n9; i += nthr) atomicAdd(db + i, red[n9 + i]);
+    }
+    float* d1 = a.dw1 + rep * a.C + c0;
+    for (int i = tid; i < CGB * N; i += nthr) atomicAdd(d1 + i, red[(HASB ? 2 : 1) * n9 + i]);
+}
+
+template <typename T, typename V, int N>
+int launch_dw_wgrad31(DwWg31Args& a, hipStream_t s) {
+    // geometry of launch_dw_wgrad for k = 3; channel groups per block / threads from tools/dw_wgrad31_sweep.py (batch 32, us, separate launches -> merged):
+    //   160 x 160 x 72 (3+3+1)  278 -> 243 with <= 8 groups (5 + 4: 4 or 3 leave 48-byte pixel rows: 316);  80 x 80 x 192  113 -> 95 with 8 groups on 512 threads (4: 115);
+    //   80 x 80 x 144  105 -> 84 and 80 x 80 x 128  80 -> 60 with 4 groups (8: 84 / 89)
+    constexpr int k = 3;
+    const bool big = (long long)a.H * a.W >= 160 * 160, wide = a.C >= 160;
+    int gmax = big || wide ? 8 : 4, maxthr = wide && !big ? 512 : 256, wgcap = 1024, abudget = 1500000;
+    if (const char* e = getenv("MAF_DWWG31")) sscanf(e, "%d,%d,%d,%d", &gmax, &maxthr, &wgcap, &abudget);
+    a.TH = min(8, a.H); a.TW = 16;
+    const int groups = a.C / N, nblk = maf_cdiv(groups, gmax);
+    const int cgb = maf_cdiv(groups, nblk);
+    a.CB = cgb * N;
+    a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH); a.nCB = maf_cdiv(a.C, a.CB);
+    const int base = cgb * k * (a.TW / 4);
+    a.RSEG = maxthr / base > a.TH ? a.TH : maxthr / base > 0 ? maxthr / base : 1;
+    MAF_REQUIRE(base * a.RSEG <= 512, "dw_wgrad31: work items exceed the workgroup");
+    const int nthr = (base * a.RSEG + 63) / 64 * 64;
+    const int nt = a.dyb ? 3 : 2;
+    size_t lds = ((size_t)(a.TH + k - 1) * (a.TW + k - 1) + (size_t)nt * a.TH * a.TW) * (cgb + 1) * 16;
+    const size_t red = (size_t)a.CB * (2 * k * k + 1) * 4;
+    if (lds < red) lds = red;
+    int per = a.B * a.tilesY * a.tilesX;
+    const int cap = maf_cdiv(wgcap, a.nCB);
+    if (per > cap) per = cap;
+    const int budget = (int)((long long)abudget / ((long long)a.C * (nt - 1) * k * k));
+    if (per > budget) per = budget > 8 ? budget : 8;
+    const dim3 g(per * a.nCB), b(nthr);
+    static bool attr = false;                                            // (8 groups x three dY tiles: 81 KB of LDS)
+    if (!attr) {
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad31_kernel<T, V, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(dw_wgrad31)");
+        if (!rc) rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad31_kernel<T, V, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(dw_wgrad31)");
+        if (rc) return rc;
+        attr = true;
+    }
+    if (a.dyb) hipLaunchKernelGGL((dw_wgrad31_kernel<T, V, N, true>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((dw_wgrad31_kernel<T, V, N, false>), g, b, lds, s, a);
+    return maf_check_hip(hipGetLastError(), "dw_wgrad31 launch");
+}
+
 // dst[b, 2y, 2x, :] += src[b, y, x, :] (NHWC, 16-byte channel chunks): the data gradient of a stride-2 1x1 conv (RepVGGBlock.rbr_1x1, common.py:203) added onto the
 // 3x3 branch's data gradient of the same input — instead of a zero-filled full-size tensor, a strided copy and a full-size add.
 template <typename T, typename V, int N>
@@ -500,4 +684,20 @@ extern "C" int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int
     }
     if (dtype == MAF_F16) return launch_dw_wgrad<half_t, half8_t, 8>(a, k, s);
     return launch_dw_wgrad<float, f32x4_t, 4>(a, k, s);
+}
+
+extern "C" int maf_dw_wgrad31(const void* x, int32_t x_stride, const void* dya, int32_t dya_stride, const void* dyb, int32_t dyb_stride, const void* dy1, int32_t dy1_stride,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, float* dwa, float* dwb, float* dw1, int32_t replicas, maf_stream_t stream) {
+    MAF_REQUIRE(replicas >= 1 && replicas <= 64, "dw_wgrad31: replicas must be 1..64");
+    MAF_REQUIRE(x && dya && dy1 && dwa && dw1 && (!dyb == !dwb) && B > 0 && H > 0 && W > 0 && C > 0, "dw_wgrad31: bad arguments (x, dya / dwa, dy1 / dw1 required; dyb and dwb together)");
+    MAF_REQUIRE(dtype == MAF_F16 || dtype == MAF_F32, "dw_wgrad31: dtype must be f16/f32");
+    const int N = dtype == MAF_F16 ? 8 : 4;
+    MAF_REQUIRE(C % N == 0 && x_stride % N == 0 && dya_stride % N == 0 && dy1_stride % N == 0 && (!dyb || dyb_stride % N == 0),
+                "dw_wgrad31: C and strides must be multiples of the 16-byte channel group");
+    DwWg31Args a;
+    a.x = x; a.dya = dya; a.dyb = dyb; a.dy1 = dy1; a.dwa = dwa; a.dwb = dwb; a.dw1 = dw1; a.B = B; a.H = H; a.W = W; a.C = C;
+    a.x_stride = x_stride; a.dya_stride = dya_stride; a.dyb_stride = dyb_stride; a.dy1_stride = dy1_stride; a.replicas = replicas;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F16) return launch_dw_wgrad31<half_t, half8_t, 8>(a, s);
+    return launch_dw_wgrad31<float, f32x4_t, 4>(a, s);
 }

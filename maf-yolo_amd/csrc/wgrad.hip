@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256) void wgrad3_fold_kernel(float* __restrict__ ws
 
 // The workgroups of the patch form end with 9 * Cout * Cin atomics each; a thousand workgroups adding into the same few hundred cache lines serialise (24 -> 48: 8 M atomics,
 // 66 us at the ~120 G/s of that pattern), so they add into kWsCopies copies (workgroup index modulo) kept by the library per (device, stream), folded by one small launch.
-constexpr int kWsCopies = 8, kWsFloats = 9 * 64 * 48;
+constexpr int kWsCopies = 8, kWsFloats = 9 * 64 * 48;            // kWsFloats: the largest dW of the patch form / of the many-chunk rule below
+// (Round 5, measured and dropped — tools/conv_wgrad_bench.py: the same copies for the WIDE layers, 3 x 3 stride 2 128 -> 128 ... 192 -> 192 and the 1 x 1 layers of the
+// 20 x 20 / 40 x 40 maps with a dW of 32 K ... 330 K floats and 30 - 56 pixel chunks, in a 64 MB workspace: +3 ... +5 us on every one of them, 2756 -> 2823 us over the
+// dense weight gradients of a step.  Their atomics land on 0.1 - 1.3 MB of distinct lines and are not what bounds them; the fold's pass over eight copies is pure cost.)
 struct WsSlot { int dev; hipStream_t s; float* p; };
 static WsSlot g_ws[16];
 static int g_nws = 0;

@@ -1249,6 +1249,61 @@ def _dw_wgrad(x, dy, dys, w):
     return dwf.reshape(w.shape).to(w.dtype)
 
 
+dw_wgrad31 = os.environ.get("MAF_DW_WGRAD31", "1") != "0"                # A/B switch: the 3x3 (+ 3x3) + 1x1 branches' weight gradients as one launch (x staged once)
+
+
+def _dw_wgrad31_ok(x, ws):
+    """The branches the merged launch takes: kernel sizes (.., 3, 1) behind an optional larger first branch, on the maps where maf_dw_wgrad routes k = 3 to the
+    vector kernel (csrc/train_ops.hip: maf_dw_wgrad; the small maps' k = 3 gradients run on the matrix cores)."""
+    if not (dw_wgrad31 and x.is_cuda and x.dtype in _DT):
+        return None
+    ks = tuple(int(w.shape[-1]) for w in ws)
+    B, c, H, W = x.shape
+    if W <= 96 and (H * W <= 400 or (H * W <= 1600 and c <= 192)):
+        return None
+    if ks == (3, 3, 1):
+        return (0, 1, 2)
+    if len(ks) == 3 and ks[1:] == (3, 1):
+        return (1, None, 2)
+    return None
+
+
+def _dw_wgrad31(x, dzs, ws, sel):
+    """maf_dw_wgrad31 on the side stream for the branches `sel` = (3x3, second 3x3 or None, 1x1): [dW or None (went into an exchange bucket)] per selected branch."""
+    B, c, H, W = x.shape
+    dt = _DT[x.dtype]
+    xx, xs = nhwc(x)
+    L = lib.load()
+    js = [j for j in sel if j is not None]
+    sinks = {j: _grad_sink(ws[j]) for j in js}
+    bufs = {}
+    for j in js:
+        if sinks[j][0] is not None:
+            bufs[j] = sinks[j][1]
+        else:
+            k = ws[j].shape[-1]
+            bufs[j] = _empty(c, k * k, dtype=torch.float32, device=x.device)
+    own = [bufs[j] for j in js if sinks[j][0] is None]
+    h = _fork(x.device, xx, *[dzs[j] for j in js], *own)
+    for t in own:
+        lib.check(L.maf_zero(t.data_ptr(), t.numel() * 4, h))
+    a, b, one = sel
+    with _prof("dw_wgrad_k31", (1 + len(js)) * B * H * W * c * x.element_size(), x.device, (B, H, W, c, len(js), xs), h):
+        lib.check(L.maf_dw_wgrad31(xx.data_ptr(), xs, dzs[a].data_ptr(), dzs[a].stride()[3],
+                                   None if b is None else dzs[b].data_ptr(), 0 if b is None else dzs[b].stride()[3],
+                                   dzs[one].data_ptr(), dzs[one].stride()[3], B, H, W, c, dt,
+                                   bufs[a].data_ptr(), None if b is None else bufs[b].data_ptr(), bufs[one].data_ptr(), 1, h))
+    out = {}
+    for j in js:
+        if sinks[j][0] is not None:
+            sinks[j][0].side_done(ws[j])
+            out[j] = None
+        else:
+            out[j] = bufs[j].reshape(ws[j].shape).to(ws[j].dtype)
+    stats["native_dw_wgrad31"] = stats.get("native_dw_wgrad31", 0) + 1
+    return out
+
+
 _PTR4 = C.c_void_p * 4
 _INT4 = C.c_int32 * 4
 
@@ -1304,10 +1359,16 @@ class _DWBranches(torch.autograd.Function):
             dzs.append(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dws = [None] * len(ws)
         returned = False
+        merged = {}
+        sel = _dw_wgrad31_ok(x, ws) if all(ctx.needs_input_grad[2:2 + len(ws)]) else None
+        if sel is not None:
+            merged = _dw_wgrad31(x, dzs, ws, sel)
         for j, w in enumerate(ws):
-            if ctx.needs_input_grad[2 + j]:
+            if j in merged:
+                dws[j] = merged[j]
+            elif ctx.needs_input_grad[2 + j]:
                 dws[j] = _dw_wgrad(x, dzs[j], dzs[j].stride()[3], w)
-                returned = returned or dws[j] is not None
+            returned = returned or dws[j] is not None
         dx = None
         if ctx.needs_input_grad[0]:                                              # sum over the branches of the correlation with the flipped kernel
             dx = _empty((B, c, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)

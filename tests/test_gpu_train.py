@@ -1080,6 +1080,65 @@ def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, re
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,C,pad,two,reps,dtype", [(2, 80, 80, 40, 24, False, 1, torch.float16), (1, 160, 160, 72, 0, True, 1, torch.float16), (3, 21, 100, 16, 8, True, 4, torch.float16),
+                                                       (2, 9, 17, 8, 0, False, 2, torch.float16), (2, 12, 20, 12, 4, True, 1, torch.float32), (1, 160, 160, 128, 0, True, 1, torch.float16),
+                                                       (1, 80, 80, 256, 0, False, 1, torch.float16)])
+def test_dw_wgrad31_c_abi_matches_the_separate_weight_gradients(B, H, W, C, pad, two, reps, dtype):
+    """Round 5: the 3x3 (+ second 3x3) + 1x1 branches of a train-form DilatedReparamBlock (kernel sets 3,3,1 / 5,3,1: yolov6/layers/common.py:2997-3008, 3024-3031) share
+    their input: maf_dw_wgrad31 stages the X halo tile once for all of them.  Through the C-ABI on channel slices of wider buffers, against the framework's fp32 weight
+    gradients of the same values (ragged tiles, several replicas, fp32 parity mode)."""
+    from maf_yolo_amd import lib
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + C)
+    mk = lambda: torch.randn(B, H, W, C + pad, generator=g).to(dtype).to(DEV)
+    xb, ab, bb, ob = mk(), mk(), mk(), mk()
+    x, dya, dyb, dy1 = xb[..., pad:], ab[..., :C], bb[..., pad:], ob[..., :C]
+    dwa, dwb, dw1 = torch.zeros(reps, C, 9, device=DEV), torch.zeros(reps, C, 9, device=DEV), torch.zeros(reps, C, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.load().maf_dw_wgrad31(x.data_ptr(), C + pad, dya.data_ptr(), C + pad, dyb.data_ptr() if two else None, C + pad if two else 0, dy1.data_ptr(), C + pad,
+                                        B, H, W, C, lib.F16 if dtype == torch.float16 else lib.F32, dwa.data_ptr(), dwb.data_ptr() if two else None, dw1.data_ptr(), reps, st))
+    torch.cuda.synchronize()
+    xf = x.permute(0, 3, 1, 2).float()
+    ref = lambda dy, k: torch.nn.grad.conv2d_weight(xf, (C, 1, k, k), dy.permute(0, 3, 1, 2).float(), padding=k // 2, groups=C)
+    ra, r1 = ref(dya, 3), ref(dy1, 1)
+    assert float((dwa.sum(0).view(C, 1, 3, 3) - ra).abs().max()) <= 2e-4 * float(ra.abs().max())
+    assert float((dw1.sum(0).view(C, 1, 1, 1) - r1).abs().max()) <= 2e-4 * float(r1.abs().max())
+    if two:
+        rb = ref(dyb, 3)
+        assert float((dwb.sum(0).view(C, 1, 3, 3) - rb).abs().max()) <= 2e-4 * float(rb.abs().max())
+    else:
+        assert float(dwb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("k0,c,hw", [(3, 24, (48, 112)), (5, 40, (50, 100))])
+def test_dw_branches_backward_takes_the_merged_weight_gradient_launch(k0, c, hw):
+    """The autograd path of the branches (train_ops.dw_branches) uses ONE maf_dw_wgrad31 launch for the (3,) 3, 1 branches on maps whose k = 3 gradient runs on the
+    vector kernel (W > 96 here) and gives the weight gradients of the per-branch launches (MAF_DW_WGRAD31 = 0 path), every branch."""
+    from maf_yolo_amd import train_ops
+    ks = {3: (3, 3, 1), 5: (5, 3, 1)}[k0]
+    g = torch.Generator().manual_seed(k0 * 100 + c)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, c, H, W, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(c, 1, k, k, generator=g) / k).to(DEV).requires_grad_(True) for k in ks]
+    dys = [torch.randn(B, c, H, W, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last) for _ in ks]
+    res = {}
+    for on in (True, False):
+        saved, train_ops.dw_wgrad31 = train_ops.dw_wgrad31, on
+        try:
+            n0 = train_ops.stats.get("native_dw_wgrad31", 0)
+            xx = x.clone().requires_grad_(True)
+            outs = train_ops.dw_branches(xx, ws)
+            torch.autograd.backward(outs, dys)
+            torch.cuda.synchronize()
+            assert (train_ops.stats.get("native_dw_wgrad31", 0) - n0) == (1 if on else 0)
+            res[on] = [w.grad.clone() for w in ws]
+            for w in ws:
+                w.grad = None
+        finally:
+            train_ops.dw_wgrad31 = saved
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+
+
 @pytest.mark.parametrize("k0,c,hw,dtype", [(3, 72, (40, 40), torch.float16), (5, 144, (20, 24), torch.float16), (7, 192, (20, 20), torch.float16),
                                             (9, 96, (13, 20), torch.float16), (9, 288, (20, 20), torch.float16), (7, 24, (9, 12), torch.float32), (5, 8, (6, 8), torch.float32)])
 def test_dw_branches_one_launch_matches_the_separate_launches(k0, c, hw, dtype):

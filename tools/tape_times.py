@@ -78,6 +78,11 @@ def main():
                 Bc, H, W, c, k = [int(a[j]) for j in range(4, 9)]
                 nbytes = 2 * Bc * H * W * c * 2
                 note = "%dx%dx%d k%d" % (H, W, c, k)
+            elif nm == "maf_dw_wgrad31":
+                Bc, H, W, c = [int(a[j]) for j in range(8, 12)]
+                nb = 2 if not int(a[4]) else 3
+                nbytes = (1 + nb) * Bc * H * W * c * 2
+                note = "%dx%dx%d k%s" % (H, W, c, "3+1" if nb == 2 else "3+3+1")
             elif nm == "maf_bn_forward_ex":
                 Mp, c = int(a[2]), int(a[3])
                 nbytes, note = (3 if not int(a[22]) else 2) * Mp * c * 2, "M %d C %d%s" % (Mp, c, " (statistics ready)" if int(a[22]) else "")
@@ -115,10 +120,10 @@ def main():
         tot[st] += us
     print("\nsum per stream index (0 main, 1 weight gradients, 2.. lanes), isolated: " + ", ".join("%d: %.2f ms" % (k, v / 1e3) for k, v in sorted(tot.items())))
     print("\n## weight-gradient launches (stream 1)\n\n| entry | shape | us alone | GB/s |\n|---|---|---|---|")
-    for which, i, st, nm, us, nb, note in sorted([r_ for r_ in rows if r_[3] in ("maf_conv_wgrad", "maf_dw_wgrad")], key=lambda r_: -r_[4]):
+    for which, i, st, nm, us, nb, note in sorted([r_ for r_ in rows if r_[3] in ("maf_conv_wgrad", "maf_dw_wgrad", "maf_dw_wgrad31")], key=lambda r_: -r_[4]):
         print("| `%s` | %s | %.1f | %.0f |" % (nm, note, us, nb / us / 1e3))
     print("\n## every other launch, longest first\n\n| list | # | entry | what | us alone | GB/s (algorithmic bytes of the call) |\n|---|---|---|---|---|---|")
-    for which, i, st, nm, us, nb, note in sorted([r_ for r_ in rows if r_[3] not in ("maf_conv_wgrad", "maf_dw_wgrad")], key=lambda r_: -r_[4]):
+    for which, i, st, nm, us, nb, note in sorted([r_ for r_ in rows if r_[3] not in ("maf_conv_wgrad", "maf_dw_wgrad", "maf_dw_wgrad31")], key=lambda r_: -r_[4]):
         print("| %s | %d | `%s` | %s | %.1f | %s |" % (which, i, nm, note, us, ("%.0f" % (nb / us / 1e3)) if nb else ""))
     ex.close()
 
