@@ -401,6 +401,12 @@ int maf_conv_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_s
                    int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t dtype, float* dw, maf_stream_t stream);
 int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_stride, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t k, int32_t dtype, float* dw, int32_t replicas, maf_stream_t stream);
+/* Training-form stem (backbone.0's RepVGGBlock over the image, yolov6/layers/common.py:199-203, 219-224; Cin = 3: configs/yaml/MAF-YOLO-n.yaml:5): z3 = conv3x3 stride 2 pad 1
+ * (img, w3) and z1 = conv1x1 stride 2 (img, w1) in ONE launch, no bias, no activation (csrc/stem_train.hip).  img: fp16 NHWC [B][Hin][Win] with 16-byte pixels (3 channels
+ * zero-padded to 8; pixel stride img_stride halfs), w3 [Cout][3][3][3] / w1 [Cout][3] fp32 — the parameters themselves, rounded to fp16 inside as autocast does —, z3 / z1
+ * dense fp16 [B][Hin/2][Win/2][Cout]. */
+int maf_stem_train(const void* img, int32_t img_stride, int32_t B, int32_t Hin, int32_t Win, const float* w3, const float* w1, int32_t Cout,
+                   void* z3, void* z1, maf_stream_t stream);
 /* The 3x3 (+ second 3x3) + 1x1 branches of a train-form DilatedReparamBlock (kernel sets 3,3,1 / 5,3,1: yolov6/layers/common.py:2997-3008, 3024-3031) share their
  * input: ONE launch stages the X halo tile once and multiplies it with dYa (and dYb, may be null together with dwb) for the 3x3 gradients [C][9] and — the items of
  * the centre tap row — with dY1 for the 1x1 branch's per-channel scale gradient dw1[C].  Same contract as maf_dw_wgrad otherwise (zeroed fp32 results, `replicas` copies). */

@@ -54,6 +54,7 @@ const Entry kEntries[] = {
     MAF_TAPE_ENTRY(maf_dw_branches_stats),
     MAF_TAPE_ENTRY(maf_dw_wgrad),
     MAF_TAPE_ENTRY(maf_dw_wgrad31),
+    MAF_TAPE_ENTRY(maf_stem_train),
     MAF_TAPE_ENTRY(maf_conv_wgrad),
     MAF_TAPE_ENTRY(maf_grad_fold),
     MAF_TAPE_ENTRY(maf_zero),

@@ -1042,6 +1042,21 @@ class _RepVGGConvs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w3, w1):
+        if stem_train and x.dtype == torch.float16 and w3.shape[1] == 3 and x.shape[1] == 8 and w3.shape[0] % 8 == 0 and w3.shape[0] <= 96 \
+                and w3.dtype == torch.float32 and w1.dtype == torch.float32 and w3.is_contiguous() and w1.is_contiguous() and x.shape[3] % 8 == 0:
+            # the image (3 channels padded to 8): both branches in ONE launch of a direct conv (csrc/stem_train.hip) — the generic kernels read it twice with a K of 72 / 8
+            x, xs = nhwc(x)
+            B, _, H, W = x.shape
+            cout = w3.shape[0]
+            z3 = _empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            z1 = _empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            with _prof("stem_train", (B * H * W * 8 + 2 * B * (H // 2) * (W // 2) * cout) * 2, x.device, (B, H, W, cout)):
+                lib.check(lib.load().maf_stem_train(x.data_ptr(), xs, B, H, W, w3.data_ptr(), w1.data_ptr(), cout, z3.data_ptr(), z1.data_ptr(), _stream(x.device)))
+            ctx.save_for_backward(x, w3, w1)
+            stats["native_conv3x3s2"] = stats.get("native_conv3x3s2", 0) + 1
+            stats["native_conv1x1"] += 1
+            stats["native_stem_train"] = stats.get("native_stem_train", 0) + 1
+            return z3, z1
         c3, c1 = _Ctx(), _Ctx()
         z3 = _Conv3x3s2.forward(c3, x, w3)
         z1 = _Conv1x1s2.forward(c1, x, w1)
@@ -1249,6 +1264,7 @@ def _dw_wgrad(x, dy, dys, w):
     return dwf.reshape(w.shape).to(w.dtype)
 
 
+stem_train = os.environ.get("MAF_STEM_TRAIN", "1") != "0"                # A/B switch: the image's two RepVGG convs as one direct-conv launch (csrc/stem_train.hip)
 dw_wgrad31 = os.environ.get("MAF_DW_WGRAD31", "1") != "0"                # A/B switch: the 3x3 (+ 3x3) + 1x1 branches' weight gradients as one launch (x staged once)
 
 

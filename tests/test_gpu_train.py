@@ -1080,6 +1080,52 @@ def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, re
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,cout", [(2, 64, 96, 24), (1, 128, 64, 32), (3, 32, 40, 48), (1, 6, 8, 8)])
+def test_stem_train_one_launch_matches_the_two_convs(B, H, W, cout):
+    """Round 5: the two convs of backbone.0's train-form RepVGGBlock over the image (3x3 stride 2 pad 1 and 1x1 stride 2: yolov6/layers/common.py:199-203, 219-224) as ONE
+    direct-conv launch (csrc/stem_train.hip, maf_stem_train): through the C-ABI against fp32 convolutions of the same fp16 image with the weights rounded to fp16 (what
+    autocast gives the reference's conv), and through train_ops.repvgg_convs against the generic two-launch path (MAF_STEM_TRAIN = 0), forward and weight gradients."""
+    from maf_yolo_amd import lib, train_ops
+    g = torch.Generator().manual_seed(H * 100 + W + cout)
+    img = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    w3 = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    w1 = (torch.randn(cout, 3, 1, 1, generator=g) * 0.5).to(DEV)
+    x8 = torch.zeros(B, H, W, 8, dtype=torch.float16, device=DEV)
+    x8[..., :3] = img.permute(0, 2, 3, 1).half()
+    z3 = torch.empty(B, H // 2, W // 2, cout, dtype=torch.float16, device=DEV)
+    z1 = torch.empty_like(z3)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.load().maf_stem_train(x8.data_ptr(), 8, B, H, W, w3.data_ptr(), w1.data_ptr(), cout, z3.data_ptr(), z1.data_ptr(), st))
+    torch.cuda.synchronize()
+    xf = img.half().float()
+    r3 = F.conv2d(xf, w3.half().float(), None, 2, 1).permute(0, 2, 3, 1)
+    r1 = F.conv2d(xf, w1.half().float(), None, 2, 0).permute(0, 2, 3, 1)
+    for got, ref in ((z3, r3), (z1, r1)):
+        assert float((got.float() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-3      # one fp16 rounding of an fp32 sum
+    # the autograd path: same forward bits as the kernel above, and the weight gradients of the generic path (they read the same padded image)
+    xp = x8.permute(0, 3, 1, 2)                                           # [B, 8, H, W] NHWC in memory
+    res = {}
+    for on in (True, False):
+        saved, train_ops.stem_train = train_ops.stem_train, on
+        try:
+            n0 = train_ops.stats.get("native_stem_train", 0)
+            a3, a1 = w3.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+            o3, o1 = train_ops.repvgg_convs(xp, a3, a1)
+            assert (train_ops.stats.get("native_stem_train", 0) - n0) == (1 if on and W % 8 == 0 else 0)
+            gg = torch.Generator().manual_seed(7)
+            d3 = torch.randn(o3.shape, generator=gg).to(DEV).half().contiguous(memory_format=torch.channels_last)
+            d1 = torch.randn(o1.shape, generator=gg).to(DEV).half().contiguous(memory_format=torch.channels_last)
+            torch.autograd.backward([o3, o1], [d3, d1])
+            train_ops.join_side(torch.device(DEV))
+            torch.cuda.synchronize()
+            res[on] = (o3.detach().float(), o1.detach().float(), a3.grad.clone(), a1.grad.clone())
+        finally:
+            train_ops.stem_train = saved
+    assert torch.equal(res[True][0].permute(0, 2, 3, 1), z3.float()) and torch.equal(res[True][1].permute(0, 2, 3, 1), z1.float())
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("B,H,W,C,pad,two,reps,dtype", [(2, 80, 80, 40, 24, False, 1, torch.float16), (1, 160, 160, 72, 0, True, 1, torch.float16), (3, 21, 100, 16, 8, True, 4, torch.float16),
                                                        (2, 9, 17, 8, 0, False, 2, torch.float16), (2, 12, 20, 12, 4, True, 1, torch.float32), (1, 160, 160, 128, 0, True, 1, torch.float16),
                                                        (1, 80, 80, 256, 0, False, 1, torch.float16)])

@@ -78,6 +78,10 @@ def main():
                 Bc, H, W, c, k = [int(a[j]) for j in range(4, 9)]
                 nbytes = 2 * Bc * H * W * c * 2
                 note = "%dx%dx%d k%d" % (H, W, c, k)
+            elif nm == "maf_stem_train":
+                Bc, Hi, Wi, co = int(a[2]), int(a[3]), int(a[4]), int(a[7])
+                nbytes = (Bc * Hi * Wi * 8 + 2 * Bc * (Hi // 2) * (Wi // 2) * co) * 2
+                note = "image %dx%d -> 2 x %d channels" % (Hi, Wi, co)
             elif nm == "maf_dw_wgrad31":
                 Bc, H, W, c = [int(a[j]) for j in range(8, 12)]
                 nb = 2 if not int(a[4]) else 3
