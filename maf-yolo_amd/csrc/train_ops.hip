@@ -485,8 +485,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     const int per = 256 / C > 0 ? 256 / C : 1;                       // pixel slabs per block (C <= 256)
     const int c = threadIdx.x % C, slab = threadIdx.x / C;
     float acc = 0.f;
-    if (slab < per)
-        for (long long m = (long long)blockIdx.x * per + slab; m < M; m += (long long)gridDim.x * per) acc += (float)x[m * stride + c];
+    if (slab < per) {
+        // eight independent 2-byte loads in flight per lane (one at a time: 42 us for the 32 x 80 x 80 x 80 class logits, 0.77 TB/s)
+        const long long step = (long long)gridDim.x * per;
+        long long m = (long long)blockIdx.x * per + slab;
+        for (; m + 7 * step < M; m += 8 * step) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(m + u * step) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (float)v[u];
+        }
+        for (; m < M; m += step) acc += (float)x[m * stride + c];
+    }
     s_part[threadIdx.x] = slab < per ? acc : 0.f;
     __syncthreads();
     if (threadIdx.x < C) {
