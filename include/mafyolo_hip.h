@@ -407,6 +407,9 @@ int maf_dw_wgrad(const void* x, int32_t x_stride, const void* dy, int32_t dy_str
  * dense fp16 [B][Hin/2][Win/2][Cout]. */
 int maf_stem_train(const void* img, int32_t img_stride, int32_t B, int32_t Hin, int32_t Win, const float* w3, const float* w1, int32_t Cout,
                    void* z3, void* z1, maf_stream_t stream);
+/* Input staging of the training step: contiguous NCHW images [B][3][H][W] (MAF_F32 or MAF_F16; the reference's `images.float() / 255`, yolov6/core/engine.py:426) -> the
+ * NHWC fp16 buffer with 16-byte pixels that maf_stem_train and the stem's weight-gradient kernels read: out [B][H][W][8], channels 3..7 zero.  One pass. */
+int maf_image_to_nhwc8(const void* x, int32_t dtype, int32_t B, int32_t H, int32_t W, void* out, maf_stream_t stream);
 /* The 3x3 (+ second 3x3) + 1x1 branches of a train-form DilatedReparamBlock (kernel sets 3,3,1 / 5,3,1: yolov6/layers/common.py:2997-3008, 3024-3031) share their
  * input: ONE launch stages the X halo tile once and multiplies it with dYa (and dYb, may be null together with dwb) for the 3x3 gradients [C][9] and — the items of
  * the centre tap row — with dY1 for the 1x1 branch's per-channel scale gradient dw1[C].  Same contract as maf_dw_wgrad otherwise (zeroed fp32 results, `replicas` copies). */

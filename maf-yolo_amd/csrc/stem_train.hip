@@ -143,3 +143,53 @@ extern "C" int maf_stem_train(const void* img, int32_t img_stride, int32_t B, in
     hipLaunchKernelGGL((stem_train_kernel<0>), dim3(maf_cdiv(M, threads)), dim3(threads), sh, static_cast<hipStream_t>(stream), a);
     return maf_check_hip(hipGetLastError(), "stem_train launch");
 }
+
+namespace {
+
+// [B][3][H][W] planar (fp32 or fp16) -> [B][H][W][8] fp16, channels 3..7 zero: one pass (torch's copy_ into the channel slice of the NHWC8 buffer ran as a strided fp32 copy,
+// a cast, a fill and a strided 16-bit copy: 186 us per step of batch 32 at 640 x 640, in front of the first kernel of the forward)
+template <typename TI>
+__global__ __launch_bounds__(256) void image_nhwc8_kernel(const TI* __restrict__ x, half_t* __restrict__ out, long long plane, long long total4) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;           // 4 consecutive pixels of one image
+    if (q >= total4) return;
+    const long long per = plane >> 2, b = q / per, p = (q - b * per) << 2;
+    const TI* src = x + b * 3 * plane + p;
+    float v[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if constexpr (sizeof(TI) == 4) {
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src + c * plane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[c][i] = t[i];
+        } else {
+            typedef half_t h4 __attribute__((ext_vector_type(4)));
+            const h4 t = *reinterpret_cast<const h4*>(src + c * plane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[c][i] = (float)t[i];
+        }
+    }
+    half_t* dst = out + (b * plane + p) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        half8_t o = (half8_t)(half_t)0;
+        o[0] = (half_t)v[0][i]; o[1] = (half_t)v[1][i]; o[2] = (half_t)v[2][i];
+        *reinterpret_cast<half8_t*>(dst + i * 8) = o;
+    }
+}
+
+}  // namespace
+
+// The training step's input staging: a contiguous NCHW image batch [B][3][H][W] (dtype MAF_F32 or MAF_F16; H * W a multiple of 4) into the NHWC8 fp16 buffer the train-form
+// stem reads (maf_stem_train, the stem's weight-gradient kernels): out [B][H][W][8], channels 3..7 zero.
+extern "C" int maf_image_to_nhwc8(const void* x, int32_t dtype, int32_t B, int32_t H, int32_t W, void* out, maf_stream_t stream) {
+    MAF_REQUIRE(x && out && B > 0 && H > 0 && W > 0, "image_to_nhwc8: bad arguments");
+    MAF_REQUIRE(dtype == MAF_F32 || dtype == MAF_F16, "image_to_nhwc8: the image is fp32 or fp16");
+    const long long plane = (long long)H * W;
+    MAF_REQUIRE(plane % 4 == 0, "image_to_nhwc8: H * W must be a multiple of 4");
+    const long long total4 = (long long)B * (plane >> 2);
+    const dim3 g((unsigned)((total4 + 255) / 256)), b(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MAF_F32) hipLaunchKernelGGL((image_nhwc8_kernel<float>), g, b, 0, s, static_cast<const float*>(x), static_cast<half_t*>(out), plane, total4);
+    else hipLaunchKernelGGL((image_nhwc8_kernel<half_t>), g, b, 0, s, static_cast<const half_t*>(x), static_cast<half_t*>(out), plane, total4);
+    return maf_check_hip(hipGetLastError(), "image_to_nhwc8 launch");
+}

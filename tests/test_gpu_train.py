@@ -1080,6 +1080,21 @@ def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, re
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_image_to_nhwc8_matches_the_slice_copy(dtype):
+    """maf_image_to_nhwc8 (the training step's input staging, csrc/stem_train.hip): a contiguous NCHW batch into the NHWC8 fp16 buffer of the train-form stem — bit-identical
+    to torch's `buf[:, :3].copy_(x)` (the reference feeds `images.float() / 255`, yolov6/core/engine.py:426), padding channels zero, through the C-ABI."""
+    from maf_yolo_amd import lib
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(3, 3, 34, 46, generator=g).to(DEV).to(dtype)
+    out = torch.full((3, 34, 46, 8), 7.0, dtype=torch.float16, device=DEV)
+    lib.check(lib.load().maf_image_to_nhwc8(x.data_ptr(), lib.F32 if dtype == torch.float32 else lib.F16, 3, 34, 46, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = torch.zeros(3, 8, 34, 46, dtype=torch.float16, device=DEV).contiguous(memory_format=torch.channels_last)
+    ref[:, :3].copy_(x)
+    assert torch.equal(out, ref.permute(0, 2, 3, 1))
+
+
 @pytest.mark.parametrize("B,H,W,cout", [(2, 64, 96, 24), (1, 128, 64, 32), (3, 32, 40, 48), (1, 6, 8, 8)])
 def test_stem_train_one_launch_matches_the_two_convs(B, H, W, cout):
     """Round 5: the two convs of backbone.0's train-form RepVGGBlock over the image (3x3 stride 2 pad 1 and 1x1 stride 2: yolov6/layers/common.py:199-203, 219-224) as ONE
