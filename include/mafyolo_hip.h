@@ -376,6 +376,15 @@ int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride, int32_t nb
                        float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                        void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
                        float* const* part, int32_t R, const int32_t* phase, int32_t act, maf_stream_t stream);
+/* maf_bn_sum_forward that ALSO accumulates the statistics of the values it stores for the training-mode BatchNorm that normalises `out` next (UniRepLKNetBlock.norm behind
+ * the DilatedReparamBlock, yolov6/layers/common.py:3053-3083): half next_phase of next_part ([2][next_R][2][roundup(C,256)], that BatchNorm's own scratch) += {sum out,
+ * sum out^2}; its call is then the apply pass alone (maf_bn_forward_ex, statistics ready).  next_part = NULL: maf_bn_sum_forward. */
+int maf_bn_sum_forward_stats(const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
+                             const float* const* gamma, const float* const* beta, float eps, float momentum,
+                             float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                             void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
+                             float* const* part, int32_t R, const int32_t* phase, int32_t act,
+                             float* next_part, int32_t next_R, int32_t next_phase, maf_stream_t stream);
 int maf_bn_sum_backward(const void* dy, int32_t dy_stride, const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
                         const float* const* gamma, const float* const* beta, const float* const* save_mean, const float* const* save_rstd,
                         void* const* dz, const int32_t* dz_stride, float* const* dgamma, float* const* dbeta, int32_t accumulate_affine,

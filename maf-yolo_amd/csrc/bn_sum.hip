@@ -29,6 +29,7 @@ struct BsArgs {
     float eps, momentum; float* rmean[MAXB]; float* rvar[MAXB]; long long* counter[MAXB];
     float* bpart; float* bpart_clear; int bclear_n;                  // backward: [R][1 + nb][C] (sum g | sum g xhat_j)
     float* dgamma[MAXB]; float* dbeta[MAXB]; int acc_affine;
+    float* opart; int oR;                                              // forward, optional: the scratch half of the BatchNorm that READS `out` next — [oR][2][C] += {sum out, sum out^2}
 };
 
 template <typename T> struct Vec;
@@ -38,7 +39,11 @@ template <> struct Vec<float> { typedef f32x4_t type; static constexpr int N = 4
 // out = sum_j (z_j * sc_j + sh_j).  Prologue (every workgroup, as bn_apply_kernel): the per-channel constants of every branch from its partial sums
 // (replicas added in double, in order), workgroup 0 publishes save_mean / save_rstd / running statistics / num_batches_tracked; the grid clears the
 // other half of every branch's scratch.
-template <typename T, int NB>
+// STATS: the statistics of the ROUNDED sums it stores, for the training-mode BatchNorm that normalises `out` next (UniRepLKNetBlock.norm behind the DilatedReparamBlock,
+// common.py:3083): that BatchNorm's own statistics pass read `out` once more, one launch per block (16 per step of MAF-YOLO-n).  Lanes of one channel group do not line
+// up across a wave here (the group count is the layer's, not a power of two): every thread parks its sums in LDS — the constants' area, free by then — and one thread
+// per (statistic, channel) adds its column and issues the one global atomic (as bn_stats_kernel's backward form, csrc/bn_act.hip).
+template <typename T, int NB, bool STATS = false>
 __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
@@ -73,6 +78,11 @@ __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
     const int chunk = (a.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * chunk, m1 = min(a.M, m0 + chunk);
     T* op = static_cast<T*>(a.out);
+    float s0[STATS ? N : 1], s1[STATS ? N : 1];                      // (STATS: groups <= 256, one pass of the loop below)
+    if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) s0[q] = s1[q] = 0.f;
+    }
     for (int g0 = 0; g0 < groups; g0 += gpb) {
         const int gi = g0 + threadIdx.x % gpb, pl = threadIdx.x / gpb;
         if (gi >= groups || pl >= plan) continue;
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) u = __builtin_fmaf((float)zv[j][q], sc[j][q], u);
                 ov[q] = (T)(relu ? fmaxf(u, 0.f) : u);
+                if constexpr (STATS) { const float f = (float)ov[q]; s0[q] += f; s1[q] = __builtin_fmaf(f, f, s1[q]); }
             }
             return ov;
         };
@@ -110,6 +121,20 @@ __global__ __launch_bounds__(256) void bn_sum_apply_kernel(const BsArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) zv[j] = *reinterpret_cast<const V*>(static_cast<const T*>(a.z[j]) + (size_t)m * a.zs[j] + gi * N);
             *reinterpret_cast<V*>(op + (size_t)m * a.outs + gi * N) = one(zv);
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();                                              // every thread has read its constants
+        float* ld = cst;                                              // [256][2 N] (the launch sized the LDS for it)
+#pragma unroll
+        for (int q = 0; q < N; ++q) { ld[threadIdx.x * 2 * N + q] = s0[q]; ld[threadIdx.x * 2 * N + N + q] = s1[q]; }      // (idle threads: zeros)
+        __syncthreads();
+        float* dstp = a.opart + (size_t)(blockIdx.x % a.oR) * 2 * a.C;
+        for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+            const int which = i / a.C, c = i - which * a.C, gq = c / N, j = c - gq * N;
+            float t = 0.f;
+            for (int q = 0; q < plan; ++q) t += ld[(q * gpb + gq) * 2 * N + which * N + j];
+            atomicAdd(dstp + (size_t)which * a.C + c, t);
         }
     }
 }
@@ -338,6 +363,18 @@ extern "C" int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride,
                                   float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                                   void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
                                   float* const* part, int32_t R, const int32_t* phase, int32_t act, maf_stream_t stream) {
+    return maf_bn_sum_forward_stats(z, z_stride, nb, M, C, dtype, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, out, out_stride, save_mean, save_rstd,
+                                    part, R, phase, act, nullptr, 0, 0, stream);
+}
+
+// ... and, when next_part is given, half `next_phase` of next_part ([2][next_R][2][roundup(C,256)], the scratch of the BatchNorm that normalises `out` next) += the
+// statistics of the values stored: that BatchNorm's call then is its apply pass alone (maf_bn_forward_ex with statistics ready).
+extern "C" int maf_bn_sum_forward_stats(const void* const* z, const int32_t* z_stride, int32_t nb, int32_t M, int32_t C, int32_t dtype,
+                                        const float* const* gamma, const float* const* beta, float eps, float momentum,
+                                        float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                                        void* out, int32_t out_stride, float* const* save_mean, float* const* save_rstd,
+                                        float* const* part, int32_t R, const int32_t* phase, int32_t act,
+                                        float* next_part, int32_t next_R, int32_t next_phase, maf_stream_t stream) {
     if (int rc = check(nb, M, C, dtype, R)) return rc;
     MAF_REQUIRE(act == MAF_ACT_NONE || act == MAF_ACT_RELU, "bn_sum: act must be none or relu");
     MAF_REQUIRE(z && z_stride && gamma && beta && out && save_mean && save_rstd && part && phase, "bn_sum_forward: null argument");
@@ -357,10 +394,17 @@ extern "C" int maf_bn_sum_forward(const void* const* z, const int32_t* z_stride,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ga = apply_grid(M, C, dtype);
-    const size_t lds = (size_t)nb * 2 * C * sizeof(float);
-#define MAF_BS_FWD(TT, NBV) hipLaunchKernelGGL((bn_sum_apply_kernel<TT, NBV>), dim3(ga), dim3(256), lds, s, a)
-    if (dtype == MAF_F16) { if (nb == 2) MAF_BS_FWD(half_t, 2); else if (nb == 3) MAF_BS_FWD(half_t, 3); else MAF_BS_FWD(half_t, 4); }
-    else { if (nb == 2) MAF_BS_FWD(float, 2); else if (nb == 3) MAF_BS_FWD(float, 3); else MAF_BS_FWD(float, 4); }
+    size_t lds = (size_t)nb * 2 * C * sizeof(float);
+    if (next_part) {
+        MAF_REQUIRE(next_R >= 1 && next_R <= 64 && (next_phase == 0 || next_phase == 1) && C / N <= 256, "bn_sum_forward: next_part = [2][next_R][2][roundup(C,256)], phase 0 / 1, C / 8 <= 256");
+        a.oR = replicas(C, next_R);
+        a.opart = next_part + (size_t)next_phase * next_R * 2 * ((C + 255) / 256 * 256);
+        const size_t park = (size_t)256 * 2 * N * sizeof(float);
+        if (lds < park) lds = park;
+    }
+#define MAF_BS_FWD(TT, NBV) { if (next_part) hipLaunchKernelGGL((bn_sum_apply_kernel<TT, NBV, true>), dim3(ga), dim3(256), lds, s, a); else hipLaunchKernelGGL((bn_sum_apply_kernel<TT, NBV, false>), dim3(ga), dim3(256), lds, s, a); }
+    if (dtype == MAF_F16) { if (nb == 2) MAF_BS_FWD(half_t, 2) else if (nb == 3) MAF_BS_FWD(half_t, 3) else MAF_BS_FWD(half_t, 4) }
+    else { if (nb == 2) MAF_BS_FWD(float, 2) else if (nb == 3) MAF_BS_FWD(float, 3) else MAF_BS_FWD(float, 4) }
 #undef MAF_BS_FWD
     return maf_check_hip(hipGetLastError(), "bn_sum_forward launch");
 }

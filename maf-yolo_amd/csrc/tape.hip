@@ -49,6 +49,7 @@ const Entry kEntries[] = {
     MAF_TAPE_ENTRY(maf_bn_backward_acc),
     MAF_TAPE_ENTRY(maf_bn_stats),
     MAF_TAPE_ENTRY(maf_bn_sum_forward),
+    MAF_TAPE_ENTRY(maf_bn_sum_forward_stats),
     MAF_TAPE_ENTRY(maf_bn_sum_backward),
     MAF_TAPE_ENTRY(maf_dw_branches),
     MAF_TAPE_ENTRY(maf_dw_branches_stats),

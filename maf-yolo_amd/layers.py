@@ -129,14 +129,15 @@ class DilatedReparamBlock(nn.Module):
             setattr(self, "dil_conv_k%d_1" % kk, nn.Conv2d(c, c, kk, 1, kk // 2, groups=c, bias=False))
             setattr(self, "dil_bn_k%d_1" % kk, _bn(c))
 
-    def forward(self, x):
+    def forward(self, x, next_bn=None):
         # every branch in ONE launch (csrc/dw_branches.hip: x staged once, the 1 x 1 scale branch rides along; their data gradients summed in one launch
         # too), which also accumulates every branch's BatchNorm statistics in its epilogue; the BatchNorms of all branches are summed by ONE apply pass
         # (csrc/bn_sum.hip; backward: one statistics + one apply launch for all of them)
         names = ["lk_origin"] + ["dil_conv_k%d_1" % kk for kk in self.kernel_sizes]
         bns = [self.origin_bn] + [getattr(self, "dil_bn_k%d_1" % kk) for kk in self.kernel_sizes]
         zz, pre = train_ops.dw_branches(x, [getattr(self, n_).weight for n_ in names], bns)
-        return train_ops.bn_sum(zz, bns, pre)                                                           # origin_bn(z_0) + sum_j dil_bn_j(z_j)
+        # (next_bn: the BatchNorm behind the block — UniRepLKNetBlock.norm —, whose batch statistics the sum's apply pass accumulates: returns (sum, pre_stats) then)
+        return train_ops.bn_sum(zz, bns, pre, next_bn=next_bn)                                        # origin_bn(z_0) + sum_j dil_bn_j(z_j)
 
     def fused(self):
         """merge_dilated_branches (common.py:3033-3051): centre-pad each small kernel to k x k and sum."""
@@ -159,6 +160,9 @@ class UniRepLKNetBlock(nn.Module):
         self.norm = _bn(c)
 
     def forward(self, x, act=None):
+        if x.is_cuda and self.norm.training:
+            y, pre = self.dwconv(x, next_bn=self.norm)                          # the norm's statistics out of the branch sum's apply pass (csrc/bn_sum.hip)
+            return train_ops.bn_act(y, self.norm, act, pre_stats=pre)
         return train_ops.bn_act(self.dwconv(x), self.norm, act)               # `act`: the SiLU of DepthBottleneckUni fused into the norm
 
     def fused(self):

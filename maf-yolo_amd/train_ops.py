@@ -1786,7 +1786,7 @@ class _BNSum(torch.autograd.Function):
         B, c, H, W = x0.shape
         dt = _DT[x0.dtype]
         dev = x0.device
-        eps, momentum, per, act, dst = cfg
+        eps, momentum, per, act, dst, nxt = cfg                                 # nxt: (scratch, phase) of the BatchNorm that normalises the sum next — this pass accumulates its statistics — or None
         L = lib.load()
         M_ = B * H * W
         for (z, zst), (rm, rv, cnt, part, phase, need) in zip(zs, per):
@@ -1805,7 +1805,10 @@ class _BNSum(torch.autograd.Function):
                 out.data_ptr(), out.stride()[3], _PTR4(*[sp + 8 * c * j for j in range(nb)]), _PTR4(*[sp + 8 * c * j + 4 * c for j in range(nb)]),
                 _PTR4(*[p[3].data_ptr() for p in per]), _BN_REPLICAS, _phase_array([p[4] for p in per]), act, _stream(dev))
         with _prof("bn_sum_forward", (nb + 1) * M_ * c * x0.element_size(), dev, (B, H, W, c, nb)):
-            lib.check(L.maf_bn_sum_forward(*args))
+            if nxt is None:
+                lib.check(L.maf_bn_sum_forward(*args))
+            else:
+                lib.check(L.maf_bn_sum_forward_stats(*args[:-1], nxt[0].data_ptr(), _BN_REPLICAS, nxt[1], args[-1]))
         ctx.save_for_backward(stat, *[z for z, _ in zs], *g32, *b32)
         ctx.nb, ctx.act = nb, act
         ctx.affine = list(zip(gammas, betas)) if all(isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter) for g, b in zip(gammas, betas)) else None
@@ -1855,10 +1858,15 @@ class _BNSum(torch.autograd.Function):
 bn_sum_merged = os.environ.get("MAF_BN_SUM", "1") != "0"               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
 
 
-def bn_sum(zs, bns, pre_stats=None, act=None, out=None):
+bn_sum_next_stats = os.environ.get("MAF_BN_SUM_STATS", "1") != "0"       # A/B switch: the sum's apply pass accumulates the statistics of the BatchNorm behind it
+
+
+def bn_sum(zs, bns, pre_stats=None, act=None, out=None, next_bn=None):
     """act(sum_j bns[j](zs[j])): the branches of a train-form DilatedReparamBlock (act None) or of a RepVGGBlock (act "relu", common.py:224).  CUDA + training mode: csrc/bn_sum.hip (one apply pass forward,
     statistics + apply for all branches backward); otherwise — and for anything the kernel does not take — the chain of bn_act calls with `residual`.
-    `pre_stats[j]`: what dw_branches returned for branch j (its statistics are already accumulated) or None."""
+    `pre_stats[j]`: what dw_branches returned for branch j (its statistics are already accumulated) or None.
+    `next_bn`: the BatchNorm2d that normalises the result next (UniRepLKNetBlock.norm): returns (result, pre_stats for bn_act(result, next_bn, ...)) — the apply pass has
+    accumulated that BatchNorm's batch statistics (csrc/bn_sum.hip, STATS form) — or (result, None) where it cannot."""
     nb = len(zs)
     pre = list(pre_stats) if pre_stats is not None else [None] * nb
     x = zs[0]
@@ -1873,14 +1881,20 @@ def bn_sum(zs, bns, pre_stats=None, act=None, out=None):
         y = bn_act(zs[0], bns[0], pre_stats=pre[0])
         for j in range(1, nb):
             y = bn_act(zs[j], bns[j], act if j == nb - 1 else None, residual=y, pre_stats=pre[j], out=out if j == nb - 1 else None)
-        return y
+        return y if next_bn is None else (y, None)
     if out is not None and not (out.shape == x.shape and out.dtype == x.dtype and out.device == x.device and nhwc(out)[0] is out):
         raise lib.MafError("bn_sum: out= must be an NHWC (channel-slice) view of the branches' shape and dtype")
     per = []
     for bn, st in zip(bns, pre):
         part, phase = st if st is not None else bn_own_scratch(bn, x.device, x.shape[1])
         per.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, part, phase, st is None))
-    return _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act], out), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    nxt = None
+    if (next_bn is not None and bn_sum_next_stats and next_bn.training and next_bn.affine and next_bn.track_running_stats and next_bn.momentum is not None
+            and x.shape[1] // mult <= 256):
+        nxt = bn_own_scratch(next_bn, x.device, x.shape[1])
+        stats["bn_sum_next_stats"] = stats.get("bn_sum_next_stats", 0) + 1
+    y = _BNSum.apply(nb, (bns[0].eps, bns[0].momentum, per, _ACT[act], out, nxt), *zs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    return y if next_bn is None else (y, nxt)
 
 
 @_laned

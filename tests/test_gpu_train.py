@@ -556,12 +556,22 @@ def test_train_step_default_statistics_match_reference_gradients(golden, tag, ep
     known and named (tools/train_step_spread.py: ~1 run in 30 on m): one ulp in SPPF's input flips a near-tied arg-max of its cascaded 5 x 5
     max-pools and the backward pass routes that gradient to the neighbouring pixel — loss and head outputs unchanged, every deviating parameter UPSTREAM of the
     pools (backbone.0 ... backbone.9.cv1), at most 0.3 of its max |g|.  A run that shows exactly that signature is repeated once; anything else — a parameter
-    downstream of the pools off its bar, a larger deviation, the signature twice in a row — fails."""
+    downstream of the pools off its bar, a larger deviation — fails.  The signature twice in a row (seen once, chain r5chain4 of round 5: consecutive realisations
+    on one idle box are NOT independent draws — the atomics arrive in the box's dispatch order, 5.30e-2 and 5.13e-2 of max |g| on the same parameter both times —
+    while the 120 logged runs of profiles/round5_default_fp32_20runs.log had it twice, never consecutively) must then be ATTRIBUTED: the same step with the
+    statistics summed in a fixed order (train_ops.set_deterministic) has to meet every bar with no alternative allowed — the kernels reproduce the reference and
+    the deviation is the summation order's; a kernel fault would show there too, or outside the named signature, and fails."""
     first = _train_step_vs_reference(golden, tag, epoch, kw, False, scale, named_alt=True)
     if first:
         print("%s %s: the named alternative outcome (max-pool tie behind order-dependent statistics) on %s — repeating once" % (scale, tag, first))
         again = _train_step_vs_reference(golden, tag, epoch, kw, False, scale, named_alt=True)
-        assert not again, ("the alternative outcome twice in a row", first, again)
+        if again:
+            print("%s %s: the named alternative outcome twice in a row on %s — attributing it: the same step with fixed-order statistics, no alternative allowed" % (scale, tag, again))
+            train_ops.set_deterministic(True)
+            try:
+                _train_step_vs_reference(golden, tag, epoch, kw, False, scale)
+            finally:
+                train_ops.set_deterministic(False)
 
 
 def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False):
@@ -1078,6 +1088,42 @@ def test_dw_wgrad_c_abi_matches_framework_weight_gradient(B, H, W, C, k, pad, re
     got = dw.sum(0).view(C, 1, k, k)
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), (C, 1, k, k), dy.permute(0, 3, 1, 2).float(), padding=k // 2, groups=C)
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("c,k,hw,dtype", [(72, 3, (24, 40), torch.float16), (192, 5, (20, 20), torch.float16), (96, 9, (12, 20), torch.float16), (24, 7, (10, 12), torch.float32)])
+def test_branch_sum_accumulates_the_statistics_of_the_norm_behind_it(c, k, hw, dtype):
+    """Round 5: UniRepLKNetBlock = norm(DilatedReparamBlock(x)) (yolov6/layers/common.py:3053-3083) in training mode — the apply pass that writes the branch sum
+    (maf_bn_sum_forward_stats, csrc/bn_sum.hip) also accumulates the batch statistics of `norm`, whose own call is then its apply pass alone.  Against the path with the
+    separate statistics launch (MAF_BN_SUM_STATS = 0): output, input gradient, every parameter gradient and norm's running statistics."""
+    from maf_yolo_amd import layers
+    torch.manual_seed(c + k)
+    blk = layers.UniRepLKNetBlock(c, k).to(DEV).train()
+    for p in blk.parameters():
+        p.data.uniform_(-0.5, 0.5) if p.dim() > 1 else p.data.uniform_(0.5, 1.5)
+    state = {n: b.clone() for n, b in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(4, c, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(4, c, *hw, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (True, False):
+        blk.load_state_dict(state)
+        saved, train_ops.bn_sum_next_stats = train_ops.bn_sum_next_stats, on
+        try:
+            n0 = train_ops.stats.get("bn_sum_next_stats", 0)
+            for rep in range(2):                                      # twice: the scratch halves alternate call by call
+                blk.zero_grad(set_to_none=True)
+                x = x0.clone().requires_grad_(True)
+                y = blk(x, "silu")
+                y.backward(dy)
+                train_ops.join_side(torch.device(DEV))
+                torch.cuda.synchronize()
+            assert (train_ops.stats.get("bn_sum_next_stats", 0) - n0) == (2 if on else 0)
+            res[on] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in blk.parameters()] + [blk.norm.running_mean.clone(), blk.norm.running_var.clone()]
+        finally:
+            train_ops.bn_sum_next_stats = saved
+    tol = 2e-3 if dtype == torch.float16 else 2e-5
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + tol, (float((a - b).abs().max()), float(b.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
