@@ -54,8 +54,15 @@ __device__ __forceinline__ void sdot(float* acc, const u32x4_t& x, const u32x4_t
     for (int d = 0; d < 4; ++d) asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc[d]) : "s"(w[d]), "v"(x[d]));
 }
 
-template <int K, int ACT>
+// NF = 0: every lane stores its own 16-byte pieces (a wave's store instruction touches 64 different lines).  NF = 1 / 2 (filters per input channel;
+// launch-time choice, see maf_launch_dwconv_p2): STAGED stores — the nw waves of a workgroup hold nw ADJACENT channel groups of one tile (channel groups
+// are the fastest unit index and in_groups % nw == 0), so once every wave has finished with its planes the results go through the dead planes
+// ([strip pixel r][wave][strip], 65 slots per row: conflict-free both ways) and leave as nw x 16-byte RUNS per pixel: 16 runs of 64 bytes per store
+// instruction (nw = 4) instead of 64 scattered 16-byte pieces.  The results of a filter pass wait in registers (8 per filter) for the last pass.
+template <int K, int ACT, int NF>
 __global__ __launch_bounds__(512) void dwconv_p2_kernel(const Dp2Args a) {
+    constexpr bool STG = NF > 0;
+    constexpr int NSP = 65;
     constexpr int P = K / 2, E = P & 1, PE = P + E, NP = (K + 1) / 2, NPL = (R + 2 * PE) / 2 + (E ? 0 : 0);
     static_assert(NPL == (E ? P + 3 : P + 2), "pairs per window");
     extern __shared__ __attribute__((aligned(16))) unsigned char p2_raw[];
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(512) void dwconv_p2_kernel(const Dp2Args a) {
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int unit = lid * nw + wv;                                      // one wave = one (image, tile, input channel group); channel groups fastest
-    if (unit >= a.nunits) return;                                        // no barrier below: a wave may leave
+    if (unit >= a.nunits) return;                                        // no barrier below unless STG (then nunits % nw == 0: nobody leaves)
     uint32_t t_ = (uint32_t)unit, q_;
     q_ = fdiv(t_, a.in_groups, a.m_ig); const int cgi = (int)(t_ - q_ * a.in_groups); t_ = q_;
     q_ = fdiv(t_, a.tilesX, a.m_tx); const int tx = (int)(t_ - q_ * a.tilesX); t_ = q_;
@@ -101,8 +108,12 @@ __global__ __launch_bounds__(512) void dwconv_p2_kernel(const Dp2Args a) {
     const uint32_t row_step = (uint32_t)a.PITCH * 16, sub_bytes = (uint32_t)a.sub_slots * 16;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    half8_t hold[STG ? NF : 1][R];
+    int hold_s = 0;
+    lp_static_for<(STG ? NF : 1)>([&](auto fidx) {
+    constexpr int FI = decltype(fidx)::value;
 #pragma unroll 1
-    for (int f = 0; f < a.nf; ++f) {
+    for (int f = FI; f < (STG ? FI + 1 : a.nf); ++f) {
         const int cg = cgi + f * a.in_groups;
         const cvec4_t wp = (cvec4_t)(uintptr_t)(a.w + (size_t)cg * (K * 16 * NP));       // row ky at wp[ky * 4 NP], entry ((h * 2 + set) * NP + m)
         const cf32x4_t bp = (cf32x4_t)(uintptr_t)(a.bias + cg * 8);
@@ -154,6 +165,14 @@ __global__ __launch_bounds__(512) void dwconv_p2_kernel(const Dp2Args a) {
                 });
             }
             const int oy = y0 + y, ox0 = x0 + R * sx;
+            if constexpr (STG) {                                         // (one pass: nstrips <= 64)
+                hold_s = s;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hold[FI][r][j] = (half_t)maf_act<ACT>(acc[r][j]);
+                }
+            } else
             if (!(MAF_KO & 128) && s0 + lane < nstrips && oy < a.H) {
                 half_t* out = a.out + a.out_coff + cg * 8 + ((size_t)((size_t)b * a.H + oy) * a.W + ox0) * a.out_stride;
 #pragma unroll
@@ -167,6 +186,32 @@ __global__ __launch_bounds__(512) void dwconv_p2_kernel(const Dp2Args a) {
                 }
             }
         }
+    }
+    });
+    if constexpr (STG) {
+        half8_t* stg = reinterpret_cast<half8_t*>(p2_raw);               // [R][nw][NSP] 16-byte slots in the workgroup's plane area
+        const int lg = 31 - __builtin_clz((unsigned)nw);                 // nw is a power of two
+        const int cg0 = cgi - wv;                                        // the workgroup's first channel group (cgi % nw == wv)
+        const int npieces = nstrips * R * nw;
+        half_t* obase = a.out + a.out_coff + (size_t)b * a.H * a.W * a.out_stride;
+        lp_static_for<NF>([&](auto fidx) {
+            constexpr int FI = decltype(fidx)::value;
+            __syncthreads();                                             // every wave has left its planes (FI = 0) / read the previous filter's runs back
+            if (lane < nstrips) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) stg[(r * nw + wv) * NSP + hold_s] = hold[FI][r];
+            }
+            __syncthreads();
+            if (!(MAF_KO & 128)) {
+                for (int q = (int)threadIdx.x; q < npieces; q += (int)blockDim.x) {
+                    const int w = q & (nw - 1), pr = q >> lg, r = pr & (R - 1), s = pr >> 2;
+                    const int y = (int)fdiv((uint32_t)s, a.SPR, a.m_spr), sx = s - y * a.SPR;
+                    const int oy = y0 + y, ox = x0 + R * sx + r;
+                    if (oy < a.H && ox < a.W)
+                        *reinterpret_cast<half8_t*>(obase + ((size_t)oy * a.W + ox) * a.out_stride + (size_t)(cg0 + w + FI * a.in_groups) * 8) = stg[(r * nw + w) * NSP + s];
+                }
+            }
+        });
     }
 }
 
@@ -203,24 +248,32 @@ int p2_pitch(int TH, int TW, int K) {
 
 uint32_t magic(int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint32_t)d - 1) / (uint32_t)d) : 0u; }
 
-template <int K, int ACT>
-int launch_p2(const Dp2Args& a, int nw, hipStream_t s) {
+template <int K, int ACT, int NF>
+int launch_p2_nf(const Dp2Args& a, int nw, hipStream_t s) {
     const size_t lds = (size_t)nw * a.rounds * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_p2_kernel<K, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsP2),
+        int rc = maf_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_p2_kernel<K, ACT, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsP2),
                                "hipFuncSetAttribute(dwconv_p2)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv_p2_kernel<K, ACT>), dim3(a.nwg), dim3(64 * nw), lds, s, a);
+    hipLaunchKernelGGL((dwconv_p2_kernel<K, ACT, NF>), dim3(a.nwg), dim3(64 * nw), lds, s, a);
     return maf_check_hip(hipGetLastError(), "dwconv_p2 launch");
+}
+
+template <int K, int ACT>
+int launch_p2(const Dp2Args& a, int nw, bool stage, hipStream_t s) {
+    if (stage) return a.nf == 2 ? launch_p2_nf<K, ACT, 2>(a, nw, s) : launch_p2_nf<K, ACT, 1>(a, nw, s);
+    return launch_p2_nf<K, ACT, 0>(a, nw, s);
 }
 
 }  // namespace
 
 // tile_p = -4: src[0].mode = MAF_SRC_PAIRS; aux[1] = weight pairs (pack.py:pack_dw_pairs); tile_c = tile columns (multiple of 4),
-// tile_k = tile rows * 256 + waves per workgroup (1..8; a wave = 8 input channels of a tile)
+// tile_k = tile rows * 256 + waves per workgroup (1..8; a wave = 8 input channels of a tile) [+ 128: staged stores — the workgroup's waves must then be
+// adjacent channel groups of one tile (2, 4 or 8 waves dividing Cin / 8), a filter pass one round of strips (rows * columns / 4 <= 64) and the planes
+// of a wave hold 4 x 65 slots]
 int maf_launch_dwconv_p2(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "dwconv (pairs): fp16 only");
     const maf_src_t& sr = op->src[0];
@@ -238,22 +291,25 @@ int maf_launch_dwconv_p2(const maf_op_t* op, hipStream_t s) {
     a.B = op->B; a.H = op->H; a.W = op->W; a.C = op->Cout; a.in_groups = op->Cin / 8; a.nf = op->Cout / op->Cin;
     a.in_stride = sr.stride; a.in_coff = sr.coff; a.out_stride = op->out_stride; a.out_coff = op->out_coff;
     a.TW = op->tile_c; a.TH = op->tile_k >> 8;
-    const int nw = op->tile_k & 255;
-    MAF_REQUIRE(a.TW > 0 && a.TW % R == 0 && a.TH > 0 && nw >= 1 && nw <= 8, "dwconv (pairs): tile_c = columns (multiple of 4), tile_k = rows * 256 + waves per workgroup (1..8)");
+    const int nw = op->tile_k & 127;
+    const bool stage = (op->tile_k & 128) != 0;
+    MAF_REQUIRE(a.TW > 0 && a.TW % R == 0 && a.TH > 0 && nw >= 1 && nw <= 8, "dwconv (pairs): tile_c = columns (multiple of 4), tile_k = rows * 256 + waves per workgroup (1..8) [+ 128]");
     a.SPR = a.TW / R;
     a.PITCH = p2_pitch(a.TH, a.TW, k);
     a.sub_slots = (a.TH + k - 1) * a.PITCH;
     a.rounds = maf_cdiv(2 * a.sub_slots, 64);
     MAF_REQUIRE((size_t)nw * a.rounds * 1024 <= kMaxLdsP2, "dwconv (pairs): tile does not fit the LDS");
+    MAF_REQUIRE(!stage || (nw >= 2 && (nw & (nw - 1)) == 0 && a.in_groups % nw == 0 && a.TH * a.SPR <= 64 && a.rounds * 1024 >= R * 65 * 16),
+                "dwconv (pairs, staged stores): 2 / 4 / 8 waves dividing Cin / 8, rows * columns / 4 <= 64, planes of >= 4160 bytes per wave");
     a.tilesX = maf_cdiv(a.W, a.TW); a.tilesY = maf_cdiv(a.H, a.TH);
     a.nunits = a.B * a.tilesY * a.tilesX * a.in_groups;
     a.nwg = maf_cdiv(a.nunits, nw);
     a.m_ig = magic(a.in_groups); a.m_tx = magic(a.tilesX); a.m_ty = magic(a.tilesY); a.m_pitch = magic(a.PITCH); a.m_spr = magic(a.SPR); a.m_sub = magic(a.sub_slots);
     const bool silu = op->act == MAF_ACT_SILU;
     switch (k) {
-        case 3: return silu ? launch_p2<3, MAF_ACT_SILU>(a, nw, s) : launch_p2<3, MAF_ACT_NONE>(a, nw, s);
-        case 5: return silu ? launch_p2<5, MAF_ACT_SILU>(a, nw, s) : launch_p2<5, MAF_ACT_NONE>(a, nw, s);
-        case 7: return silu ? launch_p2<7, MAF_ACT_SILU>(a, nw, s) : launch_p2<7, MAF_ACT_NONE>(a, nw, s);
-        default: return silu ? launch_p2<9, MAF_ACT_SILU>(a, nw, s) : launch_p2<9, MAF_ACT_NONE>(a, nw, s);
+        case 3: return silu ? launch_p2<3, MAF_ACT_SILU>(a, nw, stage, s) : launch_p2<3, MAF_ACT_NONE>(a, nw, stage, s);
+        case 5: return silu ? launch_p2<5, MAF_ACT_SILU>(a, nw, stage, s) : launch_p2<5, MAF_ACT_NONE>(a, nw, stage, s);
+        case 7: return silu ? launch_p2<7, MAF_ACT_SILU>(a, nw, stage, s) : launch_p2<7, MAF_ACT_NONE>(a, nw, stage, s);
+        default: return silu ? launch_p2<9, MAF_ACT_SILU>(a, nw, stage, s) : launch_p2<9, MAF_ACT_NONE>(a, nw, stage, s);
     }
 }

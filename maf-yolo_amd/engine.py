@@ -126,6 +126,9 @@ def sw_pitch(th, tw, k):
     return best
 
 
+_P2_STAGE = os.environ.get("MAF_DW_STAGE", "1") != "0"      # A/B switch of the tuner's staged-store candidates for dwconv_p2 (tile_k + 128)
+
+
 def p2_wave_bytes(th, tw, k):
     """LDS bytes of one wave of dwconv_p2 (two planes of 16-byte pair slots, whole DMA rounds): csrc/dwconv_p2.hip:p2_pitch / maf_launch_dwconv_p2."""
     p_ = k // 2
@@ -840,9 +843,13 @@ class Plan:
                                 plane = p2_wave_bytes(th, tw, o.ksize)
                                 if plane > 20 * 1024:                    # fewer than 8 waves per CU: never the fastest
                                     continue
-                                for nw in (2, 4, 8):
+                                for nw, stg in ((2, 0), (4, 0), (8, 0), (2, 128), (4, 128), (8, 128)):
+                                    # + 128: staged stores (the waves of a workgroup = adjacent channel groups of one tile, results through the dead planes,
+                                    # nw x 16-byte runs per pixel): where the kernel takes that form (csrc/dwconv_p2.hip:maf_launch_dwconv_p2)
+                                    if stg and not ((o.Cin // 8) % nw == 0 and th * (tw // 4) <= 64 and plane >= 4160 and o.Cout <= 2 * o.Cin and _P2_STAGE):
+                                        continue
                                     op = lib.MafOp.from_buffer_copy(o)
-                                    op.tile_p, op.tile_c, op.tile_k = -4, tw, th * 256 + nw
+                                    op.tile_p, op.tile_c, op.tile_k = -4, tw, th * 256 + nw + stg
                                     op.src[0].mode = lib.SRC_PAIRS       # (the NHWC content of the buffer read as pairs: same work)
                                     lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
                                     ts = []
@@ -851,7 +858,7 @@ class Plan:
                                         lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
                                         timer.stop(stream.cuda_stream)
                                         ts.append(timer.elapsed_ms())
-                                    results.append((min(ts), -4, tw, th * 256 + nw))
+                                    results.append((min(ts), -4, tw, th * 256 + nw + stg))
                     if self.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
                         op = lib.MafOp.from_buffer_copy(o)
                         op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
@@ -1041,7 +1048,7 @@ class Plan:
             if o.tile_p == -1:
                 return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -4:
-                return "dwconv_p2_kernel<%d, %d>" % (o.ksize, o.act)
+                return "dwconv_p2_kernel<%d, %d, %d>" % (o.ksize, o.act, (o.Cout // o.Cin) if o.tile_k & 128 else 0)
             if o.tile_p == -3:
                 return "dwconv_sw_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -2:

@@ -550,6 +550,46 @@ def test_dwconv_pixel_pair_variant(k, C_, H, W, th, tw, nw, two):
     assert lib.load().maf_op_launch(C.byref(bad), torch.cuda.current_stream().cuda_stream) != 0      # a pair source with any other variant is refused
 
 
+@pytest.mark.parametrize("k,C_,H,W,th,tw,nw", [(9, 288, 20, 20, 10, 20, 4), (9, 192, 20, 20, 10, 20, 2), (7, 128, 40, 40, 10, 20, 4), (5, 128, 80, 80, 16, 16, 4),
+                                               (5, 128, 80, 80, 16, 16, 8), (5, 64, 33, 16, 16, 16, 4), (7, 64, 21, 26, 8, 16, 4), (3, 32, 18, 40, 8, 32, 2)])
+@pytest.mark.parametrize("two", [False, True])
+def test_dwconv_pixel_pair_staged_stores(k, C_, H, W, th, tw, nw, two):
+    """tile_k + 128 of the pixel-pair kernel (csrc/dwconv_p2.hip, NF > 0): the workgroup's waves are adjacent channel groups of one tile and the results leave
+    through the dead planes as nw x 16-byte runs per pixel.  Same arithmetic as the unstaged form: BIT-identical to it (production tiles of MAF-YOLO-n, tiles
+    hanging over the map both ways, two filters per input channel whose results wait in registers), untouched channels beside the slice stay untouched,
+    and the fp32 reference bar of the other variants; a tile / wave count the form does not take is refused."""
+    g = torch.Generator().manual_seed(900 + k + C_)
+    B, dt = 2, lib.F16
+    cout = 2 * C_ if two else C_
+    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, 1, k, k, generator=g) / k, dt)
+    bias = torch.randn(cout, generator=g)
+    xp = torch.full((B, H, W // 2, (C_ + 16) * 2), 7.0, dtype=torch.float16, device=DEV)
+    xp[..., 16:16 + 2 * C_] = pack.pairs_from_nhwc(_nhwc(x, dt)).reshape(B, H, W // 2, 2 * C_)
+    wpairs = pack.pack_dw_pairs(w).to(DEV)
+    xin = torch.cat([x, x], 1) if two else x
+    for act in (lib.ACT_SILU, lib.ACT_NONE):
+        ref = _act(F.conv2d(xin, w, bias, 1, k // 2, 1, cout), act)
+        outs = []
+        for stg in (128, 0):
+            out = torch.full((B, H, W, cout + 16), 3.0, dtype=torch.float16, device=DEV)
+            op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, act, [(xp, C_, C_ + 16, 8, lib.SRC_PAIRS)], out, cout + 16, 8,
+                          pack.pack_dw(w, dt).to(DEV), bias.to(DEV), -4, tw)
+            op.ksize = k
+            op.tile_k = th * 256 + nw + stg
+            op.aux[1] = wpairs.data_ptr()
+            _launch(op)
+            _check(out[..., 8:8 + cout], ref, dt)
+            assert (out[..., :8] == 3).all() and (out[..., 8 + cout:] == 3).all()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+    bad = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, 0, [(xp, C_, C_ + 16, 8, lib.SRC_PAIRS)], out, cout + 16, 8, pack.pack_dw(w, dt).to(DEV), bias.to(DEV), -4, tw)
+    bad.ksize = k
+    bad.aux[1] = wpairs.data_ptr()
+    bad.tile_k = th * 256 + 3 + 128                                    # three waves: not a power of two
+    assert lib.load().maf_op_launch(C.byref(bad), torch.cuda.current_stream().cuda_stream) != 0
+
+
 @pytest.mark.parametrize("k,C_,H,W", [(7, 72, 21, 27), (9, 40, 20, 20), (5, 64, 33, 16), (3, 24, 16, 40), (9, 192, 9, 11)])
 def test_dwconv_matrix_core_variant(k, C_, H, W):
     """tile_p = -1: depth-wise conv as block-diagonal Toeplitz MFMAs (csrc/dwconv_mfma.hip); slices of wider buffers."""

@@ -1122,8 +1122,18 @@ def test_branch_sum_accumulates_the_statistics_of_the_norm_behind_it(c, k, hw, d
         finally:
             train_ops.bn_sum_next_stats = saved
     tol = 2e-3 if dtype == torch.float16 else 2e-5
-    for a, b in zip(res[True], res[False]):
-        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + tol, (float((a - b).abs().max()), float(b.abs().max()))
+    # The two paths differ in the ORDER norm's statistics are added in (atomics either way): mean / rstd move in their last fp32 bits and a few stored fp16 values flip by an
+    # ulp.  y, dx, the running statistics and the weight gradients see that as such.  The parameter gradients of everything in FRONT of norm are sums over M pixels that
+    # cancel (norm removes the scale and the shift of the branch sum: d loss / d beta_j = 0 in exact arithmetic, |values| ~ 2e-2 here against ~60 for an uncancelled sum),
+    # i.e. both sides are rounding noise of the fp16 dx they sum — std ~ sqrt(M) * 2^-11 per unit of |dx xhat| — and so is their difference (seen: 2.9e-3 in four of six
+    # runs on one box, 2e-4 in the other two).  Their bar carries a quarter of that noise term; in fp32 it vanishes (2^-24).
+    M = x0.shape[0] * hw[0] * hw[1]
+    noise = 0.25 * (M ** 0.5) * (2.0 ** -11 if dtype == torch.float16 else 2.0 ** -24)
+    nparam = len(list(blk.parameters()))
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        is_param_grad = 2 <= i < 2 + nparam
+        bar = tol * float(b.abs().max()) + tol + (noise if is_param_grad else 0.0)
+        assert float((a - b).abs().max()) <= bar, (i, float((a - b).abs().max()), float(b.abs().max()), bar)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
