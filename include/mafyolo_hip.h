@@ -487,6 +487,23 @@ typedef struct maf_ema_desc {
 int maf_ema_update(const maf_ema_desc_t* descs_dev, int32_t n, int32_t nblocks, float decay, float one_minus_decay, maf_stream_t stream);
 int32_t maf_ema_desc_size(void);
 
+/* The optimizer step of the train loop (yolov6/core/engine.py:375-391: `self.scaler.step(self.optimizer)`; optimizer = torch.optim.SGD(momentum, nesterov=True) over
+ * the three groups of yolov6/solver/build.py:12-33) for every parameter in ONE launch over a descriptor table in DEVICE memory: param / grad / buf fp32 (buf = the
+ * momentum buffer, NULL for momentum 0), `total` elements, block0 as in maf_ema_desc_t (1024 elements per block), group = index into the per-group hyper-parameters
+ * (host arrays of ngroups <= MAF_SGD_MAX_GROUPS doubles: what the framework's optimizer holds).  found_inf / grad_scale: the GradScaler's device scalars (NULL = none) —
+ * found_inf == 1 skips the update, grad_scale un-scales the gradients (and they are written back un-scaled), no host round trip.  Per element, in double where the
+ * framework's fused kernel computes in double (each multiply-add one fused operation, as its build contracts them):  g = g / scale;  g += wd * p;  buf = mu * buf + g;
+ * g = nesterov ? g + mu * buf : buf;  p -= lr * g. */
+#define MAF_SGD_MAX_GROUPS 8
+typedef struct maf_sgd_desc {
+    void* param; void* grad; void* buf;
+    int64_t total;
+    int32_t block0, group;
+} maf_sgd_desc_t;
+int maf_sgd_update(const maf_sgd_desc_t* descs_dev, int32_t n, int32_t nblocks, int32_t ngroups, const double* lr, const double* weight_decay, const double* momentum,
+                   const int32_t* nesterov, const float* found_inf, const float* grad_scale, maf_stream_t stream);
+int32_t maf_sgd_desc_size(void);
+
 
 /* dst = [dst +] sum_i src[i] over NHWC views with pixel strides in elements (channel slices of wider buffers are fine): n = 1, accumulate = 0 is a strided copy
  * (a concat input its producer could not store in place: torch.cat of the neck, configs/yaml/MAF-YOLO-n.yaml:16-42), n = 1, accumulate = 1 an in-place add

@@ -114,6 +114,61 @@ __global__ __launch_bounds__(256) void ema_update_kernel(const maf_ema_desc_t* _
         if (i0 + q < e.total) { const float t0 = dst[i0 + q] * d, t1 = src[i0 + q] * omd; dst[i0 + q] = t0 + t1; }
 }
 
+// torch.optim.SGD(nesterov, momentum, weight_decay) of the reference's build_optimizer (yolov6/solver/build.py:23-33) for EVERY parameter of every group in ONE launch over a
+// descriptor table (as ema_update_kernel), under a GradScaler: found_inf == 1 skips the whole update, grad_scale (when given) un-scales the gradient — and the un-scaled value is
+// written back — exactly as the framework's fused implementation does.  The arithmetic follows that implementation operation by operation (the hyper-parameters are DOUBLES
+// there: g / scale, g + wd * p, mu * buf + g, g + mu * buf' with the UNROUNDED buf', p - lr * g are formed in double — every multiply-add as ONE fused operation, which is what the
+// framework's build contracts them to: located with a dump of its outputs, 47 of 200 000 momentum values differed with separate roundings, none with the fused form — and rounded
+// to fp32 once each), so parameters and momentum buffers are bit-identical to it (tests/test_gpu_train.py:test_native_sgd_...).
+struct SgdHyper { double lr[MAF_SGD_MAX_GROUPS], wd[MAF_SGD_MAX_GROUPS], mu[MAF_SGD_MAX_GROUPS]; int nesterov[MAF_SGD_MAX_GROUPS]; };
+
+__global__ __launch_bounds__(256) void sgd_update_kernel(const maf_sgd_desc_t* __restrict__ descs, int n, const SgdHyper h, const float* __restrict__ found_inf, const float* __restrict__ grad_scale) {
+#pragma clang fp contract(off)
+    if (found_inf && *found_inf == 1.f) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                                 // last descriptor whose block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const maf_sgd_desc_t e = descs[lo];
+    float* __restrict__ pp = static_cast<float*>(e.param);
+    float* __restrict__ gp = static_cast<float*>(e.grad);
+    float* __restrict__ bp = static_cast<float*>(e.buf);
+    const double lr = h.lr[e.group], wd = h.wd[e.group], mu = h.mu[e.group];
+    const bool nest = h.nesterov[e.group] != 0, scaled = grad_scale != nullptr;
+    const double scale = scaled ? (double)*grad_scale : 1.0;
+    auto one = [&](float p, float g, float b, float& po, float& go, float& bo) {
+        if (scaled) { g = (float)((double)g / scale); go = g; }
+        if (wd != 0.0) g = (float)__builtin_fma(wd, (double)p, (double)g);
+        if (bp) {
+            const double nb = __builtin_fma(mu, (double)b, (double)g);  // (dampening 0: the reference's default)
+            bo = (float)nb;
+            g = nest ? (float)__builtin_fma(mu, nb, (double)g) : (float)nb;
+        }
+        po = (float)__builtin_fma(-lr, (double)g, (double)p);
+    };
+    const long long i0 = ((long long)(blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= e.total && (((uintptr_t)pp | (uintptr_t)gp | (uintptr_t)bp) & 15) == 0) {
+        f32x4_t p = *reinterpret_cast<const f32x4_t*>(pp + i0), g = *reinterpret_cast<const f32x4_t*>(gp + i0), b = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (bp) b = *reinterpret_cast<const f32x4_t*>(bp + i0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { float po, go = g[q], bo = b[q]; one(p[q], g[q], b[q], po, go, bo); p[q] = po; g[q] = go; b[q] = bo; }
+        *reinterpret_cast<f32x4_t*>(pp + i0) = p;
+        if (scaled) *reinterpret_cast<f32x4_t*>(gp + i0) = g;
+        if (bp) *reinterpret_cast<f32x4_t*>(bp + i0) = b;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < e.total) {
+            float po, go = gp[i0 + q], bo = bp ? bp[i0 + q] : 0.f;
+            one(pp[i0 + q], gp[i0 + q], bo, po, go, bo);
+            pp[i0 + q] = po;
+            if (scaled) gp[i0 + q] = go;
+            if (bp) bp[i0 + q] = bo;
+        }
+}
+
 // Depth-wise weight gradient: dW[c][ky][kx] = sum_{b,y,x} dY[b,y,x,c] * X[b,y+ky-P,x+kx-P,c]   (zero padding).
 // Workgroup = one TH x TW tile of one image x one block of CB channels: the X halo tile and the dY tile are staged in
 // LDS once; the partial sums reach dW with fp32 atomics (dW is zeroed by the caller).
@@ -663,6 +718,21 @@ extern "C" int maf_ema_update(const maf_ema_desc_t* descs_dev, int32_t n, int32_
 }
 
 extern "C" int32_t maf_ema_desc_size(void) { return (int32_t)sizeof(maf_ema_desc_t); }
+
+extern "C" int maf_sgd_update(const maf_sgd_desc_t* descs_dev, int32_t n, int32_t nblocks, int32_t ngroups, const double* lr, const double* weight_decay, const double* momentum,
+                              const int32_t* nesterov, const float* found_inf, const float* grad_scale, maf_stream_t stream) {
+    MAF_REQUIRE(descs_dev && n > 0 && nblocks > 0 && lr && weight_decay && momentum && nesterov, "sgd_update: bad arguments");
+    MAF_REQUIRE(ngroups >= 1 && ngroups <= MAF_SGD_MAX_GROUPS, "sgd_update: 1..8 parameter groups");
+    SgdHyper h;
+    for (int i = 0; i < MAF_SGD_MAX_GROUPS; ++i) {
+        const int j = i < ngroups ? i : 0;
+        h.lr[i] = lr[j]; h.wd[i] = weight_decay[j]; h.mu[i] = momentum[j]; h.nesterov[i] = nesterov[j];
+    }
+    hipLaunchKernelGGL(sgd_update_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), descs_dev, n, h, found_inf, grad_scale);
+    return maf_check_hip(hipGetLastError(), "sgd_update launch");
+}
+
+extern "C" int32_t maf_sgd_desc_size(void) { return (int32_t)sizeof(maf_sgd_desc_t); }
 
 extern "C" int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream) {
     MAF_REQUIRE(w && out && C > 0 && k > 0, "pack_dw: bad arguments");

@@ -13,6 +13,78 @@ import torch
 import torch.nn as nn
 
 ema_one_launch = os.environ.get("MAF_EMA_NATIVE", "1") != "0"       # A/B switch: ModelEMA.update as one launch (csrc/train_ops.hip maf_ema_update)
+sgd_one_launch = os.environ.get("MAF_SGD_NATIVE", "1") != "0"       # A/B switch: the SGD step as one launch (csrc/train_ops.hip maf_sgd_update)
+
+
+class NativeSGD(torch.optim.SGD):
+    """torch.optim.SGD (constructed with fused=True: same state_dict, param_groups, schedulers, GradScaler protocol) whose step is ONE launch over a device
+    descriptor table of every parameter with a gradient (csrc/train_ops.hip:sgd_update_kernel, include/mafyolo_hip.h:maf_sgd_update) instead of the framework's
+    multi-tensor launches (10 per step on MAF-YOLO-n's 3 groups / ~300 tensors, 171 us at the serial tail of the step).  Bit-identical parameters and momentum
+    buffers (the kernel follows the fused implementation operation by operation).  The table is rebuilt when an address in it changes (one pass over the
+    parameter list per step, no device work); anything the kernel does not take — CPU / non-fp32 / sparse / non-contiguous tensors, dampening, maximize, a
+    tensor learning rate, more than 8 groups — goes to the parent's step."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._maf_table = None
+        self._maf_sig = None
+        self.native_steps = 0
+
+    def _maf_entries(self):
+        ents = []
+        for gi, group in enumerate(self.param_groups):
+            if group.get("dampening", 0) != 0 or group.get("maximize", False) or isinstance(group["lr"], torch.Tensor) or group.get("differentiable", False):
+                return None
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                buf = self.state[p].get("momentum_buffer") if group["momentum"] != 0 else None
+                if group["momentum"] != 0 and buf is None:                        # (torch's first step: buf = grad — build_optimizer pre-allocates zero buffers)
+                    buf = self.state[p]["momentum_buffer"] = torch.zeros_like(p)
+                ts = (p, g) + ((buf,) if buf is not None else ())
+                if not all(t.is_cuda and t.dtype == torch.float32 and not t.is_sparse and t.is_contiguous() and t.device == p.device and t.numel() == p.numel() for t in ts):
+                    return None
+                if p.numel():
+                    ents.append((p, g, buf, gi))
+        return ents
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None or not sgd_one_launch or len(self.param_groups) > 8:
+            return super().step(closure)
+        ents = self._maf_entries()
+        if not ents or len({e[0].device for e in ents}) != 1:
+            return super().step(closure)
+        import ctypes as C
+        from . import lib
+        dev = ents[0][0].device
+        sig = tuple((p.data_ptr(), g.data_ptr(), b.data_ptr() if b is not None else 0, gi) for p, g, b, gi in ents)
+        if sig != self._maf_sig:
+            assert C.sizeof(lib.MafSgdDesc) == lib.load().maf_sgd_desc_size()
+            arr = (lib.MafSgdDesc * len(ents))()
+            blk = 0
+            for e, (p, g, b, gi) in zip(arr, ents):
+                e.param, e.grad, e.buf, e.total, e.block0, e.group = p.data_ptr(), g.data_ptr(), (b.data_ptr() if b is not None else None), p.numel(), blk, gi
+                blk += -(-p.numel() // 1024)
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self._maf_table, self._maf_sig = (table, len(ents), blk), sig
+        table, n, nblocks = self._maf_table
+        ng = len(self.param_groups)
+        lr = (C.c_double * ng)(*[float(g_["lr"]) for g_ in self.param_groups])
+        wd = (C.c_double * ng)(*[float(g_["weight_decay"]) for g_ in self.param_groups])
+        mu = (C.c_double * ng)(*[float(g_["momentum"]) for g_ in self.param_groups])
+        nest = (C.c_int32 * ng)(*[1 if g_["nesterov"] else 0 for g_ in self.param_groups])
+        found_inf, grad_scale = getattr(self, "found_inf", None), getattr(self, "grad_scale", None)     # set by GradScaler.step (_step_supports_amp_scaling)
+        for t in (found_inf, grad_scale):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and t.device == dev):
+                return super().step(closure)
+        with torch.cuda.device(dev):
+            lib.check(lib.load().maf_sgd_update(table.data_ptr(), n, nblocks, ng, lr, wd, mu, nest,
+                                                found_inf.data_ptr() if found_inf is not None else None, grad_scale.data_ptr() if grad_scale is not None else None,
+                                                torch.cuda.current_stream(dev).cuda_stream))
+        self.native_steps += 1
+        return None
 
 
 def param_groups(model):
@@ -37,7 +109,7 @@ def build_optimizer(model, lr0=0.01, momentum=0.937, weight_decay=5e-4, optim="S
     if fused is None:
         fused = all(p.is_cuda for p in bn_w + w + b) and len(bn_w + w + b) > 0
     if optim == "SGD":
-        opt = torch.optim.SGD(bn_w, lr=lr0, momentum=momentum, nesterov=True, fused=fused)
+        opt = (NativeSGD if fused else torch.optim.SGD)(bn_w, lr=lr0, momentum=momentum, nesterov=True, fused=fused)
     elif optim == "Adam":
         opt = torch.optim.Adam(bn_w, lr=lr0, betas=(momentum, 0.999), fused=fused)
     else:

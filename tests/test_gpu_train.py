@@ -1136,6 +1136,65 @@ def test_branch_sum_accumulates_the_statistics_of_the_norm_behind_it(c, k, hw, d
         assert float((a - b).abs().max()) <= bar, (i, float((a - b).abs().max()), float(b.abs().max()), bar)
 
 
+def test_native_sgd_step_is_bit_identical_to_the_fused_framework_step():
+    """solver.NativeSGD (one launch over a descriptor table: csrc/train_ops.hip sgd_update_kernel, maf_sgd_update) against torch.optim.SGD(fused=True) — the reference's
+    optimizer (yolov6/solver/build.py:23-33: SGD, momentum, nesterov, three groups, weight decay on one of them) as `scaler.step(optimizer)` drives it
+    (yolov6/core/engine.py:375-391): a skipped step (found_inf = 1), steps with a gradient scale (the un-scaled gradients are written back), a plain step, a
+    learning-rate change between steps, ragged and unaligned tensors, a parameter without a gradient.  Parameters, momentum buffers and gradients: torch.equal."""
+    from maf_yolo_amd import solver
+    g = torch.Generator().manual_seed(77)
+    shapes = [(5,), (17, 3, 3, 3), (4096,), (33, 7), (1,), (1030,), (64, 64)]
+    base = [torch.randn(*sh, generator=g).to(DEV) for sh in shapes]
+    flat = torch.zeros(sum(b.numel() for b in base) + 3, device=DEV)             # gradients as views of one flat bucket at an odd offset (unaligned addresses)
+
+    def make(cls):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = cls(ps[:2], lr=0.013, momentum=0.937, nesterov=True, fused=True)
+        opt.add_param_group({"params": ps[2:5], "weight_decay": 5e-4})
+        opt.add_param_group({"params": ps[5:]})
+        for grp in opt.param_groups:
+            for p_ in grp["params"]:
+                opt.state[p_]["momentum_buffer"] = torch.zeros_like(p_)
+        return ps, opt
+
+    pa, oa = make(solver.NativeSGD)
+    pb, ob = make(torch.optim.SGD)
+    plan = [(1.0, 1024.0), (0.0, 1024.0), (0.0, 3.0), (None, None), (0.0, 65536.0)]
+    for it, (inf, scale) in enumerate(plan):
+        grads = [torch.randn(*sh, generator=g).to(DEV) * (scale or 1.0) for sh in shapes]
+        for ps, opt in ((pa, oa), (pb, ob)):
+            off = 3
+            for i, (p_, gr) in enumerate(zip(ps, grads)):
+                if i == 4 and it == 3:
+                    p_.grad = None                                              # a parameter without a gradient this step: skipped by both
+                    continue
+                if opt is oa and it != 4:                                       # (step 4: separate, aligned gradient tensors — the 16-byte path; the table is rebuilt)
+                    v = flat[off:off + gr.numel()].view_as(gr)
+                    v.copy_(gr)
+                    p_.grad = v
+                    off += gr.numel()
+                else:
+                    p_.grad = gr.clone()
+            if it == 2:
+                for grp in opt.param_groups:
+                    grp["lr"] = 0.0071
+            if inf is not None:
+                opt.found_inf = torch.full((), inf, device=DEV)
+                opt.grad_scale = torch.full((), scale, device=DEV)
+            opt.step()
+            if inf is not None:
+                del opt.found_inf, opt.grad_scale
+        torch.cuda.synchronize()
+        for i, (x_, y_) in enumerate(zip(pa, pb)):
+            assert torch.equal(x_.data, y_.data), (it, i)
+            assert torch.equal(oa.state[x_]["momentum_buffer"], ob.state[y_]["momentum_buffer"]), (it, i)
+            if x_.grad is not None:
+                assert torch.equal(x_.grad, y_.grad), (it, i)
+    assert oa.native_steps == len(plan)
+    # state_dict round trip: the subclass is the framework's optimizer as far as checkpoints go
+    oa.load_state_dict(ob.state_dict())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_image_to_nhwc8_matches_the_slice_copy(dtype):
     """maf_image_to_nhwc8 (the training step's input staging, csrc/stem_train.hip): a contiguous NCHW batch into the NHWC8 fp16 buffer of the train-form stem — bit-identical
