@@ -19,7 +19,7 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", ""))))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if re.search(r"[Ff]used[_]?[Ss]gd|FusedSgd", r[2])]
+    marks = [i for i, r in enumerate(rows) if re.search(r"[Ff]used[_]?[Ss]gd|FusedSgd|sgd_update_kernel", r[2])]
     # one optimizer step may be several launches (parameter groups): merge marks that are close together
     cuts = []
     for i in marks:

@@ -32,7 +32,7 @@ def main():
         q = r.get("Queue_Id", "") or r.get("Stream_Id", "")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], q))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if re.search(r"[Ff]used[_]?[Ss]gd|FusedSgd", r[2])]
+    marks = [i for i, r in enumerate(rows) if re.search(r"[Ff]used[_]?[Ss]gd|FusedSgd|sgd_update_kernel", r[2])]
     cuts = []
     for i in marks:
         if not cuts or rows[i][0] - rows[cuts[-1]][0] > 5_000_000:
