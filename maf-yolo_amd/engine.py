@@ -876,6 +876,10 @@ class Plan:
                     _TUNE_CACHE[sig + ("nhwc",)] = [r_ for r_ in results if r_[1] != -4][0][1:]      # for a plan whose producer cannot store pixel pairs
                     if verbose:
                         print("tune %-32s %dx%d C=%d k=%d: %s" % (self.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d,%d)%.1fus" % (a, b2, c2, t * 1e3) for t, a, b2, c2 in results[:6])))
+                        p2 = [r_ for r_ in results if r_[1] == -4]
+                        if any(r_[3] & 128 for r_ in p2):                # pixel-pair kernel: best tile with plain / staged stores
+                            bu, bs = [r_ for r_ in p2 if not r_[3] & 128][0], [r_ for r_ in p2 if r_[3] & 128][0]
+                            print("     dwconv_p2 stores  plain (%d,%d) %.1fus   staged (%d,%d) %.1fus" % (bu[2], bu[3], bu[0] * 1e3, bs[2], bs[3] - 128, bs[0] * 1e3))
                 prod = self._pairs_producer(i)
                 if best[0] == -4 and prod is None:
                     best = _TUNE_CACHE.get(sig + ("nhwc",), (0, 0, 0))
