@@ -489,7 +489,7 @@ int32_t maf_ema_desc_size(void);
 
 /* The optimizer step of the train loop (yolov6/core/engine.py:375-391: `self.scaler.step(self.optimizer)`; optimizer = torch.optim.SGD(momentum, nesterov=True) over
  * the three groups of yolov6/solver/build.py:12-33) for every parameter in ONE launch over a descriptor table in DEVICE memory: param / grad / buf fp32 (buf = the
- * momentum buffer, NULL for momentum 0), `total` elements, block0 as in maf_ema_desc_t (1024 elements per block), group = index into the per-group hyper-parameters
+ * momentum buffer, NULL for momentum 0), `total` elements, block0 as in the EMA table above — 1024 elements per block, group = index into the per-group hyper-parameters
  * (host arrays of ngroups <= MAF_SGD_MAX_GROUPS doubles: what the framework's optimizer holds).  found_inf / grad_scale: the GradScaler's device scalars (NULL = none) —
  * found_inf == 1 skips the update, grad_scale un-scales the gradients (and they are written back un-scaled), no host round trip.  Per element, in double where the
  * framework's fused kernel computes in double (each multiply-add one fused operation, as its build contracts them):  g = g / scale;  g += wd * p;  buf = mu * buf + g;
