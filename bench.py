@@ -255,7 +255,7 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
         ex = M.GradExchange(model, force_collectives=bool(getattr(args, "rccl1", False)) and dist is not None)
     # build.py:12-33 grouping (BatchNorm weights and biases without decay), lr0 scaled like engine.py: fused SGD keeps the AMP inf check on the device
     opt = M.build_optimizer(model, lr0=0.01 / 64 * batch * world, momentum=0.937, weight_decay=5e-4, fused=not args.no_fused_sgd)
-    scaler = torch.amp.GradScaler("cuda")
+    scaler = M.GradScaler("cuda")                 # torch.amp.GradScaler with the inf check as one native launch (solver.GradScaler; MAF_INF_CHECK_NATIVE=0: the framework's)
     ema = M.ModelEMA(model) if rank == 0 and not args.no_ema else None          # engine.py:67: the main process keeps the weight average
     B = batch
     x = synth.synth_images(B, 640, seed=1 + rank).to(dev)          # engine.py:426: float images / 255

@@ -504,6 +504,17 @@ int maf_sgd_update(const maf_sgd_desc_t* descs_dev, int32_t n, int32_t nblocks, 
                    const int32_t* nesterov, const float* found_inf, const float* grad_scale, maf_stream_t stream);
 int32_t maf_sgd_desc_size(void);
 
+/* The inf check GradScaler.step runs over the optimizer's gradients before the step (yolov6/core/engine.py:375-391) in one launch over a table of the contiguous
+ * fp32 ranges they occupy, in DEVICE memory: ptr, `total` elements, block0 = first block of the range in the flattened grid, 4096 elements per block (ascending;
+ * nblocks = sum of ceil(total / 4096)).  *found_inf (a device float the caller has zeroed) becomes 1 if any element is Inf or NaN. */
+typedef struct maf_range_desc {
+    const void* ptr;
+    int64_t total;
+    int32_t block0, reserved;
+} maf_range_desc_t;
+int maf_nonfinite_check(const maf_range_desc_t* descs_dev, int32_t n, int32_t nblocks, float* found_inf, maf_stream_t stream);
+int32_t maf_range_desc_size(void);
+
 
 /* dst = [dst +] sum_i src[i] over NHWC views with pixel strides in elements (channel slices of wider buffers are fine): n = 1, accumulate = 0 is a strided copy
  * (a concat input its producer could not store in place: torch.cat of the neck, configs/yaml/MAF-YOLO-n.yaml:16-42), n = 1, accumulate = 1 an in-place add

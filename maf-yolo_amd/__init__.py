@@ -10,7 +10,7 @@ from .checkpoint import load_checkpoint, reference_state_dict  # noqa: F401
 from .loss import ComputeLoss, task_aligned_assign  # noqa: F401
 from .streams import concurrent_streams  # noqa: F401
 from .eval_loop import EvalLoop  # noqa: F401
-from .solver import build_optimizer, ModelEMA  # noqa: F401
+from .solver import build_optimizer, ModelEMA, GradScaler  # noqa: F401
 from .exchange import GradExchange  # noqa: F401
 from .layers import RepVGGBlock, UniRepLKNetBlock  # noqa: F401  (isinstance loops of evaler.py:101-109 stay harmless)
 

@@ -114,6 +114,32 @@ __global__ __launch_bounds__(256) void ema_update_kernel(const maf_ema_desc_t* _
         if (i0 + q < e.total) { const float t0 = dst[i0 + q] * d, t1 = src[i0 + q] * omd; dst[i0 + q] = t0 + t1; }
 }
 
+// GradScaler's inf check (yolov6/core/engine.py:375-391: `self.scaler.step(self.optimizer)` looks for non-finite gradients before the step) over the CONTIGUOUS ranges the
+// gradients occupy (the flat buckets of the gradient exchange: a handful of ranges for ~300 tensors) in one launch: *found_inf = 1 if any element is Inf / NaN.  The
+// framework's multi-tensor form takes four launches (64 us) for MAF-YOLO-n.
+__global__ __launch_bounds__(256) void nonfinite_check_kernel(const maf_range_desc_t* __restrict__ descs, int n, float* __restrict__ found_inf) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                                 // last descriptor whose block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const maf_range_desc_t e = descs[lo];
+    const float* __restrict__ src = static_cast<const float*>(e.ptr);
+    const long long base = (long long)(blockIdx.x - e.block0) * 4096;           // 4096 elements per block: 4 x 16 bytes per thread
+    bool bad = false;
+    if (base + 4096 <= e.total && ((uintptr_t)src & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + base + (r * 256 + threadIdx.x) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bad |= !(fabsf(v[q]) <= 3.402823466e+38f);     // false for Inf and NaN
+        }
+    } else {
+        for (long long i = base + threadIdx.x; i < base + 4096 && i < e.total; i += 256) bad |= !(fabsf(src[i]) <= 3.402823466e+38f);
+    }
+    if (bad) *found_inf = 1.f;                                        // (every writer stores the same value)
+}
+
 // torch.optim.SGD(nesterov, momentum, weight_decay) of the reference's build_optimizer (yolov6/solver/build.py:23-33) for EVERY parameter of every group in ONE launch over a
 // descriptor table (as ema_update_kernel), under a GradScaler: found_inf == 1 skips the whole update, grad_scale (when given) un-scales the gradient — and the un-scaled value is
 // written back — exactly as the framework's fused implementation does.  The arithmetic follows that implementation operation by operation (the hyper-parameters are DOUBLES
@@ -733,6 +759,14 @@ extern "C" int maf_sgd_update(const maf_sgd_desc_t* descs_dev, int32_t n, int32_
 }
 
 extern "C" int32_t maf_sgd_desc_size(void) { return (int32_t)sizeof(maf_sgd_desc_t); }
+
+extern "C" int maf_nonfinite_check(const maf_range_desc_t* descs_dev, int32_t n, int32_t nblocks, float* found_inf, maf_stream_t stream) {
+    MAF_REQUIRE(descs_dev && n > 0 && nblocks > 0 && found_inf, "nonfinite_check: bad arguments");
+    hipLaunchKernelGGL(nonfinite_check_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), descs_dev, n, found_inf);
+    return maf_check_hip(hipGetLastError(), "nonfinite_check launch");
+}
+
+extern "C" int32_t maf_range_desc_size(void) { return (int32_t)sizeof(maf_range_desc_t); }
 
 extern "C" int maf_pack_dw(const float* w, int32_t C, int32_t k, int32_t flip, int32_t dtype, void* out, maf_stream_t stream) {
     MAF_REQUIRE(w && out && C > 0 && k > 0, "pack_dw: bad arguments");

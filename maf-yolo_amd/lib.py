@@ -37,6 +37,11 @@ class MafSgdDesc(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("buf", C.c_void_p), ("total", C.c_int64), ("block0", C.c_int32), ("group", C.c_int32)]
 
 
+class MafRangeDesc(C.Structure):
+    """maf_range_desc_t (include/mafyolo_hip.h): one contiguous fp32 range of maf_nonfinite_check."""
+    _fields_ = [("ptr", C.c_void_p), ("total", C.c_int64), ("block0", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Phase(int):
     """The `phase` argument of a BatchNorm scratch (csrc/bn_act.hip: which half this call accumulates into) as a step tape sees it: a word that alternates
     from replay to replay (tape.py registers a toggle for the argument slot it is passed in)."""
@@ -68,7 +73,7 @@ class MafOp(C.Structure):
 
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
-           "maf_engine_run", "maf_engine_run_filtered", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_ex", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_pack_batch", "maf_pack_desc_size", "maf_ema_update", "maf_ema_desc_size", "maf_sgd_update", "maf_sgd_desc_size", "maf_maxpool_forward", "maf_maxpool_backward", "maf_upsample2x_forward", "maf_upsample2x_backward", "maf_zero", "maf_grad_fold", "maf_add_sub2", "maf_colsum", "maf_dw_wgrad", "maf_dw_wgrad31", "maf_stem_train", "maf_image_to_nhwc8", "maf_bottleneck_record_bytes", "maf_bottleneck_tail_record_bytes", "maf_bottleneck_tail_supported", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_mprep_lds_record_bytes", "maf_mprep_wreg_record_bytes", "maf_conv3s2_wreg_record_bytes", "maf_conv1x1_stats_supported", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_bn_backward_acc", "maf_set_deterministic", "maf_dw_branches", "maf_dw_branches_stats", "maf_bn_forward_ex", "maf_bn_replicas", "maf_bn_stats", "maf_bn_sum_forward", "maf_bn_sum_forward_stats", "maf_bn_sum_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
+           "maf_engine_run", "maf_engine_run_filtered", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_ex", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_pack_batch", "maf_pack_desc_size", "maf_ema_update", "maf_ema_desc_size", "maf_sgd_update", "maf_sgd_desc_size", "maf_nonfinite_check", "maf_range_desc_size", "maf_maxpool_forward", "maf_maxpool_backward", "maf_upsample2x_forward", "maf_upsample2x_backward", "maf_zero", "maf_grad_fold", "maf_add_sub2", "maf_colsum", "maf_dw_wgrad", "maf_dw_wgrad31", "maf_stem_train", "maf_image_to_nhwc8", "maf_bottleneck_record_bytes", "maf_bottleneck_tail_record_bytes", "maf_bottleneck_tail_supported", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_mprep_lds_record_bytes", "maf_mprep_wreg_record_bytes", "maf_conv3s2_wreg_record_bytes", "maf_conv1x1_stats_supported", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_bn_backward_acc", "maf_set_deterministic", "maf_dw_branches", "maf_dw_branches_stats", "maf_bn_forward_ex", "maf_bn_replicas", "maf_bn_stats", "maf_bn_sum_forward", "maf_bn_sum_forward_stats", "maf_bn_sum_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
            "maf_nhwc_sum", "maf_stream_fork", "maf_stream_join", "maf_tape_fn_id", "maf_tape_fn_nargs", "maf_tape_rec_size", "maf_tape_run", "maf_tape_toggle",
            "maf_stream_create_masked", "maf_stream_destroy",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
@@ -178,6 +183,8 @@ def load():
     lib.maf_sgd_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                    C.c_void_p, C.c_void_p, C.c_void_p]
     lib.maf_sgd_desc_size.argtypes = []
+    lib.maf_nonfinite_check.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.maf_range_desc_size.argtypes = []
     lib.maf_zero.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     lib.maf_grad_fold.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.maf_upsample2x_forward.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_void_p]
@@ -189,6 +196,7 @@ def load():
     lib.maf_pack_desc_size.restype = C.c_int32
     lib.maf_ema_desc_size.restype = C.c_int32
     lib.maf_sgd_desc_size.restype = C.c_int32
+    lib.maf_range_desc_size.restype = C.c_int32
     lib.maf_dw_wgrad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.maf_image_to_nhwc8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.maf_stem_train.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -16,6 +16,72 @@ ema_one_launch = os.environ.get("MAF_EMA_NATIVE", "1") != "0"       # A/B switch
 sgd_one_launch = os.environ.get("MAF_SGD_NATIVE", "1") != "0"       # A/B switch: the SGD step as one launch (csrc/train_ops.hip maf_sgd_update)
 
 
+inf_check_one_launch = os.environ.get("MAF_INF_CHECK_NATIVE", "1") != "0"       # A/B switch: GradScaler's inf check as one launch (maf_nonfinite_check)
+
+
+class GradScaler(torch.amp.GradScaler):
+    """torch.amp.GradScaler (the reference's `amp.GradScaler`, yolov6/core/engine.py:84, :375-391) whose inf check in front of an optimizer step that takes the scale itself
+    (`_step_supports_amp_scaling`: the fused / native SGD) is ONE launch over the contiguous ranges the gradients occupy (csrc/train_ops.hip:nonfinite_check_kernel,
+    maf_nonfinite_check) — the flat buckets of a GradExchange are a handful of ranges for ~300 tensors — instead of the framework's multi-tensor launches (four per step,
+    64 us, on MAF-YOLO-n).  Same `found_inf` (0 / 1) on the device, same scale update; gradients that are not dense fp32 CUDA tensors on the scale's device, or an explicit
+    `unscale_()`, take the parent's path."""
+
+    def __init__(self, device="cuda", **kwargs):
+        super().__init__(device, **kwargs)
+        self._maf_ranges = {}
+
+    def _maf_table(self, optimizer, dev):
+        grads = []
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (g.is_cuda and g.device == dev and g.dtype == torch.float32 and not g.is_sparse and g.is_contiguous()):
+                    return None
+                if g.numel():
+                    grads.append((g.data_ptr(), g.numel()))
+        if not grads:
+            return None
+        sig = tuple(grads)
+        ent = self._maf_ranges.get(id(optimizer))
+        if ent is None or ent[0] != sig:
+            import ctypes as C
+            from . import lib
+            assert C.sizeof(lib.MafRangeDesc) == lib.load().maf_range_desc_size()
+            merged = []
+            for ptr, n in sorted(set(grads)):
+                if merged and merged[-1][0] + 4 * merged[-1][1] == ptr:
+                    merged[-1][1] += n
+                elif merged and ptr < merged[-1][0] + 4 * merged[-1][1]:          # overlapping views: leave those to the framework
+                    return None
+                else:
+                    merged.append([ptr, n])
+            arr = (lib.MafRangeDesc * len(merged))()
+            blk = 0
+            for e, (ptr, n) in zip(arr, merged):
+                e.ptr, e.total, e.block0 = ptr, n, blk
+                blk += -(-n // 4096)
+            ent = self._maf_ranges[id(optimizer)] = (sig, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), len(merged), blk)
+        return ent[1:]
+
+    def _check_inf_per_device(self, optimizer):
+        if not inf_check_one_launch:
+            return super()._check_inf_per_device(optimizer)
+        _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
+        dev = _scale.device
+        tab = self._maf_table(optimizer, dev) if dev.type == "cuda" else None
+        if tab is None:
+            return super()._check_inf_per_device(optimizer)
+        from . import lib
+        table, n, nblocks = tab
+        found_inf = torch.full((), 0.0, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            lib.check(lib.load().maf_nonfinite_check(table.data_ptr(), n, nblocks, found_inf.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = {dev: found_inf}
+        return self._per_optimizer_states[id(optimizer)]["found_inf_per_device"]
+
+
 class NativeSGD(torch.optim.SGD):
     """torch.optim.SGD (constructed with fused=True: same state_dict, param_groups, schedulers, GradScaler protocol) whose step is ONE launch over a device
     descriptor table of every parameter with a gradient (csrc/train_ops.hip:sgd_update_kernel, include/mafyolo_hip.h:maf_sgd_update) instead of the framework's

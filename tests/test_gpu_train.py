@@ -1136,6 +1136,55 @@ def test_branch_sum_accumulates_the_statistics_of_the_norm_behind_it(c, k, hw, d
         assert float((a - b).abs().max()) <= bar, (i, float((a - b).abs().max()), float(b.abs().max()), bar)
 
 
+def test_native_inf_check_and_scaler_follow_the_framework_scaler():
+    """solver.GradScaler (inf check = one launch over the contiguous gradient ranges, maf_nonfinite_check) against torch.amp.GradScaler, both driving the native SGD as
+    the reference's loop does (yolov6/core/engine.py:375-391: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()): an Inf and a NaN at the first /
+    last element of a range and in the ragged tail of an unaligned view, finite steps between them; found_inf, the scale after every update (back-off and growth),
+    parameters and momentum buffers must be identical, and the native check must really have run (ranges merged from views of one flat buffer + a separate tensor)."""
+    from maf_yolo_amd import solver
+    g = torch.Generator().manual_seed(5)
+    shapes = [(5000,), (33, 7), (1,), (4099,)]
+    base = [torch.randn(*sh, generator=g).to(DEV) for sh in shapes]
+    flat = torch.zeros(sum(b.numel() for b in base[:3]) + 1, device=DEV)
+
+    def make(scaler_cls):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = solver.NativeSGD(ps[:2], lr=0.01, momentum=0.9, nesterov=True, fused=True)
+        opt.add_param_group({"params": ps[2:], "weight_decay": 5e-4})
+        return ps, opt, scaler_cls("cuda", init_scale=1024.0, growth_interval=2)
+
+    pa, oa, sa = make(solver.GradScaler)
+    pb, ob, sb = make(torch.amp.GradScaler)
+    poison = {1: (0, 0, float("inf")), 3: (3, 4098, float("nan")), 4: (1, 230, float("-inf")), 6: (0, 4999, float("nan"))}     # step -> (tensor, element, value)
+    for it in range(8):
+        grads = [torch.randn(*sh, generator=g).to(DEV) for sh in shapes]
+        if it in poison:
+            t_, e_, v_ = poison[it]
+            grads[t_].view(-1)[e_] = v_
+        for ps, opt, sc in ((pa, oa, sa), (pb, ob, sb)):
+            sc.scale(torch.zeros((), device=DEV))                               # (initialises the scale tensors as scaler.scale(loss) does)
+            off = 1
+            for i, (p_, gr) in enumerate(zip(ps, grads)):
+                if i < 3:
+                    v = flat[off:off + gr.numel()].view_as(gr) if opt is oa else gr.clone()
+                    if opt is oa:
+                        v.copy_(gr)
+                    p_.grad = v
+                    off += gr.numel()
+                else:
+                    p_.grad = gr.clone()
+            sc.step(opt)
+            sc.update()
+        torch.cuda.synchronize()
+        assert float(sa.get_scale()) == float(sb.get_scale()), (it, sa.get_scale(), sb.get_scale())
+        for i, (x_, y_) in enumerate(zip(pa, pb)):
+            assert torch.equal(x_.data, y_.data), (it, i)
+            assert torch.equal(oa.state[x_]["momentum_buffer"], ob.state[y_]["momentum_buffer"]), (it, i)
+    ent = sa._maf_ranges[id(oa)]
+    assert ent[2] == 2                                                          # three views of the flat buffer merged into one range + the separate tensor
+    assert float(sa.get_scale()) != 1024.0
+
+
 def test_native_sgd_step_is_bit_identical_to_the_fused_framework_step():
     """solver.NativeSGD (one launch over a descriptor table: csrc/train_ops.hip sgd_update_kernel, maf_sgd_update) against torch.optim.SGD(fused=True) — the reference's
     optimizer (yolov6/solver/build.py:23-33: SGD, momentum, nesterov, three groups, weight decay on one of them) as `scaler.step(optimizer)` drives it
