@@ -20,7 +20,7 @@ inf_check_one_launch = os.environ.get("MAF_INF_CHECK_NATIVE", "1") != "0"       
 
 
 class GradScaler(torch.amp.GradScaler):
-    """torch.amp.GradScaler (the reference's `amp.GradScaler`, yolov6/core/engine.py:84, :375-391) whose inf check in front of an optimizer step that takes the scale itself
+    """torch.amp.GradScaler (the reference's `amp.GradScaler`, yolov6/core/engine.py:297, :375-391) whose inf check in front of an optimizer step that takes the scale itself
     (`_step_supports_amp_scaling`: the fused / native SGD) is ONE launch over the contiguous ranges the gradients occupy (csrc/train_ops.hip:nonfinite_check_kernel,
     maf_nonfinite_check) — the flat buckets of a GradExchange are a handful of ranges for ~300 tensors — instead of the framework's multi-tensor launches (four per step,
     64 us, on MAF-YOLO-n).  Same `found_inf` (0 / 1) on the device, same scale update; gradients that are not dense fp32 CUDA tensors on the scale's device, or an explicit
