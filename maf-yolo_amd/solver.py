@@ -3,10 +3,12 @@ build_optimizer (yolov6/solver/build.py:12-33): BatchNorm weights without weight
 
     opt = build_optimizer(model, lr0=0.01, momentum=0.937, weight_decay=5e-4)          # configs/MAF-YOLO-n.py:19-29
 
-On CUDA parameters the SGD is torch's fused implementation: one multi-tensor launch per group, and — what matters for the step time — the
-GradScaler's inf check stays on the device (the optimizer receives grad_scale / found_inf tensors and skips the update itself), so
-`scaler.step(opt)` does not synchronise the host with the GPU and the launches of step i+1 queue up behind step i.  Same arithmetic as the
-reference's torch.optim.SGD(nesterov=True)."""
+On CUDA parameters the optimizer is NativeSGD — a subclass of torch's fused SGD whose step is ONE launch over a device table of every parameter
+(csrc/train_ops.hip:sgd_update_kernel), bit-identical to the fused implementation — and, what matters most for the step time, the GradScaler's
+inf check stays on the device (the optimizer receives grad_scale / found_inf tensors and skips the update itself), so `scaler.step(opt)` does
+not synchronise the host with the GPU and the launches of step i+1 queue up behind step i.  `GradScaler` here is torch.amp.GradScaler with
+that inf check as one launch over the contiguous gradient ranges.  Same arithmetic as the reference's torch.optim.SGD(nesterov=True) up to the
+fused kernel's double-precision hyper-parameter arithmetic (the framework's own fused = True path)."""
 import os
 
 import torch
