@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — images/s of the MAF-YOLO-n hot path on MI355X (BASELINE.json metric, configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 with no launcher around it re-executes itself as the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -384,6 +384,7 @@ def train_leg(args, torch, M, dev, rank, world, dist, scale, batch, steps, warmu
                        "convs": "torch/MIOpen" if args.torch_convs else "HIP kernels for every conv (1x1, depth-wise, 3x3 s2, 1x1 s2: forward, data gradient, weight gradient) and BatchNorm(train)+activation",
                        "native_launches": launches, "fallback": fallback, "final_loss": round(final, 5)},
             "native_launches": int(sum(v for k, v in launches.items() if k.startswith("native_"))), "fallback": fallback, "final_loss": round(final, 5),
+            "ranks_seen": 1 if dist is None else int(dist.get_world_size()),
             "roofline": roof, "cpu_baseline": cpu, "all_reduce": comm}
 
 
@@ -394,6 +395,46 @@ def train_mode(args, torch, M, dev, rank, world, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): replace this process by the launch the docstring names —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` — one rank
+    per GPU (tools/train.py:109-114 reads the same LOCAL_RANK / RANK / WORLD_SIZE).  Runs before torch is imported; does not return."""
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def rendezvous_only(args, rank, world):
+    """--rendezvous-only: the launch, the process group and the timing protocol of the N > 1 run (barrier on both sides, MAX over ranks, ONE line from rank 0)
+    with nothing between the barriers — no device, no kernel.  tests/test_host_logic.py runs `bench.py --gpus 2 --dist-backend gloo --rendezvous-only`
+    on the CPU-only build container; it is not a measurement and says so in the line."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(args.dist_backend if args.dist_backend != "nccl" or torch.cuda.is_available() else "gloo", init_method="env://")
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))                                # rank r "works" 10 (r + 1) ms: the MAX over ranks must be the last rank's
+    el = time.perf_counter() - t0
+    dist.barrier()
+    t = torch.tensor([el], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous only (no kernel ran): launch + process group + timing protocol of bench.py --gpus N", "value": None, "n_gpus": world,
+                          "ranks_seen": int(seen.item()), "world_size": dist.get_world_size(), "max_over_ranks_s": round(t.item(), 4), "rank0_s": round(el, 4),
+                          "backend": dist.get_backend(), "launched_by": "self_launch" if os.environ.get("TORCHELASTIC_RUN_ID") is not None else "env"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -429,6 +470,7 @@ def main():
     ap.add_argument("--no-fused-sgd", action="store_true", help="--train A/B: torch.optim.SGD's default (foreach) implementation; GradScaler.step then syncs the host every step")
     ap.add_argument("--rccl1", action="store_true", help="--train at N = 1: initialise a one-rank RCCL group and issue the bucket all-reduces anyway (GradExchange(force_collectives=True))")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 code on one GPU)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="N > 1: launch, process group, barrier / MAX-over-ranks protocol and the JSON line only — no device work (the CPU test of the launch path)")
     ap.add_argument("--latency", action="store_true",
                     help="BASELINE configs[4] instead: bs=1 forward replayed from a hipGraph + fused NMS, p50/p99 latency (use with --scale m)")
     args = ap.parse_args()
@@ -441,8 +483,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                 # `python bench.py --gpus N` as typed for N = 1: becomes the N-rank launch (does not return)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d, or with no launcher at all" % (args.gpus, world, args.gpus))
+    if args.rendezvous_only:
+        return rendezvous_only(args, rank, world)
     # MAF_BENCH_ONE_DEVICE=1 + --dist-backend gloo: every rank on cuda:0 with the exchange over gloo — NOT a measurement, a way to run the N > 1 code
     # paths (barriers, MAX over ranks, DDP hooks, the no_sync re-timing) on a 1-GPU box, where RCCL refuses two ranks on one device
     one_dev = os.environ.get("MAF_BENCH_ONE_DEVICE") == "1"
@@ -721,7 +767,7 @@ def main():
             return cpu
 
         out = {"metric": "images/sec MAF-YOLO-%s 640x640 bs=%d infer (Model.forward + non_max_suppression)" % (args.scale, B),
-               "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "value": round(value, 1), "unit": "images/s", "n_gpus": world, "ranks_seen": 1 if dist is None else int(dist.get_world_size()), "steps": args.steps, "warmup": args.warmup,
                "pool_settle_steps": POOL_SETTLE_STEPS, "untimed_steps_before_the_timed_region": POOL_SETTLE_STEPS + args.warmup,
                "timed_region_s": round(elapsed, 4),
                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -755,7 +801,7 @@ def main():
     # ---- every other BASELINE config at N = 1 in the same driver-timed run, compact: configs[2] / [3] at one GPU (s bs 32, m bs 16 per GPU),
     # configs[4] (m, bs 1, latency: eager launches and hipGraph replay), and the headline workload for s and m.  ~10 s each; --no-extra-legs leaves them out.
     extra = {}
-    if world == 1 and not args.no_extra_legs and not args.no_train_leg:
+    if not args.no_extra_legs and not args.no_train_leg:
         def leg(name, fn):
             t_ = time.perf_counter()
             try:
@@ -767,11 +813,16 @@ def main():
                 r_["leg_wall_s"] = round(time.perf_counter() - t_, 1)
             extra[name] = r_
             torch.cuda.empty_cache()
+        # configs[2] (s, 32 images per GPU: global 64 at N = 2) and configs[3] (m, 16 per GPU: global 128 at N = 8) run at EVERY world size the driver asks for:
+        # every rank takes part (the step carries the bucket all-reduces), rank 0 keeps the result with `all_reduce.exposed_all_reduce_ms`, the bucket sizes
+        # and `ranks_seen`.  (A failing leg raises on every rank alike — same code, same shapes — so the try / except cannot leave a peer inside a collective
+        # unless a rank fails alone; then the job dies on the collective's timeout instead of hanging.)
         leg("train_s", lambda: train_leg(args, torch, M, dev, rank, world, dist, "s", 32, 15, 8, False))
         leg("train_m", lambda: train_leg(args, torch, M, dev, rank, world, dist, "m", 16, 15, 8, False))
-        leg("latency_m", lambda: latency_leg(torch, M, dev, "m", 300, 30))
-        leg("infer_s", lambda: infer_leg(torch, M, dev, "s", 32, 100, 20, cs))
-        leg("infer_m", lambda: infer_leg(torch, M, dev, "m", 32, 60, 20, cs))
+        if world == 1:                                             # rank-local legs: replicas would only repeat them
+            leg("latency_m", lambda: latency_leg(torch, M, dev, "m", 300, 30))
+            leg("infer_s", lambda: infer_leg(torch, M, dev, "s", 32, 100, 20, cs))
+            leg("infer_m", lambda: infer_leg(torch, M, dev, "m", 32, 60, 20, cs))
     if rank == 0:
         if train is not None:
             train.pop("cpu_baseline", None)

@@ -886,6 +886,29 @@ def test_bench_train_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_train_self_launch_two_ranks_on_one_device():
+    """`python bench.py --gpus 2 --train ...` with NO launcher (the command line the driver types for N = 1): bench.self_launch re-executes it under
+    torch.distributed.run; two ranks share cuda:0 over gloo (MAF_BENCH_ONE_DEVICE), the package's GradExchange issues one all-reduce per bucket, and the line
+    carries ranks_seen = 2, the bucket sizes and the exposed all-reduce time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MAF_BENCH_ONE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--train", "--scale", "s", "--batch", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--dist-backend", "gloo"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, "\n".join(l for l in out.stderr.splitlines() if "Warning" not in l and "amdgpu.ids" not in l)[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "ddp2"
+    assert "MAF-YOLO-s" in d["metric"] and d["fallback"] == 0
+    assert d["all_reduce"] is not None and len(d["all_reduce"]["buckets"]) >= 1 and "exposed_all_reduce_ms" in d["all_reduce"]
+    assert d["config"]["exchange_stats"]["collectives"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("k", [3, 5])
 def test_maxpool_s1_matches_the_framework_forward_and_backward(dtype, k):

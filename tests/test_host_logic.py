@@ -634,3 +634,26 @@ def test_cat_buffer_join_and_fork_are_cat_and_split_for_autograd():
     assert torch.equal(y3.detach(), torch.cat([a, b], 1).detach())
     # mixed dtypes: the framework's promotion rule, through torch.cat
     assert to.join(to.CatBuffer(a, [8, 16]), [a.detach(), b.detach().double()]).dtype == torch.float64
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver types it for N = 1 — no launcher, WORLD_SIZE unset — re-executes itself under torch.distributed.run
+    (bench.self_launch), forms a two-rank group and runs the timing protocol (barrier, MAX over ranks, one JSON line from rank 0).  `--rendezvous-only` keeps the
+    device out of it (this container has none); the same launch with kernels is tests/test_gpu_train.py::test_bench_train_self_launch_two_ranks_on_one_device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["world_size"] == 2 and d["launched_by"] == "self_launch"
+    assert d["max_over_ranks_s"] >= 0.019 > d["rank0_s"]              # rank 1 slept 20 ms, rank 0 10 ms: the line carries the MAX
+    # a launcher that started the wrong number of ranks is refused, not silently benchmarked
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--rendezvous-only"], cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
