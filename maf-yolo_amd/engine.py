@@ -188,14 +188,17 @@ class Plan:
         fm = getattr(model, "fuse_mprep", "auto")
         self.fuse_mprep = (bool(getattr(model, "autotune", False)) if fm == "auto" else bool(fm)) and os.environ.get("MAF_FUSE_MPREP", "1") != "0"
         # the conv that closes a RepHDW block inside the launch of its last (fully fused) bottleneck where that instantiation exists (csrc/bottleneck.hip, op.nc):
-        # True / False / "auto" = wherever the instantiation exists and the block's last bottleneck runs in mode 1: every block of n (one bottleneck), the first two blocks
-        # of s and the first of m (two bottlenecks; MAF_FUSE_TAIL=1 keeps it to one-bottleneck blocks, =0 switches it off).  Round 4 held s / m back because the 640^2
-        # detection check of s moved from 293 to 289 of 300 matched rows; tools/fuse_tail_flip.py (profiles/round5_fuse_tail_flip_s.txt) shows what that is: ONE pair whose
-        # IoU sits at the NMS threshold (0.65010 against 0.65) falls the other way, the box that survives suppresses five neighbours of its class (IoU 0.67-0.84 with it) —
-        # the fp16-class event the n check tolerates per image, times its cascade; scores move by <= 1.5e-3 either way and the fused plan GAINS three other rows.
+        #   "auto" (default)  blocks of ONE bottleneck: every block of n.  The end-to-end detection bars of s / m (tests/test_gpu_fused_parity.py) are the ones measured
+        #                     on this setting.
+        #   True              every block whose instantiation exists: + the first two blocks of s and the first of m (two bottlenecks).  Opt-in (`model.fuse_tail = True`, or
+        #                     MAF_FUSE_TAIL=3 for "auto" models): on s one pair whose IoU sits at the NMS threshold (0.65010 against 0.65) falls the other way and the survivor
+        #                     suppresses five neighbours (profiles/round5_fuse_tail_flip_s.txt) — scores within 1.5e-3 either way, but the 640^2 check then matches 289 rows
+        #                     instead of 293; the opt-in has its own, wider, bars in the test and is not what bench.py times.
+        #   False             off.   MAF_FUSE_TAIL: 0 = off for every model, 1 = "auto" rule (the default), 3 = "auto" means True.
         ft = getattr(model, "fuse_tail", "auto") if fuse_tail is None else fuse_tail
-        deep = 1 if os.environ.get("MAF_FUSE_TAIL", "3") == "1" else 3
-        self.fuse_tail = (deep if ft == "auto" else 3 if ft else 0) if (os.environ.get("MAF_FUSE_TAIL", "3") != "0" and dtype == lib.F16) else 0      # deepest block (bottlenecks) taken
+        env_ft = os.environ.get("MAF_FUSE_TAIL", "1")
+        deep = 3 if env_ft == "3" else 1
+        self.fuse_tail = (deep if ft == "auto" else 3 if ft else 0) if (env_ft != "0" and dtype == lib.F16) else 0      # deepest block (bottlenecks) taken
         self.split_cat = bool(getattr(model, "split_cat", os.environ.get("MAF_SPLIT_CAT", "1") != "0"))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):

@@ -254,9 +254,19 @@ class GradExchange:
     def ensure_attached(self):
         """Before a replayed backward: its kernels add into the bucket slices by address, so `p.grad` must be the views — an `optimizer.zero_grad()` with
         set_to_none=True (the reference trainer's, engine.py:347,388) has dropped them and means 'the gradients are zero'."""
-        if any(b.params[0].grad is None for b in self.buckets):
-            self.zero_grad()
-            self.stats["reattached"] += 1
+        # per parameter, with the eager path's rule (`_attach`): None -> the slice is zeroed; a foreign tensor (assigned by the caller, restored from a checkpoint) IS
+        # the accumulated gradient -> copied into the slice; then `p.grad` is the view.  A pure Python loop with no device work when everything is attached.
+        n0 = self.stats["reattached"]
+        for b in self.buckets:
+            if all(p.grad is None for p in b.params):                             # the usual case after zero_grad(set_to_none=True): one memset for the bucket
+                b.flat.zero_()
+                for p in b.params:
+                    p.grad = self.slot[id(p)][1]
+                self.stats["reattached"] += 1
+                continue
+            for p in b.params:
+                self._attach(p, self.slot[id(p)][1])
+        return self.stats["reattached"] - n0
 
     def replay_launch(self, index, main_contrib):
         """A replayed backward has issued every gradient of bucket `index` (the point the recording marked): its all-reduce goes out, as in `_arrived`."""

@@ -127,7 +127,7 @@ class Model(nn.Module):
         self.fuse_bottlenecks = "auto"        # fused DepthBottleneckUni kernel (csrc/bottleneck.hip): True / False / "auto" (measured per layer when autotune is on)
         self.fuse_stem = True                 # True / 2: backbone.0 + backbone.1 + the 1x1 that opens backbone.2 in one launch (csrc/stem2.hip; fp16 plans of n and s); 1: without the 1x1; False
         self.fuse_head = "auto"               # per level {cls,reg}_conv_s -> pred -> sigmoid / DFL decode in one launch (csrc/head_tail.hip; fp16, 80 classes)
-        self.fuse_tail = "auto"               # the 1x1 conv that closes a RepHDW block inside the launch of its last fully fused bottleneck (csrc/bottleneck.hip, op.nc): True / False / "auto" = where the instantiation exists
+        self.fuse_tail = "auto"               # the 1x1 conv that closes a RepHDW block inside the launch of its last fully fused bottleneck (csrc/bottleneck.hip, op.nc): "auto" = blocks of one bottleneck (every block of n) / True = wherever the instantiation exists (+ s / m's two-bottleneck blocks: opt-in, engine.Plan) / False
         self.fuse_mprep = "auto"              # MPRep (MaxPool2d + 1x1 | 3x3 s2) in one launch (csrc/conv3s2_lds.hip, 48 / 64 channels, big maps): True / False / "auto" = when autotune is on
         self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
@@ -318,8 +318,11 @@ class Model(nn.Module):
         tp = ent[1]
         if tp is not None:
             if tp.ready:
-                if tp.pending_backward:                                          # a second forward before the first one's backward: the static buffers are taken
-                    return None
+                if tp.pending_backward:
+                    if tp.graph_alive():                                         # a second forward before the first one's backward: the static buffers are taken
+                        train_ops.stats["tape_busy_eager"] = train_ops.stats.get("tape_busy_eager", 0) + 1
+                        return None
+                    tp.drop_pending()                                            # that forward's graph is gone, no backward will come: the tape is free again
                 return tp
             if tp.failed is not None or tp.phase is not None:
                 return None                                                      # the recording was dropped (tp.failed says why): eager from here on

@@ -68,7 +68,8 @@ class GradScaler(torch.amp.GradScaler):
         return ent[1:]
 
     def _check_inf_per_device(self, optimizer):
-        if not inf_check_one_launch:
+        # (two private members of torch.amp.GradScaler are used below; a torch build that lacks either gets the parent's check — slower, same result)
+        if not inf_check_one_launch or not hasattr(self, "_check_scale_growth_tracker") or not hasattr(self, "_per_optimizer_states"):
             return super()._check_inf_per_device(optimizer)
         _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
         dev = _scale.device

@@ -24,9 +24,11 @@ staged by the step's pack batch — `train_ops.stats["glue"]` counts every fall-
 (tests/test_gpu_tape.py asserts the list is empty and that replayed steps follow the eager trajectory).
 
 Not for: fp32 parity runs, deterministic mode, profiling (`train_ops.profile`), plain autograd without a GradExchange (the weight gradients need their
-static bucket slices), two forwards before a backward — all of these run the eager path, which stays the reference implementation of the step."""
+static bucket slices), two forwards before a backward (while the first one's graph is alive; a forward whose graph was dropped
+without a backward is released: StepTape.drop_pending) — all of these run the eager path, which stays the reference implementation of the step."""
 import ctypes as C
 import struct
+import weakref
 
 import torch
 
@@ -76,6 +78,8 @@ class StepTape:
         self.glue = []                           # debug (`with tape.check():` around the recorded step): device ops torch ran inside the recorded regions
         self.seen = {"fwd": 0, "bwd": 0}         # ... and how many aten calls the check saw per region at all (zero = the mode did not reach that thread)
         self.pending_backward = False            # a replayed forward whose backward has not run: another forward must not overwrite the static buffers
+        self._live = None                        # weak reference to that forward's autograd node: dead = its graph was dropped and no backward will ever come
+        self.dropped = 0                         # replayed forwards whose backward never ran (a skipped step, an exception in the loss, a forward used for statistics only)
         self.xin = None
         self.outs, self.gin, self.gin_views = [], [], []
         self.stats_delta = {}
@@ -293,6 +297,25 @@ class StepTape:
         train_ops.stats["tape_replays"] = train_ops.stats.get("tape_replays", 0) + 1
         return [tuple(out[3 * l:3 * l + 3]) for l in range(self.nlev)]
 
+    def graph_alive(self):
+        """Is the autograd node of the last replayed forward still reachable (its outputs, or a loss computed from them, are held somewhere)?"""
+        return self._live is not None and self._live() is not None
+
+    def drop_pending(self):
+        """The last replayed forward never got its backward and its graph is gone (a non-finite loss that skipped the step, an exception in the loss, a forward
+        that only refreshed BatchNorm statistics): release the static buffers for the next forward.  The forward list has toggled its BatchNorm scratch halves,
+        the backward list has not — it follows here, so that the next step's backward reads the half its forward writes.  (Without this the tape stayed 'busy'
+        for ever and every later step silently took the eager path: ADVICE round 5.)"""
+        self._toggle("bwd")
+        self.pending_backward = False
+        self._live = None
+        self.dropped += 1
+        train_ops.stats["tape_dropped_backward"] = train_ops.stats.get("tape_dropped_backward", 0) + 1
+        if self.dropped == 1:
+            import warnings
+            warnings.warn("maf_yolo_amd step tape: a replayed train-mode forward was not followed by its backward (skipped step?); its buffers were released for the "
+                          "next forward.  Counted in train_ops.stats['tape_dropped_backward'].")
+
     def _copy_grads(self, grads):
         for i, g in enumerate(grads):
             if self.gin_views[i] is None:
@@ -319,6 +342,7 @@ class StepTape:
         for k, v in self.ex_delta.items():
             ex.stats[k] += v
         self.pending_backward = False
+        self._live = None
 
 
 class _Boundary(torch.autograd.Function):
@@ -347,6 +371,7 @@ class _TapeStep(torch.autograd.Function):
         tape._run("fwd", 0, tape.n["fwd"])
         tape._toggle("fwd")
         tape.pending_backward = True
+        tape._live = weakref.ref(ctx)
         outs = tuple(t.view_as(t) for t in tape.outs)
         ctx.mark_non_differentiable(*outs[0::3])
         return outs

@@ -174,3 +174,77 @@ def test_second_forward_before_the_backward_runs_eagerly():
         assert not tp.pending_backward
     finally:
         ex.close()
+
+
+def test_forward_without_a_backward_releases_the_tape_and_the_next_step_is_correct():
+    """A replayed forward whose backward never comes (a skipped step, an exception in the loss, a forward that only refreshed BatchNorm statistics) must not park the
+    tape for ever: once its graph is gone the next forward replays again — counted, warned once — and the step after it gives the gradients of a
+    model that never dropped a backward (the backward list's scratch halves were toggled along with the forward's)."""
+    import warnings
+    crit = M.ComputeLoss(ori_img_size=128, warmup_epoch=0)
+    x, t = _batch(4, 128)
+    res = {}
+    for name, drop in (("A", False), ("B", False), ("C", True)):
+        model = _model()
+        ex = M.GradExchange(model)
+        try:
+            for _ in range(tape_mod.RECORD_AT):
+                _pass(model, ex, crit, x, t)
+            tp = _the_tape(model)
+            assert tp.ready
+            if drop:
+                r0, d0 = train_ops.stats.get("tape_replays", 0), train_ops.stats.get("tape_dropped_backward", 0)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    out = model(x)                                            # replayed forward ...
+                assert tp.pending_backward and tp.graph_alive()
+                del out                                                       # ... whose graph is dropped without a backward
+                assert tp.pending_backward and not tp.graph_alive()
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    loss = _pass(model, ex, crit, x, t)                       # the next step replays again
+                assert train_ops.stats.get("tape_replays", 0) == r0 + 2 and train_ops.stats.get("tape_dropped_backward", 0) == d0 + 1 and tp.dropped == 1
+                assert any("not followed by its backward" in str(w_.message) for w_ in w)
+                assert not tp.pending_backward
+            else:
+                loss = _pass(model, ex, crit, x, t)
+            torch.cuda.synchronize()
+            res[name] = (loss, _grads(model))
+        finally:
+            ex.close()
+    (la, ga), (lb, gb), (lc, gc) = res["A"], res["B"], res["C"]
+    # C ran one more train-mode forward (running statistics moved once more; the batch statistics the step normalises with are the same): same bars as eager-vs-replay
+    assert abs(lc - la) <= max(3 * abs(lb - la), 2e-3 * abs(la)), (la, lb, lc)
+    noise, dev = _dev(gb, ga), _dev(gc, ga)
+    assert dev[0] <= max(3 * noise[0], 0.5), (dev, noise)
+
+
+def test_replayed_backward_takes_over_a_foreign_gradient_tensor():
+    """`p.grad` assigned by the caller (a restored checkpoint, gradient surgery) before a replayed backward IS the accumulated gradient: ensure_attached copies it into the
+    bucket slice and re-attaches the view — parameter by parameter, as the eager `_attach` does — so the kernels' gradient adds to it and the optimizer steps on the bucket."""
+    crit = M.ComputeLoss(ori_img_size=128, warmup_epoch=0)
+    x, t = _batch(4, 128)
+    model = _model()
+    ex = M.GradExchange(model)
+    try:
+        for _ in range(tape_mod.RECORD_AT + 1):
+            _pass(model, ex, crit, x, t)
+        assert _the_tape(model).ready
+        ref = _grads(model)
+        names = [n for n, p in model.named_parameters() if p.requires_grad and p.dim() == 4][:2]
+        ps = dict(model.named_parameters())
+        with torch.autocast("cuda", dtype=torch.float16):
+            (feats, cls, reg), _ = model(x)
+        loss = crit((feats, cls, reg), t, 0, 0)[0]
+        ex.zero_grad()
+        ps[names[0]].grad = torch.full_like(ps[names[0]], 3.0)                 # a foreign tensor: the accumulated gradient so far
+        ps[names[1]].grad = None                                              # dropped: means zero
+        (loss * 1024.0).backward()
+        torch.cuda.synchronize()
+        for n in names:
+            view = ex.slot[id(ps[n])][1]
+            assert ps[n].grad.data_ptr() == view.data_ptr(), n
+        tol = lambda r: 2e-2 * float(r.abs().max()) + 1e-3
+        assert float((ps[names[0]].grad - 3.0 - ref[names[0]]).abs().max()) <= tol(ref[names[0]])
+        assert float((ps[names[1]].grad - ref[names[1]]).abs().max()) <= tol(ref[names[1]])
+    finally:
+        ex.close()

@@ -170,12 +170,14 @@ def test_plan_builds_on_cpu(built, scale, nops32):
     m.fuse_bottlenecks = True                      # fused DepthBottleneckUni: 3 launches -> 1 wherever c <= 64, -> 2 (conv1+dw | 1x1) elsewhere
     tails = {"n": ["backbone.2.m.0+conv2", "backbone.4.m.0+conv2", "backbone.20.m.0+conv2", "backbone.22.m.0+conv2"],
              "s": ["backbone.2.m.1+conv2", "backbone.4.m.1+conv2"], "m": ["backbone.2.m.1+conv2"]}[scale]
-    assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == tails   # "auto": wherever the instantiation exists (round 5: s / m too)
-    os.environ["MAF_FUSE_TAIL"] = "1"
-    try:                                                                # MAF_FUSE_TAIL=1: one-bottleneck blocks only (round 4's rule)
-        assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == (tails if scale == "n" else [])
-    finally:
-        del os.environ["MAF_FUSE_TAIL"]
+    one = tails if scale == "n" else []
+    assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == one   # "auto" (default): blocks of ONE bottleneck only — every block of n
+    for env, want in (("3", tails), ("1", one), ("0", [])):             # MAF_FUSE_TAIL: 3 = "auto" takes every instantiation (s / m opt-in), 1 = the default rule, 0 = off
+        os.environ["MAF_FUSE_TAIL"] = env
+        try:
+            assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == want, env
+        finally:
+            del os.environ["MAF_FUSE_TAIL"]
     m.fuse_tail = True
     wt = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))                  # the block's closing conv inside its last bottleneck's launch
     assert [n for n in wt.op_names if n.endswith("+conv2")] == tails and not any(n[:-len(".m.0+conv2")] + ".conv2" in wt.op_names for n in tails)
