@@ -144,7 +144,19 @@ class Model(nn.Module):
     def train(self, mode=True):
         if mode:
             self._plans = {}                  # weights are about to change
+        elif getattr(self, "training", False):
+            self.release_tapes()              # train -> eval (the evaluation between epochs, engine.py:173-222): the step tapes pin a whole step's activations per batch shape
         return super().train(mode)
+
+    def release_tapes(self):
+        """Drop the recorded step tapes (tape.py) and what they pin: every activation and scratch of a full step per batch shape (several GB for m), the padded
+        gradient buffers registered in train_ops.zero_padded.  The next RECORD_AT train-mode forwards of a shape run eagerly and record again.  Outputs of a replayed
+        forward are views of the tape's static buffers (valid until the next forward of that shape): callers that keep predictions across steps clone them."""
+        for ent in getattr(self, "_tapes", {}).values():
+            tp = ent[1]
+            if tp is not None:
+                tp.release()
+        self._tapes = {}
 
     def load_state_dict(self, *a, **k):
         self.invalidate()
@@ -157,7 +169,7 @@ class Model(nn.Module):
         self._plans_version = None
         self._fp_tensors = None
         self._pack_plan = None                 # training: the staged weight transforms point at the old parameter storage
-        self._tapes = {}                       # ... and so do the recorded launch lists
+        self.release_tapes()                   # ... and so do the recorded launch lists
         self._ops_weights = (None, None)
 
     def _apply(self, fn, *a, **k):
@@ -312,7 +324,9 @@ class Model(nn.Module):
         ent = self._tapes.get(key)
         if ent is None:
             if len(self._tapes) >= 4:
-                self._tapes.pop(next(iter(self._tapes)))
+                old = self._tapes.pop(next(iter(self._tapes)))
+                if old[1] is not None:
+                    old[1].release()
             ent = self._tapes[key] = [0, None, 0]                            # forwards seen, tape, recordings tried
         ent[0] += 1
         tp = ent[1]

@@ -297,6 +297,17 @@ class StepTape:
         train_ops.stats["tape_replays"] = train_ops.stats.get("tape_replays", 0) + 1
         return [tuple(out[3 * l:3 * l + 3]) for l in range(self.nlev)]
 
+    def release(self):
+        """The model drops this tape: forget the buffers it pinned and their entries in train_ops.zero_padded (keyed by address: a later allocation at the same
+        address must not inherit 'the channels behind are zero')."""
+        for v in self.gin_views:
+            if v is not None:
+                train_ops.zero_padded.pop(v.data_ptr(), None)
+        self.ready = False
+        self.failed = self.failed or "released"
+        self.keep, self.outs, self.gin, self.gin_views, self.arr, self.tog = [], [], [], [], {}, {}
+        self.xin = None
+
     def graph_alive(self):
         """Is the autograd node of the last replayed forward still reachable (its outputs, or a loss computed from them, are held somewhere)?"""
         return self._live is not None and self._live() is not None

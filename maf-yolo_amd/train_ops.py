@@ -748,6 +748,7 @@ def _wgrad(x, dy, dys, w, ksize, stride):
     xx, xs = nhwc(x)
     co = -(-cdy // 8) * 8
     if co != cdy:                                                               # e.g. reg_pred: 68 channels, an odd class count (the 1x1 backward hands dY in padded already)
+        _glue()                                                                 # (torch kernels: not recordable by a step tape)
         dy = F.pad(dy, (0, 0, 0, 0, 0, co - cdy)).contiguous(memory_format=torch.channels_last)
         dys = co
     ex, view = _grad_sink(w)
@@ -1679,6 +1680,7 @@ class _Fork(torch.autograd.Function):
         if d_all is None:
             if d_tail is None:
                 return None, None
+            _glue()                                                               # the zero fill is a torch kernel that would run at recording time only: a step tape refuses this step
             d_all = _tzeros((d_tail.shape[0], ctx.lo + d_tail.shape[1]) + tuple(d_tail.shape[2:]), dtype=d_tail.dtype, device=d_tail.device).contiguous(memory_format=torch.channels_last)
         if d_tail is not None:
             tgt = d_all[:, ctx.lo:]
