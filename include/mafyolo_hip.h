@@ -522,6 +522,18 @@ int32_t maf_range_desc_size(void);
  * (what autograd's engine does with one add kernel per extra consumer).  fp16 (fp32 sums, one rounding) / fp32; C and strides in whole 16-byte groups. */
 int maf_nhwc_sum(const void* const* src, const int32_t* src_stride, int32_t n, void* dst, int32_t dst_stride, int64_t M, int32_t C, int32_t dtype,
                  int32_t accumulate, maf_stream_t stream);
+/* Detect_yaml.forward, TRAIN branch (yolov6/models/yolo.py:333-354) with the head's class sigmoid (yolov6/layers/common.py:1332) folded in: per level l the NHWC maps
+ * cls[l] (class LOGITS, nc channels, pixel stride cls_stride[l] elements) and reg[l] (nreg = 4 * (reg_max + 1) channels) of B images with level_pixels[l] = h*w
+ * pixels each become rows [a0_l, a0_l + h*w) of cls_out [B, A, nc] = sigmoid(logits) and reg_out [B, A, nreg] (A = sum of level_pixels) — the reference's
+ * flatten(2).permute(0, 2, 1) + torch.cat.  f16 / f32; nc, nreg and the strides multiples of 4.  Host arrays are read at call time.
+ * Backward: d logits = d_cls * y * (1 - y) (y = cls_out: what the framework's sigmoid backward computes from its saved output) and d_reg scattered back into per-level
+ * NHWC gradient maps of nc_pad / nreg_pad channels (>= nc / nreg, the 16-byte group the conv kernels read; pad channels are WRITTEN as zeros).  d_cls / d_reg NULL =
+ * no gradient (zeros). */
+int maf_detect_join(const void* const* cls, const int32_t* cls_stride, const void* const* reg, const int32_t* reg_stride, const int32_t* level_pixels,
+                    int32_t n_levels, int32_t B, int32_t nc, int32_t nreg, int32_t dtype, void* cls_out, void* reg_out, maf_stream_t stream);
+int maf_detect_join_backward(const void* d_cls, const void* d_reg, const void* cls_out, const int32_t* level_pixels, int32_t n_levels, int32_t B, int32_t nc,
+                             int32_t nreg, int32_t dtype, void* const* dcls, const int32_t* dcls_stride, void* const* dreg, const int32_t* dreg_stride,
+                             int32_t nc_pad, int32_t nreg_pad, maf_stream_t stream);
 /* `side` waits for what `main` holds now (an event record + a stream wait: the fork of a weight gradient to its own stream); join: `main` waits for `side`. */
 int maf_stream_fork(maf_stream_t main, maf_stream_t side);
 int maf_stream_join(maf_stream_t main, maf_stream_t side);

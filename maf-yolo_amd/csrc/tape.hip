@@ -66,6 +66,8 @@ const Entry kEntries[] = {
     MAF_TAPE_ENTRY(maf_maxpool_backward),
     MAF_TAPE_ENTRY(maf_upsample2x_forward),
     MAF_TAPE_ENTRY(maf_upsample2x_backward),
+    MAF_TAPE_ENTRY(maf_detect_join),
+    MAF_TAPE_ENTRY(maf_detect_join_backward),
 };
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 

@@ -74,7 +74,7 @@ class MafOp(C.Structure):
 
 EXPORTS = ["maf_last_error", "maf_version", "maf_op_size", "maf_op_launch", "maf_engine_create", "maf_engine_num_ops",
            "maf_engine_run", "maf_engine_run_filtered", "maf_engine_run_graph", "maf_engine_run_timed", "maf_engine_destroy", "maf_nms_workspace_bytes", "maf_nms", "maf_nms_ex", "maf_nms_debug", "maf_pack_w1x1_bytes", "maf_pack_w1x1", "maf_pack_dw", "maf_pack_batch", "maf_pack_desc_size", "maf_ema_update", "maf_ema_desc_size", "maf_sgd_update", "maf_sgd_desc_size", "maf_nonfinite_check", "maf_range_desc_size", "maf_maxpool_forward", "maf_maxpool_backward", "maf_upsample2x_forward", "maf_upsample2x_backward", "maf_zero", "maf_grad_fold", "maf_add_sub2", "maf_colsum", "maf_dw_wgrad", "maf_dw_wgrad31", "maf_stem_train", "maf_image_to_nhwc8", "maf_bottleneck_record_bytes", "maf_bottleneck_tail_record_bytes", "maf_bottleneck_tail_supported", "maf_conv1dw_record_bytes", "maf_head_tail_record_bytes", "maf_stem2_record_bytes", "maf_conv3s2_lds_record_bytes", "maf_mprep_lds_record_bytes", "maf_mprep_wreg_record_bytes", "maf_conv3s2_wreg_record_bytes", "maf_conv1x1_stats_supported", "maf_coco_rows", "maf_conv1x1_wgrad", "maf_conv_wgrad", "maf_bn_forward", "maf_bn_backward", "maf_bn_backward_acc", "maf_set_deterministic", "maf_dw_branches", "maf_dw_branches_stats", "maf_bn_forward_ex", "maf_bn_replicas", "maf_bn_stats", "maf_bn_sum_forward", "maf_bn_sum_forward_stats", "maf_bn_sum_backward", "maf_tal_targets", "maf_tal_assign", "maf_atss_assign", "maf_loss_partial_rows", "maf_loss_decode", "maf_loss_terms",
-           "maf_nhwc_sum", "maf_stream_fork", "maf_stream_join", "maf_tape_fn_id", "maf_tape_fn_nargs", "maf_tape_rec_size", "maf_tape_run", "maf_tape_toggle",
+           "maf_detect_join", "maf_detect_join_backward", "maf_nhwc_sum", "maf_stream_fork", "maf_stream_join", "maf_tape_fn_id", "maf_tape_fn_nargs", "maf_tape_rec_size", "maf_tape_run", "maf_tape_toggle",
            "maf_stream_create_masked", "maf_stream_destroy",
            "maf_timer_create", "maf_timer_start", "maf_timer_stop", "maf_timer_elapsed_ms", "maf_timer_destroy"]
 
@@ -201,6 +201,8 @@ def load():
     lib.maf_image_to_nhwc8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.maf_stem_train.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.maf_dw_wgrad31.argtypes = [C.c_void_p, C.c_int32] * 4 + [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p]
+    lib.maf_detect_join.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 3
+    lib.maf_detect_join_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]
     lib.maf_nhwc_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.maf_stream_fork.argtypes = [C.c_void_p, C.c_void_p]
     lib.maf_stream_join.argtypes = [C.c_void_p, C.c_void_p]

@@ -50,11 +50,26 @@ class Detect_yaml(nn.Module):
         self.proj = nn.Parameter(torch.linspace(0, self.reg_max, self.reg_max + 1), requires_grad=False)
         self.proj_conv.weight = nn.Parameter(self.proj.view(1, self.reg_max + 1, 1, 1).clone().detach(), requires_grad=False)
 
-    def forward(self, heads, val_loss=False):
-        """Training branch (yolo.py:333-354): flatten + permute + cat."""
-        cls = torch.cat([h[1].flatten(2).permute(0, 2, 1) for h in heads], 1)
-        reg = torch.cat([h[2].flatten(2).permute(0, 2, 1) for h in heads], 1)
+    def forward(self, heads, val_loss=False, logits=False):
+        """Training branch (yolo.py:333-354): flatten + permute + cat of the per-level (stem, cls, reg).  logits=True: h[1] are the class LOGITS and the head's sigmoid
+        (common.py:1332) is applied here — on HIP tensors the whole branch is one launch per direction (train_ops.detect_join, csrc/detect_join.hip)."""
+        if logits:
+            cls, reg = train_ops.detect_join(heads)
+        else:
+            cls = torch.cat([h[1].flatten(2).permute(0, 2, 1) for h in heads], 1)
+            reg = torch.cat([h[2].flatten(2).permute(0, 2, 1) for h in heads], 1)
         return [h[0] for h in heads], cls, reg
+
+    @staticmethod
+    def level_views(feats, cls, reg):
+        """[(stem, cls_l [B,nc,h,w], reg_l [B,4*(reg_max+1),h,w])] per level as VIEWS of the joined tensors: the `featmaps` the reference returns beside them
+        (yolo.py:205-209; its callers discard them: engine.py:150, evaler.py:168)."""
+        out, a0 = [], 0
+        for f in feats:
+            h, w = f.shape[-2:]
+            out.append((f, cls[:, a0:a0 + h * w].permute(0, 2, 1).unflatten(2, (h, w)), reg[:, a0:a0 + h * w].permute(0, 2, 1).unflatten(2, (h, w))))
+            a0 += h * w
+        return out
 
 
 def _nodes_from_config(config, num_classes):
@@ -221,7 +236,7 @@ class Model(nn.Module):
         return d
 
     # ------------------------------------------------------------------ forward
-    def _forward_train_form(self, x, raw_heads=False):
+    def _forward_train_form(self, x, raw_heads=False, logits=False):
         if getattr(self, "_pack_plan", None) is None:
             self._pack_plan = train_ops.PackPlan()
         train_ops.begin_step(self._pack_plan, x.device)          # every weight transform of the step in one launch (train_ops.PackPlan)
@@ -284,6 +299,8 @@ class Model(nn.Module):
             elif raw_heads and isinstance(m, Head_DepthUni):
                 x = m(x, raw=True, lanes=(2 * n_head + 1, 2 * n_head + 2))      # a recording step tape: the six head branches on lanes of their own
                 n_head += 1
+            elif logits and isinstance(m, Head_DepthUni):
+                x = m(x, raw=True)                                               # class logits: Detect's join applies the sigmoid (train_ops.detect_join)
             else:
                 x = m(x)
             n_use = uses.get(nd.i, 0)
@@ -294,19 +311,18 @@ class Model(nn.Module):
             x = [(h[0], train_ops.lane_join(h[1], h[3]), train_ops.lane_join(h[2], h[4])) for h in x]
         return x                              # list of three (stem, cls, reg)
 
-    def _train_heads(self, x):
-        """[(stem features, class probabilities, box distributions)] per level of a train-mode forward: eager (layers.py op by op), or — steady state of a
-        training loop under a GradExchange — the recorded launch lists of tape.py."""
+    def _train_out(self, x):
+        """(stem feature maps per level, cls [B,A,nc] probabilities, reg [B,A,4*(reg_max+1)]) of a train-mode forward (yolo.py:179-209 + 333-354): eager (layers.py op by
+        op, then Detect's join), or — steady state of a training loop under a GradExchange — the recorded launch lists of tape.py."""
         tape = self._tape_for(x)
         if tape is None:
+            native = x.is_cuda and not train_ops.framework_ops
             if x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the HIP kernels take
-            return self._forward_train_form(x)
+            return tuple(self.detect(self._forward_train_form(x, logits=native), logits=native))
         if tape.ready:
-            heads = tape.replay_forward(x)
-        else:
-            heads = tape.record_forward(self, x)
-        return [(f, torch.sigmoid(c), r) for f, c, r in heads]
+            return tape.replay_forward(x)
+        return tape.record_forward(self, x)
 
     def _tape_for(self, x):
         """The step tape this forward runs on (ready: replay; not ready: this call records), or None for the eager path."""
@@ -407,8 +423,8 @@ class Model(nn.Module):
 
     def forward(self, x, val_loss=False, slot=0):
         if self.training:
-            heads = self._train_heads(x)
-            return [self.detect(heads), list(heads)]
+            out = self._train_out(x)
+            return [out, self.detect.level_views(*out)]
         if getattr(self, "dispatch", "engine") == "ops" and not val_loss:
             # the same graph as a sequence of torch.ops.mafyolo.* calls (ops_forward.py): what torch.compile / export can trace
             from . import ops_forward

@@ -217,8 +217,9 @@ class StepTape:
 
     # ------------------------------------------------------------------ the recorded step
     def record_forward(self, model, x):
-        """Run the train-form forward of `model` on image batch x the normal way, recording it.  Returns the list of (feat, cls logits, reg) per level behind the boundary
-        node (their gradients are copied into static buffers before the recorded backward kernels read them)."""
+        """Run the train-form forward of `model` on image batch x the normal way, recording it — Detect's train-branch join (train_ops.detect_join) included.  Returns
+        (stem feature maps per level, cls [B,A,nc], reg [B,A,4*(reg_max+1)]) behind the boundary node (the gradients of cls / reg are copied into static buffers before
+        the recorded backward kernels read them)."""
         B, _, H, W = x.shape
         self.xin = torch.zeros((B, 8, H, W), dtype=torch.float16, device=self.dev).contiguous(memory_format=torch.channels_last)
         self._stage_input(x)
@@ -227,29 +228,20 @@ class StepTape:
         self.begin("fwd")
         try:
             heads = model._forward_train_form(self.xin, raw_heads=True)
+            cls, reg = train_ops.detect_join(heads)
         except BaseException:
             self.abort("the recorded forward raised")
             raise
         self.end()
         self._finalise("fwd")
-        flat = [t for h in heads for t in h]                                       # feat, cls, reg per level
-        self.outs = [t.detach() for t in flat]
         self.nlev = len(heads)
-        self.gin, self.gin_views = [], []
-        for i, t in enumerate(flat):
-            if i % 3 == 0:
-                self.gin.append(None); self.gin_views.append(None)                 # the stem feature maps: shapes for the loss, no gradient
-                continue
-            Bc, c, h, w = t.shape
-            cp = -(-c // 8) * 8                                                    # reg_pred: 68 channels, padded to 72 once (zeros behind: train_ops.zero_padded)
-            g = torch.zeros((Bc, cp, h, w), dtype=t.dtype, device=self.dev).contiguous(memory_format=torch.channels_last)
-            v = g[:, :c] if cp != c else g
-            if cp != c:
-                train_ops.zero_padded[v.data_ptr()] = cp
-            self.gin.append(g); self.gin_views.append(v)
+        flat = [h[0] for h in heads] + [cls, reg]                                  # the stem feature maps (shapes for the loss, no gradient), then the two joined tensors
+        self.outs = [t.detach() for t in flat]
+        self.gin = [None] * self.nlev + [torch.zeros_like(t) for t in (cls, reg)]  # contiguous [B,A,C] in the heads' dtype: what the recorded join-backward reads
+        self.gin_views = list(self.gin)
         self._stats0, self._ex0 = stats0, ex0
         out = _Boundary.apply(self, *flat)
-        return [tuple(out[3 * l:3 * l + 3]) for l in range(self.nlev)]
+        return list(out[:self.nlev]), out[self.nlev], out[self.nlev + 1]
 
     def _begin_backward_record(self):
         self.begin("bwd")
@@ -295,13 +287,13 @@ class StepTape:
         for k, v in self.stats_delta.items():
             train_ops.stats[k] = train_ops.stats.get(k, 0) + v
         train_ops.stats["tape_replays"] = train_ops.stats.get("tape_replays", 0) + 1
-        return [tuple(out[3 * l:3 * l + 3]) for l in range(self.nlev)]
+        return list(out[:self.nlev]), out[self.nlev], out[self.nlev + 1]
 
     def release(self):
         """The model drops this tape: forget the buffers it pinned and their entries in train_ops.zero_padded (keyed by address: a later allocation at the same
         address must not inherit 'the channels behind are zero')."""
-        for v in self.gin_views:
-            if v is not None:
+        for v in self.keep:                                                        # (the padded per-level gradient maps of the recorded join-backward are among these)
+            if isinstance(v, torch.Tensor):
                 train_ops.zero_padded.pop(v.data_ptr(), None)
         self.ready = False
         self.failed = self.failed or "released"
@@ -314,10 +306,11 @@ class StepTape:
 
     def drop_pending(self):
         """The last replayed forward never got its backward and its graph is gone (a non-finite loss that skipped the step, an exception in the loss, a forward
-        that only refreshed BatchNorm statistics): release the static buffers for the next forward.  The forward list has toggled its BatchNorm scratch halves,
-        the backward list has not — it follows here, so that the next step's backward reads the half its forward writes.  (Without this the tape stayed 'busy'
-        for ever and every later step silently took the eager path: ADVICE round 5.)"""
-        self._toggle("bwd")
+        that only refreshed BatchNorm statistics): release the static buffers for the next forward.  The forward list has toggled the scratch halves of ITS call
+        sites after running; the backward list did not run and keeps its phase — every recorded call site owns its scratch (train_ops._bn_part under a recording),
+        a backward site accumulates into the half its own last run cleared, so its phase advances with its own runs only (toggling it here would point it at the
+        half that still holds the last backward's sums: measured, gradients off by 4x).  (Without the release the tape stayed 'busy' for ever and every later
+        step silently took the eager path: ADVICE round 5.)"""
         self.pending_backward = False
         self._live = None
         self.dropped += 1
@@ -384,7 +377,7 @@ class _TapeStep(torch.autograd.Function):
         tape.pending_backward = True
         tape._live = weakref.ref(ctx)
         outs = tuple(t.view_as(t) for t in tape.outs)
-        ctx.mark_non_differentiable(*outs[0::3])
+        ctx.mark_non_differentiable(*outs[:tape.nlev])
         return outs
 
     @staticmethod

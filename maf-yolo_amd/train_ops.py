@@ -1694,6 +1694,82 @@ class _Fork(torch.autograd.Function):
         return d_all, None
 
 
+class _DetectJoin(torch.autograd.Function):
+    """Detect_yaml's train branch (yolov6/models/yolo.py:333-354) + the head's class sigmoid (yolov6/layers/common.py:1332): per-level NHWC (logits, box distribution)
+    maps -> (cls [B,A,nc] probabilities, reg [B,A,4*(reg_max+1)]) in ONE launch (csrc/detect_join.hip), and one launch back: d logits = d cls * y * (1 - y), d reg, into
+    per-level gradient maps padded to the conv kernels' 16-byte channel group (pad channels written as zeros: no memset, no F.pad in front of the weight gradient).
+    A step tape records both calls."""
+
+    @staticmethod
+    def forward(ctx, nl, *ts):
+        cls_l, reg_l = [nhwc(t) for t in ts[0::2]], [nhwc(t) for t in ts[1::2]]
+        t0 = cls_l[0][0]
+        B, nc = t0.shape[:2]
+        nr = reg_l[0][0].shape[1]
+        hw = [t.shape[2] * t.shape[3] for t, _ in cls_l]
+        A = sum(hw)
+        cls = _empty((B, A, nc), dtype=t0.dtype, device=t0.device)
+        reg = _empty((B, A, nr), dtype=t0.dtype, device=t0.device)
+        P, I = C.c_void_p * nl, C.c_int32 * nl
+        hwa = I(*hw)
+        with _prof("detect_join", 2 * B * A * (nc + nr) * t0.element_size(), t0.device):
+            lib.check(lib.load().maf_detect_join(P(*[t.data_ptr() for t, _ in cls_l]), I(*[s_ for _, s_ in cls_l]), P(*[t.data_ptr() for t, _ in reg_l]), I(*[s_ for _, s_ in reg_l]),
+                                                 hwa, nl, B, nc, nr, _DT[t0.dtype], cls.data_ptr(), reg.data_ptr(), _stream(t0.device)))
+        stats["native_detect_join"] = stats.get("native_detect_join", 0) + 1
+        ctx.save_for_backward(cls)
+        ctx.geo = (nl, B, nc, nr, hw, [tuple(t.shape[2:]) for t, _ in cls_l])
+        return cls, reg
+
+    @staticmethod
+    def backward(ctx, d_cls, d_reg):
+        (cls,) = ctx.saved_tensors
+        nl, B, nc, nr, hw, shapes = ctx.geo
+        dt, dev = cls.dtype, cls.device
+        for name, d in (("cls", d_cls), ("reg", d_reg)):
+            if d is not None and (d.dtype != dt or not d.is_contiguous()):
+                _glue()                                                           # (the loss kernels and a step tape's boundary hand over contiguous tensors of the head's dtype)
+        d_cls = None if d_cls is None else d_cls.to(dt).contiguous()
+        d_reg = None if d_reg is None else d_reg.to(dt).contiguous()
+        mult = 8 if dt == torch.float16 else 4
+        ncp, nrp = -(-nc // mult) * mult, -(-nr // mult) * mult
+        outs, dc, dr = [], [], []
+        for h, w in shapes:
+            gc = _empty((B, ncp, h, w), dtype=dt, device=dev, memory_format=torch.channels_last)
+            gr = _empty((B, nrp, h, w), dtype=dt, device=dev, memory_format=torch.channels_last)
+            dc.append(gc); dr.append(gr)
+            vc, vr = (gc[:, :nc] if ncp != nc else gc), (gr[:, :nr] if nrp != nr else gr)
+            if ncp != nc:
+                zero_padded[vc.data_ptr()] = ncp                                  # the channels behind the view are zeros (the kernel writes them): _wgrad / the data gradient read whole groups
+            if nrp != nr:
+                zero_padded[vr.data_ptr()] = nrp
+            outs += [vc, vr]
+        P, I = C.c_void_p * nl, C.c_int32 * nl
+        with _prof("detect_join_backward", B * sum(hw) * (3 * nc + 2 * nr) * cls.element_size(), dev):
+            lib.check(lib.load().maf_detect_join_backward(None if d_cls is None else d_cls.data_ptr(), None if d_reg is None else d_reg.data_ptr(), cls.data_ptr(), I(*hw), nl, B, nc, nr,
+                                                          _DT[dt], P(*[t.data_ptr() for t in dc]), I(*[ncp] * nl), P(*[t.data_ptr() for t in dr]), I(*[nrp] * nl), ncp, nrp, _stream(dev)))
+        stats["native_detect_join"] = stats.get("native_detect_join", 0) + 1
+        if _keep is not None:
+            _keep.extend([d_cls, d_reg])
+        return (None,) + tuple(outs)
+
+
+def detect_join(heads):
+    """(cls [B,A,nc] class probabilities, reg [B,A,4*(reg_max+1)]) from the per-level (stem, class LOGITS, box distribution) of the heads: Detect_yaml's train branch
+    (yolov6/models/yolo.py:333-354: flatten + permute + cat) with the class sigmoid of Head_DepthUni (yolov6/layers/common.py:1332) folded in.  HIP tensors: one launch
+    (csrc/detect_join.hip); CPU tensors / `framework_ops`: the reference's torch ops."""
+    cls_l, reg_l = [h[1] for h in heads], [h[2] for h in heads]
+    t0 = cls_l[0]
+    native = (t0.is_cuda and not framework_ops and len(heads) <= 4 and t0.shape[1] % 4 == 0 and reg_l[0].shape[1] % 4 == 0
+              and all(t.dim() == 4 and t.dtype == t0.dtype and t.dtype in _DT for t in cls_l + reg_l))
+    if not native:
+        if t0.is_cuda and not framework_ops:
+            _glue(); stats["fallback"] += 1
+        cls = torch.cat([torch.sigmoid(c).flatten(2).permute(0, 2, 1) for c in cls_l], 1)
+        reg = torch.cat([r.flatten(2).permute(0, 2, 1) for r in reg_l], 1)
+        return cls, reg
+    return _DetectJoin.apply(len(heads), *[t for pair in zip(cls_l, reg_l) for t in pair])
+
+
 def nhwc_sum(srcs, dst, accumulate=False):
     """dst = [dst +] sum(srcs) on NHWC views of one shape and dtype (csrc/train_ops.hip maf_nhwc_sum: 1..4 sources, channel slices welcome)."""
     B, c, H, W = dst.shape

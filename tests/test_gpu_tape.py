@@ -179,7 +179,7 @@ def test_second_forward_before_the_backward_runs_eagerly():
 def test_forward_without_a_backward_releases_the_tape_and_the_next_step_is_correct():
     """A replayed forward whose backward never comes (a skipped step, an exception in the loss, a forward that only refreshed BatchNorm statistics) must not park the
     tape for ever: once its graph is gone the next forward replays again — counted, warned once — and the step after it gives the gradients of a
-    model that never dropped a backward (the backward list's scratch halves were toggled along with the forward's)."""
+    model that never dropped a backward (the backward list's scratch phases advance with its own runs only)."""
     import warnings
     crit = M.ComputeLoss(ori_img_size=128, warmup_epoch=0)
     x, t = _batch(4, 128)

@@ -1738,3 +1738,94 @@ def test_upsample2x_kernel_with_strided_source_and_concat_slot(c, hw, dtype):
     from maf_yolo_amd.model import Upsample
     n0 = train_ops.stats.get("native_upsample", 0)
     assert torch.equal(Upsample(None, 2, "nearest")(wide[:, :c]), y) and train_ops.stats["native_upsample"] == n0 + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("nc,padded_src", [(80, False), (80, True), (4, False)])
+def test_detect_join_is_the_reference_train_branch_forward_and_backward(dtype, nc, padded_src):
+    """SURVEY 8 a12 — Detect_yaml's train branch (yolov6/models/yolo.py:333-354: flatten(2).permute(0,2,1) of every level's cls / reg, torch.cat over the levels) with the
+    head's sigmoid (common.py:1332) folded in, as ONE launch per direction (csrc/detect_join.hip) against exactly those torch ops and their autograd: probabilities to
+    one rounding of the dtype (fp32: 2e-7), reg a bit-exact copy, gradients to one rounding; the per-level gradient maps come back padded to the conv kernels' channel
+    group with ZEROS behind the view (68 -> 72 at fp16).  padded_src: the level maps are channel slices of wider buffers (a prediction conv's padded output rows)."""
+    g = torch.Generator().manual_seed(nc)
+    B, nr, hws = 3, 68, [(8, 12), (4, 6), (2, 3)]
+    heads, ref_heads = [], []
+    for h, w in hws:
+        lv = []
+        for c in (nc, nr):
+            t = (torch.randn(B, c, h, w, generator=g) * 2.5).to(dtype)
+            if padded_src:
+                buf = torch.full((B, c + 12, h, w), 7.0, dtype=dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+                buf[:, :c] = t.to(DEV)
+                lv.append(buf[:, :c].detach().requires_grad_(True))
+            else:
+                lv.append(t.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True))
+        heads.append((torch.zeros(B, 8, h, w, device=DEV), lv[0], lv[1]))
+        ref_heads.append(tuple(t.detach().clone().requires_grad_(True) for t in lv))
+    n0, g0 = train_ops.stats.get("native_detect_join", 0), train_ops.stats.get("glue", 0)
+    cls, reg = train_ops.detect_join(heads)
+    A = sum(h * w for h, w in hws)
+    assert cls.shape == (B, A, nc) and reg.shape == (B, A, nr) and cls.dtype == reg.dtype == dtype and cls.is_contiguous() and reg.is_contiguous()
+    rcls = torch.cat([torch.sigmoid(c).flatten(2).permute(0, 2, 1) for c, _ in ref_heads], 1)
+    rreg = torch.cat([r.flatten(2).permute(0, 2, 1) for _, r in ref_heads], 1)
+    assert torch.equal(reg.detach(), rreg.detach())
+    tol = 1e-3 if dtype == torch.float16 else 2e-7                      # fp16: one rounding of a value <= 1 (v_exp / v_rcp against the framework's expf / divide)
+    assert (cls.detach().float() - rcls.detach().float()).abs().max().item() <= tol
+    dc = (torch.randn(B, A, nc, generator=g) * 3).to(dtype).to(DEV)
+    dr = torch.randn(B, A, nr, generator=g).to(dtype).to(DEV)
+    torch.autograd.backward([cls, reg], [dc, dr])
+    torch.autograd.backward([rcls, rreg], [dc, dr])
+    assert train_ops.stats.get("native_detect_join", 0) == n0 + 2 and train_ops.stats.get("glue", 0) == g0
+    mult = 8 if dtype == torch.float16 else 4
+    for (_, c, r), (rc, rr) in zip(heads, ref_heads):
+        assert torch.equal(r.grad, rr.grad)
+        d = (c.grad.float() - rc.grad.float()).abs().max().item()
+        assert d <= (4e-3 if dtype == torch.float16 else 1e-6) * max(1.0, rc.grad.float().abs().max().item()), d
+    # what the weight gradient / data gradient of the prediction convs read behind a 68-channel view: the kernel wrote zeros there and registered the pad
+    gr = heads[0][2].grad
+    if nr % mult:
+        assert gr.stride()[1] == 1 and gr.stride()[3] == -(-nr // mult) * mult and train_ops.zero_padded.get(gr.data_ptr()) == gr.stride()[3]
+        whole = torch.as_strided(gr, (B, gr.stride()[3], hws[0][0], hws[0][1]), gr.stride())
+        assert float(whole[:, nr:].abs().max()) == 0.0
+    # no gradient for one of the two outputs: zeros come back, not garbage
+    heads2 = [(f, c.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)) for f, c, r in heads]
+    cls2, reg2 = train_ops.detect_join(heads2)
+    cls2.sum().backward()
+    assert all(float(r.grad.abs().max()) == 0.0 for _, _, r in heads2) and all(float(c.grad.abs().max()) > 0.0 for _, c, _ in heads2)
+
+
+@pytest.mark.gpu
+def test_train_mode_forward_returns_the_reference_structure_and_runs_no_framework_sigmoid_or_cat():
+    """Model.forward in train mode (yolo.py:179-209, 333-354): [(feats, cls [B,A,nc], reg [B,A,68]), featmaps]; the class probabilities equal sigmoid of the per-level
+    logits, the featmaps are per-level views of the joined tensors, and over forward + backward torch runs NO sigmoid, cat or their backward kernels (a12 is native:
+    the dispatch trace lists every aten op that touched a device tensor)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from maf_yolo_amd import synth
+    m = M.Model("n")
+    m.load_state_dict(synth.synth_state_dict(m, "n", 0))
+    m = m.to(DEV).train()
+    x = synth.synth_images(2, 128, seed=1).to(DEV)
+    seen = []
+
+    class Trace(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    with Trace(), torch.autocast("cuda", dtype=torch.float16):
+        (feats, cls, reg), fm = m(x)
+        (cls.float().sum() + reg.float().pow(2).sum()).backward()
+    torch.cuda.synchronize()
+    A = sum(f.shape[2] * f.shape[3] for f in feats)
+    assert cls.shape == (2, A, 80) and reg.shape == (2, A, 68) and len(fm) == 3
+    assert float(cls.min()) >= 0.0 and float(cls.max()) <= 1.0
+    a0 = 0
+    for (f, c, r), f2 in zip(fm, feats):
+        h, w = f.shape[-2:]
+        assert f is f2 and c.shape == (2, 80, h, w) and r.shape == (2, 68, h, w)
+        assert c.data_ptr() == cls[:, a0].data_ptr() and r.data_ptr() == reg[:, a0].data_ptr()
+        assert torch.equal(c.flatten(2).permute(0, 2, 1), cls[:, a0:a0 + h * w])
+        a0 += h * w
+    bad = [s for s in seen if any(k in s for k in ("aten.sigmoid", "aten.cat.", "aten._cat", "aten.sigmoid_backward", "aten.constant_pad_nd"))]
+    assert not bad, sorted(set(bad))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if "cls_pred" in n or "reg_pred" in n)
