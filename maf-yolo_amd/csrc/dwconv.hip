@@ -236,7 +236,6 @@ int launch_t(DwArgs& a, int k, hipStream_t s) {
 
 int maf_launch_dwconv_mfma(const maf_op_t* op, hipStream_t s);
 int maf_launch_dwconv_dot2(const maf_op_t* op, hipStream_t s);
-int maf_launch_dwconv_sw(const maf_op_t* op, hipStream_t s);
 int maf_launch_dwconv_p2(const maf_op_t* op, hipStream_t s);
 
 int maf_launch_dwconv(const maf_op_t* op, hipStream_t s) {
@@ -244,7 +243,7 @@ int maf_launch_dwconv(const maf_op_t* op, hipStream_t s) {
     if (op->tile_p == -2) return maf_launch_dwconv_dot2(op, s);          // v_dot2_f32_f16 over tap pairs (dwconv_dot2.hip)
     if (op->tile_p == -4) return maf_launch_dwconv_p2(op, s);            // v_dot2c with scalar weight pairs over an input stored as pixel pairs (dwconv_p2.hip)
     MAF_REQUIRE(op->nsrc < 1 || op->src[0].mode != MAF_SRC_PAIRS, "dwconv: a pixel-pair source needs tile_p = -4");
-    if (op->tile_p == -3) return maf_launch_dwconv_sw(op, s);            // a wave per channel group, weights as scalar operands, halo plane by DMA (dwconv_sw.hip)
+    MAF_REQUIRE(op->tile_p != -3, "dwconv: tile_p = -3 (the scalar-weight variant) left the library in round 6 — no tuning file of three rounds ever picked it");
     MAF_REQUIRE(op->dtype == MAF_F16 || op->dtype == MAF_F32, "dwconv: dtype must be f16/f32");
     const int N = op->dtype == MAF_F16 ? 8 : 4;
     const maf_src_t& sr = op->src[0];

@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from .config import cfg
 from . import lib, pack
 from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Head_DepthUni)
 
@@ -103,30 +104,12 @@ class TV:
         return sum(s.C for s in self.segs)
 
 
-_SW_GROUPS = ((0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27), (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
+# lanes served together by one ds_read_b128 (four groups of 16): what the LDS pitch searches below count bank-slot collisions over
+_LANE_GROUPS = ((0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27), (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
               (32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59), (36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63))
 
 
-def sw_pitch(th, tw, k):
-    """LDS row pitch (pixels) of a dwconv_sw halo plane: csrc/dwconv_sw.hip:sw_pitch (the fewest bank-slot collisions of a ds_read_b128 lane group)."""
-    rw, spr = tw + k - 1, tw // 4
-    nstrips = th * spr
-    best, bc = rw, 1 << 30
-    for p in range(rw, rw + 8):
-        c = 0
-        for g in _SW_GROUPS:
-            cnt = {}
-            for lane in g:
-                s_ = min(lane, nstrips - 1)
-                slot = ((s_ // spr) * p + 4 * (s_ % spr)) & 15
-                cnt[slot] = cnt.get(slot, 0) + 1
-            c += max(cnt.values())
-        if c < bc:
-            best, bc = p, c
-    return best
-
-
-_P2_STAGE = os.environ.get("MAF_DW_STAGE", "1") != "0"      # A/B switch of the tuner's staged-store candidates for dwconv_p2 (tile_k + 128)
+_P2_STAGE = cfg.dw_stage      # A/B switch of the tuner's staged-store candidates for dwconv_p2 (tile_k + 128)
 
 
 def p2_wave_bytes(th, tw, k):
@@ -138,7 +121,7 @@ def p2_wave_bytes(th, tw, k):
     best, bc = rwp, 1 << 30
     for pitch in range(rwp, rwp + 8):
         c = 0
-        for g in _SW_GROUPS:
+        for g in _LANE_GROUPS:
             cnt = {}
             for lane in g:
                 s_ = min(lane, nstrips - 1)
@@ -148,11 +131,6 @@ def p2_wave_bytes(th, tw, k):
         if c < bc:
             best, bc = pitch, c
     return -(-(2 * (th + k - 1) * best) // 64) * 1024
-
-
-def sw_plane_slots(th, tw, k):
-    """16-byte slots of one wave's halo plane (a multiple of 64: whole DMA rounds)."""
-    return -(-((th + k - 1) * sw_pitch(th, tw, k)) // 64) * 64
 
 
 class Plan:
@@ -186,7 +164,7 @@ class Plan:
         # MPRep's two branches in one launch where the kernel exists: True / False / "auto" = in tuned plans only (the untuned default plan keeps one
         # launch list for every batch size, so that an image's rows do not depend on how many images ran beside it — the fused kernel sums in another order)
         fm = getattr(model, "fuse_mprep", "auto")
-        self.fuse_mprep = (bool(getattr(model, "autotune", False)) if fm == "auto" else bool(fm)) and os.environ.get("MAF_FUSE_MPREP", "1") != "0"
+        self.fuse_mprep = (bool(getattr(model, "autotune", False)) if fm == "auto" else bool(fm)) and cfg.fuse_mprep
         # the conv that closes a RepHDW block inside the launch of its last (fully fused) bottleneck where that instantiation exists (csrc/bottleneck.hip, op.nc):
         #   "auto" (default)  blocks of ONE bottleneck: every block of n.  The end-to-end detection bars of s / m (tests/test_gpu_fused_parity.py) are the ones measured
         #                     on this setting.
@@ -196,10 +174,10 @@ class Plan:
         #                     instead of 293; the opt-in has its own, wider, bars in the test and is not what bench.py times.
         #   False             off.   MAF_FUSE_TAIL: 0 = off for every model, 1 = "auto" rule (the default), 3 = "auto" means True.
         ft = getattr(model, "fuse_tail", "auto") if fuse_tail is None else fuse_tail
-        env_ft = os.environ.get("MAF_FUSE_TAIL", "1")
+        env_ft = str(cfg.fuse_tail)
         deep = 3 if env_ft == "3" else 1
         self.fuse_tail = (deep if ft == "auto" else 3 if ft else 0) if (env_ft != "0" and dtype == lib.F16) else 0      # deepest block (bottlenecks) taken
-        self.split_cat = bool(getattr(model, "split_cat", os.environ.get("MAF_SPLIT_CAT", "1") != "0"))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
+        self.split_cat = bool(getattr(model, "split_cat", cfg.split_cat))   # RepHDW behind the fused stem: one dense tensor per concat slot (see the rephdw branch)
         self.lanes = getattr(model, "multi_stream", False)
         if isinstance(self.lanes, bool):
             self.lanes = 2 if self.lanes else 0                  # 0: one stream; 1: heads only; 2: heads + neck side convs
@@ -424,7 +402,7 @@ class Plan:
                     y.append(TV([Seg(out, node.cout)], out.H, out.W))
                     continue
                 if self.fuse_mprep and self.dtype == lib.F16 and (x.C, c_, w1_.shape[0]) == (96, 96, 96) and x.H % 2 == 0 and x.W % 2 == 0 \
-                        and self.B * (x.H // 2) * (x.W // 2) >= int(os.environ.get("MAF_MPREP_WREG_MIN", "65536")):
+                        and self.B * (x.H // 2) * (x.W // 2) >= cfg.mprep_wreg_min:
                     # (backbone.5 of n at bs 32, 51 200 pixels: 24.9 + 16.7 -> 38.8 us only — the pooled branch costs this kernel its read-ahead depth — so big maps only)
                     # ... and on the register-resident 3x3 kernel (csrc/conv3s2_wreg.hip with nc): the pooled operand is the maximum of four fragments the conv reads anyway
                     w2_, b2_ = m.conv2.fused()
@@ -809,32 +787,6 @@ class Plan:
                                         timer.stop(stream.cuda_stream)
                                         ts.append(timer.elapsed_ms())
                                     results.append((min(ts), -2, tw, th * 256 + cb))
-                    # (only where the pixel-pair kernel below cannot run: timed alone with warm operands the two are close on the 20 x 20 layers, inside the forward
-                    # dwconv_p2 wins every time — 21.6 against 29.1 us on backbone.12.m.0.conv2 — and a chain of the round lost 7 us to such a pick)
-                    if self.dtype == lib.F16 and self._pairs_producer(i) is None:   # a wave per 8-channel group, weights as scalar operands (csrc/dwconv_sw.hip): tile_p = -3, tile_c = columns, tile_k = rows * 256 + waves per workgroup
-                        w4 = -(-o.W // 4) * 4
-                        for th in sorted({4, 5, 8, 10, 16, 20, 32} | ({o.H} if o.H <= 40 else set())):
-                            if th > o.H:
-                                continue
-                            for tw in sorted({8, 16, 20, 32, 40, 80} | ({w4} if w4 <= 80 else set())):
-                                if tw > w4:
-                                    continue
-                                plane = sw_plane_slots(th, tw, o.ksize) * 16
-                                if plane > 20 * 1024:                    # fewer than 8 waves per CU: never the fastest
-                                    continue
-                                for nw in (4, 8):
-                                    if nw * plane > 160 * 1024:
-                                        continue
-                                    op = lib.MafOp.from_buffer_copy(o)
-                                    op.tile_p, op.tile_c, op.tile_k = -3, tw, th * 256 + nw
-                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
-                                    ts = []
-                                    for _ in range(reps):
-                                        timer.start(stream.cuda_stream)
-                                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
-                                        timer.stop(stream.cuda_stream)
-                                        ts.append(timer.elapsed_ms())
-                                    results.append((min(ts), -3, tw, th * 256 + nw))
                     if self._pairs_producer(i) is not None:              # pixel-pair input, v_dot2c with scalar weight pairs (csrc/dwconv_p2.hip): tile_p = -4, tile_c = columns, tile_k = rows * 256 + waves per workgroup
                         w4 = -(-o.W // 4) * 4
                         for th in sorted({4, 5, 8, 10, 16, 20} | ({o.H} if o.H <= 40 else set())):
@@ -1056,8 +1008,6 @@ class Plan:
                 return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -4:
                 return "dwconv_p2_kernel<%d, %d, %d>" % (o.ksize, o.act, (o.Cout // o.Cin) if o.tile_k & 128 else 0)
-            if o.tile_p == -3:
-                return "dwconv_sw_kernel<%d, %d>" % (o.ksize, o.act)
             if o.tile_p == -2:
                 return "dwconv_dot2_kernel<%d, 8, %d, %d>" % (o.ksize, 2 if (o.tile_k >> 8) % 2 == 0 else 1, o.act)
             return "dwconv_tile_kernel<%s, %d, %d>" % (T, o.ksize, o.act)

@@ -31,9 +31,10 @@ import contextlib
 
 import torch
 
+from .config import cfg
 from . import lib
 
-_DEBUG = __import__("os").environ.get("MAF_EXCHANGE_DEBUG") == "1"    # keep the Python stack of every arrival (shown when a late arrival raises)
+_DEBUG = cfg.exchange_debug    # keep the Python stack of every arrival (shown when a late arrival raises)
 current = None                                  # the exchange train_ops hands its weight gradients to (None: plain autograd)
 
 

@@ -4,8 +4,10 @@ The product path has no CPU fallback: if the library is missing this raises, lou
 import ctypes as C
 import os
 
+from .config import cfg
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MAF_HIP_LIB") or os.path.join(_HERE, "libmafyolo_hip.so")     # MAF_HIP_LIB: an instrumented build (make prof)
+LIB_PATH = cfg.hip_lib or os.path.join(_HERE, "libmafyolo_hip.so")     # MAF_HIP_LIB: an instrumented build (make prof)
 
 F16, F32, U8 = 0, 1, 2
 NMS_FLOAT_THRESHOLD = 1

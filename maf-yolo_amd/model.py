@@ -17,6 +17,7 @@ from operator import attrgetter
 import torch
 import torch.nn as nn
 
+from .config import cfg
 from . import arch, lib, train_ops
 from .engine import Plan
 from .layers import (RepVGGBlock, RepHDW, MPRep, SPPF, ConvWrapper, Concat, Head_DepthUni, Out)
@@ -147,7 +148,7 @@ class Model(nn.Module):
         self.twin_convs = True                # the two equal side convs of a MAFPN level (backbone.23 / .24, .27 / .28) as one launch
         self.autotune = False                 # True: time the MFMA tile candidates of every conv when an fp16 plan is built
         self.multi_stream = False             # False | 1 (heads) | 2 (heads + neck side convs): independent branches on separate HIP streams inside the engine
-        self.step_tape = "auto" if __import__("os").environ.get("MAF_STEP_TAPE", "1") != "0" else False      # training: replay the recorded launch lists of a step (tape.py) once a batch shape has been seen RECORD_AT times under a GradExchange; False: always eager
+        self.step_tape = "auto" if cfg.step_tape else False      # training: replay the recorded launch lists of a step (tape.py) once a batch shape has been seen RECORD_AT times under a GradExchange; False: always eager
         assert dispatch in ("engine", "ops")
         self.dispatch = dispatch              # "engine": one C call per forward (engine.py) | "ops": the graph op by op through torch.ops.mafyolo (ops_forward.py)
 

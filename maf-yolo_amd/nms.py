@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from .config import cfg
 from . import lib
 
 _ws = {}
@@ -116,7 +117,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     return rows, idx, cnt
 
 
-SINGLE_LAUNCH_MAX_BATCH = int(os.environ.get("MAF_NMS_SINGLE_MAX_BATCH", "0"))
+SINGLE_LAUNCH_MAX_BATCH = cfg.nms_single_max_batch
 
 
 def _single_launch(B):

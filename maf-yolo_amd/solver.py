@@ -11,14 +11,16 @@ that inf check as one launch over the contiguous gradient ranges.  Same arithmet
 fused kernel's double-precision hyper-parameter arithmetic (the framework's own fused = True path)."""
 import os
 
+from .config import cfg
+
 import torch
 import torch.nn as nn
 
-ema_one_launch = os.environ.get("MAF_EMA_NATIVE", "1") != "0"       # A/B switch: ModelEMA.update as one launch (csrc/train_ops.hip maf_ema_update)
-sgd_one_launch = os.environ.get("MAF_SGD_NATIVE", "1") != "0"       # A/B switch: the SGD step as one launch (csrc/train_ops.hip maf_sgd_update)
+ema_one_launch = cfg.ema_native       # A/B switch: ModelEMA.update as one launch (csrc/train_ops.hip maf_ema_update)
+sgd_one_launch = cfg.sgd_native       # A/B switch: the SGD step as one launch (csrc/train_ops.hip maf_sgd_update)
 
 
-inf_check_one_launch = os.environ.get("MAF_INF_CHECK_NATIVE", "1") != "0"       # A/B switch: GradScaler's inf check as one launch (maf_nonfinite_check)
+inf_check_one_launch = cfg.inf_check_native       # A/B switch: GradScaler's inf check as one launch (maf_nonfinite_check)
 
 
 class GradScaler(torch.amp.GradScaler):

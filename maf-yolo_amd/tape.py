@@ -32,6 +32,7 @@ import weakref
 
 import torch
 
+from .config import cfg
 from . import lib, train_ops
 
 _M64 = (1 << 64) - 1
@@ -45,7 +46,7 @@ _VIEW_OPS = ("aten.view.", "aten._unsafe_view.", "aten.as_strided.", "aten.slice
              "aten.lift_fresh.", "aten._local_scalar_dense.", "aten.sym_", "prim.", "aten.size.", "aten.stride.", "aten.storage_offset.", "aten.numel.")
 
 
-_NATIVE_STAGE = __import__("os").environ.get("MAF_STAGE_NATIVE", "1") != "0"      # A/B switch: the input staging as one native pass
+_NATIVE_STAGE = cfg.stage_native      # A/B switch: the input staging as one native pass
 
 
 class _Proxy:

@@ -21,6 +21,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+from .config import cfg
 from . import lib, pack
 
 _DT = {torch.float16: lib.F16, torch.float32: lib.F32}
@@ -137,7 +138,7 @@ _raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, "_cuda_get
 # step tape records — and therefore in every replay.  Their kernels are small (20 x 20 ... 80 x 80 maps, 5-50 us each, bound by launch latency and fixed
 # costs, not by the chip), so two or three such chains side by side cost little more than one.  Only a recording step uses them: the tape keeps every buffer
 # alive, so memory handed from one stream to another needs no allocator bookkeeping; eager steps run everything on the current stream.
-n_lanes = int(os.environ.get("MAF_TRAIN_LANES", "2"))      # at most (lane_handles: four hardware queues for main, weight gradients, lanes and RCCL)
+n_lanes = cfg.train_lanes      # at most (lane_handles: four hardware queues for main, weight gradients, lanes and RCCL)
 _cur_lane = 0                                    # 0: the current (main) stream; k: lane k
 _lane_streams = {}
 _lane_rejects = []
@@ -205,8 +206,8 @@ def _stream(dev):
 #   * without one (plain autograd, DistributedDataParallel): the Function returns dW as a tensor that AccumulateGrad / the pad backward of the
 #     stem / the DDP reducer read on the MAIN stream straight away, so the main stream waits for the side stream before the layer's backward
 #     returns (`_side_done`) — the overlap is then with the data gradient of the same layer only.
-wgrad_stream = os.environ.get("MAF_WGRAD_STREAM", "1") != "0"
-bn_affine_direct = os.environ.get("MAF_BN_AFFINE_DIRECT", "1") != "0"     # A/B switch: BatchNorm dgamma / dbeta into the exchange's bucket slices by the apply kernel
+wgrad_stream = cfg.wgrad_stream
+bn_affine_direct = cfg.bn_affine_direct     # A/B switch: BatchNorm dgamma / dbeta into the exchange's bucket slices by the apply kernel
 _side_streams = {}
 _side_events = {}
 _side_used = {}                                  # device index -> the side stream holds work the main stream has not waited for
@@ -335,7 +336,7 @@ def _launch_conv1x1(x, xs, wp, bias, B, H, W, cin, cout, ct, out, dt, pt=None, t
             op.aux[2], op.reserved0, op._tape_toggles = None, 0, None
 
 
-conv_bn_stats = os.environ.get("MAF_CONV_BN_STATS", "1") != "0"           # A/B switch: BatchNorm statistics out of the 1x1 conv's epilogue (csrc/conv_stream_lds_st.hip)
+conv_bn_stats = cfg.conv_bn_stats           # A/B switch: BatchNorm statistics out of the 1x1 conv's epilogue (csrc/conv_stream_lds_st.hip)
 
 
 def _conv_stats_ok(choice, cin, co, cout, dt, bias):
@@ -348,8 +349,8 @@ def _conv_stats_ok(choice, cin, co, cout, dt, bias):
 # the inference tuner would try for it (engine.Plan.autotune: tile_p x tile_c of the generic kernel, split-K, LDS-shared weight fragments,
 # the persistent "stream" forms) is timed on the tensors at hand and the best one kept — the static rule (pack.tile_for) loses 10-40 % on
 # individual layers.  MAF_TRAIN_TUNE=0 turns it off.
-conv_autotune = os.environ.get("MAF_TRAIN_TUNE", "1") != "0"
-conv3_autotune = conv_autotune and os.environ.get("MAF_TRAIN_TUNE3", "1") != "0"        # the 3 x 3 stride-2 launches (forward, data gradient) alone
+conv_autotune = cfg.train_tune
+conv3_autotune = conv_autotune and cfg.train_tune3        # the 3 x 3 stride-2 launches (forward, data gradient) alone
 _conv_tune = {}
 
 
@@ -1265,8 +1266,8 @@ def _dw_wgrad(x, dy, dys, w):
     return dwf.reshape(w.shape).to(w.dtype)
 
 
-stem_train = os.environ.get("MAF_STEM_TRAIN", "1") != "0"                # A/B switch: the image's two RepVGG convs as one direct-conv launch (csrc/stem_train.hip)
-dw_wgrad31 = os.environ.get("MAF_DW_WGRAD31", "1") != "0"                # A/B switch: the 3x3 (+ 3x3) + 1x1 branches' weight gradients as one launch (x staged once)
+stem_train = cfg.stem_train                # A/B switch: the image's two RepVGG convs as one direct-conv launch (csrc/stem_train.hip)
+dw_wgrad31 = cfg.dw_wgrad31                # A/B switch: the 3x3 (+ 3x3) + 1x1 branches' weight gradients as one launch (x staged once)
 
 
 def _dw_wgrad31_ok(x, ws):
@@ -1395,10 +1396,10 @@ class _DWBranches(torch.autograd.Function):
 
 
 _DWB_SETS = {3: (3, 3, 1), 5: (5, 3, 1), 7: (7, 5, 3), 9: (9, 7, 5, 3)}     # lk_origin + dil_branch_kernels(k) (arch.py), common.py:2997-3008
-dw_branches_merged = os.environ.get("MAF_DW_BRANCHES", "1") != "0"       # A/B switch: one launch per direction for the branches of a DilatedReparamBlock
+dw_branches_merged = cfg.dw_branches       # A/B switch: one launch per direction for the branches of a DilatedReparamBlock
 
 
-dw_branch_stats = os.environ.get("MAF_DW_BRANCH_STATS", "1") != "0"      # A/B switch: the branches' BatchNorm statistics out of the depth-wise kernel's epilogue
+dw_branch_stats = cfg.dw_branch_stats      # A/B switch: the branches' BatchNorm statistics out of the depth-wise kernel's epilogue
 _deterministic = False
 
 
@@ -1593,7 +1594,7 @@ def bn_act(x, bn, act=None, residual=None, pre_stats=None, out=None):
 # slot of the cat's gradient.  The in-place add is safe for what these two are built for: the gradient buffer is the data gradient the consumer conv has
 # just written, `join.backward` is its only reader, and the slot is not read again before the add (the block's backward, which produced the addend,
 # ran on OTHER slots).
-cat_free = os.environ.get("MAF_CAT_FREE", "1") != "0"
+cat_free = cfg.cat_free
 
 
 def cat_free_ok(x, bn):
@@ -1933,10 +1934,10 @@ class _BNSum(torch.autograd.Function):
         return (None, None, *dzs, *[dgb[j, 0] for j in range(nb)], *[dgb[j, 1] for j in range(nb)])
 
 
-bn_sum_merged = os.environ.get("MAF_BN_SUM", "1") != "0"               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
+bn_sum_merged = cfg.bn_sum               # A/B switch: the branch BatchNorms of a DilatedReparamBlock as one apply pass per direction
 
 
-bn_sum_next_stats = os.environ.get("MAF_BN_SUM_STATS", "1") != "0"       # A/B switch: the sum's apply pass accumulates the statistics of the BatchNorm behind it
+bn_sum_next_stats = cfg.bn_sum_stats       # A/B switch: the sum's apply pass accumulates the statistics of the BatchNorm behind it
 
 
 def bn_sum(zs, bns, pre_stats=None, act=None, out=None, next_bn=None):

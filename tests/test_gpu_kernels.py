@@ -474,40 +474,6 @@ def test_dwconv_dot2_variant(k, C_, H, W, th, tw, cb, two):
         assert (outs[0] - outs[1]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
 
 
-@pytest.mark.parametrize("k,C_,H,W,th,tw,nw", [(9, 576, 20, 20, 20, 20, 8), (9, 40, 20, 20, 10, 20, 4), (7, 72, 21, 27, 8, 16, 8), (5, 64, 33, 16, 16, 16, 4),
-                                               (3, 24, 16, 40, 4, 40, 1), (9, 192, 9, 11, 3, 8, 3), (5, 128, 80, 80, 16, 16, 8), (7, 288, 40, 40, 5, 40, 4),
-                                               (5, 128, 80, 80, 4, 80, 8)])
-@pytest.mark.parametrize("two", [False, True])
-def test_dwconv_scalar_weight_variant(k, C_, H, W, th, tw, nw, two):
-    """tile_p = -3 (csrc/dwconv_sw.hip): a wave per 8-channel group, halo plane by DMA (zero page outside the image), weights as scalar operands; odd
-    sizes, tiles hanging over the map, several passes of 64 strips and a ragged last pass, channel-group counts that do not fill the last workgroup,
-    slices of wider buffers, two filters per input channel; against F.conv2d in fp32 on the same fp16 operands and against the v_fma_mix kernel
-    (the same sums in the same order: equal after the fp16 rounding up to the accumulation of the bias)."""
-    g = torch.Generator().manual_seed(400 + k + C_)
-    B, dt = 2, lib.F16
-    cout = 2 * C_ if two else C_
-    x = _q(torch.randn(B, C_, H, W, generator=g), dt)
-    w = _q(torch.randn(cout, 1, k, k, generator=g) / k, dt)
-    bias = torch.randn(cout, generator=g)
-    xs = torch.zeros(B, H, W, C_ + 16, dtype=torch.float16, device=DEV)
-    xs[..., 8:8 + C_] = _nhwc(x, dt)
-    xin = torch.cat([x, x], 1) if two else x
-    for act in (lib.ACT_SILU, lib.ACT_NONE):
-        ref = _act(F.conv2d(xin, w, bias, 1, k // 2, 1, cout), act)
-        outs = []
-        for tp in (-3, 0):
-            out = torch.full((B, H, W, cout + 8), 3.0, dtype=torch.float16, device=DEV)
-            op = _conv_op(lib.OP_DWCONV, dt, B, H, W, C_, cout, act, [(xs, C_, C_ + 16, 8, 0)], out, cout + 8, 8,
-                          pack.pack_dw(w, dt).to(DEV), bias.to(DEV), tp, tw if tp else 0)
-            op.ksize = k
-            op.tile_k = th * 256 + nw if tp else 0
-            _launch(op)
-            _check(out[..., 8:], ref, dt)
-            assert (out[..., :8] == 3).all()
-            outs.append(out[..., 8:].float())
-        assert (outs[0] - outs[1]).abs().max() <= 2e-3 * ref.abs().max() + 2e-3
-
-
 @pytest.mark.parametrize("k,C_,H,W,th,tw,nw", [(9, 576, 20, 20, 20, 20, 8), (9, 40, 20, 20, 10, 20, 4), (7, 72, 21, 26, 8, 16, 8), (5, 64, 33, 16, 16, 16, 4),
                                                (3, 24, 16, 40, 4, 40, 1), (9, 192, 9, 12, 3, 8, 3), (5, 128, 80, 80, 16, 16, 8), (7, 288, 40, 40, 5, 40, 4),
                                                (5, 128, 80, 80, 4, 80, 8), (3, 16, 6, 10, 8, 12, 2)])

@@ -243,8 +243,11 @@ def test_replayed_backward_takes_over_a_foreign_gradient_tensor():
         for n in names:
             view = ex.slot[id(ps[n])][1]
             assert ps[n].grad.data_ptr() == view.data_ptr(), n
-        tol = lambda r: 2e-2 * float(r.abs().max()) + 1e-3
-        assert float((ps[names[0]].grad - 3.0 - ref[names[0]]).abs().max()) <= tol(ref[names[0]])
-        assert float((ps[names[1]].grad - ref[names[1]]).abs().max()) <= tol(ref[names[1]])
+        # (two steps of this small batch differ by the run-to-run noise of the fp16 step — atomics, arg-max flips: up to 10 % of max |g| on single elements — so the
+        #  check is on norms: a slice that kept the step before's gradient gives a relative error of 1.0, a lost foreign tensor shifts the median by 3)
+        rel = lambda a, r: float((a - r).norm() / r.norm())
+        g0, g1 = ps[names[0]].grad, ps[names[1]].grad
+        assert rel(g0 - 3.0, ref[names[0]]) < 0.4 and abs(float((g0 - ref[names[0]]).median()) - 3.0) < 0.5, (rel(g0 - 3.0, ref[names[0]]), float((g0 - ref[names[0]]).median()))
+        assert rel(g1, ref[names[1]]) < 0.4, rel(g1, ref[names[1]])
     finally:
         ex.close()

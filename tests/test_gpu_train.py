@@ -1750,7 +1750,7 @@ def test_detect_join_is_the_reference_train_branch_forward_and_backward(dtype, n
     group with ZEROS behind the view (68 -> 72 at fp16).  padded_src: the level maps are channel slices of wider buffers (a prediction conv's padded output rows)."""
     g = torch.Generator().manual_seed(nc)
     B, nr, hws = 3, 68, [(8, 12), (4, 6), (2, 3)]
-    heads, ref_heads = [], []
+    heads, ref_heads, leaves, raws = [], [], [], []
     for h, w in hws:
         lv = []
         for c in (nc, nr):
@@ -1761,7 +1761,13 @@ def test_detect_join_is_the_reference_train_branch_forward_and_backward(dtype, n
                 lv.append(buf[:, :c].detach().requires_grad_(True))
             else:
                 lv.append(t.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True))
-        heads.append((torch.zeros(B, 8, h, w, device=DEV), lv[0], lv[1]))
+        raw = []                                                        # the gradient tensors as the join's backward returns them (a leaf's .grad is a re-laid-out clone)
+        nonleaf = [t.view_as(t) for t in lv]
+        for t in nonleaf:
+            t.register_hook(lambda g_, raw=raw: raw.append(g_))
+        raws.append(raw)
+        heads.append((torch.zeros(B, 8, h, w, device=DEV), nonleaf[0], nonleaf[1]))
+        leaves.append(lv)
         ref_heads.append(tuple(t.detach().clone().requires_grad_(True) for t in lv))
     n0, g0 = train_ops.stats.get("native_detect_join", 0), train_ops.stats.get("glue", 0)
     cls, reg = train_ops.detect_join(heads)
@@ -1778,18 +1784,19 @@ def test_detect_join_is_the_reference_train_branch_forward_and_backward(dtype, n
     torch.autograd.backward([rcls, rreg], [dc, dr])
     assert train_ops.stats.get("native_detect_join", 0) == n0 + 2 and train_ops.stats.get("glue", 0) == g0
     mult = 8 if dtype == torch.float16 else 4
-    for (_, c, r), (rc, rr) in zip(heads, ref_heads):
+    for (c, r), (rc, rr) in zip(leaves, ref_heads):
         assert torch.equal(r.grad, rr.grad)
         d = (c.grad.float() - rc.grad.float()).abs().max().item()
         assert d <= (4e-3 if dtype == torch.float16 else 1e-6) * max(1.0, rc.grad.float().abs().max().item()), d
     # what the weight gradient / data gradient of the prediction convs read behind a 68-channel view: the kernel wrote zeros there and registered the pad
-    gr = heads[0][2].grad
+    gr = [g_ for g_ in raws[0] if g_.shape[1] == nr][0]
     if nr % mult:
         assert gr.stride()[1] == 1 and gr.stride()[3] == -(-nr // mult) * mult and train_ops.zero_padded.get(gr.data_ptr()) == gr.stride()[3]
         whole = torch.as_strided(gr, (B, gr.stride()[3], hws[0][0], hws[0][1]), gr.stride())
         assert float(whole[:, nr:].abs().max()) == 0.0
     # no gradient for one of the two outputs: zeros come back, not garbage
-    heads2 = [(f, c.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)) for f, c, r in heads]
+    heads2 = [(f, c.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True), r.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True))
+              for f, c, r in heads]
     cls2, reg2 = train_ops.detect_join(heads2)
     cls2.sum().backward()
     assert all(float(r.grad.abs().max()) == 0.0 for _, _, r in heads2) and all(float(c.grad.abs().max()) > 0.0 for _, c, _ in heads2)

@@ -172,12 +172,14 @@ def test_plan_builds_on_cpu(built, scale, nops32):
              "s": ["backbone.2.m.1+conv2", "backbone.4.m.1+conv2"], "m": ["backbone.2.m.1+conv2"]}[scale]
     one = tails if scale == "n" else []
     assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == one   # "auto" (default): blocks of ONE bottleneck only — every block of n
-    for env, want in (("3", tails), ("1", one), ("0", [])):             # MAF_FUSE_TAIL: 3 = "auto" takes every instantiation (s / m opt-in), 1 = the default rule, 0 = off
-        os.environ["MAF_FUSE_TAIL"] = env
+    from maf_yolo_amd.config import cfg, Config
+    for val, want in ((3, tails), (1, one), (0, [])):                   # cfg.fuse_tail (MAF_FUSE_TAIL): 3 = "auto" takes every instantiation (s / m opt-in), 1 = the default rule, 0 = off
+        keep, cfg.fuse_tail = cfg.fuse_tail, val
         try:
-            assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == want, env
+            assert [n for n in Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu")).op_names if n.endswith("+conv2")] == want, val
         finally:
-            del os.environ["MAF_FUSE_TAIL"]
+            cfg.fuse_tail = keep
+    assert Config({"MAF_FUSE_TAIL": "3", "MAF_STEP_TAPE": "0"}).overridden() == {"fuse_tail": 3, "step_tape": False} and Config({}).overridden() == {}
     m.fuse_tail = True
     wt = Plan(m, 2, 64, 64, lib.F16, lib.F16, torch.device("cpu"))                  # the block's closing conv inside its last bottleneck's launch
     assert [n for n in wt.op_names if n.endswith("+conv2")] == tails and not any(n[:-len(".m.0+conv2")] + ".conv2" in wt.op_names for n in tails)

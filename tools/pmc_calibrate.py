@@ -30,7 +30,8 @@ KINDS = {0: ("copy, 16-byte lanes", 1.0, 1.0), 1: ("copy, 8-byte lanes", 1.0, 1.
 def run():
     import torch
     from maf_yolo_amd import lib
-    L = lib.load()
+    lib.load()                                        # the product library (the probe library links it)
+    L = __import__("ctypes").CDLL(__import__("os").path.join(__import__("os").path.dirname(lib.LIB_PATH), "libmafyolo_probe.so"))   # `make -C maf-yolo_amd/csrc probe` (tools/probe.hip: not in the product)
     L.maf_probe_pmc_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]
     src = torch.randint(0, 255, (BYTES,), dtype=torch.uint8, device="cuda:0")
     dst = torch.empty(BYTES, dtype=torch.uint8, device="cuda:0")

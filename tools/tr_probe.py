@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maf_yolo_amd import lib  # noqa: E402
 
-L = lib.load()
+lib.load()                                        # the product library (the probe library links it)
+L = __import__("ctypes").CDLL(__import__("os").path.join(__import__("os").path.dirname(lib.LIB_PATH), "libmafyolo_probe.so"))   # `make -C maf-yolo_amd/csrc probe` (tools/probe.hip: not in the product)
 S = 72                                    # row stride in halfs
 lanes = torch.arange(64)
 g, p = lanes // 16, lanes % 16

@@ -9,7 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maf_yolo_amd import lib   # noqa: E402
 
-L = lib.load()
+lib.load()                                        # the product library (the probe library links it)
+L = __import__("ctypes").CDLL(__import__("os").path.join(__import__("os").path.dirname(lib.LIB_PATH), "libmafyolo_probe.so"))   # `make -C maf-yolo_amd/csrc probe` (tools/probe.hip: not in the product)
 L.maf_probe_valu_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_float)]
 torch.zeros(1, device="cuda:0")
 st = torch.cuda.current_stream().cuda_stream
