@@ -156,6 +156,51 @@ def infer_leg(torch, M, dev, scale, batch, steps, warmup, cs=None):
             "tiles": os.path.relpath(frozen[0], ROOT) if frozen else "timed at start-up"}
 
 
+def nms_leg(torch, M, dev, pred, conf, iou, reps=40):
+    """non_max_suppression ALONE on one batch of predictions (yolov6/utils/nms.py:31-105 at the settings of tools/eval.py: multi_label, max_det 300), milliseconds per
+    batch between two events on one stream, for two class distributions of the SAME boxes and scores:
+      synthetic_head      the timed workload's own prediction — its calibrated random head puts the ~2 000 candidates per image into two classes, so every image takes
+                          the ALL-PAIRS path (the worst case of the design: one kept-list scan over all candidates), also timed in rounds 2-5's matrix form;
+      classes_spread_80   the same tensor with every anchor's class scores rotated by (7 x anchor index) mod 80: the candidates spread over the 80 classes the way a
+                          trained detector's do (evaler.py:178 sees a few dozen per class) and nms_sort_kernel sends the images down the PER-CLASS path
+                          (nms_cscan_kernel: 80 short independent scans).
+    `images_on_per_class_path` is read back from the workspace's per-image flags after the last call."""
+    from maf_yolo_amd import nms as nms_mod, lib
+    B, N, no = pred.shape
+    nc = no - 5
+    rot = (torch.arange(nc, device=dev)[None, :] + 7 * torch.arange(N, device=dev)[:, None]) % nc
+    spread = pred.clone()
+    spread[..., 5:] = torch.gather(pred[..., 5:], 2, rot[None].expand(B, N, nc))
+    st = torch.cuda.current_stream(dev)
+
+    def timed(p, matrix=False):
+        keep, nms_mod.MATRIX_PATH = nms_mod.MATRIX_PATH, matrix
+        try:
+            for _ in range(5):
+                rows, idx, cnt = nms_mod.nms_raw(p, conf, iou, multi_label=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                rows, idx, cnt = nms_mod.nms_raw(p, conf, iou, multi_label=True)
+            e1.record(st)
+            torch.cuda.synchronize(dev)
+        finally:
+            nms_mod.MATRIX_PATH = keep
+        ws = nms_mod._workspace(dev, st, B, N, nc, 0)
+        flags = ws[:B * lib.NMS_CNT_STRIDE * 4].view(torch.int32).view(B, lib.NMS_CNT_STRIDE)      # per image one 256-byte line: [0] candidates, [1] per-class path taken (csrc/nms.hip)
+        return e0.elapsed_time(e1) / reps, int((flags[:, 1] != 0).sum()), float(flags[:, 0].float().mean()), float(cnt.float().mean())
+    out = {}
+    ms, pc, cand, det = timed(pred)
+    ms_m = timed(pred, matrix=True)[0]
+    out["synthetic_head"] = {"ms_per_batch": round(ms, 4), "images_on_per_class_path": pc, "candidates_per_image": round(cand, 1), "detections_per_image": round(det, 1),
+                             "path": "all-pairs: kept-list scan (csrc/nms.hip nms_greedy_kernel)", "matrix_form_ms_per_batch": round(ms_m, 4)}
+    ms, pc, cand, det = timed(spread)
+    out["classes_spread_80"] = {"ms_per_batch": round(ms, 4), "images_on_per_class_path": pc, "candidates_per_image": round(cand, 1), "detections_per_image": round(det, 1),
+                                "path": "per-class scans (nms_cscan_kernel)" if pc == B else "mixed"}
+    out["note"] = "NMS alone, one stream, %d calls between two events; same boxes and scores in both rows, class axis rotated per anchor in the second" % reps
+    return out
+
+
 def host_cores():
     """Host cores this process may use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box shows 256 CPUs, the container gets 16)
     and by 64 (oneDNN convs stop scaling beyond)."""
@@ -646,6 +691,10 @@ def main():
     torch.cuda.synchronize(dev)
     fwd_ms = 1e3 * (time.perf_counter() - t0) / args.steps
 
+    nms_alone = None
+    if rank == 0:
+        with torch.no_grad():
+            nms_alone = nms_leg(torch, M, dev, model(x)[0], conf, iou)
     out = None
     if rank == 0:
         plan = model.plan_for(x)
@@ -789,6 +838,10 @@ def main():
                "sequential": {"ms_per_step": round(seq_ms, 4), "images_per_s_per_gpu": round(B / (seq_ms * 1e-3), 1),
                               "note": "the same steps with no overlap: forward, NMS, result handed to the host, next forward (rank-local); the GPU idles "
                                       "during the host hand-over, so this one follows host jitter"},
+               "nms": nms_alone,
+               "parity_bar_of_the_timed_plan": "fp16 fused plan: every fused kernel within 2e-3 * max|ref| + 2e-3 of the unfused restatement (tests/test_gpu_fused_parity.py), end to end "
+                                               ">= 294 of 300 reference detections per image matched at IoU >= 0.95 and |d score| <= 2e-3 on 2 x 640^2 (n; s >= 290, m >= 280), NMS rows and "
+                                               "indices bit-identical to the reference fixtures; north_star's 1e-3 on boxes / scores is met by the fp32 plan (unfused kernels), not by this one",
                "roofline": roofline, "cpu_baseline": cpu}
     # ---- the training half of BASELINE's metric ("train imgs/s @1/2/4/8"): a short leg of the DDP train step (n, 32 images per GPU) inside the
     # same driver-timed run; `--train` is the long form (any scale / batch, per-kind roofline, CPU baseline)

@@ -241,7 +241,7 @@ void maf_engine_destroy(maf_engine_t* e);
  * does).  conf_thres is applied in fp32 (what `tensor > python_float` does).  The 10 s wall-clock
  * break (nms.py:101-103) is dropped.  max_det <= 1024.
  */
-enum { MAF_NMS_FLOAT_THRESHOLD = 1, MAF_NMS_SINGLE_LAUNCH = 2, MAF_NMS_PRECOLLECTED = 4 };
+enum { MAF_NMS_FLOAT_THRESHOLD = 1, MAF_NMS_SINGLE_LAUNCH = 2, MAF_NMS_PRECOLLECTED = 4, MAF_NMS_MATRIX = 8 };
 enum { MAF_NMS_CNT_STRIDE = 64 };       /* ints between the candidate counters of two images in the NMS workspace (one 256-byte line each) */
 /* maf_nms_ex flags.
  * MAF_NMS_FLOAT_THRESHOLD: compare the fp32 IoU with fl32(iou_thres) — torchvision's CUDA kernel (`float iou_threshold`), which is what
@@ -251,6 +251,9 @@ enum { MAF_NMS_CNT_STRIDE = 64 };       /* ints between the candidate counters o
  * MAF_NMS_SINGLE_LAUNCH: the whole call is ONE kernel (csrc/nms.hip:nms_single_kernel: every workgroup collects candidates, the last one to
  *   finish an image sorts and selects them) instead of seven; same results bit for bit.  Measured on configs[4] (m, bs 1): 0.29 ms against
  *   0.20 ms for the seven launches (whose pair-matrix kernel uses the whole chip) — available, not the default.
+ * MAF_NMS_MATRIX: images on the all-pairs path (<= 4096 candidates, no per-class split) build the n x n suppression bit matrix on the whole chip and scan its rows
+ *   (rounds 2-5's form, two launches) instead of the kept-list scan (one workgroup per image tests every block of 64 sorted candidates against the boxes kept so
+ *   far only; the default since round 6).  Same survivors bit for bit; kept for A/B.
  * MAF_NMS_PRECOLLECTED: the candidate lists of `workspace` (counters + keys) are already there — written by the forward pass that produced `pred`
  *   (maf_engine_run_filtered: the head-tail kernels test the scores they have just computed against the same conf_thres) — so the call skips its
  *   counter reset and its pass over the prediction tensor.  Only for multi_label with nc > 1, no class filter, conf_thres < 1. */

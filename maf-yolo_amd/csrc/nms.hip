@@ -803,6 +803,115 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
     if (tid == 0) a.out_count[b] = nk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Kept-list greedy scan of the all-pairs path (round 6; replaces nms_mask_kernel + nms_scan_kernel by default, which stay behind MAF_NMS_MATRIX for A/B):
+// one workgroup of 16 waves per image walks the score-sorted candidates 64 at a time and tests a block only against the boxes KEPT so far (<= max_det) and
+// against itself — n x kept / 2 + 64 n pairs (~0.3 M for 2 000 candidates, 300 kept) instead of the n^2 / 2 of the matrix (2.1 M), no n x n bit matrix in HBM,
+// one launch less.  Per block: wave w tests kept boxes w, w + 16, ... against the block's 64 candidates (lane = candidate; the kept box is a wave-uniform LDS
+// broadcast, one ballot = its 64 verdicts), rows w, w + 16, w + 32, w + 48 of the block's own 64 x 64 triangle the same way; wave 0 then runs the serial rule
+// of the matrix scan (a survivor clears the later candidates it overlaps) and appends the survivors to the kept list.  Same predicate (iou_screen, iou_gt in the
+// band), same (earlier, later) operand order, same greedy order: the survivors are those of the matrix path bit for bit (tests/test_gpu_model.py compares both).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kGreedyT = 1024;
+
+__global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
+    __shared__ Cand kept[kMaxDetCap];                          // 32 KiB
+    __shared__ Cand cb[64];
+    __shared__ unsigned long long diag[64];                    // diag[i] bit j (> i): candidate i of the block overlaps candidate j
+    __shared__ unsigned int dead_lo, dead_hi;                  // candidates of the block a kept box overlaps
+    __shared__ int s_nk;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.cnt[b * kCntStride + 1]) return;                     // the per-class path has this image
+    long long n64 = a.cnt[b * kCntStride];
+    const long long cap = (long long)a.N * a.nc;
+    if (n64 > cap) n64 = cap;
+    const int n = (int)n64;
+    if (n == 0 || n > kMaskN) return;                          // (no candidates: nms_select_kernel has written the zero count; more than kMaskN: it runs the image)
+    const int nb = (n + 63) >> 6;
+    const IouThr iouthr = {a.iou, a.iou_m, a.iou_even, (float)a.iou_m};
+    const Cand* cands = a.cands + (size_t)b * kMaskN;
+    if (tid == 0) s_nk = 0;
+    Cand nxt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+    if (tid < 64 && tid < n) nxt = cands[tid];
+    for (int blk = 0; blk < nb; ++blk) {
+        __syncthreads();                                       // the block before is decided: cb / diag / dead are free, s_nk is final
+        const int nk = s_nk;
+        if (nk >= a.max_det) break;                            // uniform
+        const int nvalid = min(64, n - blk * 64);
+        if (tid < 64) {
+            cb[tid] = nxt;
+            const int i2 = (blk + 1) * 64 + tid;
+            if (i2 < n) nxt = cands[i2];                       // the next block's candidates travel while this one is tested
+        }
+        if (tid == 0) { dead_lo = 0u; dead_hi = 0u; }
+        __syncthreads();
+        const Cand me = cb[lane];
+        const bool valid = lane < nvalid;
+        for (int i = wave; i < nvalid; i += kGreedyT / 64) {   // the block's own triangle: row i = candidate i against the later ones
+            bool hit = false;
+            if (valid && lane > i) {
+                const Cand ci = cb[i];
+                const int r = iou_screen(ci, me, iouthr.m32);
+                hit = r > 0;
+                if (r < 0) hit = iou_gt(ci, me, iouthr);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) diag[i] = m;
+        }
+        unsigned long long dead = 0;                           // wave-uniform
+        for (int k = wave; k < nk; k += kGreedyT / 64) {       // kept boxes (all earlier in score order) against the block
+            bool hit = false;
+            if (valid) {
+                const Cand kc = kept[k];
+                const int r = iou_screen(kc, me, iouthr.m32);
+                hit = r > 0;
+                if (r < 0) hit = iou_gt(kc, me, iouthr);
+            }
+            dead |= __ballot(hit);
+        }
+        if (lane == 0 && dead) { atomicOr(&dead_lo, (unsigned int)dead); atomicOr(&dead_hi, (unsigned int)(dead >> 32)); }
+        __syncthreads();
+        if (wave == 0) {                                       // the serial rule of the matrix scan on this block
+            const unsigned long long dg = valid ? diag[lane] : 0ull;
+            const unsigned int dlo = (unsigned int)dg, dhi = (unsigned int)(dg >> 32);
+            const unsigned long long dd = ((unsigned long long)dead_hi << 32) | dead_lo;
+            unsigned long long todo = ~dd & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
+            unsigned long long keep = 0;
+            int room = a.max_det - nk;
+            while (todo != 0 && room > 0) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                keep |= 1ull << j;
+                --room;
+                const unsigned long long dj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)dlo, j);
+                todo &= ~dj;
+            }
+            if ((keep >> lane) & 1ull) kept[nk + __popcll(keep & ((1ull << lane) - 1ull))] = me;
+            if (lane == 0) s_nk = nk + __popcll(keep);
+        }
+    }
+    __syncthreads();
+    // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)
+    const int nk = s_nk < a.max_det ? s_nk : a.max_det;
+    const int no = 5 + a.nc;
+    const float* pred = a.pred + (size_t)b * a.N * no;
+    float* orow = a.out_rows + (size_t)b * a.max_det * 6;
+    long long* oidx = a.out_idx + (size_t)b * a.max_det;
+    for (int k = tid; k < nk; k += kGreedyT) {
+        const Cand& c = kept[k];
+        const unsigned int flat = c.flat;
+        const unsigned int box = flat / (unsigned int)a.nc;
+        const int cls = (int)(flat - box * (unsigned int)a.nc);
+        const float* r = pred + (size_t)box * no;
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float* o = orow + (size_t)k * 6;
+        o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2; o[4] = c.score; o[5] = (float)cls;
+        oidx[k] = a.multi_label ? (long long)flat : (long long)box;
+    }
+    if (tid == 0) a.out_count[b] = nk;
+}
+
 long long pow2ceil(long long v) {
     long long p = 1;
     while (p < v) p <<= 1;
@@ -905,7 +1014,11 @@ extern "C" int maf_nms_ex(const float* pred, int32_t B, int32_t N, int32_t nc, d
     hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(kSelT), 0, s, a);        // images with > kMaskN candidates (others return at once)
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(kSortT), 0, s, a);
     if (a.cpath_ok) hipLaunchKernelGGL(nms_cscan_kernel, dim3(B), dim3(kSortT), 0, s, a);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskWgs, B), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
+    if (flags & MAF_NMS_MATRIX) {                                // A/B: the n x n suppression matrix (every pair tested by the whole chip) + the serial scan over its rows
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(kMaskWgs, B), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(kGreedyT), 0, s, a);
+    }
     return maf_check_hip(hipGetLastError(), "nms_select launch");
 }

@@ -12,6 +12,8 @@ LIB_PATH = cfg.hip_lib or os.path.join(_HERE, "libmafyolo_hip.so")     # MAF_HIP
 F16, F32, U8 = 0, 1, 2
 NMS_FLOAT_THRESHOLD = 1
 NMS_PRECOLLECTED = 4         # maf_nms_ex flag: the forward pass (maf_engine_run_filtered) has written the candidate lists of the workspace
+NMS_CNT_STRIDE = 64           # MAF_NMS_CNT_STRIDE: ints between the counter lines of two images at the start of the NMS workspace
+NMS_MATRIX = 8                # maf_nms_ex flag: the all-pairs path as suppression matrix + scan (rounds 2-5) instead of the kept-list scan (A/B)
 NMS_SINGLE_LAUNCH = 2         # maf_nms_ex flag: one launch (collect, then the last workgroup of every image sorts and selects) — the latency path
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_DIRECT, SRC_UP2, SRC_POOL2, SRC_SUB2, SRC_PAIRS = 0, 1, 2, 3, 4

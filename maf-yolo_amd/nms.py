@@ -106,7 +106,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
                                    cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
                                    int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
                                    (lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0) | (lib.NMS_SINGLE_LAUNCH if _single_launch(B) else 0)
-                                   | (lib.NMS_PRECOLLECTED if pre else 0), st.cuda_stream))
+                                   | (lib.NMS_PRECOLLECTED if pre else 0) | (lib.NMS_MATRIX if MATRIX_PATH else 0), st.cuda_stream))
             if pre:
                 ev = torch.cuda.Event()
                 ev.record(st)
@@ -118,6 +118,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
 
 
 SINGLE_LAUNCH_MAX_BATCH = cfg.nms_single_max_batch
+MATRIX_PATH = cfg.nms_matrix       # A/B: the all-pairs path as n x n suppression matrix + scan (csrc/nms.hip nms_mask_kernel / nms_scan_kernel) instead of the kept-list scan
 
 
 def _single_launch(B):

@@ -193,6 +193,48 @@ def test_nms_single_launch_form_is_bit_identical(golden, name, monkeypatch):
         assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
 
 
+@pytest.mark.parametrize("name", sorted(nms_cases.cases().keys()))
+def test_nms_matrix_form_is_bit_identical(golden, name, monkeypatch):
+    """maf_nms_ex flag MAF_NMS_MATRIX — the all-pairs path as rounds 2-5 ran it (n x n suppression bit matrix on the whole chip + a serial scan of its rows) — against
+    the same reference fixtures and oracle indices as the default kept-list scan (csrc/nms.hip:nms_greedy_kernel), which every other NMS test of this file exercises."""
+    from maf_yolo_amd import nms as nms_mod
+    monkeypatch.setattr(nms_mod, "MATRIX_PATH", True)
+    g = golden("nms_cases")
+    pred, kw = nms_cases.cases()[name]
+    out, idx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), return_index=True, **kw)
+    _, oi = O.non_max_suppression(pred, return_index=True, **kw)
+    assert [o.shape[0] for o in out] == list(g[name + "__n"])
+    for b, o in enumerate(out):
+        assert np.array_equal(o.cpu().numpy(), g["%s__%d" % (name, b)]), (name, b)
+        assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
+
+
+@pytest.mark.parametrize("max_det", [1, 64, 65, 300, 1000])
+@pytest.mark.parametrize("n_cand", [1, 63, 64, 65, 700, 2500, 4096])
+def test_nms_kept_list_scan_against_the_matrix_form_and_the_oracle(n_cand, max_det, monkeypatch):
+    """The kept-list scan over every block boundary it has (one candidate, a ragged first block, exactly one / one-plus blocks, many blocks, the path's 4096-candidate
+    limit) and kept-list lengths from 1 to past the block size and up to 1000: dense overlapping boxes in two classes (the benchmark's distribution: the all-pairs path),
+    rows and indices equal to the oracle's and to the matrix form's."""
+    from maf_yolo_amd import nms as nms_mod
+    rng = np.random.RandomState(n_cand * 7 + max_det)
+    N, nc = 8400, 80
+    pred = np.zeros((2, N, 5 + nc), np.float32)
+    for b in range(2):
+        pred[b, :, 0:2] = rng.uniform(100, 540, (N, 2)); pred[b, :, 2:4] = rng.uniform(20, 160, (N, 2))
+        pred[b, :, 4] = 1.0
+        pred[b, :, 5:] = 0.001
+        rows = rng.choice(N, n_cand, replace=False)
+        pred[b, rows, 5 + 3 * rng.randint(0, 2, n_cand)] = rng.uniform(0.05, 0.99, n_cand).astype(np.float32)
+    want, widx = O.non_max_suppression(pred, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)
+    x = torch.from_numpy(pred).to(DEV)
+    got, gidx = M.non_max_suppression(x, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)
+    monkeypatch.setattr(nms_mod, "MATRIX_PATH", True)
+    mat, midx = M.non_max_suppression(x, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)
+    for b in range(2):
+        assert np.array_equal(gidx[b].cpu().numpy(), widx[b]) and np.array_equal(got[b].cpu().numpy(), want[b]), (n_cand, max_det, b)
+        assert torch.equal(gidx[b], midx[b]) and torch.equal(got[b], mat[b]), (n_cand, max_det, b)
+
+
 @pytest.mark.parametrize("conf,kw", [(0.03, dict(iou_thres=0.65, multi_label=True)), (0.25, dict(iou_thres=0.45, multi_label=True, agnostic=True)),
                                      (0.001, dict(iou_thres=0.65, multi_label=True, max_det=1000))])
 def test_candidate_filter_inside_the_forward_gives_the_same_detections(models, conf, kw):
