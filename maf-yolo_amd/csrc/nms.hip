@@ -807,19 +807,22 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
 // Kept-list greedy scan of the all-pairs path (round 6; replaces nms_mask_kernel + nms_scan_kernel by default, which stay behind MAF_NMS_MATRIX for A/B):
 // one workgroup of 16 waves per image walks the score-sorted candidates 64 at a time and tests a block only against the boxes KEPT so far (<= max_det) and
 // against itself — n x kept / 2 + 64 n pairs (~0.3 M for 2 000 candidates, 300 kept) instead of the n^2 / 2 of the matrix (2.1 M), no n x n bit matrix in HBM,
-// one launch less.  Per block: wave w tests kept boxes w, w + 16, ... against the block's 64 candidates (lane = candidate; the kept box is a wave-uniform LDS
-// broadcast, one ballot = its 64 verdicts), rows w, w + 16, w + 32, w + 48 of the block's own 64 x 64 triangle the same way; wave 0 then runs the serial rule
-// of the matrix scan (a survivor clears the later candidates it overlaps) and appends the survivors to the kept list.  Same predicate (iou_screen, iou_gt in the
+// one launch less.  Per block: a wave tests every 16th kept box against the block's 64 candidates (lane = candidate; the kept box is a wave-uniform LDS
+// broadcast, one ballot = its 64 verdicts) and every 16th row of the block's own 64 x 64 triangle the same way; wave 0 then runs the serial rule of the matrix
+// scan (a survivor clears the later candidates it overlaps) and appends the survivors to the kept list.  Two blocks are in flight: while wave 0 decides block k
+// the other 15 waves test block k + 1 against its triangle and the boxes kept before, and only the (<= 64) boxes block k adds are tested behind the barrier.
+// Same predicate (iou_screen, iou_gt in the
 // band), same (earlier, later) operand order, same greedy order: the survivors are those of the matrix path bit for bit (tests/test_gpu_model.py compares both).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kGreedyT = 1024;
 
 __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
     __shared__ Cand kept[kMaxDetCap];                          // 32 KiB
-    __shared__ Cand cb[64];
-    __shared__ unsigned long long diag[64];                    // diag[i] bit j (> i): candidate i of the block overlaps candidate j
-    __shared__ unsigned int dead_lo, dead_hi;                  // candidates of the block a kept box overlaps
+    __shared__ Cand cb[2][64];                                 // the block being decided and the one being tested behind it
+    __shared__ unsigned long long diag[2][64];                 // diag[.][i] bit j (> i): candidate i of the block overlaps candidate j
+    __shared__ unsigned int dead_lo[2], dead_hi[2];            // candidates of the block a kept box overlaps
     __shared__ int s_nk;
+    constexpr int NWV = kGreedyT / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.cnt[b * kCntStride + 1]) return;                     // the per-class path has this image
     long long n64 = a.cnt[b * kCntStride];
@@ -830,55 +833,75 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
     const int nb = (n + 63) >> 6;
     const IouThr iouthr = {a.iou, a.iou_m, a.iou_even, (float)a.iou_m};
     const Cand* cands = a.cands + (size_t)b * kMaskN;
-    if (tid == 0) s_nk = 0;
-    Cand nxt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-    if (tid < 64 && tid < n) nxt = cands[tid];
-    for (int blk = 0; blk < nb; ++blk) {
-        __syncthreads();                                       // the block before is decided: cb / diag / dead are free, s_nk is final
+    const Cand zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+    // one (earlier box, this lane's candidate) verdict per lane, boxes as scalars in registers (a Cand handed on by reference went through scratch: 48 B of
+    // private memory per lane and a global-memory round trip per test); the exact form only when some lane of the wave sits inside the screen's band
+    // (wave-uniform branch)
+    struct Box { float x1, y1, x2, y2, area; };
+    auto ld = [&](const Cand* p) -> Box {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
+        return Box{v[0], v[1], v[2], v[3], p->area};
+    };
+    auto overlaps = [&](const Box k, const Box c, bool on) -> unsigned long long {
+        const float w = fmaxf(0.f, fminf(k.x2, c.x2) - fmaxf(k.x1, c.x1)), h = fmaxf(0.f, fminf(k.y2, c.y2) - fmaxf(k.y1, c.y1));
+        const float inter = w * h, uni = k.area + c.area - inter;
+        const float d = __builtin_fmaf(-iouthr.m32, uni, inter);                 // = iou_screen
+        const bool decided = uni > 0.f && fabsf(d) > 3e-7f * uni;
+        bool hit = on && decided && d > 0.f;
+        if (__any(on && !decided)) {
+            if (on && !decided) {
+                const Cand kc = {k.x1, k.y1, k.x2, k.y2, k.area, 0.f, 0u, 0u}, cc = {c.x1, c.y1, c.x2, c.y2, c.area, 0.f, 0u, 0u};
+                hit = iou_gt(kc, cc, iouthr);
+            }
+        }
+        return __ballot(hit);
+    };
+    // tests of block `blk` (in cb[buf]) that do not need the verdict on the block before it: its own triangle, and the kept boxes [k0, k1); waves [w0, NWV) share them
+    auto test_block = [&](int blk, int buf, int k0, int k1, bool triangle, int w0) {
+        const int nvalid = min(64, n - blk * 64);
+        const bool valid = lane < nvalid;
+        const Box me = ld(&cb[buf][lane]);
+        const int nw = NWV - w0, w = wave - w0;
+        if (w < 0) return;
+        if (triangle)
+            for (int i = w; i < nvalid; i += nw) {
+                const unsigned long long m = overlaps(ld(&cb[buf][i]), me, valid && lane > i);
+                if (lane == 0) diag[buf][i] = m;
+            }
+        unsigned long long dead = 0;                           // wave-uniform
+        int k = k0 + w;
+        for (; k + nw < k1; k += 2 * nw) {                     // two kept boxes per step: both LDS reads in flight before the first is used
+            const Box ka = ld(&kept[k]), kb = ld(&kept[k + nw]);
+            dead |= overlaps(ka, me, valid);
+            dead |= overlaps(kb, me, valid);
+        }
+        if (k < k1) dead |= overlaps(ld(&kept[k]), me, valid);
+        if (lane == 0 && dead) { atomicOr(&dead_lo[buf], (unsigned int)dead); atomicOr(&dead_hi[buf], (unsigned int)(dead >> 32)); }
+    };
+    if (tid == 0) { s_nk = 0; dead_lo[0] = dead_hi[0] = dead_lo[1] = dead_hi[1] = 0u; }
+    if (tid < 64) cb[0][tid] = tid < n ? cands[tid] : zero;
+    else if (tid < 128) cb[1][tid - 64] = tid < n ? cands[tid] : zero;
+    Cand nxt = zero;                                           // lanes 0..63 of wave 0: the block two ahead travels while the current ones are tested
+    if (tid < 64 && 128 + tid < n) nxt = cands[128 + tid];
+    __syncthreads();
+    test_block(0, 0, 0, 0, true, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int blk = 0; blk < nb; ++blk, buf ^= 1) {
+        // here: cb[buf] = block blk with its triangle and its verdicts against EVERY kept box so far complete; cb[buf ^ 1] = block blk + 1, untested
         const int nk = s_nk;
         if (nk >= a.max_det) break;                            // uniform
-        const int nvalid = min(64, n - blk * 64);
-        if (tid < 64) {
-            cb[tid] = nxt;
-            const int i2 = (blk + 1) * 64 + tid;
-            if (i2 < n) nxt = cands[i2];                       // the next block's candidates travel while this one is tested
-        }
-        if (tid == 0) { dead_lo = 0u; dead_hi = 0u; }
-        __syncthreads();
-        const Cand me = cb[lane];
-        const bool valid = lane < nvalid;
-        for (int i = wave; i < nvalid; i += kGreedyT / 64) {   // the block's own triangle: row i = candidate i against the later ones
-            bool hit = false;
-            if (valid && lane > i) {
-                const Cand ci = cb[i];
-                const int r = iou_screen(ci, me, iouthr.m32);
-                hit = r > 0;
-                if (r < 0) hit = iou_gt(ci, me, iouthr);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) diag[i] = m;
-        }
-        unsigned long long dead = 0;                           // wave-uniform
-        for (int k = wave; k < nk; k += kGreedyT / 64) {       // kept boxes (all earlier in score order) against the block
-            bool hit = false;
-            if (valid) {
-                const Cand kc = kept[k];
-                const int r = iou_screen(kc, me, iouthr.m32);
-                hit = r > 0;
-                if (r < 0) hit = iou_gt(kc, me, iouthr);
-            }
-            dead |= __ballot(hit);
-        }
-        if (lane == 0 && dead) { atomicOr(&dead_lo, (unsigned int)dead); atomicOr(&dead_hi, (unsigned int)(dead >> 32)); }
-        __syncthreads();
-        if (wave == 0) {                                       // the serial rule of the matrix scan on this block
-            const unsigned long long dg = valid ? diag[lane] : 0ull;
+        // ---- stage A: wave 0 decides block blk (the serial rule of the matrix scan); the other waves test block blk + 1 against its own triangle and the boxes kept BEFORE
+        if (wave == 0) {
+            const int nvalid = min(64, n - blk * 64);
+            const Cand me = cb[buf][lane];
+            const unsigned long long dg = lane < nvalid ? diag[buf][lane] : 0ull;
             const unsigned int dlo = (unsigned int)dg, dhi = (unsigned int)(dg >> 32);
-            const unsigned long long dd = ((unsigned long long)dead_hi << 32) | dead_lo;
+            const unsigned long long dd = ((unsigned long long)dead_hi[buf] << 32) | dead_lo[buf];
             unsigned long long todo = ~dd & (nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull));
             unsigned long long keep = 0;
             int room = a.max_det - nk;
-            while (todo != 0 && room > 0) {
+            while (todo != 0 && room > 0) {                    // one step per SURVIVOR: it clears the later candidates it overlaps
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 keep |= 1ull << j;
@@ -888,8 +911,22 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
                 todo &= ~dj;
             }
             if ((keep >> lane) & 1ull) kept[nk + __popcll(keep & ((1ull << lane) - 1ull))] = me;
-            if (lane == 0) s_nk = nk + __popcll(keep);
+            if (lane == 0) { s_nk = nk + __popcll(keep); dead_lo[buf] = 0u; dead_hi[buf] = 0u; }
+        } else if (blk + 1 < nb) {
+            test_block(blk + 1, buf ^ 1, 0, nk, true, 1);
         }
+        __syncthreads();
+        if (blk + 1 >= nb) break;
+        // ---- stage B: everybody tests block blk + 1 against the boxes block blk has just added; block blk + 2 takes the free buffer
+        const int nk2 = s_nk;
+        if (nk2 >= a.max_det) break;
+        test_block(blk + 1, buf ^ 1, nk, nk2, false, 0);
+        if (tid < 64) {
+            cb[buf][tid] = nxt;
+            const int i3 = (blk + 3) * 64 + tid;
+            nxt = i3 < n ? cands[i3] : zero;
+        }
+        __syncthreads();
     }
     __syncthreads();
     // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)

@@ -88,3 +88,31 @@ def cases():
     out["cross_band"] = (np.concatenate([b, np.ones((n, 1), np.float32), cls], 1)[None],
                          dict(conf_thres=0.25, iou_thres=0.3, multi_label=True))
     return out
+
+
+# ---- shared by the detection-level parity tests (GPU and CPU): one-to-one matching of detection rows
+def _iou(a, b):
+    """a [n,4], b [m,4] xyxy -> [n,m]"""
+    lt = np.maximum(a[:, None, :2], b[None, :, :2]); rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None] - inter + 1e-12)
+
+
+def match_detections(got, ref, iou_min=0.95, dscore=1e-2):
+    """Greedy one-to-one matching of detection rows (x1,y1,x2,y2,conf,cls) by class, IoU >= iou_min and |d score| <= dscore.
+    Returns (matched pairs, unmatched reference rows, unmatched rows of `got`)."""
+    iou = _iou(ref[:, :4], got[:, :4])
+    ok = (iou >= iou_min) & (ref[:, None, 5] == got[None, :, 5]) & (np.abs(ref[:, None, 4] - got[None, :, 4]) <= dscore)
+    used = np.zeros(got.shape[0], bool)
+    pairs, miss = [], []
+    for i in range(ref.shape[0]):
+        cand = np.where(ok[i] & ~used)[0]
+        if cand.size == 0:
+            miss.append(i)
+            continue
+        j = cand[np.argmax(iou[i, cand])]
+        used[j] = True
+        pairs.append((i, j))
+    return pairs, miss, np.where(~used)[0].tolist()

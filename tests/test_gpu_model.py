@@ -113,6 +113,31 @@ def test_headline_shape_640_vs_reference_golden(golden, models):
         assert np.array_equal(dets[b].cpu().numpy(), odets[b]) and np.array_equal(idx[b].cpu().numpy(), oidx[b])
 
 
+def test_config0_batch8_640_vs_reference_golden(golden, models):
+    """BASELINE configs[0] at its stated batch — MAF-YOLO-n, 8 x 3 x 640 x 640, forward + NMS(0.03 / 0.65 / multi_label) as tools/eval.py runs them — against what the
+    REFERENCE computed for the same eight images on the CPU (tests/golden/maf_n_b8.npz, tools/make_golden_b8.py): every 64th anchor row and the float64 column sums over
+    all 8 400 anchors of the fp32 plan's prediction (north_star's 1e-3), the fp16 plan at its fp16-class bars, and the detections: the NMS of the fp32 prediction equals the
+    oracle's on the same tensor bit for bit, and matches the reference's own rows (computed from ITS fp32 prediction, 1e-4 away) one to one where no pair sits at a threshold."""
+    from nms_cases import match_detections
+    g = golden("maf_n_b8")
+    x = O.synth_images(8, 640, 1).to(DEV)
+    with torch.no_grad():
+        p32 = models["n"](x)[0]
+        p16 = models["n"](x.half())[0]
+    assert p32.shape == (8, 8400, 85)
+    _close32(p32[:, ::64].cpu().numpy(), g["pred640_b8_rows64"])
+    np.testing.assert_allclose(p32.double().sum(1).cpu().numpy(), g["pred640_b8_colsum"], rtol=1e-5, atol=1e-2)
+    _close16(p16[:, ::64].cpu().numpy(), g["pred640_b8_rows64"])
+    dets, idx = M.non_max_suppression(p32, 0.03, 0.65, multi_label=True, return_index=True)
+    odets, oidx = O.non_max_suppression(p32.cpu().numpy(), 0.03, 0.65, multi_label=True, return_index=True)
+    assert [d.shape[0] for d in dets] == list(g["nms640_b8_n"])
+    for b in range(8):
+        assert np.array_equal(dets[b].cpu().numpy(), odets[b]) and np.array_equal(idx[b].cpu().numpy(), oidx[b])
+        ref = g["nms640_b8_%d" % b]
+        pairs, miss, extra = match_detections(dets[b].cpu().numpy(), ref, iou_min=0.99, dscore=1e-3)
+        assert len(pairs) >= ref.shape[0] - 3, (b, len(pairs), miss)     # (fp32 vs fp32: a row can only move at the max_det cut or at an IoU on the threshold)
+
+
 def test_batch32_consistency_and_uint8_input(models):
     """BASELINE config[1] size: image i of a 32-batch gives the same rows as when run alone (fp16 engine);
     uint8 input with /255 folded into the stem equals float input."""
@@ -855,7 +880,7 @@ def test_eval_loop_matches_the_reference_evaler_fixture(golden, fold):
     loop16 = M.EvalLoop(m, conf_thres=0.03, iou_thres=0.65, half=True, ids=G.COCO_IDS, fold_preprocess=fold)
     res16 = loop16.predict_model(G.batches())
     assert len(res16) == 1500
-    from test_gpu_fused_parity import match_detections       # same-class, IoU >= 0.95, |d score| <= 1e-2, one-to-one
+    from nms_cases import match_detections       # same-class, IoU >= 0.95, |d score| <= 1e-2, one-to-one
 
     def rows_of(img, ids_, cats, boxes, scores):
         k = np.asarray(ids_) == img

@@ -462,13 +462,13 @@ _AMP_BARS_N_BY_STAGE = ((31, (0.15, 3e-2)), (9, (0.3, 4e-2)), (0, (0.7, 0.25))) 
 _AMP_HEAD = {"n": (5e-3, 6e-2), "s": (5e-3, 1e-1), "m": (1e-2, 3e-1)}
 
 
-def _reference_assignment(g, tag, targets, dev):
+def _reference_assignment(g, tag, targets, dev, size=128):
     """The label assignment the REFERENCE's own assigner made in the fixture's pass (tools/make_golden_train.py stores what `warmup_assigner` /
     `formal_assigner` returned, yolov6/models/loss.py:83-100) in the form ComputeLoss(assignment=) takes: (row of the assigned label per anchor or -1
     [B, A] int32, target score [B, A] fp32).  The labels of the fixture are grouped by image, so a label's row is its row in `targets`."""
     fg, box, lab, sc = g[tag + "_asg_fg"], g[tag + "_asg_box"], g[tag + "_asg_label"], g[tag + "_asg_score"]
     t = targets.cpu().numpy()
-    xyxy = np.stack([t[:, 2] - t[:, 4] / 2, t[:, 3] - t[:, 5] / 2, t[:, 2] + t[:, 4] / 2, t[:, 3] + t[:, 5] / 2], 1) * 128.0
+    xyxy = np.stack([t[:, 2] - t[:, 4] / 2, t[:, 3] - t[:, 5] / 2, t[:, 2] + t[:, 4] / 2, t[:, 3] + t[:, 5] / 2], 1) * float(size)
     out_gt = np.full(fg.shape, -1, np.int32)
     for b, a in zip(*np.nonzero(fg)):
         rows = [j for j in range(len(t)) if int(t[j, 0]) == b and int(t[j, 1]) == int(lab[b, a]) and np.abs(xyxy[j] - box[b, a]).max() < 1e-2]
@@ -488,11 +488,25 @@ def test_train_step_matches_reference_gradients(golden, tag, epoch, kw, amp, sca
     deviating parameter upstream of SPPF, loss and head outputs unchanged): the fp32 atomics of the BatchNorm statistics land in another order every run,
     one ulp in SPPF's input flips a near-tied arg-max of its cascaded 5 x 5 max-pools, and the BACKWARD pass routes that gradient to the other pixel —
     legitimate behaviour of an order-dependent reduction, and not what a parity test should sample.  The fp32 leg therefore runs with bit-reproducible
-    BatchNorm statistics (train_ops.set_deterministic: per-workgroup slots added in a fixed order instead of atomics)."""
-    if not amp:
-        train_ops.set_deterministic(True)
+    BatchNorm statistics (train_ops.set_deterministic: per-workgroup slots added in a fixed order instead of atomics).
+    The AMP leg runs with the fixed-order statistics too (round 6): ONE realisation of the fp16 step, the same one every run, is held against the framework's
+    autocast step — rounds 4-5 took the best of five to seven atomic-order realisations, the most forgiving statistic there is."""
+    train_ops.set_deterministic(True)
     try:
         _train_step_vs_reference(golden, tag, epoch, kw, amp, scale)
+    finally:
+        train_ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize("tag,epoch,kw", [("tal", 5, dict(warmup_epoch=0)), ("atss", 0, dict())])
+def test_train_step_at_640_matches_reference_gradients(golden, tag, epoch, kw):
+    """The same pin at the BASELINE image size: ONE train step of n on 2 x 3 x 640 x 640 — 8 400 anchors per image, the 160 x 160 ... 20 x 20 maps the
+    benchmarked step runs on, every kernel on its full-size tiling — against the reference's own fp32 loss, head outputs, assignment and 32 parameter gradients of
+    every layer kind (tests/golden/train_n_640.npz: tools/make_golden_train.py n 640, the reference's Model + ComputeLoss + autograd on the CPU), fixed-order
+    statistics, same bars as the 128 x 128 fixtures."""
+    train_ops.set_deterministic(True)
+    try:
+        _train_step_vs_reference(golden, tag, epoch, kw, False, "n", size=640)
     finally:
         train_ops.set_deterministic(False)
 
@@ -574,7 +588,7 @@ def test_train_step_default_statistics_match_reference_gradients(golden, tag, ep
                 train_ops.set_deterministic(False)
 
 
-def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False):
+def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False, size=128):
     """a15 pinned to the REFERENCE for all three graphs of BASELINE's configs (n; s = configs[2]; m = configs[3]): train-mode forward of the
     HIP-backed module tree + device ComputeLoss + backward == the reference's own Model.train() + ComputeLoss + autograd on the same seeded
     weights, images and labels (tools/make_golden_train.py <scale>, CPU fp32): loss, items, head outputs, 32+ parameter gradients of every
@@ -583,14 +597,15 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False
     ASSIGNMENT FROZEN to the one the fp32 pass made on the same inputs (autocast moves the head outputs by ~1e-3, which flips a few of the
     assigner's discrete top-k choices; that is a property of the recipe, not of the kernels) — held to fp16-class bars element by element."""
     from oracle import maf_oracle as O
-    g = golden("train_" + scale)
+    g = golden("train_" + scale + ("" if size == 128 else "_%d" % size))
+    assert size == 128 or int(g["size"]) == size
     m = M.Model(scale)
     m.load_state_dict(O.synth_state_dict(scale, 0))
     m = m.to(DEV).train()
-    x = O.synth_images(2, 128, 7).to(DEV)
+    x = O.synth_images(2, size, 7).to(DEV)
     targets = torch.tensor(_TRAIN_TARGETS, dtype=torch.float32, device=DEV)
-    crit = M.ComputeLoss(ori_img_size=128, **kw)
-    frozen = _reference_assignment(g, tag, targets, DEV)
+    crit = M.ComputeLoss(ori_img_size=size, **kw)
+    frozen = _reference_assignment(g, tag, targets, DEV, size)
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
         (feats, cls, reg), _ = m(x)
     if not amp:
@@ -668,11 +683,12 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False
         # a 150-layer graph amplifies it) — a bar on the HIP MEDIAN against 2x the framework's failed one run in eight by 0.001.  A kernel defect shifts EVERY
         # realisation, so what is held against the framework is the BEST of the HIP runs, at 1.5x (+ 3 % / 2 %); the spread of the realisations is what the
         # absolute bars above bound.
-        nrun = 7 if scale == "m" else 5
-        fw_runs = [_recipe_errors_on_framework_ops(g, tag, epoch, kw, scale, frozen, x, targets) for _ in range(nrun)]     # (not bit-reproducible either: MIOpen's own atomics)
+        # Round 6: the HIP step runs under train_ops.set_deterministic (the caller sets it): its BatchNorm statistics are summed in a fixed order, so the step is ONE
+        # realisation — the same one on every run of this code — and that one run is what is held against the framework's median, at 1.5x (+ 3 % / 2 %).  No best-of-N.
+        nrun = 5
+        fw_runs = [_recipe_errors_on_framework_ops(g, tag, epoch, kw, scale, frozen, x, targets) for _ in range(nrun)]     # (not bit-reproducible: MIOpen's own atomics)
         fw = fw_runs[0]
-        # the HIP step is another realisation of the noise every run (fp32 atomics): the MEDIAN of the runs per stage is what is compared
-        hip_runs = [per_param] + [_recipe_errors_on_framework_ops(g, tag, epoch, kw, scale, frozen, x, targets, framework=False) for _ in range(nrun - 1)]
+        hip_runs = [per_param]
         rows = []
         for first, label in ((31, "heads"), (9, "neck"), (0, "backbone")):
             last = {31: 99, 9: 30, 0: 8}[first]
@@ -680,18 +696,12 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False
             for run in fw_runs:
                 sel_fw = [(e_, s_) for n_, e_, s_ in run if first <= int(n_.split(".")[1]) <= last]
                 fes.append(max(e_ for e_, _ in sel_fw)); fss.append(float(np.mean([s_ for _, s_ in sel_fw])))
-            hes, hss = [], []
-            for run in hip_runs:
-                sel = [(n_, e_, s_) for n_, e_, s_ in run if first <= int(n_.split(".")[1]) <= last]
-                hes.append(max(e_ for _, e_, _ in sel)); hss.append(float(np.mean([s_ for _, _, s_ in sel])))
-                if os.environ.get("MAF_TEST_VERBOSE"):
-                    print("      ", label, "worst sum|g|:", max(sel, key=lambda t_: t_[2])[0], "worst sampled:", max(sel, key=lambda t_: t_[1])[0],
-                          "| framework worst sum|g|:", max([t_ for t_ in fw if first <= int(t_[0].split(".")[1]) <= last], key=lambda t_: t_[2])[0])
-            he, hs = float(np.min(hes)), float(np.min(hss))
+            sel = [(n_, e_, s_) for n_, e_, s_ in per_param if first <= int(n_.split(".")[1]) <= last]
+            he, hs = max(e_ for _, e_, _ in sel), float(np.mean([s_ for _, _, s_ in sel]))
             fe, fs = float(np.median(fes)), float(np.median(fss))
             rows.append((label, he, fe, hs, fs))
-            print("%s %s amp: %-8s worst sampled error HIP (best of %d) %.3e [median %.3e] / framework (median) %.3e of max |g|; mean sum |g| error HIP %.3e [median %.3e] / framework %.3e"
-                  % (scale, tag, label, nrun, he, float(np.median(hes)), fe, hs, float(np.median(hss)), fs))
+            print("%s %s amp: %-8s worst sampled error HIP (ONE deterministic run) %.3e / framework (median of %d) %.3e of max |g| [ratio %.2f]; mean sum |g| error HIP %.3e / framework %.3e [ratio %.2f]"
+                  % (scale, tag, label, he, nrun, fe, he / max(fe, 1e-12), hs, fs, hs / max(fs, 1e-12)))
         for label, he, fe, hs, fs in rows:
             assert he <= 1.5 * fe + 3e-2, (label, he, fe)
             assert hs <= 1.5 * fs + 2e-2, (label, hs, fs)

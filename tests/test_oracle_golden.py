@@ -93,6 +93,23 @@ def test_headline_shape_640(golden, nets):
     np.testing.assert_allclose(pred.double().sum(1).numpy(), g["pred640_colsum"], rtol=1e-5, atol=1e-2)
 
 
+def test_config0_batch8_640(golden, nets):
+    """BASELINE configs[0] at its stated batch (8 x 3 x 640 x 640): the oracle's prediction and detections against the reference's own (tools/make_golden_b8.py)."""
+    g = golden("maf_n_b8")
+    with torch.no_grad():
+        pred = O.predict(nets["n"][1], "n", O.synth_images(8, 640, 1))
+    assert pred.shape == (8, 8400, 85)
+    _close(pred[:, ::64].numpy(), g["pred640_b8_rows64"])
+    np.testing.assert_allclose(pred.double().sum(1).numpy(), g["pred640_b8_colsum"], rtol=1e-5, atol=1e-2)
+    dets = O.non_max_suppression(pred.numpy(), 0.03, 0.65, multi_label=True)
+    assert [d.shape[0] for d in dets] == list(g["nms640_b8_n"])
+    from nms_cases import match_detections
+    for b, d in enumerate(dets):      # one-to-one by class, IoU >= 0.99 and |d score| <= 1e-3: the oracle's fp32 prediction is ~1e-5 from the reference's, so rows of near-equal
+        ref = g["nms640_b8_%d" % b]   # score may swap places in the list (seen on 3 of the 8 images) — every row still has its partner
+        pairs, miss, extra = match_detections(d, ref, iou_min=0.99, dscore=1e-3)
+        assert len(pairs) >= ref.shape[0] - 2, (b, len(pairs), miss, extra)
+
+
 def test_per_node_taps_64(golden, nets):
     g = golden("maf_n")
     taps = {}

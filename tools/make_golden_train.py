@@ -4,6 +4,7 @@ in the build container (CPU, fp32) on seeded weights, images and labels — what
 (yolov6/core/engine.py:149-164, without autocast: there is no GPU here).
 
     python tools/make_golden_train.py [n|s|m]    ->  tests/golden/train_<scale>.npz     (BASELINE configs[2] / [3] train the s and m graphs)
+    python tools/make_golden_train.py n 640      ->  tests/golden/train_n_640.npz       (the same step at the BASELINE image size: a full-resolution gradient, 2 x 640 x 640)
 
 Stored (DATA only): the reference's own label ASSIGNMENT of each pass (what its assigner returned: foreground mask, assigned box, class and
 target score per anchor — the parity test freezes both of its legs to it, so that no near-tied discrete choice can differ), the loss and its items, the train-branch head outputs on a strided set of anchors, the gradient of a spread of parameters
@@ -61,8 +62,12 @@ def summary(t):
 
 
 def main():
+    global SIZE
     scale = sys.argv[1] if len(sys.argv) > 1 else "n"
     assert scale in ("n", "s", "m")
+    if len(sys.argv) > 2:
+        SIZE = int(sys.argv[2])
+    suffix = "" if SIZE == 128 else "_%d" % SIZE
     torch.set_num_threads(os.cpu_count())
     ns = ref_import.load(lambda b, s, t: torch.zeros(0, dtype=torch.long))
     torch.nn.Module.cuda = lambda self, *a, **k: self          # ComputeLoss moves parameter-free sub-modules to the GPU in its constructor (loss.py:46-47)
@@ -114,8 +119,9 @@ def main():
     for i, k in enumerate(pick):
         blob["bn%d" % i] = sd[k].numpy()
     blob["bn_tracked"] = np.asarray(int(sd["backbone.0.rbr_dense.bn.num_batches_tracked"]))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_%s.npz" % scale), **blob)
-    print("wrote train_%s.npz" % scale, len(blob), "arrays")
+    blob["size"] = np.asarray(SIZE)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_%s%s.npz" % (scale, suffix)), **blob)
+    print("wrote train_%s%s.npz" % (scale, suffix), len(blob), "arrays")
 
 
 if __name__ == "__main__":
