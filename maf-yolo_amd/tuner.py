@@ -1,0 +1,377 @@
+"""Measured choices of a launch plan (engine.Plan): which fusion mode every DepthBottleneckUni takes (`choose_fusion`), which (pixels x channels) tile / kernel variant
+every conv and depth-wise launch takes (`autotune`), and the cache that freezes them (`save_tune_cache` / `load_tune_cache`: profiles/round*_tune*.json).
+
+Split out of engine.py in round 6 (engine.py = the plan: graph -> launch list -> C engine; this file = what is timed on the device; plan_report.py = what a plan
+says about itself: kernel names, algorithmic bytes, flops).  The reference has no counterpart: it leaves kernel selection to cuDNN / MIOpen heuristics per call
+(yolov6/layers/common.py:29-50 calls nn.Conv2d)."""
+import ctypes as C
+import os
+
+import torch
+
+from .config import cfg
+from . import lib, pack
+
+_TUNE_CACHE = {}          # layer signature -> (tile_p, tile_c, ...), filled by autotune
+
+
+def choose_fusion(model, B, H, W, dtype, in_dtype, device, x, reps=3):
+    """Measure, per DepthBottleneckUni, the three ways of running it on this device — three launches, the fully fused kernel
+    (c <= 64), conv1+depth-wise fused followed by the plain 1x1 — and return {bottleneck name: mode}.  Decisions are cached by layer
+    signature next to the tile choices."""
+    import numpy as np
+    # (the three ways are compared WITHOUT the block's closing conv inside the fused launch — fuse_tail — which the final plan adds wherever mode 1 wins)
+    from .engine import Plan
+    plan1 = Plan(model, B, H, W, dtype, in_dtype, device, fuse=True, fuse_tail=False)           # full fusion where it exists, partial elsewhere
+    names, sigs = [], {}
+    for i, o in enumerate(plan1.ops):
+        nm = plan1.op_names[i]
+        if o.kind == lib.OP_BOTTLENECK:
+            names.append(nm); sigs[nm] = ("bn3", dtype, B, o.H, o.W, o.Cin, o.ksize)
+        elif o.kind == lib.OP_CONV1DW:
+            names.append(nm[:-len(".conv1dw")]); sigs[names[-1]] = ("bn3", dtype, B, o.H, o.W, o.Cin, o.ksize)
+    if names and not all(sigs[n] in _TUNE_CACHE for n in names):
+        pred = torch.empty(B, plan1.A, 5 + plan1.nc, dtype=torch.float32, device=device)
+
+        def timed(plan):
+            plan.autotune(x)
+            plan.run_timed(x, pred)
+            t = np.min([plan.run_timed(x, pred) for _ in range(reps)], 0)
+            return dict(zip(plan.op_names, t))
+        t0 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=False, fuse_tail=False))
+        t1 = timed(plan1)
+        t2 = timed(Plan(model, B, H, W, dtype, in_dtype, device, fuse=2, fuse_tail=False))
+        for n in names:
+            cost = {0: t0[n + ".conv1"] + t0[n + ".conv2"] + t0[n + ".one_conv"], 2: t2[n + ".conv1dw"] + t2[n + ".one_conv"]}
+            if n in t1:
+                cost[1] = t1[n]
+            _TUNE_CACHE[sigs[n]] = (min(cost, key=cost.get),)
+    del plan1
+    return {n: _TUNE_CACHE[sigs[n]][0] for n in names}
+
+
+def stream_lds_ok(ksteps, ct):
+    """Instantiations of the persistent 1x1 conv with LDS-resident weights (tile_k = 5: csrc/conv_stream_lds.hip, conv_stream_lds_wide.hip)."""
+    if 2 <= ksteps <= 12:
+        return ksteps * ct <= 96
+    return ct in (4, 6, 8) and (13 <= ksteps <= 20 or ksteps == 24) and ksteps * ct <= 160
+
+
+def save_tune_cache(path):
+    """Persist the tile choices found by Plan.autotune (JSON: repr(signature) -> tiles) so a later process — a profiler
+    pass, a serving replica — builds byte-identical plans without re-timing."""
+    import json
+    with open(path, "w") as f:
+        json.dump({repr(k): list(v) for k, v in _TUNE_CACHE.items()}, f, indent=0, sort_keys=True)
+
+
+def load_tune_cache(path):
+    import ast
+    import json
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            _TUNE_CACHE[ast.literal_eval(k)] = tuple(v)
+    return len(_TUNE_CACHE)
+# lanes served together by one ds_read_b128 (four groups of 16): what the LDS pitch searches below count bank-slot collisions over
+_LANE_GROUPS = ((0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27), (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
+              (32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59), (36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63))
+
+
+_P2_STAGE = cfg.dw_stage      # A/B switch of the tuner's staged-store candidates for dwconv_p2 (tile_k + 128)
+
+
+def p2_wave_bytes(th, tw, k):
+    """LDS bytes of one wave of dwconv_p2 (two planes of 16-byte pair slots, whole DMA rounds): csrc/dwconv_p2.hip:p2_pitch / maf_launch_dwconv_p2."""
+    p_ = k // 2
+    pe = p_ + (p_ & 1)
+    rwp, spr = tw // 2 + pe, tw // 4
+    nstrips = th * spr
+    best, bc = rwp, 1 << 30
+    for pitch in range(rwp, rwp + 8):
+        c = 0
+        for g in _LANE_GROUPS:
+            cnt = {}
+            for lane in g:
+                s_ = min(lane, nstrips - 1)
+                slot = ((s_ // spr) * pitch + 2 * (s_ % spr)) & 15
+                cnt[slot] = cnt.get(slot, 0) + 1
+            c += max(cnt.values())
+        if c < bc:
+            best, bc = pitch, c
+    return -(-(2 * (th + k - 1) * best) // 64) * 1024
+
+
+
+def autotune(plan, x, reps=5, verbose=False):
+    """Time every (tile_p, tile_c) candidate of every MFMA conv on this device and keep the fastest.
+    The candidates differ only in how the (pixel x channel) space is cut into wave tiles (and in the matching weight
+    packing); results are cached per layer signature in `_TUNE_CACHE` so other plans of the same model reuse them."""
+    import time
+    assert x.is_cuda
+    L = lib.load()
+    stream = torch.cuda.current_stream(plan.device)
+    pred = torch.empty(plan.B, plan.A, 5 + plan.nc, dtype=torch.float32, device=plan.device)
+    plan.run_into(x, pred)                                   # every buffer holds realistic data
+    torch.cuda.synchronize(plan.device)
+    timer = lib.Timer()
+    plan._tuned = getattr(plan, "_tuned", [])
+    changed = 0
+    for i, (o, r) in enumerate(zip(plan.ops, plan._ops)):
+        if o.kind == lib.OP_STEM2:                           # stem pair: tile height (8 / 4 rows) and number of persistent workgroups
+            sig = (o.kind, plan.dtype, plan.in_dtype, plan.B, o.H, o.W, o.ksize, o.Cout, o.nc)
+            best = _TUNE_CACHE.get(sig)
+            if best is None:
+                o.src[0].ptr = x.data_ptr()
+                results = []
+                for rows in (8, 4):
+                    for wgs in (256, 512, 768, 1024):
+                        op = lib.MafOp.from_buffer_copy(o)
+                        op.tile_p, op.tile_k = rows, wgs
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        ts = []
+                        for _ in range(reps):
+                            timer.start(stream.cuda_stream)
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            timer.stop(stream.cuda_stream)
+                            ts.append(timer.elapsed_ms())
+                        results.append((min(ts), rows, wgs))
+                results.sort()
+                best = (results[0][1], 0, results[0][2])
+                _TUNE_CACHE[sig] = best
+                if verbose:
+                    print("tune %-32s %dx%d: %s" % (plan.op_names[i], o.H, o.W, " ".join("(%d,%d)%.1fus" % (r_, w_, t * 1e3) for t, r_, w_ in results)))
+            if (best[0], best[2]) != (o.tile_p, o.tile_k):
+                o.tile_p, o.tile_k = best[0], best[2]
+                changed += 1
+            continue
+        if o.kind == lib.OP_HEADTAIL:                        # head tail: persistent workgroups per CU (tile_k; the weights are staged once per workgroup)
+            sig = (o.kind, plan.dtype, plan.B, o.H, o.W, o.Cin, "percu")
+            best = _TUNE_CACHE.get(sig)
+            if best is None:
+                o.out = pred.data_ptr()
+                results = []
+                for iters in (1, 2, 3, 4, 6):
+                    op = lib.MafOp.from_buffer_copy(o)
+                    op.tile_k = iters
+                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                    ts = []
+                    for _ in range(reps):
+                        timer.start(stream.cuda_stream)
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        timer.stop(stream.cuda_stream)
+                        ts.append(timer.elapsed_ms())
+                    results.append((min(ts), iters))
+                results.sort()
+                best = (0, 0, results[0][1])
+                _TUNE_CACHE[sig] = best
+                if verbose:
+                    print("tune %-32s %dx%d C=%d: %s" % (plan.op_names[i], o.H, o.W, o.Cin, " ".join("(%d)%.1fus" % (it, t * 1e3) for t, it in results)))
+            if best[2] != o.tile_k:
+                o.tile_k = best[2]
+                changed += 1
+            continue
+        if o.kind == lib.OP_DWCONV:                          # depth-wise: workgroup tile (rows, cols, channel block)
+            sig = (o.kind, plan.dtype, plan.B, o.H, o.W, o.Cin, o.ksize, o.act) + ((o.Cout,) if o.Cout != o.Cin else ())
+            best = _TUNE_CACHE.get(sig)
+            if best is None:
+                n = 8 if plan.dtype == lib.F16 else 4
+                results = []
+                # tile heights / widths: powers of two plus the map's own size and its half (40 x 40 and 20 x 20 maps: tiles that
+                # divide the map exactly have no half-empty edge tiles and the smallest halo share)
+                ths = sorted({4, 8, 16, 32} | {v for v in (o.H, o.H // 2) if 8 <= v <= 40})
+                tws = sorted({8, 16, 32} | {v for v in (o.W, o.W // 2) if 8 <= v <= 40 and v % 4 == 0})
+                for th in ths:
+                    for tw in tws:
+                        for cbm in (8, 4, 2):
+                            t_h, t_w, cb = min(th, o.H), min(tw, -(-o.W // 4) * 4), min(cbm * n, -(-o.Cin // n) * n)
+                            lds = ((t_h + o.ksize - 1) * (t_w + o.ksize - 1) * (cb // n + 2) + o.ksize * o.ksize * (cb // n)) * 16
+                            if lds > 96 * 1024 or (t_h, t_w, cb) in [(a, b2, c2) for _, a, b2, c2 in results]:
+                                continue
+                            op = lib.MafOp.from_buffer_copy(o)
+                            op.tile_p, op.tile_c, op.tile_k = t_h, t_w, cb
+                            lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                            ts = []
+                            for _ in range(reps):
+                                timer.start(stream.cuda_stream)
+                                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                timer.stop(stream.cuda_stream)
+                                ts.append(timer.elapsed_ms())
+                            results.append((min(ts), t_h, t_w, cb))
+                if plan.dtype == lib.F16:                            # two taps per instruction (csrc/dwconv_dot2.hip): tile_p = -2, tile_c = columns, tile_k = rows * 256 + channels
+                    w8 = -(-o.W // 8) * 8
+                    for th in sorted({4, 8, 10, 16, 20} | ({o.H} if o.H <= 40 else set())):
+                        if th > o.H:
+                            continue
+                        for tw in sorted({16, 24, 32, 40} | ({w8} if w8 <= 40 else set())):
+                            if tw > w8:
+                                continue
+                            for cb in (16, 32, 64):
+                                cb = min(cb, o.Cin)
+                                nq, np_ = cb // 4, (o.ksize + 1) // 2
+                                lds = ((th + o.ksize - 1) * ((tw + o.ksize - 1) // 2) * (nq + 3) + o.ksize * 2 * np_ * nq) * 16      # (pair stride <= nq + 3: csrc/dwconv_dot2.hip)
+                                if lds > 96 * 1024 or (-2, tw, th * 256 + cb) in [r_[1:] for r_ in results]:
+                                    continue
+                                op = lib.MafOp.from_buffer_copy(o)
+                                op.tile_p, op.tile_c, op.tile_k = -2, tw, th * 256 + cb
+                                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                ts = []
+                                for _ in range(reps):
+                                    timer.start(stream.cuda_stream)
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    timer.stop(stream.cuda_stream)
+                                    ts.append(timer.elapsed_ms())
+                                results.append((min(ts), -2, tw, th * 256 + cb))
+                if plan._pairs_producer(i) is not None:              # pixel-pair input, v_dot2c with scalar weight pairs (csrc/dwconv_p2.hip): tile_p = -4, tile_c = columns, tile_k = rows * 256 + waves per workgroup
+                    w4 = -(-o.W // 4) * 4
+                    for th in sorted({4, 5, 8, 10, 16, 20} | ({o.H} if o.H <= 40 else set())):
+                        if th > o.H:
+                            continue
+                        for tw in sorted({16, 20, 32, 40, 80} | ({w4} if w4 <= 80 else set())):
+                            if tw > w4:
+                                continue
+                            plane = p2_wave_bytes(th, tw, o.ksize)
+                            if plane > 20 * 1024:                    # fewer than 8 waves per CU: never the fastest
+                                continue
+                            for nw, stg in ((2, 0), (4, 0), (8, 0), (2, 128), (4, 128), (8, 128)):
+                                # + 128: staged stores (the waves of a workgroup = adjacent channel groups of one tile, results through the dead planes,
+                                # nw x 16-byte runs per pixel): where the kernel takes that form (csrc/dwconv_p2.hip:maf_launch_dwconv_p2)
+                                if stg and not ((o.Cin // 8) % nw == 0 and th * (tw // 4) <= 64 and plane >= 4160 and o.Cout <= 2 * o.Cin and _P2_STAGE):
+                                    continue
+                                op = lib.MafOp.from_buffer_copy(o)
+                                op.tile_p, op.tile_c, op.tile_k = -4, tw, th * 256 + nw + stg
+                                op.src[0].mode = lib.SRC_PAIRS       # (the NHWC content of the buffer read as pairs: same work)
+                                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                ts = []
+                                for _ in range(reps):
+                                    timer.start(stream.cuda_stream)
+                                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                                    timer.stop(stream.cuda_stream)
+                                    ts.append(timer.elapsed_ms())
+                                results.append((min(ts), -4, tw, th * 256 + nw + stg))
+                if plan.dtype == lib.F16 and o.aux[0]:               # matrix-core variant (csrc/dwconv_mfma.hip): tile_p = -1
+                    op = lib.MafOp.from_buffer_copy(o)
+                    op.tile_p, op.tile_c, op.tile_k = -1, 0, 0
+                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                    ts = []
+                    for _ in range(reps):
+                        timer.start(stream.cuda_stream)
+                        lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                        timer.stop(stream.cuda_stream)
+                        ts.append(timer.elapsed_ms())
+                    results.append((min(ts), -1, 0, 0))
+                results.sort()
+                best = results[0][1:]
+                _TUNE_CACHE[sig] = best
+                _TUNE_CACHE[sig + ("nhwc",)] = [r_ for r_ in results if r_[1] != -4][0][1:]      # for a plan whose producer cannot store pixel pairs
+                if verbose:
+                    print("tune %-32s %dx%d C=%d k=%d: %s" % (plan.op_names[i], o.H, o.W, o.Cin, o.ksize, " ".join("(%d,%d,%d)%.1fus" % (a, b2, c2, t * 1e3) for t, a, b2, c2 in results[:6])))
+                    p2 = [r_ for r_ in results if r_[1] == -4]
+                    if any(r_[3] & 128 for r_ in p2):                # pixel-pair kernel: best tile with plain / staged stores
+                        bu, bs = [r_ for r_ in p2 if not r_[3] & 128][0], [r_ for r_ in p2 if r_[3] & 128][0]
+                        print("     dwconv_p2 stores  plain (%d,%d) %.1fus   staged (%d,%d) %.1fus" % (bu[2], bu[3], bu[0] * 1e3, bs[2], bs[3] - 128, bs[0] * 1e3))
+            prod = plan._pairs_producer(i)
+            if best[0] == -4 and prod is None:
+                best = _TUNE_CACHE.get(sig + ("nhwc",), (0, 0, 0))
+            pairs = 1 if best[0] == -4 else 0
+            if tuple(best) != (o.tile_p, o.tile_c, o.tile_k) or (prod is not None and prod.out_pairs != pairs):
+                o.tile_p, o.tile_c, o.tile_k = best
+                o.src[0].mode = lib.SRC_PAIRS if pairs else lib.SRC_DIRECT
+                if prod is not None:
+                    prod.out_pairs = pairs                           # the 1x1 conv in front stores what this kernel reads
+                changed += 1
+            continue
+        if o.kind not in (lib.OP_CONV1X1, lib.OP_CONV3X3S2):
+            continue
+        M = plan.B * o.H * o.W
+        twin = r.get("twin")
+        pool1 = r.get("pool1")
+        sig = (o.kind, plan.dtype, M, o.Cin, o.Cout, o.nsrc, tuple(o.src[k].mode for k in range(o.nsrc)), int(o.out_f32)) + (("twin",) if twin else ()) + (("pool1",) if pool1 else ())
+        best = _TUNE_CACHE.get(sig)
+        w, b, srcC = r["raw"]
+
+        def packed(wt, bt, ct_, tk_):
+            wp_ = ((pack.pack_mprep_wreg if tk_ == 7 else pack.pack_mprep_lds)(wt, bt, *pool1) if pool1 else pack.pack_conv3x3_lds(wt, bt) if tk_ == 6 else pack.pack_conv3x3_wreg(wt, bt) if tk_ == 7 else pack.pack_conv1x1(wt, srcC, ct_, plan.dtype) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(wt, ct_, plan.dtype)).to(plan.device)
+            return wp_, pack.pack_bias(bt, ct_ if tk_ not in (6, 7) else 4).to(plan.device)
+        if best is None:
+            cands = []
+            for ct in (2, 4, 6, 8):
+                nt = -(-o.Cout // (16 * ct))
+                if nt * 16 * ct > 2 * max(o.Cout, 32) or (ct == 8 and o.out_stride % 8 and not o.out_f32 and plan.dtype == lib.F16):
+                    continue
+                for pt in (1, 2, 4):
+                    if pt == 4 and ct > 4:
+                        continue
+                    if -(-M // (64 * pt)) * nt < 256 and pt > 1:
+                        continue                          # would not fill the chip
+                    cands.append((pt, ct, 1))
+                ksteps = sum(-(-o.src[k].C // (32 if plan.dtype == lib.F16 else 16)) for k in range(o.nsrc)) * (9 if o.kind == lib.OP_CONV3X3S2 else 1)
+                if ksteps >= 8 and M <= 65536:
+                    cands.append((1, ct, 4))                 # split-K across the 4 waves: long reductions on small maps
+                direct = o.kind == lib.OP_CONV1X1 and o.nsrc == 1 and o.src[0].mode == lib.SRC_DIRECT
+                if direct and plan.dtype == lib.F16 and not o.out_f32 and ksteps <= 4 and ksteps * ct <= 16:
+                    for pt in (1, 2):                                # persistent waves, next tile's activations in flight during the epilogue
+                        cands.append((pt, ct, 3))
+                if o.kind == lib.OP_CONV1X1 and plan.dtype == lib.F16 and not o.out_f32 and stream_lds_ok(ksteps, ct) \
+                        and (o.nsrc == 1 or all(o.src[k].mode != lib.SRC_POOL2 for k in range(o.nsrc))) and (direct or ct >= 4 or o.nsrc == 1):
+                    cands.append((1, ct, 5))                         # persistent waves, the channel tile's weights resident in LDS
+                    if ct >= 4 and 64 <= ksteps * ct <= 160 and (8 <= ksteps <= 20 or ksteps == 24):
+                        cands.append((2, ct, 5))                     # ... eight waves behind one copy of the weights where the LDS leaves room for one or two workgroups per CU (conv_stream_lds_w8.hip)
+                if o.kind == lib.OP_CONV3X3S2 and plan.dtype == lib.F16 and (o.Cin, o.Cout) in ((48, 48), (48, 64), (64, 64)) and ct == 4 and (M >= 65536 or pool1):
+                    for wg in (4, 8, 12, 16):                         # weights + input patch in LDS, 256 .. 1024 persistent workgroups (tile_c = workgroups / 64)
+                        cands.append((4, wg, 6))
+                if o.kind == lib.OP_CONV3X3S2 and plan.dtype == lib.F16 and pack.conv3x3_wreg_shape(o.Cin, o.Cout) and ct == 4:
+                    for wg in (2, 4, 8):                              # weights in registers, patches by DMA: 64 / 128 / 256 workgroups per conv (tile_c = that / 32)
+                        if wg * 32 * (2 if twin else 1) <= 256:
+                            cands += [(3, wg, 7), (2, wg, 7)]         # tile_p = patch buffers (3: two patches in flight ahead of the multiply)
+                pooled = o.nsrc == 1 and o.src[0].mode == lib.SRC_POOL2
+                if ksteps >= 4 and ct >= 4 and plan.dtype == lib.F16 and not o.out_f32 and not pooled:
+                    for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
+                        if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
+                            cands.append((pt, ct, 2))
+            results = []
+            if twin:
+                cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7)]    # the variants that take a twin launch
+            if pool1:
+                cands = [c_ for c_ in cands if c_[2] == r.get("pool1_tk", 6)]   # only the workgroup count (and the patch buffers of tile_k = 7) are open
+            for pt, ct, tk in cands:
+                wp, bp = packed(w, b, ct, tk)
+                op = lib.MafOp.from_buffer_copy(o)
+                op.tile_p, op.tile_c, op.tile_k, op.w, op.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
+                if twin:
+                    wp2, bp2 = packed(*twin["raw"], ct, tk)
+                    op.aux[1], op.aux[2] = wp2.data_ptr(), bp2.data_ptr()
+                lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))          # warm-up
+                ts = []
+                for _ in range(reps):
+                    timer.start(stream.cuda_stream)
+                    lib.check(L.maf_op_launch(C.byref(op), stream.cuda_stream))
+                    timer.stop(stream.cuda_stream)
+                    ts.append(timer.elapsed_ms())
+                results.append((min(ts), pt, ct, tk))
+            results.sort()
+            best = (results[0][1], results[0][2], results[0][3])
+            _TUNE_CACHE[sig] = best
+            if verbose:
+                print("tune %-32s M=%-7d %4d->%-4d: %s" % (plan.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
+        pt, ct, tk = best
+        if pool1:
+            if (pt, ct) != (o.tile_p, o.tile_c):
+                o.tile_p, o.tile_c = pt, ct                       # same record, another workgroup count
+                changed += 1
+            continue
+        if (pt, ct, tk) != (o.tile_p, o.tile_c, max(1, o.tile_k)):
+            wp, bp = packed(w, b, ct, tk)
+            plan._tuned += [wp, bp]
+            o.tile_p, o.tile_c, o.tile_k, o.w, o.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()
+            if twin:
+                wp2, bp2 = packed(*twin["raw"], ct, tk)
+                plan._tuned += [wp2, bp2]
+                o.aux[1], o.aux[2] = wp2.data_ptr(), bp2.data_ptr()
+            changed += 1
+    if changed:
+        L.maf_engine_destroy(plan._engine)
+        h = C.c_void_p()
+        lib.check(L.maf_engine_create(plan.ops, len(plan.ops), C.byref(h)))
+        plan._engine = h
+    torch.cuda.synchronize(plan.device)
+    return changed
