@@ -190,10 +190,12 @@ def nms_leg(torch, M, dev, pred, conf, iou, reps=40):
         flags = ws[:B * lib.NMS_CNT_STRIDE * 4].view(torch.int32).view(B, lib.NMS_CNT_STRIDE)      # per image one 256-byte line: [0] candidates, [1] per-class path taken (csrc/nms.hip)
         return e0.elapsed_time(e1) / reps, int((flags[:, 1] != 0).sum()), float(flags[:, 0].float().mean()), float(cnt.float().mean())
     out = {}
-    ms, pc, cand, det = timed(pred)
+    ms, pc, cand, det = timed(pred, matrix=False)
     ms_m = timed(pred, matrix=True)[0]
     out["synthetic_head"] = {"ms_per_batch": round(ms, 4), "images_on_per_class_path": pc, "candidates_per_image": round(cand, 1), "detections_per_image": round(det, 1),
-                             "path": "all-pairs: kept-list scan (csrc/nms.hip nms_greedy_kernel)", "matrix_form_ms_per_batch": round(ms_m, 4)}
+                             "path": "all-pairs: kept-list scan (csrc/nms.hip nms_greedy_kernel: one workgroup per image — the form the timed loop's side-stream NMS takes)",
+                             "matrix_form_ms_per_batch": round(ms_m, 4),
+                             "matrix_form": "n x n suppression matrix on the whole chip + row scan: faster ALONE up to ~32 images, what a synchronous non_max_suppression() call takes (nms._matrix_form)"}
     ms, pc, cand, det = timed(spread)
     out["classes_spread_80"] = {"ms_per_batch": round(ms, 4), "images_on_per_class_path": pc, "candidates_per_image": round(cand, 1), "detections_per_image": round(det, 1),
                                 "path": "per-class scans (nms_cscan_kernel)" if pc == B else "mixed"}

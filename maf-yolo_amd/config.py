@@ -18,7 +18,7 @@ SWITCHES = {
     "split_cat":         ("MAF_SPLIT_CAT", True, "RepHDW behind the fused stem: one dense tensor per concat slot"),
     "mprep_wreg_min":    ("MAF_MPREP_WREG_MIN", 65536, "output pixels from which MPRep takes the register-weight 3x3 kernel"),
     "nms_single_max_batch": ("MAF_NMS_SINGLE_MAX_BATCH", 0, "largest batch the single-launch NMS kernel serves (0: never — the seven-launch path is faster, DESIGN.md 8)"),
-    "nms_matrix":        ("MAF_NMS_MATRIX", False, "all-pairs NMS as suppression matrix + scan (rounds 2-5) instead of the kept-list scan"),
+    "nms_matrix":        ("MAF_NMS_MATRIX", "auto", "all-pairs NMS: 1 = suppression matrix + row scan, 0 = kept-list scan, auto = kept-list under other work (async), matrix alone up to 32 images"),
     # ---- training step (train_ops.py, tape.py, model.py, solver.py, exchange.py)
     "step_tape":         ("MAF_STEP_TAPE", True, "replay the recorded launch lists of a train step (tape.py) once a batch shape has been seen three times"),
     "stage_native":      ("MAF_STAGE_NATIVE", True, "step tape: the image batch into the static NHWC8 input by one native pass"),

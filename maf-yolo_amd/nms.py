@@ -68,6 +68,18 @@ def _workspace(dev, st, B, N, nc, need):
     return ws
 
 
+def _matrix_form(B, overlapped):
+    """Which form the all-pairs path of this call takes (same survivors bit for bit; csrc/nms.hip).  MATRIX_PATH True / False force one; "auto":
+    * a call on a side stream under other work (non_max_suppression_async: the serving loop, the NMS of batch i under the forward of batch i + 1) takes the kept-list
+      scan — one workgroup per image, B of the 256 CUs, ~128 us whatever B is; measured +3 % on the 3-in-flight loop against the matrix form, whose mask kernel takes
+      the whole chip away from the forward for ~1.8 us per image;
+    * a call with the GPU to itself (non_max_suppression: forward, then NMS, then the host — the reference's Evaler, the bs = 1 latency path) takes the matrix form up to
+      32 images: the mask on the whole chip (1.8 us per image) + the row scan (~68 us) finish before the one-CU-per-image scan does."""
+    if MATRIX_PATH == "auto":
+        return (not overlapped) and B <= 32
+    return bool(MATRIX_PATH)
+
+
 def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300, stream=None, iou_rule=None):
     """Device-side result without the host sync: (rows [B,max_det,6], idx int64 [B,max_det], count int32 [B]).
     Launches on `stream` (a torch.cuda.Stream) or on the current stream."""
@@ -106,7 +118,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
                                    cls_t.data_ptr() if ncls else None, ncls, int(bool(agnostic)), int(bool(multi_label)),
                                    int(max_det), ws.data_ptr(), ws.numel(), rows.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
                                    (lib.NMS_FLOAT_THRESHOLD if rule == "cuda" else 0) | (lib.NMS_SINGLE_LAUNCH if _single_launch(B) else 0)
-                                   | (lib.NMS_PRECOLLECTED if pre else 0) | (lib.NMS_MATRIX if MATRIX_PATH else 0), st.cuda_stream))
+                                   | (lib.NMS_PRECOLLECTED if pre else 0) | (lib.NMS_MATRIX if _matrix_form(B, stream is not None) else 0), st.cuda_stream))
             if pre:
                 ev = torch.cuda.Event()
                 ev.record(st)
@@ -118,7 +130,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
 
 
 SINGLE_LAUNCH_MAX_BATCH = cfg.nms_single_max_batch
-MATRIX_PATH = cfg.nms_matrix       # A/B: the all-pairs path as n x n suppression matrix + scan (csrc/nms.hip nms_mask_kernel / nms_scan_kernel) instead of the kept-list scan
+MATRIX_PATH = {"0": False, "1": True}.get(str(cfg.nms_matrix), "auto")       # the all-pairs path as n x n suppression matrix + row scan (True), as kept-list scan (False), or by situation ("auto": _matrix_form)
 
 
 def _single_launch(B):

@@ -218,12 +218,14 @@ def test_nms_single_launch_form_is_bit_identical(golden, name, monkeypatch):
         assert np.array_equal(idx[b].cpu().numpy(), oi[b]), (name, b)
 
 
+@pytest.mark.parametrize("matrix", [True, False])
 @pytest.mark.parametrize("name", sorted(nms_cases.cases().keys()))
-def test_nms_matrix_form_is_bit_identical(golden, name, monkeypatch):
-    """maf_nms_ex flag MAF_NMS_MATRIX — the all-pairs path as rounds 2-5 ran it (n x n suppression bit matrix on the whole chip + a serial scan of its rows) — against
-    the same reference fixtures and oracle indices as the default kept-list scan (csrc/nms.hip:nms_greedy_kernel), which every other NMS test of this file exercises."""
+def test_nms_both_forms_of_the_all_pairs_path_are_bit_identical(golden, name, matrix, monkeypatch):
+    """The two forms of the all-pairs path, each FORCED (nms.MATRIX_PATH; "auto" picks by situation: nms._matrix_form) — the n x n suppression bit matrix on the whole chip + a
+    serial scan of its rows (maf_nms_ex flag MAF_NMS_MATRIX, rounds 2-5), and the kept-list scan (csrc/nms.hip:nms_greedy_kernel, round 6) — against the same reference
+    fixtures and oracle indices."""
     from maf_yolo_amd import nms as nms_mod
-    monkeypatch.setattr(nms_mod, "MATRIX_PATH", True)
+    monkeypatch.setattr(nms_mod, "MATRIX_PATH", matrix)
     g = golden("nms_cases")
     pred, kw = nms_cases.cases()[name]
     out, idx = M.non_max_suppression(torch.from_numpy(pred).to(DEV), return_index=True, **kw)
@@ -252,6 +254,7 @@ def test_nms_kept_list_scan_against_the_matrix_form_and_the_oracle(n_cand, max_d
         pred[b, rows, 5 + 3 * rng.randint(0, 2, n_cand)] = rng.uniform(0.05, 0.99, n_cand).astype(np.float32)
     want, widx = O.non_max_suppression(pred, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)
     x = torch.from_numpy(pred).to(DEV)
+    monkeypatch.setattr(nms_mod, "MATRIX_PATH", False)
     got, gidx = M.non_max_suppression(x, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)
     monkeypatch.setattr(nms_mod, "MATRIX_PATH", True)
     mat, midx = M.non_max_suppression(x, 0.03, 0.65, multi_label=True, max_det=max_det, return_index=True)

@@ -603,7 +603,7 @@ def _train_step_vs_reference(golden, tag, epoch, kw, amp, scale, named_alt=False
     m.load_state_dict(O.synth_state_dict(scale, 0))
     m = m.to(DEV).train()
     x = O.synth_images(2, size, 7).to(DEV)
-    targets = torch.tensor(_TRAIN_TARGETS, dtype=torch.float32, device=DEV)
+    targets = torch.tensor(_TRAIN_TARGETS, dtype=torch.float32, device=DEV) if size == 128 else torch.from_numpy(g["targets"]).to(DEV)   # (640: centres moved off the cell corners, see the generator)
     crit = M.ComputeLoss(ori_img_size=size, **kw)
     frozen = _reference_assignment(g, tag, targets, DEV, size)
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
@@ -1835,8 +1835,10 @@ def test_train_mode_forward_returns_the_reference_structure_and_runs_no_framewor
             return func(*args, **(kwargs or {}))
     with Trace(), torch.autocast("cuda", dtype=torch.float16):
         (feats, cls, reg), fm = m(x)
+        glue0 = train_ops.stats.get("glue", 0)
         (cls.float().sum() + reg.float().pow(2).sum()).backward()
     torch.cuda.synchronize()
+    assert train_ops.stats.get("glue", 0) == glue0, "the backward took a fall-back branch (e.g. F.pad of reg_pred's 68-channel gradient: the join writes it padded)"
     A = sum(f.shape[2] * f.shape[3] for f in feats)
     assert cls.shape == (2, A, 80) and reg.shape == (2, A, 68) and len(fm) == 3
     assert float(cls.min()) >= 0.0 and float(cls.max()) <= 1.0
@@ -1847,6 +1849,6 @@ def test_train_mode_forward_returns_the_reference_structure_and_runs_no_framewor
         assert c.data_ptr() == cls[:, a0].data_ptr() and r.data_ptr() == reg[:, a0].data_ptr()
         assert torch.equal(c.flatten(2).permute(0, 2, 1), cls[:, a0:a0 + h * w])
         a0 += h * w
-    bad = [s for s in seen if any(k in s for k in ("aten.sigmoid", "aten.cat.", "aten._cat", "aten.sigmoid_backward", "aten.constant_pad_nd"))]
+    bad = [s for s in seen if any(k in s for k in ("aten.sigmoid", "aten.cat.", "aten._cat", "aten.sigmoid_backward"))]      # (the eager forward pads the 3-channel image to 8 with F.pad: not a12's)
     assert not bad, sorted(set(bad))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if "cls_pred" in n or "reg_pred" in n)
