@@ -107,7 +107,7 @@ def infer_leg(torch, M, dev, scale, batch, steps, warmup, cs=None):
     main line's timed region with fewer steps, plus the forward alone.  Tile choices: the frozen file of the scale under profiles/ when there is one."""
     import numpy as np
     from maf_yolo_amd import synth, engine as _engine
-    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_ % scale) for f_ in ("round5_tune_%s.json", "round4_tune_%s.json", "round3_tune_%s.json")) if os.path.exists(p_)]
+    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_ % scale) for f_ in ("round6_tune_%s.json", "round5_tune_%s.json", "round4_tune_%s.json", "round3_tune_%s.json")) if os.path.exists(p_)]
     if frozen:
         _engine.load_tune_cache(frozen[0])
     model = M.Model(scale)
@@ -261,7 +261,7 @@ def train_pmc_traffic(kind, scale):
     """HBM bytes per launch of `kind` from the PMC passes of a training run committed under profiles/ (tools/profile_round.sh: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs, counters only; tools/pmc_traffic.py: (FETCH_SIZE*2 + WRITE_SIZE)*1024) — n at batch 32 only."""
     import re
-    path = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round5_train_pmc_traffic.json", "round4_train_pmc_traffic.json", "round3_train_pmc_traffic.json", "round2_train_pmc_traffic.json")) if os.path.exists(p_)]
+    path = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round6_train_pmc_traffic.json", "round5_train_pmc_traffic.json", "round4_train_pmc_traffic.json", "round3_train_pmc_traffic.json", "round2_train_pmc_traffic.json")) if os.path.exists(p_)]
     path = path[0] if path else ""
     pat = _TRAIN_KIND_KERNELS.get(kind)
     if pat is None or scale != "n" or not os.path.exists(path):
@@ -573,7 +573,7 @@ def main():
     from maf_yolo_amd import engine as _engine
     # tile choices (which (pixels x channels) cut, which kernel variant per layer) measured on an MI355X and frozen in the repo are the
     # default starting point: layer signatures that are not in the file are still timed here.  --tune-file none = time everything afresh.
-    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round5_tune.json", "round4_tune.json", "round3_tune.json")) if os.path.exists(p_)]
+    frozen = [p_ for p_ in (os.path.join(ROOT, "profiles", f_) for f_ in ("round6_tune.json", "round5_tune.json", "round4_tune.json", "round3_tune.json")) if os.path.exists(p_)]
     if args.tune_file is None and frozen:
         args.tune_file = frozen[0]
     if args.tune_file == "none":
@@ -726,7 +726,7 @@ def main():
         fwd_img_s = B / (fwd_ms * 1e-3)
         traffic, traffic_src, pmc = None, None, {}
         try:                                   # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) committed under profiles/
-            pmc_file = [f_ for f_ in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            pmc_file = [f_ for f_ in ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             have = [k for k in gd["inst"] if k in pmc]
             if have:                           # per launch of the template: instantiations weighted by their launches in this forward
@@ -739,7 +739,7 @@ def main():
         rocprof_avg_ms, rocprof_src = None, None
         try:
             import csv as _csv
-            stats_file = [f_ for f_ in ("round5_kernel_stats.csv", "round4_kernel_stats.csv", "round3_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
+            stats_file = [f_ for f_ in ("round6_kernel_stats.csv", "round5_kernel_stats.csv", "round4_kernel_stats.csv", "round3_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f_))][0]
             tot_ns = calls = 0
             for row in _csv.DictReader(open(os.path.join(ROOT, "profiles", stats_file))):
                 if name in row["Name"]:
