@@ -23,6 +23,11 @@ staged by the step's pack batch — `train_ops.stats["glue"]` counts every fall-
 `with tape.check():` proves it for a recording with a TorchDispatchMode that lists every device op seen inside the recorded regions
 (tests/test_gpu_tape.py asserts the list is empty and that replayed steps follow the eager trajectory).
 
+Contract: a recording is PROCESS-wide — `lib._recorder`, `train_ops._rec` and the current lane are module globals, so while the one recorded step
+of a batch shape runs (its forward on the calling thread, its backward on the autograd engine's device thread) no other thread may issue library calls (an async
+evaluation, a background NMS): they would be written into the tape.  Replays have no such restriction.  The outputs of a replayed forward are views of the tape's
+static buffers, valid until the next forward of that shape: clone what must outlive the step.  `Model.eval()` / `invalidate()` release the tapes and what they pin.
+
 Not for: fp32 parity runs, deterministic mode, profiling (`train_ops.profile`), plain autograd without a GradExchange (the weight gradients need their
 static bucket slices), two forwards before a backward (while the first one's graph is alive; a forward whose graph was dropped
 without a backward is released: StepTape.drop_pending) — all of these run the eager path, which stays the reference implementation of the step."""
