@@ -842,30 +842,34 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
         return Box{v[0], v[1], v[2], v[3], p->area};
     };
-    auto overlaps = [&](const Box k, const Box c, bool on) -> unsigned long long {
+    // `lanes`: the lanes whose verdict counts (a scalar mask: valid candidates, for a triangle row the later ones) — applied to the ballots, not to per-lane predicates
+    auto overlaps = [&](const Box k, const Box c, unsigned long long lanes) -> unsigned long long {
         const float w = fmaxf(0.f, fminf(k.x2, c.x2) - fmaxf(k.x1, c.x1)), h = fmaxf(0.f, fminf(k.y2, c.y2) - fmaxf(k.y1, c.y1));
         const float inter = w * h, uni = k.area + c.area - inter;
         const float d = __builtin_fmaf(-iouthr.m32, uni, inter);                 // = iou_screen
         const bool decided = uni > 0.f && fabsf(d) > 3e-7f * uni;
-        bool hit = on && decided && d > 0.f;
-        if (__any(on && !decided)) {
-            if (on && !decided) {
+        unsigned long long hits = __ballot(decided && d > 0.f);
+        const unsigned long long open = __ballot(!decided) & lanes;             // inside the band (or a NaN / infinite / non-positive union): the exact form decides
+        if (open) {
+            bool hit = false;
+            if ((open >> lane) & 1ull) {
                 const Cand kc = {k.x1, k.y1, k.x2, k.y2, k.area, 0.f, 0u, 0u}, cc = {c.x1, c.y1, c.x2, c.y2, c.area, 0.f, 0u, 0u};
                 hit = iou_gt(kc, cc, iouthr);
             }
+            hits |= __ballot(hit);
         }
-        return __ballot(hit);
+        return hits & lanes;
     };
     // tests of block `blk` (in cb[buf]) that do not need the verdict on the block before it: its own triangle, and the kept boxes [k0, k1); waves [w0, NWV) share them
     auto test_block = [&](int blk, int buf, int k0, int k1, bool triangle, int w0) {
         const int nvalid = min(64, n - blk * 64);
-        const bool valid = lane < nvalid;
+        const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
         const Box me = ld(&cb[buf][lane]);
         const int nw = NWV - w0, w = wave - w0;
         if (w < 0) return;
         if (triangle)
             for (int i = w; i < nvalid; i += nw) {
-                const unsigned long long m = overlaps(ld(&cb[buf][i]), me, valid && lane > i);
+                const unsigned long long m = overlaps(ld(&cb[buf][i]), me, valid & (i == 63 ? 0ull : (~0ull << (i + 1))));
                 if (lane == 0) diag[buf][i] = m;
             }
         unsigned long long dead = 0;                           // wave-uniform
