@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other: give them room.  (Must be set
 # before the HIP runtime starts, i.e. before torch is imported; an explicit setting in the environment wins.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this pool: the host driver supports dmabuf IPC only (without this RCCL fails with hipIpcGetMemHandle: invalid argument); already exported on the
+# boxes, set here too so that a bare `python bench.py --gpus N` cannot miss it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense
@@ -549,10 +552,12 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        # a rank that dies alone must not leave its peers inside a collective for the default 10 minutes: 3 minutes, then the job fails loudly
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+            dist.init_process_group("nccl", init_method="env://", device_id=dev, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(args.dist_backend, init_method="env://")
+            dist.init_process_group(args.dist_backend, init_method="env://", timeout=datetime.timedelta(seconds=180))
 
     if args.latency:
         return latency_mode(args, torch, M, dev)
