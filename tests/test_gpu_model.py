@@ -983,3 +983,8 @@ def test_bench_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["cpu_baseline"] is None                                  # --no-cpu-baseline
+    # round 6: NMS alone on the timed head (all-pairs path, both forms) and on an 80-class spread of the same candidates (per-class path); the parity bar of the timed plan
+    assert d["ranks_seen"] == 1 and "2e-3" in d["parity_bar_of_the_timed_plan"]
+    n = d["nms"]
+    assert n["synthetic_head"]["ms_per_batch"] > 0 and n["synthetic_head"]["matrix_form_ms_per_batch"] > 0 and n["classes_spread_80"]["ms_per_batch"] > 0
+    assert n["classes_spread_80"]["images_on_per_class_path"] == 8 and n["synthetic_head"]["candidates_per_image"] == n["classes_spread_80"]["candidates_per_image"]
