@@ -13,7 +13,7 @@
 //   C  the second conv as an implicit GEMM: K = 9 taps x 24 channels = 27 (tap, 8-channel) pairs, four pairs per MFMA k-step,
 //      A fragments = two 8-byte LDS reads, weight fragments from LDS (staged once per workgroup), bias + ReLU;
 //   D  the 128 x C1 outputs leave through LDS as 16-byte pieces of whole NHWC pixels.
-// Workgroups are persistent (weights staged once).  fp16 engine only; (C0, C1) = (24, 48) [n] or (32, 64) [s].
+// Workgroups are persistent (weights staged once).  fp16 engine only; (C0, C1) = (24, 48) [n], (32, 64) [s] or (48, 96) [m: three stem tiles, 4-row tiles only].
 #include "maf_common.h"
 
 #ifndef MAF_KO
@@ -50,7 +50,8 @@ template <> struct Chunk<uint8_t> {
 };
 
 template <typename TI, int C0, int C1, int TY, int C3>
-__global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Args a) {
+__global__ __launch_bounds__(256, C0 > 32 ? 1 : TY == 8 ? 2 : 3) void stem2_kernel(const S2Args a) {
+    constexpr int NT0 = C0 <= 32 ? 2 : 3;                        // 16-channel tiles of the stem conv (m: 48 channels, round 6)
     constexpr int MR = TY / 4;                                   // output rows (16-pixel m-tiles) per wave
     constexpr int TX = 16, SR = 2 * TY + 1, SC = 2 * TX + 1, SP = SR * SC, IR = 2 * SR + 1, IC = 2 * SC + 1;
     constexpr int NCH = (IC + 1 + 3) / 4 + 1, ICS = 4 * NCH;     // patch rows as 18 aligned 4-column chunks starting one column left of the patch
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
     constexpr int TS = (C0 / 2 + 2) | 2;                         // pixel stride of T in dwords: 2 * odd  (24 ch: 14, 32 ch: 18)
     static_assert((TS / 2) % 2 == 1 && TS * 2 >= C0, "T stride");
     constexpr int TSH = TS * 2;                                  // ... in halves
-    constexpr int W0B = 2 * 64 * 16, W1B = KS1 * NT1 * 64 * 16;
+    constexpr int W0B = NT0 * 64 * 16, W1B = KS1 * NT1 * 64 * 16, B0F = 16 * NT0;
     constexpr int KS3 = (C1 + 31) / 32, NT3 = C3 / 16, W3B = KS3 * NT3 * 64 * 16, CO = C3 > 0 ? C3 : C1;   // optional third conv: 1x1, C1 -> C3, SiLU
     constexpr int IN_H = 4 * NCHUNK, OUT_H = TY * TX * CO;
     __shared__ __attribute__((aligned(16))) half_t s_in[(IN_H > OUT_H ? IN_H : OUT_H) + 8];
@@ -71,19 +72,21 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
         uint4* dst = reinterpret_cast<uint4*>(s_w1);
         for (int i = tid; i < W1B / 16; i += 256) dst[i] = src[i];
         if constexpr (C3 > 0) {                                  // third conv's fragments sit behind the two bias vectors
-            const uint4* src3 = reinterpret_cast<const uint4*>(a.rec + W0B + W1B + (32 + C1) * 4);
+            const uint4* src3 = reinterpret_cast<const uint4*>(a.rec + W0B + W1B + (B0F + C1) * 4);
             for (int i = tid; i < W3B / 16; i += 256) dst[W1B / 16 + i] = src3[i];
         }
     }
     const half8_t w0a = reinterpret_cast<const half8_t*>(a.rec)[lane], w0b = reinterpret_cast<const half8_t*>(a.rec)[64 + lane];
+    const half8_t w0c = reinterpret_cast<const half8_t*>(a.rec)[(NT0 - 1) * 64 + lane];                                               // third tile (NT0 = 3; else = w0b, unused)
     const float* bias = reinterpret_cast<const float*>(a.rec + W0B + W1B);
     const f32x4_t b0a = *reinterpret_cast<const f32x4_t*>(bias + 4 * g), b0b = *reinterpret_cast<const f32x4_t*>(bias + 16 + 4 * g);   // lane (g, n): channels 16t + 4g + q
+    const f32x4_t b0c = *reinterpret_cast<const f32x4_t*>(bias + 16 * (NT0 - 1) + 4 * g);
     f32x4_t b1[NT1];
 #pragma unroll
-    for (int t = 0; t < NT1; ++t) b1[t] = *reinterpret_cast<const f32x4_t*>(bias + 32 + 16 * t + 4 * g);
+    for (int t = 0; t < NT1; ++t) b1[t] = *reinterpret_cast<const f32x4_t*>(bias + B0F + 16 * t + 4 * g);
     f32x4_t b3[NT3 > 0 ? NT3 : 1];
     if constexpr (C3 > 0) {
-        const float* bias3 = reinterpret_cast<const float*>(a.rec + W0B + W1B + (32 + C1) * 4 + W3B);
+        const float* bias3 = reinterpret_cast<const float*>(a.rec + W0B + W1B + (B0F + C1) * 4 + W3B);
 #pragma unroll
         for (int t = 0; t < NT3; ++t) b3[t] = *reinterpret_cast<const f32x4_t*>(bias3 + 16 * t + 4 * g);
     }
@@ -158,6 +161,8 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                 const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
                 const f32x4_t ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0a, bf, z, 0, 0, 0);
                 const f32x4_t cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, bf, z, 0, 0, 0);
+                f32x4_t cc = z;
+                if constexpr (NT0 == 3) cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0c, bf, z, 0, 0, 0);
                 if (pp < SP) {
                     const bool in = (unsigned)(2 * Y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * X0 - 1 + c) < (unsigned)a.W0;   // else: zero padding of conv 2
                     half4_t va, vb;
@@ -168,6 +173,12 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
                     }
                     *reinterpret_cast<half4_t*>(s_T + pp * TSH + 4 * g) = va;
                     if (16 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 16 + 4 * g) = vb;
+                    if constexpr (NT0 == 3) {
+                        half4_t vc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) vc[q] = (half_t)(in ? fmaxf(cc[q] + b0c[q], 0.f) : 0.f);
+                        if (32 + 4 * g < C0) *reinterpret_cast<half4_t*>(s_T + pp * TSH + 32 + 4 * g) = vc;
+                    }
                 }
             }
         } else if (!(MAF_KO & 1)) {
@@ -300,14 +311,15 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void stem2_kernel(const S2Arg
 }  // namespace
 
 extern "C" int64_t maf_stem2_record_bytes(int32_t C0, int32_t C1, int32_t C3) {
-    const int ks1 = (9 * (C0 / 8) + 3) / 4;
-    const int64_t base = 2 * 64 * 16 + (int64_t)ks1 * (C1 / 16) * 64 * 16 + 32 * 4 + C1 * 4;
+    const int ks1 = (9 * (C0 / 8) + 3) / 4, nt0 = C0 <= 32 ? 2 : 3;
+    const int64_t base = nt0 * 64 * 16 + (int64_t)ks1 * (C1 / 16) * 64 * 16 + nt0 * 16 * 4 + C1 * 4;
     return C3 > 0 ? base + (int64_t)((C1 + 31) / 32) * (C3 / 16) * 64 * 16 + C3 * 4 : base;
 }
 
 int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->dtype == MAF_F16, "stem2: fp16 engine only");
-    MAF_REQUIRE(op->Cin == 3 && ((op->ksize == 24 && op->Cout == 48) || (op->ksize == 32 && op->Cout == 64)), "stem2: (C0, C1) must be (24, 48) or (32, 64); ksize carries C0");
+    MAF_REQUIRE(op->Cin == 3 && ((op->ksize == 24 && op->Cout == 48) || (op->ksize == 32 && op->Cout == 64) || (op->ksize == 48 && op->Cout == 96)),
+                "stem2: (C0, C1) must be (24, 48), (32, 64) or (48, 96); ksize carries C0");
     MAF_REQUIRE(op->act == MAF_ACT_RELU, "stem2: both RepVGG blocks end in ReLU (common.py:198)");
     MAF_REQUIRE(op->nc == 0 || op->nc == op->Cout, "stem2: the optional third conv (nc = its output channels; 1x1 + SiLU) must keep the channel count (48 -> 48, 64 -> 64)");
     MAF_REQUIRE(op->src[0].ptr && op->w && op->out, "stem2: null pointer");
@@ -322,17 +334,20 @@ int maf_launch_stem2(const maf_op_t* op, hipStream_t s) {
     a.out2 = static_cast<half_t*>(const_cast<void*>(op->aux[0])); a.out2_stride = op->reg_stride;
     MAF_REQUIRE(!a.out2 || (op->nc == op->Cout && op->Cout % 16 == 0 && op->reg_stride % 8 == 0 && op->reg_stride >= op->Cout / 2),
                 "stem2: a second output (aux[0] = the upper half of the channels, reg_stride = its pixel stride, a multiple of 8) needs the third conv");
-    const int ty_rows = op->tile_p == 4 ? 4 : 8;                  // tile height of the quarter-resolution map (tile_p: 0 / 8 = 8 rows, 4 = 4 rows: less LDS and registers, more halo)
+    const int ty_rows = (op->tile_p == 4 || op->Cout == 96) ? 4 : 8;                  // tile height of the quarter-resolution map (tile_p: 0 / 8 = 8 rows, 4 = 4 rows: less LDS and registers, more halo)
     a.tilesX = maf_cdiv(a.W1, 16); a.tilesY = maf_cdiv(a.H1, ty_rows); a.ntiles = a.B * a.tilesX * a.tilesY;
     a.in_scale = op->in_dtype == MAF_U8 ? 1.0f / 255.0f : 1.0f;
-    const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : (ty_rows == 4 ? 768 : 512))), blk(256);
+    const dim3 grid(std::min(a.ntiles, op->tile_k > 0 ? op->tile_k : op->Cout == 96 ? 256 : (ty_rows == 4 ? 768 : 512))), blk(256);
 #define MAF_S2(TI, C0, C1, C3) do { if (ty_rows == 4) hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 4, C3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((stem2_kernel<TI, C0, C1, 8, C3>), grid, blk, 0, s, a); } while (0)
-#define MAF_S2T(TI) do { if (op->Cout == 48) { if (op->nc) MAF_S2(TI, 24, 48, 48); else MAF_S2(TI, 24, 48, 0); } else { if (op->nc) MAF_S2(TI, 32, 64, 64); else MAF_S2(TI, 32, 64, 0); } } while (0)
+    // (48, 96) [m, round 6]: 84 + 18 KiB of weights + the 4-row stem tile (31 KiB) + the patch / output stage (12 KiB) = 145 KiB of LDS: 4-row tiles only, one workgroup per CU
+#define MAF_S2M(TI) do { if (op->nc) hipLaunchKernelGGL((stem2_kernel<TI, 48, 96, 4, 96>), grid, blk, 0, s, a); else hipLaunchKernelGGL((stem2_kernel<TI, 48, 96, 4, 0>), grid, blk, 0, s, a); } while (0)
+#define MAF_S2T(TI) do { if (op->Cout == 96) MAF_S2M(TI); else if (op->Cout == 48) { if (op->nc) MAF_S2(TI, 24, 48, 48); else MAF_S2(TI, 24, 48, 0); } else { if (op->nc) MAF_S2(TI, 32, 64, 64); else MAF_S2(TI, 32, 64, 0); } } while (0)
     if (op->in_dtype == MAF_F16) MAF_S2T(half_t);
     else if (op->in_dtype == MAF_F32) MAF_S2T(float);
     else if (op->in_dtype == MAF_U8) MAF_S2T(uint8_t);
     else { maf_set_error("stem2: bad in_dtype"); return MAF_E_ARG; }
 #undef MAF_S2T
+#undef MAF_S2M
 #undef MAF_S2
     return maf_check_hip(hipGetLastError(), "stem2 launch");
 }

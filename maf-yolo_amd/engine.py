@@ -216,7 +216,7 @@ class Plan:
             elif node.kind == "repvgg":
                 w, b = m.fused()
                 if node.i == 0 and self.fuse_stem and len(model.nodes) > 1 and model.nodes[1].kind == "repvgg" and list(model.nodes[1].sources()) == [0] \
-                        and (node.cout, model.nodes[1].cout) in ((24, 48), (32, 64)) and not any(0 in n_.sources() for n_ in model.nodes[2:]):
+                        and (node.cout, model.nodes[1].cout) in ((24, 48), (32, 64), (48, 96)) and not any(0 in n_.sources() for n_ in model.nodes[2:]):
                     self._stem2 = (w, b, node.cout)               # emitted together with node 1
                     y.append(None)
                     continue

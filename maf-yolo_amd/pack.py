@@ -289,16 +289,17 @@ def pack_stem2(w0, b0, w1, b1, w3=None, b3=None):
     the 1x1 conv w3 [C3,C1] + b3 that follows (appended: fragments [C3/16][ceil(C1/32)][64][8] f16 — lane (g, i): output channel 16t + i,
     k-slot q of step j = channel 32j + 4g + q for q < 4, 32j + 16 + 4g + q - 4 otherwise, the order the accumulators of conv 1 come in —
     then b3 fp32 [C3]).
-    Layout: B fragments of conv 0 [2 tiles][64 lanes][8] f16 (lane (g, n): tap k = 8g + j = (c*3 + ky)*3 + kx, output channel 16t + n;
+    Layout: B fragments of conv 0 [NT0 = 2 (C0 <= 32) or 3 (C0 = 48) tiles][64 lanes][8] f16 (lane (g, n): tap k = 8g + j = (c*3 + ky)*3 + kx, output channel 16t + n;
     zero for k >= 27 and channels >= C0) | B fragments of conv 1 [ceil(9*C0/8 / 4)][C1/16][64][8] f16 (lane (g, n) of k-step s: pair
     q = 4s + g -> tap q // (C0/8), channel group q % (C0/8); element j = input channel 8*group + j; output channel 16t + n; zero for
-    pairs past the last tap) | b0 fp32 [32] (zero padded) | b1 fp32 [C1]."""
+    pairs past the last tap) | b0 fp32 [16 NT0] (zero padded) | b1 fp32 [C1]."""
     w0 = w0.detach().float().cpu(); w1 = w1.detach().float().cpu()
     C0, C1 = w0.shape[0], w1.shape[0]
-    assert w0.shape[1:] == (3, 3, 3) and w1.shape[1:] == (C0, 3, 3) and C0 % 8 == 0 and C0 <= 32 and C1 % 16 == 0
-    m0 = torch.zeros(32, 32)                                          # [k][channel]
+    assert w0.shape[1:] == (3, 3, 3) and w1.shape[1:] == (C0, 3, 3) and C0 % 8 == 0 and C0 <= 48 and C1 % 16 == 0
+    nt0 = 2 if C0 <= 32 else 3                                        # 16-channel tiles of conv 0 (n: 24, s: 32 -> 2; m: 48 -> 3, round 6)
+    m0 = torch.zeros(32, 16 * nt0)                                    # [k][channel]
     m0[:27, :C0] = w0.reshape(C0, 27).t()
-    f0 = m0.view(4, 8, 2, 16).permute(2, 0, 3, 1).contiguous().half()           # [t][g][n][j]
+    f0 = m0.view(4, 8, nt0, 16).permute(2, 0, 3, 1).contiguous().half()         # [t][g][n][j]
     gr = C0 // 8
     npair = 9 * gr
     ks1 = (npair + 3) // 4
@@ -307,9 +308,9 @@ def pack_stem2(w0, b0, w1, b1, w3=None, b3=None):
         tap, grp = divmod(q, gr)
         m1[q] = w1[:, 8 * grp:8 * grp + 8, tap // 3, tap % 3].t()
     f1 = m1.view(ks1, 4, 8, C1 // 16, 16).permute(0, 3, 1, 4, 2).contiguous().half()   # [s][t][g][n][j]
-    b0p = torch.zeros(32); b0p[:C0] = b0.detach().float().cpu()
+    b0p = torch.zeros(16 * nt0); b0p[:C0] = b0.detach().float().cpu()
     parts = [f0.reshape(-1).view(torch.uint8), f1.reshape(-1).view(torch.uint8), b0p.view(torch.uint8), b1.detach().float().cpu().contiguous().view(torch.uint8)]
-    n = 2048 + ks1 * (C1 // 16) * 1024 + 128 + C1 * 4
+    n = nt0 * 1024 + ks1 * (C1 // 16) * 1024 + nt0 * 64 + C1 * 4
     if w3 is not None:
         w3 = w3.detach().float().cpu().reshape(w3.shape[0], -1)
         C3 = w3.shape[0]

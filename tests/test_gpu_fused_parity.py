@@ -81,7 +81,7 @@ def test_head_tail_vs_fp32_torch(c, B, H, W, lvl, iters):
     assert err <= 2e-3 * scale + 2e-3, (err, scale)
 
 
-@pytest.mark.parametrize("cfg", [(24, 48), (32, 64)])
+@pytest.mark.parametrize("cfg", [(24, 48), (32, 64), (48, 96)])
 @pytest.mark.parametrize("third", [True, False])
 @pytest.mark.parametrize("B,H,W,dt,rows", [(2, 64, 96, "f16", 8), (1, 100, 72, "u8", 8), (2, 352, 608, "f16", 4), (3, 36, 20, "f32", 4), (1, 640, 640, "u8", 8)])
 def test_stem2_vs_fp32_torch(cfg, third, B, H, W, dt, rows):

@@ -475,7 +475,8 @@ def test_fused_head_tail_matches_unfused(shape, scale):
 
 
 @pytest.mark.parametrize("shape,dt,scale", [((2, 320, 320), "f16", "n"), ((3, 256, 384), "u8", "n"), ((2, 352, 608), "f16", "n"), ((32, 640, 640), "u8", "n"),
-                                            ((1, 64, 96), "f32", "n"), ((2, 320, 352), "f16", "s"), ((2, 96, 64), "u8", "s")])
+                                            ((1, 64, 96), "f32", "n"), ((2, 320, 352), "f16", "s"), ((2, 96, 64), "u8", "s"),
+                                            ((2, 320, 288), "f16", "m"), ((1, 96, 160), "u8", "m")])
 def test_fused_stem_matches_unfused(shape, dt, scale):
     """MAF_OP_STEM2 (backbone.0 + backbone.1 in one launch, both on the matrix cores, the half-resolution tensor in LDS) vs the VALU stem +
     the 3x3 s2 MFMA conv: node 1's output to fp16 rounding (the fused stem rounds its weights to fp16, the VALU stem keeps them fp32),

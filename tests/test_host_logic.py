@@ -215,17 +215,17 @@ def test_plan_builds_on_cpu(built, scale, nops32):
     assert len(Plan(m, 2, 64, 64, lib.F32, lib.F32, torch.device("cpu")).ops) == nops32
     m.fuse_stem = True                             # backbone.0 + backbone.1 in one launch (scale n: 24 -> 48 channels)
     st = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
-    if scale in ("n", "s"):                        # ... and the 1x1 that opens backbone.2 rides along (its output goes straight into the concat buffer)
+    if scale in ("n", "s", "m"):                   # ... and the 1x1 that opens backbone.2 rides along (its output goes straight into the concat buffer); m (48 -> 96): round 6
         assert len(st.ops) == len(ht.ops) - 2 and st.ops[0].kind == lib.OP_STEM2
-        assert (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].nc, st.ops[0].H, st.ops[0].Hin) == {"n": (24, 48, 48, 16, 64), "s": (32, 64, 64, 16, 64)}[scale]
+        assert (st.ops[0].ksize, st.ops[0].Cout, st.ops[0].nc, st.ops[0].H, st.ops[0].Hin) == {"n": (24, 48, 48, 16, 64), "s": (32, 64, 64, 16, 64), "m": (48, 96, 96, 16, 64)}[scale]
         # ... as two dense halves (one tensor per slot of RepHDW's concatenation; its closing 1x1 reads them as separate sources)
-        c_ = {"n": 24, "s": 32}[scale]
+        c_ = {"n": 24, "s": 32, "m": 48}[scale]
         assert st.ops[0].out_stride == c_ and st.ops[0].aux[0] and st.ops[0].reg_stride == c_ and st.op_names[0] == "backbone.0+1+2.conv1"
         cv2 = st.ops[st.op_names.index("backbone.2.conv2")]
-        assert cv2.nsrc == {"n": 3, "s": 4}[scale] and all(cv2.src[k].C == c_ and cv2.src[k].stride == c_ and cv2.src[k].coff == 0 for k in range(cv2.nsrc))
+        assert cv2.nsrc == {"n": 3, "s": 4, "m": 4}[scale] and all(cv2.src[k].C == c_ and cv2.src[k].stride == c_ and cv2.src[k].coff == 0 for k in range(cv2.nsrc))
         m.split_cat = False                        # the interleaved concat buffer
         il = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
-        assert il.ops[0].out_stride == {"n": 72, "s": 128}[scale] and not il.ops[0].aux[0] and il.ops[il.op_names.index("backbone.2.conv2")].nsrc == 1
+        assert il.ops[0].out_stride == {"n": 72, "s": 128, "m": 192}[scale] and not il.ops[0].aux[0] and il.ops[il.op_names.index("backbone.2.conv2")].nsrc == 1
         del m.split_cat
         m.fuse_stem = 1
         st1 = Plan(m, 2, 64, 64, lib.F16, lib.U8, torch.device("cpu"), fuse=False)
