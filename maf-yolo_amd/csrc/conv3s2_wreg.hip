@@ -1,6 +1,7 @@
 // 3x3 stride-2 pad-1 conv with the WEIGHTS IN REGISTERS (tile_k = 7 of MAF_OP_CONV3X3S2): ConvWrapper / MPRep.conv2 / RepVGGBlock in deploy form
 // (yolov6/layers/common.py:76-83, 776-792, 216-217) for the layers whose 9 * Cin * Cout weights do not fit the LDS but do fit the register
-// file of one workgroup — 128 -> 128 (the side convs of the MAFPN neck, backbone.23 / .24 / .27 / .28 of MAF-YOLO-n: 295 KB), 96 -> 96, 96 -> 64.
+// file of one workgroup — 128 -> 128 (the side convs of the MAFPN neck, backbone.23 / .24 / .27 / .28 of MAF-YOLO-n: 295 KB), 96 -> 96, 96 -> 64, 64 -> 64 and
+// (round 6) the side convs of s whose input fits the 256-byte patch pixel: 64 -> 96, 128 -> 96.
 //
 // Why: the generic template (conv_mfma.inc.h VAR_3X3S2) reads every input pixel 2.25 times (the taps of neighbouring outputs overlap) for
 // every channel tile and fetches its weight fragments once per wave and k-step: knock-out builds (tools/probe_ko.sh) put 40 of 79 us of the
@@ -288,6 +289,11 @@ static int w3_shape(int cin, int cout, int* nwn, int* nwm) {
     if (cin == 96 && cout == 96) { *nwn = 6; *nwm = 1; return 1; }
     if (cin == 96 && cout == 64) { *nwn = 4; *nwm = 2; return 1; }
     if (cin == 64 && cout == 64) { *nwn = 4; *nwm = 2; return 1; }
+    // round 6 — the ConvWrapper side convs of s whose input fits the 256-byte patch pixel (Cin <= 128): backbone.18 / .14 (64 -> 96 on 160 x 160, 128 -> 96 on 80 x 80),
+    // one 16-channel tile per wave.  (m's backbone.18, 96 -> 192, was tried as twelve waves of one tile each: 168 registers with spills, two patch buffers only — the
+    // generic template stayed faster, 178 us, and the instantiation was dropped.)
+    if (cin == 64 && cout == 96) { *nwn = 6; *nwm = 1; return 1; }
+    if (cin == 128 && cout == 96) { *nwn = 6; *nwm = 1; return 1; }
     return 0;
 }
 
@@ -313,7 +319,7 @@ int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s) {
     MAF_REQUIRE(op->act >= 0 && op->act <= 3, "conv3x3s2: bad act");
     int nwn, nwm;
     if (!w3_shape(op->Cin, op->Cout, &nwn, &nwm)) {
-        maf_set_error("conv3x3s2 (tile_k = 7): (Cin, Cout) must be (128, 128), (96, 96), (96, 64) or (64, 64)");
+        maf_set_error("conv3x3s2 (tile_k = 7): (Cin, Cout) must be (128, 128), (96, 96), (96, 64), (64, 64), (64, 96) or (128, 96)");
         return MAF_E_UNSUPPORTED;
     }
     C3wArgs a;
@@ -344,6 +350,8 @@ int maf_launch_conv3s2_wreg(const maf_op_t* op, hipStream_t s) {
     if (op->Cin == 128 && op->Cout == 128) MAF_W3(128, 128, 8, 1);
     if (op->Cin == 96 && op->Cout == 96) MAF_W3(96, 96, 6, 1);
     if (op->Cin == 96 && op->Cout == 64) MAF_W3(96, 64, 4, 2);
+    if (op->Cin == 64 && op->Cout == 96) MAF_W3(64, 96, 6, 1);
+    if (op->Cin == 128 && op->Cout == 96) MAF_W3(128, 96, 6, 1);
     MAF_W3(64, 64, 4, 2);
 #undef MAF_W3
 }

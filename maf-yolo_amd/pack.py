@@ -363,7 +363,7 @@ def pack_mprep_lds(w, b, w1, b1):
     return rec
 
 
-_WREG_SHAPES = {(128, 128): (8, 1), (96, 96): (6, 1), (96, 64): (4, 2), (64, 64): (4, 2)}        # (Cin, Cout) -> (waves along the channels, waves along the pixels)
+_WREG_SHAPES = {(128, 128): (8, 1), (96, 96): (6, 1), (96, 64): (4, 2), (64, 64): (4, 2), (64, 96): (6, 1), (128, 96): (6, 1)}        # (Cin, Cout) -> (waves along the channels, waves along the pixels)
 
 
 def conv3x3_wreg_shape(cin, cout):

@@ -304,7 +304,8 @@ def test_conv3x3_stride2(dt, cin, cout, pt, ct, act):
 
 
 @pytest.mark.parametrize("cin,cout,act,hw", [(128, 128, lib.ACT_SILU, (40, 40)), (128, 128, lib.ACT_RELU, (21, 35)), (96, 96, lib.ACT_RELU, (38, 50)), (96, 64, lib.ACT_SILU, (80, 80)),
-                                             (64, 64, lib.ACT_SILU, (16, 18)), (128, 128, lib.ACT_SILU, (80, 80))])
+                                             (64, 64, lib.ACT_SILU, (16, 18)), (128, 128, lib.ACT_SILU, (80, 80)),
+                                             (64, 96, lib.ACT_SILU, (40, 44)), (64, 96, lib.ACT_SILU, (13, 22)), (128, 96, lib.ACT_SILU, (41, 40))])   # round 6: the side convs of s
 @pytest.mark.parametrize("twin", [False, True])
 def test_conv3x3_stride2_register_resident_weights(cin, cout, act, hw, twin):
     """tile_k = 7 (csrc/conv3s2_wreg.hip): every weight fragment in registers, the input patch of a 4 x 8 output tile by DMA into a source-permuted
