@@ -3,6 +3,8 @@
 // workgroup per CU, one wave per SIMD with the whole register file for its two activation tiles.  tile_c in {4, 6, 8}.
 #include "conv_stream_lds.inc.h"
 
+int maf_conv1x1_stream_lds_xwide(const ConvArgs& a, int var, hipStream_t s);      // 26 .. 40 k-steps at tile_c = 4 (conv_stream_lds_xwide.hip)
+
 namespace {
 
 template <int CT, bool MULTI>
@@ -19,6 +21,7 @@ int launch_wide(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 int maf_conv1x1_stream_lds_wide(const ConvArgs& a, int var, int ct, hipStream_t s) {
+    if (ct == 4 && a.ksteps > 24) return maf_conv1x1_stream_lds_xwide(a, var, s);
     if (ct == 4) return var == VAR_MULTI ? launch_wide<4, true>(a, s) : launch_wide<4, false>(a, s);
     if (ct == 6) return var == VAR_MULTI ? launch_wide<6, true>(a, s) : launch_wide<6, false>(a, s);
     if (ct == 8) return var == VAR_MULTI ? launch_wide<8, true>(a, s) : launch_wide<8, false>(a, s);

@@ -54,6 +54,8 @@ def stream_lds_ok(ksteps, ct):
     """Instantiations of the persistent 1x1 conv with LDS-resident weights (tile_k = 5: csrc/conv_stream_lds.hip, conv_stream_lds_wide.hip)."""
     if 2 <= ksteps <= 12:
         return ksteps * ct <= 96
+    if ct == 4 and ksteps in (26, 28, 30, 32, 34, 36, 40):          # conv_stream_lds_xwide.hip (round 6: the 832 ... 1280-channel reductions of s / m)
+        return True
     return ct in (4, 6, 8) and (13 <= ksteps <= 20 or ksteps == 24) and ksteps * ct <= 160
 
 

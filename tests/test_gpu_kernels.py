@@ -171,7 +171,9 @@ def test_conv1x1_persistent_stream(cin, cout, pt, ct, act):
 
 
 @pytest.mark.parametrize("kind,cin,cout,ct", [("direct", 200, 128, 8), ("direct", 384, 96, 6), ("direct", 72, 48, 4), ("direct", 144, 24, 2), ("direct", 576, 192, 6), ("direct", 768, 96, 6), ("direct", 576, 128, 8), ("direct", 448, 64, 4),
-                                              ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4), ("multi8", 0, 128, 8), ("multi8", 0, 192, 6)])
+                                              ("multi", 0, 96, 6), ("multi", 0, 128, 8), ("multi", 0, 64, 4), ("multi8", 0, 128, 8), ("multi8", 0, 192, 6),
+                                              # round 6 (csrc/conv_stream_lds_xwide.hip): 26 .. 40 k-steps at tile_c = 4 — the 832 ... 1280-channel reductions of s / m
+                                              ("direct", 1024, 128, 4), ("direct", 1280, 64, 4), ("direct", 896, 192, 4), ("direct", 1152, 80, 4), ("multi26", 0, 192, 4), ("multi34", 0, 64, 4)])
 def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     """tile_k = 5: persistent waves with the channel tile's weights resident in LDS; single source or concat (with upsample)."""
     g = torch.Generator().manual_seed(31 + cout + ct)
@@ -184,7 +186,7 @@ def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
         xs[..., 8:] = _nhwc(x, dt)
         srcs, full = [(xs, cin, cin + 8, 8, 0)], x
     else:
-        ca, cb, cc = (40, 64, 24) if kind == "multi" else (128, 192, 128)       # multi8: a wide MAFPN concat (14 k-steps), the shapes the eight-wave form is for
+        ca, cb, cc = {"multi": (40, 64, 24), "multi8": (128, 192, 128), "multi26": (320, 256, 256), "multi34": (384, 512, 192)}[kind]   # multi8: a wide MAFPN concat (14 k-steps), the shapes the eight-wave form is for; multi26 / 34: s / m (backbone.26.conv1, backbone.16.conv1)
         cin = ca + cb + cc
         a = _q(torch.randn(B, ca, H, W, generator=g), dt)
         bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
@@ -207,7 +209,7 @@ def test_conv1x1_persistent_lds_weights(kind, cin, cout, ct):
     out8 = torch.full((B, H, W, cout + 8), 5.0, dtype=DT[dt], device=DEV)
     op8 = _conv_op(lib.OP_CONV1X1, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, out8, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), 2, ct)
     op8.tile_k = 5
-    if ct >= 4 and 64 <= ksteps * ct <= 160 and 8 <= ksteps:
+    if ct >= 4 and 64 <= ksteps * ct <= 160 and 8 <= ksteps <= 24:
         _launch(op8)
         assert torch.equal(out8, out)
     else:
