@@ -842,23 +842,25 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
         return Box{v[0], v[1], v[2], v[3], p->area};
     };
-    // `lanes`: the lanes whose verdict counts (a scalar mask: valid candidates, for a triangle row the later ones) — applied to the ballots, not to per-lane predicates
-    auto overlaps = [&](const Box k, const Box c, unsigned long long lanes) -> unsigned long long {
+    // One (earlier box, this lane's candidate) verdict per lane.  The single-precision screen of iou_gt decides all but the pairs inside a band of 3e-7 x union around the
+    // threshold; the loops below run the screen alone (two ballots per box: decided hits, undecided lanes) and only if some lane of the wave was left undecided by ANY box
+    // — practically never — does the wave walk its boxes again with the exact form for those lanes.  (A pair the screen decided gets the same verdict from iou_gt, which
+    // starts with the same screen: re-testing every box for the open lanes is consistent.)
+    auto screen = [&](const Box k, const Box c, unsigned long long& hits, unsigned long long& open) {
         const float w = fmaxf(0.f, fminf(k.x2, c.x2) - fmaxf(k.x1, c.x1)), h = fmaxf(0.f, fminf(k.y2, c.y2) - fmaxf(k.y1, c.y1));
         const float inter = w * h, uni = k.area + c.area - inter;
         const float d = __builtin_fmaf(-iouthr.m32, uni, inter);                 // = iou_screen
         const bool decided = uni > 0.f && fabsf(d) > 3e-7f * uni;
-        unsigned long long hits = __ballot(decided && d > 0.f);
-        const unsigned long long open = __ballot(!decided) & lanes;             // inside the band (or a NaN / infinite / non-positive union): the exact form decides
-        if (open) {
-            bool hit = false;
-            if ((open >> lane) & 1ull) {
-                const Cand kc = {k.x1, k.y1, k.x2, k.y2, k.area, 0.f, 0u, 0u}, cc = {c.x1, c.y1, c.x2, c.y2, c.area, 0.f, 0u, 0u};
-                hit = iou_gt(kc, cc, iouthr);
-            }
-            hits |= __ballot(hit);
+        hits = __ballot(decided && d > 0.f);
+        open = __ballot(!decided);
+    };
+    auto exact = [&](const Box k, const Box c, unsigned long long lanes) -> unsigned long long {
+        bool hit = false;
+        if ((lanes >> lane) & 1ull) {
+            const Cand kc = {k.x1, k.y1, k.x2, k.y2, k.area, 0.f, 0u, 0u}, cc = {c.x1, c.y1, c.x2, c.y2, c.area, 0.f, 0u, 0u};
+            hit = iou_gt(kc, cc, iouthr);
         }
-        return hits & lanes;
+        return __ballot(hit) & lanes;
     };
     // tests of block `blk` (in cb[buf]) that do not need the verdict on the block before it: its own triangle, and the kept boxes [k0, k1); waves [w0, NWV) share them
     auto test_block = [&](int blk, int buf, int k0, int k1, bool triangle, int w0) {
@@ -869,17 +871,31 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
         if (w < 0) return;
         if (triangle)
             for (int i = w; i < nvalid; i += nw) {
-                const unsigned long long m = overlaps(ld(&cb[buf][i]), me, valid & (i == 63 ? 0ull : (~0ull << (i + 1))));
-                if (lane == 0) diag[buf][i] = m;
+                const unsigned long long later = valid & (i == 63 ? 0ull : (~0ull << (i + 1)));      // row i: candidate i against the later ones
+                const Box bi = ld(&cb[buf][i]);
+                unsigned long long hits, open;
+                screen(bi, me, hits, open);
+                hits &= later;
+                if (open & later) hits |= exact(bi, me, open & later);
+                if (lane == 0) diag[buf][i] = hits;
             }
-        unsigned long long dead = 0;                           // wave-uniform
+        unsigned long long dead = 0, open_any = 0;             // wave-uniform
         int k = k0 + w;
         for (; k + nw < k1; k += 2 * nw) {                     // two kept boxes per step: both LDS reads in flight before the first is used
             const Box ka = ld(&kept[k]), kb = ld(&kept[k + nw]);
-            dead |= overlaps(ka, me, valid);
-            dead |= overlaps(kb, me, valid);
+            unsigned long long ha, oa, hb, ob;
+            screen(ka, me, ha, oa);
+            screen(kb, me, hb, ob);
+            dead |= ha | hb; open_any |= oa | ob;
         }
-        if (k < k1) dead |= overlaps(ld(&kept[k]), me, valid);
+        if (k < k1) {
+            unsigned long long ha, oa;
+            screen(ld(&kept[k]), me, ha, oa);
+            dead |= ha; open_any |= oa;
+        }
+        dead &= valid; open_any &= valid & ~dead;              // an undecided lane some other box already suppresses needs no second look
+        if (open_any)
+            for (int kk = k0 + w; kk < k1; kk += nw) dead |= exact(ld(&kept[kk]), me, open_any);
         if (lane == 0 && dead) { atomicOr(&dead_lo[buf], (unsigned int)dead); atomicOr(&dead_hi[buf], (unsigned int)(dead >> 32)); }
     };
     if (tid == 0) { s_nk = 0; dead_lo[0] = dead_hi[0] = dead_lo[1] = dead_hi[1] = 0u; }
