@@ -855,16 +855,21 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
         return Box{v[0], v[1], v[2], v[3], p->area};
     };
     // One (earlier box, this lane's candidate) verdict per lane.  The single-precision screen of iou_gt decides all but the pairs inside a band of 3e-7 x union around the
-    // threshold; the loops below run the screen alone (two ballots per box: decided hits, undecided lanes) and only if some lane of the wave was left undecided by ANY box
+    // threshold; the loops below run the screen alone (two per-lane flags OR-ed over the boxes: hit, undecided) and only if some lane of the wave was left undecided by ANY box
     // — practically never — does the wave walk its boxes again with the exact form for those lanes.  (A pair the screen decided gets the same verdict from iou_gt, which
     // starts with the same screen: re-testing every box for the open lanes is consistent.)
-    auto screen = [&](const Box k, const Box c, unsigned long long& hits, unsigned long long& open) {
-        const float w = fmaxf(0.f, fminf(k.x2, c.x2) - fmaxf(k.x1, c.x1)), h = fmaxf(0.f, fminf(k.y2, c.y2) - fmaxf(k.y1, c.y1));
+    // v_min_f32 / v_max_f32 as they are: fminf / fmaxf put a canonicalising `v_max_f32 x, x, x` in front of every loaded operand (8 of the 43 vector instructions of two
+    // tests).  Same result for every input but a SIGNALLING NaN coordinate (quiet NaNs — what arithmetic produces — give the other operand either way, and leave the pair
+    // undecided: the exact form, which keeps fminf / fmaxf, then decides it).
+    auto vmin = [](float x, float y) -> float { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto vmax = [](float x, float y) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto screen = [&](const Box k, const Box c, bool& hit, bool& open) {      // per-lane verdicts, OR-ed into the caller's (lane masks in scalar registers: one ballot behind the loop)
+        const float w = vmax(0.f, vmin(k.x2, c.x2) - vmax(k.x1, c.x1)), h = vmax(0.f, vmin(k.y2, c.y2) - vmax(k.y1, c.y1));
         const float inter = w * h, uni = k.area + c.area - inter;
         const float d = __builtin_fmaf(-iouthr.m32, uni, inter);                 // = iou_screen
         const bool decided = uni > 0.f && fabsf(d) > 3e-7f * uni;
-        hits = __ballot(decided && d > 0.f);
-        open = __ballot(!decided);
+        hit = hit || (decided && d > 0.f);
+        open = open || !decided;
     };
     auto exact = [&](const Box k, const Box c, unsigned long long lanes) -> unsigned long long {
         bool hit = false;
@@ -885,27 +890,23 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
             for (int i = w; i < nvalid; i += nw) {
                 const unsigned long long later = valid & (i == 63 ? 0ull : (~0ull << (i + 1)));      // row i: candidate i against the later ones
                 const Box bi = ld(&cb[buf][i]);
-                unsigned long long hits, open;
-                screen(bi, me, hits, open);
-                hits &= later;
-                if (open & later) hits |= exact(bi, me, open & later);
+                bool h1 = false, o1 = false;
+                screen(bi, me, h1, o1);
+                unsigned long long hits = __ballot(h1) & later;
+                const unsigned long long open = __ballot(o1) & later;
+                if (open) hits |= exact(bi, me, open);
                 if (lane == 0) diag[buf][i] = hits;
             }
-        unsigned long long dead = 0, open_any = 0;             // wave-uniform
+        bool dl = false, ol = false;
         int k = k0 + w;
         for (; k + nw < k1; k += 2 * nw) {                     // two kept boxes per step: both LDS reads in flight before the first is used
             const Box ka = ld(&kept[k]), kb = ld(&kept[k + nw]);
-            unsigned long long ha, oa, hb, ob;
-            screen(ka, me, ha, oa);
-            screen(kb, me, hb, ob);
-            dead |= ha | hb; open_any |= oa | ob;
+            screen(ka, me, dl, ol);
+            screen(kb, me, dl, ol);
         }
-        if (k < k1) {
-            unsigned long long ha, oa;
-            screen(ld(&kept[k]), me, ha, oa);
-            dead |= ha; open_any |= oa;
-        }
-        dead &= valid; open_any &= valid & ~dead;              // an undecided lane some other box already suppresses needs no second look
+        if (k < k1) screen(ld(&kept[k]), me, dl, ol);
+        unsigned long long dead = __ballot(dl) & valid;        // wave-uniform
+        const unsigned long long open_any = __ballot(ol) & valid & ~dead;      // an undecided lane some other box already suppresses needs no second look
         if (open_any)
             for (int kk = k0 + w; kk < k1; kk += nw) dead |= exact(ld(&kept[kk]), me, open_any);
         if (lane == 0 && dead) { atomicOr(&dead_lo[buf], (unsigned int)dead); atomicOr(&dead_hi[buf], (unsigned int)(dead >> 32)); }
@@ -919,11 +920,18 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
     test_block(0, 0, 0, 0, true, 0);
     __syncthreads();
     int buf = 0;
+#ifdef MAF_NMS_PROF
+    unsigned long long t_dec = 0, t_testA = 0, t_barA = 0, t_B = 0, t_barB = 0, t_all0 = __builtin_readcyclecounter(), nblk = 0;
+#endif
     for (int blk = 0; blk < nb; ++blk, buf ^= 1) {
         // here: cb[buf] = block blk with its triangle and its verdicts against EVERY kept box so far complete; cb[buf ^ 1] = block blk + 1, untested
         const int nk = s_nk;
         if (nk >= a.max_det) break;                            // uniform
         // ---- stage A: wave 0 decides block blk (the serial rule of the matrix scan); the other waves test block blk + 1 against its own triangle and the boxes kept BEFORE
+#ifdef MAF_NMS_PROF
+        const unsigned long long tA0 = __builtin_readcyclecounter();
+        ++nblk;
+#endif
         if (wave == 0) {
             const int nvalid = min(64, n - blk * 64);
             const Cand me = cb[buf][lane];
@@ -947,7 +955,15 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
         } else if (blk + 1 < nb) {
             test_block(blk + 1, buf ^ 1, 0, nk, true, 1);
         }
+#ifdef MAF_NMS_PROF
+        const unsigned long long tA1 = __builtin_readcyclecounter();
+        if (wave == 0) t_dec += tA1 - tA0; else t_testA += tA1 - tA0;
+#endif
         __syncthreads();
+#ifdef MAF_NMS_PROF
+        const unsigned long long tA2 = __builtin_readcyclecounter();
+        t_barA += tA2 - tA1;
+#endif
         if (blk + 1 >= nb) break;
         // ---- stage B: everybody tests block blk + 1 against the boxes block blk has just added; block blk + 2 takes the free buffer
         const int nk2 = s_nk;
@@ -958,9 +974,23 @@ __global__ __launch_bounds__(kGreedyT) void nms_greedy_kernel(const NmsArgs a) {
             const int i3 = (blk + 3) * 64 + tid;
             nxt = i3 < n ? cands[i3] : zero;
         }
+#ifdef MAF_NMS_PROF
+        const unsigned long long tB1 = __builtin_readcyclecounter();
+        t_B += tB1 - tA2;
+#endif
         __syncthreads();
+#ifdef MAF_NMS_PROF
+        t_barB += __builtin_readcyclecounter() - tB1;
+#endif
     }
     __syncthreads();
+#ifdef MAF_NMS_PROF
+    if (b == 0 && lane == 0 && (wave == 0 || wave == 1)) {      // image 0: wave 0 = the decider, wave 1 = a tester
+        const int o = wave * 4;
+        g_nms_dbg[o + 0] = wave == 0 ? t_dec : t_testA; g_nms_dbg[o + 1] = t_barA; g_nms_dbg[o + 2] = t_B; g_nms_dbg[o + 3] = wave == 0 ? (__builtin_readcyclecounter() - t_all0) : ((nblk << 32) | (unsigned)s_nk);
+        if (wave == 1) g_nms_dbg[o + 2] = t_barB;
+    }
+#endif
     // ---- emit rows (x1,y1,x2,y2,conf,cls) of the survivors, un-offset boxes recomputed from the prediction (nms.py:21-28)
     const int nk = s_nk < a.max_det ? s_nk : a.max_det;
     const int no = 5 + a.nc;
