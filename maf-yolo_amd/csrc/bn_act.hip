@@ -57,7 +57,9 @@ constexpr int kU = 4;                                                // independ
 // blockIdx.x % R.  The global atomics are what bounds this kernel when a workgroup sees too few pixels (~40 G atomics/s chip-wide
 // measured, i.e. 2C atomics cost as much as streaming ~250 B per channel): slicing the channels keeps >= 512 pixels per workgroup for
 // any C at >= 2 workgroups per CU.
-template <typename T, bool BWD, bool RES = false>
+// ACT: the activation as a compile-time constant (round 6).  With `a.act` read at run time the SiLU / ReLU / none choice was a scalar compare + branch per ELEMENT in the
+// unrolled streaming loops — 130 branches and 96 s_nop per 32 elements of the backward apply pass, in kernels that are bound by their vector work, not by bytes.
+template <typename T, bool BWD, bool RES = false, int ACT = MAF_ACT_NONE>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs2 a) {
                 const float xh = ((float)xv[j] - mu[j]) * rs[j];
                 float u = __builtin_fmaf(xh, ga[j], be[j]);
                 if (RES) u += (float)rv[j];
-                const float gq = (float)dv[j] * act_grad(u, a.act);
+                const float gq = (float)dv[j] * act_grad(u, ACT);
                 s0[j] += gq; s1[j] = __builtin_fmaf(gq, xh, s1[j]);
             }
         }
@@ -189,7 +191,7 @@ __global__ void bn_det_reduce_kernel(const float* det, int nslot, int C, float* 
 // prologue: per-channel constants from the partial sums into LDS (every workgroup; the sums are added in double, in replica order, so all
 // workgroups agree), workgroup 0 publishes the statistics / parameter gradients; the grid clears the scratch half of the previous call.
 // thread = one N-channel group (its constants live in registers) x a strided set of pixels of the workgroup's chunk
-template <typename T, bool BWD, bool RES = false>
+template <typename T, bool BWD, bool RES = false, int ACT = MAF_ACT_NONE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
                 for (int j = 0; j < N; ++j) {
                     float u = __builtin_fmaf((float)xv[j], sc[j], sh[j]);
                     if (RES) u += (float)rv[j];
-                    ov[j] = (T)act_fwd(u, a.act);
+                    ov[j] = (T)act_fwd(u, ACT);
                 }
             } else {
 #pragma unroll
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs2 a) {
                     const float xh = ((float)xv[j] - mu[j]) * rs[j];
                     float u = __builtin_fmaf(xh, ga[j], be[j]);
                     if (RES) u += (float)rv[j];
-                    const float gq = (float)dv[j] * act_grad(u, a.act);
+                    const float gq = (float)dv[j] * act_grad(u, ACT);
                     if (RES) gv[j] = (T)gq;                          // gradient of the residual input
                     ov[j] = (T)(sc[j] * (gq - k0[j] - xh * k1[j]));
                 }
@@ -431,13 +433,15 @@ extern "C" int maf_bn_forward_ex(const void* x, int32_t x_stride, int32_t M, int
     }
     a.res = residual; a.rs = res_stride;
     const size_t la = (size_t)2 * C * sizeof(float);
+#define MAF_BN_FWD(T_, RES_, ACT_) hipLaunchKernelGGL((bn_apply_kernel<T_, false, RES_, ACT_>), dim3(ga), dim3(256), la, s, a)
+#define MAF_BN_FWD_A(T_, RES_) do { if (act == MAF_ACT_SILU) MAF_BN_FWD(T_, RES_, MAF_ACT_SILU); else if (act == MAF_ACT_RELU) MAF_BN_FWD(T_, RES_, MAF_ACT_RELU); else MAF_BN_FWD(T_, RES_, MAF_ACT_NONE); } while (0)
     if (residual) {
-        if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false, true>), dim3(ga), dim3(256), la, s, a);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, false, true>), dim3(ga), dim3(256), la, s, a);
+        if (dtype == MAF_F16) MAF_BN_FWD_A(half_t, true); else MAF_BN_FWD_A(float, true);
     } else {
-        if (dtype == MAF_F16) hipLaunchKernelGGL((bn_apply_kernel<half_t, false>), dim3(ga), dim3(256), la, s, a);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(ga), dim3(256), la, s, a);
+        if (dtype == MAF_F16) MAF_BN_FWD_A(half_t, false); else MAF_BN_FWD_A(float, false);
     }
+#undef MAF_BN_FWD_A
+#undef MAF_BN_FWD
     return maf_check_hip(hipGetLastError(), "bn_forward launch");
 }
 
@@ -486,24 +490,15 @@ extern "C" int maf_bn_backward_acc(const void* x, int32_t x_stride, const void* 
     a.res = residual; a.rs = res_stride; a.dres = dres; a.drs = dres_stride;
     const size_t la = (size_t)6 * C * sizeof(float);
     if (int rc = det_prepare(a, gs, C, dtype, &lds_s, s)) return rc;
+#define MAF_BN_BWD(T_, RES_, ACT_) do { hipLaunchKernelGGL((bn_stats_kernel<T_, true, RES_, ACT_>), gs, dim3(256), lds_s, s, a); det_reduce(a, gs, C, s); \
+                                        hipLaunchKernelGGL((bn_apply_kernel<T_, true, RES_, ACT_>), dim3(ga), dim3(256), la, s, a); } while (0)
+#define MAF_BN_BWD_A(T_, RES_) do { if (act == MAF_ACT_SILU) MAF_BN_BWD(T_, RES_, MAF_ACT_SILU); else if (act == MAF_ACT_RELU) MAF_BN_BWD(T_, RES_, MAF_ACT_RELU); else MAF_BN_BWD(T_, RES_, MAF_ACT_NONE); } while (0)
     if (residual) {
-        if (dtype == MAF_F16) {
-            hipLaunchKernelGGL((bn_stats_kernel<half_t, true, true>), gs, dim3(256), lds_s, s, a);
-            det_reduce(a, gs, C, s);
-            hipLaunchKernelGGL((bn_apply_kernel<half_t, true, true>), dim3(ga), dim3(256), la, s, a);
-        } else {
-            hipLaunchKernelGGL((bn_stats_kernel<float, true, true>), gs, dim3(256), lds_s, s, a);
-            det_reduce(a, gs, C, s);
-            hipLaunchKernelGGL((bn_apply_kernel<float, true, true>), dim3(ga), dim3(256), la, s, a);
-        }
-    } else if (dtype == MAF_F16) {
-        hipLaunchKernelGGL((bn_stats_kernel<half_t, true>), gs, dim3(256), lds_s, s, a);
-        det_reduce(a, gs, C, s);
-        hipLaunchKernelGGL((bn_apply_kernel<half_t, true>), dim3(ga), dim3(256), la, s, a);
+        if (dtype == MAF_F16) MAF_BN_BWD_A(half_t, true); else MAF_BN_BWD_A(float, true);
     } else {
-        hipLaunchKernelGGL((bn_stats_kernel<float, true>), gs, dim3(256), lds_s, s, a);
-        det_reduce(a, gs, C, s);
-        hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(ga), dim3(256), la, s, a);
+        if (dtype == MAF_F16) MAF_BN_BWD_A(half_t, false); else MAF_BN_BWD_A(float, false);
     }
+#undef MAF_BN_BWD_A
+#undef MAF_BN_BWD
     return maf_check_hip(hipGetLastError(), "bn_backward launch");
 }
