@@ -17,6 +17,7 @@ SWITCHES = {
     "fuse_tail":         ("MAF_FUSE_TAIL", 1, "what Model.fuse_tail = 'auto' means: 0 off, 1 blocks of one bottleneck (default), 3 every instantiation (s / m opt-in)"),
     "split_cat":         ("MAF_SPLIT_CAT", True, "RepHDW behind the fused stem: one dense tensor per concat slot"),
     "mprep_wreg_min":    ("MAF_MPREP_WREG_MIN", 65536, "output pixels from which MPRep takes the register-weight 3x3 kernel"),
+    "head_tail_256_max": ("MAF_HEAD_TAIL_256_MAX", 16384, "largest level (B * H * W pixels) whose 256-channel head runs as the fused tail (weights streamed through LDS per 16-pixel unit)"),
     "nms_single_max_batch": ("MAF_NMS_SINGLE_MAX_BATCH", 0, "largest batch the single-launch NMS kernel serves (0: never — the seven-launch path is faster, DESIGN.md 8)"),
     "nms_matrix":        ("MAF_NMS_MATRIX", "auto", "all-pairs NMS: 1 = suppression matrix + row scan, 0 = kept-list scan, auto = kept-list under other work (async), matrix alone up to 32 images"),
     # ---- training step (train_ops.py, tape.py, model.py, solver.py, exchange.py)

@@ -45,17 +45,17 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
     if (a.twin) {
         MAF_REQUIRE(op->aux[1] && op->aux[2] && op->aux[3], "conv twin: aux = {src, w, bias, out} of the second conv, all four");
         MAF_REQUIRE(op->nsrc == 1 && op->src[0].mode != MAF_SRC_UP2, "conv twin: single-source variants only");
-        MAF_REQUIRE(op->tile_k <= 2 || op->tile_k == 4, "conv twin: generic, LDS-shared-weight and split-K variants only");
+        MAF_REQUIRE(op->tile_k <= 2 || op->tile_k == 4 || op->tile_k == 8, "conv twin: generic, LDS-shared-weight and split-K variants only");
         a.src_t = op->aux[0]; a.w_t = op->aux[1]; a.bias_t = static_cast<const float*>(op->aux[2]); a.out_t = const_cast<void*>(op->aux[3]);
     }
     int pt = op->tile_p;
     const int ct = op->tile_c;
     MAF_REQUIRE(pt > 0 && ct > 0, "conv: tile_p/tile_c not set");
     const bool ks4 = op->tile_k == 4;
-    MAF_REQUIRE(op->tile_k >= 0 && op->tile_k <= 5, "conv: tile_k must be 1, 2 (weights through LDS), 3 / 5 (persistent streaming 1x1) or 4 (split-K)");
+    MAF_REQUIRE((op->tile_k >= 0 && op->tile_k <= 5) || op->tile_k == 8, "conv: tile_k must be 1, 2 / 8 (weights through LDS), 3 / 5 (persistent streaming 1x1) or 4 (split-K)");
     const bool stream = op->tile_k == 3;
-    const bool lb = op->tile_k == 2;
-    MAF_REQUIRE(!lb || (op->dtype == MAF_F16 && !op->out_f32), "conv: tile_k = 2 is an fp16-output variant");
+    const bool lb = op->tile_k == 2, dma = op->tile_k == 8;
+    MAF_REQUIRE(!(lb || dma) || (op->dtype == MAF_F16 && !op->out_f32), "conv: tile_k = 2 / 8 are fp16-output variants");
     MAF_REQUIRE(!ks4 || pt == 1, "conv: split-K (tile_k = 4) needs tile_p = 1");
     a.nM = ks4 ? maf_cdiv(a.M, 16) : maf_cdiv(a.M, 64 * pt);
     if (ks4) pt = 0;                                                 // dispatch key of the split-K instantiations
@@ -113,6 +113,7 @@ int maf_launch_conv_mfma(const maf_op_t* op, hipStream_t s) {
         return maf_conv1x1_stream_lds(a, var == VAR_POOL2 ? VAR_DIRECT : var, ct, s);      // a pooled / sub-sampled single source: the direct form with a.srcMode[0] set
     }
     if (lb) return maf_conv_mfma_f16_lb(a, var, pt, ct, s);
+    if (dma) return maf_conv_mfma_f16_dma(a, var, pt, ct, s);
     if (op->dtype == MAF_F16) return maf_conv_mfma_f16(a, var, outf32, pt, ct, s);
     return maf_conv_mfma_f32(a, var, false, pt, ct, s);
 }

@@ -70,6 +70,7 @@ enum { VAR_DIRECT = 0, VAR_MULTI = 1, VAR_POOL2 = 2, VAR_3X3S2 = 3, VAR_DGRAD3 =
 int maf_conv_mfma_f16(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f32(const ConvArgs& a, int var, bool outf32, int pt, int ct, hipStream_t s);
 int maf_conv_mfma_f16_lb(const ConvArgs& a, int var, int pt, int ct, hipStream_t s);   // weights shared through LDS (tile_k = 2)
+int maf_conv_mfma_f16_dma(const ConvArgs& a, int var, int pt, int ct, hipStream_t s);  // ... by DMA, a ring of two-k-step stages (tile_k = 8)
 int maf_conv_mfma_dgrad3(const ConvArgs& a, int dtype, int pt, int ct, hipStream_t s);  // VAR_DGRAD3 (conv_mfma_dgrad.hip)
 int maf_conv1x1_stream(const ConvArgs& a, int pt, int ct, hipStream_t s);              // persistent waves, cross-tile prefetch (tile_k = 3)
 int maf_conv1x1_stream_lds(const ConvArgs& a, int var, int ct, hipStream_t s);        // the same with LDS-resident weights (tile_k = 5)
@@ -118,15 +119,28 @@ template <> struct Frag<float> {
     }
 };
 
+template <int OFF> __device__ __forceinline__ void cm_ds_read_b128(u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N> __device__ __forceinline__ void cm_wait_lgkm(u32x4_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }   // "+v": the MFMA that reads `a` stays below the wait
+template <int N> __device__ __forceinline__ void cm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int N, int I = 0, typename Fn>
+__device__ __forceinline__ void cm_static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cm_static_for<N, I + 1>(f);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ typename Frag<T>::type ldg16(const T* p) {
     return *reinterpret_cast<const typename Frag<T>::type*>(p);
 }
 
-template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false, bool LB = false>
+template <typename T, int PT, int CT, int VAR, bool OUTF32, bool KS4 = false, bool LB = false, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(!KS4 || PT == 1, "split-K variant is defined for one pixel tile per wave");
     static_assert(!(KS4 && LB), "split-K and LDS-shared weights are separate variants");
+    static_assert(!DMA || (LB && sizeof(T) == 2 && CT % 2 == 0), "the DMA ring is a form of the LDS-shared-weight variant (fp16, even tile_c)");
     typedef Frag<T> F;
     typedef typename F::type frag_t;
     constexpr int CH = F::CH;
@@ -322,7 +336,162 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
     };
 
-    if constexpr (LB) {
+    if constexpr (LB && DMA) {
+        // tile_k = 8 (round 6): the LDS-shared weights of the branch below, but the fragments travel global -> LDS by DMA (global_load_lds: no registers, no
+        // ds_write), in STAGES of two k-steps through a ring of four slots, three stages in flight ahead of the one being multiplied, ONE barrier per stage
+        // (2 x PT x CT MFMAs per wave between barriers, 16 .. 32; the branch below: one barrier and one register -> LDS copy per k-step).  The wave's own
+        // activation fragments ride the same distance ahead in a register ring.  What it is for: the K-heavy layers of the 40 x 40 / 20 x 20 maps of s and m
+        // (1x1 over 960 .. 1536 concatenated channels, 3x3 stride 2 over 192 .. 384), where the generic form streams every wave's weight fragments out of the L2
+        // separately (15 TB/s of L2 traffic for 1280 -> 384 on 40 x 40: the bound) and the branch below spends its time at barriers.
+        // vmcnt bookkeeping: a wave issues, per stage, FW DMA instructions + KST * PT activation loads, all VMEM loads, which return in order — "at most
+        // (D - 1) stage-issues outstanding" therefore means stage st's pieces (and its activations) have landed; the barrier behind that wait publishes
+        // everybody's pieces and, since every wave is then past the multiplies of stage st - 1, frees slot (st - 1) % R = (st + D) % R for the next DMA.
+        extern __shared__ __attribute__((aligned(16))) unsigned char lb_raw[];
+        constexpr int KST = 2, R = 4, D = 3;
+        constexpr int FR = KST * CT, FW = FR / 4;                         // fragments (KiB) per stage, per wave
+        static_assert(FR % 4 == 0 && R * FR * 1024 <= 65536, "stage splits over the four waves; the ring stays inside one DS offset range");
+        // the DMA as a BUFFER load (descriptor = this channel tile's fragments, per-lane part lane * 16, fragment offset in the scalar operand): the compiler files
+        // global_load_lds under "flat access that may touch LDS and memory" and from then on waits for vmcnt(0) in front of every use of a loaded register —
+        // the activation fragments of the stage three ahead included; a buffer load it counts like any other
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(w_all)) + ((size_t)(n_tile * CT) * w_steps) * 1024, 0, 0x7fffffff, 0x00020000);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);         // provably uniform: the fragment offset stays a scalar
+        frag_t bst[R][KST][PT];
+        // The activation loads of this branch: the addressing of load_b with everything a lane needs held in REGISTERS — the general loader re-reads kernel
+        // arguments with scalar loads inside divergent branches (3x3: Hin, stride, channel offset per tap and pixel tile) and keeps the per-source offsets of a
+        // concat in scratch; either stalls the issue phase of a stage for longer than its multiplies take.
+        auto pin = [](auto v) __attribute__((always_inline)) { asm volatile("" : "+s"(v)); return v; };   // a kernel argument as a live scalar register, not a re-load
+        const int kst_ = pin(a.ksteps), Cin_ = pin(a.Cin);
+        const int str0 = pin(a.srcStride[0]), cof0 = pin(a.srcCoff[0]);
+        int pixm[PT], pixu[PT];                                           // VAR_MULTI: linear pixel, pixel of the half-resolution grid
+        unsigned int tapok[PT];                                           // VAR_3X3S2: bit tap = the tap is inside the image
+        long long tap0[PT];                                               // VAR_3X3S2: element offset of tap (0, 0) (may be negative: never used when the tap is outside)
+        int st1 = 0, st2 = 0, st3 = 0, co1 = 0, co2 = 0, co3 = 0, c1 = 0, c2 = 0, c3 = 0, sc0 = 0, sc1 = 0, sc2 = 0, sc3 = 0;
+        bool up0 = false, up1 = false, up2 = false, up3 = false;
+        const T* p1 = s0; const T* p2 = s0; const T* p3 = s0;
+        if constexpr (VAR == VAR_MULTI) {
+            st1 = pin(a.srcStride[1]); st2 = pin(a.srcStride[2]); st3 = pin(a.srcStride[3]);
+            co1 = pin(a.srcCoff[1]); co2 = pin(a.srcCoff[2]); co3 = pin(a.srcCoff[3]);
+            c1 = pin(a.cum[1]); c2 = pin(a.cum[2]); c3 = pin(a.cum[3]);
+            sc0 = pin(a.srcC[0]); sc1 = pin(a.srcC[1]); sc2 = pin(a.srcC[2]); sc3 = pin(a.srcC[3]);
+            up0 = a.srcMode[0] == MAF_SRC_UP2; up1 = a.nsrc > 1 && a.srcMode[1] == MAF_SRC_UP2; up2 = a.nsrc > 2 && a.srcMode[2] == MAF_SRC_UP2; up3 = a.nsrc > 3 && a.srcMode[3] == MAF_SRC_UP2;
+            p1 = static_cast<const T*>(a.nsrc > 1 ? a.src[1] : a.src[0]); p2 = static_cast<const T*>(a.nsrc > 2 ? a.src[2] : a.src[0]); p3 = static_cast<const T*>(a.nsrc > 3 ? a.src[3] : a.src[0]);   // (constant indices: a computed one sends the argument block through scratch)
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = m_base + pt * 16 + p;
+            const int mm = m < a.M ? m : 0;
+            pixm[pt] = mm; pixu[pt] = mm; tapok[pt] = 0; tap0[pt] = 0;
+            if constexpr (VAR != VAR_DIRECT) {
+                const int x = mm % a.W, t = mm / a.W, y = t % a.H, b = t / a.H;
+                if constexpr (VAR == VAR_MULTI) pixu[pt] = (b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
+                if constexpr (VAR == VAR_3X3S2) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int iy = 2 * y - 1 + tap / 3, ix = 2 * x - 1 + tap % 3;
+                        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win) tapok[pt] |= 1u << tap;
+                    }
+                    tap0[pt] = ((long long)(b * a.Hin + 2 * y - 1) * a.Win + (2 * x - 1)) * str0 + cof0;
+                }
+            }
+        }
+        const int Win_ = VAR == VAR_3X3S2 ? pin(a.Win) : 0;
+        auto load_fast = [&](int step, frag_t (&bf)[PT]) __attribute__((always_inline)) {
+            const bool pad = step > last_step;                             // uniform
+            const int sc = pad ? last_step : step;
+            if (MAF_KO & 2) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) bf[pt] = (frag_t)(T)(0.001f * (float)(lane + step));
+                return;
+            }
+            if constexpr (VAR == VAR_DIRECT) {
+                int c0 = sc * F::KS + g * CH;
+                c0 = c0 < Cin_ ? c0 : 0;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) bf[pt] = ldg16<T>(pad ? zpage : s0 + (size_t)pixm[pt] * str0 + cof0 + c0);
+            } else if constexpr (VAR == VAR_3X3S2) {
+                const int tap = sc / kst_, ks = sc - tap * kst_;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                int c0 = ks * F::KS + g * CH;
+                c0 = c0 < Cin_ ? c0 : 0;
+                const long long toff = (long long)(ky * Win_ + kx) * str0 + c0;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const bool ok = !pad && ((tapok[pt] >> tap) & 1u);
+                    const T* q = s0 + (tap0[pt] + toff);
+                    bf[pt] = ldg16<T>(ok ? q : zpage);
+                }
+            } else {
+                // every captured scalar read HERE, in front of the conditionals: read inside their arms, the loads (from the closure, before it is inlined away) are
+                // merged into one load of a selected ADDRESS, and closure and variables stay in scratch for good (360 bytes, a waterfall loop around every DMA)
+                const int c1v = c1, c2v = c2, c3v = c3, sc0v = sc0, sc1v = sc1, sc2v = sc2, sc3v = sc3, st0v = str0, st1v = st1, st2v = st2, st3v = st3;
+                const int co0v = cof0, co1v = co1, co2v = co2, co3v = co3;
+                const bool up0v = up0, up1v = up1, up2v = up2, up3v = up3;
+                const T* const p0v = s0; const T* const p1v = p1; const T* const p2v = p2; const T* const p3v = p3;
+                const bool i1 = sc >= c1v, i2 = sc >= c2v, i3 = sc >= c3v;  // (scalar) which source this k-step belongs to
+                const int first = i3 ? c3v : i2 ? c2v : i1 ? c1v : 0;
+                const int srcC = i3 ? sc3v : i2 ? sc2v : i1 ? sc1v : sc0v;
+                const int str = i3 ? st3v : i2 ? st2v : i1 ? st1v : st0v;
+                const int cof = i3 ? co3v : i2 ? co2v : i1 ? co1v : co0v;
+                const bool up = i3 ? up3v : i2 ? up2v : i1 ? up1v : up0v;
+                const T* sp = i3 ? p3v : i2 ? p2v : i1 ? p1v : p0v;
+                int c0 = (sc - first) * F::KS + g * CH;
+                c0 = c0 < srcC ? c0 : 0;
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int pu = pixu[pt], pm = pixm[pt];
+                    const int pix = up ? pu : pm;
+                    bf[pt] = ldg16<T>(pad ? zpage : sp + (size_t)pix * str + cof + c0);
+                }
+            }
+        };
+        auto issue = [&](int st, auto slot_tag) __attribute__((always_inline)) {      // stage st -> ring slot (static)
+            constexpr int slot = decltype(slot_tag)::value;
+#pragma unroll
+            for (int i = 0; i < FW; ++i) {
+                const int f = wave_u * FW + i;                            // fragment of the stage: k-step u = f / CT, channel tile ct = f % CT
+                const int u = f / CT, ct = f - u * CT;
+                int step = st * KST + u;
+                step = step > last_step ? last_step : step;               // padding steps re-read the last one (times zero activations)
+                if (!(MAF_KO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (void __attribute__((address_space(3)))*)(lb_raw + (slot * FR + f) * 1024), 16, lane * 16,
+                                                         (ct * w_steps + step) * 1024, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < KST; ++u) load_fast(st * KST + u, bst[slot][u]);
+        };
+        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(lb_raw + lane * 16);
+        const int nstage = (total_steps + KST - 1) / KST;
+        cm_static_for<D>([&](auto j) __attribute__((always_inline)) { issue(decltype(j)::value, j); });
+        for (int st0 = 0; st0 < nstage; st0 += R) {
+            cm_static_for<R>([&](auto q_tag) __attribute__((always_inline)) {
+                constexpr int q = decltype(q_tag)::value;
+                const int st = st0 + q;
+                __builtin_amdgcn_sched_barrier(0);
+                cm_wait_vm<(D - 1) * (FW + KST * PT)>();
+                __builtin_amdgcn_s_barrier();                             // the bare instruction: __syncthreads() carries a fence that waits for vmcnt(0), i.e. for the whole look-ahead
+                __builtin_amdgcn_sched_barrier(0);
+                issue(st + D, std::integral_constant<int, (q + D) % R>{});
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the counter now counts only the reads below
+                u32x4_t wr[FR];
+                cm_static_for<FR>([&](auto f_tag) __attribute__((always_inline)) {
+                    constexpr int f = decltype(f_tag)::value;
+                    cm_ds_read_b128<(q * FR + f) * 1024>(wr[f], lbase);
+                });
+                cm_static_for<FR>([&](auto f_tag) __attribute__((always_inline)) {
+                    constexpr int f = decltype(f_tag)::value, u = f / CT, ct = f % CT;
+                    cm_wait_lgkm<FR - 1 - f>(wr[f]);
+                    const frag_t wf = __builtin_bit_cast(frag_t, wr[f]);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        if (MAF_KO & 8) acc[pt][ct][0] += (float)bst[q][u][pt][0] + (float)wf[0];
+                        else acc[pt][ct] = F::mma(bst[q][u][pt], wf, acc[pt][ct]);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the look-ahead stages past the end (clamped re-reads) are still landing
+    } else if constexpr (LB) {
         // Long reductions (3x3 taps, wide concats): the four waves of a workgroup use the SAME weight fragments, and at
         // CT KiB per k-step per wave the L2 -> L1 weight stream, not HBM, bounds the layer.  Here the workgroup fetches each
         // k-step's CT fragments once (global -> registers during the previous step's MFMAs -> LDS, double-buffered, one
@@ -528,6 +697,23 @@ int launch_lb_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
     MAF_LB(1, 4) MAF_LB(2, 4) MAF_LB(4, 4) MAF_LB(1, 6) MAF_LB(2, 6) MAF_LB(1, 8) MAF_LB(2, 8)
 #undef MAF_LB
     maf_set_error("conv: tile_k = 2 (LDS-shared weights) supports tile_c in {4,6,8}, tile_p in {1,2} (4 with tile_c 4)");
+    return MAF_E_UNSUPPORTED;
+}
+
+template <int PT, int CT, int VAR>
+int launch_dma(const ConvArgs& a, hipStream_t s) {
+    const int grid = maf_cdiv(a.nM, 8) * 8 * a.nN;
+    hipLaunchKernelGGL((conv_mfma_kernel<half_t, PT, CT, VAR, false, false, true, true>), dim3(grid, a.twin ? 2 : 1), dim3(256), 4 * 2 * CT * 1024, s, a);
+    return maf_check_hip(hipGetLastError(), "conv_mfma (weights by DMA ring) launch");
+}
+
+template <int VAR>
+int launch_dma_tile(const ConvArgs& a, int pt, int ct, hipStream_t s) {
+#define MAF_DMA(P, C) \
+    if (pt == P && ct == C) return launch_dma<P, C, VAR>(a, s);
+    MAF_DMA(1, 4) MAF_DMA(2, 4) MAF_DMA(1, 6) MAF_DMA(2, 6) MAF_DMA(1, 8) MAF_DMA(2, 8)
+#undef MAF_DMA
+    maf_set_error("conv: tile_k = 8 (weights by DMA ring) supports tile_c in {4,6,8}, tile_p in {1,2}");
     return MAF_E_UNSUPPORTED;
 }
 

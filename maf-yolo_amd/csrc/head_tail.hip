@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void head_tail_kernel(const 
 #pragma unroll
         for (int v = 0; v < CHV; ++v) {
             const int i = tid + v * 256;
-            if (i < CHB / 16) r[v] = rec16[(size_t)c * (CHB / 16) + i];
+            if (CHB / 16 % 256 == 0 || i < CHB / 16) r[v] = rec16[(size_t)c * (CHB / 16) + i];
         }
     };
     auto chunk_store = [&](int buf, const uint4 (&r)[CHV]) {
 #pragma unroll
         for (int v = 0; v < CHV; ++v) {
             const int i = tid + v * 256;
-            if (i < CHB / 16) reinterpret_cast<uint4*>(s_w + buf * CHB)[i] = r[v];
+            if (CHB / 16 % 256 == 0 || i < CHB / 16) reinterpret_cast<uint4*>(s_w + buf * CHB)[i] = r[v];
         }
     };
     if constexpr (!WLDS) {

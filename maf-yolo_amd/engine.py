@@ -376,7 +376,7 @@ class Plan:
                 tv = TV([Seg(t, c)], x.H, x.W)
                 # 64 / 128 / 192: weights LDS-resident; 256: weight chunks streamed through LDS once per 16-pixel unit — pays on small levels
                 # (the bs = 1 latency path, P5 of s); 384 (P4 / P5 of m) keeps the convs + decode kernel (its instantiation spills)
-                if self.fuse_head and (c in (64, 128, 192) or (c == 256 and self.B * x.H * x.W <= 16384)):
+                if self.fuse_head and (c in (64, 128, 192) or (c == 256 and self.B * x.H * x.W <= cfg.head_tail_256_max)):
                     # cls_conv and reg_conv read the same tensor: ONE depth-wise launch with two filters per input channel
                     (wc, bc), (wr, brg) = m.cls_conv.fused(), m.reg_conv.fused()
                     assert wc.shape == wr.shape

@@ -28,7 +28,8 @@ def kernel_name(plan, idx):
             return "conv3s2_wreg_kernel<%d, %d, %d, %d, %d, %d>" % ((o.Cin, o.Cout) + pack.conv3x3_wreg_shape(o.Cin, o.Cout) + (2 if o.tile_p == 2 else 3, o.nc))
         if o.tile_k == 5:
             return "conv1x1_stream_lds_kernel<%d, %d, %s, %d, false>" % (o.tile_c, sum(-(-o.src[k].C // 32) for k in range(o.nsrc)), "true" if var == 1 else "false", 8 if o.tile_p == 2 else 4)      # (last: the statistics epilogue of the training form — never in a plan)
-        return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k == 2 else "false")
+        return "conv_mfma_kernel<%s, %d, %d, %d, %s, %s, %s, %s>" % (T, o.tile_p, o.tile_c, var, outf32, "true" if o.tile_k == 4 else "false", "true" if o.tile_k in (2, 8) else "false",
+                                                                     "true" if o.tile_k == 8 else "false")
     if o.kind == lib.OP_DWCONV:
         if o.tile_p == -1:
             return "dwconv_mfma_kernel<%d, %d>" % (o.ksize, o.act)

@@ -241,6 +241,8 @@ def _conv3_fwd_cands(cin, cout, M, static):
             for pt in ((1, 2, 4) if ct == 4 else (1, 2)):                        # each k-step's weight fragments through LDS once per workgroup
                 if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
                     cands.append((pt, ct, 2))
+                    if pt <= 2:
+                        cands.append((pt, ct, 8))                                # ... by DMA, two k-steps per barrier (csrc/conv_mfma_dma.hip)
     if static not in cands:
         cands.append(static)
     return cands

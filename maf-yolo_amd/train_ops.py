@@ -393,6 +393,8 @@ def _conv_choice(x, xs, B, H, W, K, Nc, dt, w2d, rows, cols, transpose, want_sta
             for pt in ((1, 2, 4) if ct == 4 else (1, 2)):
                 if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
                     cands.append((pt, ct, 2))
+                    if pt <= 2 and ksteps >= 8:
+                        cands.append((pt, ct, 8))                                # ... by DMA, two k-steps per barrier (csrc/conv_mfma_dma.hip)
     if (pt0, ct0, 1) not in cands:
         cands.append((pt0, ct0, 1))
     out = _empty((B, Nc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)

@@ -330,9 +330,11 @@ def autotune(plan, x, reps=5, verbose=False):
                     for pt in ((1, 2, 4) if ct == 4 else (1, 2)):     # the workgroup shares each k-step's weight fragments through LDS
                         if pt == 1 or -(-M // (64 * pt)) * nt >= 256:
                             cands.append((pt, ct, 2))
+                            if pt <= 2 and ksteps >= 8:                # ... that arrive by DMA, two k-steps per barrier, three stages ahead (K-heavy layers)
+                                cands.append((pt, ct, 8))
             results = []
             if twin:
-                cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7)]    # the variants that take a twin launch
+                cands = [c_ for c_ in cands if c_[2] in (1, 2, 4, 7, 8)] # the variants that take a twin launch
             if pool1:
                 cands = [c_ for c_ in cands if c_[2] == r.get("pool1_tk", 6)]   # only the workgroup count (and the patch buffers of tile_k = 7) are open
             for pt, ct, tk in cands:
@@ -354,7 +356,7 @@ def autotune(plan, x, reps=5, verbose=False):
             best = (results[0][1], results[0][2], results[0][3])
             _TUNE_CACHE[sig] = best
             if verbose:
-                print("tune %-32s M=%-7d %4d->%-4d: %s" % (plan.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
+                print("tune %-32s M=%-7d %4d->%-4d: %s" % (plan.op_names[i], M, o.Cin, o.Cout, " ".join("(%d,%d%s)%.1fus" % (p, c, {4: ",k4", 2: ",lds", 3: ",stream", 5: ",streamlds", 6: ",ldsall", 7: ",wreg", 8: ",dma"}.get(k, ""), t * 1e3) for t, p, c, k in results)))
         pt, ct, tk = best
         if pool1:
             if (pt, ct) != (o.tile_p, o.tile_c):

@@ -109,9 +109,13 @@ def test_conv_split_k(dt, kind):
     _check(out, ref_fn(bias), dt)
 
 
-@pytest.mark.parametrize("kind,pt,ct", [("1x1", 2, 8), ("1x1", 1, 6), ("3x3", 2, 4), ("3x3", 1, 8), ("3x3", 4, 4), ("multi", 2, 6)])
-def test_conv_lds_shared_weights(kind, pt, ct):
-    """tile_k = 2: the workgroup stages each k-step's weight fragments in LDS once for its four waves (long reductions)."""
+@pytest.mark.parametrize("tk", [2, 8])
+@pytest.mark.parametrize("kind,pt,ct", [("1x1", 2, 8), ("1x1", 1, 6), ("1x1", 2, 4), ("3x3", 2, 4), ("3x3", 1, 8), ("3x3", 2, 6), ("3x3", 4, 4), ("multi", 2, 6), ("multi", 1, 4), ("multi3", 2, 8)])
+def test_conv_lds_shared_weights(kind, pt, ct, tk):
+    """tile_k = 2: the workgroup stages each k-step's weight fragments in LDS once for its four waves (long reductions).  tile_k = 8: the fragments arrive by DMA,
+    in stages of two k-steps through a ring of four slots (odd step counts, fewer stages than slots, three concatenated sources with an up-sampled one in the middle)."""
+    if tk == 8 and pt > 2:
+        pytest.skip("tile_k = 8 has tile_p = 1 / 2")
     g = torch.Generator().manual_seed(17 + pt + ct)
     dt, B = lib.F16, 2
     cout = {8: 128, 6: 88, 4: 64}[ct]
@@ -130,6 +134,16 @@ def test_conv_lds_shared_weights(kind, pt, ct):
         wp = pack.pack_conv3x3(w, ct, dt)
         ref_fn = lambda b: F.silu(F.conv2d(x, w, b, 2, 1))
         opk, srcs = lib.OP_CONV3X3S2, [(_nhwc(x, dt), cin, cin, 0, 0)]
+    elif kind == "multi3":
+        ca, cb, cc, H, W = 104, 72, 256, 10, 14
+        cin = ca + cb + cc
+        a = _q(torch.randn(B, ca, H, W, generator=g), dt)
+        bsm = _q(torch.randn(B, cb, H // 2, W // 2, generator=g), dt)
+        c3 = _q(torch.randn(B, cc, H, W, generator=g), dt)
+        w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+        wp = pack.pack_conv1x1(w, [ca, cb, cc], ct, dt)
+        ref_fn = lambda b: F.silu(F.conv2d(torch.cat([a, F.interpolate(bsm, scale_factor=2, mode="nearest"), c3], 1), w, b))
+        opk, srcs = lib.OP_CONV1X1, [(_nhwc(a, dt), ca, ca, 0, 0), (_nhwc(bsm, dt), cb, cb, 0, 1), (_nhwc(c3, dt), cc, cc, 0, 0)]
     else:
         ca, cb, H, W = 40, 64, 8, 12
         cin = ca + cb
@@ -142,7 +156,7 @@ def test_conv_lds_shared_weights(kind, pt, ct):
     bias = torch.randn(cout, generator=g)
     out = torch.zeros(B, H, W, cout + 8, dtype=DT[dt], device=DEV)
     op = _conv_op(opk, dt, B, H, W, cin, cout, lib.ACT_SILU, srcs, out, cout + 8, 8, wp.to(DEV), pack.pack_bias(bias, ct).to(DEV), pt, ct, Hin=Hin, Win=Win)
-    op.tile_k = 2
+    op.tile_k = tk
     _launch(op)
     _check(out[..., 8:], ref_fn(bias), dt)
     assert (out[..., :8] == 0).all()
@@ -772,10 +786,10 @@ def test_conv1_dw_partial_fusion(c, k, H, W):
 
 
 @pytest.mark.parametrize("dt", [lib.F16, lib.F32])
-@pytest.mark.parametrize("tk,pt,ct", [(1, 2, 4), (2, 1, 4), (4, 1, 4), (1, 1, 8)])
+@pytest.mark.parametrize("tk,pt,ct", [(1, 2, 4), (2, 1, 4), (4, 1, 4), (1, 1, 8), (8, 2, 4), (8, 1, 8)])
 def test_conv3x3s2_twin_launch(dt, tk, pt, ct):
     """MAF_OP_CONV3X3S2 with aux = {src, w, bias, out} of a second conv: both results equal their own fp32 references."""
-    if dt == lib.F32 and tk == 2:
+    if dt == lib.F32 and tk in (2, 8):
         pytest.skip("tile_k = 2 is an fp16 variant")
     g = torch.Generator().manual_seed(tk * 10 + pt)
     B, Hin, Win, cin, cout = 2, 22, 18, 64, 64

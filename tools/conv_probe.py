@@ -13,7 +13,8 @@ specs = []
 for a in sys.argv[1:]:
     parts = a.split(":")
     specs.append((parts[0], [tuple(int(v) for v in p.split(",")) for p in parts[1:]]))
-model = M.Model("n"); model.load_state_dict(synth.synth_state_dict(model, "n", 0)); model = model.cuda().eval().half()
+scale = os.environ.get("MAF_PROBE_SCALE", "n")                     # MAF_PROBE_SCALE=m: the layers of another scale
+model = M.Model(scale); model.load_state_dict(synth.synth_state_dict(model, scale, 0)); model = model.cuda().eval().half()
 x = synth.synth_images(32, 640, seed=1).cuda().half()
 plan = Plan(model, 32, 640, 640, lib.F16, lib.F16, x.device, fuse=False)
 pred = torch.empty(32, plan.A, 85, dtype=torch.float32, device=x.device)
@@ -42,7 +43,7 @@ for name, cands in specs:
     else:
         w, b, srcC = r["raw"]
     for pt, ct, tk in cands:
-        wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv1x1(w, srcC, ct, lib.F16) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, lib.F16)).cuda()
+        wp = (pack.pack_conv3x3_lds(w, b) if tk == 6 else pack.pack_conv3x3_wreg(w, b) if tk == 7 else pack.pack_conv1x1(w, srcC, ct, lib.F16) if o.kind == lib.OP_CONV1X1 else pack.pack_conv3x3(w, ct, lib.F16)).cuda()
         bp = pack.pack_bias(b, ct if tk != 6 else 4).cuda()
         op = lib.MafOp.from_buffer_copy(o)
         op.tile_p, op.tile_c, op.tile_k, op.w, op.bias = pt, ct, tk, wp.data_ptr(), bp.data_ptr()

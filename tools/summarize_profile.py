@@ -18,10 +18,10 @@ _T = {"DF16_": "_Float16", "f": "float", "h": "unsigned char"}
 def demangle(n):
     """c++filt does not know the _Float16 mangling (DF16_), so the few kernel templates of this library are decoded here."""
     import re
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+conv_mfma_kernelI(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])EEEv", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+conv_mfma_kernelI(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])(?:ELb([01]))?EEEv", n)
     if m:
         tf = lambda g: "true" if m.group(g) == "1" else "false"
-        return "conv_mfma_kernel<%s, %s, %s, %s, %s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3), m.group(4), tf(5), tf(6), tf(7))
+        return "conv_mfma_kernel<%s, %s, %s, %s, %s, %s, %s%s>" % (_T[m.group(1)], m.group(2), m.group(3), m.group(4), tf(5), tf(6), tf(7), ", " + tf(8) if m.group(8) else "")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+dwconv_tile_kernelI(DF16_|f)Li(\d+)ELi(\d+)EEEv", n)
     if m:
         return "dwconv_tile_kernel<%s, %s, %s>" % (_T[m.group(1)], m.group(2), m.group(3))
