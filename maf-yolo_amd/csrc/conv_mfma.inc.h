@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         // activation fragments ride the same distance ahead in a register ring.  What it is for: the K-heavy layers of the 40 x 40 / 20 x 20 maps of s and m
         // (1x1 over 960 .. 1536 concatenated channels, 3x3 stride 2 over 192 .. 384), where the generic form streams every wave's weight fragments out of the L2
         // separately (15 TB/s of L2 traffic for 1280 -> 384 on 40 x 40: the bound) and the branch below spends its time at barriers.
+        // Knock-outs (make ko, tools/conv_probe.py; 1152 -> 384 on 40 x 40, tile (2, 8)): 76 us as shipped, 60 without the DMA, 55 without the activation loads, 49
+        // with neither — 0.96 PFLOP/s is what barriers + fragment reads + MFMAs reach here; the vendor GEMM (tools/gemm_probe.py) does this shape in 64 us.  A form that
+        // also read the next stage's first fragments and issued the look-ahead loads under the MFMAs measured the same (76.6 / 47.1 us) and was not kept.
         // vmcnt bookkeeping: a wave issues, per stage, FW DMA instructions + KST * PT activation loads, all VMEM loads, which return in order — "at most
         // (D - 1) stage-issues outstanding" therefore means stage st's pieces (and its activations) have landed; the barrier behind that wait publishes
         // everybody's pieces and, since every wave is then past the multiplies of stage st - 1, frees slot (st - 1) % R = (st + D) % R for the next DMA.
