@@ -22,9 +22,7 @@ timer = lib.Timer()
 n = len(plan.ops)
 ts = np.zeros((n, 30))
 for rep in range(30):
-    for i in range(n):
-        timer.start(st); lib.check(L.maf_op_launch(C.byref(plan.ops[i]), st)); timer.stop(st)
-        ts[i, rep] = timer.elapsed_ms() * 1e3
+    ts[:, rep] = np.array(plan.run_timed(x, pred)) * 1e3
 med = np.median(ts, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(20): plan.run_into(x, pred)
