@@ -71,9 +71,13 @@ typedef struct {
  *                   tile_k = 5 (fp16, 2 <= K / 32 <= 24, K / 32 * tile_c <= 160): persistent workgroups with the channel tile's weight fragments resident
  *                   in LDS (csrc/conv_stream_lds.inc.h); tile_p = 1: four waves per workgroup, 2 (64 <= K / 32 * tile_c, K / 32 >= 8, tile_c in {4, 6, 8}):
  *                   eight waves behind the same LDS copy (csrc/conv_stream_lds_w8.hip) — same result bit for bit.
+ *                   tile_k = 2 / 8 (fp16; CONV1X1 with direct / up-sampled sources and CONV3X3S2; tile_c in {4, 6, 8}, tile_p in {1, 2}, tile_k = 2 also
+ *                   (4, 4)): the four waves of a workgroup share each k-step's weight fragments through LDS — 2: register -> LDS copy and a barrier per
+ *                   k-step; 8: the fragments arrive by DMA (buffer load with LDS destination) in stages of two k-steps through a ring of four slots, three
+ *                   stages ahead, one barrier per stage (csrc/conv_mfma_dma.hip: the K-heavy layers of the 40 x 40 / 20 x 20 maps of s and m).
  * MAF_OP_CONV3X3S2  replaces rbr_reparam / ConvWrapper.block.conv stride-2 convs.  src[0] is the
  *                   2H x 2W input (Hin, Win below); w packed per tap.
- *                   Twin launch (CONV1X1 with one direct / pooled source, CONV3X3S2; tile_k 0 / 1 / 2 / 4): aux[0] != NULL runs a SECOND conv of
+ *                   Twin launch (CONV1X1 with one direct / pooled source, CONV3X3S2; tile_k 0 / 1 / 2 / 4 / 8): aux[0] != NULL runs a SECOND conv of
  *                   identical shape, strides and tiles as blockIdx.y = 1 of the same grid — aux = {src, w, bias, out} of the second conv
  *                   (the two side ConvWrappers of a MAFPN level, configs/yaml/MAF-YOLO-n.yaml nodes 23 / 24 and 27 / 28).
  *                   tile_k = 6 (fp16; (Cin, Cout) = (48, 48), (48, 64), (64, 64)): persistent workgroups with all weight fragments and the
@@ -155,7 +159,7 @@ typedef struct {
     int32_t out_stride, out_coff;
     int32_t out_f32;             /* CONV1X1: store fp32 regardless of dtype (cls_pred/reg_pred) */
     int32_t tile_p, tile_c;      /* MFMA tile: 16*tile_p pixels x 16*tile_c channels per wave   */
-    int32_t tile_k;              /* 0/1: each wave reduces all of K; 4: the 4 waves of a workgroup split K (tile_p = 1) */
+    int32_t tile_k;              /* 0/1: each wave reduces all of K; 4: the 4 waves of a workgroup split K (tile_p = 1); 2 / 8: weight fragments shared through LDS */
     const void* w;
     const float* bias;
     /* DECODE only */
