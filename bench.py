@@ -66,7 +66,8 @@ def latency_leg(torch, M, dev, scale, n, warmup, lanes=-1):
     model = M.Model(scale)
     model.load_state_dict(synth.synth_state_dict(model, scale, 0))
     model = model.to(dev).eval()
-    if lanes >= 0:
+    model.autotune = True                                  # the bs = 1 plan gets its own tile / variant choices, timed when the plan is built — outside every timed request,
+    if lanes >= 0:                                         # like the headline's (until round 6 this leg ran the UNTUNED plan: 1.87 ms per forward where the tuned one takes 1.18)
         model.multi_stream = lanes
     x = synth.synth_images(1, 640, seed=1).to(dev).half()
     calibrate_cls_bias(model, x, 2000, M, torch)

@@ -960,6 +960,34 @@ def test_config4_m_bs1_640_hipgraph_latency_path(models):
     assert np.array_equal(dets[0].cpu().numpy(), odets[0]) and np.array_equal(idx[0].cpu().numpy(), oidx[0])
 
 
+def test_config4_tuned_bs1_plan_matches_oracle():
+    """The plan `bench.py --latency` times since round 6: m, bs = 1, 640 x 640 with `autotune` on (fusion choices and tiles timed for THIS batch size — split-K,
+    DMA-ring and pair-input variants that the batch-32 plans never pick).  Its prediction meets the oracle at the fp16 bar, the hipGraph replay gives the eager
+    bits, and its detections equal the oracle's NMS of that prediction."""
+    m = M.Model("m")
+    m.load_state_dict(O.synth_state_dict("m", 0))
+    m = m.to(DEV).eval()
+    m.autotune = True
+    x32 = O.synth_images(1, 640, 3)
+    x = x32.to(DEV).half()
+    with torch.no_grad():
+        plan = m.plan_for(x)
+        eager = torch.empty(1, plan.A, 85, dtype=torch.float32, device=DEV)
+        plan.run_into(x, eager)
+        pred = torch.empty_like(eager)
+        for _ in range(3):
+            plan.run_into(x, pred, graph=True)
+        torch.cuda.synchronize()
+    names = [plan.kernel_name(i) for i in range(len(plan.ops))]
+    assert any("stream_lds" in n_ or "true" in n_ for n_ in names), "the tuner changed nothing: is autotune on?"
+    assert torch.equal(pred, eager)
+    ref = O.predict(O.reparam(O.synth_state_dict("m", 0), "m"), "m", x32).numpy()
+    _close16(pred.cpu().numpy(), ref, "m")
+    dets, idx = M.non_max_suppression(pred, 0.03, 0.65, multi_label=True, return_index=True)
+    odets, oidx = O.non_max_suppression(pred.cpu().numpy(), 0.03, 0.65, multi_label=True, return_index=True)
+    assert np.array_equal(dets[0].cpu().numpy(), odets[0]) and np.array_equal(idx[0].cpu().numpy(), oidx[0])
+
+
 def test_bench_line_contract():
     """`python bench.py` prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
     higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the roofline object of the dominant kernel; a short run at
